@@ -1,0 +1,205 @@
+/*
+ * xmaps.h -- C-ABI of the MI355X-native X-maps hot path (libxmaps_hip.so).
+ *
+ * Plain C, plain pointers and sizes, no torch / C++ types.  Every entry point returns XM_OK (0) or a
+ * negative error code and never throws; xm_last_error() gives the text for the calling thread.
+ *
+ * What it replaces (all file:line relative to the reference repo, python/ directory):
+ *   xm_create            <- table setup consumed by the hot path: CamProjMaps LUTs
+ *                           (cam_proj_calibration.py:246-270), XMapsDisparity.proj_x_map
+ *                           (x_maps_disparity.py:44-67), DisparityToDepth (disp_to_depth.py:66-74)
+ *   xm_process_frame*    <- DepthReprojectionPipe.process_ev_frame (depth_reprojection_pipe.py:121-167):
+ *                           rectify_cam_coords_i16 -> compute_event_disparity ->
+ *                           compute_disp_map_{projector,camera}_view -> remap_rectified_disp_map_to_proj
+ *                           -> colorize_depth_from_disp, fused into three kernels
+ *   xm_stage_*           <- the same stages one by one, with the reference's per-stage signatures
+ *                           (cam_proj_calibration.py:277-281,299-317; x_maps_disparity.py:9-32,69-82;
+ *                            disp_to_depth.py:46-63,76-115)
+ *   xm_shard_*           <- (new) the event buffer sharded by index over several GPUs; the caller
+ *                           max-reduces the packed key frame between xm_shard_scatter and
+ *                           xm_shard_finish (RCCL all-reduce, MAX on int64)
+ *
+ * Threading: one handle = one device + its own HIP streams; a handle is not thread-safe.
+ * Ownership: the caller owns every pointer it passes; tables are copied to the device in xm_create.
+ */
+#ifndef XMAPS_H
+#define XMAPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XM_API_VERSION 1
+
+/* error codes */
+#define XM_OK 0
+#define XM_ERR_INVALID (-1)  /* bad argument / config                                              */
+#define XM_ERR_HIP (-2)      /* a HIP runtime call failed (xm_last_error has the hipError string)   */
+#define XM_ERR_NOMEM (-3)
+#define XM_ERR_INDEX (-4)    /* >= 1 event indexed outside a table/frame: where NumPy raises
+                                IndexError in the reference.  The frame is still produced with the
+                                offending events dropped; stats.n_index_errors counts them.        */
+#define XM_ERR_TOO_MANY (-5) /* more events in one frame than the key's index field can hold       */
+
+/* view (RuntimeParams.camera_perspective, depth_reprojection_processor.py:34) */
+#define XM_VIEW_PROJECTOR 0
+#define XM_VIEW_CAMERA 1
+
+/* where the event / output buffers of a call live */
+#define XM_MEM_HOST 0   /* host pointers: staged H2D/D2H inside the call, call returns synchronised  */
+#define XM_MEM_DEVICE 1 /* device pointers: everything is enqueued on the handle's stream; xm_sync() */
+
+/* dtype of the time column: int64 microseconds (Metavision EventCD) or an already-normalised
+ * float time surface (python/eval/compute_depth_x_maps.py:89-96) */
+#define XM_T_INT64 0
+#define XM_T_FLOAT32 1
+#define XM_T_FLOAT64 2
+
+/* packed last-writer-wins key:  [63]=0 | tag:19 | event index:28 | disparity:16 */
+#define XM_KEY_DISP_BITS 16
+#define XM_KEY_IDX_BITS 28
+#define XM_KEY_TAG_BITS 19
+#define XM_KEY_MAX_EVENTS (1ull << XM_KEY_IDX_BITS)
+
+typedef struct xm_handle xm_handle;
+
+typedef struct xm_config {
+  uint32_t struct_size; /* = sizeof(xm_config), for forward compatibility */
+  int32_t device;       /* HIP device ordinal */
+  int32_t cam_width, cam_height;
+  int32_t proj_width, proj_height;
+  int32_t rect_width, rect_height; /* rectified frame (calib.rect_image_{width,height})            */
+  int32_t xmap_width;              /* X_MAP_WIDTH; T_PX_SCALE = xmap_width - 1 (xmd:58-59)         */
+  int32_t xmap_height;             /* rows of proj_x_map (0 => rect_height)                        */
+  int32_t x_offset;                /* X_OFFSET = 4242 (xmd:49); must fit int16                     */
+  int32_t view;                    /* XM_VIEW_*                                                    */
+  int32_t n_slots;                 /* frames that may be in flight at once (>=1; own stream each)  */
+  int32_t reserved0;
+  double p03;                      /* P2[0,3] (calib:207, d2d:104-107)                              */
+  float z_near, z_far;             /* d2d:71-72                                                     */
+  /* host tables, reference layouts (row-major int16); copied + re-packed for the device in xm_create */
+  const int16_t* cam_mapx_i16;        /* [cam_height][cam_width]   disp_cam_mapx_i16 (calib:253)    */
+  const int16_t* cam_mapy_i16;        /* [cam_height][cam_width]   disp_cam_mapy_i16 (calib:254)    */
+  const int16_t* proj_x_map;          /* [xmap_height][xmap_width] proj_x_map (xmd:61-67)           */
+  const int16_t* disp_proj_mapxy_i16; /* [proj_height][proj_width][2] (x,y) (calib:270); may be NULL
+                                         for XM_VIEW_CAMERA                                         */
+} xm_config;
+
+typedef struct xm_frame_stats {
+  uint64_t n_events;       /* events handed in                                                       */
+  uint64_t n_used;         /* after the polarity mask (== n_events when p == NULL)                    */
+  uint64_t n_inliers;      /* events that passed both inlier masks (xmd:23,29) and were scattered    */
+  uint64_t n_index_errors; /* events that would raise IndexError in the reference                    */
+  double t_min, t_max;     /* frame extrema of t (over the used events), as double                   */
+  float gpu_ms[4];         /* HIP-event time of {minmax, scatter, frame kernel, whole frame}; filled
+                              only by xm_profile_frame, else 0                                       */
+} xm_frame_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+int xm_api_version(void);
+const char* xm_last_error(void);
+int xm_create(const xm_config* cfg, xm_handle** out);
+void xm_destroy(xm_handle* h);
+int xm_sync(xm_handle* h); /* wait for everything enqueued on every slot of the handle */
+
+/* ---- the fused hot path: one projector frame of events -> depth frame (+ BGR) -------------------- */
+/*
+ * SoA events x[n], y[n], t[n] (dtype t_dtype), optional p[n] (NULL = all events used; otherwise only
+ * events with p == 1 belong to the frame, which is what PolarityFilterAlgorithm(1) does upstream,
+ * depth_reprojection_pipe.py:43,114).  Outputs (either may be NULL):
+ *   depth_out f32 [H][W]      -- disparity_to_depth_rectified of the final disparity frame (A5)
+ *   bgr_out   u8  [H][W][3]   -- the array process_ev_frame hands to frame_callback (A6+A7)
+ * with H x W = projector size (XM_VIEW_PROJECTOR) or camera size (XM_VIEW_CAMERA).
+ * mem == XM_MEM_HOST  : synchronous; stats (may be NULL) filled; returns XM_ERR_INDEX if any event
+ *                       indexed out of range (frame still written).
+ * mem == XM_MEM_DEVICE: asynchronous on the next slot's stream; the buffers must stay valid until
+ *                       xm_sync(); stats of the most recent frame via xm_last_frame_stats() after it.
+ * n == 0 and t_max == t_min are defined: an empty frame, resp. every event in X-map column 0.
+ */
+int xm_process_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
+                     size_t n, int t_dtype, int mem, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
+
+/* Same for Metavision's 16-byte EventCD records {u16 x; u16 y; i16 p; (pad) ; i64 t} (AoS), the
+ * layout `evs` has when trigger_finder.py:172 calls process_ev_frame.  use_polarity != 0 applies p==1. */
+int xm_process_frame_aos(xm_handle* h, const void* eventcd16, size_t n, int use_polarity, int mem,
+                         float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
+
+int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats);
+
+/* Instrumented run of one frame (device-resident SoA buffers): HIP events around each kernel on the
+ * stream they run on; synchronous; stats->gpu_ms filled.  Used by bench.py for the roofline line. */
+int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
+                     size_t n, int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
+
+/* ---- a batch of frames captured once into a hipGraph and replayed (BASELINE config 5) ------------ */
+/* All pointers are device pointers that stay valid for the graph's lifetime.  Frame f reads events
+ * [offsets[f], offsets[f+1]) of the SoA columns and writes depth_out + f*H*W (and bgr_out + f*H*W*3). */
+typedef struct xm_graph xm_graph;
+int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
+                    int t_dtype, const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out,
+                    xm_graph** out);
+int xm_graph_launch(xm_graph* g); /* asynchronous; xm_sync(handle) to wait */
+void xm_graph_destroy(xm_graph* g);
+
+/* ---- per-event debug view: every intermediate of A1/A2 for bit-exact tests ------------------------ */
+/* Host or device SoA in (mem), host or device out (same mem).  Any output may be NULL.
+ *   xr, yr  : rectify_cam_coords_i16            ts : X-map column (t_scaled, xmd:19)
+ *   disp    : xp - xr - x_offset (int16 wrap), defined where the y-mask holds, else 0
+ *   mask    : final inlier mask (u8 0/1), y-mask & disp >= 0 (& p == 1 when p given)              */
+int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
+                           size_t n, int t_dtype, int mem, int16_t* xr, int16_t* yr, int16_t* ts, int16_t* disp,
+                           uint8_t* mask);
+
+/* ---- the reference's stages one by one (host pointers, synchronous) -------------------------------- */
+/* A1  CamProjMaps.rectify_cam_coords_i16(events) -> (xr, yr) */
+int xm_stage_rectify(xm_handle* h, const uint16_t* x, const uint16_t* y, size_t n, int16_t* xr, int16_t* yr);
+/* A2  compute_disparity(xr, yr, t, X, T_PX_SCALE, X_OFFSET): full-length disp[n] (0 where masked out)
+ *     and mask[n]; the caller compacts disp[mask] to get the reference's first return value */
+int xm_stage_event_disparity(xm_handle* h, const int16_t* xr, const int16_t* yr, const void* t, size_t n,
+                             int t_dtype, int16_t* disp, uint8_t* mask);
+/* A3  compute_disp_map_projector_view: full-length xr, yr, disp + mask -> f32 [rect_h][rect_w] */
+int xm_stage_disp_map_projector_view(xm_handle* h, const int16_t* xr, const int16_t* yr, const int16_t* disp,
+                                     const uint8_t* mask, size_t n, float* disp_map);
+/* A3' compute_disp_map_camera_view: x, y, disp + mask -> f32 [cam_h][cam_w] */
+int xm_stage_disp_map_camera_view(xm_handle* h, const uint16_t* x, const uint16_t* y, const int16_t* disp,
+                                  const uint8_t* mask, size_t n, float* disp_map);
+/* A4  DisparityToDepth.remap_rectified_disp_map_to_proj: f32 [rect_h][rect_w] -> f32 [proj_h][proj_w] */
+int xm_stage_remap_rectified_disp_map_to_proj(xm_handle* h, const float* rect_disp, float* proj_disp);
+/* A5  disparity_to_depth_rectified(disp, P2): f32 [h][w] -> f32 [h][w] */
+int xm_stage_disparity_to_depth(xm_handle* h, const float* disp, int height, int width, float* depth);
+/* A5+A6+A7 DisparityToDepth.colorize_depth_from_disp: f32 disparity frame -> BGR u8 [h][w][3] */
+int xm_stage_colorize_depth_from_disp(xm_handle* h, const float* disp, int height, int width, uint8_t* bgr);
+
+/* ---- multi-GPU: one shard of a frame ---------------------------------------------------------------- */
+/* All pointers are DEVICE pointers.  key_frame is a caller-owned u64 [H][W] buffer (H x W = rect size
+ * for the projector view, camera size for the camera view), e.g. a torch.int64 tensor, so that the
+ * caller can all-reduce it (MAX) between scatter and finish.  Calls are enqueued on slot 0's stream
+ * and are asynchronous unless noted. */
+/* extrema of this shard's t (over p == 1 events when p given), written as 2 values of t's dtype to
+ * minmax_out_host; synchronous.  An empty shard returns (+max, -max) sentinels of the dtype. */
+int xm_shard_minmax(xm_handle* h, const void* t, const int16_t* p, size_t n, int t_dtype, void* minmax_out_host);
+/* zero the key frame (once per buffer, or when the tag wraps) */
+int xm_shard_clear(xm_handle* h, uint64_t* key_frame);
+/* scatter this shard's events; idx_offset = global index of the shard's first event; frame_minmax_host
+ * = the FRAME's (tmin, tmax) in t's dtype; tag in [1, 2^19) must grow from frame to frame */
+int xm_shard_scatter(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                     int t_dtype, uint64_t idx_offset, const void* frame_minmax_host, uint32_t tag,
+                     uint64_t* key_frame);
+/* key frame (after the reduce) -> depth / BGR device buffers */
+int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float* depth_out, uint8_t* bgr_out);
+/* the stream the shard calls run on (hipStream_t as void*), so the caller can order its collective */
+void* xm_stream(xm_handle* h, int slot);
+
+/* ---- small device-memory helpers so that a host without torch can stage buffers ------------------- */
+int xm_dev_alloc(xm_handle* h, size_t bytes, void** out);
+int xm_dev_free(xm_handle* h, void* p);
+int xm_dev_upload(xm_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int xm_dev_download(xm_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMAPS_H */

@@ -1,0 +1,163 @@
+"""ctypes binding of libxmaps_hip.so (the C-ABI in include/xmaps.h) + the in-tree build recipe.
+
+There is NO CPU fallback: if the library is missing and cannot be built, or no AMD GPU is visible,
+the product path raises.  (The CPU restatement under oracle/ is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libxmaps_hip.so")
+SOURCES = [os.path.join(PKG_DIR, "csrc", "xmaps_hip.hip")]
+DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", "xmaps_kernels.hpp"),
+                     os.path.join(PKG_DIR, "csrc", "turbo_lut.inc"),
+                     os.path.join(ROOT, "include", "xmaps.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY = 0, -1, -2, -3, -4, -5
+XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
+XM_MEM_HOST, XM_MEM_DEVICE = 0, 1
+XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2
+
+
+class XMapsNativeError(RuntimeError):
+    pass
+
+
+def _hipcc() -> str | None:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    so_m = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(d) and os.path.getmtime(d) > so_m for d in DEPENDS)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... -> x_maps_amd/libxmaps_hip.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise XMapsNativeError("hipcc not found: cannot build libxmaps_hip.so (and there is no CPU fallback)")
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + SOURCES + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise XMapsNativeError("hipcc failed:\n" + r.stderr[-4000:])
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+class xm_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32),
+        ("cam_width", C.c_int32), ("cam_height", C.c_int32),
+        ("proj_width", C.c_int32), ("proj_height", C.c_int32),
+        ("rect_width", C.c_int32), ("rect_height", C.c_int32),
+        ("xmap_width", C.c_int32), ("xmap_height", C.c_int32),
+        ("x_offset", C.c_int32), ("view", C.c_int32), ("n_slots", C.c_int32), ("reserved0", C.c_int32),
+        ("p03", C.c_double), ("z_near", C.c_float), ("z_far", C.c_float),
+        ("cam_mapx_i16", C.c_void_p), ("cam_mapy_i16", C.c_void_p),
+        ("proj_x_map", C.c_void_p), ("disp_proj_mapxy_i16", C.c_void_p),
+    ]
+
+
+class xm_frame_stats(C.Structure):
+    _fields_ = [
+        ("n_events", C.c_uint64), ("n_used", C.c_uint64), ("n_inliers", C.c_uint64),
+        ("n_index_errors", C.c_uint64), ("t_min", C.c_double), ("t_max", C.c_double),
+        ("gpu_ms", C.c_float * 4),
+    ]
+
+
+# every symbol include/xmaps.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "xm_api_version": (C.c_int, []),
+    "xm_last_error": (C.c_char_p, []),
+    "xm_create": (C.c_int, [C.POINTER(xm_config), C.POINTER(_P)]),
+    "xm_destroy": (None, [_P]),
+    "xm_sync": (C.c_int, [_P]),
+    "xm_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
+    "xm_process_frame_aos": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
+    "xm_last_frame_stats": (C.c_int, [_P, C.POINTER(xm_frame_stats)]),
+    "xm_profile_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
+    "xm_graph_create": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P, C.POINTER(_P)]),
+    "xm_graph_launch": (C.c_int, [_P]),
+    "xm_graph_destroy": (None, [_P]),
+    "xm_debug_event_outputs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "xm_stage_rectify": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
+    "xm_stage_event_disparity": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P]),
+    "xm_stage_disp_map_projector_view": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "xm_stage_disp_map_camera_view": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "xm_stage_remap_rectified_disp_map_to_proj": (C.c_int, [_P, _P, _P]),
+    "xm_stage_disparity_to_depth": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "xm_stage_colorize_depth_from_disp": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "xm_shard_minmax": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "xm_shard_clear": (C.c_int, [_P, _P]),
+    "xm_shard_scatter": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_uint64, _P, C.c_uint32, _P]),
+    "xm_shard_finish": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
+    "xm_stream": (_P, [_P, C.c_int]),
+    "xm_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "xm_dev_free": (C.c_int, [_P, _P]),
+    "xm_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "xm_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load_library(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen libxmaps_hip.so (building it first when needed).  Raises -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and needs_build():
+        if _hipcc() is not None:
+            build_native()
+        elif not os.path.exists(LIB_PATH):
+            raise XMapsNativeError(f"{LIB_PATH} is missing and hipcc is not available to build it")
+    if not os.path.exists(LIB_PATH):
+        raise XMapsNativeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load_library().xm_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, *, index_error_ok: bool = False) -> int:
+    """Map C-ABI error codes onto the exceptions the reference's NumPy code raises."""
+    if rc == XM_OK:
+        return rc
+    msg = last_error()
+    if rc == XM_ERR_INDEX:
+        if index_error_ok:
+            return rc
+        raise IndexError(msg)  # NumPy fancy indexing out of range
+    if rc == XM_ERR_INVALID or rc == XM_ERR_TOO_MANY:
+        raise ValueError(msg)
+    if rc == XM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise XMapsNativeError(f"libxmaps_hip error {rc}: {msg}")

@@ -1,0 +1,989 @@
+// xmaps_hip.hip -- host side of libxmaps_hip.so: the C-ABI declared in include/xmaps.h.
+// Written for MI355X (gfx950) only: build with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared xmaps_hip.hip -o libxmaps_hip.so
+// -ffp-contract=off keeps the time normalisation (divide, multiply, rint) unfused = bit-exact with NumPy.
+#include "xmaps_kernels.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <new>
+#include <type_traits>
+#include <string>
+#include <vector>
+
+#include "../../include/xmaps.h"
+
+using namespace xm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(XM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                          \
+  } while (0)
+
+struct DevBuf {  // grow-only device scratch
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return XM_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return XM_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  u64* key_frame = nullptr;
+  SlotState* st = nullptr;  // device
+  u32 host_tag = 0;         // mirrors st->tag_a after the enqueued work has run
+  bool any_frame = false;
+  uint64_t last_n = 0;
+  // staging for XM_MEM_HOST calls
+  DevBuf ev_x, ev_y, ev_t, ev_p, ev_aos, out_depth, out_bgr, dbg[5];
+};
+
+struct EventsView {
+  const uint16_t* x = nullptr;
+  const uint16_t* y = nullptr;
+  const void* t = nullptr;
+  const int16_t* p = nullptr;
+  const void* aos = nullptr;
+  size_t n = 0;
+  int t_dtype = XM_T_INT64;
+  bool use_p = false;
+};
+
+}  // namespace
+
+struct xm_handle {
+  xm_config cfg{};
+  DevTables tb{};
+  u32* d_lut = nullptr;
+  int16_t* d_xmap = nullptr;
+  u32* d_pmap = nullptr;
+  SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
+  SlotState* aux_st = nullptr;
+  std::vector<Slot> slots;
+  int next_slot = 0;
+  int last_slot = 0;
+  size_t key_cells = 0;   // cells of the fused path's key frame (rect or camera frame)
+  int out_w = 0, out_h = 0;
+  u64* stage_frame = nullptr;  // lazily allocated scratch for the stage API (max(rect, cam) cells)
+  size_t stage_cells = 0;
+  hipEvent_t prof_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
+  std::vector<hipEvent_t> join_ev;
+};
+
+struct xm_graph {
+  xm_handle* h = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<u32> frames_on_slot;
+  int n_frames = 0;
+};
+
+namespace {
+
+inline unsigned grid_for(u64 items, unsigned per_block) {
+  u64 g = (items + per_block - 1) / per_block;
+  return (unsigned)(g ? g : 1);
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+size_t t_size(int t_dtype) { return t_dtype == XM_T_FLOAT32 ? 4 : 8; }
+
+int reset_slot(xm_handle* h, Slot& s) {
+  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells);
+  HIP_TRY(hipGetLastError());
+  s.host_tag = 0;
+  return XM_OK;
+}
+
+// ---- kernel dispatch ---------------------------------------------------------------------------------
+template <typename T, bool AOS, bool HAS_P>
+void launch_minmax_t(const EventsView& ev, SlotState* st, u32 tag_override, hipStream_t stream) {
+  const u64 n = ev.n;
+  const bool vec2 = !AOS && sizeof(T) == 8 && std::is_same<T, long long>::value && aligned(ev.t, 16) &&
+                    (!HAS_P || aligned(ev.p, 4));
+  // ~2048 events per thread-block iteration keeps every CU busy without drowning the 32 atomic slots
+  const unsigned per_block = BLOCK * (vec2 ? 2 : 1) * 4;
+  unsigned grid = grid_for(n, per_block);
+  if (grid > 1024) grid = 1024;
+  if constexpr (std::is_same<T, long long>::value && !AOS) {
+    if (vec2) {
+      hipLaunchKernelGGL((k_minmax<T, false, HAS_P, 2>), dim3(grid), dim3(BLOCK), 0, stream, (const T*)ev.t, ev.p,
+                         (const uint4*)nullptr, n, st, tag_override);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_minmax<T, AOS, HAS_P, 1>), dim3(grid), dim3(BLOCK), 0, stream, (const T*)ev.t, ev.p,
+                     (const uint4*)ev.aos, n, st, tag_override);
+}
+
+void launch_minmax(const EventsView& ev, SlotState* st, u32 tag_override, hipStream_t stream) {
+  if (ev.aos) {
+    if (ev.use_p) launch_minmax_t<long long, true, true>(ev, st, tag_override, stream);
+    else launch_minmax_t<long long, true, false>(ev, st, tag_override, stream);
+    return;
+  }
+  const bool hp = ev.use_p;
+  switch (ev.t_dtype) {
+    case XM_T_INT64:
+      hp ? launch_minmax_t<long long, false, true>(ev, st, tag_override, stream)
+         : launch_minmax_t<long long, false, false>(ev, st, tag_override, stream);
+      break;
+    case XM_T_FLOAT32:
+      hp ? launch_minmax_t<float, false, true>(ev, st, tag_override, stream)
+         : launch_minmax_t<float, false, false>(ev, st, tag_override, stream);
+      break;
+    default:
+      hp ? launch_minmax_t<double, false, true>(ev, st, tag_override, stream)
+         : launch_minmax_t<double, false, false>(ev, st, tag_override, stream);
+  }
+}
+
+template <typename T, bool AOS, bool HAS_P, int VIEW>
+void launch_scatter_tv(const EventsView& ev, const DevTables& tb, SlotState* st, u32 tag_override, u64 idx_offset,
+                       u64 mm_lo, u64 mm_hi, u64* frame, hipStream_t stream) {
+  const u64 n = ev.n;
+  if constexpr (AOS) {
+    hipLaunchKernelGGL((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream,
+                       nullptr, nullptr, (const T*)nullptr, nullptr, (const uint4*)ev.aos, n, idx_offset, tb, st,
+                       tag_override, mm_lo, mm_hi, frame);
+  } else {
+    const bool vec = aligned(ev.x, 8) && aligned(ev.y, 8) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 8));
+    if (vec) {
+      hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, stream,
+                         ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, idx_offset, tb, st, tag_override,
+                         mm_lo, mm_hi, frame);
+    } else {
+      hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, ev.x,
+                         ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, idx_offset, tb, st, tag_override, mm_lo,
+                         mm_hi, frame);
+    }
+  }
+}
+
+template <typename T, bool AOS, bool HAS_P>
+void launch_scatter_t(const EventsView& ev, const DevTables& tb, int view, SlotState* st, u32 tag_override,
+                      u64 idx_offset, u64 mm_lo, u64 mm_hi, u64* frame, hipStream_t stream) {
+  if (view == XM_VIEW_PROJECTOR)
+    launch_scatter_tv<T, AOS, HAS_P, 0>(ev, tb, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream);
+  else
+    launch_scatter_tv<T, AOS, HAS_P, 1>(ev, tb, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream);
+}
+
+void launch_scatter(const EventsView& ev, const DevTables& tb, int view, SlotState* st, u32 tag_override,
+                    u64 idx_offset, u64 mm_lo, u64 mm_hi, u64* frame, hipStream_t stream) {
+#define XM_SC(T, AOS, HP) launch_scatter_t<T, AOS, HP>(ev, tb, view, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream)
+  if (ev.aos) {
+    ev.use_p ? XM_SC(long long, true, true) : XM_SC(long long, true, false);
+    return;
+  }
+  switch (ev.t_dtype) {
+    case XM_T_INT64: ev.use_p ? XM_SC(long long, false, true) : XM_SC(long long, false, false); break;
+    case XM_T_FLOAT32: ev.use_p ? XM_SC(float, false, true) : XM_SC(float, false, false); break;
+    default: ev.use_p ? XM_SC(double, false, true) : XM_SC(double, false, false);
+  }
+#undef XM_SC
+}
+
+void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 tag_override, float* depth,
+                         uint8_t* bgr, hipStream_t stream) {
+  KeyCells cells{key_frame, 0};
+  if (h->cfg.view == XM_VIEW_PROJECTOR) {
+    const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
+    hipLaunchKernelGGL((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
+                       tag_override, depth, bgr);
+  } else {
+    const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
+    hipLaunchKernelGGL((k_frame_direct<KeyCells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, px,
+                       h->tb.p03, h->tb.z_near, h->tb.z_far, st, tag_override, 1, depth, bgr);
+  }
+}
+
+int check_events(const EventsView& ev) {
+  if (ev.n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "frame of %zu events exceeds 2^%d", ev.n, XM_KEY_IDX_BITS);
+  if (ev.n == 0) return XM_OK;
+  if (ev.aos) {
+    if (!aligned(ev.aos, 16)) return fail(XM_ERR_INVALID, "EventCD buffer must be 16-byte aligned");
+    return XM_OK;
+  }
+  if (!ev.x || !ev.y || !ev.t) return fail(XM_ERR_INVALID, "x, y, t must be non-NULL when n > 0");
+  if (ev.t_dtype != XM_T_INT64 && ev.t_dtype != XM_T_FLOAT32 && ev.t_dtype != XM_T_FLOAT64)
+    return fail(XM_ERR_INVALID, "unknown t_dtype %d", ev.t_dtype);
+  if (!aligned(ev.t, t_size(ev.t_dtype)) || !aligned(ev.x, 2) || !aligned(ev.y, 2) || (ev.p && !aligned(ev.p, 2)))
+    return fail(XM_ERR_INVALID, "event columns must be naturally aligned");
+  return XM_OK;
+}
+
+// enqueue K0 -> K1 -> K2 for one frame on a slot.  All pointers are device pointers.
+int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof) {
+  if (s.host_tag >= KEY_MAX_TAG) {  // tag field about to wrap: clear the frame once per 2^19 frames
+    int rc = reset_slot(h, s);
+    if (rc) return rc;
+  }
+  if (prof) HIP_TRY(hipEventRecord(prof[0], s.stream));
+  launch_minmax(ev, s.st, 0, s.stream);
+  if (prof) HIP_TRY(hipEventRecord(prof[1], s.stream));
+  launch_scatter(ev, h->tb, h->cfg.view, s.st, 0, 0, 0, 0, s.key_frame, s.stream);
+  if (prof) HIP_TRY(hipEventRecord(prof[2], s.stream));
+  launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, s.stream);
+  if (prof) HIP_TRY(hipEventRecord(prof[3], s.stream));
+  HIP_TRY(hipGetLastError());
+  s.host_tag += 1;
+  s.any_frame = true;
+  s.last_n = ev.n;
+  return XM_OK;
+}
+
+template <typename T>
+void decode_minmax(const SlotState& hs, u32 parity, double& lo, double& hi, bool& any) {
+  u64 a = MM_INIT_MIN, b = MM_INIT_MAX;
+  for (int i = 0; i < MM_SLOTS; ++i) {
+    a = hs.mm[parity][i][0] < a ? hs.mm[parity][i][0] : a;
+    b = hs.mm[parity][i][1] > b ? hs.mm[parity][i][1] : b;
+  }
+  any = !(a == MM_INIT_MIN && b == MM_INIT_MAX);
+  lo = any ? (double)TimeCodec<T>::dec(a) : 0.0;
+  hi = any ? (double)TimeCodec<T>::dec(b) : 0.0;
+}
+
+// read the slot's state back and fill stats for its most recent frame (stream must be idle)
+int fetch_stats(xm_handle* h, Slot& s, int t_dtype, xm_frame_stats* out) {
+  SlotState hs;
+  HIP_TRY(hipMemcpy(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost));
+  const u32 parity = s.host_tag & 1;
+  memset(out, 0, sizeof *out);
+  out->n_events = s.last_n;
+  for (int i = 0; i < CNT_SLOTS; ++i) {
+    out->n_used += hs.cnt[parity][i][CNT_USED];
+    out->n_inliers += hs.cnt[parity][i][CNT_INLIER];
+    out->n_index_errors += hs.cnt[parity][i][CNT_OOB];
+  }
+  bool any;
+  if (t_dtype == XM_T_FLOAT32) decode_minmax<float>(hs, parity, out->t_min, out->t_max, any);
+  else if (t_dtype == XM_T_FLOAT64) decode_minmax<double>(hs, parity, out->t_min, out->t_max, any);
+  else decode_minmax<long long>(hs, parity, out->t_min, out->t_max, any);
+  (void)h;
+  return XM_OK;
+}
+
+int stage_in(DevBuf& b, const void* host, size_t bytes, hipStream_t st) {
+  int rc = b.reserve(bytes ? bytes : 16);
+  if (rc) return rc;
+  if (bytes) HIP_TRY(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, st));
+  return XM_OK;
+}
+
+Slot& pick_slot(xm_handle* h) {
+  h->last_slot = h->next_slot;
+  h->next_slot = (h->next_slot + 1) % (int)h->slots.size();
+  return h->slots[h->last_slot];
+}
+
+int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats,
+                   bool profile) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  int rc = check_events(ev);
+  if (rc) return rc;
+  const size_t px = (size_t)h->out_w * h->out_h;
+  Slot& s = profile ? h->slots[0] : pick_slot(h);
+  if (profile) h->last_slot = 0;
+  float* d_depth = depth_out;
+  uint8_t* d_bgr = bgr_out;
+  if (mem == XM_MEM_HOST) {
+    const size_t n = ev.n;
+    if (ev.aos) {
+      if ((rc = stage_in(s.ev_aos, ev.aos, n * 16, s.stream))) return rc;
+      ev.aos = s.ev_aos.p;
+    } else {
+      if ((rc = stage_in(s.ev_x, ev.x, n * 2, s.stream))) return rc;
+      if ((rc = stage_in(s.ev_y, ev.y, n * 2, s.stream))) return rc;
+      if ((rc = stage_in(s.ev_t, ev.t, n * t_size(ev.t_dtype), s.stream))) return rc;
+      ev.x = (const uint16_t*)s.ev_x.p;
+      ev.y = (const uint16_t*)s.ev_y.p;
+      ev.t = s.ev_t.p;
+      if (ev.p) {
+        if ((rc = stage_in(s.ev_p, ev.p, n * 2, s.stream))) return rc;
+        ev.p = (const int16_t*)s.ev_p.p;
+      }
+    }
+    if (depth_out) {
+      if ((rc = s.out_depth.reserve(px * 4))) return rc;
+      d_depth = (float*)s.out_depth.p;
+    }
+    if (bgr_out) {
+      if ((rc = s.out_bgr.reserve(px * 3))) return rc;
+      d_bgr = (uint8_t*)s.out_bgr.p;
+    }
+  } else if (mem != XM_MEM_DEVICE) {
+    return fail(XM_ERR_INVALID, "mem must be XM_MEM_HOST or XM_MEM_DEVICE");
+  }
+  if ((rc = enqueue_frame(h, s, ev, d_depth, d_bgr, profile ? h->prof_ev : nullptr))) return rc;
+  if (mem == XM_MEM_HOST) {
+    if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
+    if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
+  }
+  if (mem == XM_MEM_HOST || profile) {
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    xm_frame_stats st;
+    if ((rc = fetch_stats(h, s, ev.aos ? XM_T_INT64 : ev.t_dtype, &st))) return rc;
+    if (profile) {
+      for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[i], h->prof_ev[i + 1]));
+      HIP_TRY(hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[0], h->prof_ev[3]));
+    }
+    if (stats) *stats = st;
+    if (st.n_index_errors)
+      return fail(XM_ERR_INDEX, "%llu event(s) indexed outside a table/frame (IndexError in the reference)",
+                  (unsigned long long)st.n_index_errors);
+  }
+  return XM_OK;
+}
+
+int ensure_stage_frame(xm_handle* h) {
+  const size_t need = std::max((size_t)h->tb.rect_w * h->tb.rect_h, (size_t)h->tb.cam_w * h->tb.cam_h);
+  if (h->stage_frame && h->stage_cells >= need) return XM_OK;
+  if (h->stage_frame) (void)hipFree(h->stage_frame);
+  h->stage_frame = nullptr;
+  HIP_TRY(hipMalloc((void**)&h->stage_frame, need * sizeof(u64)));
+  h->stage_cells = need;
+  return XM_OK;
+}
+
+int rearm_aux(xm_handle* h, hipStream_t stream, u64* frame, u64 cells) {
+  hipLaunchKernelGGL(k_reset_slot, dim3(cells ? 1024 : 1), dim3(BLOCK), 0, stream, h->aux_st, frame, cells);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+template <typename T>
+void host_minmax_out(const SlotState& hs, void* out) {
+  u64 a = MM_INIT_MIN, b = MM_INIT_MAX;
+  for (int i = 0; i < MM_SLOTS; ++i) {
+    a = hs.mm[0][i][0] < a ? hs.mm[0][i][0] : a;
+    b = hs.mm[0][i][1] > b ? hs.mm[0][i][1] : b;
+  }
+  T* o = (T*)out;
+  o[0] = TimeCodec<T>::dec(a);  // empty shard: dec(~0) = +max sentinel, dec(0) = -max sentinel
+  o[1] = TimeCodec<T>::dec(b);
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int xm_api_version(void) { return XM_API_VERSION; }
+const char* xm_last_error(void) { return g_err.c_str(); }
+
+int xm_create(const xm_config* cfg, xm_handle** out) {
+  if (!cfg || !out) return fail(XM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(xm_config))
+    return fail(XM_ERR_INVALID, "xm_config.struct_size %u != %zu", cfg->struct_size, sizeof(xm_config));
+  if (cfg->cam_width <= 0 || cfg->cam_height <= 0 || cfg->rect_width <= 0 || cfg->rect_height <= 0 ||
+      cfg->xmap_width <= 1)
+    return fail(XM_ERR_INVALID, "bad dimensions");
+  if (cfg->cam_width > 32767 || cfg->cam_height > 32767 || cfg->rect_width > 32767 || cfg->rect_height > 32767 ||
+      cfg->xmap_width > 32767 || cfg->proj_width > 32767 || cfg->proj_height > 32767)
+    return fail(XM_ERR_INVALID, "dimensions must fit int16 indices (x_maps_disparity.py:52-53)");
+  if (cfg->x_offset < 0 || cfg->x_offset > 32767) return fail(XM_ERR_INVALID, "x_offset must fit int16");
+  if (cfg->view != XM_VIEW_PROJECTOR && cfg->view != XM_VIEW_CAMERA) return fail(XM_ERR_INVALID, "bad view");
+  if (!cfg->cam_mapx_i16 || !cfg->cam_mapy_i16 || !cfg->proj_x_map) return fail(XM_ERR_INVALID, "NULL table");
+  if (cfg->view == XM_VIEW_PROJECTOR && (!cfg->disp_proj_mapxy_i16 || cfg->proj_width <= 0 || cfg->proj_height <= 0))
+    return fail(XM_ERR_INVALID, "projector view needs disp_proj_mapxy_i16 and the projector size");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(XM_ERR_HIP, "no HIP device visible: the X-maps hot path needs an AMD GPU (no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(XM_ERR_INVALID, "device %d out of range (%d)", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  xm_handle* h = new (std::nothrow) xm_handle();
+  if (!h) return fail(XM_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  const int n_slots = cfg->n_slots > 0 ? cfg->n_slots : 1;
+  const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
+  h->cfg.n_slots = n_slots;
+  h->cfg.xmap_height = xmap_h;
+
+#define XM_TRY_CREATE(expr)                   \
+  do {                                        \
+    hipError_t e_ = (expr);                   \
+    if (e_ != hipSuccess) {                   \
+      int rc_ = fail(XM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+      xm_destroy(h);                          \
+      return rc_;                             \
+    }                                         \
+  } while (0)
+
+  // re-pack the int16 tables: one 4-byte gather per event / pixel instead of two 2-byte ones
+  const size_t cam_px = (size_t)cfg->cam_width * cfg->cam_height;
+  std::vector<u32> lut(cam_px);
+  for (size_t i = 0; i < cam_px; ++i)
+    lut[i] = ((u32)(uint16_t)cfg->cam_mapy_i16[i] << 16) | (u32)(uint16_t)cfg->cam_mapx_i16[i];
+  XM_TRY_CREATE(hipMalloc((void**)&h->d_lut, cam_px * 4));
+  XM_TRY_CREATE(hipMemcpy(h->d_lut, lut.data(), cam_px * 4, hipMemcpyHostToDevice));
+  const size_t xm_cells = (size_t)xmap_h * cfg->xmap_width;
+  XM_TRY_CREATE(hipMalloc((void**)&h->d_xmap, xm_cells * 2));
+  XM_TRY_CREATE(hipMemcpy(h->d_xmap, cfg->proj_x_map, xm_cells * 2, hipMemcpyHostToDevice));
+  if (cfg->disp_proj_mapxy_i16 && cfg->proj_width > 0 && cfg->proj_height > 0) {
+    const size_t ppx = (size_t)cfg->proj_width * cfg->proj_height;
+    std::vector<u32> pm(ppx);
+    for (size_t i = 0; i < ppx; ++i)
+      pm[i] = ((u32)(uint16_t)cfg->disp_proj_mapxy_i16[2 * i + 1] << 16) | (u32)(uint16_t)cfg->disp_proj_mapxy_i16[2 * i];
+    XM_TRY_CREATE(hipMalloc((void**)&h->d_pmap, ppx * 4));
+    XM_TRY_CREATE(hipMemcpy(h->d_pmap, pm.data(), ppx * 4, hipMemcpyHostToDevice));
+  }
+  h->tb.lut = h->d_lut;
+  h->tb.xmap = h->d_xmap;
+  h->tb.pmap = h->d_pmap;
+  h->tb.cam_w = cfg->cam_width;
+  h->tb.cam_h = cfg->cam_height;
+  h->tb.proj_w = cfg->proj_width;
+  h->tb.proj_h = cfg->proj_height;
+  h->tb.rect_w = cfg->rect_width;
+  h->tb.rect_h = cfg->rect_height;
+  h->tb.xmap_w = cfg->xmap_width;
+  h->tb.xmap_h = xmap_h;
+  h->tb.x_offset = cfg->x_offset;
+  h->tb.t_px_scale = cfg->xmap_width - 1;
+  h->tb.p03 = cfg->p03;
+  h->tb.z_near = cfg->z_near;
+  h->tb.z_far = cfg->z_far;
+  if (cfg->view == XM_VIEW_PROJECTOR) {
+    h->key_cells = (size_t)cfg->rect_width * cfg->rect_height;
+    h->out_w = cfg->proj_width;
+    h->out_h = cfg->proj_height;
+  } else {
+    h->key_cells = cam_px;
+    h->out_w = cfg->cam_width;
+    h->out_h = cfg->cam_height;
+  }
+
+  XM_TRY_CREATE(hipMalloc((void**)&h->d_states, sizeof(SlotState) * (n_slots + 1)));
+  h->aux_st = h->d_states + n_slots;
+  h->slots.resize(n_slots);
+  for (int i = 0; i < n_slots; ++i) {
+    Slot& s = h->slots[i];
+    XM_TRY_CREATE(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    XM_TRY_CREATE(hipMalloc((void**)&s.key_frame, h->key_cells * sizeof(u64)));
+    s.st = h->d_states + i;
+    hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells);
+    XM_TRY_CREATE(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_reset_slot, dim3(1), dim3(BLOCK), 0, h->slots[0].stream, h->aux_st, (u64*)nullptr, (u64)0);
+  XM_TRY_CREATE(hipGetLastError());
+  for (int i = 0; i < 4; ++i) XM_TRY_CREATE(hipEventCreate(&h->prof_ev[i]));
+  XM_TRY_CREATE(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  h->join_ev.resize(n_slots, nullptr);
+  for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
+  for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipStreamSynchronize(h->slots[i].stream));
+#undef XM_TRY_CREATE
+  *out = h;
+  return XM_OK;
+}
+
+void xm_destroy(xm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  for (Slot& s : h->slots) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    s.ev_x.release(); s.ev_y.release(); s.ev_t.release(); s.ev_p.release(); s.ev_aos.release();
+    s.out_depth.release(); s.out_bgr.release();
+    for (auto& d : s.dbg) d.release();
+    if (s.key_frame) (void)hipFree(s.key_frame);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+  for (auto& e : h->join_ev) if (e) (void)hipEventDestroy(e);
+  if (h->stage_frame) (void)hipFree(h->stage_frame);
+  if (h->d_states) (void)hipFree(h->d_states);
+  if (h->d_lut) (void)hipFree(h->d_lut);
+  if (h->d_xmap) (void)hipFree(h->d_xmap);
+  if (h->d_pmap) (void)hipFree(h->d_pmap);
+  delete h;
+}
+
+int xm_sync(xm_handle* h) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  return XM_OK;
+}
+
+void* xm_stream(xm_handle* h, int slot) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size()) return nullptr;
+  return (void*)h->slots[slot].stream;
+}
+
+int xm_process_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                     int t_dtype, int mem, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats) {
+  EventsView ev;
+  ev.x = x; ev.y = y; ev.t = t; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  return process_common(h, ev, mem, depth_out, bgr_out, stats, false);
+}
+
+int xm_process_frame_aos(xm_handle* h, const void* eventcd16, size_t n, int use_polarity, int mem, float* depth_out,
+                         uint8_t* bgr_out, xm_frame_stats* stats) {
+  if (n && !eventcd16) return fail(XM_ERR_INVALID, "NULL event buffer");
+  EventsView ev;
+  static const uint4 dummy = {0, 0, 0, 0};
+  ev.aos = eventcd16 ? eventcd16 : (const void*)&dummy;
+  ev.n = n; ev.t_dtype = XM_T_INT64; ev.use_p = use_polarity != 0;
+  if (mem == XM_MEM_DEVICE && n == 0) ev.aos = h ? (const void*)h->d_lut : ev.aos;  // any valid device address
+  return process_common(h, ev, mem, depth_out, bgr_out, stats, false);
+}
+
+int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                     int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats) {
+  EventsView ev;
+  ev.x = x; ev.y = y; ev.t = t; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  return process_common(h, ev, XM_MEM_DEVICE, depth_out, bgr_out, stats, true);
+}
+
+int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats) {
+  if (!h || !stats) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[h->last_slot];
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return fetch_stats(h, s, XM_T_INT64, stats);
+}
+
+// ---- hipGraph batch ------------------------------------------------------------------------------------
+int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                    const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, xm_graph** out) {
+  if (!h || !out || !offsets_host || n_frames <= 0) return fail(XM_ERR_INVALID, "bad argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int ns = (int)h->slots.size();
+  if ((u64)n_frames / ns + 1 >= KEY_MAX_TAG) return fail(XM_ERR_INVALID, "too many frames per graph");
+  for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  xm_graph* g = new (std::nothrow) xm_graph();
+  if (!g) return fail(XM_ERR_NOMEM, "out of host memory");
+  g->h = h;
+  g->n_frames = n_frames;
+  g->frames_on_slot.assign(ns, 0);
+  const size_t px = (size_t)h->out_w * h->out_h;
+  const size_t tsz = t_size(t_dtype);
+  std::vector<u32> saved(ns);
+  for (int i = 0; i < ns; ++i) saved[i] = h->slots[i].host_tag;
+  hipStream_t origin = h->slots[0].stream;
+  int rc = XM_OK;
+  hipError_t e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    delete g;
+    return fail(XM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  }
+  do {
+    if (ns > 1) {
+      if ((e = hipEventRecord(h->fork_ev, origin)) != hipSuccess) break;
+      for (int i = 1; i < ns; ++i)
+        if ((e = hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0)) != hipSuccess) break;
+      if (e != hipSuccess) break;
+    }
+    for (int f = 0; f < n_frames && rc == XM_OK; ++f) {
+      Slot& s = h->slots[f % ns];
+      EventsView ev;
+      const u64 a = offsets_host[f], b = offsets_host[f + 1];
+      ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
+      ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+      if ((rc = check_events(ev))) break;
+      // tags inside a graph advance on the device; keep the host mirror from triggering a reset mid-capture
+      s.host_tag = 0;
+      rc = enqueue_frame(h, s, ev, depth_out ? depth_out + f * px : nullptr, bgr_out ? bgr_out + f * px * 3 : nullptr,
+                         nullptr);
+      g->frames_on_slot[f % ns] += 1;
+    }
+    if (ns > 1) {
+      for (int i = 1; i < ns; ++i) {
+        if ((e = hipEventRecord(h->join_ev[i], h->slots[i].stream)) != hipSuccess) break;
+        if ((e = hipStreamWaitEvent(origin, h->join_ev[i], 0)) != hipSuccess) break;
+      }
+    }
+  } while (0);
+  hipError_t e2 = hipStreamEndCapture(origin, &g->graph);
+  for (int i = 0; i < ns; ++i) h->slots[i].host_tag = saved[i];
+  if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
+    rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  if (rc == XM_OK) {
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) rc = fail(XM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  if (rc != XM_OK) {
+    xm_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return XM_OK;
+}
+
+int xm_graph_launch(xm_graph* g) {
+  if (!g || !g->exec) return fail(XM_ERR_INVALID, "NULL graph");
+  xm_handle* h = g->h;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  const int ns = (int)h->slots.size();
+  hipStream_t origin = h->slots[0].stream;
+  // order the replay after whatever the other slots are doing, and handle tag wrap per slot
+  for (int i = 1; i < ns; ++i) {
+    HIP_TRY(hipEventRecord(h->join_ev[i], h->slots[i].stream));
+    HIP_TRY(hipStreamWaitEvent(origin, h->join_ev[i], 0));
+  }
+  for (int i = 0; i < ns; ++i) {
+    Slot& s = h->slots[i];
+    if ((u64)s.host_tag + g->frames_on_slot[i] >= KEY_MAX_TAG) {
+      hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, origin, s.st, s.key_frame, (u64)h->key_cells);
+      HIP_TRY(hipGetLastError());
+      s.host_tag = 0;
+    }
+  }
+  HIP_TRY(hipGraphLaunch(g->exec, origin));
+  for (int i = 0; i < ns; ++i) {
+    h->slots[i].host_tag += g->frames_on_slot[i];
+    if (g->frames_on_slot[i]) h->slots[i].any_frame = true;
+  }
+  if (ns > 1) {
+    HIP_TRY(hipEventRecord(h->fork_ev, origin));
+    for (int i = 1; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0));
+  }
+  return XM_OK;
+}
+
+void xm_graph_destroy(xm_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
+// ---- debug: all per-event intermediates -----------------------------------------------------------------
+int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                           int t_dtype, int mem, int16_t* xr, int16_t* yr, int16_t* ts, int16_t* disp, uint8_t* mask) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  EventsView ev;
+  ev.x = x; ev.y = y; ev.t = t; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  int rc = check_events(ev);
+  if (rc) return rc;
+  if (n == 0) return XM_OK;
+  Slot& s = h->slots[0];
+  void* outs_host[5] = {xr, yr, ts, disp, mask};
+  void* outs_dev[5] = {xr, yr, ts, disp, mask};
+  const size_t osz[5] = {2, 2, 2, 2, 1};
+  if (mem == XM_MEM_HOST) {
+    if ((rc = stage_in(s.ev_x, x, n * 2, s.stream))) return rc;
+    if ((rc = stage_in(s.ev_y, y, n * 2, s.stream))) return rc;
+    if ((rc = stage_in(s.ev_t, t, n * t_size(t_dtype), s.stream))) return rc;
+    ev.x = (const uint16_t*)s.ev_x.p; ev.y = (const uint16_t*)s.ev_y.p; ev.t = s.ev_t.p;
+    if (p) {
+      if ((rc = stage_in(s.ev_p, p, n * 2, s.stream))) return rc;
+      ev.p = (const int16_t*)s.ev_p.p;
+    }
+    for (int i = 0; i < 5; ++i)
+      if (outs_host[i]) {
+        if ((rc = s.dbg[i].reserve(n * osz[i]))) return rc;
+        outs_dev[i] = s.dbg[i].p;
+      }
+  }
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  launch_minmax(ev, h->aux_st, 2, s.stream);
+  const unsigned grid = grid_for(n, BLOCK);
+#define XM_DBG(T, HP)                                                                                           \
+  hipLaunchKernelGGL((k_debug_events<T, HP>), dim3(grid), dim3(BLOCK), 0, s.stream, ev.x, ev.y, (const T*)ev.t, \
+                     ev.p, (u64)n, h->tb, h->aux_st, 2u, (int16_t*)outs_dev[0], (int16_t*)outs_dev[1],          \
+                     (int16_t*)outs_dev[2], (int16_t*)outs_dev[3], (uint8_t*)outs_dev[4])
+  switch (t_dtype) {
+    case XM_T_INT64: if (p) XM_DBG(long long, true); else XM_DBG(long long, false); break;
+    case XM_T_FLOAT32: if (p) XM_DBG(float, true); else XM_DBG(float, false); break;
+    default: if (p) XM_DBG(double, true); else XM_DBG(double, false);
+  }
+#undef XM_DBG
+  HIP_TRY(hipGetLastError());
+  if (mem == XM_MEM_HOST)
+    for (int i = 0; i < 5; ++i)
+      if (outs_host[i]) HIP_TRY(hipMemcpyAsync(outs_host[i], outs_dev[i], n * osz[i], hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return XM_OK;
+}
+
+// ---- stage API (host pointers, synchronous) ---------------------------------------------------------------
+static int read_oob(xm_handle* h, hipStream_t stream, const char* what) {
+  u32 c[CNT_STRIDE];
+  HIP_TRY(hipMemcpyAsync(c, &h->aux_st->cnt[0][0][0], sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (c[CNT_OOB]) return fail(XM_ERR_INDEX, "%s: %u index(es) out of range (IndexError in the reference)", what, c[CNT_OOB]);
+  return XM_OK;
+}
+
+int xm_stage_rectify(xm_handle* h, const uint16_t* x, const uint16_t* y, size_t n, int16_t* xr, int16_t* yr) {
+  if (!h || (n && (!x || !y || !xr || !yr))) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (n == 0) return XM_OK;
+  Slot& s = h->slots[0];
+  int rc;
+  if ((rc = stage_in(s.ev_x, x, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.ev_y, y, n * 2, s.stream))) return rc;
+  if ((rc = s.dbg[0].reserve(n * 2)) || (rc = s.dbg[1].reserve(n * 2))) return rc;
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  hipLaunchKernelGGL(k_stage_rectify, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s.stream, (const uint16_t*)s.ev_x.p,
+                     (const uint16_t*)s.ev_y.p, (u64)n, h->tb, (int16_t*)s.dbg[0].p, (int16_t*)s.dbg[1].p,
+                     &h->aux_st->cnt[0][0][CNT_OOB]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(xr, s.dbg[0].p, n * 2, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipMemcpyAsync(yr, s.dbg[1].p, n * 2, hipMemcpyDeviceToHost, s.stream));
+  return read_oob(h, s.stream, "rectify_cam_coords_i16");
+}
+
+int xm_stage_event_disparity(xm_handle* h, const int16_t* xr, const int16_t* yr, const void* t, size_t n, int t_dtype,
+                             int16_t* disp, uint8_t* mask) {
+  if (!h || (n && (!xr || !yr || !t || !disp || !mask))) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (n == 0) return XM_OK;
+  Slot& s = h->slots[0];
+  int rc;
+  if ((rc = stage_in(s.ev_x, xr, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.ev_y, yr, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.ev_t, t, n * t_size(t_dtype), s.stream))) return rc;
+  if ((rc = s.dbg[3].reserve(n * 2)) || (rc = s.dbg[4].reserve(n))) return rc;
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  EventsView ev;
+  ev.t = s.ev_t.p; ev.n = n; ev.t_dtype = t_dtype;
+  ev.x = (const uint16_t*)s.ev_x.p; ev.y = (const uint16_t*)s.ev_y.p;
+  launch_minmax(ev, h->aux_st, 2, s.stream);
+  const unsigned grid = grid_for(n, BLOCK);
+#define XM_ED(T)                                                                                                   \
+  hipLaunchKernelGGL((k_stage_event_disparity<T>), dim3(grid), dim3(BLOCK), 0, s.stream, (const int16_t*)s.ev_x.p, \
+                     (const int16_t*)s.ev_y.p, (const T*)s.ev_t.p, (u64)n, h->tb, h->aux_st, 2u,                   \
+                     (int16_t*)s.dbg[3].p, (uint8_t*)s.dbg[4].p)
+  switch (t_dtype) {
+    case XM_T_INT64: XM_ED(long long); break;
+    case XM_T_FLOAT32: XM_ED(float); break;
+    case XM_T_FLOAT64: XM_ED(double); break;
+    default: return fail(XM_ERR_INVALID, "unknown t_dtype");
+  }
+#undef XM_ED
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(disp, s.dbg[3].p, n * 2, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipMemcpyAsync(mask, s.dbg[4].p, n, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return XM_OK;
+}
+
+static int stage_scatter_common(xm_handle* h, int view, const void* a, const void* b, const int16_t* disp,
+                                const uint8_t* mask, size_t n, float* disp_map) {
+  if (!h || !disp_map || (n && (!a || !b || !disp || !mask))) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "too many events");
+  Slot& s = h->slots[0];
+  int rc;
+  if ((rc = ensure_stage_frame(h))) return rc;
+  const u64 cells = view == 0 ? (u64)h->tb.rect_w * h->tb.rect_h : (u64)h->tb.cam_w * h->tb.cam_h;
+  if ((rc = stage_in(s.ev_x, a, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.ev_y, b, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.dbg[3], disp, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.dbg[4], mask, n, s.stream))) return rc;
+  if ((rc = s.out_depth.reserve(cells * 4))) return rc;
+  if ((rc = rearm_aux(h, s.stream, h->stage_frame, cells))) return rc;
+  if (n) {
+    const unsigned grid = grid_for(n, BLOCK);
+    if (view == 0)
+      hipLaunchKernelGGL((k_stage_scatter<0>), dim3(grid), dim3(BLOCK), 0, s.stream, (const int16_t*)s.ev_x.p,
+                         (const int16_t*)s.ev_y.p, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
+                         (const int16_t*)s.dbg[3].p, (const uint8_t*)s.dbg[4].p, (u64)n, h->tb, 1u, h->stage_frame,
+                         &h->aux_st->cnt[0][0][CNT_OOB]);
+    else
+      hipLaunchKernelGGL((k_stage_scatter<1>), dim3(grid), dim3(BLOCK), 0, s.stream, (const int16_t*)nullptr,
+                         (const int16_t*)nullptr, (const uint16_t*)s.ev_x.p, (const uint16_t*)s.ev_y.p,
+                         (const int16_t*)s.dbg[3].p, (const uint8_t*)s.dbg[4].p, (u64)n, h->tb, 1u, h->stage_frame,
+                         &h->aux_st->cnt[0][0][CNT_OOB]);
+    HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_decode_keys_signed, dim3(grid_for(cells, BLOCK)), dim3(BLOCK), 0, s.stream, h->stage_frame, cells,
+                     1u, (float*)s.out_depth.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(disp_map, s.out_depth.p, cells * 4, hipMemcpyDeviceToHost, s.stream));
+  return read_oob(h, s.stream, view == 0 ? "compute_disp_map_projector_view" : "compute_disp_map_camera_view");
+}
+
+int xm_stage_disp_map_projector_view(xm_handle* h, const int16_t* xr, const int16_t* yr, const int16_t* disp,
+                                     const uint8_t* mask, size_t n, float* disp_map) {
+  return stage_scatter_common(h, 0, xr, yr, disp, mask, n, disp_map);
+}
+
+int xm_stage_disp_map_camera_view(xm_handle* h, const uint16_t* x, const uint16_t* y, const int16_t* disp,
+                                  const uint8_t* mask, size_t n, float* disp_map) {
+  return stage_scatter_common(h, 1, x, y, disp, mask, n, disp_map);
+}
+
+int xm_stage_remap_rectified_disp_map_to_proj(xm_handle* h, const float* rect_disp, float* proj_disp) {
+  if (!h || !rect_disp || !proj_disp) return fail(XM_ERR_INVALID, "NULL argument");
+  if (!h->d_pmap) return fail(XM_ERR_INVALID, "handle was created without disp_proj_mapxy_i16");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[0];
+  const size_t cells = (size_t)h->tb.rect_w * h->tb.rect_h, px = (size_t)h->tb.proj_w * h->tb.proj_h;
+  int rc;
+  if ((rc = stage_in(s.dbg[0], rect_disp, cells * 4, s.stream))) return rc;
+  if ((rc = s.out_depth.reserve(px * 4))) return rc;
+  F32Cells cellsv{(const float*)s.dbg[0].p};
+  hipLaunchKernelGGL((k_frame_proj<F32Cells, 1>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, s.stream, cellsv, h->tb,
+                     (SlotState*)nullptr, 0u, (float*)s.out_depth.p, (uint8_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(proj_disp, s.out_depth.p, px * 4, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return XM_OK;
+}
+
+static int stage_pixels(xm_handle* h, const float* disp, int height, int width, float* depth, uint8_t* bgr) {
+  if (!h || !disp || height <= 0 || width <= 0) return fail(XM_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[0];
+  const size_t px = (size_t)height * width;
+  int rc;
+  if ((rc = stage_in(s.dbg[0], disp, px * 4, s.stream))) return rc;
+  if (depth && (rc = s.out_depth.reserve(px * 4))) return rc;
+  if (bgr && (rc = s.out_bgr.reserve(px * 3))) return rc;
+  F32Cells cellsv{(const float*)s.dbg[0].p};
+  hipLaunchKernelGGL((k_frame_direct<F32Cells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, s.stream, cellsv, (u64)px,
+                     h->tb.p03, h->tb.z_near, h->tb.z_far, (SlotState*)nullptr, 0u, 0,
+                     depth ? (float*)s.out_depth.p : nullptr, bgr ? (uint8_t*)s.out_bgr.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  if (depth) HIP_TRY(hipMemcpyAsync(depth, s.out_depth.p, px * 4, hipMemcpyDeviceToHost, s.stream));
+  if (bgr) HIP_TRY(hipMemcpyAsync(bgr, s.out_bgr.p, px * 3, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return XM_OK;
+}
+
+int xm_stage_disparity_to_depth(xm_handle* h, const float* disp, int height, int width, float* depth) {
+  if (!depth) return fail(XM_ERR_INVALID, "NULL output");
+  return stage_pixels(h, disp, height, width, depth, nullptr);
+}
+
+int xm_stage_colorize_depth_from_disp(xm_handle* h, const float* disp, int height, int width, uint8_t* bgr) {
+  if (!bgr) return fail(XM_ERR_INVALID, "NULL output");
+  return stage_pixels(h, disp, height, width, nullptr, bgr);
+}
+
+// ---- shards -----------------------------------------------------------------------------------------------
+int xm_shard_minmax(xm_handle* h, const void* t, const int16_t* p, size_t n, int t_dtype, void* minmax_out_host) {
+  if (!h || !minmax_out_host || (n && !t)) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[0];
+  int rc;
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  EventsView ev;
+  ev.t = n ? t : (const void*)h->d_lut; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  ev.x = (const uint16_t*)h->d_lut; ev.y = ev.x;
+  launch_minmax(ev, h->aux_st, 2, s.stream);
+  HIP_TRY(hipGetLastError());
+  SlotState hs;
+  HIP_TRY(hipMemcpyAsync(&hs, h->aux_st, sizeof hs, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  switch (t_dtype) {
+    case XM_T_INT64: host_minmax_out<long long>(hs, minmax_out_host); break;
+    case XM_T_FLOAT32: host_minmax_out<float>(hs, minmax_out_host); break;
+    case XM_T_FLOAT64: host_minmax_out<double>(hs, minmax_out_host); break;
+    default: return fail(XM_ERR_INVALID, "unknown t_dtype");
+  }
+  return XM_OK;
+}
+
+int xm_shard_clear(xm_handle* h, uint64_t* key_frame) {
+  if (!h || !key_frame) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipMemsetAsync(key_frame, 0, h->key_cells * sizeof(u64), h->slots[0].stream));
+  return XM_OK;
+}
+
+int xm_shard_scatter(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                     int t_dtype, uint64_t idx_offset, const void* frame_minmax_host, uint32_t tag, uint64_t* key_frame) {
+  if (!h || !key_frame || !frame_minmax_host) return fail(XM_ERR_INVALID, "NULL argument");
+  if (tag == 0 || tag > KEY_MAX_TAG) return fail(XM_ERR_INVALID, "tag must be in [1, 2^19)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (n == 0) return XM_OK;
+  if (idx_offset + n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "global event index exceeds 2^%d", XM_KEY_IDX_BITS);
+  EventsView ev;
+  ev.x = x; ev.y = y; ev.t = t; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  int rc = check_events(ev);
+  if (rc) return rc;
+  u64 lo, hi;
+  switch (t_dtype) {
+    case XM_T_INT64: lo = TimeCodec<long long>::enc(((const long long*)frame_minmax_host)[0]);
+                     hi = TimeCodec<long long>::enc(((const long long*)frame_minmax_host)[1]); break;
+    case XM_T_FLOAT32: lo = TimeCodec<float>::enc(((const float*)frame_minmax_host)[0]);
+                       hi = TimeCodec<float>::enc(((const float*)frame_minmax_host)[1]); break;
+    case XM_T_FLOAT64: lo = TimeCodec<double>::enc(((const double*)frame_minmax_host)[0]);
+                       hi = TimeCodec<double>::enc(((const double*)frame_minmax_host)[1]); break;
+    default: return fail(XM_ERR_INVALID, "unknown t_dtype");
+  }
+  launch_scatter(ev, h->tb, h->cfg.view, h->aux_st, tag, idx_offset, lo, hi, (u64*)key_frame, h->slots[0].stream);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float* depth_out, uint8_t* bgr_out) {
+  if (!h || !key_frame) return fail(XM_ERR_INVALID, "NULL argument");
+  if (tag == 0 || tag > KEY_MAX_TAG) return fail(XM_ERR_INVALID, "tag must be in [1, 2^19)");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  launch_frame_kernel(h, (const u64*)key_frame, h->aux_st, tag, depth_out, bgr_out, h->slots[0].stream);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// ---- device memory helpers ----------------------------------------------------------------------------------
+int xm_dev_alloc(xm_handle* h, size_t bytes, void** out) {
+  if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+  return XM_OK;
+}
+int xm_dev_free(xm_handle* h, void* p) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (p) HIP_TRY(hipFree(p));
+  return XM_OK;
+}
+int xm_dev_upload(xm_handle* h, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (bytes) HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return XM_OK;
+}
+int xm_dev_download(xm_handle* h, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (bytes) HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return XM_OK;
+}
+
+}  // extern "C"

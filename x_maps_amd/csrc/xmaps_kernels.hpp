@@ -1,0 +1,699 @@
+// xmaps_kernels.hpp -- gfx950 (MI355X / CDNA4) device code for the X-maps hot path.
+//
+// Three kernels per frame (no memset, no host round trip):
+//   K0 k_minmax   : frame extrema of t (x_maps_disparity.py:12-13)  -- pure streaming reduction
+//   K1 k_scatter  : per event: rectify-LUT gather (cam_proj_calibration.py:277-281) -> FP64 time
+//                   normalise + rint (x_maps_disparity.py:16-19) -> X-map gather (:25) -> int16
+//                   disparity + inlier masks (:23-29) -> last-writer-wins scatter
+//                   (cam_proj_calibration.py:299-303 / 312-317) as ONE 64-bit atomic max
+//   K2 k_frame_*  : per output pixel: 7x7 max (cv2.dilate) composed with the nearest remap
+//                   (disp_to_depth.py:86-95) -> depth (disp_to_depth.py:46-63) -> u8 normalise
+//                   (:7-21) -> Turbo BGR + white mask (:24-43)
+//
+// Last-writer-wins without a clear: every cell of the disparity frame holds a packed key
+//   [63]=0 | frame tag:19 | event index:28 | disparity:16
+// and K1 does atomic max.  Inside a frame the largest event index wins (= NumPy's fancy-assignment
+// order); keys of older frames carry a smaller tag, lose every max and are ignored by K2, so the
+// 9-56 MB frame is never zero-filled.  The tag lives in device memory (SlotState) so that the same
+// launches can be replayed from a hipGraph.
+//
+// This is gather/scatter + integer work: no MFMA.  What matters is coalesced event reads, L2-resident
+// tables, fire-and-forget atomics and enough waves in flight to hide three dependent memory latencies.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xm {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int KEY_IDX_SHIFT = 16;
+constexpr int KEY_TAG_SHIFT = 44;
+constexpr u32 KEY_MAX_TAG = (1u << 19) - 1;
+constexpr int MM_SLOTS = 32;   // spread the min/max atomics over 32 addresses (one contended word
+                               // retires only ~88 atomics/us on this chip)
+constexpr int CNT_SLOTS = 64;  // same for the counters
+constexpr int BLOCK = 256;
+
+enum { CNT_USED = 0, CNT_INLIER = 1, CNT_OOB = 2, CNT_STRIDE = 4 };
+
+struct DevTables {
+  const u32* lut;       // [cam_h][cam_w]  (u16(yr) << 16) | u16(xr)
+  const int16_t* xmap;  // [xmap_h][xmap_w]
+  const u32* pmap;      // [proj_h][proj_w] (u16(my) << 16) | u16(mx)
+  int cam_w, cam_h, proj_w, proj_h, rect_w, rect_h, xmap_w, xmap_h;
+  int x_offset, t_px_scale;
+  double p03;
+  float z_near, z_far;
+};
+
+// Per-slot device state.  tag_a is written by K0 (block 0) and read by K1/K2; tag_b is written by K1
+// (block 0) and read by K0 -- so no kernel reads a word that one of its own blocks is writing.
+struct SlotState {
+  u32 tag_a;
+  u32 tag_b;
+  u32 pad[2];
+  u64 mm[2][MM_SLOTS][2];               // [parity][slot]{min, max} in order-preserving u64 encoding
+  u32 cnt[2][CNT_SLOTS][CNT_STRIDE];    // [parity][slot]{used, inliers, index errors, -}
+};
+
+// ---- order-preserving u64 encodings so that one pair of unsigned atomics serves every t dtype ------
+template <typename T> struct TimeCodec;
+template <> struct TimeCodec<long long> {
+  static __host__ __device__ u64 enc(long long v) { return (u64)v ^ 0x8000000000000000ull; }
+  static __host__ __device__ long long dec(u64 u) { return (long long)(u ^ 0x8000000000000000ull); }
+};
+template <> struct TimeCodec<double> {
+  static __host__ __device__ u64 enc(double v) {
+    u64 b;
+    __builtin_memcpy(&b, &v, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+  }
+  static __host__ __device__ double dec(u64 u) {
+    u64 b = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    double v;
+    __builtin_memcpy(&v, &b, 8);
+    return v;
+  }
+};
+template <> struct TimeCodec<float> {  // f32 -> f64 is exact and monotone
+  static __host__ __device__ u64 enc(float v) { return TimeCodec<double>::enc((double)v); }
+  static __host__ __device__ float dec(u64 u) { return (float)TimeCodec<double>::dec(u); }
+};
+
+constexpr u64 MM_INIT_MIN = ~0ull;
+constexpr u64 MM_INIT_MAX = 0ull;
+
+// ---- t -> X-map column, bit-exact with NumPy (x_maps_disparity.py:16-19) ---------------------------
+// int64: (t - tmin) and (tmax - tmin) are exact int64, both converted to f64, IEEE divide, multiply by
+// S, round-half-even.  Compiled with -ffp-contract=off so nothing is fused.
+template <typename T> struct TimeNorm;
+template <> struct TimeNorm<long long> {
+  long long tmin;
+  double den, scale;
+  bool degenerate;
+  __device__ TimeNorm(long long lo, long long hi, int S)
+      : tmin(lo), den((double)(hi - lo)), scale((double)S), degenerate(hi == lo) {}
+  __device__ int column(long long t) const {
+    if (degenerate) return 0;  // 0/0 = NaN -> int16 cast = 0 (what NumPy yields on x86-64)
+    double tn = (double)(t - tmin) / den;
+    return (int)(short)(int)rint(tn * scale);
+  }
+};
+template <> struct TimeNorm<double> {
+  double tmin, den, scale;
+  bool degenerate;
+  __device__ TimeNorm(double lo, double hi, int S) : tmin(lo), den(hi - lo), scale((double)S), degenerate(hi == lo) {}
+  __device__ int column(double t) const {
+    if (degenerate) return 0;
+    double tn = (t - tmin) / den;
+    return (int)(short)(int)rint(tn * scale);
+  }
+};
+template <> struct TimeNorm<float> {  // eval caller with an f32 time surface: NumPy stays in f32
+  float tmin, den, scale;
+  bool degenerate;
+  __device__ TimeNorm(float lo, float hi, int S) : tmin(lo), den(hi - lo), scale((float)S), degenerate(hi == lo) {}
+  __device__ int column(float t) const {
+    if (degenerate) return 0;
+    float tn = (t - tmin) / den;
+    return (int)(short)(int)rintf(tn * scale);
+  }
+};
+
+// ---- wave helpers (wave = 64 lanes) ------------------------------------------------------------------
+__device__ inline u64 wave_min_u64(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    u64 w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+__device__ inline u64 wave_max_u64(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    u64 w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+// frame extrema as written by K0: every wave reduces the MM_SLOTS partials itself (512 B, L2-hot)
+__device__ inline void load_frame_minmax(const SlotState* st, u32 parity, u64& lo, u64& hi) {
+  int lane = threadIdx.x & 63;
+  u64 a = MM_INIT_MIN, b = MM_INIT_MAX;
+  if (lane < MM_SLOTS) {
+    a = st->mm[parity][lane][0];
+    b = st->mm[parity][lane][1];
+  }
+  lo = wave_min_u64(a);
+  hi = wave_max_u64(b);
+}
+
+// =====================================================================================================
+// K0: min / max of t over the frame's events (those with p == 1 when a polarity column is given).
+//   SoA : t[n] (+ p[n]);  VEC = events per 16-byte load of int64 t (2) or scalar (1)
+//   AoS : EventCD records, one 16-byte load per event
+// Also: advances the slot's frame tag (block 0) and counts the used events.
+// =====================================================================================================
+template <typename T, bool AOS, bool HAS_P, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const int16_t* __restrict__ p,
+                                                  const uint4* __restrict__ aos, u64 n, SlotState* st,
+                                                  u32 tag_override) {
+  const u32 tag = tag_override ? tag_override : st->tag_b + 1;
+  const u32 parity = tag & 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->tag_a = tag;
+
+  u64 lo = MM_INIT_MIN, hi = MM_INIT_MAX;
+  u32 used = 0;
+  const u64 stride = (u64)gridDim.x * BLOCK;
+  if constexpr (AOS) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+      uint4 r = aos[i];
+      bool ok = !HAS_P || (short)(r.y & 0xffff) == 1;
+      if (ok) {
+        u64 e = TimeCodec<long long>::enc((long long)(((u64)r.w << 32) | r.z));
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+        ++used;
+      }
+    }
+  } else if constexpr (VEC == 2) {
+    const u64 n2 = n >> 1;
+    const longlong2* t2 = reinterpret_cast<const longlong2*>(t);
+    const u32* p2 = reinterpret_cast<const u32*>(p);
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) {
+      longlong2 v = t2[i];
+      bool ok0 = true, ok1 = true;
+      if constexpr (HAS_P) {
+        u32 pp = p2[i];
+        ok0 = (short)(pp & 0xffff) == 1;
+        ok1 = (short)(pp >> 16) == 1;
+      }
+      if (ok0) {
+        u64 e = TimeCodec<T>::enc((T)v.x);
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+        ++used;
+      }
+      if (ok1) {
+        u64 e = TimeCodec<T>::enc((T)v.y);
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+        ++used;
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      u64 i = n - 1;
+      if (!HAS_P || p[i] == 1) {
+        u64 e = TimeCodec<T>::enc(t[i]);
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+        ++used;
+      }
+    }
+  } else {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+      if (!HAS_P || p[i] == 1) {
+        u64 e = TimeCodec<T>::enc(t[i]);
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+        ++used;
+      }
+    }
+  }
+
+  // wave -> block -> one pair of fire-and-forget atomics per block, spread over MM_SLOTS addresses
+  lo = wave_min_u64(lo);
+  hi = wave_max_u64(hi);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) used += __shfl_xor(used, o, 64);
+  __shared__ u64 s_lo[BLOCK / 64], s_hi[BLOCK / 64];
+  __shared__ u32 s_used[BLOCK / 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+    s_used[wave] = used;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 u = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+      u += s_used[w];
+    }
+    if (u) {
+      const int slot = blockIdx.x % MM_SLOTS;
+      __hip_atomic_fetch_min(&st->mm[parity][slot][0], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(&st->mm[parity][slot][1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&st->cnt[parity][blockIdx.x % CNT_SLOTS][CNT_USED], u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// =====================================================================================================
+// K1: the fused per-event kernel.
+// =====================================================================================================
+struct EventResult {
+  int xr, yr, ts, disp;
+  bool inlier;
+};
+
+// A1 + A2 for one event.  `used` = belongs to the frame (polarity).  Sets oob when NumPy would raise.
+template <typename T>
+__device__ inline EventResult event_disparity(const DevTables& tb, const TimeNorm<T>& tn, u32 x, u32 y, T t,
+                                              bool used, bool& oob) {
+  EventResult r{0, 0, 0, 0, false};
+  oob = false;
+  if (!used) return r;
+  if (x >= (u32)tb.cam_w || y >= (u32)tb.cam_h) {  // map[y, x] IndexError (calib:279-280)
+    oob = true;
+    return r;
+  }
+  const u32 l = tb.lut[y * (u32)tb.cam_w + x];
+  r.xr = (int)(short)(l & 0xffff);
+  r.yr = (int)(short)(l >> 16);
+  r.ts = tn.column(t);
+  const bool y_ok = r.yr >= 0 && r.yr < tb.xmap_h - 1;  // xmd:23 (last X-map row excluded)
+  if (!y_ok) return r;
+  if ((u32)r.ts >= (u32)tb.xmap_w) {  // only reachable when a caller hands in extrema that do not bound t
+    oob = true;
+    return r;
+  }
+  const int xp = (int)tb.xmap[r.yr * tb.xmap_w + r.ts];                // xmd:25
+  r.disp = (int)(short)(xp - r.xr - tb.x_offset);                      // int16 wrap-around (xmd:27)
+  r.inlier = r.disp >= 0;                                              // xmd:29
+  return r;
+}
+
+// cell of the disparity frame an inlier event writes; false = NumPy IndexError
+template <int VIEW>
+__device__ inline bool event_cell(const DevTables& tb, const EventResult& r, u32 x, u32 y, u32& cell) {
+  if constexpr (VIEW == 0) {
+    int col = (int)(short)(r.xr + r.disp);  // calib:300: int16 add (= xp - x_offset), rint is a no-op
+    if (col < 0) col += tb.rect_w;          // NumPy negative index wraps once
+    if (col < 0 || col >= tb.rect_w || r.yr >= tb.rect_h) return false;
+    cell = (u32)r.yr * (u32)tb.rect_w + (u32)col;
+  } else {
+    cell = y * (u32)tb.cam_w + x;  // bounds already checked by the LUT gather
+  }
+  return true;
+}
+
+// EPT = events per thread: 4 (vector loads: 8 B of x, 8 B of y, 2 x 16 B of t, 8 B of p per thread;
+// needs 8/8/16/8-byte aligned columns) or 1 (any alignment).  AOS: one 16-B record per thread.
+template <typename T, bool AOS, bool HAS_P, int EPT, int VIEW>
+__global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                   const T* __restrict__ ts, const int16_t* __restrict__ ps,
+                                                   const uint4* __restrict__ aos, u64 n, u64 idx_offset,
+                                                   DevTables tb, SlotState* st, u32 tag_override, u64 mm_lo,
+                                                   u64 mm_hi, u64* __restrict__ frame) {
+  const u32 tag = tag_override ? tag_override : st->tag_a;
+  const u32 parity = tag & 1;
+  u64 lo, hi;
+  if (tag_override) {  // sharded mode: the FRAME's extrema come from the host-side all-reduce
+    lo = mm_lo;
+    hi = mm_hi;
+  } else {
+    load_frame_minmax(st, parity, lo, hi);
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) st->tag_b = tag;
+      // re-arm the other parity's min/max slots for the next frame on this slot
+      if (threadIdx.x < MM_SLOTS) {
+        st->mm[parity ^ 1][threadIdx.x][0] = MM_INIT_MIN;
+        st->mm[parity ^ 1][threadIdx.x][1] = MM_INIT_MAX;
+      }
+    }
+  }
+  const TimeNorm<T> tn(TimeCodec<T>::dec(lo), TimeCodec<T>::dec(hi), tb.t_px_scale);
+  const u64 key_hi = (u64)tag << KEY_TAG_SHIFT;
+
+  u32 x[EPT], y[EPT];
+  T t[EPT];
+  bool used[EPT];
+  const u64 base = ((u64)blockIdx.x * BLOCK + threadIdx.x) * EPT;
+  if constexpr (AOS) {
+    static_assert(EPT == 1, "AoS: one record per thread");
+    used[0] = base < n;
+    if (used[0]) {
+      uint4 r = aos[base];
+      x[0] = r.x & 0xffff;
+      y[0] = r.x >> 16;
+      t[0] = (T)(long long)(((u64)r.w << 32) | r.z);
+      if (HAS_P) used[0] = (short)(r.y & 0xffff) == 1;
+    }
+  } else if constexpr (EPT == 4) {
+    if (base + 4 <= n) {
+      const uint2 xv = *reinterpret_cast<const uint2*>(xs + base);
+      const uint2 yv = *reinterpret_cast<const uint2*>(ys + base);
+      x[0] = xv.x & 0xffff; x[1] = xv.x >> 16; x[2] = xv.y & 0xffff; x[3] = xv.y >> 16;
+      y[0] = yv.x & 0xffff; y[1] = yv.x >> 16; y[2] = yv.y & 0xffff; y[3] = yv.y >> 16;
+      if constexpr (sizeof(T) == 8) {
+        const longlong2 a = *reinterpret_cast<const longlong2*>(ts + base);
+        const longlong2 b = *reinterpret_cast<const longlong2*>(ts + base + 2);
+        __builtin_memcpy(&t[0], &a.x, 8); __builtin_memcpy(&t[1], &a.y, 8);
+        __builtin_memcpy(&t[2], &b.x, 8); __builtin_memcpy(&t[3], &b.y, 8);
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(ts + base);
+        __builtin_memcpy(&t[0], &a.x, 4); __builtin_memcpy(&t[1], &a.y, 4);
+        __builtin_memcpy(&t[2], &a.z, 4); __builtin_memcpy(&t[3], &a.w, 4);
+      }
+      used[0] = used[1] = used[2] = used[3] = true;
+      if constexpr (HAS_P) {
+        const uint2 pv = *reinterpret_cast<const uint2*>(ps + base);
+        used[0] = (short)(pv.x & 0xffff) == 1; used[1] = (short)(pv.x >> 16) == 1;
+        used[2] = (short)(pv.y & 0xffff) == 1; used[3] = (short)(pv.y >> 16) == 1;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        used[k] = base + k < n;
+        if (used[k]) {
+          x[k] = xs[base + k];
+          y[k] = ys[base + k];
+          t[k] = ts[base + k];
+          if (HAS_P) used[k] = ps[base + k] == 1;
+        }
+      }
+    }
+  } else {
+    used[0] = base < n;
+    if (used[0]) {
+      x[0] = xs[base];
+      y[0] = ys[base];
+      t[0] = ts[base];
+      if (HAS_P) used[0] = ps[base] == 1;
+    }
+  }
+
+  u32 n_in = 0, n_oob = 0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    bool oob;
+    const EventResult r = event_disparity<T>(tb, tn, x[k], y[k], t[k], used[k], oob);
+    bool write = r.inlier;
+    u32 cell = 0;
+    if (write && !event_cell<VIEW>(tb, r, x[k], y[k], cell)) {
+      write = false;
+      oob = true;
+    }
+    if (write) {
+      const u64 key = key_hi | ((idx_offset + base + k) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
+      __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // wavefront ballots: one popcount per wave instead of per-lane counters
+    n_in += __popcll(__ballot(write));
+    n_oob += __popcll(__ballot(oob));
+  }
+  __shared__ u32 s_in, s_oob;
+  if (threadIdx.x == 0) {
+    s_in = 0;
+    s_oob = 0;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    if (n_in) atomicAdd(&s_in, n_in);
+    if (n_oob) atomicAdd(&s_oob, n_oob);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32* c = st->cnt[parity][blockIdx.x % CNT_SLOTS];
+    if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// =====================================================================================================
+// K2: frame kernels.
+// =====================================================================================================
+__device__ const u32 kTurbo[256] = {
+#include "turbo_lut.inc"
+};
+
+struct PixelOut {
+  float depth;
+  u32 bgr;  // byte0 = B, byte1 = G, byte2 = R
+};
+
+// A5 + A6 + A7 for one pixel of the final disparity frame
+__device__ inline PixelOut disparity_pixel(float d, double p03, float z_near, float z_far) {
+  PixelOut o;
+  // disp_to_depth.py:58-61 -- P2 is float64, so the divide is FP64; max(., 1e-9); stored as f32
+  o.depth = d == 0.0f ? 0.0f : (float)fmax(p03 / (double)d, 1e-9);
+  // disp_to_depth.py:12-20 -- clamp, normalise in f32; `* 255` is f32 x int64 -> f64 under Numba; trunc
+  u32 u8 = 0;
+  if (o.depth != 0.0f) {
+    const float range = z_far - z_near;
+    const float c = fmaxf(fminf(o.depth, z_far), z_near);
+    const float q = (c - z_near) / range;
+    u8 = (u32)(int)((double)q * 255.0) & 0xff;
+  }
+  // disp_to_depth.py:24-43 -- Turbo, undefined depth (u8 == 0) painted white
+  o.bgr = u8 == 0 ? 0x00ffffffu : kTurbo[u8];
+  return o;
+}
+
+// cooperative, coalesced store of BLOCK pixels' BGR bytes (3 B each) through LDS
+__device__ inline void store_bgr_block(uint8_t* __restrict__ bgr, u64 first_pixel, u64 n_pixels, u32 v) {
+  __shared__ __attribute__((aligned(16))) uint8_t s[BLOCK * 3];
+  s[threadIdx.x * 3 + 0] = (uint8_t)(v & 0xff);
+  s[threadIdx.x * 3 + 1] = (uint8_t)((v >> 8) & 0xff);
+  s[threadIdx.x * 3 + 2] = (uint8_t)((v >> 16) & 0xff);
+  __syncthreads();
+  const u64 remaining = n_pixels - first_pixel;
+  uint8_t* dst = bgr + first_pixel * 3;  // BLOCK*3 = 768 B per block -> 4-byte aligned
+  if (remaining >= BLOCK) {
+    if (threadIdx.x < BLOCK * 3 / 4) reinterpret_cast<u32*>(dst)[threadIdx.x] = reinterpret_cast<u32*>(s)[threadIdx.x];
+  } else {
+    for (u32 i = threadIdx.x; i < remaining * 3; i += BLOCK) dst[i] = s[i];
+  }
+}
+
+struct KeyCells {  // cells of the packed-key frame written by K1
+  static constexpr bool keyed = true;
+  const u64* f;
+  u32 tag;
+  __device__ float get(u32 i) const {
+    const u64 k = f[i];
+    return (u32)(k >> KEY_TAG_SHIFT) == tag ? (float)(u32)(k & 0xffff) : 0.0f;
+  }
+};
+struct F32Cells {  // a plain f32 disparity frame (stage API)
+  static constexpr bool keyed = false;
+  const float* f;
+  __device__ float get(u32 i) const { return f[i]; }
+};
+
+// dilate(7x7) o remap(nearest) composed: out[v,u] = max over the 7x7 window centred on map[v,u] of the
+// rectified frame, 0 when the map points outside it; window cells outside the image are ignored.
+template <typename Cells>
+__device__ inline float dilated_remap(const Cells& cells, const DevTables& tb, u32 pixel) {
+  const u32 m = tb.pmap[pixel];
+  const int mx = (int)(short)(m & 0xffff), my = (int)(short)(m >> 16);
+  if (mx < 0 || mx >= tb.rect_w || my < 0 || my >= tb.rect_h) return 0.0f;  // BORDER_CONSTANT 0
+  float best = 0.0f;  // disparities are >= 0, so ignoring the border == zero padding
+  const int y0 = max(my - 3, 0), y1 = min(my + 3, tb.rect_h - 1);
+  const int x0 = max(mx - 3, 0), x1 = min(mx + 3, tb.rect_w - 1);
+  for (int yy = y0; yy <= y1; ++yy) {
+    const u32 row = (u32)yy * (u32)tb.rect_w;
+#pragma unroll 7
+    for (int xx = x0; xx <= x1; ++xx) best = fmaxf(best, cells.get(row + (u32)xx));
+  }
+  return best;
+}
+
+// projector view: one thread per projector pixel.  MODE 0: packed-key frame -> depth + BGR (fused hot
+// path); MODE 1: f32 frame -> f32 remapped disparity (stage A4)
+template <typename Cells, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb, SlotState* st, u32 tag_override,
+                                                      float* __restrict__ out_f32, uint8_t* __restrict__ bgr) {
+  const u64 n_pixels = (u64)tb.proj_w * tb.proj_h;
+  const u64 pixel = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if constexpr (MODE == 0) {
+    const u32 tag = tag_override ? tag_override : st->tag_a;
+    cells.tag = tag;
+    if (!tag_override && blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {  // re-arm the next frame's counters
+      u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
+      c[0] = c[1] = c[2] = c[3] = 0;
+    }
+  }
+  float d = 0.0f;
+  if (pixel < n_pixels) d = dilated_remap(cells, tb, (u32)pixel);
+  if constexpr (MODE == 1) {
+    if (pixel < n_pixels) out_f32[pixel] = d;
+  } else {
+    const PixelOut o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
+    if (out_f32 && pixel < n_pixels) out_f32[pixel] = o.depth;
+    if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, o.bgr);
+  }
+}
+
+// camera view / plain per-pixel conversion of a frame of n_pixels cells -> depth + BGR
+template <typename Cells>
+__global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixels, double p03, float z_near,
+                                                        float z_far, SlotState* st, u32 tag_override, int use_tag,
+                                                        float* __restrict__ depth, uint8_t* __restrict__ bgr) {
+  const u64 pixel = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if constexpr (Cells::keyed) {
+    if (use_tag) {
+      const u32 tag = tag_override ? tag_override : st->tag_a;
+      cells.tag = tag;
+      if (!tag_override && blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {
+        u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
+        c[0] = c[1] = c[2] = c[3] = 0;
+      }
+    }
+  }
+  float d = 0.0f;
+  if (pixel < n_pixels) d = cells.get((u32)pixel);
+  const PixelOut o = disparity_pixel(d, p03, z_near, z_far);
+  if (depth && pixel < n_pixels) depth[pixel] = o.depth;
+  if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, o.bgr);
+}
+
+// packed-key frame -> f32 disparity frame (stage A3 / A3' output)
+__global__ __launch_bounds__(BLOCK) void k_decode_keys(const u64* __restrict__ f, u64 n_cells, u32 tag,
+                                                       float* __restrict__ out) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n_cells) {
+    const u64 k = f[i];
+    out[i] = (u32)(k >> KEY_TAG_SHIFT) == tag ? (float)(u32)(k & 0xffff) : 0.0f;
+  }
+}
+
+// =====================================================================================================
+// stage / debug kernels (reference stage signatures; not on the fused path)
+// =====================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_stage_rectify(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                         u64 n, DevTables tb, int16_t* __restrict__ xr,
+                                                         int16_t* __restrict__ yr, u32* __restrict__ oob_count) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const u32 x = xs[i], y = ys[i];
+  if (x >= (u32)tb.cam_w || y >= (u32)tb.cam_h) {
+    atomicAdd(oob_count, 1u);
+    xr[i] = 0;
+    yr[i] = 0;
+    return;
+  }
+  const u32 l = tb.lut[y * (u32)tb.cam_w + x];
+  xr[i] = (int16_t)(l & 0xffff);
+  yr[i] = (int16_t)(l >> 16);
+}
+
+// A2 on caller-supplied rectified coordinates
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_stage_event_disparity(const int16_t* __restrict__ xr,
+                                                                 const int16_t* __restrict__ yr, const T* __restrict__ ts,
+                                                                 u64 n, DevTables tb, const SlotState* st, u32 tag,
+                                                                 int16_t* __restrict__ disp, uint8_t* __restrict__ mask) {
+  u64 lo, hi;
+  load_frame_minmax(st, tag & 1, lo, hi);
+  const TimeNorm<T> tn(TimeCodec<T>::dec(lo), TimeCodec<T>::dec(hi), tb.t_px_scale);
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int x = xr[i], y = yr[i];
+  int d = 0;
+  bool ok = y >= 0 && y < tb.xmap_h - 1;
+  if (ok) {
+    const int col = tn.column(ts[i]);
+    const int xp = (int)tb.xmap[y * tb.xmap_w + col];
+    d = (int)(short)(xp - x - tb.x_offset);
+    ok = d >= 0;
+  }
+  disp[i] = (int16_t)(ok ? d : 0);
+  mask[i] = ok ? 1 : 0;
+}
+
+// A3 / A3' on caller-supplied per-event arrays (full length + mask)
+template <int VIEW>
+__global__ __launch_bounds__(BLOCK) void k_stage_scatter(const int16_t* __restrict__ xr, const int16_t* __restrict__ yr,
+                                                         const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                         const int16_t* __restrict__ disp, const uint8_t* __restrict__ mask,
+                                                         u64 n, DevTables tb, u32 tag, u64* __restrict__ frame,
+                                                         u32* __restrict__ oob_count) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n || !mask[i]) return;
+  u32 cell;
+  const int d = disp[i];
+  if constexpr (VIEW == 0) {
+    int col = (int)(short)(xr[i] + d);
+    const int row = yr[i];
+    if (col < 0) col += tb.rect_w;
+    int r = row;
+    if (r < 0) r += tb.rect_h;  // stage API: arbitrary caller arrays, NumPy index rules
+    if (col < 0 || col >= tb.rect_w || r < 0 || r >= tb.rect_h) {
+      atomicAdd(oob_count, 1u);
+      return;
+    }
+    cell = (u32)r * (u32)tb.rect_w + (u32)col;
+  } else {
+    const u32 x = xs[i], y = ys[i];
+    if (x >= (u32)tb.cam_w || y >= (u32)tb.cam_h) {
+      atomicAdd(oob_count, 1u);
+      return;
+    }
+    cell = y * (u32)tb.cam_w + x;
+  }
+  // the stage frame stores the f32 value of the int16 disparity; negative values never pass the mask
+  // in the reference's pipeline, but keep the low 16 bits faithfully and sign-extend on decode
+  const u64 key = ((u64)tag << KEY_TAG_SHIFT) | (i << KEY_IDX_SHIFT) | (u64)(u32)(uint16_t)d;
+  __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_decode_keys_signed(const u64* __restrict__ f, u64 n_cells, u32 tag,
+                                                              float* __restrict__ out) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n_cells) {
+    const u64 k = f[i];
+    out[i] = (u32)(k >> KEY_TAG_SHIFT) == tag ? (float)(int)(short)(k & 0xffff) : 0.0f;
+  }
+}
+
+// every intermediate of A1/A2 per event (tests)
+template <typename T, bool HAS_P>
+__global__ __launch_bounds__(BLOCK) void k_debug_events(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                        const T* __restrict__ ts, const int16_t* __restrict__ ps, u64 n,
+                                                        DevTables tb, const SlotState* st, u32 tag,
+                                                        int16_t* __restrict__ xr, int16_t* __restrict__ yr,
+                                                        int16_t* __restrict__ tcol, int16_t* __restrict__ disp,
+                                                        uint8_t* __restrict__ mask) {
+  u64 lo, hi;
+  load_frame_minmax(st, tag & 1, lo, hi);
+  const TimeNorm<T> tn(TimeCodec<T>::dec(lo), TimeCodec<T>::dec(hi), tb.t_px_scale);
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  bool oob;
+  const bool used = !HAS_P || ps[i] == 1;
+  const EventResult r = event_disparity<T>(tb, tn, xs[i], ys[i], ts[i], used, oob);
+  if (xr) xr[i] = (int16_t)r.xr;
+  if (yr) yr[i] = (int16_t)r.yr;
+  if (tcol) tcol[i] = (int16_t)r.ts;
+  if (disp) disp[i] = (int16_t)r.disp;
+  if (mask) mask[i] = r.inlier ? 1 : 0;
+}
+
+// slot (re)initialisation: zero the key frame, arm min/max + counters, tag = 0
+__global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells) {
+  const u64 stride = (u64)gridDim.x * BLOCK;
+  for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n_cells; i += stride) frame[i] = 0;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      st->tag_a = 0;
+      st->tag_b = 0;
+    }
+    for (int i = threadIdx.x; i < 2 * MM_SLOTS; i += BLOCK) {
+      st->mm[i / MM_SLOTS][i % MM_SLOTS][0] = MM_INIT_MIN;
+      st->mm[i / MM_SLOTS][i % MM_SLOTS][1] = MM_INIT_MAX;
+    }
+    for (int i = threadIdx.x; i < 2 * CNT_SLOTS * CNT_STRIDE; i += BLOCK) (&st->cnt[0][0][0])[i] = 0;
+  }
+}
+
+}  // namespace xm

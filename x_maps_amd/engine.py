@@ -1,0 +1,336 @@
+"""XMapsEngine: thin, typed Python face of one xm_handle (include/xmaps.h).
+
+All compute happens in libxmaps_hip.so on the GPU; this file only marshals NumPy arrays / raw device
+pointers into the C-ABI and maps error codes to the exceptions the reference's NumPy code raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+_T_DTYPES = {np.dtype(np.int64): N.XM_T_INT64, np.dtype(np.float32): N.XM_T_FLOAT32,
+             np.dtype(np.float64): N.XM_T_FLOAT64}
+
+
+@dataclass
+class FrameStats:
+    n_events: int = 0
+    n_used: int = 0
+    n_inliers: int = 0
+    n_index_errors: int = 0
+    t_min: float = 0.0
+    t_max: float = 0.0
+    gpu_ms: tuple = (0.0, 0.0, 0.0, 0.0)  # minmax, scatter, frame kernel, whole frame (profile only)
+
+    @staticmethod
+    def from_c(s: N.xm_frame_stats) -> "FrameStats":
+        return FrameStats(int(s.n_events), int(s.n_used), int(s.n_inliers), int(s.n_index_errors),
+                          float(s.t_min), float(s.t_max), tuple(float(v) for v in s.gpu_ms))
+
+
+def _ptr(a) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(None)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(int(a))  # raw device pointer
+
+
+def _coords_u16(a, what: str) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.uint16:
+        if a.size and (a.min() < 0 or a.max() > 65535):
+            raise IndexError(f"{what} coordinate outside the sensor")
+        a = a.astype(np.uint16)
+    return np.ascontiguousarray(a)
+
+
+def _time_col(t) -> tuple[np.ndarray, int]:
+    t = np.asarray(t)
+    if t.dtype not in _T_DTYPES:
+        if np.issubdtype(t.dtype, np.integer):
+            t = t.astype(np.int64)
+        else:
+            raise TypeError(f"unsupported time dtype {t.dtype}")
+    return np.ascontiguousarray(t), _T_DTYPES[t.dtype]
+
+
+class XMapsEngine:
+    """One GPU handle: tables resident in HBM + the fused per-frame kernels.
+
+    tables: dict with the reference's arrays / scalars --
+      cam_mapx_i16, cam_mapy_i16   (cam_h, cam_w) int16    CamProjMaps.disp_cam_map{x,y}_i16
+      proj_x_map                   (H_x, W_t)     int16    XMapsDisparity.proj_x_map
+      disp_proj_mapxy_i16          (proj_h, proj_w, 2) int16   CamProjMaps.disp_proj_mapxy_i16
+      rect_w, rect_h, p03 (= P2[0,3]), z_near, z_far, x_offset (4242)
+    """
+
+    def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1):
+        self._lib = N.load_library()
+        self._h = C.c_void_p(None)
+        mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
+        mapy = np.ascontiguousarray(tables["cam_mapy_i16"], dtype=np.int16)
+        xmap = np.ascontiguousarray(tables["proj_x_map"], dtype=np.int16)
+        pmap = tables.get("disp_proj_mapxy_i16")
+        if pmap is not None:
+            pmap = np.ascontiguousarray(pmap, dtype=np.int16)
+        if mapx.shape != mapy.shape or mapx.ndim != 2 or xmap.ndim != 2:
+            raise ValueError("bad table shapes")
+        cam_h, cam_w = mapx.shape
+        proj_h, proj_w = (pmap.shape[:2] if pmap is not None else (0, 0))
+        cfg = N.xm_config()
+        cfg.struct_size = C.sizeof(N.xm_config)
+        cfg.device = device
+        cfg.cam_width, cfg.cam_height = cam_w, cam_h
+        cfg.proj_width, cfg.proj_height = proj_w, proj_h
+        cfg.rect_width, cfg.rect_height = int(tables["rect_w"]), int(tables["rect_h"])
+        cfg.xmap_height, cfg.xmap_width = xmap.shape
+        cfg.x_offset = int(tables.get("x_offset", 4242))
+        cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
+        cfg.n_slots = n_slots
+        cfg.p03 = float(tables["p03"])
+        cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
+        cfg.cam_mapx_i16 = mapx.ctypes.data
+        cfg.cam_mapy_i16 = mapy.ctypes.data
+        cfg.proj_x_map = xmap.ctypes.data
+        cfg.disp_proj_mapxy_i16 = pmap.ctypes.data if pmap is not None else None
+        N.check(self._lib.xm_create(C.byref(cfg), C.byref(self._h)))
+        self.camera_perspective = camera_perspective
+        self.device = device
+        self.n_slots = n_slots
+        self.cam_w, self.cam_h, self.proj_w, self.proj_h = cam_w, cam_h, proj_w, proj_h
+        self.rect_w, self.rect_h = cfg.rect_width, cfg.rect_height
+        self.out_h, self.out_w = (cam_h, cam_w) if camera_perspective else (proj_h, proj_w)
+        self.key_shape = (cam_h, cam_w) if camera_perspective else (self.rect_h, self.rect_w)
+        self.t_px_scale = xmap.shape[1] - 1
+
+    # ---- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.xm_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def sync(self):
+        N.check(self._lib.xm_sync(self._h))
+
+    def stream(self, slot: int = 0) -> int:
+        return int(self._lib.xm_stream(self._h, slot) or 0)
+
+    # ---- fused hot path, host arrays ------------------------------------------------------------
+    def process_frame(self, x, y, t, p=None, want_depth=True, want_bgr=True, raise_on_index_error=True):
+        """SoA events (host) -> (depth f32 [H,W] | None, bgr u8 [H,W,3] | None, FrameStats)."""
+        x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
+        t, tdt = _time_col(t)
+        n = len(t)
+        if len(x) != n or len(y) != n:
+            raise ValueError("x, y, t must have equal length")
+        if p is not None:
+            p = np.ascontiguousarray(p, dtype=np.int16)
+        depth = np.empty((self.out_h, self.out_w), np.float32) if want_depth else None
+        bgr = np.empty((self.out_h, self.out_w, 3), np.uint8) if want_bgr else None
+        st = N.xm_frame_stats()
+        rc = self._lib.xm_process_frame(self._h, _ptr(x), _ptr(y), _ptr(t), _ptr(p), n, tdt, N.XM_MEM_HOST,
+                                        _ptr(depth), _ptr(bgr), C.byref(st))
+        N.check(rc, index_error_ok=not raise_on_index_error)
+        return depth, bgr, FrameStats.from_c(st)
+
+    def process_events(self, evs: np.ndarray, use_polarity=False, want_depth=True, want_bgr=True,
+                       raise_on_index_error=True):
+        """Metavision EventCD structured array (16-byte AoS records) -> (depth, bgr, FrameStats)."""
+        if evs.dtype.itemsize != 16 or evs.dtype.fields is None:
+            raise TypeError("expected a structured EventCD array with 16-byte records")
+        f = evs.dtype.fields
+        if (f["x"][1], f["y"][1], f["p"][1], f["t"][1]) != (0, 2, 4, 8):
+            raise TypeError("unexpected EventCD field offsets")
+        evs = np.ascontiguousarray(evs)
+        depth = np.empty((self.out_h, self.out_w), np.float32) if want_depth else None
+        bgr = np.empty((self.out_h, self.out_w, 3), np.uint8) if want_bgr else None
+        st = N.xm_frame_stats()
+        rc = self._lib.xm_process_frame_aos(self._h, _ptr(evs) if len(evs) else None, len(evs), int(use_polarity),
+                                            N.XM_MEM_HOST, _ptr(depth), _ptr(bgr), C.byref(st))
+        N.check(rc, index_error_ok=not raise_on_index_error)
+        return depth, bgr, FrameStats.from_c(st)
+
+    # ---- fused hot path, device pointers (async) -------------------------------------------------
+    def process_frame_device(self, x_ptr, y_ptr, t_ptr, p_ptr, n, depth_ptr=None, bgr_ptr=None,
+                             t_dtype=N.XM_T_INT64):
+        N.check(self._lib.xm_process_frame(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), n, t_dtype,
+                                           N.XM_MEM_DEVICE, _ptr(depth_ptr), _ptr(bgr_ptr), None))
+
+    def process_events_device(self, aos_ptr, n, use_polarity=False, depth_ptr=None, bgr_ptr=None):
+        N.check(self._lib.xm_process_frame_aos(self._h, _ptr(aos_ptr), n, int(use_polarity), N.XM_MEM_DEVICE,
+                                               _ptr(depth_ptr), _ptr(bgr_ptr), None))
+
+    def profile_frame_device(self, x_ptr, y_ptr, t_ptr, p_ptr, n, depth_ptr=None, bgr_ptr=None,
+                             t_dtype=N.XM_T_INT64) -> FrameStats:
+        st = N.xm_frame_stats()
+        N.check(self._lib.xm_profile_frame(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), n, t_dtype,
+                                           _ptr(depth_ptr), _ptr(bgr_ptr), C.byref(st)), index_error_ok=True)
+        return FrameStats.from_c(st)
+
+    def last_frame_stats(self) -> FrameStats:
+        st = N.xm_frame_stats()
+        N.check(self._lib.xm_last_frame_stats(self._h, C.byref(st)))
+        return FrameStats.from_c(st)
+
+    # ---- hipGraph batch ----------------------------------------------------------------------------
+    def graph_create(self, x_ptr, y_ptr, t_ptr, p_ptr, offsets, depth_ptr=None, bgr_ptr=None,
+                     t_dtype=N.XM_T_INT64) -> "XMapsGraph":
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        g = C.c_void_p(None)
+        N.check(self._lib.xm_graph_create(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), t_dtype,
+                                          offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1,
+                                          _ptr(depth_ptr), _ptr(bgr_ptr), C.byref(g)))
+        return XMapsGraph(self, g, len(offs) - 1)
+
+    # ---- debug: every per-event intermediate -------------------------------------------------------
+    def debug_event_outputs(self, x, y, t, p=None):
+        x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
+        t, tdt = _time_col(t)
+        n = len(t)
+        if p is not None:
+            p = np.ascontiguousarray(p, dtype=np.int16)
+        out = {k: np.zeros(n, np.int16) for k in ("xr", "yr", "ts", "disp")}
+        out["mask"] = np.zeros(n, np.uint8)
+        N.check(self._lib.xm_debug_event_outputs(self._h, _ptr(x), _ptr(y), _ptr(t), _ptr(p), n, tdt, N.XM_MEM_HOST,
+                                                 _ptr(out["xr"]), _ptr(out["yr"]), _ptr(out["ts"]),
+                                                 _ptr(out["disp"]), _ptr(out["mask"])))
+        out["mask"] = out["mask"].astype(bool)
+        return out
+
+    # ---- the reference's stages one by one ----------------------------------------------------------
+    def rectify_cam_coords_i16(self, x, y):
+        x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
+        xr = np.empty(len(x), np.int16)
+        yr = np.empty(len(x), np.int16)
+        N.check(self._lib.xm_stage_rectify(self._h, _ptr(x), _ptr(y), len(x), _ptr(xr), _ptr(yr)))
+        return xr, yr
+
+    def event_disparity_full(self, xr_i16, yr_i16, t):
+        """A2 with full-length outputs: (disp[n] int16 with 0 where masked, mask[n] bool)."""
+        xr = np.ascontiguousarray(xr_i16, dtype=np.int16)
+        yr = np.ascontiguousarray(yr_i16, dtype=np.int16)
+        t, tdt = _time_col(t)
+        n = len(t)
+        if n == 0:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        disp = np.empty(n, np.int16)
+        mask = np.empty(n, np.uint8)
+        N.check(self._lib.xm_stage_event_disparity(self._h, _ptr(xr), _ptr(yr), _ptr(t), n, tdt, _ptr(disp), _ptr(mask)))
+        return disp, mask.astype(bool)
+
+    def disp_map_projector_view(self, xr_i16, yr_i16, disp_full, mask):
+        xr = np.ascontiguousarray(xr_i16, dtype=np.int16)
+        yr = np.ascontiguousarray(yr_i16, dtype=np.int16)
+        d = np.ascontiguousarray(disp_full, dtype=np.int16)
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        out = np.empty((self.rect_h, self.rect_w), np.float32)
+        N.check(self._lib.xm_stage_disp_map_projector_view(self._h, _ptr(xr), _ptr(yr), _ptr(d), _ptr(m), len(d), _ptr(out)))
+        return out
+
+    def disp_map_camera_view(self, x, y, disp_full, mask):
+        x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
+        d = np.ascontiguousarray(disp_full, dtype=np.int16)
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        out = np.empty((self.cam_h, self.cam_w), np.float32)
+        N.check(self._lib.xm_stage_disp_map_camera_view(self._h, _ptr(x), _ptr(y), _ptr(d), _ptr(m), len(d), _ptr(out)))
+        return out
+
+    def remap_rectified_disp_map_to_proj(self, rect_disp):
+        src = np.ascontiguousarray(rect_disp, dtype=np.float32)
+        if src.shape != (self.rect_h, self.rect_w):
+            raise ValueError(f"expected a {(self.rect_h, self.rect_w)} frame, got {src.shape}")
+        out = np.empty((self.proj_h, self.proj_w), np.float32)
+        N.check(self._lib.xm_stage_remap_rectified_disp_map_to_proj(self._h, _ptr(src), _ptr(out)))
+        return out
+
+    def disparity_to_depth(self, disp):
+        src = np.ascontiguousarray(disp, dtype=np.float32)
+        out = np.empty(src.shape, np.float32)
+        N.check(self._lib.xm_stage_disparity_to_depth(self._h, _ptr(src), src.shape[0], src.shape[1], _ptr(out)))
+        return out
+
+    def colorize_depth_from_disp(self, disp):
+        src = np.ascontiguousarray(disp, dtype=np.float32)
+        out = np.empty(src.shape + (3,), np.uint8)
+        N.check(self._lib.xm_stage_colorize_depth_from_disp(self._h, _ptr(src), src.shape[0], src.shape[1], _ptr(out)))
+        return out
+
+    # ---- shards (device pointers) ----------------------------------------------------------------------
+    def shard_minmax(self, t_ptr, p_ptr, n, t_dtype=N.XM_T_INT64):
+        np_dt = {N.XM_T_INT64: np.int64, N.XM_T_FLOAT32: np.float32, N.XM_T_FLOAT64: np.float64}[t_dtype]
+        out = np.zeros(2, np_dt)
+        N.check(self._lib.xm_shard_minmax(self._h, _ptr(t_ptr), _ptr(p_ptr), n, t_dtype, _ptr(out)))
+        return out
+
+    def shard_clear(self, key_ptr):
+        N.check(self._lib.xm_shard_clear(self._h, _ptr(key_ptr)))
+
+    def shard_scatter(self, x_ptr, y_ptr, t_ptr, p_ptr, n, idx_offset, frame_minmax, tag, key_ptr,
+                      t_dtype=N.XM_T_INT64):
+        np_dt = {N.XM_T_INT64: np.int64, N.XM_T_FLOAT32: np.float32, N.XM_T_FLOAT64: np.float64}[t_dtype]
+        mm = np.ascontiguousarray(frame_minmax, dtype=np_dt)
+        N.check(self._lib.xm_shard_scatter(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), n, t_dtype,
+                                           int(idx_offset), _ptr(mm), int(tag), _ptr(key_ptr)))
+
+    def shard_finish(self, key_ptr, tag, depth_ptr=None, bgr_ptr=None):
+        N.check(self._lib.xm_shard_finish(self._h, _ptr(key_ptr), int(tag), _ptr(depth_ptr), _ptr(bgr_ptr)))
+
+    # ---- device memory helpers (for hosts without torch) -------------------------------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p(None)
+        N.check(self._lib.xm_dev_alloc(self._h, nbytes, C.byref(p)))
+        return int(p.value)
+
+    def dev_free(self, ptr: int):
+        N.check(self._lib.xm_dev_free(self._h, _ptr(ptr)))
+
+    def dev_upload(self, ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        N.check(self._lib.xm_dev_upload(self._h, _ptr(ptr), _ptr(arr), arr.nbytes))
+
+    def dev_download(self, arr: np.ndarray, ptr: int):
+        assert arr.flags.c_contiguous
+        N.check(self._lib.xm_dev_download(self._h, _ptr(arr), _ptr(ptr), arr.nbytes))
+
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.dev_alloc(arr.nbytes)
+        self.dev_upload(p, arr)
+        return p
+
+
+class XMapsGraph:
+    def __init__(self, engine: XMapsEngine, handle: C.c_void_p, n_frames: int):
+        self._e, self._g, self.n_frames = engine, handle, n_frames
+
+    def launch(self):
+        N.check(self._e._lib.xm_graph_launch(self._g))
+
+    def close(self):
+        if self._g is not None and self._g.value:
+            self._e._lib.xm_graph_destroy(self._g)
+            self._g = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
