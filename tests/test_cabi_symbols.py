@@ -1,0 +1,40 @@
+"""CPU: the C-ABI library loads and exports every symbol include/xmaps.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from x_maps_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "xmaps.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 25
+    lib = N.load_library()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in xmaps.h but not exported by libxmaps_hip.so"
+    assert set(names) == set(N.SYMBOLS), set(names) ^ set(N.SYMBOLS)
+    assert lib.xm_api_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    # xm_config: 14 int32 + double + 2 float + 4 pointers; xm_frame_stats: 4 u64 + 2 double + 4 float
+    assert ctypes.sizeof(N.xm_config) == 14 * 4 + 8 + 2 * 4 + 4 * 8
+    assert ctypes.sizeof(N.xm_frame_stats) == 4 * 8 + 2 * 8 + 4 * 4
+    assert N.xm_config.p03.offset == 56 and N.xm_config.cam_mapx_i16.offset == 72
+
+
+def test_no_cpu_fallback_in_product_package():
+    """The product package must never import the oracle."""
+    pkg = os.path.join(ROOT, "x_maps_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(pkg, fn)).read()
+            assert "xmaps_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, fn

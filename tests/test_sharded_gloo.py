@@ -1,0 +1,94 @@
+"""CPU, world_size 2, gloo: the sharding protocol (index partition, (tmin,-tmax) MIN-reduce, packed-key MAX
+all-reduce, finish) reproduces the single-process frame exactly.  Compute provider = the oracle (tests only)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleShardProvider:
+    """CPU stand-in for GpuShardProvider, built on oracle/xmaps_oracle.py (checker only)."""
+
+    def __init__(self, tables, camera):
+        import xmaps_oracle as O
+        self.O, self.tb, self.camera = O, tables, camera
+        self.shape = (tables["cam_h"], tables["cam_w"]) if camera else (tables["rect_h"], tables["rect_w"])
+
+    def new_key_frame(self):
+        return torch.zeros(self.shape, dtype=torch.int64)
+
+    def clear_key_frame(self, kf):
+        kf.zero_()
+
+    def minmax(self, shard):
+        t = shard[2]
+        if len(t) == 0:
+            i = np.iinfo(np.int64)
+            return np.int64(i.max), np.int64(i.min)
+        return t.min(), t.max()
+
+    def scatter(self, shard, idx_offset, mm, tag, key_frame):
+        x, y, t, _ = shard
+        if len(t) == 0:
+            return
+        kf = self.O.key_frame(self.tb, x.astype(np.int64), y.astype(np.int64), t, mm[0], mm[1], idx_offset=idx_offset,
+                              tag=tag, camera_perspective=self.camera)
+        torch.maximum(key_frame, torch.from_numpy(kf.astype(np.int64)), out=key_frame)
+
+    def finish(self, key_frame, tag, want_bgr=True):
+        O = self.O
+        d = O.decode_key_frame(key_frame.numpy().astype(np.uint64), tag)
+        if not self.camera:
+            d = O.remap_rectified_disp_map_to_proj(d, self.tb["disp_proj_mapxy_i16"])
+        depth = O.disparity_to_depth_rectified(d, self.tb["p03"])
+        bgr = O.generate_color_map(O.clip_normalize_uint8_depth_frame(depth, self.tb["z_near"], self.tb["z_far"]))
+        return depth, bgr
+
+    def as_tensor(self, a):
+        return a
+
+
+def _worker(rank, world, port, camera, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from x_maps_amd import synthetic as S
+    from x_maps_amd.sharded import ShardedFrameProcessor, shard_bounds
+    tb = S.make_tables(S.C_TINY)
+    proc = ShardedFrameProcessor(OracleShardProvider(tb, camera), dist)
+    for frame, n in ((0, 4000), (1, 2501), (2, 1)):  # incl. an odd split and a frame with an EMPTY shard
+        evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(frame == 1))
+        x, y, t, _ = S.to_soa(evs)
+        a, b = shard_bounds(n, rank, world)
+        depth, bgr = proc.process_shard((x[a:b], y[a:b], t[a:b], None), a)
+        np.savez(os.path.join(out_dir, f"r{rank}_f{frame}.npz"), depth=depth, bgr=bgr)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("camera", [False, True])
+def test_two_rank_shards_equal_single_process(tmp_path, camera):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, camera, str(tmp_path)), nprocs=2, join=True)
+    import xmaps_oracle as O
+    from x_maps_amd import synthetic as S
+    tb = S.make_tables(S.C_TINY)
+    for frame, n in ((0, 4000), (1, 2501), (2, 1)):
+        evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(frame == 1))
+        x, y, t, _ = S.to_soa(evs)
+        ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
+        for r in range(2):
+            got = np.load(os.path.join(str(tmp_path), f"r{r}_f{frame}.npz"))
+            assert np.array_equal(got["depth"], ref["depth"]), (frame, r)
+            assert np.array_equal(got["bgr"], ref["bgr"]), (frame, r)

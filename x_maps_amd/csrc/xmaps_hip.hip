@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <algorithm>
 #include <new>
 #include <type_traits>
@@ -395,7 +396,12 @@ void host_minmax_out(const SlotState& hs, void* out) {
     b = hs.mm[0][i][1] > b ? hs.mm[0][i][1] : b;
   }
   T* o = (T*)out;
-  o[0] = TimeCodec<T>::dec(a);  // empty shard: dec(~0) = +max sentinel, dec(0) = -max sentinel
+  if (a == MM_INIT_MIN && b == MM_INIT_MAX) {  // empty shard: neutral elements of min / max
+    o[0] = std::numeric_limits<T>::has_infinity ? std::numeric_limits<T>::infinity() : std::numeric_limits<T>::max();
+    o[1] = std::numeric_limits<T>::has_infinity ? -std::numeric_limits<T>::infinity() : std::numeric_limits<T>::lowest();
+    return;
+  }
+  o[0] = TimeCodec<T>::dec(a);
   o[1] = TimeCodec<T>::dec(b);
 }
 

@@ -1,0 +1,119 @@
+"""DepthReprojectionPipe with the reference's interface (python/depth_reprojection_pipe.py:37-175) and the
+hot path on the GPU.
+
+    pipe = DepthReprojectionPipe(params, stats_printer, frame_callback)
+    pipe.process_events(evs)        # packets from the camera / file reader
+    pipe.process_ev_frame(evs)      # one projector frame of EventCD records -> frame_callback(BGR u8)
+
+`process_ev_frame` is the function the trigger finder calls (trigger_finder.py:172).  In the reference it
+runs six NumPy/Numba/OpenCV stages; here it is one C-ABI call (xm_process_frame_aos) = three HIP kernels,
+and the frame handed to `frame_callback` is a fresh (H, W, 3) uint8 BGR array exactly as before.
+Out of scope in this build: Metavision's ActivityNoiseFilterAlgorithm (closed source), the
+timing watchdog, the optional per-frame de-duplication filters (default NoFilter is what runs).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+
+from .cam_proj_calibration import CamProjMaps, load_tables_npz
+from .disp_to_depth import DisparityToDepth
+from .stats import StatsPrinter
+from .trigger_finder import RobustTriggerFinder
+from .x_maps_disparity import XMapsDisparity
+
+
+@dataclass
+class DepthReprojectionPipe:
+    params: "RuntimeParams"
+    stats_printer: StatsPrinter
+    frame_callback: Callable
+
+    calib_maps: CamProjMaps = field(init=False)
+    x_maps_disp: XMapsDisparity = field(init=False)
+    disp_to_depth: DisparityToDepth = field(init=False)
+    trigger_finder: RobustTriggerFinder = field(init=False)
+    activity_filter: Optional[Callable[[np.ndarray], np.ndarray]] = None  # plug a Metavision filter in here
+    fused: bool = True  # False = run the reference's six stages one by one (each still a HIP kernel)
+
+    def __post_init__(self):
+        p = self.params
+        tables = getattr(p, "tables", None)
+        if tables is None:
+            if isinstance(p.calib, str) and p.calib.endswith(".npz"):
+                tables = load_tables_npz(p.calib)
+            else:
+                raise NotImplementedError(
+                    "building the rectification tables from a calibration YAML needs OpenCV's stereoRectify "
+                    "(python/cam_proj_calibration.py:194-270), which is outside this build's scope: export the "
+                    "tables once from a reference installation (INTEGRATION.md) and pass the .npz as `calib`, "
+                    "or set RuntimeParams.tables")
+        tables = dict(tables)
+        tables.setdefault("z_near", p.z_near)
+        tables.setdefault("z_far", p.z_far)
+        tables["z_near"], tables["z_far"] = p.z_near, p.z_far
+        cam_h, cam_w = np.asarray(tables["cam_mapx_i16"]).shape
+        if (cam_w, cam_h) != (p.camera_width, p.camera_height):
+            raise ValueError(f"tables are for a {cam_w}x{cam_h} camera, params say {p.camera_width}x{p.camera_height}")
+        self.calib_maps = CamProjMaps(tables, camera_perspective=p.camera_perspective,
+                                      device=getattr(p, "device", 0))
+        self.x_maps_disp = XMapsDisparity(self.calib_maps)
+        self.disp_to_depth = DisparityToDepth(stats=self.stats_printer, calib_maps=self.calib_maps,
+                                              z_near=p.z_near, z_far=p.z_far)
+        self.trigger_finder = RobustTriggerFinder(projector_fps=p.projector_fps, stats=self.stats_printer,
+                                                  frame_callback=self.process_ev_frame)
+
+    # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------
+    def process_events(self, evs):
+        pos = evs[evs["p"] == 1]  # PolarityFilterAlgorithm(1), pipe:43,114
+        if self.activity_filter is not None:
+            pos = self.activity_filter(pos)
+        self.trigger_finder.process_events(pos)
+
+    # ---- one frame of events -> BGR frame (the hot path) ------------------------------------------------
+    def process_ev_frame(self, evs):
+        if len(evs) == 0:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")  # xmd:12
+        if not self.fused:
+            return self._process_ev_frame_staged(evs)
+        with self.stats_printer.measure_time("x-maps frame (fused)"):
+            _, bgr, st = self.calib_maps.engine.process_events(evs, use_polarity=False, want_depth=False)
+        self.stats_printer.add_metric("frame evs filtered out [%]", 0.0)
+        self.last_stats = st
+        self.frame_callback(bgr)
+
+    def depth_frame(self, evs):
+        """Same frame as process_ev_frame but returning the f32 depth map (A5 output) instead of calling back."""
+        depth, _, st = self.calib_maps.engine.process_events(evs, want_bgr=False)
+        self.last_stats = st
+        return depth
+
+    def _process_ev_frame_staged(self, evs):
+        sp = self.stats_printer
+        with sp.measure_time("ev rect"):
+            xr, yr = self.calib_maps.rectify_cam_coords_i16(evs)
+        with sp.measure_time("x-maps disp"):
+            disp, mask = self.x_maps_disp.compute_event_disparity(events=evs, ev_x_rect_i16=xr, ev_y_rect_i16=yr)
+        with sp.measure_time("disp map"):
+            if self.params.camera_perspective:
+                disp_map = self.calib_maps.compute_disp_map_camera_view(events=evs, inlier_mask=mask,
+                                                                        ev_disparity_f32=disp)
+            else:
+                disp_map = self.calib_maps.compute_disp_map_projector_view(
+                    ev_x_rect_i16=xr, ev_y_rect_i16=yr, inlier_mask=mask, ev_disparity_f32=disp)
+        if not self.params.camera_perspective:
+            disp_map = self.disp_to_depth.remap_rectified_disp_map_to_proj(disp_map)
+        with sp.measure_time("disp2rgb"):
+            depth_map = self.disp_to_depth.colorize_depth_from_disp(disp_map)
+        self.frame_callback(depth_map)
+
+    def select_next_frame_event_filter(self):
+        self.stats_printer.log("Selected event filter: NoFilter (the only one in this build)")
+
+    def reset(self):
+        self.trigger_finder.reset()
+
+    def close(self):
+        self.calib_maps.engine.close()

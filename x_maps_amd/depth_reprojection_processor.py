@@ -1,0 +1,117 @@
+"""RuntimeParams / DepthReprojectionProcessor with the reference's interface
+(python/depth_reprojection_processor.py:13-36, 50-114):
+
+    with DepthReprojectionProcessor(params) as proc:
+        for evs in event_packets:
+            proc.process_events(evs)
+            if proc.should_close(): break
+
+The window is pluggable; without Metavision's MTWindow the reference's own FakeWindow behaviour is used
+(processor.py:39-47).  Frames reach `window.show_async(bgr)` exactly as in the reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+from .depth_reprojection_pipe import DepthReprojectionPipe
+from .stats import StatsPrinter
+
+
+@dataclass
+class RuntimeParams:
+    camera_width: int
+    camera_height: int
+
+    projector_width: int
+    projector_height: int
+
+    projector_fps: int
+
+    z_near: float
+    z_far: float
+
+    calib: Any  # path of the exported tables (.npz); the reference takes the calibration YAML here
+
+    projector_time_map: Optional[str] = None
+
+    no_frame_dropping: bool = True
+
+    camera_perspective: bool = False
+
+    # additions of this build (defaults keep the reference's positional signature valid)
+    tables: Optional[dict] = None  # pre-built tables instead of `calib`
+    device: int = 0
+
+    @property
+    def should_drop_frames(self):
+        return not self.no_frame_dropping
+
+
+class FakeWindow:
+    """Headless window: keeps the last frame so callers/tests can look at it."""
+
+    def __init__(self):
+        self.last_frame = None
+        self.frames_shown = 0
+        self._close = False
+
+    def should_close(self):
+        return self._close
+
+    def set_close_flag(self):
+        self._close = True
+
+    def show_async(self, img):
+        self.last_frame = img
+        self.frames_shown += 1
+
+    def set_keyboard_callback(self, cb):
+        pass
+
+
+@dataclass
+class DepthReprojectionProcessor:
+    params: RuntimeParams
+    stats_printer: StatsPrinter = field(default_factory=StatsPrinter)
+    window: Any = None  # anything with should_close() / show_async(img); default FakeWindow
+
+    _pipe: DepthReprojectionPipe = field(init=False, default=None)
+    _window: Any = field(init=False, default=None)
+
+    def should_close(self):
+        return self._window.should_close()
+
+    def show_async(self, depth_map):
+        self._window.show_async(depth_map)
+        self.stats_printer.count("frames shown")
+
+    def __enter__(self):
+        self._pipe = DepthReprojectionPipe(params=self.params, stats_printer=self.stats_printer,
+                                           frame_callback=self.show_async)
+        self._window = self.window if self.window is not None else FakeWindow()
+        if hasattr(self._window, "set_keyboard_callback"):
+            self._window.set_keyboard_callback(self.keyboard_cb)
+        return self
+
+    def __exit__(self, *exc_info):
+        self.stats_printer.print_stats()
+        self._pipe.close()
+        return False
+
+    def keyboard_cb(self, key, scancode=None, action=None, mods=None):
+        if key in ("q", "Q", "esc"):
+            self._window.set_close_flag()
+        elif key in ("e", "E"):
+            self._pipe.select_next_frame_event_filter()
+        elif key in ("s", "S"):
+            self.stats_printer.toggle_silence()
+
+    def process_events(self, evs):
+        self.stats_printer.print_stats_if_needed()
+        self.stats_printer.count("processed evs", len(evs))
+        self._pipe.process_events(evs)
+        self.stats_printer.print_stats_if_needed()
+
+    def reset(self):
+        self._pipe.reset()

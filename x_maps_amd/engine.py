@@ -154,11 +154,14 @@ class XMapsEngine:
     def process_events(self, evs: np.ndarray, use_polarity=False, want_depth=True, want_bgr=True,
                        raise_on_index_error=True):
         """Metavision EventCD structured array (16-byte AoS records) -> (depth, bgr, FrameStats)."""
-        if evs.dtype.itemsize != 16 or evs.dtype.fields is None:
-            raise TypeError("expected a structured EventCD array with 16-byte records")
         f = evs.dtype.fields
-        if (f["x"][1], f["y"][1], f["p"][1], f["t"][1]) != (0, 2, 4, 8):
-            raise TypeError("unexpected EventCD field offsets")
+        if f is None or not {"x", "y", "p", "t"} <= set(f):
+            raise TypeError("expected a structured EventCD array with fields x, y, p, t")
+        if evs.dtype.itemsize != 16 or (f["x"][1], f["y"][1], f["p"][1], f["t"][1]) != (0, 2, 4, 8) or \
+                (f["x"][0], f["y"][0], f["p"][0], f["t"][0]) != (np.uint16, np.uint16, np.int16, np.int64):
+            # e.g. np.concatenate of EventCD buffers under NumPy 2 returns the PACKED 14-byte layout
+            from .synthetic import EVENT_CD_DTYPE
+            evs = evs.astype(EVENT_CD_DTYPE)
         evs = np.ascontiguousarray(evs)
         depth = np.empty((self.out_h, self.out_w), np.float32) if want_depth else None
         bgr = np.empty((self.out_h, self.out_w, 3), np.uint8) if want_bgr else None

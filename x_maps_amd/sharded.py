@@ -1,0 +1,132 @@
+"""One frame's event buffer sharded by index over the GPUs of a node.
+
+    rank g owns events [g*N/W, (g+1)*N/W); tables are replicated; every rank scatters its shard into a
+    private full-size packed-key frame; ONE all-reduce (MAX on int64) of that frame over RCCL/xGMI merges
+    the shards; the frame kernel (dilate o remap -> depth -> BGR) then runs on the reduced keys.
+
+Why MAX of packed keys and not "min of the depth frame": the reference's collision rule is NumPy's
+last-writer-wins (python/cam_proj_calibration.py:299-303).  key = tag<<44 | GLOBAL event index<<16 | disp,
+so the element-wise maximum over shards is exactly the event with the largest global index -- bit-exact
+with the single-GPU frame, which min-of-depth (nearest-surface-wins) is not.  Bit 63 of a key is always 0,
+so a signed int64 MAX (what torch/RCCL offer) orders keys like the unsigned compare on the device.
+
+The only other coupling is (tmin, tmax) of the whole frame (python/x_maps_disparity.py:12-13): a 16-byte
+MIN all-reduce of (tmin, -tmax).
+
+The collective is torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  Compute is
+behind a small provider protocol so that the sharding logic itself is testable without a GPU:
+  provider.minmax(shard)                  -> (tmin, tmax) of the shard's t (dtype-typed NumPy scalars)
+  provider.scatter(shard, idx_offset, (tmin, tmax), tag, key_frame)   (in place)
+  provider.finish(key_frame, tag)         -> (depth, bgr)
+`GpuShardProvider` is the product implementation (C-ABI xm_shard_* on device tensors).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+KEY_MAX_TAG = (1 << 19) - 1
+
+
+def shard_bounds(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Index range of rank's shard: [rank*N/W, (rank+1)*N/W) with integer arithmetic."""
+    return (rank * n_total) // world, ((rank + 1) * n_total) // world
+
+
+class GpuShardProvider:
+    """Shard compute on one MI355X through the C-ABI.  Event columns are torch CUDA tensors."""
+
+    def __init__(self, engine, device):
+        import torch
+        self.torch = torch
+        self.eng = engine
+        self.device = device
+        self.stream = torch.cuda.ExternalStream(engine.stream(0), device=device)
+
+    def new_key_frame(self):
+        kf = self.torch.zeros(self.eng.key_shape, dtype=self.torch.int64, device=self.device)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return kf
+
+    def clear_key_frame(self, kf):
+        self.eng.shard_clear(kf.data_ptr())
+
+    def minmax(self, shard):
+        x, y, t, p = shard
+        return self.eng.shard_minmax(t.data_ptr() if len(t) else None, None if p is None else p.data_ptr(), len(t))
+
+    def scatter(self, shard, idx_offset, frame_minmax, tag, key_frame):
+        x, y, t, p = shard
+        if len(t):
+            self.eng.shard_scatter(x.data_ptr(), y.data_ptr(), t.data_ptr(), None if p is None else p.data_ptr(),
+                                   len(t), idx_offset, frame_minmax, tag, key_frame.data_ptr())
+
+    def finish(self, key_frame, tag, want_bgr=True):
+        torch = self.torch
+        depth = torch.empty((self.eng.out_h, self.eng.out_w), dtype=torch.float32, device=self.device)
+        bgr = torch.empty((self.eng.out_h, self.eng.out_w, 3), dtype=torch.uint8, device=self.device) if want_bgr else None
+        self.eng.shard_finish(key_frame.data_ptr(), tag, depth.data_ptr(), None if bgr is None else bgr.data_ptr())
+        return depth, bgr
+
+    def as_tensor(self, a):
+        return a
+
+    def collective_stream(self):
+        return self.torch.cuda.stream(self.stream)  # collectives are ordered on the engine's own stream
+
+
+class ShardedFrameProcessor:
+    """Drives one rank of the sharded frame.  `dist` = torch.distributed (already initialised)."""
+
+    def __init__(self, provider, dist, group=None):
+        self.p = provider
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.key_frame = provider.new_key_frame()
+        self.tag = 0
+
+    def _next_tag(self):
+        if self.tag >= KEY_MAX_TAG:
+            self.p.clear_key_frame(self.key_frame)
+            self.tag = 0
+        self.tag += 1
+        return self.tag
+
+    def process_shard(self, shard, idx_offset: int, want_bgr=True, finish_on_all_ranks=True):
+        """shard = (x, y, t, p|None) of THIS rank's events; idx_offset = global index of its first event.
+        Returns (depth, bgr) of the whole frame (on every rank, or only rank 0)."""
+        import contextlib
+        torch_like = self.dist
+        tag = self._next_tag()
+        ctx = self.p.collective_stream() if hasattr(self.p, "collective_stream") else contextlib.nullcontext()
+        with ctx:
+            # 1. frame extrema: MIN-reduce (tmin, -tmax)
+            tmin, tmax = self.p.minmax(shard)
+            mm = self._reduce_minmax(tmin, tmax)
+            # 2. private scatter, 3. merge
+            self.p.scatter(shard, idx_offset, mm, tag, self.key_frame)
+            if self.world > 1:
+                torch_like.all_reduce(self.p.as_tensor(self.key_frame), op=torch_like.ReduceOp.MAX, group=self.group)
+            # 4. frame kernel on the merged keys
+            if finish_on_all_ranks or self.rank == 0:
+                return self.p.finish(self.key_frame, tag, want_bgr)
+        return None, None
+
+    def _reduce_minmax(self, tmin, tmax):
+        import torch
+        dt = np.asarray(tmin).dtype
+        if np.issubdtype(dt, np.integer):
+            info = np.iinfo(dt)
+            neg = info.max if tmax == info.min else -int(tmax)
+            v = torch.tensor([int(tmin), neg], dtype=torch.int64)
+        else:
+            v = torch.tensor([float(tmin), -float(tmax)], dtype=torch.float64)
+        if self.world > 1:
+            dev = getattr(self.p, "device", None)
+            if dev is not None:
+                v = v.to(dev)
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN, group=self.group)
+            v = v.cpu()
+        lo, hi = v[0].item(), -v[1].item()
+        return np.array([lo, hi], dtype=dt)
