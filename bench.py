@@ -220,8 +220,23 @@ def main():
                 spent += dt
                 reps += 1
             cpu = {"value": round(n_ev / (spent / reps) / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
-                   "sample": f"{reps} x the C-1M frame 0 (1 M events -> depth+BGR), mean; best {n_ev / best / 1e6:.2f} Mev/s",
+                   "sample": f"{reps} x the C-1M frame 0 (1 M events -> depth+BGR), mean; best {n_ev / best / 1e6:.2f} Mev/s; "
+                             "NumPy port with the reference's pass structure (its per-event path is 1-threaded NumPy)",
                    "host_cpus": os.cpu_count()}
+            try:  # upper bound for the reference: fused C loops on every host core (what Numba prange could reach)
+                from c_oracle import COracle
+                co = COracle(tables, args.camera_perspective, omp=True)
+                co.process_ev_frame(x, y, t, want_events=False)
+                c0 = time.perf_counter()
+                creps = 0
+                while time.perf_counter() - c0 < min(3.0, args.cpu_seconds) and creps < 200:
+                    co.process_ev_frame(x, y, t, want_events=False)
+                    creps += 1
+                cdt = (time.perf_counter() - c0) / creps
+                cpu["all_cores_c_openmp"] = {"value": round(n_ev / cdt / 1e6, 2), "unit": "Mevents/s",
+                                             "cores": co.threads, "kind": "port", "sample": f"{creps} x frame 0"}
+            except Exception as e:  # the checker is optional for the bench
+                cpu["all_cores_c_openmp"] = {"error": str(e)[:200]}
 
         host_path = None
         if args.host_path:
