@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true", help="also time the PCIe-inclusive host->host call")
+    ap.add_argument("--no-parity", action="store_true", help="EXPERIMENTS ONLY (ablation builds): skip the parity gate")
     return ap.parse_args()
 
 
@@ -117,7 +118,9 @@ def main():
         st = eng.last_frame_stats()
         parity["n_inliers_equal"] = bool(st.n_inliers == int(ref["mask"].sum()))
         ok = rel <= 1e-4 and parity["empty_mask_equal"] and parity["n_inliers_equal"] and parity.get("bgr_equal", True)
-        if not ok:
+        if not ok and args.no_parity:
+            parity["IGNORED"] = True
+        elif not ok:
             print(json.dumps({"error": "parity check failed", "parity": parity}))
             sys.exit(1)
 

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <algorithm>
@@ -100,6 +101,10 @@ struct xm_handle {
   size_t stage_cells = 0;
   hipEvent_t prof_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr;
+  // K1 tiling: LDS windows (time columns / camera columns) and the dynamic LDS they need; 0 = direct kernel
+  int w_ts = 0, w_x = 0;
+  size_t k1_lds = 0;
+  bool k1_direct = false, k2_direct = false;
   std::vector<hipEvent_t> join_ev;
 };
 
@@ -136,7 +141,7 @@ void launch_minmax_t(const EventsView& ev, SlotState* st, u32 tag_override, hipS
   const bool vec2 = !AOS && sizeof(T) == 8 && std::is_same<T, long long>::value && aligned(ev.t, 16) &&
                     (!HAS_P || aligned(ev.p, 4));
   // ~2048 events per thread-block iteration keeps every CU busy without drowning the 32 atomic slots
-  const unsigned per_block = BLOCK * (vec2 ? 2 : 1) * 4;
+  const unsigned per_block = BLOCK * (vec2 ? 8 : 4);  // VEC2: 4 loads x 2 events per thread per sweep
   unsigned grid = grid_for(n, per_block);
   if (grid > 1024) grid = 1024;
   if constexpr (std::is_same<T, long long>::value && !AOS) {
@@ -172,56 +177,78 @@ void launch_minmax(const EventsView& ev, SlotState* st, u32 tag_override, hipStr
   }
 }
 
+struct ScatterArgs {
+  const EventsView* ev;
+  const DevTables* tb;
+  int view;
+  SlotState* st;
+  u32 tag_override;
+  u64 idx_offset, mm_lo, mm_hi;
+  u64* frame;
+  hipStream_t stream;
+  int w_ts, w_x;
+  size_t lds;
+  bool direct;
+};
+
 template <typename T, bool AOS, bool HAS_P, int VIEW>
-void launch_scatter_tv(const EventsView& ev, const DevTables& tb, SlotState* st, u32 tag_override, u64 idx_offset,
-                       u64 mm_lo, u64 mm_hi, u64* frame, hipStream_t stream) {
+int launch_scatter_tv(const ScatterArgs& a) {
+  const EventsView& ev = *a.ev;
   const u64 n = ev.n;
-  if constexpr (AOS) {
-    hipLaunchKernelGGL((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream,
-                       nullptr, nullptr, (const T*)nullptr, nullptr, (const uint4*)ev.aos, n, idx_offset, tb, st,
-                       tag_override, mm_lo, mm_hi, frame);
-  } else {
-    const bool vec = aligned(ev.x, 8) && aligned(ev.y, 8) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 8));
-    if (vec) {
-      hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, stream,
-                         ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, idx_offset, tb, st, tag_override,
-                         mm_lo, mm_hi, frame);
-    } else {
-      hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, ev.x,
-                         ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, idx_offset, tb, st, tag_override, mm_lo,
-                         mm_hi, frame);
+  const bool vec = !AOS && aligned(ev.x, 8) && aligned(ev.y, 8) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 8));
+  if (!a.direct && a.w_ts > 0 && a.w_x > 0) {
+    auto kern = k_scatter_tiled<T, AOS, HAS_P, VIEW>;
+    static size_t lds_set = 0;  // per instantiation: raise the dynamic-LDS cap once (gfx950: 160 KB / CU)
+    if (a.lds > lds_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)a.lds));
+      lds_set = a.lds;
     }
+    hipLaunchKernelGGL(kern, dim3(grid_for(n, TILE_EVENTS)), dim3(TILE_THREADS), a.lds, a.stream, ev.x, ev.y,
+                       (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
+                       a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec ? 1 : 0);
+    return XM_OK;
   }
+  if constexpr (AOS) {
+    hipLaunchKernelGGL((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream,
+                       nullptr, nullptr, (const T*)nullptr, nullptr, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st,
+                       a.tag_override, a.mm_lo, a.mm_hi, a.frame);
+  } else if (vec) {
+    hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, a.stream,
+                       ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st,
+                       a.tag_override, a.mm_lo, a.mm_hi, a.frame);
+  } else {
+    hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream, ev.x,
+                       ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st, a.tag_override,
+                       a.mm_lo, a.mm_hi, a.frame);
+  }
+  return XM_OK;
 }
 
 template <typename T, bool AOS, bool HAS_P>
-void launch_scatter_t(const EventsView& ev, const DevTables& tb, int view, SlotState* st, u32 tag_override,
-                      u64 idx_offset, u64 mm_lo, u64 mm_hi, u64* frame, hipStream_t stream) {
-  if (view == XM_VIEW_PROJECTOR)
-    launch_scatter_tv<T, AOS, HAS_P, 0>(ev, tb, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream);
-  else
-    launch_scatter_tv<T, AOS, HAS_P, 1>(ev, tb, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream);
+int launch_scatter_t(const ScatterArgs& a) {
+  return a.view == XM_VIEW_PROJECTOR ? launch_scatter_tv<T, AOS, HAS_P, 0>(a) : launch_scatter_tv<T, AOS, HAS_P, 1>(a);
 }
 
-void launch_scatter(const EventsView& ev, const DevTables& tb, int view, SlotState* st, u32 tag_override,
-                    u64 idx_offset, u64 mm_lo, u64 mm_hi, u64* frame, hipStream_t stream) {
-#define XM_SC(T, AOS, HP) launch_scatter_t<T, AOS, HP>(ev, tb, view, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream)
-  if (ev.aos) {
-    ev.use_p ? XM_SC(long long, true, true) : XM_SC(long long, true, false);
-    return;
-  }
+int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_override, u64 idx_offset, u64 mm_lo,
+                   u64 mm_hi, u64* frame, hipStream_t stream) {
+  ScatterArgs a{&ev, &h->tb, h->cfg.view, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream,
+                h->w_ts, h->w_x, h->k1_lds, h->k1_direct};
+  if (ev.aos) return ev.use_p ? launch_scatter_t<long long, true, true>(a) : launch_scatter_t<long long, true, false>(a);
   switch (ev.t_dtype) {
-    case XM_T_INT64: ev.use_p ? XM_SC(long long, false, true) : XM_SC(long long, false, false); break;
-    case XM_T_FLOAT32: ev.use_p ? XM_SC(float, false, true) : XM_SC(float, false, false); break;
-    default: ev.use_p ? XM_SC(double, false, true) : XM_SC(double, false, false);
+    case XM_T_INT64: return ev.use_p ? launch_scatter_t<long long, false, true>(a) : launch_scatter_t<long long, false, false>(a);
+    case XM_T_FLOAT32: return ev.use_p ? launch_scatter_t<float, false, true>(a) : launch_scatter_t<float, false, false>(a);
+    default: return ev.use_p ? launch_scatter_t<double, false, true>(a) : launch_scatter_t<double, false, false>(a);
   }
-#undef XM_SC
 }
 
 void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 tag_override, float* depth,
                          uint8_t* bgr, hipStream_t stream) {
   KeyCells cells{key_frame, 0};
-  if (h->cfg.view == XM_VIEW_PROJECTOR) {
+  if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
+    hipLaunchKernelGGL(k_frame_proj_tiled, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+                       dim3(K2_TX * K2_TY), 0, stream, key_frame, h->tb, st, tag_override, depth, bgr);
+  } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
     const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
     hipLaunchKernelGGL((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
                        tag_override, depth, bgr);
@@ -256,7 +283,10 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
   if (prof) HIP_TRY(hipEventRecord(prof[0], s.stream));
   launch_minmax(ev, s.st, 0, s.stream);
   if (prof) HIP_TRY(hipEventRecord(prof[1], s.stream));
-  launch_scatter(ev, h->tb, h->cfg.view, s.st, 0, 0, 0, 0, s.key_frame, s.stream);
+  {
+    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.stream);
+    if (rc) return rc;
+  }
   if (prof) HIP_TRY(hipEventRecord(prof[2], s.stream));
   launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, s.stream);
   if (prof) HIP_TRY(hipEventRecord(prof[3], s.stream));
@@ -453,16 +483,28 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     }                                         \
   } while (0)
 
-  // re-pack the int16 tables: one 4-byte gather per event / pixel instead of two 2-byte ones
+  // re-pack the int16 tables: one 4-byte gather per event instead of two 2-byte ones, and the scan axis made the
+  // slow axis (column-major) so that a time slice of events touches a few contiguous runs (see DevTables)
   const size_t cam_px = (size_t)cfg->cam_width * cfg->cam_height;
-  std::vector<u32> lut(cam_px);
-  for (size_t i = 0; i < cam_px; ++i)
-    lut[i] = ((u32)(uint16_t)cfg->cam_mapy_i16[i] << 16) | (u32)(uint16_t)cfg->cam_mapx_i16[i];
-  XM_TRY_CREATE(hipMalloc((void**)&h->d_lut, cam_px * 4));
-  XM_TRY_CREATE(hipMemcpy(h->d_lut, lut.data(), cam_px * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<u32> lut(cam_px);
+    for (int y = 0; y < cfg->cam_height; ++y)
+      for (int x = 0; x < cfg->cam_width; ++x) {
+        const size_t i = (size_t)y * cfg->cam_width + x;
+        lut[(size_t)x * cfg->cam_height + y] =
+            ((u32)(uint16_t)cfg->cam_mapy_i16[i] << 16) | (u32)(uint16_t)cfg->cam_mapx_i16[i];
+      }
+    XM_TRY_CREATE(hipMalloc((void**)&h->d_lut, cam_px * 4 + 64));  // +slack: bands are read in aligned 16-B vectors
+    XM_TRY_CREATE(hipMemcpy(h->d_lut, lut.data(), cam_px * 4, hipMemcpyHostToDevice));
+  }
   const size_t xm_cells = (size_t)xmap_h * cfg->xmap_width;
-  XM_TRY_CREATE(hipMalloc((void**)&h->d_xmap, xm_cells * 2));
-  XM_TRY_CREATE(hipMemcpy(h->d_xmap, cfg->proj_x_map, xm_cells * 2, hipMemcpyHostToDevice));
+  {
+    std::vector<int16_t> xt(xm_cells);
+    for (int r = 0; r < xmap_h; ++r)
+      for (int c = 0; c < cfg->xmap_width; ++c) xt[(size_t)c * xmap_h + r] = cfg->proj_x_map[(size_t)r * cfg->xmap_width + c];
+    XM_TRY_CREATE(hipMalloc((void**)&h->d_xmap, xm_cells * 2 + 64));
+    XM_TRY_CREATE(hipMemcpy(h->d_xmap, xt.data(), xm_cells * 2, hipMemcpyHostToDevice));
+  }
   if (cfg->disp_proj_mapxy_i16 && cfg->proj_width > 0 && cfg->proj_height > 0) {
     const size_t ppx = (size_t)cfg->proj_width * cfg->proj_height;
     std::vector<u32> pm(ppx);
@@ -497,6 +539,43 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     h->out_h = cfg->cam_height;
   }
 
+  {  // K1 LDS windows: as wide as the 160 KB LDS of a gfx950 CU allows (one 1024-thread block per CU)
+    const char* e1 = getenv("XM_K1_DIRECT");
+    const char* e2 = getenv("XM_K2_DIRECT");
+    h->k1_direct = e1 && e1[0] == '1';
+    h->k2_direct = e2 && e2[0] == '1';
+    // <= 76 KB per block lets two 1024-thread blocks (e.g. of two frames in flight) share one CU's 160 KB
+    size_t budget = 76 * 1024;
+    if (const char* e = getenv("XM_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+    int w_ts = 6, w_x = 12;
+    if (const char* e = getenv("XM_W_TS")) w_ts = atoi(e);
+    if (const char* e = getenv("XM_W_X")) w_x = atoi(e);
+    auto need = [&](int wt, int wx) {
+      // must mirror the carve-up at the top of k_scatter_tiled (uint4 units, +1 uint4 of alignment slack per band)
+      const size_t win_words = cfg->view == XM_VIEW_PROJECTOR ? (size_t)wt * xmap_h : (size_t)wx * cfg->cam_height;
+      const size_t win_q = (win_words + 3) / 4, lut_q = ((size_t)wx * cfg->cam_height + 3) / 4 + 1,
+                   xm_q = ((size_t)wt * xmap_h + 7) / 8 + 1;
+      return 16 * (win_q + lut_q + xm_q + 1);  // +1: dummy slot for the branch-free band loads
+    };
+    while (need(w_ts, w_x) > budget && (w_ts > 1 || w_x > 1)) {
+      if (w_ts * xmap_h * 6 >= w_x * cfg->cam_height * 4 && w_ts > 1) w_ts -= 1;
+      else if (w_x > 1) w_x /= 2;
+      else w_ts -= 1;
+    }
+    if (need(w_ts, w_x) <= budget && w_ts >= 1 && w_x >= 1) {
+      h->w_ts = w_ts;
+      h->w_x = w_x;
+      h->k1_lds = need(w_ts, w_x);
+    } else {
+      h->k1_direct = true;  // tables too tall for LDS: every event takes the direct path
+    }
+  }
+#ifdef XM_ABLATE
+  if (const char* e = getenv("XM_ABLATE")) {
+    int v = atoi(e);
+    XM_TRY_CREATE(hipMemcpyToSymbol(HIP_SYMBOL(xm::g_ablate), &v, sizeof v));
+  }
+#endif
   XM_TRY_CREATE(hipMalloc((void**)&h->d_states, sizeof(SlotState) * (n_slots + 1)));
   h->aux_st = h->d_states + n_slots;
   h->slots.resize(n_slots);
@@ -952,7 +1031,7 @@ int xm_shard_scatter(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
                        hi = TimeCodec<double>::enc(((const double*)frame_minmax_host)[1]); break;
     default: return fail(XM_ERR_INVALID, "unknown t_dtype");
   }
-  launch_scatter(ev, h->tb, h->cfg.view, h->aux_st, tag, idx_offset, lo, hi, (u64*)key_frame, h->slots[0].stream);
+  if ((rc = launch_scatter(h, ev, h->aux_st, tag, idx_offset, lo, hi, (u64*)key_frame, h->slots[0].stream))) return rc;
   HIP_TRY(hipGetLastError());
   return XM_OK;
 }

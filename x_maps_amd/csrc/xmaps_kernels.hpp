@@ -38,10 +38,14 @@ constexpr int BLOCK = 256;
 
 enum { CNT_USED = 0, CNT_INLIER = 1, CNT_OOB = 2, CNT_STRIDE = 4 };
 
+// HBM layouts (built once in xm_create).  The scan axis is the SLOW axis of every table an event touches:
+// events arrive time-sorted and the projector scans x-slow, so the events of one thread block sit in a band of
+// a few camera columns / a few X-map time columns / a few frame columns.  Column-major tables make that band a
+// handful of contiguous runs -> coalesced tile loads into LDS and coalesced flushes out of it.
 struct DevTables {
-  const u32* lut;       // [cam_h][cam_w]  (u16(yr) << 16) | u16(xr)
-  const int16_t* xmap;  // [xmap_h][xmap_w]
-  const u32* pmap;      // [proj_h][proj_w] (u16(my) << 16) | u16(mx)
+  const u32* lut;       // [cam_w][cam_h]   TRANSPOSED  (u16(yr) << 16) | u16(xr)
+  const int16_t* xmap;  // [xmap_w][xmap_h] TRANSPOSED  X-map, time column major
+  const u32* pmap;      // [proj_h][proj_w] row-major   (u16(my) << 16) | u16(mx)
   int cam_w, cam_h, proj_w, proj_h, rect_w, rect_h, xmap_w, xmap_h;
   int x_offset, t_px_scale;
   double p03;
@@ -184,25 +188,40 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
     const u64 n2 = n >> 1;
     const longlong2* t2 = reinterpret_cast<const longlong2*>(t);
     const u32* p2 = reinterpret_cast<const u32*>(p);
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) {
-      longlong2 v = t2[i];
-      bool ok0 = true, ok1 = true;
-      if constexpr (HAS_P) {
-        u32 pp = p2[i];
-        ok0 = (short)(pp & 0xffff) == 1;
-        ok1 = (short)(pp >> 16) == 1;
+    // 4 independent 16-byte loads per thread per sweep: latency-bound otherwise (8 MB must be in flight at once)
+    for (u64 i0 = (u64)blockIdx.x * BLOCK + threadIdx.x; i0 < n2; i0 += 4 * stride) {
+      longlong2 v[4];
+      u32 pp[4];
+      bool in[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u64 i = i0 + (u64)j * stride;
+        in[j] = i < n2;
+        if (in[j]) {
+          v[j] = t2[i];
+          if constexpr (HAS_P) pp[j] = p2[i];
+        }
       }
-      if (ok0) {
-        u64 e = TimeCodec<T>::enc((T)v.x);
-        lo = e < lo ? e : lo;
-        hi = e > hi ? e : hi;
-        ++used;
-      }
-      if (ok1) {
-        u64 e = TimeCodec<T>::enc((T)v.y);
-        lo = e < lo ? e : lo;
-        hi = e > hi ? e : hi;
-        ++used;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!in[j]) continue;
+        bool ok0 = true, ok1 = true;
+        if constexpr (HAS_P) {
+          ok0 = (short)(pp[j] & 0xffff) == 1;
+          ok1 = (short)(pp[j] >> 16) == 1;
+        }
+        if (ok0) {
+          u64 e = TimeCodec<T>::enc((T)v[j].x);
+          lo = e < lo ? e : lo;
+          hi = e > hi ? e : hi;
+          ++used;
+        }
+        if (ok1) {
+          u64 e = TimeCodec<T>::enc((T)v[j].y);
+          lo = e < lo ? e : lo;
+          hi = e > hi ? e : hi;
+          ++used;
+        }
       }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -276,7 +295,7 @@ __device__ inline EventResult event_disparity(const DevTables& tb, const TimeNor
     oob = true;
     return r;
   }
-  const u32 l = tb.lut[y * (u32)tb.cam_w + x];
+  const u32 l = tb.lut[x * (u32)tb.cam_h + y];
   r.xr = (int)(short)(l & 0xffff);
   r.yr = (int)(short)(l >> 16);
   r.ts = tn.column(t);
@@ -286,7 +305,7 @@ __device__ inline EventResult event_disparity(const DevTables& tb, const TimeNor
     oob = true;
     return r;
   }
-  const int xp = (int)tb.xmap[r.yr * tb.xmap_w + r.ts];                // xmd:25
+  const int xp = (int)tb.xmap[r.ts * tb.xmap_h + r.yr];                // xmd:25
   r.disp = (int)(short)(xp - r.xr - tb.x_offset);                      // int16 wrap-around (xmd:27)
   r.inlier = r.disp >= 0;                                              // xmd:29
   return r;
@@ -299,9 +318,9 @@ __device__ inline bool event_cell(const DevTables& tb, const EventResult& r, u32
     int col = (int)(short)(r.xr + r.disp);  // calib:300: int16 add (= xp - x_offset), rint is a no-op
     if (col < 0) col += tb.rect_w;          // NumPy negative index wraps once
     if (col < 0 || col >= tb.rect_w || r.yr >= tb.rect_h) return false;
-    cell = (u32)r.yr * (u32)tb.rect_w + (u32)col;
+    cell = (u32)col * (u32)tb.rect_h + (u32)r.yr;  // projector-view key frame is column-major [col][row]
   } else {
-    cell = y * (u32)tb.cam_w + x;  // bounds already checked by the LUT gather
+    cell = y * (u32)tb.cam_w + x;  // camera-view key frame is row-major; bounds checked by the LUT gather
   }
   return true;
 }
@@ -429,6 +448,307 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
   }
 }
 
+
+// =====================================================================================================
+// K1 (tiled): the same per-event work, restructured around what the chip charges for.
+//
+// Measured on MI355X (profiles/r01_ubench_atomics.md): a lane-divergent atomic costs ~39 ps of chip time per
+// lane whatever its width/scope, a divergent load ~13 ps, but the same operations coalesced cost 6-10x less:
+// the price is per (lane -> distinct cache line) request.  The direct kernel issues 3 such requests per event
+// (LUT gather, X-map gather, atomic).  Here one block owns TILE_EVENTS consecutive events = one thin time slice:
+//   * its LUT band  (w_x camera columns around the slice's mean x)   -> LDS, coalesced (column-major table)
+//   * its X-map band (w_ts time columns around the slice's mean column) -> LDS, coalesced
+//   * last-writer-wins is resolved in LDS first: one u32 slot per (time column, rectified row) -- events of
+//     the same slot hit the same frame cell because cell = (yr, X[yr, ts]) -- holding max((local idx+1)<<16 | disp)
+//   * winners are flushed with lanes walking consecutive rows of one time column; the key frame is
+//     column-major, so a wave's atomics fall into a few cache lines instead of 64.
+// Events outside the windows (unsorted / raster-ordered input, noise) take the direct global path inside
+// the same kernel: always correct, only slower.  Camera view: slot = (row, x - x_lo), frame row-major.
+// =====================================================================================================
+#ifdef XM_ABLATE
+__device__ int g_ablate = 0;  // bit0: no flush atomics, bit1: no LDS slot atomics, bit2: no band loads, bit3: no time divide
+#define XM_ABL(bit) (g_ablate & (1 << (bit)))
+#else
+#define XM_ABL(bit) 0
+#endif
+constexpr int TILE_THREADS = 1024;
+constexpr int TILE_EPT = 4;
+constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;
+
+template <typename T, bool AOS, bool HAS_P, int VIEW>
+__global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
+    const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
+    const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
+    u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, int w_ts, int w_x, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift)
+  const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
+  const int win_q = (win_words + 3) >> 2;                 // uint4 count
+  const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1;
+  u32* win = reinterpret_cast<u32*>(smem);
+  u32* lut_base = win + 4 * win_q;
+  int16_t* xm_base = reinterpret_cast<int16_t*>(lut_base + 4 * lut_q);
+  __shared__ u32 s_in, s_oob;
+
+  const int tid = threadIdx.x;
+  const u32 tag = tag_override ? tag_override : st->tag_a;
+  const u32 parity = tag & 1;
+  u64 lo, hi;
+  if (tag_override) {
+    lo = mm_lo;
+    hi = mm_hi;
+  } else {
+    load_frame_minmax(st, parity, lo, hi);
+    if (blockIdx.x == 0) {
+      if (tid == 0) st->tag_b = tag;
+      if (tid < MM_SLOTS) {
+        st->mm[parity ^ 1][tid][0] = MM_INIT_MIN;
+        st->mm[parity ^ 1][tid][1] = MM_INIT_MAX;
+      }
+    }
+  }
+  const TimeNorm<T> tn(TimeCodec<T>::dec(lo), TimeCodec<T>::dec(hi), tb.t_px_scale);
+  const u64 key_hi = (u64)tag << KEY_TAG_SHIFT;
+  if (tid == 0) {
+    s_in = 0;
+    s_oob = 0;
+  }
+  const u64 block_base = (u64)blockIdx.x * TILE_EVENTS;
+
+  // ---- 1. this thread's events: issued FIRST (they depend on nothing), consumed after the bands are on their way ------------------------------------------
+  u32 x[TILE_EPT], y[TILE_EPT], lidx[TILE_EPT];
+  int col[TILE_EPT];
+  T tt[TILE_EPT];
+  bool used[TILE_EPT];
+  const bool vec = !AOS && vec_ok && block_base + TILE_EVENTS <= n;
+  if (vec) {  // 4 consecutive events per thread: 8-byte loads of x / y / p, 2 x 16-byte loads of t
+    const u64 base = block_base + (u64)tid * 4;
+    const uint2 xv = *reinterpret_cast<const uint2*>(xs + base);
+    const uint2 yv = *reinterpret_cast<const uint2*>(ys + base);
+    x[0] = xv.x & 0xffff; x[1] = xv.x >> 16; x[2] = xv.y & 0xffff; x[3] = xv.y >> 16;
+    y[0] = yv.x & 0xffff; y[1] = yv.x >> 16; y[2] = yv.y & 0xffff; y[3] = yv.y >> 16;
+    T t[4];
+    if constexpr (sizeof(T) == 8) {
+      const longlong2 a = *reinterpret_cast<const longlong2*>(ts + base);
+      const longlong2 b = *reinterpret_cast<const longlong2*>(ts + base + 2);
+      __builtin_memcpy(&t[0], &a.x, 8); __builtin_memcpy(&t[1], &a.y, 8);
+      __builtin_memcpy(&t[2], &b.x, 8); __builtin_memcpy(&t[3], &b.y, 8);
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(ts + base);
+      __builtin_memcpy(&t[0], &a.x, 4); __builtin_memcpy(&t[1], &a.y, 4);
+      __builtin_memcpy(&t[2], &a.z, 4); __builtin_memcpy(&t[3], &a.w, 4);
+    }
+    used[0] = used[1] = used[2] = used[3] = true;
+    if constexpr (HAS_P) {
+      const uint2 pv = *reinterpret_cast<const uint2*>(ps + base);
+      used[0] = (short)(pv.x & 0xffff) == 1; used[1] = (short)(pv.x >> 16) == 1;
+      used[2] = (short)(pv.y & 0xffff) == 1; used[3] = (short)(pv.y >> 16) == 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lidx[k] = (u32)tid * 4 + k;
+      tt[k] = t[k];
+    }
+  } else {  // any alignment / ragged tail / AoS records: event k*1024 + tid, still coalesced across lanes
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      lidx[k] = (u32)k * TILE_THREADS + tid;
+      const u64 i = block_base + lidx[k];
+      used[k] = i < n;
+      col[k] = 0;
+      tt[k] = (T)0;
+      x[k] = y[k] = 0;
+      if (used[k]) {
+        T t;
+        if constexpr (AOS) {
+          const uint4 r = aos[i];
+          x[k] = r.x & 0xffff;
+          y[k] = r.x >> 16;
+          t = (T)(long long)(((u64)r.w << 32) | r.z);
+          if (HAS_P) used[k] = (short)(r.y & 0xffff) == 1;
+        } else {
+          x[k] = xs[i];
+          y[k] = ys[i];
+          t = ts[i];
+          if (HAS_P) used[k] = ps[i] == 1;
+        }
+        tt[k] = t;
+      }
+    }
+  }
+  // ---- 2. where is this time slice?  median of three sampled events (first / middle / last of the block): uniform
+  //         loads that do not wait for the block's own events, so the band loads below overlap the event loads.
+  //         A wrong guess (unsorted input, a noise event) only sends events down the direct path.
+  int x_lo, ts_lo;
+  {
+    const bool have = block_base < n;  // false only for the single block of an empty frame
+    const u64 last = have ? (block_base + TILE_EVENTS <= n ? block_base + TILE_EVENTS : n) - 1 : 0;
+    const u64 first = have ? block_base : 0;
+    const u64 si[3] = {first, first + ((last - first) >> 1), last};
+    int sx[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+    if (have) {  // block-uniform; the three loads are independent and issued back to back, divides afterwards
+      T tj[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if constexpr (AOS) {
+          const uint4 r = aos[si[j]];
+          sx[j] = (int)(r.x & 0xffff);
+          tj[j] = (T)(long long)(((u64)r.w << 32) | r.z);
+        } else {
+          sx[j] = (int)xs[si[j]];
+          tj[j] = ts[si[j]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sc[j] = tn.column(tj[j]);
+    }
+    const int mx = max(min(sx[0], sx[1]), min(max(sx[0], sx[1]), sx[2]));
+    const int mc = max(min(sc[0], sc[1]), min(max(sc[0], sc[1]), sc[2]));
+    x_lo = min(max(mx - w_x / 2, 0), max(tb.cam_w - w_x, 0));
+    ts_lo = min(max(mc - w_ts / 2, 0), max(tb.xmap_w - w_ts, 0));
+  }
+  // the bands are contiguous runs of the column-major tables: [x_lo, x_lo + w_x) x cam_h words and
+  // [ts_lo, ts_lo + w_ts) x xmap_h int16.  Load them with aligned 16-byte vectors, every load in flight at once;
+  // the LDS copies keep the global misalignment (a few elements of slack in front).
+  const int wx_eff = min(w_x, tb.cam_w), wts_eff = min(w_ts, tb.xmap_w);
+  const u32 lut_start = (u32)x_lo * (u32)tb.cam_h, lut_shift = lut_start & 3u;           // in words
+  const u32 xm_start = (u32)ts_lo * (u32)tb.xmap_h, xm_shift = xm_start & 7u;            // in int16
+  const u32* lut_t = lut_base + lut_shift;
+  const int16_t* xm_t = xm_base + xm_shift;
+  {
+    const uint4* g_lut = reinterpret_cast<const uint4*>(tb.lut + (lut_start - lut_shift));
+    const int nq_lut = (int)((lut_shift + (u32)wx_eff * (u32)tb.cam_h + 3u) >> 2);
+    const uint4* g_xm = reinterpret_cast<const uint4*>(tb.xmap + (xm_start - xm_shift));
+    const int nq_xm = (int)((xm_shift + (u32)wts_eff * (u32)tb.xmap_h + 7u) >> 3);
+    uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
+    uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
+    constexpr int UN = 4;
+    // Branch-free on purpose: loads use a clamped index and out-of-range lanes store into a dummy LDS slot.  Any
+    // predication here turns into one basic block per load with an s_waitcnt vmcnt(0) behind it (seen in the ISA),
+    // i.e. 8 serialized L2 round trips per block instead of one.
+    const int dummy = 0;  // l_dummy[0]
+    uint4* l_dummy = reinterpret_cast<uint4*>(xm_base) + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
+    if (!XM_ABL(2)) {
+      for (int i0 = tid; i0 < nq_lut; i0 += UN * TILE_THREADS) {
+        uint4 v[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) v[j] = g_lut[min(i0 + j * TILE_THREADS, nq_lut - 1)];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+          const int i = i0 + j * TILE_THREADS;
+          (i < nq_lut ? l_lut + i : l_dummy + dummy)[0] = v[j];
+        }
+      }
+      for (int i0 = tid; i0 < nq_xm; i0 += UN * TILE_THREADS) {
+        uint4 v[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) v[j] = g_xm[min(i0 + j * TILE_THREADS, nq_xm - 1)];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+          const int i = i0 + j * TILE_THREADS;
+          (i < nq_xm ? l_xm + i : l_dummy + dummy)[0] = v[j];
+        }
+      }
+    }
+    uint4* l_win = reinterpret_cast<uint4*>(win);
+    for (int i = tid; i < win_q; i += TILE_THREADS) l_win[i] = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- 3. time columns of this thread's events (FP64 divide, bit-exact with NumPy) -- overlaps the band loads
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) col[k] = used[k] ? (XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k])) : 0;
+  __syncthreads();  // bands + cleared slots visible
+
+  // ---- 4. per event: A1 + A2 out of LDS, resolve collisions in LDS ---------------------------------------------
+  u32 n_in = 0, n_oob = 0;
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) {
+    bool oob = false, write = false;
+    if (used[k]) {
+      if (x[k] >= (u32)tb.cam_w || y[k] >= (u32)tb.cam_h) {
+        oob = true;  // map[y, x] IndexError (calib:279-280)
+      } else {
+        const int xl = (int)x[k] - x_lo;
+        const bool x_in = (u32)xl < (u32)w_x;
+        const u32 l = x_in ? lut_t[xl * tb.cam_h + (int)y[k]] : tb.lut[x[k] * (u32)tb.cam_h + y[k]];
+        const int xr = (int)(short)(l & 0xffff), yr = (int)(short)(l >> 16);
+        if (yr >= 0 && yr < tb.xmap_h - 1) {  // xmd:23
+          const int c = col[k];
+          if ((u32)c >= (u32)tb.xmap_w) {
+            oob = true;
+          } else {
+            const int tl = c - ts_lo;
+            const bool t_in = (u32)tl < (u32)w_ts;
+            const int xp = t_in ? (int)xm_t[tl * tb.xmap_h + yr] : (int)tb.xmap[(u32)c * (u32)tb.xmap_h + (u32)yr];
+            const int disp = (int)(short)(xp - xr - tb.x_offset);  // int16 wrap (xmd:27)
+            if (disp >= 0) {                                          // xmd:29
+              const u32 slot_val = ((lidx[k] + 1) << 16) | (u32)disp;
+              if constexpr (VIEW == 0) {
+                int fc = (int)(short)(xr + disp);  // = xp - x_offset (calib:300)
+                if (fc < 0) fc += tb.rect_w;
+                if (fc < 0 || fc >= tb.rect_w || yr >= tb.rect_h) {
+                  oob = true;
+                } else {
+                  write = true;
+                  if (t_in) {
+                    if (!XM_ABL(1)) atomicMax(&win[tl * tb.xmap_h + yr], slot_val);
+                    else win[tl * tb.xmap_h + yr] = slot_val;
+                  } else {
+                    const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)disp;
+                    __hip_atomic_fetch_max(&frame[(u32)fc * (u32)tb.rect_h + (u32)yr], key, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                }
+              } else {
+                write = true;
+                if (x_in) {
+                  atomicMax(&win[(int)y[k] * w_x + xl], slot_val);
+                } else {
+                  const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)disp;
+                  __hip_atomic_fetch_max(&frame[y[k] * (u32)tb.cam_w + x[k]], key, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
+    n_oob += __popcll(__ballot(oob));
+  }
+  if ((tid & 63) == 0) {
+    if (n_in) atomicAdd(&s_in, n_in);
+    if (n_oob) atomicAdd(&s_oob, n_oob);
+  }
+  __syncthreads();
+
+  // ---- 5. flush the winners: consecutive lanes -> consecutive rows of one frame column ---------------------------
+  for (int i = tid; i < win_words; i += TILE_THREADS) {
+    const u32 v = win[i];
+    if (!v) continue;
+    const u32 disp = v & 0xffff;
+    const u64 key = key_hi | ((idx_offset + block_base + (v >> 16) - 1) << KEY_IDX_SHIFT) | (u64)disp;
+    u32 cell;
+    if constexpr (VIEW == 0) {
+      const int tl = i / tb.xmap_h, yr = i - tl * tb.xmap_h;
+      int fc = (int)(short)((int)xm_t[i] - tb.x_offset);
+      if (fc < 0) fc += tb.rect_w;
+      cell = (u32)fc * (u32)tb.rect_h + (u32)yr;
+    } else {
+      const int yy = i / w_x, xl = i - yy * w_x;
+      cell = (u32)yy * (u32)tb.cam_w + (u32)(x_lo + xl);
+    }
+    if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (key == 0x1234) frame[cell] = key;
+  }
+  if (tid == 0) {
+    u32* c = st->cnt[parity][blockIdx.x % CNT_SLOTS];
+    if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // =====================================================================================================
 // K2: frame kernels.
 // =====================================================================================================
@@ -475,19 +795,19 @@ __device__ inline void store_bgr_block(uint8_t* __restrict__ bgr, u64 first_pixe
   }
 }
 
-struct KeyCells {  // cells of the packed-key frame written by K1
+struct KeyCells {  // cells of the packed-key frame written by K1 (projector view: column-major)
   static constexpr bool keyed = true;
   const u64* f;
   u32 tag;
-  __device__ float get(u32 i) const {
-    const u64 k = f[i];
-    return (u32)(k >> KEY_TAG_SHIFT) == tag ? (float)(u32)(k & 0xffff) : 0.0f;
-  }
+  __device__ float decode(u64 k) const { return (u32)(k >> KEY_TAG_SHIFT) == tag ? (float)(u32)(k & 0xffff) : 0.0f; }
+  __device__ float get(u32 i) const { return decode(f[i]); }
+  __device__ float at(const DevTables& tb, int col, int row) const { return decode(f[(u32)col * (u32)tb.rect_h + (u32)row]); }
 };
-struct F32Cells {  // a plain f32 disparity frame (stage API)
+struct F32Cells {  // a plain row-major f32 disparity frame (stage API)
   static constexpr bool keyed = false;
   const float* f;
   __device__ float get(u32 i) const { return f[i]; }
+  __device__ float at(const DevTables& tb, int col, int row) const { return f[(u32)row * (u32)tb.rect_w + (u32)col]; }
 };
 
 // dilate(7x7) o remap(nearest) composed: out[v,u] = max over the 7x7 window centred on map[v,u] of the
@@ -500,10 +820,9 @@ __device__ inline float dilated_remap(const Cells& cells, const DevTables& tb, u
   float best = 0.0f;  // disparities are >= 0, so ignoring the border == zero padding
   const int y0 = max(my - 3, 0), y1 = min(my + 3, tb.rect_h - 1);
   const int x0 = max(mx - 3, 0), x1 = min(mx + 3, tb.rect_w - 1);
-  for (int yy = y0; yy <= y1; ++yy) {
-    const u32 row = (u32)yy * (u32)tb.rect_w;
+  for (int xx = x0; xx <= x1; ++xx) {
 #pragma unroll 7
-    for (int xx = x0; xx <= x1; ++xx) best = fmaxf(best, cells.get(row + (u32)xx));
+    for (int yy = y0; yy <= y1; ++yy) best = fmaxf(best, cells.at(tb, xx, yy));
   }
   return best;
 }
@@ -531,6 +850,130 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
     const PixelOut o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
     if (out_f32 && pixel < n_pixels) out_f32[pixel] = o.depth;
     if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, o.bgr);
+  }
+}
+
+
+// K2 (tiled, projector view, fused path): one block = a 32 x 8 tile of projector pixels.  Their map targets span
+// a (32*sx+6) x (8*sy+6) patch of the rectified key frame (sx, sy ~ 2.75): load that patch ONCE into LDS as u16
+// disparities (stale tags decoded to 0, cells outside the frame = 0), then every pixel takes its 7x7 max out of
+// LDS: 49 LDS reads instead of 49 lane-divergent global loads.  Falls back to global reads when the patch does
+// not fit (wild maps).  Column-major frame -> the patch is `cols` contiguous runs of `rows` cells.
+constexpr int K2_TX = 32, K2_TY = 8, K2_TILE_MAX = 12288;  // 24 KB of u16
+
+__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
+                                                                  SlotState* st, u32 tag_override,
+                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr) {
+  __shared__ uint16_t tile[K2_TILE_MAX];
+  __shared__ int s_box[4][4];
+  __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
+  const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
+  const u32 tag = tag_override ? tag_override : st->tag_a;
+  if (!tag_override && blockIdx.x == 0 && blockIdx.y == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
+    u32* c = st->cnt[(tag & 1) ^ 1][tid];
+    c[0] = c[1] = c[2] = c[3] = 0;
+  }
+  const int u = blockIdx.x * K2_TX + tx, v = blockIdx.y * K2_TY + ty;
+  const bool in_img = u < tb.proj_w && v < tb.proj_h;
+  int mx = 0, my = 0;
+  bool valid = false;
+  if (in_img) {
+    const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u];
+    mx = (int)(short)(m & 0xffff);
+    my = (int)(short)(m >> 16);
+    valid = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;  // else BORDER_CONSTANT 0
+  }
+  // bounding box of the tile's map targets
+  int x0 = valid ? mx : 0x7fffffff, x1 = valid ? mx : -0x7fffffff, y0 = valid ? my : 0x7fffffff, y1 = valid ? my : -0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, o, 64));
+    x1 = max(x1, __shfl_xor(x1, o, 64));
+    y0 = min(y0, __shfl_xor(y0, o, 64));
+    y1 = max(y1, __shfl_xor(y1, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    s_box[tid >> 6][0] = x0;
+    s_box[tid >> 6][1] = x1;
+    s_box[tid >> 6][2] = y0;
+    s_box[tid >> 6][3] = y1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    x0 = min(x0, s_box[w][0]);
+    x1 = max(x1, s_box[w][1]);
+    y0 = min(y0, s_box[w][2]);
+    y1 = max(y1, s_box[w][3]);
+  }
+  float d = 0.0f;
+  if (x1 >= x0) {  // at least one pixel of the tile maps into the frame
+    const int cols = x1 - x0 + 7, rows = y1 - y0 + 7;  // patch incl. the 3-cell dilate margin
+    if (cols * rows <= K2_TILE_MAX) {
+      const int bx = x0 - 3, by = y0 - 3;
+      const int total = cols * rows;
+      const float inv_rows = 1.0f / (float)rows;
+      constexpr int UN = 8, NT = K2_TX * K2_TY;
+      for (int i0 = tid; i0 < total; i0 += UN * NT) {  // UN independent 8-byte loads in flight per thread
+        u64 k[UN];
+        bool inside[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {  // unconditional loads (coordinates clamped into the frame), select afterwards
+          const int i = min(i0 + j * NT, total - 1);
+          int c = (int)((float)i * inv_rows), r = i - c * rows;  // i / rows without the integer divide
+          if (r < 0) { c -= 1; r += rows; }
+          if (r >= rows) { c += 1; r -= rows; }
+          const int gx = bx + c, gy = by + r;
+          inside[j] = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
+          const int cx = min(max(gx, 0), tb.rect_w - 1), cy = min(max(gy, 0), tb.rect_h - 1);
+          k[j] = keys[(u32)cx * (u32)tb.rect_h + (u32)cy];
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+          const int i = i0 + j * NT;
+          if (i < total) tile[i] = (inside[j] && (u32)(k[j] >> KEY_TAG_SHIFT) == tag) ? (uint16_t)(k[j] & 0xffff) : (uint16_t)0;
+        }
+      }
+      __syncthreads();
+      if (valid) {
+        u32 best = 0;
+        const uint16_t* p = tile + (mx - x0) * rows + (my - y0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i) best = max(best, (u32)p[j * rows + i]);
+        }
+        d = (float)best;
+      }
+    } else if (valid) {
+      KeyCells cells{keys, tag};
+      const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
+      for (int xx = xa; xx <= xb; ++xx)
+        for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, cells.at(tb, xx, yy));
+    }
+  }
+  const PixelOut o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
+  if (depth && in_img) depth[(u32)v * (u32)tb.proj_w + (u32)u] = o.depth;
+  if (bgr) {
+    const bool full_rows = (tb.proj_w & 3) == 0 && (blockIdx.x + 1) * K2_TX <= tb.proj_w;
+    if (full_rows) {  // 96 contiguous bytes per tile row: assemble in LDS, store as dwords
+      s_bgr[ty][tx * 3 + 0] = (uint8_t)(o.bgr & 0xff);
+      s_bgr[ty][tx * 3 + 1] = (uint8_t)((o.bgr >> 8) & 0xff);
+      s_bgr[ty][tx * 3 + 2] = (uint8_t)((o.bgr >> 16) & 0xff);
+      __syncthreads();
+      constexpr int DW = K2_TX * 3 / 4;  // 24 dwords per row
+      if (tid < K2_TY * DW) {
+        const int r = tid / DW, q = tid - r * DW, vv = blockIdx.y * K2_TY + r;
+        if (vv < tb.proj_h)
+          reinterpret_cast<u32*>(bgr + ((u64)vv * tb.proj_w + (u64)blockIdx.x * K2_TX) * 3)[q] =
+              reinterpret_cast<const u32*>(&s_bgr[r][0])[q];
+      }
+    } else if (in_img) {
+      uint8_t* b = bgr + ((u64)v * tb.proj_w + u) * 3;
+      b[0] = (uint8_t)(o.bgr & 0xff);
+      b[1] = (uint8_t)((o.bgr >> 8) & 0xff);
+      b[2] = (uint8_t)((o.bgr >> 16) & 0xff);
+    }
   }
 }
 
@@ -582,7 +1025,7 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rectify(const uint16_t* __restr
     yr[i] = 0;
     return;
   }
-  const u32 l = tb.lut[y * (u32)tb.cam_w + x];
+  const u32 l = tb.lut[x * (u32)tb.cam_h + y];
   xr[i] = (int16_t)(l & 0xffff);
   yr[i] = (int16_t)(l >> 16);
 }
@@ -603,7 +1046,7 @@ __global__ __launch_bounds__(BLOCK) void k_stage_event_disparity(const int16_t* 
   bool ok = y >= 0 && y < tb.xmap_h - 1;
   if (ok) {
     const int col = tn.column(ts[i]);
-    const int xp = (int)tb.xmap[y * tb.xmap_w + col];
+    const int xp = (int)tb.xmap[col * tb.xmap_h + y];
     d = (int)(short)(xp - x - tb.x_offset);
     ok = d >= 0;
   }

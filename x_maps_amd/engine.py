@@ -105,7 +105,8 @@ class XMapsEngine:
         self.cam_w, self.cam_h, self.proj_w, self.proj_h = cam_w, cam_h, proj_w, proj_h
         self.rect_w, self.rect_h = cfg.rect_width, cfg.rect_height
         self.out_h, self.out_w = (cam_h, cam_w) if camera_perspective else (proj_h, proj_w)
-        self.key_shape = (cam_h, cam_w) if camera_perspective else (self.rect_h, self.rect_w)
+        # packed-key frame as laid out in HBM: camera view row-major [y][x]; projector view column-major [col][row]
+        self.key_shape = (cam_h, cam_w) if camera_perspective else (self.rect_w, self.rect_h)
         self.t_px_scale = xmap.shape[1] - 1
 
     # ---- lifetime ------------------------------------------------------------------------------
