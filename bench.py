@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "4")),
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "8")),
                     help="frames in flight per GPU (own stream + key frame each)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames resident in HBM")
     ap.add_argument("--camera-perspective", action="store_true")
@@ -156,6 +156,7 @@ def main():
     else:
         for i in range(args.steps):
             step(i)
+    t_enqueued = time.perf_counter()
     eng.sync()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -261,6 +262,7 @@ def main():
                        "events_per_frame": n_ev, "frames_in_flight": args.slots, "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
                        "launch": "hipGraph" if args.graph else "eager", "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "host_enqueue_us_per_step": round((t_enqueued - t0) / args.steps * 1e6, 2),
         }
         if host_path:
             out["host_path"] = host_path

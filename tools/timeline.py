@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Experiment: per-phase s_memtime timeline of k_scatter_tiled (needs the -DXM_ABLATE build, see tools/timeline.sh)."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from x_maps_amd import XMapsEngine, synthetic as S, _native as N
+dev = torch.device("cuda", 0)
+cfg = S.C_1M
+tb = S.make_tables(cfg)
+eng = XMapsEngine(tb, n_slots=1)
+ev = S.make_events(cfg)
+x, y, t, _ = S.to_soa(ev)
+X, Y, T = (torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t))
+depth = torch.empty((eng.out_h, eng.out_w), dtype=torch.float32, device=dev)
+torch.cuda.synchronize()
+lib = N.load_library()
+names = ["start", "minmax loaded", "events issued", "samples->window", "bands issued+stored", "cols computed(pre-barrier)", "barrier1",
+         "per-event done", "barrier2", "flush issued", "end"]
+acc = []
+for it in range(30):
+    eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None)
+    eng.sync()
+    buf = np.zeros((64, 16), np.uint64)
+    lib.xm_debug_timeline(ctypes.c_void_p(buf.ctypes.data))
+    if it >= 5:
+        acc.append((buf[:, :11].astype(np.int64) - buf[:, :1].astype(np.int64)))
+a = np.mean(acc, axis=0)  # [block][phase] in s_memtime ticks (100 MHz constant clock on gfx9: 10 ns)
+print("phase                          mean over blocks 0..63   (ticks; s_memtime = 100 MHz => x10 ns)")
+prev = 0
+for i, nm in enumerate(names):
+    m = a[:, i].mean()
+    print(f"{nm:32s} t={m:9.1f}  (+{m - prev:8.1f})")
+    prev = m

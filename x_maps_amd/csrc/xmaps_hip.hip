@@ -90,6 +90,7 @@ struct xm_handle {
   u32* d_lut = nullptr;
   int16_t* d_xmap = nullptr;
   u32* d_pmap = nullptr;
+  uint2* d_dlut = nullptr;
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
   SlotState* aux_st = nullptr;
   std::vector<Slot> slots;
@@ -195,6 +196,7 @@ template <typename T, bool AOS, bool HAS_P, int VIEW>
 int launch_scatter_tv(const ScatterArgs& a) {
   const EventsView& ev = *a.ev;
   const u64 n = ev.n;
+  const bool vec16 = !AOS && aligned(ev.x, 16) && aligned(ev.y, 16) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 16));
   const bool vec = !AOS && aligned(ev.x, 8) && aligned(ev.y, 8) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 8));
   if (!a.direct && a.w_ts > 0 && a.w_x > 0) {
     auto kern = k_scatter_tiled<T, AOS, HAS_P, VIEW>;
@@ -206,7 +208,7 @@ int launch_scatter_tv(const ScatterArgs& a) {
     }
     hipLaunchKernelGGL(kern, dim3(grid_for(n, TILE_EVENTS)), dim3(TILE_THREADS), a.lds, a.stream, ev.x, ev.y,
                        (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-                       a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec ? 1 : 0);
+                       a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec16 ? 1 : 0);
     return XM_OK;
   }
   if constexpr (AOS) {
@@ -255,7 +257,7 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     hipLaunchKernelGGL((k_frame_direct<KeyCells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, px,
-                       h->tb.p03, h->tb.z_near, h->tb.z_far, st, tag_override, 1, depth, bgr);
+                       h->tb.p03, h->tb.z_near, h->tb.z_far, st, tag_override, 1, h->tb.dlut, depth, bgr);
   }
 }
 
@@ -280,15 +282,20 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
     int rc = reset_slot(h, s);
     if (rc) return rc;
   }
+#ifdef XM_ABLATE
+  static const int skip = getenv("XM_SKIP_MASK") ? atoi(getenv("XM_SKIP_MASK")) : 0;  // experiments: 1=K0 2=K1 4=K2
+#else
+  constexpr int skip = 0;
+#endif
   if (prof) HIP_TRY(hipEventRecord(prof[0], s.stream));
-  launch_minmax(ev, s.st, 0, s.stream);
+  if (!(skip & 1)) launch_minmax(ev, s.st, 0, s.stream);
   if (prof) HIP_TRY(hipEventRecord(prof[1], s.stream));
-  {
+  if (!(skip & 2)) {
     int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.stream);
     if (rc) return rc;
   }
   if (prof) HIP_TRY(hipEventRecord(prof[2], s.stream));
-  launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, s.stream);
+  if (!(skip & 4)) launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, s.stream);
   if (prof) HIP_TRY(hipEventRecord(prof[3], s.stream));
   HIP_TRY(hipGetLastError());
   s.host_tag += 1;
@@ -513,6 +520,11 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     XM_TRY_CREATE(hipMalloc((void**)&h->d_pmap, ppx * 4));
     XM_TRY_CREATE(hipMemcpy(h->d_pmap, pm.data(), ppx * 4, hipMemcpyHostToDevice));
   }
+  XM_TRY_CREATE(hipMalloc((void**)&h->d_dlut, 65536 * sizeof(uint2)));
+  hipLaunchKernelGGL(k_build_dlut, dim3(65536 / BLOCK), dim3(BLOCK), 0, 0, h->d_dlut, cfg->p03, cfg->z_near, cfg->z_far);
+  XM_TRY_CREATE(hipGetLastError());
+  XM_TRY_CREATE(hipDeviceSynchronize());
+  h->tb.dlut = h->d_dlut;
   h->tb.lut = h->d_lut;
   h->tb.xmap = h->d_xmap;
   h->tb.pmap = h->d_pmap;
@@ -547,8 +559,9 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     // <= 76 KB per block lets two 1024-thread blocks (e.g. of two frames in flight) share one CU's 160 KB
     size_t budget = 76 * 1024;
     if (const char* e = getenv("XM_LDS_KB")) budget = (size_t)atoi(e) * 1024;
-    int w_ts = 6, w_x = 12;
+    int w_ts = 5, w_x = 16;  // 5 time columns, 16 camera columns: 70 KB at C-1M
     if (const char* e = getenv("XM_W_TS")) w_ts = atoi(e);
+    if (w_ts > 64) w_ts = 64;  // s_col_used[64] in k_scatter_tiled
     if (const char* e = getenv("XM_W_X")) w_x = atoi(e);
     auto need = [&](int wt, int wx) {
       // must mirror the carve-up at the top of k_scatter_tiled (uint4 units, +1 uint4 of alignment slack per band)
@@ -618,6 +631,7 @@ void xm_destroy(xm_handle* h) {
   if (h->d_lut) (void)hipFree(h->d_lut);
   if (h->d_xmap) (void)hipFree(h->d_xmap);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
+  if (h->d_dlut) (void)hipFree(h->d_dlut);
   delete h;
 }
 
@@ -627,6 +641,15 @@ int xm_sync(xm_handle* h) {
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
   return XM_OK;
 }
+
+#ifdef XM_ABLATE
+// experiments only: copy out the s_memtime timeline written by k_scatter_tiled
+int xm_debug_timeline(unsigned long long* out /*[64][16]*/) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(xm::g_timeline), sizeof(unsigned long long) * 64 * 16));
+  return XM_OK;
+}
+#endif
 
 void* xm_stream(xm_handle* h, int slot) {
   if (!h || slot < 0 || slot >= (int)h->slots.size()) return nullptr;
@@ -960,7 +983,7 @@ static int stage_pixels(xm_handle* h, const float* disp, int height, int width, 
   if (bgr && (rc = s.out_bgr.reserve(px * 3))) return rc;
   F32Cells cellsv{(const float*)s.dbg[0].p};
   hipLaunchKernelGGL((k_frame_direct<F32Cells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, s.stream, cellsv, (u64)px,
-                     h->tb.p03, h->tb.z_near, h->tb.z_far, (SlotState*)nullptr, 0u, 0,
+                     h->tb.p03, h->tb.z_near, h->tb.z_far, (SlotState*)nullptr, 0u, 0, (const uint2*)nullptr,
                      depth ? (float*)s.out_depth.p : nullptr, bgr ? (uint8_t*)s.out_bgr.p : nullptr);
   HIP_TRY(hipGetLastError());
   if (depth) HIP_TRY(hipMemcpyAsync(depth, s.out_depth.p, px * 4, hipMemcpyDeviceToHost, s.stream));

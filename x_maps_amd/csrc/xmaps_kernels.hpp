@@ -31,8 +31,8 @@ typedef unsigned int u32;
 constexpr int KEY_IDX_SHIFT = 16;
 constexpr int KEY_TAG_SHIFT = 44;
 constexpr u32 KEY_MAX_TAG = (1u << 19) - 1;
-constexpr int MM_SLOTS = 32;   // spread the min/max atomics over 32 addresses (one contended word
-                               // retires only ~88 atomics/us on this chip)
+constexpr int MM_SLOTS = 32;   // spread the min/max atomics over 32 addresses: one contended word retires only
+                               // ~88 atomics/us on this chip (8 slots measured +3 us on K0)
 constexpr int CNT_SLOTS = 64;  // same for the counters
 constexpr int BLOCK = 256;
 
@@ -46,6 +46,7 @@ struct DevTables {
   const u32* lut;       // [cam_w][cam_h]   TRANSPOSED  (u16(yr) << 16) | u16(xr)
   const int16_t* xmap;  // [xmap_w][xmap_h] TRANSPOSED  X-map, time column major
   const u32* pmap;      // [proj_h][proj_w] row-major   (u16(my) << 16) | u16(mx)
+  const uint2* dlut;    // [65536] per integer disparity: {f32 bits of depth, BGR word} = disparity_pixel(d) (A5-A7)
   int cam_w, cam_h, proj_w, proj_h, rect_w, rect_h, xmap_w, xmap_h;
   int x_offset, t_px_scale;
   double p03;
@@ -95,13 +96,26 @@ constexpr u64 MM_INIT_MAX = 0ull;
 template <typename T> struct TimeNorm;
 template <> struct TimeNorm<long long> {
   long long tmin;
-  double den, scale;
-  bool degenerate;
+  double den, scale, rinv;
+  bool degenerate, small;
   __device__ TimeNorm(long long lo, long long hi, int S)
-      : tmin(lo), den((double)(hi - lo)), scale((double)S), degenerate(hi == lo) {}
+      : tmin(lo), den((double)(hi - lo)), scale((double)S), degenerate(hi == lo) {
+    small = (u64)(hi - lo) <= 0xffffffffull;  // a frame spans microseconds: always true in practice
+    rinv = 1.0 / den;
+  }
+  // Reference: rint(fl(fl(a / den) * S)), a = t - tmin.  Fast path: e = fl(fl(a * fl(1/den)) * S) differs from the
+  // reference's product by < 5 ulp (< 2e-11 for columns <= 32767); whenever e is further than 1e-6 from a rounding
+  // boundary (x.5) both round to the same integer, so rint(e) IS the reference result.  Closer than that (exact
+  // ties such as golden g1d_rint_ties land here) the IEEE divide below decides.  ~8 instructions instead of ~50.
   __device__ int column(long long t) const {
     if (degenerate) return 0;  // 0/0 = NaN -> int16 cast = 0 (what NumPy yields on x86-64)
-    double tn = (double)(t - tmin) / den;
+    const u64 a = (u64)(t - tmin);
+    if (small && a <= 0xffffffffull) {
+      const double e = ((double)(u32)a * rinv) * scale;
+      const double r = rint(e);
+      if (fabs(fabs(e - r) - 0.5) > 1e-6) return (int)(short)(int)r;
+    }
+    const double tn = (double)(t - tmin) / den;
     return (int)(short)(int)rint(tn * scale);
   }
 };
@@ -144,16 +158,27 @@ __device__ inline u64 wave_max_u64(u64 v) {
   return v;
 }
 
-// frame extrema as written by K0: every wave reduces the MM_SLOTS partials itself (512 B, L2-hot)
+// frame extrema as written by K0: every wave reduces the MM_SLOTS partials itself (128 B, L2-hot) and broadcasts
+// the result through SGPRs (readfirstlane), so everything derived from it is wave-uniform
+__device__ inline u64 uniform_u64(u64 v) {
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
 __device__ inline void load_frame_minmax(const SlotState* st, u32 parity, u64& lo, u64& hi) {
-  int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   u64 a = MM_INIT_MIN, b = MM_INIT_MAX;
   if (lane < MM_SLOTS) {
     a = st->mm[parity][lane][0];
     b = st->mm[parity][lane][1];
   }
-  lo = wave_min_u64(a);
-  hi = wave_max_u64(b);
+#pragma unroll
+  for (int o = MM_SLOTS / 2; o > 0; o >>= 1) {
+    const u64 a2 = __shfl_xor(a, o, 64), b2 = __shfl_xor(b, o, 64);
+    a = a2 < a ? a2 : a;
+    b = b2 > b ? b2 : b;
+  }
+  lo = uniform_u64(a);
+  hi = uniform_u64(b);
 }
 
 // =====================================================================================================
@@ -284,13 +309,10 @@ struct EventResult {
   bool inlier;
 };
 
-// A1 + A2 for one event.  `used` = belongs to the frame (polarity).  Sets oob when NumPy would raise.
-template <typename T>
-__device__ inline EventResult event_disparity(const DevTables& tb, const TimeNorm<T>& tn, u32 x, u32 y, T t,
-                                              bool used, bool& oob) {
-  EventResult r{0, 0, 0, 0, false};
+// A1 + A2 for one event whose time column is already known.  Sets oob when NumPy would raise IndexError.
+__device__ inline EventResult event_disparity_col(const DevTables& tb, int column, u32 x, u32 y, bool& oob) {
+  EventResult r{0, 0, column, 0, false};
   oob = false;
-  if (!used) return r;
   if (x >= (u32)tb.cam_w || y >= (u32)tb.cam_h) {  // map[y, x] IndexError (calib:279-280)
     oob = true;
     return r;
@@ -298,7 +320,6 @@ __device__ inline EventResult event_disparity(const DevTables& tb, const TimeNor
   const u32 l = tb.lut[x * (u32)tb.cam_h + y];
   r.xr = (int)(short)(l & 0xffff);
   r.yr = (int)(short)(l >> 16);
-  r.ts = tn.column(t);
   const bool y_ok = r.yr >= 0 && r.yr < tb.xmap_h - 1;  // xmd:23 (last X-map row excluded)
   if (!y_ok) return r;
   if ((u32)r.ts >= (u32)tb.xmap_w) {  // only reachable when a caller hands in extrema that do not bound t
@@ -309,6 +330,15 @@ __device__ inline EventResult event_disparity(const DevTables& tb, const TimeNor
   r.disp = (int)(short)(xp - r.xr - tb.x_offset);                      // int16 wrap-around (xmd:27)
   r.inlier = r.disp >= 0;                                              // xmd:29
   return r;
+}
+
+// A1 + A2 for one event.  `used` = belongs to the frame (polarity).
+template <typename T>
+__device__ inline EventResult event_disparity(const DevTables& tb, const TimeNorm<T>& tn, u32 x, u32 y, T t,
+                                              bool used, bool& oob) {
+  oob = false;
+  if (!used) return EventResult{0, 0, 0, 0, false};
+  return event_disparity_col(tb, tn.column(t), x, y, oob);
 }
 
 // cell of the disparity frame an inlier event writes; false = NumPy IndexError
@@ -468,11 +498,17 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
 #ifdef XM_ABLATE
 __device__ int g_ablate = 0;  // bit0: no flush atomics, bit1: no LDS slot atomics, bit2: no band loads, bit3: no time divide
 #define XM_ABL(bit) (g_ablate & (1 << (bit)))
+__device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime stamps of thread 0 (experiments only)
+#define XM_STAMP(ph) do { if ((threadIdx.x == 0) && blockIdx.x < 64) g_timeline[blockIdx.x][ph] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define XM_ABL(bit) 0
+#define XM_STAMP(ph) do { } while (0)
 #endif
-constexpr int TILE_THREADS = 1024;
-constexpr int TILE_EPT = 4;
+#ifndef XM_TILE_THREADS
+#define XM_TILE_THREADS 1024
+#endif
+constexpr int TILE_THREADS = XM_TILE_THREADS;   // 512 x 8 or 1024 x 4 events: same LDS tile, different latency/issue trade
+constexpr int TILE_EPT = 4096 / XM_TILE_THREADS;
 constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;
 
 template <typename T, bool AOS, bool HAS_P, int VIEW>
@@ -483,14 +519,119 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift)
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
-  const int win_q = (win_words + 3) >> 2;                 // uint4 count
+  const int win_q = (win_words + 3) >> 2;  // uint4 count
   const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1;
   u32* win = reinterpret_cast<u32*>(smem);
   u32* lut_base = win + 4 * win_q;
   int16_t* xm_base = reinterpret_cast<int16_t*>(lut_base + 4 * lut_q);
   __shared__ u32 s_in, s_oob;
+  __shared__ u32 s_col_used[64];  // VIEW 0: which time columns of the window received an event
 
   const int tid = threadIdx.x;
+  XM_STAMP(0);
+  if (tid < 64) s_col_used[tid] = 0;
+  const u64 block_base = (u64)blockIdx.x * TILE_EVENTS;
+  const bool have = block_base < n;  // false only for the single block of an empty frame
+
+  // ---- 1. loads that depend on nothing, issued first: this thread's 4 events and the 3 window samples ---------------
+  u32 x[TILE_EPT], y[TILE_EPT], lidx[TILE_EPT];
+  T tt[TILE_EPT];
+  bool used[TILE_EPT];
+  const bool vec = !AOS && vec_ok && block_base + TILE_EVENTS <= n;
+  if (vec) {  // TILE_EPT consecutive events per thread: 8/16-byte loads of x / y / p, 16-byte loads of t
+    const u64 base = block_base + (u64)tid * TILE_EPT;
+    u32 xw[TILE_EPT / 2], yw[TILE_EPT / 2], pw[TILE_EPT / 2];
+    if constexpr (TILE_EPT == 8) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(xs + base);
+      const uint4 yv = *reinterpret_cast<const uint4*>(ys + base);
+      xw[0] = xv.x; xw[1] = xv.y; xw[2] = xv.z; xw[3] = xv.w;
+      yw[0] = yv.x; yw[1] = yv.y; yw[2] = yv.z; yw[3] = yv.w;
+      if constexpr (HAS_P) {
+        const uint4 pv = *reinterpret_cast<const uint4*>(ps + base);
+        pw[0] = pv.x; pw[1] = pv.y; pw[2] = pv.z; pw[3] = pv.w;
+      }
+    } else {
+      const uint2 xv = *reinterpret_cast<const uint2*>(xs + base);
+      const uint2 yv = *reinterpret_cast<const uint2*>(ys + base);
+      xw[0] = xv.x; xw[1] = xv.y;
+      yw[0] = yv.x; yw[1] = yv.y;
+      if constexpr (HAS_P) {
+        const uint2 pv = *reinterpret_cast<const uint2*>(ps + base);
+        pw[0] = pv.x; pw[1] = pv.y;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TILE_EPT / 2; ++q) {
+      x[2 * q] = xw[q] & 0xffff; x[2 * q + 1] = xw[q] >> 16;
+      y[2 * q] = yw[q] & 0xffff; y[2 * q + 1] = yw[q] >> 16;
+      used[2 * q] = used[2 * q + 1] = true;
+      if constexpr (HAS_P) {
+        used[2 * q] = (short)(pw[q] & 0xffff) == 1;
+        used[2 * q + 1] = (short)(pw[q] >> 16) == 1;
+      }
+    }
+    if constexpr (sizeof(T) == 8) {
+#pragma unroll
+      for (int q = 0; q < TILE_EPT / 2; ++q) {
+        const longlong2 a = *reinterpret_cast<const longlong2*>(ts + base + 2 * q);
+        __builtin_memcpy(&tt[2 * q], &a.x, 8);
+        __builtin_memcpy(&tt[2 * q + 1], &a.y, 8);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < TILE_EPT / 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(ts + base + 4 * q);
+        __builtin_memcpy(&tt[4 * q], &a.x, 4); __builtin_memcpy(&tt[4 * q + 1], &a.y, 4);
+        __builtin_memcpy(&tt[4 * q + 2], &a.z, 4); __builtin_memcpy(&tt[4 * q + 3], &a.w, 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) lidx[k] = (u32)tid * TILE_EPT + k;
+  } else {  // any alignment / ragged tail / AoS records: event k*512 + tid, still coalesced across lanes
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      lidx[k] = (u32)k * TILE_THREADS + tid;
+      const u64 i = block_base + lidx[k];
+      used[k] = i < n;
+      tt[k] = (T)0;
+      x[k] = y[k] = 0;
+      if (used[k]) {
+        if constexpr (AOS) {
+          const uint4 r = aos[i];
+          x[k] = r.x & 0xffff;
+          y[k] = r.x >> 16;
+          tt[k] = (T)(long long)(((u64)r.w << 32) | r.z);
+          if (HAS_P) used[k] = (short)(r.y & 0xffff) == 1;
+        } else {
+          x[k] = xs[i];
+          y[k] = ys[i];
+          tt[k] = ts[i];
+          if (HAS_P) used[k] = ps[i] == 1;
+        }
+      }
+    }
+  }
+  // three sampled events (first / middle / last of the block) locate the time slice: uniform loads
+  int sx[3] = {0, 0, 0};
+  T st_t[3] = {(T)0, (T)0, (T)0};
+  if (have) {
+    const u64 last = (block_base + TILE_EVENTS <= n ? block_base + TILE_EVENTS : n) - 1;
+    const u64 si[3] = {block_base, block_base + ((last - block_base) >> 1), last};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if constexpr (AOS) {
+        const uint4 r = aos[si[j]];
+        sx[j] = (int)(r.x & 0xffff);
+        st_t[j] = (T)(long long)(((u64)r.w << 32) | r.z);
+      } else {
+        sx[j] = (int)xs[si[j]];
+        st_t[j] = ts[si[j]];
+      }
+    }
+  }
+  XM_STAMP(1);
+
+  // ---- 2. frame extrema (written by K0) -> time normalisation ---------------------------------------------------------
   const u32 tag = tag_override ? tag_override : st->tag_a;
   const u32 parity = tag & 1;
   u64 lo, hi;
@@ -501,7 +642,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     load_frame_minmax(st, parity, lo, hi);
     if (blockIdx.x == 0) {
       if (tid == 0) st->tag_b = tag;
-      if (tid < MM_SLOTS) {
+      if (tid < MM_SLOTS) {  // re-arm the other parity's slots for the next frame on this slot
         st->mm[parity ^ 1][tid][0] = MM_INIT_MIN;
         st->mm[parity ^ 1][tid][1] = MM_INIT_MAX;
       }
@@ -513,106 +654,27 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     s_in = 0;
     s_oob = 0;
   }
-  const u64 block_base = (u64)blockIdx.x * TILE_EVENTS;
+  XM_STAMP(2);
 
-  // ---- 1. this thread's events: issued FIRST (they depend on nothing), consumed after the bands are on their way ------------------------------------------
-  u32 x[TILE_EPT], y[TILE_EPT], lidx[TILE_EPT];
-  int col[TILE_EPT];
-  T tt[TILE_EPT];
-  bool used[TILE_EPT];
-  const bool vec = !AOS && vec_ok && block_base + TILE_EVENTS <= n;
-  if (vec) {  // 4 consecutive events per thread: 8-byte loads of x / y / p, 2 x 16-byte loads of t
-    const u64 base = block_base + (u64)tid * 4;
-    const uint2 xv = *reinterpret_cast<const uint2*>(xs + base);
-    const uint2 yv = *reinterpret_cast<const uint2*>(ys + base);
-    x[0] = xv.x & 0xffff; x[1] = xv.x >> 16; x[2] = xv.y & 0xffff; x[3] = xv.y >> 16;
-    y[0] = yv.x & 0xffff; y[1] = yv.x >> 16; y[2] = yv.y & 0xffff; y[3] = yv.y >> 16;
-    T t[4];
-    if constexpr (sizeof(T) == 8) {
-      const longlong2 a = *reinterpret_cast<const longlong2*>(ts + base);
-      const longlong2 b = *reinterpret_cast<const longlong2*>(ts + base + 2);
-      __builtin_memcpy(&t[0], &a.x, 8); __builtin_memcpy(&t[1], &a.y, 8);
-      __builtin_memcpy(&t[2], &b.x, 8); __builtin_memcpy(&t[3], &b.y, 8);
-    } else {
-      const float4 a = *reinterpret_cast<const float4*>(ts + base);
-      __builtin_memcpy(&t[0], &a.x, 4); __builtin_memcpy(&t[1], &a.y, 4);
-      __builtin_memcpy(&t[2], &a.z, 4); __builtin_memcpy(&t[3], &a.w, 4);
-    }
-    used[0] = used[1] = used[2] = used[3] = true;
-    if constexpr (HAS_P) {
-      const uint2 pv = *reinterpret_cast<const uint2*>(ps + base);
-      used[0] = (short)(pv.x & 0xffff) == 1; used[1] = (short)(pv.x >> 16) == 1;
-      used[2] = (short)(pv.y & 0xffff) == 1; used[3] = (short)(pv.y >> 16) == 1;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      lidx[k] = (u32)tid * 4 + k;
-      tt[k] = t[k];
-    }
-  } else {  // any alignment / ragged tail / AoS records: event k*1024 + tid, still coalesced across lanes
-#pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) {
-      lidx[k] = (u32)k * TILE_THREADS + tid;
-      const u64 i = block_base + lidx[k];
-      used[k] = i < n;
-      col[k] = 0;
-      tt[k] = (T)0;
-      x[k] = y[k] = 0;
-      if (used[k]) {
-        T t;
-        if constexpr (AOS) {
-          const uint4 r = aos[i];
-          x[k] = r.x & 0xffff;
-          y[k] = r.x >> 16;
-          t = (T)(long long)(((u64)r.w << 32) | r.z);
-          if (HAS_P) used[k] = (short)(r.y & 0xffff) == 1;
-        } else {
-          x[k] = xs[i];
-          y[k] = ys[i];
-          t = ts[i];
-          if (HAS_P) used[k] = ps[i] == 1;
-        }
-        tt[k] = t;
-      }
-    }
-  }
-  // ---- 2. where is this time slice?  median of three sampled events (first / middle / last of the block): uniform
-  //         loads that do not wait for the block's own events, so the band loads below overlap the event loads.
-  //         A wrong guess (unsorted input, a noise event) only sends events down the direct path.
+  // ---- 3. window = median of the samples.  A wrong guess (unsorted input, a noise event) only sends events down
+  //         the direct path.
   int x_lo, ts_lo;
   {
-    const bool have = block_base < n;  // false only for the single block of an empty frame
-    const u64 last = have ? (block_base + TILE_EVENTS <= n ? block_base + TILE_EVENTS : n) - 1 : 0;
-    const u64 first = have ? block_base : 0;
-    const u64 si[3] = {first, first + ((last - first) >> 1), last};
-    int sx[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
-    if (have) {  // block-uniform; the three loads are independent and issued back to back, divides afterwards
-      T tj[3];
+    int sc[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if constexpr (AOS) {
-          const uint4 r = aos[si[j]];
-          sx[j] = (int)(r.x & 0xffff);
-          tj[j] = (T)(long long)(((u64)r.w << 32) | r.z);
-        } else {
-          sx[j] = (int)xs[si[j]];
-          tj[j] = ts[si[j]];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) sc[j] = tn.column(tj[j]);
-    }
+    for (int j = 0; j < 3; ++j) sc[j] = have ? tn.column(st_t[j]) : 0;
     const int mx = max(min(sx[0], sx[1]), min(max(sx[0], sx[1]), sx[2]));
     const int mc = max(min(sc[0], sc[1]), min(max(sc[0], sc[1]), sc[2]));
     x_lo = min(max(mx - w_x / 2, 0), max(tb.cam_w - w_x, 0));
     ts_lo = min(max(mc - w_ts / 2, 0), max(tb.xmap_w - w_ts, 0));
   }
+  XM_STAMP(3);
   // the bands are contiguous runs of the column-major tables: [x_lo, x_lo + w_x) x cam_h words and
-  // [ts_lo, ts_lo + w_ts) x xmap_h int16.  Load them with aligned 16-byte vectors, every load in flight at once;
-  // the LDS copies keep the global misalignment (a few elements of slack in front).
+  // [ts_lo, ts_lo + w_ts) x xmap_h int16.  Aligned 16-byte loads, every load in flight at once; the LDS copies keep
+  // the global misalignment (a few elements of slack in front).
   const int wx_eff = min(w_x, tb.cam_w), wts_eff = min(w_ts, tb.xmap_w);
-  const u32 lut_start = (u32)x_lo * (u32)tb.cam_h, lut_shift = lut_start & 3u;           // in words
-  const u32 xm_start = (u32)ts_lo * (u32)tb.xmap_h, xm_shift = xm_start & 7u;            // in int16
+  const u32 lut_start = (u32)x_lo * (u32)tb.cam_h, lut_shift = lut_start & 3u;  // in words
+  const u32 xm_start = (u32)ts_lo * (u32)tb.xmap_h, xm_shift = xm_start & 7u;   // in int16
   const u32* lut_t = lut_base + lut_shift;
   const int16_t* xm_t = xm_base + xm_shift;
   {
@@ -626,7 +688,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     // Branch-free on purpose: loads use a clamped index and out-of-range lanes store into a dummy LDS slot.  Any
     // predication here turns into one basic block per load with an s_waitcnt vmcnt(0) behind it (seen in the ISA),
     // i.e. 8 serialized L2 round trips per block instead of one.
-    const int dummy = 0;  // l_dummy[0]
     uint4* l_dummy = reinterpret_cast<uint4*>(xm_base) + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
     if (!XM_ABL(2)) {
       for (int i0 = tid; i0 < nq_lut; i0 += UN * TILE_THREADS) {
@@ -636,7 +697,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
           const int i = i0 + j * TILE_THREADS;
-          (i < nq_lut ? l_lut + i : l_dummy + dummy)[0] = v[j];
+          (i < nq_lut ? l_lut + i : l_dummy)[0] = v[j];
         }
       }
       for (int i0 = tid; i0 < nq_xm; i0 += UN * TILE_THREADS) {
@@ -646,107 +707,162 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
           const int i = i0 + j * TILE_THREADS;
-          (i < nq_xm ? l_xm + i : l_dummy + dummy)[0] = v[j];
+          (i < nq_xm ? l_xm + i : l_dummy)[0] = v[j];
         }
       }
     }
     uint4* l_win = reinterpret_cast<uint4*>(win);
     for (int i = tid; i < win_q; i += TILE_THREADS) l_win[i] = make_uint4(0, 0, 0, 0);
   }
+  XM_STAMP(4);
 
-  // ---- 3. time columns of this thread's events (FP64 divide, bit-exact with NumPy) -- overlaps the band loads
+  // ---- 4. time columns of this thread's events (bit-exact with NumPy, see TimeNorm) ------------------------------------
+  int col[TILE_EPT];
 #pragma unroll
   for (int k = 0; k < TILE_EPT; ++k) col[k] = used[k] ? (XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k])) : 0;
+  XM_STAMP(5);
   __syncthreads();  // bands + cleared slots visible
+  XM_STAMP(6);
 
-  // ---- 4. per event: A1 + A2 out of LDS, resolve collisions in LDS ---------------------------------------------
-  u32 n_in = 0, n_oob = 0;
+  // ---- 5. fast path, BRANCH-FREE so that the four events' LDS round trips overlap: A1 + A2 out of the LDS bands with
+  //         clamped addresses, collisions resolved with ds_max_u32.  Events that need anything else (outside a window,
+  //         index error) are only flagged here and handled in the rare pass below.
+  u32 n_in = 0;
+  bool slow[TILE_EPT];
+  {
+    int xl[TILE_EPT], tl[TILE_EPT];
+    bool fast[TILE_EPT];
+    u32 l[TILE_EPT];
 #pragma unroll
-  for (int k = 0; k < TILE_EPT; ++k) {
-    bool oob = false, write = false;
-    if (used[k]) {
-      if (x[k] >= (u32)tb.cam_w || y[k] >= (u32)tb.cam_h) {
-        oob = true;  // map[y, x] IndexError (calib:279-280)
+    for (int k = 0; k < TILE_EPT; ++k) {
+      xl[k] = (int)x[k] - x_lo;
+      tl[k] = col[k] - ts_lo;
+      fast[k] = used[k] && (u32)xl[k] < (u32)wx_eff && (u32)tl[k] < (u32)wts_eff && y[k] < (u32)tb.cam_h;
+      slow[k] = used[k] && !fast[k];
+      l[k] = lut_t[fast[k] ? xl[k] * tb.cam_h + (int)y[k] : 0];
+    }
+    int xr[TILE_EPT], yr[TILE_EPT], xp[TILE_EPT];
+    bool yok[TILE_EPT];
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      xr[k] = (int)(short)(l[k] & 0xffff);
+      yr[k] = (int)(short)(l[k] >> 16);
+      yok[k] = fast[k] && yr[k] >= 0 && yr[k] < tb.xmap_h - 1;  // xmd:23
+      xp[k] = (int)xm_t[yok[k] ? tl[k] * tb.xmap_h + yr[k] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      const int disp = (int)(short)(xp[k] - xr[k] - tb.x_offset);  // int16 wrap (xmd:27)
+      bool write = yok[k] && disp >= 0;                               // xmd:29
+      int slot;
+      if constexpr (VIEW == 0) {
+        int fc = (int)(short)(xr[k] + disp);  // = xp - x_offset (calib:300)
+        if (fc < 0) fc += tb.rect_w;
+        const bool inb = fc >= 0 && fc < tb.rect_w && yr[k] < tb.rect_h;
+        slow[k] = slow[k] || (write && !inb);  // IndexError candidates are counted by the slow pass
+        write = write && inb;
+        slot = tl[k] * tb.xmap_h + yr[k];
       } else {
-        const int xl = (int)x[k] - x_lo;
-        const bool x_in = (u32)xl < (u32)w_x;
-        const u32 l = x_in ? lut_t[xl * tb.cam_h + (int)y[k]] : tb.lut[x[k] * (u32)tb.cam_h + y[k]];
-        const int xr = (int)(short)(l & 0xffff), yr = (int)(short)(l >> 16);
-        if (yr >= 0 && yr < tb.xmap_h - 1) {  // xmd:23
-          const int c = col[k];
-          if ((u32)c >= (u32)tb.xmap_w) {
-            oob = true;
-          } else {
-            const int tl = c - ts_lo;
-            const bool t_in = (u32)tl < (u32)w_ts;
-            const int xp = t_in ? (int)xm_t[tl * tb.xmap_h + yr] : (int)tb.xmap[(u32)c * (u32)tb.xmap_h + (u32)yr];
-            const int disp = (int)(short)(xp - xr - tb.x_offset);  // int16 wrap (xmd:27)
-            if (disp >= 0) {                                          // xmd:29
-              const u32 slot_val = ((lidx[k] + 1) << 16) | (u32)disp;
-              if constexpr (VIEW == 0) {
-                int fc = (int)(short)(xr + disp);  // = xp - x_offset (calib:300)
-                if (fc < 0) fc += tb.rect_w;
-                if (fc < 0 || fc >= tb.rect_w || yr >= tb.rect_h) {
-                  oob = true;
-                } else {
-                  write = true;
-                  if (t_in) {
-                    if (!XM_ABL(1)) atomicMax(&win[tl * tb.xmap_h + yr], slot_val);
-                    else win[tl * tb.xmap_h + yr] = slot_val;
-                  } else {
-                    const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)disp;
-                    __hip_atomic_fetch_max(&frame[(u32)fc * (u32)tb.rect_h + (u32)yr], key, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                  }
-                }
-              } else {
-                write = true;
-                if (x_in) {
-                  atomicMax(&win[(int)y[k] * w_x + xl], slot_val);
-                } else {
-                  const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)disp;
-                  __hip_atomic_fetch_max(&frame[y[k] * (u32)tb.cam_w + x[k]], key, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-                }
-              }
-            }
-          }
+        slot = (int)y[k] * w_x + xl[k];
+      }
+      if (write && !XM_ABL(1)) {
+        atomicMax(&win[slot], ((lidx[k] + 1) << 16) | (u32)disp);
+        if constexpr (VIEW == 0) s_col_used[tl[k]] = 1;
+      }
+      n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
+    }
+  }
+  // ---- 5b. rare pass: events outside the windows take the global path (same arithmetic, direct atomics) --------------
+  u32 n_oob = 0;
+  bool any_slow = false;
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) any_slow = any_slow || slow[k];
+  if (__ballot(any_slow)) {
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      bool oob = false, write = false;
+      if (slow[k]) {
+        const EventResult r = event_disparity_col(tb, col[k], x[k], y[k], oob);
+        u32 cell = 0;
+        write = r.inlier;
+        if (write && !event_cell<VIEW>(tb, r, x[k], y[k], cell)) {
+          write = false;
+          oob = true;
+        }
+        if (write) {
+          const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
+          __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      n_in += __popcll(__ballot(write));
+      n_oob += __popcll(__ballot(oob));
     }
-    n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
-    n_oob += __popcll(__ballot(oob));
   }
   if ((tid & 63) == 0) {
     if (n_in) atomicAdd(&s_in, n_in);
     if (n_oob) atomicAdd(&s_oob, n_oob);
   }
+  XM_STAMP(7);
   __syncthreads();
+  XM_STAMP(8);
 
-  // ---- 5. flush the winners: consecutive lanes -> consecutive rows of one frame column ---------------------------
-  for (int i = tid; i < win_words; i += TILE_THREADS) {
-    const u32 v = win[i];
-    if (!v) continue;
-    const u32 disp = v & 0xffff;
-    const u64 key = key_hi | ((idx_offset + block_base + (v >> 16) - 1) << KEY_IDX_SHIFT) | (u64)disp;
-    u32 cell;
-    if constexpr (VIEW == 0) {
-      const int tl = i / tb.xmap_h, yr = i - tl * tb.xmap_h;
-      int fc = (int)(short)((int)xm_t[i] - tb.x_offset);
-      if (fc < 0) fc += tb.rect_w;
-      cell = (u32)fc * (u32)tb.rect_h + (u32)yr;
-    } else {
-      const int yy = i / w_x, xl = i - yy * w_x;
-      cell = (u32)yy * (u32)tb.cam_w + (u32)(x_lo + xl);
+  // ---- 6. flush the winners: consecutive lanes -> consecutive slots = consecutive rows of one frame column (VIEW 0) /
+  //         consecutive x of one row (VIEW 1).  All LDS reads of a thread are issued before the first atomic.
+  if constexpr (VIEW == 0) {
+    constexpr int FL = 4;
+    for (int c = 0; c < w_ts; ++c) {
+      if (!s_col_used[c]) continue;  // block-uniform: a sorted slice touches 3-4 of the window's columns
+      const int base = c * tb.xmap_h;
+      for (int r0 = tid; r0 < tb.xmap_h; r0 += FL * TILE_THREADS) {
+        u32 v[FL];
+        int xv[FL];
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {  // all LDS reads first (clamped), atomics afterwards
+          const int r = min(r0 + j * TILE_THREADS, tb.xmap_h - 1);
+          v[j] = win[base + r];
+          xv[j] = (int)xm_t[base + r];
+        }
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+          const int r = r0 + j * TILE_THREADS;
+          if (r < tb.xmap_h && v[j]) {
+            const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
+            int fc = (int)(short)(xv[j] - tb.x_offset);
+            if (fc < 0) fc += tb.rect_w;
+            if (!XM_ABL(0))
+              __hip_atomic_fetch_max(&frame[(u32)fc * (u32)tb.rect_h + (u32)r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
     }
-    if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if (key == 0x1234) frame[cell] = key;
+  } else {
+    constexpr int FL = 4;
+    const float inv_d = 1.0f / (float)w_x;
+    for (int i0 = tid; i0 < win_words; i0 += FL * TILE_THREADS) {
+      u32 v[FL];
+#pragma unroll
+      for (int j = 0; j < FL; ++j) v[j] = win[min(i0 + j * TILE_THREADS, win_words - 1)];
+#pragma unroll
+      for (int j = 0; j < FL; ++j) {
+        const int i = i0 + j * TILE_THREADS;
+        if (i < win_words && v[j]) {
+          int q = (int)((float)i * inv_d), r = i - q * w_x;  // camera row, x - x_lo (no integer divide)
+          if (r < 0) { q -= 1; r += w_x; }
+          if (r >= w_x) { q += 1; r -= w_x; }
+          const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
+          __hip_atomic_fetch_max(&frame[(u32)q * (u32)tb.cam_w + (u32)(x_lo + r)], key, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
   }
+  XM_STAMP(9);
   if (tid == 0) {
     u32* c = st->cnt[parity][blockIdx.x % CNT_SLOTS];
     if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  XM_STAMP(10);
 }
 
 // =====================================================================================================
@@ -777,6 +893,18 @@ __device__ inline PixelOut disparity_pixel(float d, double p03, float z_near, fl
   // disp_to_depth.py:24-43 -- Turbo, undefined depth (u8 == 0) painted white
   o.bgr = u8 == 0 ? 0x00ffffffu : kTurbo[u8];
   return o;
+}
+
+// The fused path only ever sees integer disparities 0..65535 (low 16 bits of a key), and A5-A7 are a pure function of
+// the disparity for fixed P2[0,3] / z_near / z_far: tabulate it once per handle with the very same device function
+// (bit-identical by construction) -- K2 then replaces an FP64 divide, an f32 divide and the Turbo lookup by one
+// 8-byte gather from a table whose live part (disparities < rect_w) sits in L1/L2.
+__global__ __launch_bounds__(BLOCK) void k_build_dlut(uint2* __restrict__ dlut, double p03, float z_near, float z_far) {
+  const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+  if (d < 65536u) {
+    const PixelOut o = disparity_pixel((float)d, p03, z_near, z_far);
+    dlut[d] = make_uint2(__float_as_uint(o.depth), o.bgr);
+  }
 }
 
 // cooperative, coalesced store of BLOCK pixels' BGR bytes (3 B each) through LDS
@@ -854,18 +982,34 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 }
 
 
-// K2 (tiled, projector view, fused path): one block = a 32 x 8 tile of projector pixels.  Their map targets span
-// a (32*sx+6) x (8*sy+6) patch of the rectified key frame (sx, sy ~ 2.75): load that patch ONCE into LDS as u16
-// disparities (stale tags decoded to 0, cells outside the frame = 0), then every pixel takes its 7x7 max out of
-// LDS: 49 LDS reads instead of 49 lane-divergent global loads.  Falls back to global reads when the patch does
-// not fit (wild maps).  Column-major frame -> the patch is `cols` contiguous runs of `rows` cells.
-constexpr int K2_TX = 32, K2_TY = 8, K2_TILE_MAX = 12288;  // 24 KB of u16
+// K2 (tiled, projector view, fused path): one block = a 16 x 16 tile of projector pixels (measured best of 32x8, 16x16,
+// 16x32, 32x16, 8x32: least patch overlap + cache-line waste).  Their map targets span a (16*sx+6) x (16*sy+6) patch of
+// the rectified key frame (sx, sy ~ 2.75):
+//   1. the patch is loaded ONCE into LDS as u16 disparities (stale tags -> 0, cells outside the frame -> 0); the key
+//      frame is column-major, so the patch is `cols` contiguous runs -> paired 16-byte loads, 8 in flight per thread;
+//   2. the 7-tap max along rows is taken once per patch cell with 16-byte LDS reads (separable max filter);
+//   3. every pixel then needs 7 LDS reads (one per window column) instead of 49.
+// PMC on the 49-tap version: SQ_LDS_IDX_ACTIVE 3.1 M cycles / dispatch -- it was LDS-bound.
+// Falls back to global reads when the patch does not fit (wild maps).
+#ifndef XM_K2_TILE_MAX
+#define XM_K2_TILE_MAX 5120
+#endif
+#ifndef XM_K2_TX
+#define XM_K2_TX 16
+#define XM_K2_TY 16
+#endif
+constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX;  // 2 x 10 KB of u16: >= 6 blocks per CU, so all
+                                                                    // 1200 blocks of a 640x480 frame are resident at once
+
+__device__ inline uint16_t key_disp(u64 k, u32 tag) { return (u32)(k >> KEY_TAG_SHIFT) == tag ? (uint16_t)(k & 0xffff) : (uint16_t)0; }
 
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
                                                                   SlotState* st, u32 tag_override,
                                                                   float* __restrict__ depth, uint8_t* __restrict__ bgr) {
-  __shared__ uint16_t tile[K2_TILE_MAX];
-  __shared__ int s_box[4][4];
+  __shared__ __attribute__((aligned(16))) uint16_t tile[K2_TILE_MAX + 16];  // +16: the last 16-byte read may overrun
+  __shared__ __attribute__((aligned(16))) uint16_t vmax[K2_TILE_MAX];
+  constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
+  __shared__ int s_box[NW][4];
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
   const u32 tag = tag_override ? tag_override : st->tag_a;
@@ -900,7 +1044,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     x0 = min(x0, s_box[w][0]);
     x1 = max(x1, s_box[w][1]);
     y0 = min(y0, s_box[w][2]);
@@ -908,41 +1052,89 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   }
   float d = 0.0f;
   if (x1 >= x0) {  // at least one pixel of the tile maps into the frame
-    const int cols = x1 - x0 + 7, rows = y1 - y0 + 7;  // patch incl. the 3-cell dilate margin
-    if (cols * rows <= K2_TILE_MAX) {
-      const int bx = x0 - 3, by = y0 - 3;
-      const int total = cols * rows;
-      const float inv_rows = 1.0f / (float)rows;
-      constexpr int UN = 8, NT = K2_TX * K2_TY;
-      for (int i0 = tid; i0 < total; i0 += UN * NT) {  // UN independent 8-byte loads in flight per thread
-        u64 k[UN];
-        bool inside[UN];
+    const int bx = x0 - 3, by = (y0 - 3) & ~1;          // patch origin (rows start on an even row: 16-byte aligned pairs)
+    const int cols = x1 + 3 - bx + 1, rows = y1 + 3 - by + 1;
+    const int rows_p = (rows + 7) & ~7;                  // column stride in LDS: 16-byte aligned runs
+    if (cols * rows_p <= K2_TILE_MAX) {
+      constexpr int UN = 8;
+      if ((tb.rect_h & 1) == 0) {
+        // pairs of cells (gy, gy+1), gy even: one 16-byte load; in-frame iff 0 <= gy < rect_h (rect_h even)
+        const int half = rows_p >> 1, total = cols * half;
+        // (c, rp) = divmod(i, half) advanced incrementally: i -> i + NT is (c + dq, rp + dr) with one carry
+        const int dq = NT / half, dr = NT - dq * half;
+        int c_i = tid / half, rp_i = tid - c_i * half;
+        for (int i0 = tid; i0 < total; i0 += UN * NT) {
+          ulonglong2 k[UN];
+          bool inside[UN];
 #pragma unroll
-        for (int j = 0; j < UN; ++j) {  // unconditional loads (coordinates clamped into the frame), select afterwards
-          const int i = min(i0 + j * NT, total - 1);
-          int c = (int)((float)i * inv_rows), r = i - c * rows;  // i / rows without the integer divide
-          if (r < 0) { c -= 1; r += rows; }
-          if (r >= rows) { c += 1; r -= rows; }
-          const int gx = bx + c, gy = by + r;
-          inside[j] = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
-          const int cx = min(max(gx, 0), tb.rect_w - 1), cy = min(max(gy, 0), tb.rect_h - 1);
-          k[j] = keys[(u32)cx * (u32)tb.rect_h + (u32)cy];
+          for (int j = 0; j < UN; ++j) {  // unconditional loads (coordinates clamped into the frame), select afterwards
+            const int gx = bx + c_i, gy = by + 2 * rp_i;
+            inside[j] = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
+            const int cx = min(max(gx, 0), tb.rect_w - 1), cy = min(max(gy, 0), tb.rect_h - 2);
+            k[j] = *reinterpret_cast<const ulonglong2*>(keys + ((u32)cx * (u32)tb.rect_h + (u32)cy));
+            c_i += dq;
+            rp_i += dr;
+            if (rp_i >= half) { rp_i -= half; c_i += 1; }
+          }
+#pragma unroll
+          for (int j = 0; j < UN; ++j) {
+            const int i = i0 + j * NT;
+            if (i < total) {
+              const u32 pr = inside[j] ? ((u32)key_disp(k[j].x, tag) | ((u32)key_disp(k[j].y, tag) << 16)) : 0u;
+              reinterpret_cast<u32*>(tile)[i] = pr;  // tile[c * rows_p + 2 * rp] (+1): i == c * half + rp
+            }
+          }
         }
+      } else {
+        const int total = cols * rows_p;
+        const float inv_rows = 1.0f / (float)rows_p;
+        for (int i0 = tid; i0 < total; i0 += UN * NT) {
+          u64 k[UN];
+          bool inside[UN];
 #pragma unroll
-        for (int j = 0; j < UN; ++j) {
-          const int i = i0 + j * NT;
-          if (i < total) tile[i] = (inside[j] && (u32)(k[j] >> KEY_TAG_SHIFT) == tag) ? (uint16_t)(k[j] & 0xffff) : (uint16_t)0;
+          for (int j = 0; j < UN; ++j) {
+            const int i = min(i0 + j * NT, total - 1);
+            int c = (int)((float)i * inv_rows), r = i - c * rows_p;
+            if (r < 0) { c -= 1; r += rows_p; }
+            if (r >= rows_p) { c += 1; r -= rows_p; }
+            const int gx = bx + c, gy = by + r;
+            inside[j] = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
+            const int cx = min(max(gx, 0), tb.rect_w - 1), cy = min(max(gy, 0), tb.rect_h - 1);
+            k[j] = keys[(u32)cx * (u32)tb.rect_h + (u32)cy];
+          }
+#pragma unroll
+          for (int j = 0; j < UN; ++j) {
+            const int i = i0 + j * NT;
+            if (i < total) tile[i] = inside[j] ? key_disp(k[j], tag) : (uint16_t)0;
+          }
+        }
+      }
+      __syncthreads();
+      {  // 7-tap max along the rows of every patch column: 8 outputs per task from 14 inputs (two 16-byte LDS reads)
+        const int nseg = rows_p >> 3, tasks = cols * nseg;
+        for (int t = tid; t < tasks; t += NT) {
+          const uint4 a = *reinterpret_cast<const uint4*>(tile + t * 8);  // task t covers tile[t*8 .. t*8+7] (c*rows_p + 8*seg)
+          const uint4 b = *reinterpret_cast<const uint4*>(tile + t * 8 + 8);
+          u32 e[16];
+          e[0] = a.x & 0xffff; e[1] = a.x >> 16; e[2] = a.y & 0xffff; e[3] = a.y >> 16;
+          e[4] = a.z & 0xffff; e[5] = a.z >> 16; e[6] = a.w & 0xffff; e[7] = a.w >> 16;
+          e[8] = b.x & 0xffff; e[9] = b.x >> 16; e[10] = b.y & 0xffff; e[11] = b.y >> 16;
+          e[12] = b.z & 0xffff; e[13] = b.z >> 16; e[14] = 0; e[15] = 0;
+          u32 o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            o[i] = max(max(max(e[i], e[i + 1]), max(e[i + 2], e[i + 3])), max(max(e[i + 4], e[i + 5]), e[i + 6]));
+          uint4 w;
+          w.x = o[0] | (o[1] << 16); w.y = o[2] | (o[3] << 16); w.z = o[4] | (o[5] << 16); w.w = o[6] | (o[7] << 16);
+          *reinterpret_cast<uint4*>(vmax + t * 8) = w;
         }
       }
       __syncthreads();
       if (valid) {
+        const uint16_t* p = vmax + (mx - 3 - bx) * rows_p + (my - 3 - by);
         u32 best = 0;
-        const uint16_t* p = tile + (mx - x0) * rows + (my - y0);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-#pragma unroll
-          for (int i = 0; i < 7; ++i) best = max(best, (u32)p[j * rows + i]);
-        }
+        for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
         d = (float)best;
       }
     } else if (valid) {
@@ -952,7 +1144,16 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
         for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, cells.at(tb, xx, yy));
     }
   }
-  const PixelOut o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
+  PixelOut o;
+#ifndef XM_K2_NO_DLUT
+  {
+    const uint2 e = tb.dlut[(u32)d & 0xffffu];  // d is an integer disparity here (max of u16 key fields)
+    o.depth = __uint_as_float(e.x);
+    o.bgr = e.y;
+  }
+#else
+  o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
+#endif
   if (depth && in_img) depth[(u32)v * (u32)tb.proj_w + (u32)u] = o.depth;
   if (bgr) {
     const bool full_rows = (tb.proj_w & 3) == 0 && (blockIdx.x + 1) * K2_TX <= tb.proj_w;
@@ -981,7 +1182,8 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
 template <typename Cells>
 __global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixels, double p03, float z_near,
                                                         float z_far, SlotState* st, u32 tag_override, int use_tag,
-                                                        float* __restrict__ depth, uint8_t* __restrict__ bgr) {
+                                                        const uint2* __restrict__ dlut, float* __restrict__ depth,
+                                                        uint8_t* __restrict__ bgr) {
   const u64 pixel = (u64)blockIdx.x * BLOCK + threadIdx.x;
   if constexpr (Cells::keyed) {
     if (use_tag) {
@@ -995,7 +1197,14 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixel
   }
   float d = 0.0f;
   if (pixel < n_pixels) d = cells.get((u32)pixel);
-  const PixelOut o = disparity_pixel(d, p03, z_near, z_far);
+  PixelOut o;
+  if (Cells::keyed && dlut) {  // fused path: integer disparity -> tabulated A5-A7 (see k_build_dlut)
+    const uint2 e = dlut[(u32)d & 0xffffu];
+    o.depth = __uint_as_float(e.x);
+    o.bgr = e.y;
+  } else {
+    o = disparity_pixel(d, p03, z_near, z_far);
+  }
   if (depth && pixel < n_pixels) depth[pixel] = o.depth;
   if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, o.bgr);
 }
