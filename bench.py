@@ -196,16 +196,36 @@ def main():
             dom = 1 if k_ms[1] >= k_ms[2] else 2
         ach = alg[names[dom]] / (k_ms[dom] * 1e-3) / 1e9
         frame_alg = alg["k_scatter"] + alg["k_frame"]
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_run.sh -> profiles/pmc_traffic.json)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            wl = "camera" if args.camera_perspective else "projector"
+            traffic = pt[wl][names[dom]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        pipeline_traffic = None
+        try:
+            tot = sum(pt[wl][k]["hbm_bytes_per_launch"] for k in names)
+            pipeline_traffic = {"hbm_bytes_per_frame_all_kernels": tot,
+                                "GBps_at_measured_step_time": round(tot / (elapsed / args.steps) / 1e9 / world * world, 1),
+                                "frac_of_peak": round(tot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception:
+            pass
         roofline = {
             "bound": "hbm", "kernel": names[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE calibration, MI355X_MICROARCH.md)" if traffic else None,
             "algorithmic_bytes_per_launch": alg[names[dom]],
             "avg_launch_us": {n: round(float(k_ms[i]) * 1e3, 2) for i, n in enumerate(names)},
+            "timing": "HIP start/stop events attached to each dispatch (hipExtLaunchKernelGGL) on the stream it runs on",
+            "empty_event_pair_us": round(eng.profile_event_overhead_ms(15) * 1e3, 2),
             "frame_us_serial": round(float(k_ms[3]) * 1e3, 2),
             "whole_frame": {"algorithmic_bytes": frame_alg,
                             "achieved_GBps_pipelined": round(frame_alg / (elapsed / args.steps) / 1e9, 2),
                             "frac_of_peak_pipelined": round(frame_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
             "event_stream_read_roofline_frac": round(value * 1e6 / world * 14 / 1e9 / HBM_PEAK_GBS, 5),
+            "pipeline_hbm_traffic": pipeline_traffic,
         }
 
         # ---- CPU baseline: NumPy port of the reference path (same pass structure, 1 core), bounded sample ---

@@ -94,8 +94,8 @@ typedef struct xm_frame_stats {
   uint64_t n_inliers;      /* events that passed both inlier masks (xmd:23,29) and were scattered    */
   uint64_t n_index_errors; /* events that would raise IndexError in the reference                    */
   double t_min, t_max;     /* frame extrema of t (over the used events), as double                   */
-  float gpu_ms[4];         /* HIP-event time of {minmax, scatter, frame kernel, whole frame}; filled
-                              only by xm_profile_frame, else 0                                       */
+  float gpu_ms[4];         /* HIP-event time of {minmax, scatter, frame kernel, start of first .. end of
+                              last}; filled only by xm_profile_frame, else 0                           */
 } xm_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -129,8 +129,14 @@ int xm_process_frame_aos(xm_handle* h, const void* eventcd16, size_t n, int use_
 
 int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats);
 
-/* Instrumented run of one frame (device-resident SoA buffers): HIP events around each kernel on the
- * stream they run on; synchronous; stats->gpu_ms filled.  Used by bench.py for the roofline line. */
+/* HIP-event time of an EMPTY event pair on slot 0's stream (milliseconds, median of `reps`): what every
+ * gpu_ms[] interval of xm_profile_frame contains on top of the kernel itself.  bench.py subtracts it. */
+int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out);
+
+/* Instrumented run of one frame (device-resident SoA buffers): each of the three kernels is launched with
+ * hipExtLaunchKernelGGL, i.e. with a start and a stop HIP event attached to its own dispatch packet on the
+ * stream it runs on (the timestamps rocprofv3 --kernel-trace reports); synchronous; stats->gpu_ms filled.
+ * Used by bench.py for the roofline line. */
 int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
                      size_t n, int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
 

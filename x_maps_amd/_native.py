@@ -97,6 +97,7 @@ SYMBOLS = {
     "xm_process_frame_aos": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_last_frame_stats": (C.c_int, [_P, C.POINTER(xm_frame_stats)]),
     "xm_profile_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
+    "xm_profile_event_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "xm_graph_create": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P, C.POINTER(_P)]),
     "xm_graph_launch": (C.c_int, [_P]),
     "xm_graph_destroy": (None, [_P]),

@@ -4,6 +4,8 @@
 // -ffp-contract=off keeps the time normalisation (divide, multiply, rint) unfused = bit-exact with NumPy.
 #include "xmaps_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -100,7 +102,7 @@ struct xm_handle {
   int out_w = 0, out_h = 0;
   u64* stage_frame = nullptr;  // lazily allocated scratch for the stage API (max(rect, cam) cells)
   size_t stage_cells = 0;
-  hipEvent_t prof_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t prof_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr;
   // K1 tiling: LDS windows (time columns / camera columns) and the dynamic LDS they need; 0 = direct kernel
   int w_ts = 0, w_x = 0;
@@ -118,6 +120,22 @@ struct xm_graph {
 };
 
 namespace {
+
+// Profile mode (xm_profile_frame): the three hot-path launches go through hipExtLaunchKernelGGL, which ties a start
+// and a stop event to the dispatch packet itself -- the same timestamps rocprofv3 --kernel-trace reports -- instead
+// of bracketing the launch with hipEventRecord (which adds ~3-5 us of event processing to every interval).
+struct ProfCtx {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+thread_local ProfCtx g_prof;
+
+#define XM_LAUNCH(kernel, grid, block, lds, stream, ...)                                                   \
+  do {                                                                                                      \
+    if (g_prof.start)                                                                                       \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, g_prof.start, g_prof.stop, 0u, __VA_ARGS__); \
+    else                                                                                                    \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                    \
+  } while (0)
 
 inline unsigned grid_for(u64 items, unsigned per_block) {
   u64 g = (items + per_block - 1) / per_block;
@@ -147,13 +165,13 @@ void launch_minmax_t(const EventsView& ev, SlotState* st, u32 tag_override, hipS
   if (grid > 1024) grid = 1024;
   if constexpr (std::is_same<T, long long>::value && !AOS) {
     if (vec2) {
-      hipLaunchKernelGGL((k_minmax<T, false, HAS_P, 2>), dim3(grid), dim3(BLOCK), 0, stream, (const T*)ev.t, ev.p,
-                         (const uint4*)nullptr, n, st, tag_override);
+      XM_LAUNCH((k_minmax<T, false, HAS_P, 2>), dim3(grid), dim3(BLOCK), 0, stream, (const T*)ev.t, ev.p,
+                (const uint4*)nullptr, n, st, tag_override);
       return;
     }
   }
-  hipLaunchKernelGGL((k_minmax<T, AOS, HAS_P, 1>), dim3(grid), dim3(BLOCK), 0, stream, (const T*)ev.t, ev.p,
-                     (const uint4*)ev.aos, n, st, tag_override);
+  XM_LAUNCH((k_minmax<T, AOS, HAS_P, 1>), dim3(grid), dim3(BLOCK), 0, stream, (const T*)ev.t, ev.p,
+            (const uint4*)ev.aos, n, st, tag_override);
 }
 
 void launch_minmax(const EventsView& ev, SlotState* st, u32 tag_override, hipStream_t stream) {
@@ -206,23 +224,23 @@ int launch_scatter_tv(const ScatterArgs& a) {
                                   (int)a.lds));
       lds_set = a.lds;
     }
-    hipLaunchKernelGGL(kern, dim3(grid_for(n, TILE_EVENTS)), dim3(TILE_THREADS), a.lds, a.stream, ev.x, ev.y,
-                       (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-                       a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec16 ? 1 : 0);
+    XM_LAUNCH(kern, dim3(grid_for(n, TILE_EVENTS)), dim3(TILE_THREADS), a.lds, a.stream, ev.x, ev.y,
+              (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
+              a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec16 ? 1 : 0);
     return XM_OK;
   }
   if constexpr (AOS) {
-    hipLaunchKernelGGL((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream,
-                       nullptr, nullptr, (const T*)nullptr, nullptr, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st,
-                       a.tag_override, a.mm_lo, a.mm_hi, a.frame);
+    XM_LAUNCH((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream,
+              (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const T*)nullptr, (const int16_t*)nullptr,
+              (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override, a.mm_lo, a.mm_hi, a.frame);
   } else if (vec) {
-    hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, a.stream,
-                       ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st,
-                       a.tag_override, a.mm_lo, a.mm_hi, a.frame);
+    XM_LAUNCH((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, a.stream,
+              ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st,
+              a.tag_override, a.mm_lo, a.mm_hi, a.frame);
   } else {
-    hipLaunchKernelGGL((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream, ev.x,
-                       ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-                       a.mm_lo, a.mm_hi, a.frame);
+    XM_LAUNCH((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream, ev.x,
+              ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st, a.tag_override,
+              a.mm_lo, a.mm_hi, a.frame);
   }
   return XM_OK;
 }
@@ -248,16 +266,16 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
                          uint8_t* bgr, hipStream_t stream) {
   KeyCells cells{key_frame, 0};
   if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
-    hipLaunchKernelGGL(k_frame_proj_tiled, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
-                       dim3(K2_TX * K2_TY), 0, stream, key_frame, h->tb, st, tag_override, depth, bgr);
+    XM_LAUNCH(k_frame_proj_tiled, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+              dim3(K2_TX * K2_TY), 0, stream, key_frame, h->tb, st, tag_override, depth, bgr);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
     const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
-    hipLaunchKernelGGL((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
-                       tag_override, depth, bgr);
+    XM_LAUNCH((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
+              tag_override, depth, bgr);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
-    hipLaunchKernelGGL((k_frame_direct<KeyCells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, px,
-                       h->tb.p03, h->tb.z_near, h->tb.z_far, st, tag_override, 1, h->tb.dlut, depth, bgr);
+    XM_LAUNCH((k_frame_direct<KeyCells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, px,
+              h->tb.p03, h->tb.z_near, h->tb.z_far, st, tag_override, 1, h->tb.dlut, depth, bgr);
   }
 }
 
@@ -287,16 +305,20 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 #else
   constexpr int skip = 0;
 #endif
-  if (prof) HIP_TRY(hipEventRecord(prof[0], s.stream));
+  // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the three dispatch packets
+  if (prof) g_prof = ProfCtx{prof[0], prof[1]};
   if (!(skip & 1)) launch_minmax(ev, s.st, 0, s.stream);
-  if (prof) HIP_TRY(hipEventRecord(prof[1], s.stream));
+  if (prof) g_prof = ProfCtx{prof[2], prof[3]};
   if (!(skip & 2)) {
     int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.stream);
-    if (rc) return rc;
+    if (rc) {
+      g_prof = ProfCtx{};
+      return rc;
+    }
   }
-  if (prof) HIP_TRY(hipEventRecord(prof[2], s.stream));
+  if (prof) g_prof = ProfCtx{prof[4], prof[5]};
   if (!(skip & 4)) launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, s.stream);
-  if (prof) HIP_TRY(hipEventRecord(prof[3], s.stream));
+  g_prof = ProfCtx{};
   HIP_TRY(hipGetLastError());
   s.host_tag += 1;
   s.any_frame = true;
@@ -398,8 +420,8 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     xm_frame_stats st;
     if ((rc = fetch_stats(h, s, ev.aos ? XM_T_INT64 : ev.t_dtype, &st))) return rc;
     if (profile) {
-      for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[i], h->prof_ev[i + 1]));
-      HIP_TRY(hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[0], h->prof_ev[3]));
+      for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+      HIP_TRY(hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[0], h->prof_ev[5]));  // start of K0 .. end of K2
     }
     if (stats) *stats = st;
     if (st.n_index_errors)
@@ -602,7 +624,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   }
   hipLaunchKernelGGL(k_reset_slot, dim3(1), dim3(BLOCK), 0, h->slots[0].stream, h->aux_st, (u64*)nullptr, (u64)0);
   XM_TRY_CREATE(hipGetLastError());
-  for (int i = 0; i < 4; ++i) XM_TRY_CREATE(hipEventCreate(&h->prof_ev[i]));
+  for (int i = 0; i < 6; ++i) XM_TRY_CREATE(hipEventCreate(&h->prof_ev[i]));
   XM_TRY_CREATE(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
   h->join_ev.resize(n_slots, nullptr);
   for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
@@ -687,6 +709,24 @@ int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats) {
   Slot& s = h->slots[h->last_slot];
   HIP_TRY(hipStreamSynchronize(s.stream));
   return fetch_stats(h, s, XM_T_INT64, stats);
+}
+
+int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
+  if (!h || !ms_out || reps <= 0) return fail(XM_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[0];
+  std::vector<float> v;
+  for (int i = 0; i < reps; ++i) {
+    HIP_TRY(hipEventRecord(h->prof_ev[0], s.stream));
+    HIP_TRY(hipEventRecord(h->prof_ev[1], s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->prof_ev[0], h->prof_ev[1]));
+    v.push_back(ms);
+  }
+  std::sort(v.begin(), v.end());
+  *ms_out = v[v.size() / 2];
+  return XM_OK;
 }
 
 // ---- hipGraph batch ------------------------------------------------------------------------------------

@@ -189,6 +189,11 @@ class XMapsEngine:
                                            _ptr(depth_ptr), _ptr(bgr_ptr), C.byref(st)), index_error_ok=True)
         return FrameStats.from_c(st)
 
+    def profile_event_overhead_ms(self, reps: int = 25) -> float:
+        ms = C.c_float(0)
+        N.check(self._lib.xm_profile_event_overhead(self._h, reps, C.byref(ms)))
+        return float(ms.value)
+
     def last_frame_stats(self) -> FrameStats:
         st = N.xm_frame_stats()
         N.check(self._lib.xm_last_frame_stats(self._h, C.byref(st)))
