@@ -199,6 +199,13 @@ int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float
 /* the stream the shard calls run on (hipStream_t as void*), so the caller can order its collective */
 void* xm_stream(xm_handle* h, int slot);
 
+/* ---- setup-time table construction ("next" row N1) --------------------------------------------------- */
+/* compute_x_map_from_time_map (x_map.py:5-55): rectified projector time map f32 [height][width] (0 = undefined)
+ * -> X-map int16 [height][x_map_width] (values x + x_offset, 0 = undefined) and, optionally, the matched time
+ * differences f32 [height][x_map_width] (t_diffs may be NULL).  Host pointers, synchronous, no handle needed. */
+int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
+                   int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out);
+
 /* ---- small device-memory helpers so that a host without torch can stage buffers ------------------- */
 int xm_dev_alloc(xm_handle* h, size_t bytes, void** out);
 int xm_dev_free(xm_handle* h, void* p);

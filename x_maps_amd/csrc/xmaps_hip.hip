@@ -1108,6 +1108,51 @@ int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float
   return XM_OK;
 }
 
+// ---- N1: X-map construction ----------------------------------------------------------------------------------
+int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
+                   int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out) {
+  if (!time_map || !x_map_out || height <= 0 || width <= 0 || x_map_width <= 0 || t_px_scale <= 0 || num_scanlines <= 0)
+    return fail(XM_ERR_INVALID, "bad argument");
+  if (height > 32767 || width + x_offset > 32767) return fail(XM_ERR_INVALID, "indices must fit int16 (x_maps_disparity.py:52-53)");
+  if ((size_t)width * sizeof(double) > 150 * 1024) return fail(XM_ERR_INVALID, "time-map row does not fit LDS");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(XM_ERR_HIP, "no HIP device visible");
+  HIP_TRY(hipSetDevice(device));
+  const size_t n_in = (size_t)height * width, n_out = (size_t)height * x_map_width;
+  float* d_in = nullptr;
+  int16_t* d_x = nullptr;
+  float* d_d = nullptr;
+  int rc = XM_OK;
+  do {
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_in, n_in * 4)) != hipSuccess || (e = hipMalloc((void**)&d_x, n_out * 2)) != hipSuccess ||
+        (t_diffs_out && (e = hipMalloc((void**)&d_d, n_out * 4)) != hipSuccess) ||
+        (e = hipMemcpy(d_in, time_map, n_in * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+      rc = fail(XM_ERR_HIP, "xm_build_x_map: %s", hipGetErrorString(e));
+      break;
+    }
+    const size_t lds = (size_t)width * sizeof(double);
+    if (lds > 64 * 1024 &&
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_x_map), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds)) != hipSuccess) {
+      rc = fail(XM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      break;
+    }
+    hipLaunchKernelGGL(k_build_x_map, dim3(height), dim3(BLOCK), lds, 0, d_in, height, width, x_map_width, t_px_scale,
+                       x_offset, 2.0 / (double)num_scanlines, d_x, d_d);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(x_map_out, d_x, n_out * 2, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (t_diffs_out && (e = hipMemcpy(t_diffs_out, d_d, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess)) {
+      rc = fail(XM_ERR_HIP, "xm_build_x_map: %s", hipGetErrorString(e));
+      break;
+    }
+  } while (0);
+  if (d_in) (void)hipFree(d_in);
+  if (d_x) (void)hipFree(d_x);
+  if (d_d) (void)hipFree(d_d);
+  return rc;
+}
+
 // ---- device memory helpers ----------------------------------------------------------------------------------
 int xm_dev_alloc(xm_handle* h, size_t bytes, void** out) {
   if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");

@@ -1331,6 +1331,47 @@ __global__ __launch_bounds__(BLOCK) void k_debug_events(const uint16_t* __restri
   if (mask) mask[i] = r.inlier ? 1 : 0;
 }
 
+// =====================================================================================================
+// N1 (setup time): X-map construction, reference python/x_map.py:5-55 (Numba prange over rows).
+//   x_map[y, c] = X_OFFSET + argmin_x |c / t_px_scale - time_map[y, x]|   over cells with time_map != 0,
+//   FIRST minimum wins (strict <), kept only if the minimum is <= 2 / num_scanlines; c == 0 (t == 0) is skipped.
+// All arithmetic in FP64 with the f32 map widened (what Numba does).  One block per rectified row: the row is
+// staged in LDS as f64 once, every thread owns one time column and scans the row out of LDS (all lanes read the
+// same address -> broadcast, conflict-free).  H*W_t*W compares = 1.5 G for the C-1M tables: ~1 ms here.
+// =====================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_build_x_map(const float* __restrict__ time_map, int height, int width,
+                                                       int x_map_width, int t_px_scale, int x_offset,
+                                                       double max_t_diff, int16_t* __restrict__ x_map,
+                                                       float* __restrict__ t_diffs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* row = reinterpret_cast<double*>(smem);
+  const int y = blockIdx.x;
+  for (int x = threadIdx.x; x < width; x += BLOCK) row[x] = (double)time_map[(size_t)y * width + x];
+  __syncthreads();
+  for (int c = threadIdx.x; c < x_map_width; c += BLOCK) {
+    int16_t out = 0;
+    float out_d = 0.0f;
+    const double t = (double)c / (double)t_px_scale;
+    if (t != 0.0) {
+      double best = __builtin_inf();
+      int best_x = -1;
+      for (int x = 0; x < width; ++x) {
+        const double m = row[x];
+        const double d = fabs(t - m);
+        const bool take = (m != 0.0) && (d < best);  // zero cells are undefined; strict < keeps the first minimum
+        best = take ? d : best;
+        best_x = take ? x : best_x;
+      }
+      if (best_x != -1 && best <= max_t_diff) {
+        out = (int16_t)(best_x + x_offset);
+        out_d = (float)best;
+      }
+    }
+    x_map[(size_t)y * x_map_width + c] = out;
+    if (t_diffs) t_diffs[(size_t)y * x_map_width + c] = out_d;
+  }
+}
+
 // slot (re)initialisation: zero the key frame, arm min/max + counters, tag = 0
 __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells) {
   const u64 stride = (u64)gridDim.x * BLOCK;
