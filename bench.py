@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true", help="also time the PCIe-inclusive host->host call")
     ap.add_argument("--no-parity", action="store_true", help="EXPERIMENTS ONLY (ablation builds): skip the parity gate")
+    ap.add_argument("--assume-sorted", action="store_true",
+                    help="XM_FLAG_TIME_SORTED: extrema = t[0], t[n-1], verified on the device; the extrema pass K0 is skipped")
     return ap.parse_args()
 
 
@@ -75,7 +77,8 @@ def main():
 
     cfg = S.C_1M
     tables = S.make_tables(cfg)
-    eng = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots)
+    eng = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots,
+                      assume_time_sorted=args.assume_sorted)
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 
@@ -280,7 +283,8 @@ def main():
             "config": {"workload": "C-1M: synthetic 1M events/frame, 640x480 cam/proj, rect 1760x1320, 1xMI355X fused kernels"
                        + (" (camera view)" if args.camera_perspective else " (projector view)"),
                        "events_per_frame": n_ev, "frames_in_flight": args.slots, "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
-                       "launch": "hipGraph" if args.graph else "eager", "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM"},
+                       "launch": "hipGraph" if args.graph else "eager", "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM",
+                       "time_sorted_declared": bool(args.assume_sorted)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "host_enqueue_us_per_step": round((t_enqueued - t0) / args.steps * 1e6, 2),
         }

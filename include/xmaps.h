@@ -43,6 +43,18 @@ extern "C" {
                                 IndexError in the reference.  The frame is still produced with the
                                 offending events dropped; stats.n_index_errors counts them.        */
 #define XM_ERR_TOO_MANY (-5) /* more events in one frame than the key's index field can hold       */
+#define XM_ERR_UNSORTED (-6) /* XM_FLAG_TIME_SORTED was set but a frame processed asynchronously since the
+                                last xm_sync() was not sorted by t: its output is invalid (see the flag)  */
+
+/* xm_config.flags */
+#define XM_FLAG_TIME_SORTED 1u /* The caller declares every frame sorted by t -- true for the frames the trigger
+                                  finder cuts out of the camera stream (trigger_finder.py:172) unless a frame event
+                                  filter re-ordered them.  Then (tmin, tmax) = (t[0], t[n-1]) and the extrema pass
+                                  (K0, 8 B/event re-read) is skipped.  The declaration is VERIFIED on the device for
+                                  every frame: synchronous calls (XM_MEM_HOST) transparently redo an unsorted frame on
+                                  the general path (result always exact); asynchronous calls report it through
+                                  xm_frame_stats.n_unsorted and xm_sync() -> XM_ERR_UNSORTED.  Ignored when a polarity
+                                  column is given. */
 
 /* view (RuntimeParams.camera_perspective, depth_reprojection_processor.py:34) */
 #define XM_VIEW_PROJECTOR 0
@@ -77,7 +89,7 @@ typedef struct xm_config {
   int32_t x_offset;                /* X_OFFSET = 4242 (xmd:49); must fit int16                     */
   int32_t view;                    /* XM_VIEW_*                                                    */
   int32_t n_slots;                 /* frames that may be in flight at once (>=1; own stream each)  */
-  int32_t reserved0;
+  uint32_t flags;                  /* XM_FLAG_*                                                    */
   double p03;                      /* P2[0,3] (calib:207, d2d:104-107)                              */
   float z_near, z_far;             /* d2d:71-72                                                     */
   /* host tables, reference layouts (row-major int16); copied + re-packed for the device in xm_create */
@@ -96,6 +108,8 @@ typedef struct xm_frame_stats {
   double t_min, t_max;     /* frame extrema of t (over the used events), as double                   */
   float gpu_ms[4];         /* HIP-event time of {minmax, scatter, frame kernel, start of first .. end of
                               last}; filled only by xm_profile_frame, else 0                           */
+  uint64_t n_unsorted;     /* XM_FLAG_TIME_SORTED: > 0 if the frame was NOT sorted (wavefronts that saw an event
+                              outside [t[0], t[n-1]]); synchronous calls have already redone such a frame    */
 } xm_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -103,7 +117,7 @@ int xm_api_version(void);
 const char* xm_last_error(void);
 int xm_create(const xm_config* cfg, xm_handle** out);
 void xm_destroy(xm_handle* h);
-int xm_sync(xm_handle* h); /* wait for everything enqueued on every slot of the handle */
+int xm_sync(xm_handle* h); /* wait for everything enqueued on every slot of the handle; XM_ERR_UNSORTED see above */
 
 /* ---- the fused hot path: one projector frame of events -> depth frame (+ BGR) -------------------- */
 /*

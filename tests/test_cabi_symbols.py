@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_struct_layouts_match_the_header():
     # xm_config: 14 int32 + double + 2 float + 4 pointers; xm_frame_stats: 4 u64 + 2 double + 4 float
     assert ctypes.sizeof(N.xm_config) == 14 * 4 + 8 + 2 * 4 + 4 * 8
-    assert ctypes.sizeof(N.xm_frame_stats) == 4 * 8 + 2 * 8 + 4 * 4
+    assert ctypes.sizeof(N.xm_frame_stats) == 4 * 8 + 2 * 8 + 4 * 4 + 8
     assert N.xm_config.p03.offset == 56 and N.xm_config.cam_mapx_i16.offset == 72
 
 

@@ -182,3 +182,39 @@ def test_shard_calls_merge_to_the_single_frame(camera):
                                  camera_perspective=camera)
             # the projector-view key frame lives column-major in HBM ([col][row]); the camera-view one row-major
             assert np.array_equal(merged.cpu().numpy().astype(np.uint64), kf_ref if camera else kf_ref.T)
+
+
+def test_time_sorted_mode_is_exact_and_verified():
+    """XM_FLAG_TIME_SORTED: sorted frames skip the extrema pass and give the same frame; an unsorted frame is detected on
+    the device -- redone transparently by the synchronous call, reported by xm_sync for asynchronous ones."""
+    torch = pytest.importorskip("torch")
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    srt = S.make_events(cfg, frame=1)
+    uns = S.make_events(cfg, frame=2, shuffled=True)
+    with XMapsEngine(tb, assume_time_sorted=True, n_slots=2) as eng:
+        for evs, expect_flag in ((srt, False), (uns, True), (srt, False)):
+            x, y, t, _ = S.to_soa(evs)
+            ref = _ref(tb, evs)
+            d, b, st = eng.process_frame(x, y, t)
+            assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+            assert (st.n_unsorted > 0) == expect_flag and st.n_inliers == int(ref["mask"].sum())
+            assert st.t_min == t.min() and st.t_max == t.max() and st.n_used == len(t)
+            d2, _, st2 = eng.process_events(evs)
+            assert np.array_equal(d2, ref["depth"]) and (st2.n_unsorted > 0) == expect_flag
+        eng.sync()  # synchronous fallbacks already handled: no error pending
+        # asynchronous path: the sorted frame is fine, the unsorted one makes xm_sync fail loudly
+        dev = torch.device("cuda", 0)
+        out = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+        for evs, bad in ((srt, False), (uns, True)):
+            x, y, t, _ = S.to_soa(evs)
+            X, Y, T = (torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t))
+            torch.cuda.synchronize()
+            eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), out.data_ptr(), None)
+            if bad:
+                with pytest.raises(ValueError):
+                    eng.sync()
+                eng.sync()  # the error is reported once
+            else:
+                eng.sync()
+                assert np.array_equal(out.cpu().numpy(), _ref(tb, evs)["depth"])

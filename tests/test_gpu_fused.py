@@ -164,3 +164,58 @@ def test_out_of_sensor_event_raises_index_error():
             eng.process_frame(x, y, t)
     with pytest.raises(IndexError):
         O.rectify_cam_coords_i16(tb["cam_mapx_i16"], tb["cam_mapy_i16"], x.astype(np.int64), y.astype(np.int64))
+
+
+def test_c10m_full_size_matches_c_oracle():
+    """BASELINE config 4 shapes (1280x720, rect 3520x1980, 10 M events) on one GPU vs the C oracle (all host cores)."""
+    from c_oracle import COracle
+    cfg = S.C_10M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg)
+    x, y, t, _ = S.to_soa(evs)
+    ref = COracle(tb, False, omp=True).process_ev_frame(x, y, t)
+    with XMapsEngine(tb) as eng:
+        depth, bgr, st = eng.process_frame(x, y, t)
+    assert st.n_inliers == ref["n_inliers"] and st.n_index_errors == 0
+    assert np.array_equal(depth, ref["depth"]) and np.array_equal(bgr, ref["bgr"])
+
+
+def test_c1m_direct_kernels_match_tiled(monkeypatch):
+    """The one-thread-per-event kernels (XM_K1_DIRECT / XM_K2_DIRECT, also the automatic fallback for tables that do not
+    fit LDS) give the same frame as the tiled ones."""
+    tb = S.make_tables(S.C_1M)
+    evs = S.make_events(S.C_1M, frame=2)
+    x, y, t, _ = S.to_soa(evs)
+    with XMapsEngine(tb) as eng:
+        d0, b0, s0 = eng.process_frame(x, y, t)
+    monkeypatch.setenv("XM_K1_DIRECT", "1")
+    monkeypatch.setenv("XM_K2_DIRECT", "1")
+    with XMapsEngine(tb) as eng:
+        d1, b1, s1 = eng.process_frame(x, y, t)
+    assert np.array_equal(d0, d1) and np.array_equal(b0, b1) and s0.n_inliers == s1.n_inliers
+
+
+def test_order_invariance_property_full_size():
+    """Domain property at full size: events hitting DIFFERENT cells commute.  Reversing the frame changes which event
+    is 'last' per cell, but a frame whose events are de-duplicated per cell beforehand must not depend on order."""
+    tb = S.make_tables(S.C_1M)
+    evs = S.make_events(S.C_1M, frame=5)
+    x, y, t, _ = S.to_soa(evs)
+    with XMapsEngine(tb) as eng:
+        dbg = eng.debug_event_outputs(x, y, t)
+        m = dbg["mask"]
+        cell = dbg["yr"][m].astype(np.int64) * 100000 + (dbg["xr"][m].astype(np.int64) + dbg["disp"][m])
+        # keep the last event of every cell, in original order
+        idx = np.nonzero(m)[0]
+        _, last_pos = np.unique(cell[::-1], return_index=True)
+        keep = np.sort(idx[len(idx) - 1 - last_pos])
+        d_full, _, _ = eng.process_frame(x, y, t)
+        # same extrema are needed for identical time columns: re-attach the frame's first and last event
+        tmin_i, tmax_i = int(np.argmin(t)), int(np.argmax(t))
+        keep = np.unique(np.concatenate((keep, [tmin_i, tmax_i])))
+        perm = np.random.default_rng(0).permutation(len(keep))
+        d_sub, _, _ = eng.process_frame(x[keep], y[keep], t[keep])
+        d_perm, _, _ = eng.process_frame(x[keep][perm], y[keep][perm], t[keep][perm])
+    assert np.array_equal(d_sub, d_perm)
+    # and de-duplication itself does not change the frame unless the two re-attached events win a cell they lost before
+    assert (d_full != d_sub).mean() < 1e-4

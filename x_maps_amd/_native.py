@@ -19,7 +19,8 @@ DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", "xmaps_kernels.hpp"),
                      os.path.join(ROOT, "include", "xmaps.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
-XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY = 0, -1, -2, -3, -4, -5
+XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY, XM_ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6
+XM_FLAG_TIME_SORTED = 1
 XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
 XM_MEM_HOST, XM_MEM_DEVICE = 0, 1
 XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2
@@ -70,7 +71,7 @@ class xm_config(C.Structure):
         ("proj_width", C.c_int32), ("proj_height", C.c_int32),
         ("rect_width", C.c_int32), ("rect_height", C.c_int32),
         ("xmap_width", C.c_int32), ("xmap_height", C.c_int32),
-        ("x_offset", C.c_int32), ("view", C.c_int32), ("n_slots", C.c_int32), ("reserved0", C.c_int32),
+        ("x_offset", C.c_int32), ("view", C.c_int32), ("n_slots", C.c_int32), ("flags", C.c_uint32),
         ("p03", C.c_double), ("z_near", C.c_float), ("z_far", C.c_float),
         ("cam_mapx_i16", C.c_void_p), ("cam_mapy_i16", C.c_void_p),
         ("proj_x_map", C.c_void_p), ("disp_proj_mapxy_i16", C.c_void_p),
@@ -81,7 +82,7 @@ class xm_frame_stats(C.Structure):
     _fields_ = [
         ("n_events", C.c_uint64), ("n_used", C.c_uint64), ("n_inliers", C.c_uint64),
         ("n_index_errors", C.c_uint64), ("t_min", C.c_double), ("t_max", C.c_double),
-        ("gpu_ms", C.c_float * 4),
+        ("gpu_ms", C.c_float * 4), ("n_unsorted", C.c_uint64),
     ]
 
 
@@ -158,7 +159,7 @@ def check(rc: int, *, index_error_ok: bool = False) -> int:
         if index_error_ok:
             return rc
         raise IndexError(msg)  # NumPy fancy indexing out of range
-    if rc == XM_ERR_INVALID or rc == XM_ERR_TOO_MANY:
+    if rc == XM_ERR_INVALID or rc == XM_ERR_TOO_MANY or rc == XM_ERR_UNSORTED:
         raise ValueError(msg)
     if rc == XM_ERR_NOMEM:
         raise MemoryError(msg)

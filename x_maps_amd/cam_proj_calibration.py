@@ -41,6 +41,7 @@ class CamProjMaps:
     camera_perspective: bool = False
     device: int = 0
     n_slots: int = 1
+    assume_time_sorted: bool = False
     engine: XMapsEngine = field(init=False)
 
     def __post_init__(self):
@@ -56,7 +57,7 @@ class CamProjMaps:
         self.P2 = np.zeros((3, 4))
         self.P2[0, 3] = float(tb["p03"])
         self.engine = XMapsEngine(tb, camera_perspective=self.camera_perspective, device=self.device,
-                                  n_slots=self.n_slots)
+                                  n_slots=self.n_slots, assume_time_sorted=self.assume_time_sorted)
 
     def rectify_cam_coords_i16(self, events):
         x, y = _events_xy(events)

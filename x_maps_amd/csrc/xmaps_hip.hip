@@ -68,6 +68,7 @@ struct Slot {
   SlotState* st = nullptr;  // device
   u32 host_tag = 0;         // mirrors st->tag_a after the enqueued work has run
   bool any_frame = false;
+  bool last_sorted = false;
   uint64_t last_n = 0;
   // staging for XM_MEM_HOST calls
   DevBuf ev_x, ev_y, ev_t, ev_p, ev_aos, out_depth, out_bgr, dbg[5];
@@ -108,6 +109,8 @@ struct xm_handle {
   int w_ts = 0, w_x = 0;
   size_t k1_lds = 0;
   bool k1_direct = false, k2_direct = false;
+  bool time_sorted = false;   // XM_FLAG_TIME_SORTED
+  uint64_t sorted_fallbacks = 0;
   std::vector<hipEvent_t> join_ev;
 };
 
@@ -208,6 +211,7 @@ struct ScatterArgs {
   int w_ts, w_x;
   size_t lds;
   bool direct;
+  bool sorted;
 };
 
 template <typename T, bool AOS, bool HAS_P, int VIEW>
@@ -226,7 +230,7 @@ int launch_scatter_tv(const ScatterArgs& a) {
     }
     XM_LAUNCH(kern, dim3(grid_for(n, TILE_EVENTS)), dim3(TILE_THREADS), a.lds, a.stream, ev.x, ev.y,
               (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-              a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec16 ? 1 : 0);
+              a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec16 ? 1 : 0, a.sorted ? 1 : 0);
     return XM_OK;
   }
   if constexpr (AOS) {
@@ -251,9 +255,9 @@ int launch_scatter_t(const ScatterArgs& a) {
 }
 
 int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_override, u64 idx_offset, u64 mm_lo,
-                   u64 mm_hi, u64* frame, hipStream_t stream) {
+                   u64 mm_hi, u64* frame, hipStream_t stream, bool sorted = false) {
   ScatterArgs a{&ev, &h->tb, h->cfg.view, st, tag_override, idx_offset, mm_lo, mm_hi, frame, stream,
-                h->w_ts, h->w_x, h->k1_lds, h->k1_direct};
+                h->w_ts, h->w_x, h->k1_lds, h->k1_direct, sorted};
   if (ev.aos) return ev.use_p ? launch_scatter_t<long long, true, true>(a) : launch_scatter_t<long long, true, false>(a);
   switch (ev.t_dtype) {
     case XM_T_INT64: return ev.use_p ? launch_scatter_t<long long, false, true>(a) : launch_scatter_t<long long, false, false>(a);
@@ -295,7 +299,13 @@ int check_events(const EventsView& ev) {
 }
 
 // enqueue K0 -> K1 -> K2 for one frame on a slot.  All pointers are device pointers.
-int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof) {
+bool sorted_path(const xm_handle* h, const EventsView& ev) {
+  return h->time_sorted && !ev.use_p && !h->k1_direct && h->w_ts > 0 && h->w_x > 0;
+}
+
+int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,
+                  bool allow_sorted = true) {
+  const bool sorted = allow_sorted && sorted_path(h, ev);
   if (s.host_tag >= KEY_MAX_TAG) {  // tag field about to wrap: clear the frame once per 2^19 frames
     int rc = reset_slot(h, s);
     if (rc) return rc;
@@ -307,10 +317,10 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 #endif
   // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the three dispatch packets
   if (prof) g_prof = ProfCtx{prof[0], prof[1]};
-  if (!(skip & 1)) launch_minmax(ev, s.st, 0, s.stream);
+  if (!(skip & 1) && !sorted) launch_minmax(ev, s.st, 0, s.stream);
   if (prof) g_prof = ProfCtx{prof[2], prof[3]};
   if (!(skip & 2)) {
-    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.stream);
+    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.stream, sorted);
     if (rc) {
       g_prof = ProfCtx{};
       return rc;
@@ -323,6 +333,7 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
   s.host_tag += 1;
   s.any_frame = true;
   s.last_n = ev.n;
+  s.last_sorted = sorted;
   return XM_OK;
 }
 
@@ -349,7 +360,9 @@ int fetch_stats(xm_handle* h, Slot& s, int t_dtype, xm_frame_stats* out) {
     out->n_used += hs.cnt[parity][i][CNT_USED];
     out->n_inliers += hs.cnt[parity][i][CNT_INLIER];
     out->n_index_errors += hs.cnt[parity][i][CNT_OOB];
+    out->n_unsorted += hs.cnt[parity][i][CNT_UNSORTED];
   }
+  if (s.last_sorted) out->n_used = s.last_n;  // no polarity column on the time-sorted path; K0 (which counts) did not run
   bool any;
   if (t_dtype == XM_T_FLOAT32) decode_minmax<float>(hs, parity, out->t_min, out->t_max, any);
   else if (t_dtype == XM_T_FLOAT64) decode_minmax<double>(hs, parity, out->t_min, out->t_max, any);
@@ -420,8 +433,24 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     xm_frame_stats st;
     if ((rc = fetch_stats(h, s, ev.aos ? XM_T_INT64 : ev.t_dtype, &st))) return rc;
     if (profile) {
-      for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
-      HIP_TRY(hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[0], h->prof_ev[5]));  // start of K0 .. end of K2
+      const int first = s.last_sorted ? 1 : 0;  // K0 is not launched on the time-sorted path
+      for (int i = first; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+      HIP_TRY(hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[2 * first], h->prof_ev[5]));  // start of first .. end of K2
+    }
+    if (st.n_unsorted && s.last_sorted) {
+      // the time-sorted declaration did not hold for this frame: redo it on the general path (K0 -> K1 -> K2)
+      h->sorted_fallbacks += 1;
+      if ((rc = enqueue_frame(h, s, ev, d_depth, d_bgr, nullptr, false))) return rc;
+      if (mem == XM_MEM_HOST) {
+        if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
+        if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
+      }
+      HIP_TRY(hipStreamSynchronize(s.stream));
+      const uint64_t flagged = st.n_unsorted;
+      if ((rc = fetch_stats(h, s, ev.aos ? XM_T_INT64 : ev.t_dtype, &st))) return rc;
+      st.n_unsorted = flagged;
+      HIP_TRY(hipMemsetAsync(&s.st->unsorted_sticky, 0, sizeof(u32), s.stream));  // handled here, not an xm_sync error
+      HIP_TRY(hipStreamSynchronize(s.stream));
     }
     if (stats) *stats = st;
     if (st.n_index_errors)
@@ -500,6 +529,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   const int n_slots = cfg->n_slots > 0 ? cfg->n_slots : 1;
   const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
   h->cfg.n_slots = n_slots;
+  h->time_sorted = (cfg->flags & XM_FLAG_TIME_SORTED) != 0;
   h->cfg.xmap_height = xmap_h;
 
 #define XM_TRY_CREATE(expr)                   \
@@ -661,6 +691,19 @@ int xm_sync(xm_handle* h) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->cfg.device));
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  if (h->time_sorted) {  // any asynchronously processed frame that was not sorted after all?
+    u32 bad = 0;
+    for (Slot& s : h->slots) {
+      u32 v = 0;
+      HIP_TRY(hipMemcpy(&v, &s.st->unsorted_sticky, sizeof v, hipMemcpyDeviceToHost));
+      if (v) {
+        bad += v;
+        HIP_TRY(hipMemset(&s.st->unsorted_sticky, 0, sizeof v));
+      }
+    }
+    if (bad) return fail(XM_ERR_UNSORTED, "XM_FLAG_TIME_SORTED: %u wavefront(s) saw events outside [t[0], t[n-1]] -- a frame "
+                         "processed since the last xm_sync was not time-sorted, its output is invalid", bad);
+  }
   return XM_OK;
 }
 

@@ -36,7 +36,7 @@ constexpr int MM_SLOTS = 32;   // spread the min/max atomics over 32 addresses: 
 constexpr int CNT_SLOTS = 64;  // same for the counters
 constexpr int BLOCK = 256;
 
-enum { CNT_USED = 0, CNT_INLIER = 1, CNT_OOB = 2, CNT_STRIDE = 4 };
+enum { CNT_USED = 0, CNT_INLIER = 1, CNT_OOB = 2, CNT_UNSORTED = 3, CNT_STRIDE = 4 };
 
 // HBM layouts (built once in xm_create).  The scan axis is the SLOW axis of every table an event touches:
 // events arrive time-sorted and the projector scans x-slow, so the events of one thread block sit in a band of
@@ -60,7 +60,9 @@ struct SlotState {
   u32 tag_b;
   u32 pad[2];
   u64 mm[2][MM_SLOTS][2];               // [parity][slot]{min, max} in order-preserving u64 encoding
-  u32 cnt[2][CNT_SLOTS][CNT_STRIDE];    // [parity][slot]{used, inliers, index errors, -}
+  u32 cnt[2][CNT_SLOTS][CNT_STRIDE];    // [parity][slot]{used, inliers, index errors, events outside [t[0], t[n-1]]}
+  u32 unsorted_sticky;                  // time-sorted mode: frames whose declaration did not hold (read by xm_sync)
+  u32 pad2[3];
 };
 
 // ---- order-preserving u64 encodings so that one pair of unsigned atomics serves every t dtype ------
@@ -515,7 +517,7 @@ template <typename T, bool AOS, bool HAS_P, int VIEW>
 __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
-    u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, int w_ts, int w_x, int vec_ok) {
+    u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, int w_ts, int w_x, int vec_ok, int sorted_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift)
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
@@ -631,17 +633,44 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   }
   XM_STAMP(1);
 
-  // ---- 2. frame extrema (written by K0) -> time normalisation ---------------------------------------------------------
-  const u32 tag = tag_override ? tag_override : st->tag_a;
+  // ---- 2. frame extrema -> time normalisation.  General mode: written by K0.  Time-sorted mode (the caller declared
+  //         the frame sorted by t, true for every frame the trigger finder emits): extrema = t[0], t[n-1], K0 is not
+  //         launched at all, and the declaration is VERIFIED below (every event must lie inside [t[0], t[n-1]]).
+  const u32 tag = tag_override ? tag_override : (sorted_mode ? st->tag_b + 1 : st->tag_a);
   const u32 parity = tag & 1;
   u64 lo, hi;
   if (tag_override) {
     lo = mm_lo;
     hi = mm_hi;
   } else {
-    load_frame_minmax(st, parity, lo, hi);
+    if (sorted_mode) {
+      T t_first = (T)0, t_last = (T)0;
+      if (n) {
+        if constexpr (AOS) {
+          const uint4 a = aos[0], b = aos[n - 1];
+          t_first = (T)(long long)(((u64)a.w << 32) | a.z);
+          t_last = (T)(long long)(((u64)b.w << 32) | b.z);
+        } else {
+          t_first = ts[0];
+          t_last = ts[n - 1];
+        }
+      }
+      lo = TimeCodec<T>::enc(t_first);
+      hi = TimeCodec<T>::enc(t_last);
+      if (hi < lo) hi = lo;  // not sorted at all: keep the arithmetic defined; the verification flags the frame
+    } else {
+      load_frame_minmax(st, parity, lo, hi);
+    }
     if (blockIdx.x == 0) {
-      if (tid == 0) st->tag_b = tag;
+      if (tid == 0) {
+        if (sorted_mode) {
+          st->tag_a = tag;  // K2 reads tag_a and copies it to tag_b
+          st->mm[parity][0][0] = lo;  // for xm_frame_stats.t_min / t_max
+          st->mm[parity][0][1] = hi;
+        } else {
+          st->tag_b = tag;
+        }
+      }
       if (tid < MM_SLOTS) {  // re-arm the other parity's slots for the next frame on this slot
         st->mm[parity ^ 1][tid][0] = MM_INIT_MIN;
         st->mm[parity ^ 1][tid][1] = MM_INIT_MAX;
@@ -720,6 +749,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   int col[TILE_EPT];
 #pragma unroll
   for (int k = 0; k < TILE_EPT; ++k) col[k] = used[k] ? (XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k])) : 0;
+  if (sorted_mode) {  // verify the time-sorted declaration: 2 compares per event
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      const u64 e = TimeCodec<T>::enc(tt[k]);
+      bad = bad || (used[k] && (e < lo || e > hi));
+    }
+    if (__ballot(bad) && (tid & 63) == 0) {
+      __hip_atomic_fetch_add(&st->cnt[parity][blockIdx.x % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   XM_STAMP(5);
   __syncthreads();  // bands + cleared slots visible
   XM_STAMP(6);
@@ -968,6 +1009,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
     if (!tag_override && blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {  // re-arm the next frame's counters
       u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
       c[0] = c[1] = c[2] = c[3] = 0;
+      if (threadIdx.x == 0) st->tag_b = tag;
     }
   }
   float d = 0.0f;
@@ -1016,6 +1058,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   if (!tag_override && blockIdx.x == 0 && blockIdx.y == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
     u32* c = st->cnt[(tag & 1) ^ 1][tid];
     c[0] = c[1] = c[2] = c[3] = 0;
+    if (tid == 0) st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
   }
   const int u = blockIdx.x * K2_TX + tx, v = blockIdx.y * K2_TY + ty;
   const bool in_img = u < tb.proj_w && v < tb.proj_h;
@@ -1192,6 +1235,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixel
       if (!tag_override && blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {
         u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
         c[0] = c[1] = c[2] = c[3] = 0;
+        if (threadIdx.x == 0) st->tag_b = tag;
       }
     }
   }
@@ -1380,6 +1424,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __rest
     if (threadIdx.x == 0) {
       st->tag_a = 0;
       st->tag_b = 0;
+      st->unsorted_sticky = 0;
     }
     for (int i = threadIdx.x; i < 2 * MM_SLOTS; i += BLOCK) {
       st->mm[i / MM_SLOTS][i % MM_SLOTS][0] = MM_INIT_MIN;

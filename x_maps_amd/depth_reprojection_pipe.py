@@ -57,8 +57,11 @@ class DepthReprojectionPipe:
         cam_h, cam_w = np.asarray(tables["cam_mapx_i16"]).shape
         if (cam_w, cam_h) != (p.camera_width, p.camera_height):
             raise ValueError(f"tables are for a {cam_w}x{cam_h} camera, params say {p.camera_width}x{p.camera_height}")
+        # frames cut out of the camera stream by the trigger finder are time-sorted (NoFilter): let the GPU take
+        # (tmin, tmax) = (t[0], t[-1]) and verify it; an unsorted frame handed to process_ev_frame directly is detected
+        # on the device and redone on the general path inside the same call, so results are exact either way
         self.calib_maps = CamProjMaps(tables, camera_perspective=p.camera_perspective,
-                                      device=getattr(p, "device", 0))
+                                      device=getattr(p, "device", 0), assume_time_sorted=True)
         self.x_maps_disp = XMapsDisparity(self.calib_maps)
         self.disp_to_depth = DisparityToDepth(stats=self.stats_printer, calib_maps=self.calib_maps,
                                               z_near=p.z_near, z_far=p.z_far)

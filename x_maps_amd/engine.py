@@ -25,11 +25,12 @@ class FrameStats:
     t_min: float = 0.0
     t_max: float = 0.0
     gpu_ms: tuple = (0.0, 0.0, 0.0, 0.0)  # minmax, scatter, frame kernel, whole frame (profile only)
+    n_unsorted: int = 0  # time-sorted mode: > 0 if the declaration did not hold for this frame
 
     @staticmethod
     def from_c(s: N.xm_frame_stats) -> "FrameStats":
         return FrameStats(int(s.n_events), int(s.n_used), int(s.n_inliers), int(s.n_index_errors),
-                          float(s.t_min), float(s.t_max), tuple(float(v) for v in s.gpu_ms))
+                          float(s.t_min), float(s.t_max), tuple(float(v) for v in s.gpu_ms), int(s.n_unsorted))
 
 
 def _ptr(a) -> C.c_void_p:
@@ -69,7 +70,8 @@ class XMapsEngine:
       rect_w, rect_h, p03 (= P2[0,3]), z_near, z_far, x_offset (4242)
     """
 
-    def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1):
+    def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1,
+                 assume_time_sorted: bool = False):
         self._lib = N.load_library()
         self._h = C.c_void_p(None)
         mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
@@ -92,6 +94,7 @@ class XMapsEngine:
         cfg.x_offset = int(tables.get("x_offset", 4242))
         cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
         cfg.n_slots = n_slots
+        cfg.flags = N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0
         cfg.p03 = float(tables["p03"])
         cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
         cfg.cam_mapx_i16 = mapx.ctypes.data
