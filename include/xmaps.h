@@ -220,6 +220,20 @@ void* xm_stream(xm_handle* h, int slot);
 int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
                    int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out);
 
+/* ---- per-frame de-duplication filters ("next" row N3), frame_event_filter.py:19-128 --------------------------- */
+#define XM_FILTER_FIRST_PER_YT 1      /* FirstEventPerYTFilter          (:68-97)  cell = (y, xp[i])          */
+#define XM_FILTER_FIRST_PER_XY 2      /* FirstEventPerXYFilter          (:43-65)  cell = (y, x)              */
+#define XM_FILTER_LAST_PER_XY 3       /* LastEventPerXYFilter           (:19-40)                            */
+#define XM_FILTER_MEAN_FIRST_LAST_PER_XY 4 /* MeanFirstLastEventPerXYFilter (:100-128)                       */
+/* EventCD records in (host, n), events with p != 1 are ignored; xp_i16[n] only for XM_FILTER_FIRST_PER_YT.  The
+ * reference sizes its maps map_height = max(y)+1, map_width = max(x)+1 (or max(xp)+1): pass those.  Output: EventCD
+ * records in raster order of the cells (capacity map_height*map_width), *n_out of them.  Synchronous.
+ * intended_semantics == 0 reproduces what the reference computes: its "first event" maps are written through
+ * reversed views (`map[y[::-1], x[::-1]] = t[::-1]`), which NumPy iterates in memory order, so every filter keeps
+ * the LAST event per cell (golden vectors g5_filters).  != 0: the first event, as the class names say. */
+int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, const void* eventcd16_in, size_t n,
+                          const int16_t* xp_i16, int map_height, int map_width, void* eventcd16_out, size_t* n_out);
+
 /* ---- small device-memory helpers so that a host without torch can stage buffers ------------------- */
 int xm_dev_alloc(xm_handle* h, size_t bytes, void** out);
 int xm_dev_free(xm_handle* h, void* p);

@@ -218,3 +218,91 @@ def test_time_sorted_mode_is_exact_and_verified():
             else:
                 eng.sync()
                 assert np.array_equal(out.cpu().numpy(), _ref(tb, evs)["depth"])
+
+
+@pytest.mark.parametrize("sorted_mode", [False, True])
+def test_frame_tag_wraparound_clears_the_key_frame(sorted_mode):
+    """The packed key carries a 19-bit frame tag; after 2^19 - 1 frames on a slot the host enqueues one clear and the
+    tags restart.  Run a slot through the wrap (asynchronous tiny frames) and check frames on both sides of it."""
+    torch = pytest.importorskip("torch")
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    frames = []
+    for f in range(3):
+        evs = S.make_events(cfg, frame=20 + f, n=300)
+        x, y, t, _ = S.to_soa(evs)
+        frames.append((tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t)), _ref(tb, evs)["depth"]))
+    out = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    total = (1 << 19) + 40
+    with XMapsEngine(tb, n_slots=1, assume_time_sorted=sorted_mode) as eng:
+        for i in range(total):
+            (X, Y, T), ref = frames[i % 3]
+            eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, 300, out.data_ptr(), None)
+            if i in (0, 1, (1 << 19) - 3, (1 << 19) - 2, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, total - 1) or i % 100_000 == 0:
+                eng.sync()
+                assert np.array_equal(out.cpu().numpy(), ref), i
+        eng.sync()
+
+
+def test_frame_event_filters_match_reference_golden(golden_dir):
+    """N3: the four de-duplication filters on the GPU vs outputs of the reference's classes (golden G5)."""
+    import os
+    from x_maps_amd import frame_event_filter as F
+    g = np.load(os.path.join(golden_dir, "g5_filters.npz"))
+    ev = np.zeros(len(g["t"]), S.EVENT_CD_DTYPE)
+    ev["x"], ev["y"], ev["t"], ev["p"] = g["x"], g["y"], g["t"], g["p"]
+    tb = S.make_tables(S.C_TINY)
+    with XMapsEngine(tb) as eng:
+        for cls in ("LastEventPerXYFilter", "FirstEventPerXYFilter", "MeanFirstLastEventPerXYFilter", "FirstEventPerYTFilter"):
+            out = getattr(F, cls)(eng).filter_events(ev, g["xp"])
+            assert out.dtype == S.EVENT_CD_DTYPE
+            for fld in ("x", "y", "t", "p"):
+                assert np.array_equal(out[fld], g[f"{cls}_{fld}"]), (cls, fld)
+        # the semantics the class names promise (NOT what the reference computes, see x_maps_amd/frame_event_filter.py)
+        pos = ev[ev["p"] == 1]
+        first = np.full((pos["y"].max() + 1, pos["x"].max() + 1), -1, np.int64)
+        for i in range(len(pos) - 1, -1, -1):
+            first[pos["y"][i], pos["x"][i]] = pos["t"][i]
+        out = F.FirstEventPerXYFilter(eng, intended_semantics=True).filter_events(ev, None)
+        assert np.array_equal(out["t"], first[first >= 0])
+        last = np.full_like(first, -1)
+        last[pos["y"], pos["x"]] = pos["t"]
+        out = F.MeanFirstLastEventPerXYFilter(eng, intended_semantics=True).filter_events(ev, None)
+        assert np.array_equal(out["t"], (first[first >= 0] + last[last >= 0]) // 2)
+        # timestamps beyond 2^31 go through the reference's int32 maps: wrap, like NumPy's unsafe setitem cast
+        big = ev.copy()
+        big["t"] += (1 << 31) + 12345
+        out = F.LastEventPerXYFilter(eng).filter_events(big, None)
+        pos = big[big["p"] == 1]
+        m = np.zeros((pos["y"].max() + 1, pos["x"].max() + 1), np.int32)
+        m[pos["y"], pos["x"]] = pos["t"].astype(np.int32)
+        k = np.zeros_like(m, bool)
+        k[pos["y"], pos["x"]] = True
+        assert np.array_equal(out["t"], m[k].astype(np.int64))
+
+
+def test_pipe_cycles_frame_event_filters_like_the_reference():
+    tb = S.make_tables(S.C_TINY)
+    evs = S.make_events(S.C_TINY, frame=6)
+    got = []
+    st = StatsPrinter()
+    pipe = DepthReprojectionPipe(_params(S.C_TINY, tb), st, got.append)
+    names = []
+    for _ in range(5):
+        pipe.process_ev_frame(evs)
+        pipe.select_next_frame_event_filter()
+        names.append(st.logs[-1])
+    assert [n.split(": ")[1] for n in names] == ["FirstEventPerYTFilter", "FirstEventPerXYFilter", "LastEventPerXYFilter",
+                                                 "MeanFirstLastEventPerXYFilter", "NoFilter"]
+    assert len(got) == 5 and np.array_equal(got[0], _ref(tb, evs)["bgr"])
+    # LastEventPerXY: equivalent to running the oracle on the de-duplicated, raster-ordered events
+    pos = evs[evs["p"] == 1]
+    m = np.full((pos["y"].max() + 1, pos["x"].max() + 1), -1, np.int64)
+    m[pos["y"], pos["x"]] = pos["t"]
+    yy, xx = np.nonzero(m >= 0)
+    dedup = np.zeros(len(yy), S.EVENT_CD_DTYPE)
+    dedup["x"], dedup["y"], dedup["t"], dedup["p"] = xx, yy, m[yy, xx], 1
+    assert np.array_equal(got[3], _ref(tb, dedup)["bgr"])
+    pipe.close()

@@ -1151,6 +1151,51 @@ int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float
   return XM_OK;
 }
 
+// ---- N3: frame event filters ------------------------------------------------------------------------------------
+int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, const void* eventcd16_in, size_t n,
+                          const int16_t* xp_i16, int map_height, int map_width, void* eventcd16_out, size_t* n_out) {
+  if (!h || !n_out || (n && !eventcd16_in)) return fail(XM_ERR_INVALID, "NULL argument");
+  if (filter < FILTER_FIRST_PER_YT || filter > FILTER_MEAN_PER_XY) return fail(XM_ERR_INVALID, "unknown filter %d", filter);
+  if (filter == FILTER_FIRST_PER_YT && n && !xp_i16) return fail(XM_ERR_INVALID, "FirstEventPerYT needs xp_i16");
+  if (n >= 0xffffffffull) return fail(XM_ERR_TOO_MANY, "too many events");
+  *n_out = 0;
+  if (n == 0 || map_height <= 0 || map_width <= 0) return XM_OK;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[0];
+  const size_t cells = (size_t)map_height * map_width;
+  if (cells >= 0x7fffffffull) return fail(XM_ERR_INVALID, "map too large");
+  if (!eventcd16_out) return fail(XM_ERR_INVALID, "NULL output");
+  const u32 n_blocks = (u32)((cells + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  int rc;
+  if ((rc = stage_in(s.ev_aos, eventcd16_in, n * 16, s.stream))) return rc;
+  if (filter == FILTER_FIRST_PER_YT && (rc = stage_in(s.ev_p, xp_i16, n * 2, s.stream))) return rc;
+  // scratch: first[cells] last[cells] pos[cells] sums[n_blocks] total[1]
+  if ((rc = s.dbg[0].reserve((3 * cells + n_blocks + 4) * sizeof(u32)))) return rc;
+  if ((rc = s.dbg[1].reserve(cells * 16))) return rc;
+  u32* first = (u32*)s.dbg[0].p;
+  u32* last = first + cells;
+  u32* pos = last + cells;
+  u32* sums = pos + cells;
+  u32* total = sums + n_blocks;
+  HIP_TRY(hipMemsetAsync(first, 0xff, cells * sizeof(u32), s.stream));
+  HIP_TRY(hipMemsetAsync(last, 0, cells * sizeof(u32), s.stream));
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  hipLaunchKernelGGL(k_filter_scatter, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s.stream, (const uint4*)s.ev_aos.p,
+                     (const int16_t*)s.ev_p.p, (u64)n, filter == FILTER_FIRST_PER_YT ? 1 : 0, map_height, map_width, first,
+                     last, &h->aux_st->cnt[0][0][CNT_OOB]);
+  hipLaunchKernelGGL(k_filter_scan_blocks, dim3(n_blocks), dim3(SCAN_BLOCK), 0, s.stream, last, (u32)cells, pos, sums);
+  hipLaunchKernelGGL(k_filter_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, sums, n_blocks, total);
+  hipLaunchKernelGGL(k_filter_emit, dim3(n_blocks), dim3(SCAN_BLOCK), 0, s.stream, (const uint4*)s.ev_aos.p, first, last, pos,
+                     sums, (u32)cells, map_width, filter, intended_semantics, (uint4*)s.dbg[1].p);
+  HIP_TRY(hipGetLastError());
+  u32 cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, total, sizeof cnt, hipMemcpyDeviceToHost, s.stream));
+  if ((rc = read_oob(h, s.stream, "frame event filter"))) return rc;  // synchronises the stream
+  if (cnt) HIP_TRY(hipMemcpy(eventcd16_out, s.dbg[1].p, (size_t)cnt * 16, hipMemcpyDeviceToHost));
+  *n_out = cnt;
+  return XM_OK;
+}
+
 // ---- N1: X-map construction ----------------------------------------------------------------------------------
 int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
                    int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out) {

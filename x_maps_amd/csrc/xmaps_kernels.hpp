@@ -1416,6 +1416,110 @@ __global__ __launch_bounds__(BLOCK) void k_build_x_map(const float* __restrict__
   }
 }
 
+// =====================================================================================================
+// N3: per-frame de-duplication filters, reference python/frame_event_filter.py:19-128.
+//   LastEventPerXY / FirstEventPerXY / MeanFirstLastEventPerXY: one output event per camera pixel that fired, carrying
+//   the last / first / mean(first,last) timestamp; FirstEventPerYT: one per (row, x_proj) cell carrying the first event's
+//   x and t.  The reference writes `map[y, x] = t` for all events (forward = last writer wins, reversed = first wins) into
+//   int32 maps and reads them back in raster order.  Here: (1) per event, atomic max / min of the event index per cell,
+//   (2) exclusive scan of the occupancy mask (two-level block scan), (3) emit EventCD records in raster order.
+//   Timestamps go through the reference's int32 maps: t_out = (int64)(int32)t, mean = ((int32)a + (int32)b) >> 1.
+//   OBSERVED REFERENCE BEHAVIOUR: the "first" maps are filled with `map[y[::-1], x[::-1]] = t[::-1]`; NumPy (1.26 and
+//   2.2 checked) normalises the negative strides of all operands together and iterates in memory order, so that
+//   statement keeps the LAST event exactly like the forward one.  As the reference actually runs, FirstEventPerXY ==
+//   LastEventPerXY == MeanFirstLast and FirstEventPerYT keeps the last event per (y, x_proj).  `intended == 0`
+//   reproduces that (it is what the golden vectors captured from the reference contain); `intended != 0` gives
+//   the semantics the class names promise.
+// =====================================================================================================
+enum { FILTER_FIRST_PER_YT = 1, FILTER_FIRST_PER_XY = 2, FILTER_LAST_PER_XY = 3, FILTER_MEAN_PER_XY = 4 };
+constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(BLOCK) void k_filter_scatter(const uint4* __restrict__ aos, const int16_t* __restrict__ xp, u64 n,
+                                                          int by_xp, int map_h, int map_w, u32* __restrict__ first_idx,
+                                                          u32* __restrict__ last_idx, u32* __restrict__ oob_count) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint4 r = aos[i];
+  if ((short)(r.y & 0xffff) != 1) return;  // events[events["p"] == 1]
+  int col = by_xp ? (int)xp[i] : (int)(r.x & 0xffff);
+  const int row = (int)(r.x >> 16);
+  if (col < 0) col += map_w;  // NumPy negative index
+  if (col < 0 || col >= map_w || row >= map_h) {
+    atomicAdd(oob_count, 1u);
+    return;
+  }
+  const u32 cell = (u32)row * (u32)map_w + (u32)col;
+  __hip_atomic_fetch_max(&last_idx[cell], (u32)i + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_min(&first_idx[cell], (u32)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exclusive scan of (last_idx != 0) inside each SCAN_BLOCK-cell block; block totals to sums[]
+__global__ __launch_bounds__(SCAN_BLOCK) void k_filter_scan_blocks(const u32* __restrict__ last_idx, u32 n_cells,
+                                                                   u32* __restrict__ pos, u32* __restrict__ sums) {
+  __shared__ u32 s_wave[SCAN_BLOCK / 64];
+  const u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const bool occ = i < n_cells && last_idx[i] != 0;
+  const u64 ballot = __ballot(occ);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32 before = __popcll(ballot & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave[wave] = __popcll(ballot);
+  __syncthreads();
+  u32 base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  if (i < n_cells) pos[i] = base + before;
+  if (threadIdx.x == SCAN_BLOCK - 1) sums[blockIdx.x] = base + before + (occ ? 1u : 0u);
+}
+
+// exclusive scan of the block totals (single block; n_blocks is a few hundred)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_filter_scan_sums(u32* __restrict__ sums, u32 n_blocks, u32* __restrict__ total) {
+  __shared__ u32 s[SCAN_BLOCK];
+  u32 carry = 0;
+  for (u32 b0 = 0; b0 < n_blocks; b0 += SCAN_BLOCK) {
+    const u32 i = b0 + threadIdx.x;
+    const u32 v = i < n_blocks ? sums[i] : 0u;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {  // Hillis-Steele inclusive scan
+      const u32 add = threadIdx.x >= (u32)o ? s[threadIdx.x - o] : 0u;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n_blocks) sums[i] = carry + s[threadIdx.x] - v;
+    const u32 blk_total = s[SCAN_BLOCK - 1];
+    __syncthreads();
+    carry += blk_total;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_filter_emit(const uint4* __restrict__ aos, const u32* __restrict__ first_idx,
+                                                            const u32* __restrict__ last_idx, const u32* __restrict__ pos,
+                                                            const u32* __restrict__ sums, u32 n_cells, int map_w, int filter,
+                                                            int intended, uint4* __restrict__ out) {
+  const u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  if (i >= n_cells) return;
+  const u32 li = last_idx[i];
+  if (!li) return;
+  const u32 o = sums[blockIdx.x] + pos[i];
+  const uint4 last = aos[li - 1];
+  const uint4 first = intended ? aos[first_idx[i]] : last;
+  const int t_first = (int)first.z, t_last = (int)last.z;  // low 32 bits = the reference's int32 maps
+  int t32, x = (int)(i % (u32)map_w);
+  const int y = (int)(i / (u32)map_w);
+  if (filter == FILTER_LAST_PER_XY) t32 = t_last;
+  else if (filter == FILTER_MEAN_PER_XY) t32 = (int)((u32)t_last + (u32)t_first) >> 1;  // int32 wrap, floor division by 2
+  else t32 = t_first;
+  if (filter == FILTER_FIRST_PER_YT) x = (int)(first.x & 0xffff);
+  const long long t64 = (long long)t32;
+  uint4 rec;
+  rec.x = ((u32)(uint16_t)y << 16) | (u32)(uint16_t)x;
+  rec.y = 1u;  // p = True
+  rec.z = (u32)((u64)t64 & 0xffffffffull);
+  rec.w = (u32)((u64)t64 >> 32);
+  out[o] = rec;
+}
+
 // slot (re)initialisation: zero the key frame, arm min/max + counters, tag = 0
 __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells) {
   const u64 stride = (u64)gridDim.x * BLOCK;

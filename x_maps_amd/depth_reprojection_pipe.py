@@ -9,7 +9,7 @@ hot path on the GPU.
 runs six NumPy/Numba/OpenCV stages; here it is one C-ABI call (xm_process_frame_aos) = three HIP kernels,
 and the frame handed to `frame_callback` is a fresh (H, W, 3) uint8 BGR array exactly as before.
 Out of scope in this build: Metavision's ActivityNoiseFilterAlgorithm (closed source), the
-timing watchdog, the optional per-frame de-duplication filters (default NoFilter is what runs).
+timing watchdog.
 """
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ import numpy as np
 
 from .cam_proj_calibration import CamProjMaps, load_tables_npz
 from .disp_to_depth import DisparityToDepth
+from .frame_event_filter import FrameEventFilterProcessor, NoFilter
 from .stats import StatsPrinter
 from .trigger_finder import RobustTriggerFinder
 from .x_maps_disparity import XMapsDisparity
@@ -65,6 +66,7 @@ class DepthReprojectionPipe:
         self.x_maps_disp = XMapsDisparity(self.calib_maps)
         self.disp_to_depth = DisparityToDepth(stats=self.stats_printer, calib_maps=self.calib_maps,
                                               z_near=p.z_near, z_far=p.z_far)
+        self.ev_filter_proc = FrameEventFilterProcessor(self.calib_maps.engine)
         self.trigger_finder = RobustTriggerFinder(projector_fps=p.projector_fps, stats=self.stats_printer,
                                                   frame_callback=self.process_ev_frame)
 
@@ -79,6 +81,12 @@ class DepthReprojectionPipe:
     def process_ev_frame(self, evs):
         if len(evs) == 0:
             raise ValueError("zero-size array to reduction operation minimum which has no identity")  # xmd:12
+        if not isinstance(self.ev_filter_proc.selected_filter(), NoFilter):  # pipe:131-139
+            with self.stats_printer.measure_time("frame ev filter"):
+                n_before = len(evs)
+                xr, _ = self.calib_maps.rectify_cam_coords_i16(evs)
+                evs = self.ev_filter_proc.filter_events(evs, xr)
+                self.stats_printer.add_metric("frame evs filtered out [%]", 100 - len(evs) / n_before * 100)
         if not self.fused:
             return self._process_ev_frame_staged(evs)
         with self.stats_printer.measure_time("x-maps frame (fused)"):
@@ -113,7 +121,8 @@ class DepthReprojectionPipe:
         self.frame_callback(depth_map)
 
     def select_next_frame_event_filter(self):
-        self.stats_printer.log("Selected event filter: NoFilter (the only one in this build)")
+        new_filter = self.ev_filter_proc.select_next_filter()
+        self.stats_printer.log(f"Selected event filter: {new_filter}")
 
     def reset(self):
         self.trigger_finder.reset()

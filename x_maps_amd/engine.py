@@ -285,6 +285,22 @@ class XMapsEngine:
         N.check(self._lib.xm_stage_colorize_depth_from_disp(self._h, _ptr(src), src.shape[0], src.shape[1], _ptr(out)))
         return out
 
+    # ---- N3: per-frame de-duplication filters ------------------------------------------------------------
+    def frame_event_filter(self, filter_id: int, evs: np.ndarray, xp_i16=None, map_shape=None,
+                           intended_semantics: bool = False) -> np.ndarray:
+        from .synthetic import EVENT_CD_DTYPE
+        if evs.dtype != EVENT_CD_DTYPE:
+            evs = evs.astype(EVENT_CD_DTYPE)
+        evs = np.ascontiguousarray(evs)
+        h, w = map_shape
+        out = np.zeros(max(int(h) * int(w), 1), dtype=EVENT_CD_DTYPE)
+        n_out = C.c_size_t(0)
+        xp = None if xp_i16 is None else np.ascontiguousarray(xp_i16, dtype=np.int16)
+        N.check(self._lib.xm_frame_event_filter(self._h, int(filter_id), int(intended_semantics),
+                                                _ptr(evs) if len(evs) else None, len(evs), _ptr(xp),
+                                                int(h), int(w), _ptr(out), C.byref(n_out)))
+        return out[:n_out.value].copy()
+
     # ---- shards (device pointers) ----------------------------------------------------------------------
     def shard_minmax(self, t_ptr, p_ptr, n, t_dtype=N.XM_T_INT64):
         np_dt = {N.XM_T_INT64: np.int64, N.XM_T_FLOAT32: np.float32, N.XM_T_FLOAT64: np.float64}[t_dtype]
