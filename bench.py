@@ -63,7 +63,7 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("XM_BENCH_FORCE_DIST") == "1":  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
@@ -233,7 +233,7 @@ def main():
 
         # ---- CPU baseline: NumPy port of the reference path (same pass structure, 1 core), bounded sample ---
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N = 1 only
             x, y, t = host_frames[0]
             xi, yi = x.astype(np.int64), y.astype(np.int64)
             reps, spent = 0, 0.0

@@ -306,3 +306,35 @@ def test_pipe_cycles_frame_event_filters_like_the_reference():
     dedup["x"], dedup["y"], dedup["t"], dedup["p"] = xx, yy, m[yy, xx], 1
     assert np.array_equal(got[3], _ref(tb, dedup)["bgr"])
     pipe.close()
+
+
+def test_sharded_processor_with_real_nccl_group(tmp_path):
+    """x_maps_amd/sharded.py end to end on the GPU with a real RCCL process group (world_size 1 here; the gloo test covers
+    world_size 2 logic): ExternalStream ordering of the collectives, device tensors, GpuShardProvider."""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from x_maps_amd.sharded import GpuShardProvider, ShardedFrameProcessor
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        with XMapsEngine(tb) as eng:
+            proc = ShardedFrameProcessor(GpuShardProvider(eng, dev), dist)
+            for f in range(3):
+                evs = S.make_events(cfg, frame=30 + f, n=2000 + 500 * f, shuffled=(f == 1))
+                x, y, t, _ = S.to_soa(evs)
+                sh = tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t)) + (None,)
+                torch.cuda.synchronize()
+                depth, bgr = proc.process_shard(sh, 0)
+                eng.sync()
+                torch.cuda.synchronize()
+                ref = _ref(tb, evs)
+                assert np.array_equal(depth.cpu().numpy(), ref["depth"]) and np.array_equal(bgr.cpu().numpy(), ref["bgr"])
+    finally:
+        if created:
+            dist.destroy_process_group()
