@@ -330,3 +330,25 @@ if __name__ == "__main__":
     g3_x_map(ref)
     g4_time_map(ref)
     g5_trigger_and_filters(ref)
+
+
+def g6_calibration_data():
+    """The numbers of the reference's calibration file data/ESL_calib_hhi.yaml (intrinsics, distortion, relative pose and
+    the R1/R2/P1/P2/Q that OpenCV's stereoRectify wrote into it) as a fixture: data, so that GPU-box tests can build
+    realistic tables without /root/reference."""
+    import yaml
+    with open("/root/reference/data/ESL_calib_hhi.yaml") as f:
+        d = yaml.safe_load(f)
+
+    def mat(name):
+        n = d[name]
+        return np.array(n["data"], dtype=np.float64).reshape(n["rows"], n["cols"])
+
+    save("g6_esl_calib.npz", camera_K=mat("camera_intrinsic_matrix"), camera_D=mat("camera_distortion_coefficients"),
+         projector_K=mat("projector_intrinsic_matrix"), projector_D=mat("projector_distortion_coefficients"),
+         R=mat("relative_rotation"), T=mat("relative_translation"), R1=mat("R1"), R2=mat("R2"), P1=mat("P1"), P2=mat("P2"),
+         Q=mat("Q"))
+
+
+if __name__ == "__main__":
+    g6_calibration_data()

@@ -190,8 +190,9 @@ def test_time_sorted_mode_is_exact_and_verified():
     torch = pytest.importorskip("torch")
     cfg = S.C_TINY
     tb = S.make_tables(cfg)
-    srt = S.make_events(cfg, frame=1)
-    uns = S.make_events(cfg, frame=2, shuffled=True)
+    # >= 18.7 K events so that the tiled kernel (which carries the verified shortcut) is chosen for this 64-column X-map
+    srt = S.make_events(cfg, frame=1, n=24_000)
+    uns = S.make_events(cfg, frame=2, n=24_000, shuffled=True)
     with XMapsEngine(tb, assume_time_sorted=True, n_slots=2) as eng:
         for evs, expect_flag in ((srt, False), (uns, True), (srt, False)):
             x, y, t, _ = S.to_soa(evs)
@@ -229,8 +230,9 @@ def test_frame_tag_wraparound_clears_the_key_frame(sorted_mode):
     tb = S.make_tables(cfg)
     dev = torch.device("cuda", 0)
     frames = []
+    n_ev = 20_000 if sorted_mode else 300  # sorted mode: enough events for the tiled kernel (tag derived from tag_b)
     for f in range(3):
-        evs = S.make_events(cfg, frame=20 + f, n=300)
+        evs = S.make_events(cfg, frame=20 + f, n=n_ev)
         x, y, t, _ = S.to_soa(evs)
         frames.append((tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t)), _ref(tb, evs)["depth"]))
     out = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
@@ -239,7 +241,7 @@ def test_frame_tag_wraparound_clears_the_key_frame(sorted_mode):
     with XMapsEngine(tb, n_slots=1, assume_time_sorted=sorted_mode) as eng:
         for i in range(total):
             (X, Y, T), ref = frames[i % 3]
-            eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, 300, out.data_ptr(), None)
+            eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, n_ev, out.data_ptr(), None)
             if i in (0, 1, (1 << 19) - 3, (1 << 19) - 2, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, total - 1) or i % 100_000 == 0:
                 eng.sync()
                 assert np.array_equal(out.cpu().numpy(), ref), i
@@ -338,3 +340,30 @@ def test_sharded_processor_with_real_nccl_group(tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_esl_like_rig_parity_and_accuracy():
+    """BASELINE configs 1/3 stand-in: the reference's real calibration geometry (tests/golden/g6_esl_calib.npz), tables
+    from the cv2-free builder (X-map built on the GPU), events rendered from a 3-D scene with microsecond stamps.
+    HIP path == oracle bit-exact, and the depth it reports is the scene's depth (integer-disparity quantisation)."""
+    from x_maps_amd import rig
+    cp, tb, evs, gt = rig.make_esl_like(row_stride=13)
+    assert 120_000 < len(evs) < 200_000 and (np.diff(evs["t"]) >= 0).all()
+    ref = _ref(tb, evs)
+    # the X-map the GPU built equals the oracle's construction from the same rectified time map
+    xm, _ = O.compute_x_map_from_time_map(tb["time_map_rect"], tb["x_map_width"], tb["t_px_scale"], 4242, cp.projector_width)
+    assert np.array_equal(xm, tb["proj_x_map"])
+    with XMapsEngine(tb) as eng:
+        depth, bgr, st = eng.process_events(evs)
+    assert st.n_inliers == int(ref["mask"].sum()) > 0.9 * len(evs)
+    assert np.array_equal(depth, ref["depth"]) and np.array_equal(bgr, ref["bgr"])
+    est = depth[gt["proj_v"], gt["proj_u"]]
+    ok = est > 0
+    rel = np.abs(est[ok] - gt["z_rect"][ok]) / gt["z_rect"][ok]
+    assert ok.mean() > 0.97 and np.median(rel) < 0.015 and np.percentile(rel, 95) < 0.03
+    # a denser frame of the same scene goes through the tiled kernel (LDS windows on rotated, distorted geometry)
+    evs2, gt2 = rig.render_events(cp, tb, row_stride=3, seed=1)
+    ref2 = _ref(tb, evs2)
+    with XMapsEngine(tb, assume_time_sorted=True) as eng:
+        depth2, bgr2, st2 = eng.process_events(evs2)
+    assert st2.n_unsorted == 0 and np.array_equal(depth2, ref2["depth"]) and np.array_equal(bgr2, ref2["bgr"])

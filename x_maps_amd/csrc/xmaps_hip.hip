@@ -220,7 +220,13 @@ int launch_scatter_tv(const ScatterArgs& a) {
   const u64 n = ev.n;
   const bool vec16 = !AOS && aligned(ev.x, 16) && aligned(ev.y, 16) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 16));
   const bool vec = !AOS && aligned(ev.x, 8) && aligned(ev.y, 8) && aligned(ev.t, 16) && (!HAS_P || aligned(ev.p, 8));
-  if (!a.direct && a.w_ts > 0 && a.w_x > 0) {
+  // The tiled kernel pays a fixed price per block (copy the bands, clear + scan w_ts * xmap_h slots), so it needs blocks
+  // of >= 1024 events whose time slice still fits the LDS window of w_ts X-map columns.  A frame of n events spreads over
+  // xmap_w columns: a block of E events spans about E * xmap_w / n of them.  Dense frames (C-1M: 1 M events / 640
+  // columns) get 4096-event blocks; sparse ones (ESL-like: 150 K events / 1080 columns, < 1 event per slot, nothing to
+  // de-duplicate) go to the one-thread-per-event kernel, whose cost is proportional to n.
+  const double max_ev = a.tb->xmap_w > 0 ? (a.w_ts - 1.5) * (double)n / (double)a.tb->xmap_w : 0.0;
+  if (!a.direct && a.w_ts > 0 && a.w_x > 0 && max_ev >= 1024.0) {
     auto kern = k_scatter_tiled<T, AOS, HAS_P, VIEW>;
     static size_t lds_set = 0;  // per instantiation: raise the dynamic-LDS cap once (gfx950: 160 KB / CU)
     if (a.lds > lds_set) {
@@ -228,7 +234,9 @@ int launch_scatter_tv(const ScatterArgs& a) {
                                   (int)a.lds));
       lds_set = a.lds;
     }
-    XM_LAUNCH(kern, dim3(grid_for(n, TILE_EVENTS)), dim3(TILE_THREADS), a.lds, a.stream, ev.x, ev.y,
+    unsigned threads = TILE_THREADS;
+    while (threads > 256 && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;
+    XM_LAUNCH(kern, dim3(grid_for(n, threads * TILE_EPT)), dim3(threads), a.lds, a.stream, ev.x, ev.y,
               (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
               a.mm_lo, a.mm_hi, a.frame, a.w_ts, a.w_x, vec16 ? 1 : 0, a.sorted ? 1 : 0);
     return XM_OK;
@@ -300,7 +308,9 @@ int check_events(const EventsView& ev) {
 
 // enqueue K0 -> K1 -> K2 for one frame on a slot.  All pointers are device pointers.
 bool sorted_path(const xm_handle* h, const EventsView& ev) {
-  return h->time_sorted && !ev.use_p && !h->k1_direct && h->w_ts > 0 && h->w_x > 0;
+  // the verified (t[0], t[n-1]) shortcut lives in the tiled kernel; sparse frames (direct kernel) keep K0
+  const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)ev.n / (double)h->tb.xmap_w : 0.0;
+  return h->time_sorted && !ev.use_p && !h->k1_direct && h->w_ts > 0 && h->w_x > 0 && max_ev >= 1024.0;
 }
 
 int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,

@@ -511,7 +511,7 @@ __device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime s
 #endif
 constexpr int TILE_THREADS = XM_TILE_THREADS;   // 512 x 8 or 1024 x 4 events: same LDS tile, different latency/issue trade
 constexpr int TILE_EPT = 4096 / XM_TILE_THREADS;
-constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;
+constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;  // largest block: 4096 events (the LDS slots hold (local idx + 1) << 16)
 
 template <typename T, bool AOS, bool HAS_P, int VIEW>
 __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
@@ -530,16 +530,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   __shared__ u32 s_col_used[64];  // VIEW 0: which time columns of the window received an event
 
   const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;             // 64 .. 1024, chosen per frame by the host so that the block's
+  const int ev_per_block = nthreads * TILE_EPT;  // time slice fits the LDS window (see launch_scatter)
   XM_STAMP(0);
-  if (tid < 64) s_col_used[tid] = 0;
-  const u64 block_base = (u64)blockIdx.x * TILE_EVENTS;
+  for (int i = tid; i < 64; i += nthreads) s_col_used[i] = 0;
+  const u64 block_base = (u64)blockIdx.x * ev_per_block;
   const bool have = block_base < n;  // false only for the single block of an empty frame
 
   // ---- 1. loads that depend on nothing, issued first: this thread's 4 events and the 3 window samples ---------------
   u32 x[TILE_EPT], y[TILE_EPT], lidx[TILE_EPT];
   T tt[TILE_EPT];
   bool used[TILE_EPT];
-  const bool vec = !AOS && vec_ok && block_base + TILE_EVENTS <= n;
+  const bool vec = !AOS && vec_ok && block_base + ev_per_block <= n;
   if (vec) {  // TILE_EPT consecutive events per thread: 8/16-byte loads of x / y / p, 16-byte loads of t
     const u64 base = block_base + (u64)tid * TILE_EPT;
     u32 xw[TILE_EPT / 2], yw[TILE_EPT / 2], pw[TILE_EPT / 2];
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   } else {  // any alignment / ragged tail / AoS records: event k*512 + tid, still coalesced across lanes
 #pragma unroll
     for (int k = 0; k < TILE_EPT; ++k) {
-      lidx[k] = (u32)k * TILE_THREADS + tid;
+      lidx[k] = (u32)k * nthreads + tid;
       const u64 i = block_base + lidx[k];
       used[k] = i < n;
       tt[k] = (T)0;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   int sx[3] = {0, 0, 0};
   T st_t[3] = {(T)0, (T)0, (T)0};
   if (have) {
-    const u64 last = (block_base + TILE_EVENTS <= n ? block_base + TILE_EVENTS : n) - 1;
+    const u64 last = (block_base + ev_per_block <= n ? block_base + ev_per_block : n) - 1;
     const u64 si[3] = {block_base, block_base + ((last - block_base) >> 1), last};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -671,9 +673,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
           st->tag_b = tag;
         }
       }
-      if (tid < MM_SLOTS) {  // re-arm the other parity's slots for the next frame on this slot
-        st->mm[parity ^ 1][tid][0] = MM_INIT_MIN;
-        st->mm[parity ^ 1][tid][1] = MM_INIT_MAX;
+      for (int i = tid; i < MM_SLOTS; i += nthreads) {  // re-arm the other parity's slots for the next frame on this slot
+        st->mm[parity ^ 1][i][0] = MM_INIT_MIN;
+        st->mm[parity ^ 1][i][1] = MM_INIT_MAX;
       }
     }
   }
@@ -719,29 +721,29 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     // i.e. 8 serialized L2 round trips per block instead of one.
     uint4* l_dummy = reinterpret_cast<uint4*>(xm_base) + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
     if (!XM_ABL(2)) {
-      for (int i0 = tid; i0 < nq_lut; i0 += UN * TILE_THREADS) {
+      for (int i0 = tid; i0 < nq_lut; i0 += UN * nthreads) {
         uint4 v[UN];
 #pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = g_lut[min(i0 + j * TILE_THREADS, nq_lut - 1)];
+        for (int j = 0; j < UN; ++j) v[j] = g_lut[min(i0 + j * nthreads, nq_lut - 1)];
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
-          const int i = i0 + j * TILE_THREADS;
+          const int i = i0 + j * nthreads;
           (i < nq_lut ? l_lut + i : l_dummy)[0] = v[j];
         }
       }
-      for (int i0 = tid; i0 < nq_xm; i0 += UN * TILE_THREADS) {
+      for (int i0 = tid; i0 < nq_xm; i0 += UN * nthreads) {
         uint4 v[UN];
 #pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = g_xm[min(i0 + j * TILE_THREADS, nq_xm - 1)];
+        for (int j = 0; j < UN; ++j) v[j] = g_xm[min(i0 + j * nthreads, nq_xm - 1)];
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
-          const int i = i0 + j * TILE_THREADS;
+          const int i = i0 + j * nthreads;
           (i < nq_xm ? l_xm + i : l_dummy)[0] = v[j];
         }
       }
     }
     uint4* l_win = reinterpret_cast<uint4*>(win);
-    for (int i = tid; i < win_q; i += TILE_THREADS) l_win[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < win_q; i += nthreads) l_win[i] = make_uint4(0, 0, 0, 0);
   }
   XM_STAMP(4);
 
@@ -854,18 +856,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     for (int c = 0; c < w_ts; ++c) {
       if (!s_col_used[c]) continue;  // block-uniform: a sorted slice touches 3-4 of the window's columns
       const int base = c * tb.xmap_h;
-      for (int r0 = tid; r0 < tb.xmap_h; r0 += FL * TILE_THREADS) {
+      for (int r0 = tid; r0 < tb.xmap_h; r0 += FL * nthreads) {
         u32 v[FL];
         int xv[FL];
 #pragma unroll
         for (int j = 0; j < FL; ++j) {  // all LDS reads first (clamped), atomics afterwards
-          const int r = min(r0 + j * TILE_THREADS, tb.xmap_h - 1);
+          const int r = min(r0 + j * nthreads, tb.xmap_h - 1);
           v[j] = win[base + r];
           xv[j] = (int)xm_t[base + r];
         }
 #pragma unroll
         for (int j = 0; j < FL; ++j) {
-          const int r = r0 + j * TILE_THREADS;
+          const int r = r0 + j * nthreads;
           if (r < tb.xmap_h && v[j]) {
             const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
             int fc = (int)(short)(xv[j] - tb.x_offset);
@@ -879,13 +881,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   } else {
     constexpr int FL = 4;
     const float inv_d = 1.0f / (float)w_x;
-    for (int i0 = tid; i0 < win_words; i0 += FL * TILE_THREADS) {
+    for (int i0 = tid; i0 < win_words; i0 += FL * nthreads) {
       u32 v[FL];
 #pragma unroll
-      for (int j = 0; j < FL; ++j) v[j] = win[min(i0 + j * TILE_THREADS, win_words - 1)];
+      for (int j = 0; j < FL; ++j) v[j] = win[min(i0 + j * nthreads, win_words - 1)];
 #pragma unroll
       for (int j = 0; j < FL; ++j) {
-        const int i = i0 + j * TILE_THREADS;
+        const int i = i0 + j * nthreads;
         if (i < win_words && v[j]) {
           int q = (int)((float)i * inv_d), r = i - q * w_x;  // camera row, x - x_lo (no integer divide)
           if (r < 0) { q -= 1; r += w_x; }
