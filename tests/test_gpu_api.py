@@ -367,3 +367,36 @@ def test_esl_like_rig_parity_and_accuracy():
     with XMapsEngine(tb, assume_time_sorted=True) as eng:
         depth2, bgr2, st2 = eng.process_events(evs2)
     assert st2.n_unsorted == 0 and np.array_equal(depth2, ref2["depth"]) and np.array_equal(bgr2, ref2["bgr"])
+
+
+def test_pipe_accepts_the_reference_calibration_yaml(tmp_path, golden_dir):
+    """RuntimeParams.calib = a calibration YAML in the reference's format (python/cam_proj_calibration.py:10-28,77-108):
+    the pipe builds its tables itself (cv2-free builder + GPU X-map) and produces the same frame as the oracle run on
+    those tables."""
+    import os
+    import yaml
+    from x_maps_amd import rig
+    g = np.load(os.path.join(golden_dir, "g6_esl_calib.npz"))
+
+    def node(a):
+        a = np.asarray(a, dtype=float)
+        a = a.reshape(a.shape[0], -1)
+        return {"type-id": "opencv_matrix", "rows": int(a.shape[0]), "cols": int(a.shape[1]), "dt": "d", "data": a.ravel().tolist()}
+
+    doc = {"camera_intrinsic_matrix": node(g["camera_K"]), "camera_distortion_coefficients": node(rig.NEBRA_CAMERA_D.reshape(1, 5)),
+           "projector_intrinsic_matrix": node(g["projector_K"]), "projector_distortion_coefficients": node(g["projector_D"]),
+           "relative_rotation": node(g["R"]), "relative_translation": node(g["T"]), "F": node(np.eye(3))}
+    path = tmp_path / "calib.yaml"
+    path.write_text(yaml.safe_dump(doc))
+    params = RuntimeParams(camera_width=640, camera_height=480, projector_width=1080, projector_height=1920, projector_fps=60,
+                           z_near=0.1, z_far=1.2, calib=str(path), projector_time_map=None, no_frame_dropping=True,
+                           camera_perspective=False)
+    got = []
+    pipe = DepthReprojectionPipe(params, StatsPrinter(), got.append)
+    cp = rig.esl_like_params(os.path.join(golden_dir, "g6_esl_calib.npz"))
+    evs, _ = rig.render_events(cp, pipe.calib_maps.tables | {"R1": np.eye(3)}, row_stride=29)
+    pipe.process_ev_frame(evs)
+    assert got[0].shape == (1920, 1080, 3)
+    tb = dict(pipe.calib_maps.tables)
+    assert np.array_equal(got[0], _ref(tb, evs)["bgr"])
+    pipe.close()

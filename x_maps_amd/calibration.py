@@ -240,7 +240,7 @@ class CamProjCalibrationParams:
 
 
 def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwards=True, device: int = 0,
-                 x_map_on_gpu: bool = True) -> dict:
+                 x_map_on_gpu: bool = True, projector_time_map_rectified: Optional[np.ndarray] = None) -> dict:
     """Everything DepthReprojectionPipe.__post_init__ builds (python/depth_reprojection_pipe.py:69-99), as the
     tables dict XMapsEngine / RuntimeParams.tables take.  Projector = camera 1 of the stereo pair (calib:194-217)."""
     size = (cp.rect_image_width, cp.rect_image_height)
@@ -252,8 +252,11 @@ def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwar
     cmx, cmy = init_undistort_rectify_map_inverse(cp.camera_K, cp.camera_D, R1, P1, (cp.camera_width, cp.camera_height))
     qmx, qmy = init_undistort_rectify_map_inverse(cp.projector_K, cp.projector_D, R2, P2,
                                                   (cp.projector_width, cp.projector_height))
-    time_map = generate_linear_projector_time_map(cp.projector_width, cp.projector_height, scan_upwards)
-    time_map_rect = remap_nearest(time_map, pmx, pmy, "replicate")
+    if projector_time_map_rectified is not None:  # ProjectorTimeMap.from_file (python/proj_time_map.py:46-49)
+        time_map_rect = np.ascontiguousarray(projector_time_map_rectified, dtype=np.float32)
+    else:                                         # ProjectorTimeMap.from_calib (:36-44)
+        time_map = generate_linear_projector_time_map(cp.projector_width, cp.projector_height, scan_upwards)
+        time_map_rect = remap_nearest(time_map, pmx, pmy, "replicate")
     x_off, xw = 4242, cp.projector_width
     if x_map_on_gpu:
         from .x_map import compute_x_map_from_time_map
