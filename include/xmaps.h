@@ -63,6 +63,10 @@ extern "C" {
 /* where the event / output buffers of a call live */
 #define XM_MEM_HOST 0   /* host pointers: staged H2D/D2H inside the call, call returns synchronised  */
 #define XM_MEM_DEVICE 1 /* device pointers: everything is enqueued on the handle's stream; xm_sync() */
+#define XM_MEM_HOST_PINNED 2 /* PINNED host pointers (xm_host_alloc / hipHostMalloc / hipHostRegister): asynchronous like
+                                XM_MEM_DEVICE -- H2D copies, the three kernels and the D2H copies are enqueued on the next
+                                slot's stream and the call returns; with n_slots > 1 the copies of one frame overlap the
+                                kernels of another.  Buffers must stay valid and untouched until xm_sync(). */
 
 /* dtype of the time column: int64 microseconds (Metavision EventCD) or an already-normalised
  * float time surface (python/eval/compute_depth_x_maps.py:89-96) */
@@ -233,6 +237,10 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
  * the LAST event per cell (golden vectors g5_filters).  != 0: the first event, as the class names say. */
 int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, const void* eventcd16_in, size_t n,
                           const int16_t* xp_i16, int map_height, int map_width, void* eventcd16_out, size_t* n_out);
+
+/* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
+int xm_host_alloc(xm_handle* h, size_t bytes, void** out);
+int xm_host_free(xm_handle* h, void* p);
 
 /* ---- small device-memory helpers so that a host without torch can stage buffers ------------------- */
 int xm_dev_alloc(xm_handle* h, size_t bytes, void** out);

@@ -400,3 +400,27 @@ def test_pipe_accepts_the_reference_calibration_yaml(tmp_path, golden_dir):
     tb = dict(pipe.calib_maps.tables)
     assert np.array_equal(got[0], _ref(tb, evs)["bgr"])
     pipe.close()
+
+
+def test_pinned_host_asynchronous_path():
+    """XM_MEM_HOST_PINNED: pinned host SoA / AoS in, pinned host depth + BGR out, asynchronous over 3 slots."""
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    with XMapsEngine(tb, n_slots=3) as eng:
+        jobs = []
+        for f in range(7):
+            evs = S.make_events(cfg, frame=40 + f, n=3000 + 111 * f)
+            x, y, t, _ = S.to_soa(evs)
+            px, py, pt = eng.host_empty(x.shape, np.uint16), eng.host_empty(y.shape, np.uint16), eng.host_empty(t.shape, np.int64)
+            px[:], py[:], pt[:] = x, y, t
+            pa = eng.host_empty(evs.shape, S.EVENT_CD_DTYPE)
+            pa[:] = evs
+            d1, b1 = eng.host_empty((cfg.proj_h, cfg.proj_w), np.float32), eng.host_empty((cfg.proj_h, cfg.proj_w, 3), np.uint8)
+            d2 = eng.host_empty((cfg.proj_h, cfg.proj_w), np.float32)
+            eng.process_frame_pinned(px, py, pt, None, d1, b1)
+            eng.process_events_pinned(pa, d2, None)
+            jobs.append((evs, d1, b1, d2))
+        eng.sync()
+        for evs, d1, b1, d2 in jobs:
+            ref = _ref(tb, evs)
+            assert np.array_equal(d1, ref["depth"]) and np.array_equal(b1, ref["bgr"]) and np.array_equal(d2, ref["depth"])

@@ -22,7 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY, XM_ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6
 XM_FLAG_TIME_SORTED = 1
 XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
-XM_MEM_HOST, XM_MEM_DEVICE = 0, 1
+XM_MEM_HOST, XM_MEM_DEVICE, XM_MEM_HOST_PINNED = 0, 1, 2
 XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2
 
 
@@ -117,6 +117,8 @@ SYMBOLS = {
     "xm_frame_event_filter": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
     "xm_build_x_map": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "xm_stream": (_P, [_P, C.c_int]),
+    "xm_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "xm_host_free": (C.c_int, [_P, _P]),
     "xm_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "xm_dev_free": (C.c_int, [_P, _P]),
     "xm_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),

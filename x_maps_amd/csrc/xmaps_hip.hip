@@ -405,7 +405,8 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
   if (profile) h->last_slot = 0;
   float* d_depth = depth_out;
   uint8_t* d_bgr = bgr_out;
-  if (mem == XM_MEM_HOST) {
+  const bool host_in = mem == XM_MEM_HOST || mem == XM_MEM_HOST_PINNED;
+  if (host_in) {
     const size_t n = ev.n;
     if (ev.aos) {
       if ((rc = stage_in(s.ev_aos, ev.aos, n * 16, s.stream))) return rc;
@@ -431,10 +432,10 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
       d_bgr = (uint8_t*)s.out_bgr.p;
     }
   } else if (mem != XM_MEM_DEVICE) {
-    return fail(XM_ERR_INVALID, "mem must be XM_MEM_HOST or XM_MEM_DEVICE");
+    return fail(XM_ERR_INVALID, "mem must be XM_MEM_HOST, XM_MEM_HOST_PINNED or XM_MEM_DEVICE");
   }
   if ((rc = enqueue_frame(h, s, ev, d_depth, d_bgr, profile ? h->prof_ev : nullptr))) return rc;
-  if (mem == XM_MEM_HOST) {
+  if (host_in) {
     if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
     if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
   }
@@ -1249,6 +1250,20 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
   if (d_x) (void)hipFree(d_x);
   if (d_d) (void)hipFree(d_d);
   return rc;
+}
+
+// ---- pinned host memory --------------------------------------------------------------------------------------
+int xm_host_alloc(xm_handle* h, size_t bytes, void** out) {
+  if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+  return XM_OK;
+}
+int xm_host_free(xm_handle* h, void* p) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (p) HIP_TRY(hipHostFree(p));
+  return XM_OK;
 }
 
 // ---- device memory helpers ----------------------------------------------------------------------------------

@@ -102,6 +102,7 @@ class XMapsEngine:
         cfg.proj_x_map = xmap.ctypes.data
         cfg.disp_proj_mapxy_i16 = pmap.ctypes.data if pmap is not None else None
         N.check(self._lib.xm_create(C.byref(cfg), C.byref(self._h)))
+        self._pinned = []
         self.camera_perspective = camera_perspective
         self.device = device
         self.n_slots = n_slots
@@ -115,6 +116,9 @@ class XMapsEngine:
     # ---- lifetime ------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            for p in getattr(self, "_pinned", []):
+                self._lib.xm_host_free(self._h, C.c_void_p(p))
+            self._pinned = []
             self._lib.xm_destroy(self._h)
             self._h = C.c_void_p(None)
 
@@ -320,6 +324,28 @@ class XMapsEngine:
 
     def shard_finish(self, key_ptr, tag, depth_ptr=None, bgr_ptr=None):
         N.check(self._lib.xm_shard_finish(self._h, _ptr(key_ptr), int(tag), _ptr(depth_ptr), _ptr(bgr_ptr)))
+
+    # ---- pinned host memory + asynchronous host path ---------------------------------------------------------
+    def host_empty(self, shape, dtype) -> np.ndarray:
+        """NumPy array backed by pinned host memory (freed with the engine).  For process_frame_pinned."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p(None)
+        N.check(self._lib.xm_host_alloc(self._h, max(n, 16), C.byref(p)))
+        self._pinned.append(p.value)
+        buf = (C.c_char * max(n, 16)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def process_frame_pinned(self, x, y, t, p=None, depth_out=None, bgr_out=None):
+        """Asynchronous frame from PINNED host arrays (host_empty): H2D, kernels and D2H enqueued on the next slot's
+        stream; returns at once; sync() before reading depth_out / bgr_out or reusing the inputs."""
+        _, tdt = _time_col(t)
+        N.check(self._lib.xm_process_frame(self._h, _ptr(x), _ptr(y), _ptr(t), _ptr(p), len(t), tdt, N.XM_MEM_HOST_PINNED,
+                                           _ptr(depth_out), _ptr(bgr_out), None))
+
+    def process_events_pinned(self, evs, depth_out=None, bgr_out=None, use_polarity=False):
+        N.check(self._lib.xm_process_frame_aos(self._h, _ptr(evs), len(evs), int(use_polarity), N.XM_MEM_HOST_PINNED,
+                                               _ptr(depth_out), _ptr(bgr_out), None))
 
     # ---- device memory helpers (for hosts without torch) -------------------------------------------------
     def dev_alloc(self, nbytes: int) -> int:
