@@ -219,3 +219,17 @@ def test_order_invariance_property_full_size():
     assert np.array_equal(d_sub, d_perm)
     # and de-duplication itself does not change the frame unless the two re-attached events win a cell they lost before
     assert (d_full != d_sub).mean() < 1e-4
+
+
+def test_dirty_line_flags_option_gives_the_same_frames(monkeypatch):
+    """XM_K2_FLAGS=1 (K1 marks dirty key-frame lines, K2 skips clean ones): an optional byte-saving path, same frames,
+    also across consecutive frames on one slot (stale flags must only ever be false positives)."""
+    monkeypatch.setenv("XM_K2_FLAGS", "1")
+    tb = S.make_tables(S.C_1M)
+    with XMapsEngine(tb) as eng:
+        for f, kw in ((0, {}), (1, {"shuffled": True}), (2, {"n": 50_000}), (3, {})):
+            evs = S.make_events(S.C_1M, frame=f, **kw)
+            x, y, t, _ = S.to_soa(evs)
+            d, b, _ = eng.process_frame(x, y, t)
+            ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t)
+            assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]), f

@@ -89,6 +89,12 @@ template <> struct TimeCodec<float> {  // f32 -> f64 is exact and monotone
   static __host__ __device__ float dec(u64 u) { return (float)TimeCodec<double>::dec(u); }
 };
 
+// Dirty-line flags of the projector-view key frame: one byte per 128-byte line (16 cells).  K1 stores the frame's tag
+// byte for every line it writes a key into; K2 only fetches lines whose flag carries the current tag byte (at C-1M only
+// 46 % of the lines are dirty, so K2 skips half of its 34 MB read).  Plain idempotent stores, no clearing: a stale flag
+// (tags repeat every 255 frames) is only a false positive -- the line is fetched and its keys' full tags decide.
+__host__ __device__ inline unsigned char dirty_byte(u32 tag) { return (unsigned char)(tag % 255u + 1u); }
+
 constexpr u64 MM_INIT_MIN = ~0ull;
 constexpr u64 MM_INIT_MAX = 0ull;
 
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
                                                    const T* __restrict__ ts, const int16_t* __restrict__ ps,
                                                    const uint4* __restrict__ aos, u64 n, u64 idx_offset,
                                                    DevTables tb, SlotState* st, u32 tag_override, u64 mm_lo,
-                                                   u64 mm_hi, u64* __restrict__ frame) {
+                                                   u64 mm_hi, u64* __restrict__ frame, unsigned char* __restrict__ dirty) {
   const u32 tag = tag_override ? tag_override : st->tag_a;
   const u32 parity = tag & 1;
   u64 lo, hi;
@@ -457,6 +463,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
     if (write) {
       const u64 key = key_hi | ((idx_offset + base + k) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
       __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
     }
     // wavefront ballots: one popcount per wave instead of per-lane counters
     n_in += __popcll(__ballot(write));
@@ -517,7 +524,8 @@ template <typename T, bool AOS, bool HAS_P, int VIEW>
 __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
-    u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, int w_ts, int w_x, int vec_ok, int sorted_mode) {
+    u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, unsigned char* __restrict__ dirty, int w_ts, int w_x,
+    int vec_ok, int sorted_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift)
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
@@ -835,6 +843,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
         if (write) {
           const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
           __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
         }
       }
       n_in += __popcll(__ballot(write));
@@ -872,8 +881,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
             const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
             int fc = (int)(short)(xv[j] - tb.x_offset);
             if (fc < 0) fc += tb.rect_w;
-            if (!XM_ABL(0))
-              __hip_atomic_fetch_max(&frame[(u32)fc * (u32)tb.rect_h + (u32)r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 cell = (u32)fc * (u32)tb.rect_h + (u32)r;
+            if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dirty) dirty[cell >> 4] = dirty_byte(tag);  // consecutive lanes = consecutive rows: same byte for 16 lanes
           }
         }
       }
@@ -1049,12 +1059,16 @@ __device__ inline uint16_t key_disp(u64 k, u32 tag) { return (u32)(k >> KEY_TAG_
 
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
                                                                   SlotState* st, u32 tag_override,
+                                                                  const unsigned char* __restrict__ dirty,
+                                                                  const ulonglong2* __restrict__ zero16,
                                                                   float* __restrict__ depth, uint8_t* __restrict__ bgr) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[K2_TILE_MAX + 16];  // +16: the last 16-byte read may overrun
   __shared__ __attribute__((aligned(16))) uint16_t vmax[K2_TILE_MAX];
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ int s_box[NW][4];
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
+  constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
+  __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
   const u32 tag = tag_override ? tag_override : st->tag_a;
   if (!tag_override && blockIdx.x == 0 && blockIdx.y == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
@@ -1102,8 +1116,24 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
     const int rows_p = (rows + 7) & ~7;                  // column stride in LDS: 16-byte aligned runs
     if (cols * rows_p <= K2_TILE_MAX) {
       constexpr int UN = 8;
+      // which 128-byte lines of the patch carry keys of THIS frame?  (flag bytes written by K1; all lines when no flags)
+      const bool use_flags = dirty != nullptr && cols <= FLAG_COLS && rows_p <= 16 * (FLAG_LINES - 1);
+      if (use_flags) {
+        const unsigned char want = dirty_byte(tag);
+        const u32 n_lines = ((u32)tb.rect_w * (u32)tb.rect_h + 15u) >> 4;
+        for (int i = tid; i < cols * FLAG_LINES; i += NT) {
+          const int c = i / FLAG_LINES, j = i - c * FLAG_LINES, gx = bx + c;
+          unsigned char live = 0;
+          if (gx >= 0 && gx < tb.rect_w) {
+            const int first_cell = gx * tb.rect_h + max(by, 0);  // first in-frame cell of this patch column
+            const u32 line = ((u32)first_cell >> 4) + (u32)j;
+            if (line < n_lines) live = dirty[line] == want;
+          }
+          s_live[i] = live;
+        }
+        __syncthreads();
+      }
       if ((tb.rect_h & 1) == 0) {
-        // pairs of cells (gy, gy+1), gy even: one 16-byte load; in-frame iff 0 <= gy < rect_h (rect_h even)
         const int half = rows_p >> 1, total = cols * half;
         // (c, rp) = divmod(i, half) advanced incrementally: i -> i + NT is (c + dq, rp + dr) with one carry
         const int dq = NT / half, dr = NT - dq * half;
@@ -1116,7 +1146,16 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
             const int gx = bx + c_i, gy = by + 2 * rp_i;
             inside[j] = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
             const int cx = min(max(gx, 0), tb.rect_w - 1), cy = min(max(gy, 0), tb.rect_h - 2);
-            k[j] = *reinterpret_cast<const ulonglong2*>(keys + ((u32)cx * (u32)tb.rect_h + (u32)cy));
+            const u32 cell = (u32)cx * (u32)tb.rect_h + (u32)cy;
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(keys + cell);
+            if (use_flags) {  // clean line: read the 16-byte zero constant instead (L2-hot, no HBM traffic)
+              const int first_cell = cx * tb.rect_h + max(by, 0);
+              const int jl = (int)(cell >> 4) - (first_cell >> 4);
+              const bool live = inside[j] && (u32)jl < (u32)FLAG_LINES && s_live[min(c_i, FLAG_COLS - 1) * FLAG_LINES + max(min(jl, FLAG_LINES - 1), 0)];
+              inside[j] = live;
+              src = live ? src : zero16;
+            }
+            k[j] = *src;
             c_i += dq;
             rp_i += dr;
             if (rp_i >= half) { rp_i -= half; c_i += 1; }
@@ -1523,9 +1562,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_filter_emit(const uint4* __restr
 }
 
 // slot (re)initialisation: zero the key frame, arm min/max + counters, tag = 0
-__global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells) {
+__global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells,
+                                                      unsigned char* __restrict__ dirty) {
   const u64 stride = (u64)gridDim.x * BLOCK;
   for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n_cells; i += stride) frame[i] = 0;
+  if (dirty)
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ((n_cells + 15) >> 4); i += stride) dirty[i] = 0;
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
       st->tag_a = 0;
