@@ -95,6 +95,8 @@ struct xm_handle {
   int16_t* d_xmap = nullptr;
   u32* d_pmap = nullptr;
   uint2* d_dlut = nullptr;
+  int4* d_k2_tiles = nullptr;
+  u32* d_k2_pix = nullptr;
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
   SlotState* aux_st = nullptr;
@@ -613,6 +615,16 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->tb.p03 = cfg->p03;
   h->tb.z_near = cfg->z_near;
   h->tb.z_far = cfg->z_far;
+  if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets
+    const unsigned tiles_x = grid_for(cfg->proj_width, K2_TX), tiles_y = grid_for(cfg->proj_height, K2_TY);
+    XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_tiles, (size_t)tiles_x * tiles_y * sizeof(int4)));
+    XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix, (size_t)cfg->proj_width * cfg->proj_height * sizeof(u32)));
+    hipLaunchKernelGGL(k_build_k2_tables, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles, h->d_k2_pix);
+    XM_TRY_CREATE(hipGetLastError());
+    XM_TRY_CREATE(hipDeviceSynchronize());
+    h->tb.k2_tiles = h->d_k2_tiles;
+    h->tb.k2_pix = h->d_k2_pix;
+  }
   if (cfg->view == XM_VIEW_PROJECTOR) {
     h->key_cells = (size_t)cfg->rect_width * cfg->rect_height;
     h->out_w = cfg->proj_width;
@@ -709,6 +721,8 @@ void xm_destroy(xm_handle* h) {
   if (h->d_xmap) (void)hipFree(h->d_xmap);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
+  if (h->d_k2_tiles) (void)hipFree(h->d_k2_tiles);
+  if (h->d_k2_pix) (void)hipFree(h->d_k2_pix);
   if (h->d_zero16) (void)hipFree(h->d_zero16);
   delete h;
 }

@@ -47,6 +47,10 @@ struct DevTables {
   const int16_t* xmap;  // [xmap_w][xmap_h] TRANSPOSED  X-map, time column major
   const u32* pmap;      // [proj_h][proj_w] row-major   (u16(my) << 16) | u16(mx)
   const uint2* dlut;    // [65536] per integer disparity: {f32 bits of depth, BGR word} = disparity_pixel(d) (A5-A7)
+  const int4* k2_tiles; // [tiles_y][tiles_x] {bx, by, cols, rows_p} of every K2 tile's key-frame patch (cols = 0: none of
+                        //   its pixels maps into the frame; cols < 0: patch too large for LDS -> generic path), precomputed
+  const u32* k2_pix;    // [proj_h][proj_w] offset of the pixel's 7-tap column run inside its tile's LDS patch, ~0u = the
+                        //   pixel maps outside the frame (BORDER_CONSTANT 0)
   int cam_w, cam_h, proj_w, proj_h, rect_w, rect_h, xmap_w, xmap_h;
   int x_offset, t_px_scale;
   double p03;
@@ -1057,25 +1061,14 @@ constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX; 
 
 __device__ inline uint16_t key_disp(u64 k, u32 tag) { return (u32)(k >> KEY_TAG_SHIFT) == tag ? (uint16_t)(k & 0xffff) : (uint16_t)0; }
 
-__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
-                                                                  SlotState* st, u32 tag_override,
-                                                                  const unsigned char* __restrict__ dirty,
-                                                                  const ulonglong2* __restrict__ zero16,
-                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr) {
-  __shared__ __attribute__((aligned(16))) uint16_t tile[K2_TILE_MAX + 16];  // +16: the last 16-byte read may overrun
-  __shared__ __attribute__((aligned(16))) uint16_t vmax[K2_TILE_MAX];
+// One-off (xm_create): per K2 tile, the bounding box of its pixels' map targets (+3 cells of dilate margin, rows starting
+// on an even row and padded to 8) and, per pixel, where its window starts inside that patch.  The maps are static, so
+// K2 no longer decodes the map, reduces a bounding box over the block and synchronises before it can issue its loads.
+__global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, int4* __restrict__ tiles,
+                                                                 u32* __restrict__ pix) {
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ int s_box[NW][4];
-  __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
-  constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
-  __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
-  const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
-  const u32 tag = tag_override ? tag_override : st->tag_a;
-  if (!tag_override && blockIdx.x == 0 && blockIdx.y == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
-    u32* c = st->cnt[(tag & 1) ^ 1][tid];
-    c[0] = c[1] = c[2] = c[3] = 0;
-    if (tid == 0) st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
-  }
+  const int tid = threadIdx.x, tx = tid % K2_TX, ty = tid / K2_TX;
   const int u = blockIdx.x * K2_TX + tx, v = blockIdx.y * K2_TY + ty;
   const bool in_img = u < tb.proj_w && v < tb.proj_h;
   int mx = 0, my = 0;
@@ -1084,9 +1077,8 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
     const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u];
     mx = (int)(short)(m & 0xffff);
     my = (int)(short)(m >> 16);
-    valid = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;  // else BORDER_CONSTANT 0
+    valid = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;
   }
-  // bounding box of the tile's map targets
   int x0 = valid ? mx : 0x7fffffff, x1 = valid ? mx : -0x7fffffff, y0 = valid ? my : 0x7fffffff, y1 = valid ? my : -0x7fffffff;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1109,12 +1101,62 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
     y0 = min(y0, s_box[w][2]);
     y1 = max(y1, s_box[w][3]);
   }
+  int4 rec = make_int4(0, 0, 0, 0);
+  u32 off = ~0u;
+  if (x1 >= x0) {
+    const int bx = x0 - 3, by = (y0 - 3) & ~1;
+    const int cols = x1 + 3 - bx + 1, rows = y1 + 3 - by + 1, rows_p = (rows + 7) & ~7;
+    const bool fits = cols * rows_p <= K2_TILE_MAX;
+    rec = make_int4(bx, by, fits ? cols : -1, rows_p);
+    if (valid && fits) off = (u32)((mx - 3 - bx) * rows_p + (my - 3 - by));
+  }
+  if (tid == 0) tiles[blockIdx.y * gridDim.x + blockIdx.x] = rec;
+  if (in_img) pix[(u32)v * (u32)tb.proj_w + (u32)u] = off;
+}
+
+__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
+                                                                  SlotState* st, u32 tag_override,
+                                                                  const unsigned char* __restrict__ dirty,
+                                                                  const ulonglong2* __restrict__ zero16,
+                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[K2_TILE_MAX + 16];  // +16: the last 16-byte read may overrun
+  __shared__ __attribute__((aligned(16))) uint16_t vmax[K2_TILE_MAX];
+  constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
+  __shared__ int s_box[NW][4];
+  __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
+  constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
+  __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
+  const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
+  const u32 tag = tag_override ? tag_override : st->tag_a;
+  if (!tag_override && blockIdx.x == 0 && blockIdx.y == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
+    u32* c = st->cnt[(tag & 1) ^ 1][tid];
+    c[0] = c[1] = c[2] = c[3] = 0;
+    if (tid == 0) st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
+  }
+  const int u = blockIdx.x * K2_TX + tx, v = blockIdx.y * K2_TY + ty;
+  const bool in_img = u < tb.proj_w && v < tb.proj_h;
+  // the tile's patch rectangle and the pixel's offset into it were computed once in xm_create (k_build_k2_tables)
+  const int4 rec = tb.k2_tiles[blockIdx.y * gridDim.x + blockIdx.x];  // block-uniform
+  const u32 poff = in_img ? tb.k2_pix[(u32)v * (u32)tb.proj_w + (u32)u] : ~0u;
+  int mx = 0, my = 0;
+  bool valid = poff != ~0u;
+  int x0 = 0, x1 = -1, y0 = 0, y1 = 0;
+  if (rec.z < 0) {  // patch too large for LDS (wild map): generic path needs the map entry itself
+    if (in_img) {
+      const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u];
+      mx = (int)(short)(m & 0xffff);
+      my = (int)(short)(m >> 16);
+      valid = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;  // else BORDER_CONSTANT 0
+    }
+    x1 = 0;  // "some pixel maps into the frame": take the branch below, which falls through to the global reads
+  } else if (rec.z > 0) {
+    x1 = 0;
+  }
   float d = 0.0f;
   if (x1 >= x0) {  // at least one pixel of the tile maps into the frame
-    const int bx = x0 - 3, by = (y0 - 3) & ~1;          // patch origin (rows start on an even row: 16-byte aligned pairs)
-    const int cols = x1 + 3 - bx + 1, rows = y1 + 3 - by + 1;
-    const int rows_p = (rows + 7) & ~7;                  // column stride in LDS: 16-byte aligned runs
-    if (cols * rows_p <= K2_TILE_MAX) {
+    const int bx = rec.x, by = rec.y;                    // patch origin (rows start on an even row: 16-byte aligned pairs)
+    const int cols = rec.z, rows_p = rec.w;              // column stride in LDS: 16-byte aligned runs
+    if (cols > 0) {
       constexpr int UN = 8;
       // which 128-byte lines of the patch carry keys of THIS frame?  (flag bytes written by K1; all lines when no flags)
       const bool use_flags = dirty != nullptr && cols <= FLAG_COLS && rows_p <= 16 * (FLAG_LINES - 1);
@@ -1215,7 +1257,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
       }
       __syncthreads();
       if (valid) {
-        const uint16_t* p = vmax + (mx - 3 - bx) * rows_p + (my - 3 - by);
+        const uint16_t* p = vmax + poff;
         u32 best = 0;
 #pragma unroll
         for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
