@@ -22,7 +22,8 @@ def _random_case(seed):
     sx, sy = rect_w / cam_w, rect_h / cam_h
     mapx = np.rint(rng.uniform(0.5, 1.0) * sx * xs + rng.uniform(-6, 6) + rng.uniform(-0.1, 0.1) * ys).astype(np.int16)
     mapy = np.rint(rng.uniform(0.7, 1.1) * sy * ys + rng.uniform(-5, 3) + rng.uniform(-0.1, 0.1) * xs).astype(np.int16)
-    yr, tc = np.mgrid[0:rect_h, 0:xmap_w]
+    xmap_h = max(3, rect_h + int(rng.integers(-3, 4)))  # the X-map may have more / fewer rows than the rectified frame
+    yr, tc = np.mgrid[0:xmap_h, 0:xmap_w]
     xmap = np.rint(4242 + rng.uniform(0, 0.3) * rect_w + tc * rng.uniform(0.3, 0.9) * rect_w / xmap_w
                    + rng.uniform(-0.15, 0.15) * yr).astype(np.int16)
     xmap[rng.random(xmap.shape) < rng.uniform(0, 0.2)] = 0
