@@ -1043,6 +1043,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 // K2 (tiled, projector view, fused path): one block = a 16 x 16 tile of projector pixels (measured best of 32x8, 16x16,
 // 16x32, 32x16, 8x32: least patch overlap + cache-line waste).  Their map targets span a (16*sx+6) x (16*sy+6) patch of
 // the rectified key frame (sx, sy ~ 2.75):
+//   0. the patch rectangle of the tile and every pixel's offset into it are static (the maps never change): they come
+//      from tables built once in xm_create (k_build_k2_tables), so the loads below start right after one uniform load;
 //   1. the patch is loaded ONCE into LDS as u16 disparities (stale tags -> 0, cells outside the frame -> 0); the key
 //      frame is column-major, so the patch is `cols` contiguous runs -> paired 16-byte loads, 8 in flight per thread;
 //   2. the 7-tap max along rows is taken once per patch cell with 16-byte LDS reads (separable max filter);
@@ -1122,7 +1124,6 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   __shared__ __attribute__((aligned(16))) uint16_t tile[K2_TILE_MAX + 16];  // +16: the last 16-byte read may overrun
   __shared__ __attribute__((aligned(16))) uint16_t vmax[K2_TILE_MAX];
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
-  __shared__ int s_box[NW][4];
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
