@@ -238,6 +238,14 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
 int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, const void* eventcd16_in, size_t n,
                           const int16_t* xp_i16, int map_height, int map_width, void* eventcd16_out, size_t* n_out);
 
+/* ---- device-side ingest ("next" row N2): inter-event pauses of a stream ------------------------------------------ */
+/* np.nonzero(np.diff(t) >= thresh_us)[0] (trigger_finder.py:153-155) for a stream of n events.  Exactly one of t
+ * (int64[n]) / eventcd16 (n 16-byte EventCD records) is given; mem = XM_MEM_HOST or XM_MEM_DEVICE for that input.
+ * idx_out: host buffer of capacity idx_capacity (uint32 indices, ascending); *n_out = number of pauses found (may
+ * exceed idx_capacity: then only the first idx_capacity are written).  Synchronous. */
+int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t n, int mem, int64_t thresh_us,
+                   uint32_t* idx_out, size_t idx_capacity, size_t* n_out);
+
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out);
 int xm_host_free(xm_handle* h, void* p);

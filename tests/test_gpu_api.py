@@ -424,3 +424,25 @@ def test_pinned_host_asynchronous_path():
         for evs, d1, b1, d2 in jobs:
             ref = _ref(tb, evs)
             assert np.array_equal(d1, ref["depth"]) and np.array_equal(b1, ref["bgr"]) and np.array_equal(d2, ref["depth"])
+
+
+def test_device_side_pause_detection_matches_numpy(golden_dir):
+    """N2: np.nonzero(np.diff(t) >= 40)[0] on the GPU (host SoA, host EventCD, device pointer), incl. the golden G5 stream."""
+    import os
+    torch = pytest.importorskip("torch")
+    g = np.load(os.path.join(golden_dir, "g5_trigger.npz"))
+    rng = np.random.default_rng(3)
+    streams = [g["t"].astype(np.int64), np.cumsum(rng.integers(0, 60, 200_003)).astype(np.int64),
+               np.array([5], np.int64), np.array([5, 100], np.int64), np.zeros(0, np.int64)]
+    with XMapsEngine(S.make_tables(S.C_TINY)) as eng:
+        for t in streams:
+            ref = np.nonzero(np.diff(t) >= 40)[0]
+            assert np.array_equal(eng.find_pauses(t=t), ref)
+            ev = np.zeros(len(t), S.EVENT_CD_DTYPE)
+            ev["t"] = t
+            assert np.array_equal(eng.find_pauses(evs=ev), ref)
+            if len(t):
+                dt = torch.from_numpy(t).to("cuda:0")
+                torch.cuda.synchronize()
+                assert np.array_equal(eng.find_pauses(device_ptr=dt.data_ptr(), n=len(t)), ref)
+        assert np.array_equal(eng.find_pauses(t=streams[1], thresh_us=55), np.nonzero(np.diff(streams[1]) >= 55)[0])

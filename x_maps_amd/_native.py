@@ -115,6 +115,7 @@ SYMBOLS = {
     "xm_shard_scatter": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_uint64, _P, C.c_uint32, _P]),
     "xm_shard_finish": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
     "xm_frame_event_filter": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
+    "xm_find_pauses": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "xm_build_x_map": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "xm_stream": (_P, [_P, C.c_int]),
     "xm_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

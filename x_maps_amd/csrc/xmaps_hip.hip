@@ -1236,6 +1236,51 @@ int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, cons
   return XM_OK;
 }
 
+// ---- N2: pause detection -----------------------------------------------------------------------------------------
+int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t n, int mem, int64_t thresh_us,
+                   uint32_t* idx_out, size_t idx_capacity, size_t* n_out) {
+  if (!h || !n_out || (!t == !eventcd16 && n)) return fail(XM_ERR_INVALID, "give exactly one of t / eventcd16");
+  if (n >= 0x7fffffffull) return fail(XM_ERR_TOO_MANY, "too many events");
+  *n_out = 0;
+  if (n < 2) return XM_OK;
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  Slot& s = h->slots[0];
+  int rc;
+  const long long* d_t = (const long long*)t;
+  const uint4* d_aos = (const uint4*)eventcd16;
+  if (mem == XM_MEM_HOST) {
+    if (t) {
+      if ((rc = stage_in(s.ev_t, t, n * 8, s.stream))) return rc;
+      d_t = (const long long*)s.ev_t.p;
+    } else {
+      if ((rc = stage_in(s.ev_aos, eventcd16, n * 16, s.stream))) return rc;
+      d_aos = (const uint4*)s.ev_aos.p;
+    }
+  } else if (mem != XM_MEM_DEVICE) {
+    return fail(XM_ERR_INVALID, "mem must be XM_MEM_HOST or XM_MEM_DEVICE");
+  }
+  const u32 n_blocks = (u32)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  // scratch: flags[n] pos[n] out[n] sums[n_blocks] total[1]
+  if ((rc = s.dbg[0].reserve((3 * n + n_blocks + 4) * sizeof(u32)))) return rc;
+  u32* flags = (u32*)s.dbg[0].p;
+  u32* pos = flags + n;
+  u32* out = pos + n;
+  u32* sums = out + n;
+  u32* total = sums + n_blocks;
+  hipLaunchKernelGGL(k_pause_flags, dim3(n_blocks), dim3(SCAN_BLOCK), 0, s.stream, d_t, d_aos, (u32)n, (long long)thresh_us, flags);
+  hipLaunchKernelGGL(k_filter_scan_blocks, dim3(n_blocks), dim3(SCAN_BLOCK), 0, s.stream, flags, (u32)n, pos, sums);
+  hipLaunchKernelGGL(k_filter_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, sums, n_blocks, total);
+  hipLaunchKernelGGL(k_pause_emit, dim3(n_blocks), dim3(SCAN_BLOCK), 0, s.stream, flags, pos, sums, (u32)n, out);
+  HIP_TRY(hipGetLastError());
+  u32 cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, total, sizeof cnt, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  *n_out = cnt;
+  const size_t ncopy = cnt < idx_capacity ? cnt : idx_capacity;
+  if (ncopy && idx_out) HIP_TRY(hipMemcpy(idx_out, out, ncopy * sizeof(u32), hipMemcpyDeviceToHost));
+  return XM_OK;
+}
+
 // ---- N1: X-map construction ----------------------------------------------------------------------------------
 int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
                    int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out) {

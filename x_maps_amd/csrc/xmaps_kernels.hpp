@@ -1604,6 +1604,38 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_filter_emit(const uint4* __restr
   out[o] = rec;
 }
 
+// =====================================================================================================
+// N2: pause detection for the frame segmentation, reference python/trigger_finder.py:153-155:
+//   frame_paused_ev_idx = np.nonzero(np.diff(evs["t"]) >= frame_paused_thresh_us)[0]
+// on a device-resident stream: flag -> two-level exclusive scan (same scan kernels as the filters) -> emit indices.
+// Works on SoA t[n] or on EventCD records (t at byte 8 of each 16-byte record).
+// =====================================================================================================
+__global__ __launch_bounds__(SCAN_BLOCK) void k_pause_flags(const long long* __restrict__ t, const uint4* __restrict__ aos,
+                                                            u32 n, long long thresh, u32* __restrict__ flags) {
+  const u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  u32 f = 0;
+  if (i + 1 < n) {
+    long long a, b;
+    if (aos) {
+      const uint4 ra = aos[i], rb = aos[i + 1];
+      a = (long long)(((u64)ra.w << 32) | ra.z);
+      b = (long long)(((u64)rb.w << 32) | rb.z);
+    } else {
+      a = t[i];
+      b = t[i + 1];
+    }
+    f = (b - a) >= thresh ? 1u : 0u;
+  }
+  flags[i] = f;  // k_filter_scan_blocks treats non-zero as "occupied"
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_pause_emit(const u32* __restrict__ flags, const u32* __restrict__ pos,
+                                                           const u32* __restrict__ sums, u32 n, u32* __restrict__ out) {
+  const u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  if (i < n && flags[i]) out[sums[blockIdx.x] + pos[i]] = i;
+}
+
 // slot (re)initialisation: zero the key frame, arm min/max + counters, tag = 0
 __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells,
                                                       unsigned char* __restrict__ dirty) {

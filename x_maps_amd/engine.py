@@ -305,6 +305,25 @@ class XMapsEngine:
                                                 int(h), int(w), _ptr(out), C.byref(n_out)))
         return out[:n_out.value].copy()
 
+    # ---- N2: pause detection on the device -------------------------------------------------------------------
+    def find_pauses(self, t=None, evs=None, thresh_us: int = 40, device_ptr=None, n=None, aos=False) -> np.ndarray:
+        """np.nonzero(np.diff(t) >= thresh_us)[0] (python/trigger_finder.py:155).  Host arrays (t int64 or EventCD evs) or a
+        device pointer (device_ptr, n, aos=True for EventCD records)."""
+        if device_ptr is not None:
+            cap = int(n)
+            mem, tp, ap = N.XM_MEM_DEVICE, (None if aos else device_ptr), (device_ptr if aos else None)
+        elif evs is not None:
+            from .synthetic import EVENT_CD_DTYPE
+            evs = np.ascontiguousarray(evs if evs.dtype == EVENT_CD_DTYPE else evs.astype(EVENT_CD_DTYPE))
+            cap, mem, tp, ap = len(evs), N.XM_MEM_HOST, None, evs
+        else:
+            t = np.ascontiguousarray(t, dtype=np.int64)
+            cap, mem, tp, ap = len(t), N.XM_MEM_HOST, t, None
+        out = np.empty(max(cap, 1), np.uint32)
+        n_out = C.c_size_t(0)
+        N.check(self._lib.xm_find_pauses(self._h, _ptr(tp), _ptr(ap), cap, mem, int(thresh_us), _ptr(out), len(out), C.byref(n_out)))
+        return out[:n_out.value].astype(np.int64)
+
     # ---- shards (device pointers) ----------------------------------------------------------------------
     def shard_minmax(self, t_ptr, p_ptr, n, t_dtype=N.XM_T_INT64):
         np_dt = {N.XM_T_INT64: np.int64, N.XM_T_FLOAT32: np.float32, N.XM_T_FLOAT64: np.float64}[t_dtype]
