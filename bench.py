@@ -268,7 +268,7 @@ def main():
         host_path = None
         if args.host_path:
             x, y, t = host_frames[0]
-            for _ in range(3):
+            for _ in range(max(3, args.slots + 1)):  # every slot allocates its staging buffers on first use
                 eng.process_frame(x, y, t, want_bgr=bgr_out is not None)
             c0 = time.perf_counter()
             for _ in range(20):
