@@ -180,6 +180,15 @@ int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, c
 /* ---- the reference's stages one by one (host pointers, synchronous) -------------------------------- */
 /* A1  CamProjMaps.rectify_cam_coords_i16(events) -> (xr, yr) */
 int xm_stage_rectify(xm_handle* h, const uint16_t* x, const uint16_t* y, size_t n, int16_t* xr, int16_t* yr);
+/* A1f CamProjMaps.rectify_cam_coords_f32(events) (cam_proj_calibration.py:272-275): gather from the caller's float
+ *     rectify maps, row-major [cam_h][cam_w]; the offline evaluation caller needs it for the point cloud
+ *     (eval/compute_depth_x_maps.py:99).  Out-of-range coordinates -> XM_ERR_INDEX. */
+int xm_stage_rectify_f32(xm_handle* h, const float* mapx_f32, const float* mapy_f32, const uint16_t* x,
+                         const uint16_t* y, size_t n, float* xr, float* yr);
+/* CamProjMaps.construct_point_cloud(xpr, ypr, disp) (cam_proj_calibration.py:319-331): Q is the 4x4 float64
+ *     reprojection matrix (row-major; cast to float32 like the reference), cloud is float32 [n][3]. */
+int xm_stage_point_cloud(xm_handle* h, const double* Q, const float* xpr, const float* ypr, const float* disp, size_t n,
+                         float* cloud);
 /* A2  compute_disparity(xr, yr, t, X, T_PX_SCALE, X_OFFSET): full-length disp[n] (0 where masked out)
  *     and mask[n]; the caller compacts disp[mask] to get the reference's first return value */
 int xm_stage_event_disparity(xm_handle* h, const int16_t* xr, const int16_t* yr, const void* t, size_t n,

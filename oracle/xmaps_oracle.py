@@ -292,6 +292,40 @@ def decode_key_frame(kf, tag=1):
 
 # --------------------------------------------------------------------------------------------------
 # setup-time tables ("next" row N1; used here to build realistic X-maps for tests)
+def rectify_cam_coords_f32(mapx_f32, mapy_f32, x, y):
+    """python/cam_proj_calibration.py:272-275"""
+    x = np.asarray(x).astype(np.int64)
+    y = np.asarray(y).astype(np.int64)
+    return np.asarray(mapx_f32, np.float32)[y, x], np.asarray(mapy_f32, np.float32)[y, x]
+
+
+def construct_point_cloud(Q, xpr_f32, ypr_f32, disp_f32):
+    """python/cam_proj_calibration.py:319-331: homogeneous [x+d, y, -d, 1] through Q (float32), perspective divide,
+    y and z negated.  d == 0 divides by zero exactly as there (inf / nan rows)."""
+    n = len(xpr_f32)
+    pts = np.ones((n, 4), np.float32)
+    pts[:, 0] = np.asarray(xpr_f32, np.float32) + np.asarray(disp_f32, np.float32)
+    pts[:, 1] = ypr_f32
+    pts[:, 2] = -np.asarray(disp_f32, np.float32)
+    pc = (np.asarray(Q).astype(np.float32) @ pts.T).T
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pc = (pc / pc[:, 3:])[:, :3]
+    pc[:, 1] = -pc[:, 1]
+    pc[:, 2] = -pc[:, 2]
+    return pc
+
+
+def time_surface_to_events(cam_image):
+    """python/eval/compute_depth_x_maps.py:83-97: the evaluation caller's event list (raster order, float t in (0, 1])."""
+    img = np.array(cam_image, dtype=np.float64, copy=True)
+    nz = img != 0
+    lo, hi = img[nz].min(), img[nz].max()
+    img = (img - lo) / (hi - lo)
+    img[img < 0] = 0
+    yx = np.argwhere(img > 0)
+    return yx[:, 1], yx[:, 0], img[img > 0]
+
+
 def generate_linear_projector_time_map(proj_w, proj_h, scan_upwards):
     """Ideal raster time map: x is the slow axis, y the fast one.  python/proj_time_map.py:6-19."""
     ys, xs = np.mgrid[0:proj_h, 0:proj_w]

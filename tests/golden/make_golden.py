@@ -352,3 +352,46 @@ def g6_calibration_data():
 
 if __name__ == "__main__":
     g6_calibration_data()
+
+
+def g7_eval_caller(ref):
+    """The offline-evaluation caller (python/eval/compute_depth_x_maps.py:81-114) through the reference's functions:
+    time surface -> normalise -> events (raster order, float t) -> rectify i16 / f32 -> compute_event_disparity ->
+    compute_disp_map_camera_view -> disparity_to_depth_rectified -> construct_point_cloud."""
+    rng = np.random.default_rng(71)
+    cw, ch, rw, rh, xw = 64, 48, 176, 132, 64
+    tb = small_tables(rng, cw, ch, rw, rh, xw)
+    # f32 rectify maps (disp_cam_map{x,y}_f32) whose rint gives the i16 LUT
+    mapx_f = (tb["mapx"] + rng.uniform(-0.45, 0.45, tb["mapx"].shape)).astype(np.float32)
+    mapy_f = (tb["mapy"] + rng.uniform(-0.45, 0.45, tb["mapy"].shape)).astype(np.float32)
+    cam_image = (rng.random((ch, cw)) * 0.8 + 0.1).astype(np.float64)
+    cam_image[rng.random(cam_image.shape) < 0.35] = 0
+    raw = cam_image.copy()
+    # lines 83-87 of the script
+    cam_image = (cam_image - np.min(cam_image[cam_image != 0])) / (np.max(cam_image[cam_image != 0]) - np.min(cam_image[cam_image != 0]))
+    cam_image[cam_image < 0] = 0
+    event_y = np.argwhere(cam_image > 0)[:, 0]
+    event_x = np.argwhere(cam_image > 0)[:, 1]
+    event_t = cam_image[cam_image > 0]
+    events = {"x": event_x, "y": event_y, "t": event_t}
+    CPM = ref.calib.CamProjMaps
+    obj = _duck_maps(tb["mapx"], tb["mapy"], rh, rw, ch, cw)
+    obj.disp_cam_mapx_f32, obj.disp_cam_mapy_f32 = mapx_f, mapy_f
+    Q = np.array([[1, 0, 0, -80.5], [0, 1, 0, -60.25], [0, 0, 0, 540.0], [0, 0, -7.75, 0]], dtype=np.float64)
+    obj.Q = Q
+    xr_f, yr_f = CPM.rectify_cam_coords_f32(obj, events)
+    xr, yr = CPM.rectify_cam_coords_i16(obj, events)
+    disp, mask = ref.xmd.compute_disparity(xr, yr, events["t"], tb["xmap"], xw - 1, 4242)
+    disp_map = CPM.compute_disp_map_camera_view(obj, events, mask, disp)
+    P = np.zeros((3, 4))
+    P[0, 3] = 69.4
+    depth = ref.d2d.disparity_to_depth_rectified(disp_map, P)
+    cloud = CPM.construct_point_cloud(obj, xr_f[mask], yr_f[mask], disp)
+    save("g7_eval_caller.npz", raw_time_surface=raw, mapx=tb["mapx"], mapy=tb["mapy"], mapx_f32=mapx_f, mapy_f32=mapy_f,
+         xmap=tb["xmap"], rect_h=np.array(rh), rect_w=np.array(rw), t_px_scale=np.array(xw - 1), Q=Q, p03=np.array(69.4),
+         event_x=event_x, event_y=event_y, event_t=event_t, disp=disp, mask=mask, disp_map=disp_map, depth=depth,
+         xr_f32=xr_f, yr_f32=yr_f, cloud=cloud)
+
+
+if __name__ == "__main__":
+    g7_eval_caller(import_reference())

@@ -123,3 +123,24 @@ def test_dilate_and_remap_properties():
             mx, my = m[v, u]
             exp = d[my, mx] if (0 <= mx < 31 and 0 <= my < 23) else 0
             assert r[v, u] == exp
+
+
+def test_eval_caller_matches_reference(golden_dir):
+    """The offline-evaluation caller (eval/compute_depth_x_maps.py:81-114) and construct_point_cloud, restated."""
+    g = _load(golden_dir, "g7_eval_caller")
+    x, y, t = O.time_surface_to_events(g["raw_time_surface"])
+    assert np.array_equal(x, g["event_x"]) and np.array_equal(y, g["event_y"]) and np.array_equal(t, g["event_t"])
+    assert np.any(np.diff(t) < 0)  # raster order: not time-sorted
+    xr, yr = O.rectify_cam_coords_i16(g["mapx"], g["mapy"], x, y)
+    disp, mask = O.compute_disparity(xr, yr, t, g["xmap"], int(g["t_px_scale"]))
+    assert np.array_equal(disp, g["disp"]) and np.array_equal(mask, g["mask"])
+    ch, cw = g["mapx"].shape
+    dm = O.disp_map_camera_view(x, y, mask, disp, ch, cw)
+    assert np.array_equal(dm, g["disp_map"])
+    assert np.array_equal(O.disparity_to_depth_rectified(dm, float(g["p03"])), g["depth"])
+    xf, yf = O.rectify_cam_coords_f32(g["mapx_f32"], g["mapy_f32"], x, y)
+    assert xf.dtype == np.float32 and np.array_equal(xf, g["xr_f32"]) and np.array_equal(yf, g["yr_f32"])
+    cloud = O.construct_point_cloud(g["Q"], xf[mask], yf[mask], disp)
+    assert cloud.dtype == np.float32 and cloud.shape == g["cloud"].shape
+    assert np.array_equal(cloud, g["cloud"], equal_nan=True)
+    assert np.isfinite(cloud).all() == bool((disp != 0).all())

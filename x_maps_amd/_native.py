@@ -104,6 +104,8 @@ SYMBOLS = {
     "xm_graph_destroy": (None, [_P]),
     "xm_debug_event_outputs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "xm_stage_rectify": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
+    "xm_stage_rectify_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
+    "xm_stage_point_cloud": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),
     "xm_stage_event_disparity": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P]),
     "xm_stage_disp_map_projector_view": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),
     "xm_stage_disp_map_camera_view": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -56,12 +56,29 @@ class CamProjMaps:
                                      projector_height=proj_h)
         self.P2 = np.zeros((3, 4))
         self.P2[0, 3] = float(tb["p03"])
+        # optional: float rectify maps and Q, only the offline evaluation caller needs them
+        self.disp_cam_mapx_f32 = tb.get("cam_mapx_f32")
+        self.disp_cam_mapy_f32 = tb.get("cam_mapy_f32")
+        self.Q = tb.get("Q")
         self.engine = XMapsEngine(tb, camera_perspective=self.camera_perspective, device=self.device,
                                   n_slots=self.n_slots, assume_time_sorted=self.assume_time_sorted)
 
     def rectify_cam_coords_i16(self, events):
         x, y = _events_xy(events)
         return self.engine.rectify_cam_coords_i16(x, y)
+
+    def rectify_cam_coords_f32(self, events):
+        """python/cam_proj_calibration.py:272-275"""
+        if self.disp_cam_mapx_f32 is None or self.disp_cam_mapy_f32 is None:
+            raise AttributeError("tables hold no cam_mapx_f32 / cam_mapy_f32 (export them to use the f32 rectification)")
+        x, y = _events_xy(events)
+        return self.engine.rectify_cam_coords_f32(self.disp_cam_mapx_f32, self.disp_cam_mapy_f32, x, y)
+
+    def construct_point_cloud(self, xpr_f32, ypr_f32, disp_f32):
+        """python/cam_proj_calibration.py:319-331"""
+        if self.Q is None:
+            raise AttributeError("tables hold no Q (4x4 reprojection matrix)")
+        return self.engine.construct_point_cloud(self.Q, xpr_f32, ypr_f32, disp_f32)
 
     def compute_disp_map_projector_view(self, ev_x_rect_i16, ev_y_rect_i16, inlier_mask, ev_disparity_f32):
         full = np.zeros(len(inlier_mask), np.int16)

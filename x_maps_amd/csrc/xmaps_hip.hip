@@ -996,6 +996,50 @@ int xm_stage_rectify(xm_handle* h, const uint16_t* x, const uint16_t* y, size_t 
   return read_oob(h, s.stream, "rectify_cam_coords_i16");
 }
 
+int xm_stage_rectify_f32(xm_handle* h, const float* mapx_f32, const float* mapy_f32, const uint16_t* x, const uint16_t* y,
+                         size_t n, float* xr, float* yr) {
+  if (!h || !mapx_f32 || !mapy_f32 || (n && (!x || !y || !xr || !yr))) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (n == 0) return XM_OK;
+  Slot& s = h->slots[0];
+  const size_t map_bytes = (size_t)h->cfg.cam_width * h->cfg.cam_height * 4;
+  int rc;
+  if ((rc = stage_in(s.ev_x, x, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.ev_y, y, n * 2, s.stream))) return rc;
+  if ((rc = stage_in(s.dbg[2], mapx_f32, map_bytes, s.stream))) return rc;
+  if ((rc = stage_in(s.dbg[3], mapy_f32, map_bytes, s.stream))) return rc;
+  if ((rc = s.dbg[0].reserve(n * 4)) || (rc = s.dbg[1].reserve(n * 4))) return rc;
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  hipLaunchKernelGGL(k_stage_rectify_f32, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s.stream, (const uint16_t*)s.ev_x.p,
+                     (const uint16_t*)s.ev_y.p, (u64)n, h->cfg.cam_width, h->cfg.cam_height, (const float*)s.dbg[2].p,
+                     (const float*)s.dbg[3].p, (float*)s.dbg[0].p, (float*)s.dbg[1].p, &h->aux_st->cnt[0][0][CNT_OOB]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(xr, s.dbg[0].p, n * 4, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipMemcpyAsync(yr, s.dbg[1].p, n * 4, hipMemcpyDeviceToHost, s.stream));
+  return read_oob(h, s.stream, "rectify_cam_coords_f32");
+}
+
+int xm_stage_point_cloud(xm_handle* h, const double* Q, const float* xpr, const float* ypr, const float* disp, size_t n,
+                         float* cloud) {
+  if (!h || !Q || (n && (!xpr || !ypr || !disp || !cloud))) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->cfg.device));
+  if (n == 0) return XM_OK;
+  Slot& s = h->slots[0];
+  int rc;
+  if ((rc = stage_in(s.dbg[0], xpr, n * 4, s.stream))) return rc;
+  if ((rc = stage_in(s.dbg[1], ypr, n * 4, s.stream))) return rc;
+  if ((rc = stage_in(s.dbg[2], disp, n * 4, s.stream))) return rc;
+  if ((rc = s.dbg[3].reserve(n * 12))) return rc;
+  Mat4f q;
+  for (int i = 0; i < 16; ++i) q.m[i] = (float)Q[i];  // self.Q.astype(np.float32)
+  hipLaunchKernelGGL(k_point_cloud, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s.stream, (const float*)s.dbg[0].p,
+                     (const float*)s.dbg[1].p, (const float*)s.dbg[2].p, (u64)n, q, (float*)s.dbg[3].p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(cloud, s.dbg[3].p, n * 12, hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  return XM_OK;
+}
+
 int xm_stage_event_disparity(xm_handle* h, const int16_t* xr, const int16_t* yr, const void* t, size_t n, int t_dtype,
                              int16_t* disp, uint8_t* mask) {
   if (!h || (n && (!xr || !yr || !t || !disp || !mask))) return fail(XM_ERR_INVALID, "NULL argument");

@@ -1367,6 +1367,52 @@ __global__ __launch_bounds__(BLOCK) void k_stage_rectify(const uint16_t* __restr
   yr[i] = (int16_t)(l >> 16);
 }
 
+// CamProjMaps.rectify_cam_coords_f32 (cam_proj_calibration.py:272-275): gather from the caller's float rectify maps
+// (row-major [cam_h][cam_w]); used by the offline evaluation caller (eval/compute_depth_x_maps.py:99) for the point cloud.
+__global__ __launch_bounds__(BLOCK) void k_stage_rectify_f32(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                             u64 n, int cam_w, int cam_h, const float* __restrict__ mapx,
+                                                             const float* __restrict__ mapy, float* __restrict__ xr,
+                                                             float* __restrict__ yr, u32* __restrict__ oob_count) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const u32 x = xs[i], y = ys[i];
+  if (x >= (u32)cam_w || y >= (u32)cam_h) {
+    atomicAdd(oob_count, 1u);
+    xr[i] = 0.f;
+    yr[i] = 0.f;
+    return;
+  }
+  const u32 o = y * (u32)cam_w + x;
+  xr[i] = mapx[o];
+  yr[i] = mapy[o];
+}
+
+// CamProjMaps.construct_point_cloud (cam_proj_calibration.py:319-331): [x+d, y, -d, 1] through Q in float32,
+// perspective divide, y and z negated.  d == 0 gives the same inf/nan the NumPy code produces.
+struct Mat4f {
+  float m[16];
+};
+__global__ __launch_bounds__(BLOCK) void k_point_cloud(const float* __restrict__ xpr, const float* __restrict__ ypr,
+                                                       const float* __restrict__ disp, u64 n, Mat4f Q,
+                                                       float* __restrict__ cloud) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const float d = disp[i];
+  const float p0 = xpr[i] + d, p1 = ypr[i], p2 = -d;
+  float r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float acc = Q.m[4 * k] * p0;
+    acc = fmaf(Q.m[4 * k + 1], p1, acc);
+    acc = fmaf(Q.m[4 * k + 2], p2, acc);
+    acc = acc + Q.m[4 * k + 3];
+    r[k] = acc;
+  }
+  cloud[3 * i + 0] = r[0] / r[3];
+  cloud[3 * i + 1] = -(r[1] / r[3]);
+  cloud[3 * i + 2] = -(r[2] / r[3]);
+}
+
 // A2 on caller-supplied rectified coordinates
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_stage_event_disparity(const int16_t* __restrict__ xr,

@@ -7,6 +7,14 @@ from dataclasses import dataclass
 from .cam_proj_calibration import CamProjMaps
 
 
+def disparity_to_depth_rectified(disparity, P2, engine):
+    """Module-level form the evaluation script calls (python/disp_to_depth.py:46-63): depth = max(P2[0,3]/d, 1e-9)
+    where d != 0.  `engine` is the XMapsEngine whose p03 must be P2[0,3] (it is a table of that engine)."""
+    if abs(float(P2[0, 3]) - engine.p03) > 0:
+        raise ValueError("P2[0,3] differs from the engine's p03")
+    return engine.disparity_to_depth(disparity)
+
+
 @dataclass
 class DisparityToDepth:
     stats: object

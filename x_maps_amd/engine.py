@@ -96,6 +96,7 @@ class XMapsEngine:
         cfg.n_slots = n_slots
         cfg.flags = N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0
         cfg.p03 = float(tables["p03"])
+        self.p03 = cfg.p03
         cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
         cfg.cam_mapx_i16 = mapx.ctypes.data
         cfg.cam_mapy_i16 = mapy.ctypes.data
@@ -238,6 +239,32 @@ class XMapsEngine:
         yr = np.empty(len(x), np.int16)
         N.check(self._lib.xm_stage_rectify(self._h, _ptr(x), _ptr(y), len(x), _ptr(xr), _ptr(yr)))
         return xr, yr
+
+    def rectify_cam_coords_f32(self, mapx_f32, mapy_f32, x, y):
+        """CamProjMaps.rectify_cam_coords_f32 (cam_proj_calibration.py:272-275) from float maps [cam_h][cam_w]."""
+        mx = np.ascontiguousarray(mapx_f32, dtype=np.float32)
+        my = np.ascontiguousarray(mapy_f32, dtype=np.float32)
+        if mx.shape != (self.cam_h, self.cam_w) or my.shape != mx.shape:
+            raise ValueError(f"float rectify maps must be ({self.cam_h}, {self.cam_w})")
+        x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
+        xr = np.empty(len(x), np.float32)
+        yr = np.empty(len(x), np.float32)
+        N.check(self._lib.xm_stage_rectify_f32(self._h, _ptr(mx), _ptr(my), _ptr(x), _ptr(y), len(x), _ptr(xr), _ptr(yr)))
+        return xr, yr
+
+    def construct_point_cloud(self, Q, xpr_f32, ypr_f32, disp_f32):
+        """CamProjMaps.construct_point_cloud (cam_proj_calibration.py:319-331) -> float32 [n][3]."""
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        if Q.shape != (4, 4):
+            raise ValueError("Q must be 4x4")
+        xp = np.ascontiguousarray(xpr_f32, dtype=np.float32)
+        yp = np.ascontiguousarray(ypr_f32, dtype=np.float32)
+        d = np.ascontiguousarray(disp_f32, dtype=np.float32)
+        if not (len(xp) == len(yp) == len(d)):
+            raise ValueError("xpr, ypr and disp must have the same length")
+        cloud = np.empty((len(d), 3), np.float32)
+        N.check(self._lib.xm_stage_point_cloud(self._h, _ptr(Q), _ptr(xp), _ptr(yp), _ptr(d), len(d), _ptr(cloud)))
+        return cloud
 
     def event_disparity_full(self, xr_i16, yr_i16, t):
         """A2 with full-length outputs: (disp[n] int16 with 0 where masked, mask[n] bool)."""
