@@ -14,8 +14,9 @@ X, Y, T = (torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int
 depth = torch.empty((eng.out_h, eng.out_w), dtype=torch.float32, device=dev)
 torch.cuda.synchronize()
 lib = N.load_library()
-names = ["start", "minmax loaded", "events issued", "samples->window", "bands issued+stored", "cols computed(pre-barrier)", "barrier1",
-         "per-event done", "barrier2", "flush issued", "end"]
+names = ["0 start", "1 event+sample loads issued", "2 extrema loaded, TimeNorm", "3 window from samples", "4 bands loaded+stored, slots zeroed",
+         "5 time columns computed", "6 barrier1", "7 fast + slow pass done", "8 barrier2", "9 flush issued", "10 end",
+         "11 (s_col_used zeroed)", "12 (event loads issued)"]
 acc = []
 for it in range(30):
     eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None)
@@ -23,11 +24,13 @@ for it in range(30):
     buf = np.zeros((64, 16), np.uint64)
     lib.xm_debug_timeline(ctypes.c_void_p(buf.ctypes.data))
     if it >= 5:
-        acc.append((buf[:, :11].astype(np.int64) - buf[:, :1].astype(np.int64)))
+        acc.append((buf[:, :13].astype(np.int64) - buf[:, :1].astype(np.int64)))
 a = np.mean(acc, axis=0)  # [block][phase] in s_memtime ticks (100 MHz constant clock on gfx9: 10 ns)
-print("phase                          mean over blocks 0..63   (ticks; s_memtime = 100 MHz => x10 ns)")
+print("phase                          mean over blocks 0..63   (s_memtime ticks; scale with the kernel duration printed below)")
 prev = 0
 for i, nm in enumerate(names):
     m = a[:, i].mean()
-    print(f"{nm:32s} t={m:9.1f}  (+{m - prev:8.1f})")
+    print(f"{nm:44s} t={m:9.1f}  (+{m - prev:8.1f})" if i < 11 else f"{nm:44s} t={m:9.1f}")
     prev = m
+import subprocess
+print("kernel duration by events:", eng.profile_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None).gpu_ms)

@@ -234,18 +234,25 @@ int launch_scatter_tv(const ScatterArgs& a) {
   // de-duplicate) go to the one-thread-per-event kernel, whose cost is proportional to n.
   const double max_ev = a.tb->xmap_w > 0 ? (a.w_ts - 1.5) * (double)n / (double)a.tb->xmap_w : 0.0;
   if (!a.direct && a.w_ts > 0 && a.w_x > 0 && max_ev >= 1024.0) {
-    auto kern = k_scatter_tiled<T, AOS, HAS_P, VIEW>;
-    static size_t lds_set = 0;  // per instantiation: raise the dynamic-LDS cap once (gfx950: 160 KB / CU)
-    if (a.lds > lds_set) {
+    // vector-load variant: 16-byte aligned SoA columns with int64 t (the EventCD time type); everything else takes the
+    // lane-strided loads (any alignment)
+    constexpr bool kHasVec = !AOS && std::is_same<T, long long>::value;
+    auto kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, false>;
+    if constexpr (kHasVec) {
+      if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, true>;
+    }
+    static size_t lds_set[2] = {0, 0};  // per kernel: raise the dynamic-LDS cap once (gfx950: 160 KB / CU)
+    size_t& set = lds_set[kHasVec && vec16 ? 1 : 0];
+    if (a.lds > set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)a.lds));
-      lds_set = a.lds;
+      set = a.lds;
     }
     unsigned threads = TILE_THREADS;
     while (threads > 256 && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;
     XM_LAUNCH(kern, dim3(grid_for(n, threads * TILE_EPT)), dim3(threads), a.lds, a.stream, ev.x, ev.y,
               (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-              a.mm_lo, a.mm_hi, a.frame, a.dirty, a.w_ts, a.w_x, vec16 ? 1 : 0, a.sorted ? 1 : 0);
+              a.mm_lo, a.mm_hi, a.frame, a.dirty, a.w_ts, a.w_x, a.sorted ? 1 : 0);
     return XM_OK;
   }
   if constexpr (AOS) {

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
 // =====================================================================================================
 #ifdef XM_ABLATE
 __device__ int g_ablate = 0;  // bit0: no flush atomics, bit1: no LDS slot atomics, bit2: no band loads, bit3: no time divide
-#define XM_ABL(bit) (g_ablate & (1 << (bit)))
+#define XM_ABL(bit) (g_ablate & (1 << (bit)))  // bit 2 (band loads) no longer wired
 __device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime stamps of thread 0 (experiments only)
 #define XM_STAMP(ph) do { if ((threadIdx.x == 0) && blockIdx.x < 64) g_timeline[blockIdx.x][ph] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -524,13 +524,30 @@ constexpr int TILE_THREADS = XM_TILE_THREADS;   // 512 x 8 or 1024 x 4 events: s
 constexpr int TILE_EPT = 4096 / XM_TILE_THREADS;
 constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;  // largest block: 4096 events (the LDS slots hold (local idx + 1) << 16)
 
-template <typename T, bool AOS, bool HAS_P, int VIEW>
+// VEC: SoA columns 16-byte aligned -> each thread loads TILE_EPT consecutive events with 8/16-byte loads.  A compile-time
+// switch, not a per-block branch: with both load paths in one kernel the compiler's wait-count bookkeeping at the join
+// put full vmcnt waits in front of the event loads and of the extrema reduction (seen in the ISA).
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
 __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
     u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, unsigned char* __restrict__ dirty, int w_ts, int w_x,
-    int vec_ok, int sorted_mode) {
+    int sorted_mode) {
+  static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifndef XM_NO_KERNARG_BATCH
+  // All kernel arguments into SGPRs in ONE scalar-load round trip: a test that needs every one of them, placed first.
+  // Left alone the compiler fetches them lazily, block by block -- eight dependent s_load -> s_waitcnt pairs along the
+  // critical chain of every block (seen in the ISA).  (Inline asm would do it too, but makes every later uniform load a
+  // vector load.)  Never true: sizes are non-negative and device addresses have bit 63 clear.
+  {
+    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)ps | (u64)aos | (u64)tb.lut | (u64)tb.xmap | (u64)st | (u64)frame |
+                   (u64)dirty | n | idx_offset;
+    const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.t_px_scale | tb.x_offset | tb.rect_w | tb.rect_h |
+                   (int)tag_override | w_ts | w_x | sorted_mode;
+    if ((long long)(pp | (u64)(long long)pi) < 0) return;
+  }
+#endif
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift)
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
   const int win_q = (win_words + 3) >> 2;  // uint4 count
@@ -539,24 +556,84 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   u32* lut_base = win + 4 * win_q;
   int16_t* xm_base = reinterpret_cast<int16_t*>(lut_base + 4 * lut_q);
   __shared__ u32 s_in, s_oob;
-  __shared__ u32 s_col_used[64];  // VIEW 0: which time columns of the window received an event
 
   const int tid = threadIdx.x;
-  const int nthreads = blockDim.x;             // 64 .. 1024, chosen per frame by the host so that the block's
+  const int nthreads = blockDim.x;               // 64 .. 1024, chosen per frame by the host so that the block's
   const int ev_per_block = nthreads * TILE_EPT;  // time slice fits the LDS window (see launch_scatter)
   XM_STAMP(0);
-  for (int i = tid; i < 64; i += nthreads) s_col_used[i] = 0;
-  const u64 block_base = (u64)blockIdx.x * ev_per_block;
-  const bool have = block_base < n;  // false only for the single block of an empty frame
+  const u64 block_base = (u64)blockIdx.x * ev_per_block;  // < n: the host launches ceil(n / ev_per_block) blocks, n > 0
 
-  // ---- 1. loads that depend on nothing, issued first: this thread's 4 events and the 3 window samples ---------------
-  u32 x[TILE_EPT], y[TILE_EPT], lidx[TILE_EPT];
+  // ---- 1. Every load that depends on nothing is ISSUED here, small ones first, and nothing is consumed before the
+  //         last one is out: vector memory returns in order, so the few bytes that locate the tile (samples, frame
+  //         extrema) can be waited for with the 48 KB of events still in flight behind them.
+  // 1a. three sampled events (first / middle / last of the block) locate the time slice; t[0] and t[n-1] are the frame
+  //     extrema of the time-sorted mode.  Uniform loads.
+  int sx[3];
+  T st_t[3];
+  T t_first, t_last;
+  {
+    const u64 last = (block_base + ev_per_block <= n ? block_base + ev_per_block : n) - 1;
+    const u64 si[3] = {block_base, block_base + ((last - block_base) >> 1), last};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if constexpr (AOS) {
+        const uint4 r = aos[si[j]];
+        sx[j] = (int)(r.x & 0xffff);
+        st_t[j] = (T)(long long)(((u64)r.w << 32) | r.z);
+      } else {
+        sx[j] = (int)xs[si[j]];
+        st_t[j] = ts[si[j]];
+      }
+    }
+    if constexpr (AOS) {
+      const uint4 a = aos[0], b = aos[n - 1];
+      t_first = (T)(long long)(((u64)a.w << 32) | a.z);
+      t_last = (T)(long long)(((u64)b.w << 32) | b.z);
+    } else {
+      t_first = ts[0];
+      t_last = ts[n - 1];
+    }
+  }
+  // 1b. frame extrema as K0 left them: BOTH parities (2 x 16 B in lanes < MM_SLOTS), selected once the tag is known --
+  //     loading only the right one would put a scalar load (the tag) in front of this vector load.
+  //     Lanes >= MM_SLOTS load a duplicate slot, which a min/max reduction does not notice.
+  const ulonglong2 mm_p0 = *reinterpret_cast<const ulonglong2*>(&st->mm[0][tid & (MM_SLOTS - 1)][0]);
+  const ulonglong2 mm_p1 = *reinterpret_cast<const ulonglong2*>(&st->mm[1][tid & (MM_SLOTS - 1)][0]);
+  // 1c. this thread's events, kept PACKED (two 16-bit coordinates per register) until after the window is known
+  u32 xw[TILE_EPT / 2], yw[TILE_EPT / 2], pw[TILE_EPT / 2];
   T tt[TILE_EPT];
-  bool used[TILE_EPT];
-  const bool vec = !AOS && vec_ok && block_base + ev_per_block <= n;
-  if (vec) {  // TILE_EPT consecutive events per thread: 8/16-byte loads of x / y / p, 16-byte loads of t
-    const u64 base = block_base + (u64)tid * TILE_EPT;
-    u32 xw[TILE_EPT / 2], yw[TILE_EPT / 2], pw[TILE_EPT / 2];
+  u32 inb = 0;  // bit k: event k of this thread exists (index < n)
+#pragma unroll
+  for (int q = 0; q < TILE_EPT / 2; ++q) xw[q] = yw[q] = pw[q] = 0;
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) tt[k] = (T)0;
+  if constexpr (AOS) {  // EventCD records: event k*nthreads + tid, one 16-byte load each, clamped (branch-free)
+    {
+#pragma unroll
+      for (int k = 0; k < TILE_EPT; ++k) {
+        const u64 i = block_base + (u32)k * nthreads + tid;
+        const bool ok = i < n;
+        const uint4 r = aos[ok ? i : block_base];
+        inb |= ok ? 1u << k : 0u;
+        if (k & 1) {
+          xw[k >> 1] |= (r.x & 0xffff) << 16;
+          yw[k >> 1] |= r.x & 0xffff0000u;
+          pw[k >> 1] |= r.y << 16;
+        } else {
+          xw[k >> 1] = r.x & 0xffff;
+          yw[k >> 1] = r.x >> 16;
+          pw[k >> 1] = r.y & 0xffff;
+        }
+        tt[k] = (T)(long long)(((u64)r.w << 32) | r.z);
+      }
+    }
+  } else if constexpr (VEC) {  // TILE_EPT consecutive events per thread: 8/16-byte loads of x / y / p, 16-byte loads of t
+    // Ragged end of the frame, branch-free: a thread past the end re-reads the last group (its events are masked out);
+    // the thread that straddles the end loads its whole aligned group -- an aligned 8/16-byte word whose first element
+    // is valid cannot cross into another page -- and a t pair that starts past the end is redirected to the first pair.
+    const u64 base_true = block_base + (u64)tid * TILE_EPT;
+    const u64 last_grp = (n - 1) & ~(u64)(TILE_EPT - 1);
+    const u64 base = base_true < last_grp ? base_true : last_grp;
     if constexpr (TILE_EPT == 8) {
       const uint4 xv = *reinterpret_cast<const uint4*>(xs + base);
       const uint4 yv = *reinterpret_cast<const uint4*>(ys + base);
@@ -576,73 +653,35 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
         pw[0] = pv.x; pw[1] = pv.y;
       }
     }
-#pragma unroll
-    for (int q = 0; q < TILE_EPT / 2; ++q) {
-      x[2 * q] = xw[q] & 0xffff; x[2 * q + 1] = xw[q] >> 16;
-      y[2 * q] = yw[q] & 0xffff; y[2 * q + 1] = yw[q] >> 16;
-      used[2 * q] = used[2 * q + 1] = true;
-      if constexpr (HAS_P) {
-        used[2 * q] = (short)(pw[q] & 0xffff) == 1;
-        used[2 * q + 1] = (short)(pw[q] >> 16) == 1;
-      }
-    }
     if constexpr (sizeof(T) == 8) {
 #pragma unroll
       for (int q = 0; q < TILE_EPT / 2; ++q) {
-        const longlong2 a = *reinterpret_cast<const longlong2*>(ts + base + 2 * q);
+        const longlong2 a = *reinterpret_cast<const longlong2*>(ts + (base + 2 * q < n ? base + 2 * q : base));
         __builtin_memcpy(&tt[2 * q], &a.x, 8);
         __builtin_memcpy(&tt[2 * q + 1], &a.y, 8);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < TILE_EPT / 4; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(ts + base + 4 * q);
+        const float4 a = *reinterpret_cast<const float4*>(ts + (base + 4 * q < n ? base + 4 * q : base));
         __builtin_memcpy(&tt[4 * q], &a.x, 4); __builtin_memcpy(&tt[4 * q + 1], &a.y, 4);
         __builtin_memcpy(&tt[4 * q + 2], &a.z, 4); __builtin_memcpy(&tt[4 * q + 3], &a.w, 4);
       }
     }
 #pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) lidx[k] = (u32)tid * TILE_EPT + k;
-  } else {  // any alignment / ragged tail / AoS records: event k*512 + tid, still coalesced across lanes
+    for (int k = 0; k < TILE_EPT; ++k) inb |= base_true + k < n ? 1u << k : 0u;
+  } else {  // any alignment / ragged tail: event k*nthreads + tid, still coalesced across lanes, clamped
 #pragma unroll
     for (int k = 0; k < TILE_EPT; ++k) {
-      lidx[k] = (u32)k * nthreads + tid;
-      const u64 i = block_base + lidx[k];
-      used[k] = i < n;
-      tt[k] = (T)0;
-      x[k] = y[k] = 0;
-      if (used[k]) {
-        if constexpr (AOS) {
-          const uint4 r = aos[i];
-          x[k] = r.x & 0xffff;
-          y[k] = r.x >> 16;
-          tt[k] = (T)(long long)(((u64)r.w << 32) | r.z);
-          if (HAS_P) used[k] = (short)(r.y & 0xffff) == 1;
-        } else {
-          x[k] = xs[i];
-          y[k] = ys[i];
-          tt[k] = ts[i];
-          if (HAS_P) used[k] = ps[i] == 1;
-        }
-      }
-    }
-  }
-  // three sampled events (first / middle / last of the block) locate the time slice: uniform loads
-  int sx[3] = {0, 0, 0};
-  T st_t[3] = {(T)0, (T)0, (T)0};
-  if (have) {
-    const u64 last = (block_base + ev_per_block <= n ? block_base + ev_per_block : n) - 1;
-    const u64 si[3] = {block_base, block_base + ((last - block_base) >> 1), last};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if constexpr (AOS) {
-        const uint4 r = aos[si[j]];
-        sx[j] = (int)(r.x & 0xffff);
-        st_t[j] = (T)(long long)(((u64)r.w << 32) | r.z);
-      } else {
-        sx[j] = (int)xs[si[j]];
-        st_t[j] = ts[si[j]];
-      }
+      const u64 i = block_base + (u32)k * nthreads + tid;
+      const bool ok = i < n;
+      const u64 ic = ok ? i : block_base;
+      const u32 xv = xs[ic], yv = ys[ic];
+      tt[k] = ts[ic];
+      inb |= ok ? 1u << k : 0u;
+      xw[k >> 1] |= xv << ((k & 1) * 16);
+      yw[k >> 1] |= yv << ((k & 1) * 16);
+      if constexpr (HAS_P) pw[k >> 1] |= (u32)(uint16_t)ps[ic] << ((k & 1) * 16);
     }
   }
   XM_STAMP(1);
@@ -653,27 +692,24 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   const u32 tag = tag_override ? tag_override : (sorted_mode ? st->tag_b + 1 : st->tag_a);
   const u32 parity = tag & 1;
   u64 lo, hi;
-  if (tag_override) {
+  if (tag_override) {  // sharded mode: the FRAME's extrema come from the host-side all-reduce
     lo = mm_lo;
     hi = mm_hi;
   } else {
     if (sorted_mode) {
-      T t_first = (T)0, t_last = (T)0;
-      if (n) {
-        if constexpr (AOS) {
-          const uint4 a = aos[0], b = aos[n - 1];
-          t_first = (T)(long long)(((u64)a.w << 32) | a.z);
-          t_last = (T)(long long)(((u64)b.w << 32) | b.z);
-        } else {
-          t_first = ts[0];
-          t_last = ts[n - 1];
-        }
-      }
       lo = TimeCodec<T>::enc(t_first);
       hi = TimeCodec<T>::enc(t_last);
       if (hi < lo) hi = lo;  // not sorted at all: keep the arithmetic defined; the verification flags the frame
     } else {
-      load_frame_minmax(st, parity, lo, hi);
+      u64 a = parity ? mm_p1.x : mm_p0.x, b = parity ? mm_p1.y : mm_p0.y;
+#pragma unroll
+      for (int o = MM_SLOTS / 2; o > 0; o >>= 1) {
+        const u64 a2 = __shfl_xor(a, o, 64), b2 = __shfl_xor(b, o, 64);
+        a = a2 < a ? a2 : a;
+        b = b2 > b ? b2 : b;
+      }
+      lo = uniform_u64(a);
+      hi = uniform_u64(b);
     }
     if (blockIdx.x == 0) {
       if (tid == 0) {
@@ -705,64 +741,55 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   {
     int sc[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) sc[j] = have ? tn.column(st_t[j]) : 0;
+    for (int j = 0; j < 3; ++j) sc[j] = tn.column(st_t[j]);
     const int mx = max(min(sx[0], sx[1]), min(max(sx[0], sx[1]), sx[2]));
     const int mc = max(min(sc[0], sc[1]), min(max(sc[0], sc[1]), sc[2]));
     x_lo = min(max(mx - w_x / 2, 0), max(tb.cam_w - w_x, 0));
     ts_lo = min(max(mc - w_ts / 2, 0), max(tb.xmap_w - w_ts, 0));
   }
   XM_STAMP(3);
-  // the bands are contiguous runs of the column-major tables: [x_lo, x_lo + w_x) x cam_h words and
-  // [ts_lo, ts_lo + w_ts) x xmap_h int16.  Aligned 16-byte loads, every load in flight at once; the LDS copies keep
-  // the global misalignment (a few elements of slack in front).
+  // The bands are contiguous runs of the column-major tables: [x_lo, x_lo + w_x) x cam_h words and
+  // [ts_lo, ts_lo + w_ts) x xmap_h int16.  Aligned 16-byte loads over ONE index space (LUT quads, then X-map quads), so a
+  // 1024-thread block issues 3 loads per thread, all in flight at once; the LDS copies keep the global misalignment (a
+  // few elements of slack in front).  Branch-free on purpose: loads use a clamped index and out-of-range lanes store into
+  // a dummy LDS slot -- any predication here turns into one basic block per load with an s_waitcnt vmcnt(0) behind it
+  // (seen in the ISA), i.e. serialized L2 round trips.
   const int wx_eff = min(w_x, tb.cam_w), wts_eff = min(w_ts, tb.xmap_w);
   const u32 lut_start = (u32)x_lo * (u32)tb.cam_h, lut_shift = lut_start & 3u;  // in words
   const u32 xm_start = (u32)ts_lo * (u32)tb.xmap_h, xm_shift = xm_start & 7u;   // in int16
   const u32* lut_t = lut_base + lut_shift;
   const int16_t* xm_t = xm_base + xm_shift;
+  const uint4* g_lut = reinterpret_cast<const uint4*>(tb.lut + (lut_start - lut_shift));
+  const int nq_lut = (int)((lut_shift + (u32)wx_eff * (u32)tb.cam_h + 3u) >> 2);
+  const uint4* g_xm = reinterpret_cast<const uint4*>(tb.xmap + (xm_start - xm_shift));
+  const int nq_xm = (int)((xm_shift + (u32)wts_eff * (u32)tb.xmap_h + 7u) >> 3);
+  const int nq_all = nq_lut + nq_xm;
+  uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
+  uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
+  uint4* l_dummy = l_xm + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
+  constexpr int UNB = 3;
+  const auto band_src = [&](int i) -> const uint4* { return i < nq_lut ? g_lut + i : g_xm + min(i - nq_lut, nq_xm - 1); };
+  const auto band_dst = [&](int i) -> uint4* { return i < nq_lut ? l_lut + i : (i < nq_all ? l_xm + (i - nq_lut) : l_dummy); };
+  const uint4 bv0 = *band_src(tid), bv1 = *band_src(tid + nthreads), bv2 = *band_src(tid + 2 * nthreads);
   {
-    const uint4* g_lut = reinterpret_cast<const uint4*>(tb.lut + (lut_start - lut_shift));
-    const int nq_lut = (int)((lut_shift + (u32)wx_eff * (u32)tb.cam_h + 3u) >> 2);
-    const uint4* g_xm = reinterpret_cast<const uint4*>(tb.xmap + (xm_start - xm_shift));
-    const int nq_xm = (int)((xm_shift + (u32)wts_eff * (u32)tb.xmap_h + 7u) >> 3);
-    uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
-    uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
-    constexpr int UN = 4;
-    // Branch-free on purpose: loads use a clamped index and out-of-range lanes store into a dummy LDS slot.  Any
-    // predication here turns into one basic block per load with an s_waitcnt vmcnt(0) behind it (seen in the ISA),
-    // i.e. 8 serialized L2 round trips per block instead of one.
-    uint4* l_dummy = reinterpret_cast<uint4*>(xm_base) + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
-    if (!XM_ABL(2)) {
-      for (int i0 = tid; i0 < nq_lut; i0 += UN * nthreads) {
-        uint4 v[UN];
-#pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = g_lut[min(i0 + j * nthreads, nq_lut - 1)];
-#pragma unroll
-        for (int j = 0; j < UN; ++j) {
-          const int i = i0 + j * nthreads;
-          (i < nq_lut ? l_lut + i : l_dummy)[0] = v[j];
-        }
-      }
-      for (int i0 = tid; i0 < nq_xm; i0 += UN * nthreads) {
-        uint4 v[UN];
-#pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = g_xm[min(i0 + j * nthreads, nq_xm - 1)];
-#pragma unroll
-        for (int j = 0; j < UN; ++j) {
-          const int i = i0 + j * nthreads;
-          (i < nq_xm ? l_xm + i : l_dummy)[0] = v[j];
-        }
-      }
-    }
     uint4* l_win = reinterpret_cast<uint4*>(win);
     for (int i = tid; i < win_q; i += nthreads) l_win[i] = make_uint4(0, 0, 0, 0);
   }
   XM_STAMP(4);
 
-  // ---- 4. time columns of this thread's events (bit-exact with NumPy, see TimeNorm) ------------------------------------
+  // ---- 4. with the bands in flight: unpack the events, their time columns (bit-exact with NumPy, see TimeNorm) ---------
+  u32 x[TILE_EPT], y[TILE_EPT], lidx[TILE_EPT];
+  bool used[TILE_EPT];
   int col[TILE_EPT];
 #pragma unroll
-  for (int k = 0; k < TILE_EPT; ++k) col[k] = used[k] ? (XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k])) : 0;
+  for (int k = 0; k < TILE_EPT; ++k) {
+    x[k] = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+    y[k] = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+    used[k] = (inb >> k) & 1;
+    if constexpr (HAS_P) used[k] = used[k] && (short)((pw[k >> 1] >> ((k & 1) * 16)) & 0xffff) == 1;
+    lidx[k] = VEC ? (u32)tid * TILE_EPT + k : (u32)k * nthreads + tid;
+    col[k] = used[k] ? (XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k])) : 0;
+  }
   if (sorted_mode) {  // verify the time-sorted declaration: 2 compares per event
     bool bad = false;
 #pragma unroll
@@ -775,27 +802,70 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
       __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  // Events outside the windows (unsorted / raster-ordered input, a noise event) take the global path: same arithmetic as
+  // event_disparity_col + event_cell, but its three dependent round trips are spread over waits the block has anyway --
+  // the LUT gather rides with the band loads, the X-map gather with the fast path's LDS work, the atomic is issued
+  // before the flush.  Whole waves skip all of it (the ballot is wave-uniform) unless one of their events needs it.
+  int xl[TILE_EPT], tl[TILE_EPT];
+  bool fast[TILE_EPT], slow[TILE_EPT], s_oob_ev[TILE_EPT];
+  bool any_slow_lane = false;
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) {
+    xl[k] = (int)x[k] - x_lo;
+    tl[k] = col[k] - ts_lo;
+    fast[k] = used[k] && (u32)xl[k] < (u32)wx_eff && (u32)tl[k] < (u32)wts_eff && y[k] < (u32)tb.cam_h;
+    slow[k] = used[k] && !fast[k];
+    s_oob_ev[k] = slow[k] && (x[k] >= (u32)tb.cam_w || y[k] >= (u32)tb.cam_h);  // map[y, x] IndexError (calib:279-280)
+    any_slow_lane = any_slow_lane || slow[k];
+  }
+  const bool wave_slow = __ballot(any_slow_lane) != 0;
+  u32 l_s[TILE_EPT];
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) l_s[k] = 0;
+  if (wave_slow) {
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) l_s[k] = tb.lut[slow[k] && !s_oob_ev[k] ? x[k] * (u32)tb.cam_h + y[k] : 0u];
+  }
   XM_STAMP(5);
+  {
+    *band_dst(tid) = bv0;
+    *band_dst(tid + nthreads) = bv1;
+    *band_dst(tid + 2 * nthreads) = bv2;
+    for (int i0 = tid + UNB * nthreads; i0 < nq_all; i0 += UNB * nthreads) {  // blocks smaller than 1024 threads
+      const uint4 v0 = *band_src(i0), v1 = *band_src(i0 + nthreads), v2 = *band_src(i0 + 2 * nthreads);
+      *band_dst(i0) = v0;
+      *band_dst(i0 + nthreads) = v1;
+      *band_dst(i0 + 2 * nthreads) = v2;
+    }
+  }
+  // slow events, second gather (X-map) issued before the barrier
+  int xr_s[TILE_EPT], yr_s[TILE_EPT], xp_s[TILE_EPT];
+  bool yok_s[TILE_EPT];
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) xr_s[k] = yr_s[k] = xp_s[k] = 0, yok_s[k] = false;
+  if (wave_slow) {
+#pragma unroll
+    for (int k = 0; k < TILE_EPT; ++k) {
+      xr_s[k] = (int)(short)(l_s[k] & 0xffff);
+      yr_s[k] = (int)(short)(l_s[k] >> 16);
+      yok_s[k] = slow[k] && !s_oob_ev[k] && yr_s[k] >= 0 && yr_s[k] < tb.xmap_h - 1;  // xmd:23
+      if (yok_s[k] && (u32)col[k] >= (u32)tb.xmap_w) {  // only reachable when the caller's extrema do not bound t
+        s_oob_ev[k] = true;
+        yok_s[k] = false;
+      }
+      xp_s[k] = (int)tb.xmap[yok_s[k] ? col[k] * tb.xmap_h + yr_s[k] : 0];  // xmd:25
+    }
+  }
   __syncthreads();  // bands + cleared slots visible
   XM_STAMP(6);
 
   // ---- 5. fast path, BRANCH-FREE so that the four events' LDS round trips overlap: A1 + A2 out of the LDS bands with
-  //         clamped addresses, collisions resolved with ds_max_u32.  Events that need anything else (outside a window,
-  //         index error) are only flagged here and handled in the rare pass below.
-  u32 n_in = 0;
-  bool slow[TILE_EPT];
+  //         clamped addresses, collisions resolved with ds_max_u32.
+  u32 n_in = 0, n_oob = 0;
   {
-    int xl[TILE_EPT], tl[TILE_EPT];
-    bool fast[TILE_EPT];
     u32 l[TILE_EPT];
 #pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) {
-      xl[k] = (int)x[k] - x_lo;
-      tl[k] = col[k] - ts_lo;
-      fast[k] = used[k] && (u32)xl[k] < (u32)wx_eff && (u32)tl[k] < (u32)wts_eff && y[k] < (u32)tb.cam_h;
-      slow[k] = used[k] && !fast[k];
-      l[k] = lut_t[fast[k] ? xl[k] * tb.cam_h + (int)y[k] : 0];
-    }
+    for (int k = 0; k < TILE_EPT; ++k) l[k] = lut_t[fast[k] ? xl[k] * tb.cam_h + (int)y[k] : 0];
     int xr[TILE_EPT], yr[TILE_EPT], xp[TILE_EPT];
     bool yok[TILE_EPT];
 #pragma unroll
@@ -813,45 +883,41 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
       if constexpr (VIEW == 0) {
         int fc = (int)(short)(xr[k] + disp);  // = xp - x_offset (calib:300)
         if (fc < 0) fc += tb.rect_w;
-        const bool inb = fc >= 0 && fc < tb.rect_w && yr[k] < tb.rect_h;
-        slow[k] = slow[k] || (write && !inb);  // IndexError candidates are counted by the slow pass
-        write = write && inb;
+        const bool in_frame = fc >= 0 && fc < tb.rect_w && yr[k] < tb.rect_h;
+        n_oob += __popcll(__ballot(write && !in_frame));  // NumPy IndexError
+        write = write && in_frame;
         slot = tl[k] * tb.xmap_h + yr[k];
       } else {
         slot = (int)y[k] * w_x + xl[k];
       }
-      if (write && !XM_ABL(1)) {
-        atomicMax(&win[slot], ((lidx[k] + 1) << 16) | (u32)disp);
-        if constexpr (VIEW == 0) s_col_used[tl[k]] = 1;
-      }
+      if (write && !XM_ABL(1)) atomicMax(&win[slot], ((lidx[k] + 1) << 16) | (u32)disp);
       n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
     }
   }
-  // ---- 5b. rare pass: events outside the windows take the global path (same arithmetic, direct atomics) --------------
-  u32 n_oob = 0;
-  bool any_slow = false;
-#pragma unroll
-  for (int k = 0; k < TILE_EPT; ++k) any_slow = any_slow || slow[k];
-  if (__ballot(any_slow)) {
+  // slow events: disparity, cell, atomic straight into the key frame
+  if (wave_slow) {
 #pragma unroll
     for (int k = 0; k < TILE_EPT; ++k) {
-      bool oob = false, write = false;
-      if (slow[k]) {
-        const EventResult r = event_disparity_col(tb, col[k], x[k], y[k], oob);
-        u32 cell = 0;
-        write = r.inlier;
-        if (write && !event_cell<VIEW>(tb, r, x[k], y[k], cell)) {
-          write = false;
-          oob = true;
-        }
-        if (write) {
-          const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
-          __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
-        }
+      const int disp = (int)(short)(xp_s[k] - xr_s[k] - tb.x_offset);
+      bool write = yok_s[k] && disp >= 0;
+      u32 cell;
+      if constexpr (VIEW == 0) {
+        int fc = (int)(short)(xr_s[k] + disp);
+        if (fc < 0) fc += tb.rect_w;
+        const bool in_frame = fc >= 0 && fc < tb.rect_w && yr_s[k] < tb.rect_h;
+        s_oob_ev[k] = s_oob_ev[k] || (write && !in_frame);
+        write = write && in_frame;
+        cell = (u32)fc * (u32)tb.rect_h + (u32)yr_s[k];
+      } else {
+        cell = y[k] * (u32)tb.cam_w + x[k];
+      }
+      if (write) {
+        const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)disp;
+        __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
       }
       n_in += __popcll(__ballot(write));
-      n_oob += __popcll(__ballot(oob));
+      n_oob += __popcll(__ballot(s_oob_ev[k]));
     }
   }
   if ((tid & 63) == 0) {
@@ -863,52 +929,39 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   XM_STAMP(8);
 
   // ---- 6. flush the winners: consecutive lanes -> consecutive slots = consecutive rows of one frame column (VIEW 0) /
-  //         consecutive x of one row (VIEW 1).  All LDS reads of a thread are issued before the first atomic.
-  if constexpr (VIEW == 0) {
+  //         consecutive x of one row (VIEW 1).  One pass over the whole window (empty slots cost an LDS read, nothing
+  //         else); all LDS reads of a thread are issued before its first atomic.
+  {
     constexpr int FL = 4;
-    for (int c = 0; c < w_ts; ++c) {
-      if (!s_col_used[c]) continue;  // block-uniform: a sorted slice touches 3-4 of the window's columns
-      const int base = c * tb.xmap_h;
-      for (int r0 = tid; r0 < tb.xmap_h; r0 += FL * nthreads) {
-        u32 v[FL];
-        int xv[FL];
-#pragma unroll
-        for (int j = 0; j < FL; ++j) {  // all LDS reads first (clamped), atomics afterwards
-          const int r = min(r0 + j * nthreads, tb.xmap_h - 1);
-          v[j] = win[base + r];
-          xv[j] = (int)xm_t[base + r];
-        }
-#pragma unroll
-        for (int j = 0; j < FL; ++j) {
-          const int r = r0 + j * nthreads;
-          if (r < tb.xmap_h && v[j]) {
-            const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
-            int fc = (int)(short)(xv[j] - tb.x_offset);
-            if (fc < 0) fc += tb.rect_w;
-            const u32 cell = (u32)fc * (u32)tb.rect_h + (u32)r;
-            if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (dirty) dirty[cell >> 4] = dirty_byte(tag);  // consecutive lanes = consecutive rows: same byte for 16 lanes
-          }
-        }
-      }
-    }
-  } else {
-    constexpr int FL = 4;
-    const float inv_d = 1.0f / (float)w_x;
+    const int per = VIEW == 0 ? tb.xmap_h : w_x;  // slots per window column (VIEW 0) / per camera row (VIEW 1)
+    const float inv_per = 1.0f / (float)per;
     for (int i0 = tid; i0 < win_words; i0 += FL * nthreads) {
       u32 v[FL];
+      int xv[FL];
 #pragma unroll
-      for (int j = 0; j < FL; ++j) v[j] = win[min(i0 + j * nthreads, win_words - 1)];
+      for (int j = 0; j < FL; ++j) {
+        const int i = min(i0 + j * nthreads, win_words - 1);
+        v[j] = win[i];
+        xv[j] = VIEW == 0 ? (int)xm_t[i] : 0;
+      }
 #pragma unroll
       for (int j = 0; j < FL; ++j) {
         const int i = i0 + j * nthreads;
         if (i < win_words && v[j]) {
-          int q = (int)((float)i * inv_d), r = i - q * w_x;  // camera row, x - x_lo (no integer divide)
-          if (r < 0) { q -= 1; r += w_x; }
-          if (r >= w_x) { q += 1; r -= w_x; }
+          int q = (int)((float)i * inv_per), r = i - q * per;  // no integer divide
+          if (r < 0) { q -= 1; r += per; }
+          if (r >= per) { q += 1; r -= per; }
           const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
-          __hip_atomic_fetch_max(&frame[(u32)q * (u32)tb.cam_w + (u32)(x_lo + r)], key, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+          u32 cell;
+          if constexpr (VIEW == 0) {  // q = window column, r = rectified row; the frame column comes from the X-map band
+            int fc = (int)(short)(xv[j] - tb.x_offset);
+            if (fc < 0) fc += tb.rect_w;
+            cell = (u32)fc * (u32)tb.rect_h + (u32)r;
+          } else {  // q = camera row, r = x - x_lo
+            cell = (u32)q * (u32)tb.cam_w + (u32)(x_lo + r);
+          }
+          if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);  // consecutive lanes = consecutive rows
         }
       }
     }
