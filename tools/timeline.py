@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 lib = N.load_library()
 names = ["0 start", "1 event+sample loads issued", "2 extrema loaded, TimeNorm", "3 window from samples", "4 bands loaded+stored, slots zeroed",
          "5 time columns computed", "6 barrier1", "7 fast + slow pass done", "8 barrier2", "9 flush issued", "10 end",
-         "11 (s_col_used zeroed)", "12 (event loads issued)"]
+         "11 (bands stored to LDS)", "12 (slow gather 2 issued, before barrier1)"]
 acc = []
 for it in range(30):
     eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None)

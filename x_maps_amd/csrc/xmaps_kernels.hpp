@@ -152,6 +152,14 @@ template <> struct TimeNorm<float> {  // eval caller with an f32 time surface: N
   }
 };
 
+// blockIdx -> work item such that the blocks that land on one XCD (blockIdx % 8 under round-robin dispatch) own a
+// contiguous range of items.  Bijective for any grid size.
+constexpr u32 N_XCD = 8;
+__device__ inline u32 xcd_contiguous(u32 b, u32 nb) {
+  const u32 xcd = b % N_XCD, j = b / N_XCD, q = nb / N_XCD, r = nb % N_XCD;
+  return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
 // ---- wave helpers (wave = 64 lanes) ------------------------------------------------------------------
 __device__ inline u64 wave_min_u64(u64 v) {
 #pragma unroll
@@ -203,10 +211,10 @@ template <typename T, bool AOS, bool HAS_P, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const int16_t* __restrict__ p,
                                                   const uint4* __restrict__ aos, u64 n, SlotState* st,
                                                   u32 tag_override) {
-  const u32 tag = tag_override ? tag_override : st->tag_b + 1;
-  const u32 parity = tag & 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->tag_a = tag;
-
+  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
+  if ((long long)((u64)t | (u64)p | (u64)aos | (u64)st | n | (u64)tag_override) < 0) return;
+  // the frame tag is only needed for the final atomics: its load (kernarg -> st -> tag_b, a dependent scalar chain) must
+  // not sit in front of the event loads
   u64 lo = MM_INIT_MIN, hi = MM_INIT_MAX;
   u32 used = 0;
   const u64 stride = (u64)gridDim.x * BLOCK;
@@ -281,11 +289,19 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
     }
   }
 
-  // wave -> block -> one pair of fire-and-forget atomics per block, spread over MM_SLOTS addresses
-  lo = wave_min_u64(lo);
-  hi = wave_max_u64(hi);
+  const u32 tag = tag_override ? tag_override : st->tag_b + 1;
+  const u32 parity = tag & 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->tag_a = tag;
+  // wave -> block -> one pair of fire-and-forget atomics per block, spread over MM_SLOTS addresses.  The three wave
+  // reductions advance together: 6 dependent cross-lane steps instead of 18.
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) used += __shfl_xor(used, o, 64);
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 lo2 = __shfl_xor(lo, o, 64), hi2 = __shfl_xor(hi, o, 64);
+    const u32 u2 = __shfl_xor(used, o, 64);
+    lo = lo2 < lo ? lo2 : lo;
+    hi = hi2 > hi ? hi2 : hi;
+    used += u2;
+  }
   __shared__ u64 s_lo[BLOCK / 64], s_hi[BLOCK / 64];
   __shared__ u32 s_used[BLOCK / 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -561,7 +577,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   const int nthreads = blockDim.x;               // 64 .. 1024, chosen per frame by the host so that the block's
   const int ev_per_block = nthreads * TILE_EPT;  // time slice fits the LDS window (see launch_scatter)
   XM_STAMP(0);
-  const u64 block_base = (u64)blockIdx.x * ev_per_block;  // < n: the host launches ceil(n / ev_per_block) blocks, n > 0
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share
+  // almost all of their LUT band and a column of their X-map band, so XCD k takes the k-th CONTIGUOUS eighth of the
+  // frame's tiles: the bands then come out of that XCD's L2 instead of being fetched over the fabric once per block.
+  const u32 tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const u64 block_base = (u64)tile * ev_per_block;  // < n: the host launches ceil(n / ev_per_block) blocks, n > 0
 
   // ---- 1. Every load that depends on nothing is ISSUED here, small ones first, and nothing is consumed before the
   //         last one is out: vector memory returns in order, so the few bytes that locate the tile (samples, frame
@@ -802,29 +822,53 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
       __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  // Events outside the windows (unsorted / raster-ordered input, a noise event) take the global path: same arithmetic as
-  // event_disparity_col + event_cell, but its three dependent round trips are spread over waits the block has anyway --
-  // the LUT gather rides with the band loads, the X-map gather with the fast path's LDS work, the atomic is issued
-  // before the flush.  Whole waves skip all of it (the ballot is wave-uniform) unless one of their events needs it.
+  // Events outside the windows (unsorted / raster-ordered input, a noise event) take the global path -- the very functions
+  // of the direct kernel -- in a compact loop: one pass handles every lane's next such event, so a wave with a single
+  // stray event (the common case, 0.3 % of the events of a sorted frame but half of its waves) runs ~100 instructions, and
+  // a wave without any skips the loop.  The block is issue-bound here (4 waves per SIMD), so the two dependent round
+  // trips of a stray event are covered by the other waves' arithmetic; the band loads above are in flight meanwhile.
   int xl[TILE_EPT], tl[TILE_EPT];
-  bool fast[TILE_EPT], slow[TILE_EPT], s_oob_ev[TILE_EPT];
-  bool any_slow_lane = false;
+  bool fast[TILE_EPT];
+  u32 smask = 0;
 #pragma unroll
   for (int k = 0; k < TILE_EPT; ++k) {
     xl[k] = (int)x[k] - x_lo;
     tl[k] = col[k] - ts_lo;
     fast[k] = used[k] && (u32)xl[k] < (u32)wx_eff && (u32)tl[k] < (u32)wts_eff && y[k] < (u32)tb.cam_h;
-    slow[k] = used[k] && !fast[k];
-    s_oob_ev[k] = slow[k] && (x[k] >= (u32)tb.cam_w || y[k] >= (u32)tb.cam_h);  // map[y, x] IndexError (calib:279-280)
-    any_slow_lane = any_slow_lane || slow[k];
+    smask |= used[k] && !fast[k] ? 1u << k : 0u;
   }
-  const bool wave_slow = __ballot(any_slow_lane) != 0;
-  u32 l_s[TILE_EPT];
+  u32 n_in = 0, n_oob = 0;
+  while (__ballot(smask != 0)) {
+    const bool act = smask != 0;
+    const int ks = act ? __builtin_ctz(smask) : 0;
+    smask &= smask - 1;
+    u32 ex = x[0], ey = y[0], el = lidx[0];
+    int ec = col[0];
 #pragma unroll
-  for (int k = 0; k < TILE_EPT; ++k) l_s[k] = 0;
-  if (wave_slow) {
-#pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) l_s[k] = tb.lut[slow[k] && !s_oob_ev[k] ? x[k] * (u32)tb.cam_h + y[k] : 0u];
+    for (int kk = 1; kk < TILE_EPT; ++kk) {
+      const bool sel = ks == kk;
+      ex = sel ? x[kk] : ex;
+      ey = sel ? y[kk] : ey;
+      el = sel ? lidx[kk] : el;
+      ec = sel ? col[kk] : ec;
+    }
+    bool oob = false, write = false;
+    if (act) {
+      const EventResult r = event_disparity_col(tb, ec, ex, ey, oob);
+      u32 cell = 0;
+      write = r.inlier;
+      if (write && !event_cell<VIEW>(tb, r, ex, ey, cell)) {
+        write = false;
+        oob = true;
+      }
+      if (write) {
+        const u64 key = key_hi | ((idx_offset + block_base + el) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
+        __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
+      }
+    }
+    n_in += __popcll(__ballot(write));
+    n_oob += __popcll(__ballot(oob));
   }
   XM_STAMP(5);
   {
@@ -838,30 +882,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
       *band_dst(i0 + 2 * nthreads) = v2;
     }
   }
-  // slow events, second gather (X-map) issued before the barrier
-  int xr_s[TILE_EPT], yr_s[TILE_EPT], xp_s[TILE_EPT];
-  bool yok_s[TILE_EPT];
-#pragma unroll
-  for (int k = 0; k < TILE_EPT; ++k) xr_s[k] = yr_s[k] = xp_s[k] = 0, yok_s[k] = false;
-  if (wave_slow) {
-#pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) {
-      xr_s[k] = (int)(short)(l_s[k] & 0xffff);
-      yr_s[k] = (int)(short)(l_s[k] >> 16);
-      yok_s[k] = slow[k] && !s_oob_ev[k] && yr_s[k] >= 0 && yr_s[k] < tb.xmap_h - 1;  // xmd:23
-      if (yok_s[k] && (u32)col[k] >= (u32)tb.xmap_w) {  // only reachable when the caller's extrema do not bound t
-        s_oob_ev[k] = true;
-        yok_s[k] = false;
-      }
-      xp_s[k] = (int)tb.xmap[yok_s[k] ? col[k] * tb.xmap_h + yr_s[k] : 0];  // xmd:25
-    }
-  }
+  XM_STAMP(11);
+  XM_STAMP(12);
   __syncthreads();  // bands + cleared slots visible
   XM_STAMP(6);
 
   // ---- 5. fast path, BRANCH-FREE so that the four events' LDS round trips overlap: A1 + A2 out of the LDS bands with
   //         clamped addresses, collisions resolved with ds_max_u32.
-  u32 n_in = 0, n_oob = 0;
   {
     u32 l[TILE_EPT];
 #pragma unroll
@@ -892,32 +919,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
       }
       if (write && !XM_ABL(1)) atomicMax(&win[slot], ((lidx[k] + 1) << 16) | (u32)disp);
       n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
-    }
-  }
-  // slow events: disparity, cell, atomic straight into the key frame
-  if (wave_slow) {
-#pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) {
-      const int disp = (int)(short)(xp_s[k] - xr_s[k] - tb.x_offset);
-      bool write = yok_s[k] && disp >= 0;
-      u32 cell;
-      if constexpr (VIEW == 0) {
-        int fc = (int)(short)(xr_s[k] + disp);
-        if (fc < 0) fc += tb.rect_w;
-        const bool in_frame = fc >= 0 && fc < tb.rect_w && yr_s[k] < tb.rect_h;
-        s_oob_ev[k] = s_oob_ev[k] || (write && !in_frame);
-        write = write && in_frame;
-        cell = (u32)fc * (u32)tb.rect_h + (u32)yr_s[k];
-      } else {
-        cell = y[k] * (u32)tb.cam_w + x[k];
-      }
-      if (write) {
-        const u64 key = key_hi | ((idx_offset + block_base + lidx[k]) << KEY_IDX_SHIFT) | (u64)(u32)disp;
-        __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
-      }
-      n_in += __popcll(__ballot(write));
-      n_oob += __popcll(__ballot(s_oob_ev[k]));
     }
   }
   if ((tid & 63) == 0) {
@@ -1181,16 +1182,21 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
-  const u32 tag = tag_override ? tag_override : st->tag_a;
-  if (!tag_override && blockIdx.x == 0 && blockIdx.y == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
-    u32* c = st->cnt[(tag & 1) ^ 1][tid];
-    c[0] = c[1] = c[2] = c[3] = 0;
-    if (tid == 0) st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
-  }
-  const int u = blockIdx.x * K2_TX + tx, v = blockIdx.y * K2_TY + ty;
+  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
+  if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
+                  (u64)zero16 | (u64)depth | (u64)bgr |
+                  (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
+    return;
+  // XCD-aware tile order (see xcd_contiguous): each XCD takes a contiguous run of the tile raster, so the halos that
+  // neighbouring tiles share (3 of 22 patch columns each side, boundary cache lines above/below) hit in its own L2.
+  const u32 grid_x = gridDim.x;
+  const u32 lin_tile = xcd_contiguous(blockIdx.y * grid_x + blockIdx.x, grid_x * gridDim.y);
+  const u32 tile_y = lin_tile / grid_x, tile_x = lin_tile - tile_y * grid_x;
+  const u32 tag = tag_override ? tag_override : st->tag_a;  // first needed when the patch is decoded
+  const int u = tile_x * K2_TX + tx, v = tile_y * K2_TY + ty;
   const bool in_img = u < tb.proj_w && v < tb.proj_h;
   // the tile's patch rectangle and the pixel's offset into it were computed once in xm_create (k_build_k2_tables)
-  const int4 rec = tb.k2_tiles[blockIdx.y * gridDim.x + blockIdx.x];  // block-uniform
+  const int4 rec = tb.k2_tiles[lin_tile];  // block-uniform
   const u32 poff = in_img ? tb.k2_pix[(u32)v * (u32)tb.proj_w + (u32)u] : ~0u;
   int mx = 0, my = 0;
   bool valid = poff != ~0u;
@@ -1334,9 +1340,14 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
 #else
   o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
 #endif
+  if (!tag_override && lin_tile == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
+    u32* c = st->cnt[(tag & 1) ^ 1][tid];
+    c[0] = c[1] = c[2] = c[3] = 0;
+    if (tid == 0) st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
+  }
   if (depth && in_img) depth[(u32)v * (u32)tb.proj_w + (u32)u] = o.depth;
   if (bgr) {
-    const bool full_rows = (tb.proj_w & 3) == 0 && (blockIdx.x + 1) * K2_TX <= tb.proj_w;
+    const bool full_rows = (tb.proj_w & 3) == 0 && (tile_x + 1) * K2_TX <= tb.proj_w;
     if (full_rows) {  // 96 contiguous bytes per tile row: assemble in LDS, store as dwords
       s_bgr[ty][tx * 3 + 0] = (uint8_t)(o.bgr & 0xff);
       s_bgr[ty][tx * 3 + 1] = (uint8_t)((o.bgr >> 8) & 0xff);
@@ -1344,9 +1355,9 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
       __syncthreads();
       constexpr int DW = K2_TX * 3 / 4;  // 24 dwords per row
       if (tid < K2_TY * DW) {
-        const int r = tid / DW, q = tid - r * DW, vv = blockIdx.y * K2_TY + r;
+        const int r = tid / DW, q = tid - r * DW, vv = tile_y * K2_TY + r;
         if (vv < tb.proj_h)
-          reinterpret_cast<u32*>(bgr + ((u64)vv * tb.proj_w + (u64)blockIdx.x * K2_TX) * 3)[q] =
+          reinterpret_cast<u32*>(bgr + ((u64)vv * tb.proj_w + (u64)tile_x * K2_TX) * 3)[q] =
               reinterpret_cast<const u32*>(&s_bgr[r][0])[q];
       }
     } else if (in_img) {
