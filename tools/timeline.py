@@ -18,12 +18,14 @@ names = ["0 start", "1 event+sample loads issued", "2 extrema loaded, TimeNorm",
          "5 time columns computed", "6 barrier1", "7 fast + slow pass done", "8 barrier2", "9 flush issued", "10 end",
          "11 (bands stored to LDS)", "12 (slow gather 2 issued, before barrier1)"]
 acc = []
+acc_raw = []
 for it in range(30):
     eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None)
     eng.sync()
     buf = np.zeros((64, 16), np.uint64)
     lib.xm_debug_timeline(ctypes.c_void_p(buf.ctypes.data))
     if it >= 5:
+        acc_raw.append(buf.astype(np.float64))
         acc.append((buf[:, :13].astype(np.int64) - buf[:, :1].astype(np.int64)))
 a = np.mean(acc, axis=0)  # [block][phase] in s_memtime ticks (100 MHz constant clock on gfx9: 10 ns)
 print("phase                          mean over blocks 0..63   (s_memtime ticks; scale with the kernel duration printed below)")
@@ -34,3 +36,10 @@ for i, nm in enumerate(names):
     prev = m
 import subprocess
 print("kernel duration by events:", eng.profile_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None).gpu_ms)
+
+if os.environ.get("XM_STAMP_WAVES"):
+    print("per-wave stamps of block 0 (ticks since the wave-0 start), phases 1 2 3 4 5 6 7 8 9:")
+    raw = np.mean([b for b in acc_raw], axis=0)
+    t0 = raw[0, 0]
+    for w in range(16):
+        print(f"  wave {w:2d} start {raw[w,0]-t0:7.0f} | " + " ".join(f"{raw[w,i]-t0:7.0f}" for i in (1, 2, 3, 4, 5, 6, 7, 8, 9)))

@@ -96,6 +96,7 @@ struct xm_handle {
   u32* d_pmap = nullptr;
   uint2* d_dlut = nullptr;
   int4* d_k2_tiles = nullptr;
+  int k2_tile_cap = K2_TILE_MAX;  // cells of the largest K2 patch (multiple of 8)
   u32* d_k2_pix = nullptr;
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
@@ -293,8 +294,8 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
   KeyCells cells{key_frame, 0};
   if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
     XM_LAUNCH(k_frame_proj_tiled, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), 0, stream, key_frame, h->tb, st, tag_override, dirty, (const ulonglong2*)h->d_zero16,
-              depth, bgr);
+              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
+              tag_override, dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
     const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
     XM_LAUNCH((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
@@ -631,6 +632,14 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     XM_TRY_CREATE(hipDeviceSynchronize());
     h->tb.k2_tiles = h->d_k2_tiles;
     h->tb.k2_pix = h->d_k2_pix;
+    {  // largest LDS patch any tile of this rig needs -> K2's dynamic LDS
+      std::vector<int4> tiles((size_t)tiles_x * tiles_y);
+      XM_TRY_CREATE(hipMemcpy(tiles.data(), h->d_k2_tiles, tiles.size() * sizeof(int4), hipMemcpyDeviceToHost));
+      int cap = 8;
+      for (const int4& r : tiles)
+        if (r.z > 0) cap = std::max(cap, r.z * r.w);
+      h->k2_tile_cap = std::min((cap + 7) & ~7, (int)K2_TILE_MAX);
+    }
   }
   if (cfg->view == XM_VIEW_PROJECTOR) {
     h->key_cells = (size_t)cfg->rect_width * cfg->rect_height;
@@ -693,6 +702,13 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     s.st = h->d_states + i;
     hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
     XM_TRY_CREATE(hipGetLastError());
+#ifdef XM_BLOG
+    {
+      const u32 id = (u32)i;  // experiments only: the block log is indexed by slot
+      XM_TRY_CREATE(hipMemcpyAsync(&s.st->pad[0], &id, sizeof id, hipMemcpyHostToDevice, s.stream));
+      XM_TRY_CREATE(hipStreamSynchronize(s.stream));
+    }
+#endif
   }
   hipLaunchKernelGGL(k_reset_slot, dim3(1), dim3(BLOCK), 0, h->slots[0].stream, h->aux_st, (u64*)nullptr, (u64)0,
                      (unsigned char*)nullptr);
@@ -754,6 +770,19 @@ int xm_sync(xm_handle* h) {
   return XM_OK;
 }
 
+#ifdef XM_BLOG
+// experiments only: copy out (and clear) the per-block log of the hot kernels
+int xm_debug_blog(unsigned long long* out /*[BLOG_FRAMES * BLOG_SLOTS * BLOG_PER][4]*/, unsigned int cap, unsigned int* n_out) {
+  HIP_TRY(hipDeviceSynchronize());
+  const unsigned int n = xm::BLOG_FRAMES * xm::BLOG_SLOTS * xm::BLOG_PER;
+  if (out && cap >= n) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(xm::g_blog), sizeof(unsigned long long) * 4 * n));
+  void* p = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(xm::g_blog)));
+  HIP_TRY(hipMemset(p, 0, sizeof(unsigned long long) * 4 * n));
+  if (n_out) *n_out = n;
+  return XM_OK;
+}
+#endif
 #ifdef XM_ABLATE
 // experiments only: copy out the s_memtime timeline written by k_scatter_tiled
 int xm_debug_timeline(unsigned long long* out /*[64][16]*/) {

@@ -21,6 +21,7 @@
 // tables, fire-and-forget atomics and enough waves in flight to hide three dependent memory latencies.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace xm {
@@ -119,14 +120,15 @@ template <> struct TimeNorm<long long> {
   // reference's product by < 5 ulp (< 2e-11 for columns <= 32767); whenever e is further than 1e-6 from a rounding
   // boundary (x.5) both round to the same integer, so rint(e) IS the reference result.  Closer than that (exact
   // ties such as golden g1d_rint_ties land here) the IEEE divide below decides.  ~8 instructions instead of ~50.
+  // Straight-line on purpose (K1 is bound by instruction issue): the fast value is computed for every lane from the low
+  // 32 bits of a, and ONE rare branch covers everything else (a >= 2^32, near-tie, degenerate frame).
   __device__ int column(long long t) const {
-    if (degenerate) return 0;  // 0/0 = NaN -> int16 cast = 0 (what NumPy yields on x86-64)
     const u64 a = (u64)(t - tmin);
-    if (small && a <= 0xffffffffull) {
-      const double e = ((double)(u32)a * rinv) * scale;
-      const double r = rint(e);
-      if (fabs(fabs(e - r) - 0.5) > 1e-6) return (int)(short)(int)r;
-    }
+    const double e = (__uint2double_rn((u32)a) * rinv) * scale;  // meaningful only when a < 2^32
+    const double r = rint(e);
+    const bool fast_ok = small && !degenerate && (u32)(a >> 32) == 0u && fabs(fabs(e - r) - 0.5) > 1e-6;
+    if (__builtin_expect(fast_ok, 1)) return (int)(short)(int)r;
+    if (degenerate) return 0;  // 0/0 = NaN -> int16 cast = 0 (what NumPy yields on x86-64)
     const double tn = (double)(t - tmin) / den;
     return (int)(short)(int)rint(tn * scale);
   }
@@ -159,6 +161,30 @@ __device__ inline u32 xcd_contiguous(u32 b, u32 nb) {
   const u32 xcd = b % N_XCD, j = b / N_XCD, q = nb / N_XCD, r = nb % N_XCD;
   return xcd * q + (xcd < r ? xcd : r) + j;
 }
+
+// experiments only (-DXM_ABLATE): every block of the three hot kernels logs {kind, slot state, tag, start, end} in the
+// 100 MHz real-time counter -> a block-level timeline of the pipelined run (tools/block_timeline.py)
+#ifdef XM_BLOG
+// [tag & 7][slot][block within the frame: K0 at 0, K1 at 1024, K2 at 2048][kind|tag, start, end, -]: no atomics, one store
+constexpr u32 BLOG_FRAMES = 8, BLOG_SLOTS = 16, BLOG_PER = 4096;
+__device__ unsigned long long g_blog[BLOG_FRAMES * BLOG_SLOTS * BLOG_PER][4];
+#define XM_BLOG_BEGIN() const unsigned long long blog_t0 = __builtin_amdgcn_s_memrealtime()
+#define XM_BLOG_END(kind, stp, tagv)                                                                     \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) { /* thread 0 only, no barrier: its end stands for the block's */              \
+      const unsigned long long blog_t1 = __builtin_amdgcn_s_memrealtime();                               \
+      const u32 lb = blockIdx.y * gridDim.x + blockIdx.x;                                                \
+      const u32 sl = (stp)->pad[0] % BLOG_SLOTS;                                                         \
+      const u32 bi = (((tagv) & (BLOG_FRAMES - 1)) * BLOG_SLOTS + sl) * BLOG_PER + (kind) * 1024u + ((kind) == 2 ? lb % 2048u : lb % 1024u); \
+      g_blog[bi][0] = (unsigned long long)(kind) | ((unsigned long long)(tagv) << 8) | ((unsigned long long)sl << 40) | (1ull << 63); \
+      g_blog[bi][1] = blog_t0;                                                                           \
+      g_blog[bi][2] = blog_t1;                                                                           \
+    }                                                                                                    \
+  } while (0)
+#else
+#define XM_BLOG_BEGIN() do { } while (0)
+#define XM_BLOG_END(kind, stp, tagv) do { } while (0)
+#endif
 
 // ---- wave helpers (wave = 64 lanes) ------------------------------------------------------------------
 __device__ inline u64 wave_min_u64(u64 v) {
@@ -211,6 +237,7 @@ template <typename T, bool AOS, bool HAS_P, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const int16_t* __restrict__ p,
                                                   const uint4* __restrict__ aos, u64 n, SlotState* st,
                                                   u32 tag_override) {
+  XM_BLOG_BEGIN();
   // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
   if ((long long)((u64)t | (u64)p | (u64)aos | (u64)st | n | (u64)tag_override) < 0) return;
   // the frame tag is only needed for the final atomics: its load (kernarg -> st -> tag_b, a dependent scalar chain) must
@@ -327,6 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
                              __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  XM_BLOG_END(0, st, tag);
 }
 
 // =====================================================================================================
@@ -528,7 +556,11 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
 __device__ int g_ablate = 0;  // bit0: no flush atomics, bit1: no LDS slot atomics, bit2: no band loads, bit3: no time divide
 #define XM_ABL(bit) (g_ablate & (1 << (bit)))  // bit 2 (band loads) no longer wired
 __device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime stamps of thread 0 (experiments only)
+#ifdef XM_STAMP_WAVES  // rows = the 16 waves of blocks 0..3 instead of thread 0 of blocks 0..63
+#define XM_STAMP(ph) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4) g_timeline[blockIdx.x * 16 + (threadIdx.x >> 6)][ph] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define XM_STAMP(ph) do { if ((threadIdx.x == 0) && blockIdx.x < 64) g_timeline[blockIdx.x][ph] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define XM_ABL(bit) 0
 #define XM_STAMP(ph) do { } while (0)
@@ -551,6 +583,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     int sorted_mode) {
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XM_BLOG_BEGIN();
 #ifndef XM_NO_KERNARG_BATCH
   // All kernel arguments into SGPRs in ONE scalar-load round trip: a test that needs every one of them, placed first.
   // Left alone the compiler fetches them lazily, block by block -- eight dependent s_load -> s_waitcnt pairs along the
@@ -651,45 +684,51 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     // Ragged end of the frame, branch-free: a thread past the end re-reads the last group (its events are masked out);
     // the thread that straddles the end loads its whole aligned group -- an aligned 8/16-byte word whose first element
     // is valid cannot cross into another page -- and a t pair that starts past the end is redirected to the first pair.
-    const u64 base_true = block_base + (u64)tid * TILE_EPT;
-    const u64 last_grp = (n - 1) & ~(u64)(TILE_EPT - 1);
-    const u64 base = base_true < last_grp ? base_true : last_grp;
+    // 32-bit element indices (n <= 2^28) and byte offsets: the loads take the scalar-base + 32-bit-offset form
+    const u32 n32 = (u32)n;
+    const u32 base_true = (u32)block_base + (u32)tid * TILE_EPT;
+    const u32 last_grp = (n32 - 1u) & ~(u32)(TILE_EPT - 1);
+    const u32 base = base_true < last_grp ? base_true : last_grp;
+    const char* xs_b = reinterpret_cast<const char*>(xs);
+    const char* ys_b = reinterpret_cast<const char*>(ys);
+    const char* ps_b = reinterpret_cast<const char*>(ps);
+    const char* ts_b = reinterpret_cast<const char*>(ts);
     if constexpr (TILE_EPT == 8) {
-      const uint4 xv = *reinterpret_cast<const uint4*>(xs + base);
-      const uint4 yv = *reinterpret_cast<const uint4*>(ys + base);
+      const uint4 xv = *reinterpret_cast<const uint4*>(xs_b + base * 2u);
+      const uint4 yv = *reinterpret_cast<const uint4*>(ys_b + base * 2u);
       xw[0] = xv.x; xw[1] = xv.y; xw[2] = xv.z; xw[3] = xv.w;
       yw[0] = yv.x; yw[1] = yv.y; yw[2] = yv.z; yw[3] = yv.w;
       if constexpr (HAS_P) {
-        const uint4 pv = *reinterpret_cast<const uint4*>(ps + base);
+        const uint4 pv = *reinterpret_cast<const uint4*>(ps_b + base * 2u);
         pw[0] = pv.x; pw[1] = pv.y; pw[2] = pv.z; pw[3] = pv.w;
       }
     } else {
-      const uint2 xv = *reinterpret_cast<const uint2*>(xs + base);
-      const uint2 yv = *reinterpret_cast<const uint2*>(ys + base);
+      const uint2 xv = *reinterpret_cast<const uint2*>(xs_b + base * 2u);
+      const uint2 yv = *reinterpret_cast<const uint2*>(ys_b + base * 2u);
       xw[0] = xv.x; xw[1] = xv.y;
       yw[0] = yv.x; yw[1] = yv.y;
       if constexpr (HAS_P) {
-        const uint2 pv = *reinterpret_cast<const uint2*>(ps + base);
+        const uint2 pv = *reinterpret_cast<const uint2*>(ps_b + base * 2u);
         pw[0] = pv.x; pw[1] = pv.y;
       }
     }
     if constexpr (sizeof(T) == 8) {
 #pragma unroll
       for (int q = 0; q < TILE_EPT / 2; ++q) {
-        const longlong2 a = *reinterpret_cast<const longlong2*>(ts + (base + 2 * q < n ? base + 2 * q : base));
+        const longlong2 a = *reinterpret_cast<const longlong2*>(ts_b + (base + 2 * q < n32 ? base + 2 * q : base) * 8u);
         __builtin_memcpy(&tt[2 * q], &a.x, 8);
         __builtin_memcpy(&tt[2 * q + 1], &a.y, 8);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < TILE_EPT / 4; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(ts + (base + 4 * q < n ? base + 4 * q : base));
+        const float4 a = *reinterpret_cast<const float4*>(ts_b + (base + 4 * q < n32 ? base + 4 * q : base) * 4u);
         __builtin_memcpy(&tt[4 * q], &a.x, 4); __builtin_memcpy(&tt[4 * q + 1], &a.y, 4);
         __builtin_memcpy(&tt[4 * q + 2], &a.z, 4); __builtin_memcpy(&tt[4 * q + 3], &a.w, 4);
       }
     }
 #pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) inb |= base_true + k < n ? 1u << k : 0u;
+    for (int k = 0; k < TILE_EPT; ++k) inb |= base_true + k < n32 ? 1u << k : 0u;
   } else {  // any alignment / ragged tail: event k*nthreads + tid, still coalesced across lanes, clamped
 #pragma unroll
     for (int k = 0; k < TILE_EPT; ++k) {
@@ -759,11 +798,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   //         the direct path.
   int x_lo, ts_lo;
   {
-    int sc[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) sc[j] = tn.column(st_t[j]);
+    // the column is monotone in t: the median column is the column of the median time (one conversion, not three)
+    const u64 e0 = TimeCodec<T>::enc(st_t[0]), e1 = TimeCodec<T>::enc(st_t[1]), e2 = TimeCodec<T>::enc(st_t[2]);
+    const u64 lo01 = e0 < e1 ? e0 : e1, hi01 = e0 < e1 ? e1 : e0;
+    const u64 m2 = hi01 < e2 ? hi01 : e2;
+    const u64 em = lo01 > m2 ? lo01 : m2;
+    const int mc = tn.column(TimeCodec<T>::dec(em));
     const int mx = max(min(sx[0], sx[1]), min(max(sx[0], sx[1]), sx[2]));
-    const int mc = max(min(sc[0], sc[1]), min(max(sc[0], sc[1]), sc[2]));
     x_lo = min(max(mx - w_x / 2, 0), max(tb.cam_w - w_x, 0));
     ts_lo = min(max(mc - w_ts / 2, 0), max(tb.xmap_w - w_ts, 0));
   }
@@ -808,7 +849,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     used[k] = (inb >> k) & 1;
     if constexpr (HAS_P) used[k] = used[k] && (short)((pw[k >> 1] >> ((k & 1) * 16)) & 0xffff) == 1;
     lidx[k] = VEC ? (u32)tid * TILE_EPT + k : (u32)k * nthreads + tid;
-    col[k] = used[k] ? (XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k])) : 0;
+    col[k] = XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k]);  // every lane; `used` masks the event below
   }
   if (sorted_mode) {  // verify the time-sorted declaration: 2 compares per event
     bool bad = false;
@@ -934,25 +975,39 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
   //         else); all LDS reads of a thread are issued before its first atomic.
   {
     constexpr int FL = 4;
+    static_assert(KEY_IDX_SHIFT == 16, "slot value ((local idx + 1) << 16 | disp) is added to the key as is");
+    // key = tag | (global idx << 16) | disp, and the slot holds ((local idx + 1) << 16) | disp: one 64-bit add
+    const u64 key_base = key_hi + ((idx_offset + block_base - 1) << KEY_IDX_SHIFT);
     const int per = VIEW == 0 ? tb.xmap_h : w_x;  // slots per window column (VIEW 0) / per camera row (VIEW 1)
-    const float inv_per = 1.0f / (float)per;
+    // (q, r) = divmod(slot, per), advanced incrementally: slot -> slot + nthreads is (q + dq, r + dr) with one carry
+    const int dq = nthreads / per, dr = nthreads - dq * per;
+    int q_i, r_i;
+    {
+      q_i = (int)((float)tid * (1.0f / (float)per));
+      r_i = tid - q_i * per;
+      if (r_i < 0) { q_i -= 1; r_i += per; }
+      if (r_i >= per) { q_i += 1; r_i -= per; }
+    }
     for (int i0 = tid; i0 < win_words; i0 += FL * nthreads) {
       u32 v[FL];
-      int xv[FL];
+      int xv[FL], qs[FL], rs[FL];
 #pragma unroll
       for (int j = 0; j < FL; ++j) {
         const int i = min(i0 + j * nthreads, win_words - 1);
         v[j] = win[i];
         xv[j] = VIEW == 0 ? (int)xm_t[i] : 0;
+        qs[j] = q_i;
+        rs[j] = r_i;
+        q_i += dq;
+        r_i += dr;
+        if (r_i >= per) { r_i -= per; q_i += 1; }
       }
 #pragma unroll
       for (int j = 0; j < FL; ++j) {
         const int i = i0 + j * nthreads;
         if (i < win_words && v[j]) {
-          int q = (int)((float)i * inv_per), r = i - q * per;  // no integer divide
-          if (r < 0) { q -= 1; r += per; }
-          if (r >= per) { q += 1; r -= per; }
-          const u64 key = key_hi | ((idx_offset + block_base + (v[j] >> 16) - 1) << KEY_IDX_SHIFT) | (u64)(v[j] & 0xffff);
+          const int q = qs[j], r = rs[j];
+          const u64 key = key_base + v[j];
           u32 cell;
           if constexpr (VIEW == 0) {  // q = window column, r = rectified row; the frame column comes from the X-map band
             int fc = (int)(short)(xv[j] - tb.x_offset);
@@ -974,6 +1029,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
     if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   XM_STAMP(10);
+  XM_BLOG_END(1, st, tag);
 }
 
 // =====================================================================================================
@@ -1174,14 +1230,20 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
                                                                   SlotState* st, u32 tag_override,
                                                                   const unsigned char* __restrict__ dirty,
                                                                   const ulonglong2* __restrict__ zero16,
-                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr) {
-  __shared__ __attribute__((aligned(16))) uint16_t tile[K2_TILE_MAX + 16];  // +16: the last 16-byte read may overrun
-  __shared__ __attribute__((aligned(16))) uint16_t vmax[K2_TILE_MAX];
+                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr,
+                                                                  int tile_cap) {
+  // Dynamic LDS sized to the largest patch of THIS rig (tile_cap cells, a multiple of 8, <= K2_TILE_MAX; set in xm_create):
+  // how many blocks fit beside K1's 70 KB blocks on a CU is what bounds the pipelined frame rate, and the static
+  // worst case (2 x 10 KB) was twice what C-1M's 50 x 56 patches need.
+  extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
+  uint16_t* tile = k2_lds;                  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
+  uint16_t* vmax = k2_lds + tile_cap + 16;  // [tile_cap]
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
+  XM_BLOG_BEGIN();
   // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
   if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
                   (u64)zero16 | (u64)depth | (u64)bgr |
@@ -1239,7 +1301,42 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
         const int half = rows_p >> 1, total = cols * half;
         // (c, rp) = divmod(i, half) advanced incrementally: i -> i + NT is (c + dq, rp + dr) with one carry
         const int dq = NT / half, dr = NT - dq * half;
-        int c_i = tid / half, rp_i = tid - c_i * half;
+        int c_i = (int)((float)tid * (1.0f / (float)half)), rp_i = tid - c_i * half;  // no integer divide
+        if (rp_i < 0) { c_i -= 1; rp_i += half; }
+        if (rp_i >= half) { c_i += 1; rp_i -= half; }
+        // K2 is bound by instruction issue, and most tiles' patches lie entirely inside the frame: those take a lean
+        // loader -- the cell index advances incrementally with the (column, row pair) carry, no clamps, no inside tests --
+        // unrolled to what the patch needs (a 46 x 24 patch is 2.2 sixteen-byte loads per thread, not 8).
+        const bool interior = !use_flags && bx >= 0 && by >= 0 && bx + cols <= tb.rect_w && by + rows_p <= tb.rect_h;
+        if (interior) {
+          u32 cell = (u32)(bx + c_i) * (u32)tb.rect_h + (u32)(by + 2 * rp_i);
+          const u32 cell_origin = (u32)bx * (u32)tb.rect_h + (u32)by;
+          const u32 dcell = (u32)dq * (u32)tb.rect_h + 2u * (u32)dr, carry = (u32)tb.rect_h - 2u * (u32)half;
+          auto pass = [&](auto un_tag) {
+            constexpr int UL = decltype(un_tag)::value;
+            for (int i0 = tid; i0 < total; i0 += UL * NT) {
+              ulonglong2 k[UL];
+#pragma unroll
+              for (int j = 0; j < UL; ++j) {
+                k[j] = *reinterpret_cast<const ulonglong2*>(keys + (i0 + j * NT < total ? cell : cell_origin));
+                cell += dcell;
+                rp_i += dr;
+                if (rp_i >= half) { rp_i -= half; cell += carry; }
+              }
+#pragma unroll
+              for (int j = 0; j < UL; ++j) {
+                const int i = i0 + j * NT;
+                if (i < total)
+                  reinterpret_cast<u32*>(tile)[i] = (u32)key_disp(k[j].x, tag) | ((u32)key_disp(k[j].y, tag) << 16);
+              }
+            }
+          };
+          const int need = (total + NT - 1) / NT;
+          if (need <= 2) pass(std::integral_constant<int, 2>{});
+          else if (need <= 3) pass(std::integral_constant<int, 3>{});
+          else if (need <= 4) pass(std::integral_constant<int, 4>{});
+          else pass(std::integral_constant<int, 8>{});
+        } else
         for (int i0 = tid; i0 < total; i0 += UN * NT) {
           ulonglong2 k[UN];
           bool inside[UN];
@@ -1367,6 +1464,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
       b[2] = (uint8_t)((o.bgr >> 16) & 0xff);
     }
   }
+  XM_BLOG_END(2, st, tag);
 }
 
 // camera view / plain per-pixel conversion of a frame of n_pixels cells -> depth + BGR
