@@ -35,7 +35,9 @@ t0 = time.perf_counter(); run(K); dt = time.perf_counter() - t0
 cap = 8 * 16 * 4096
 buf = np.zeros((cap, 4), np.uint64)
 lib.xm_debug_blog(buf.ctypes.data, cap, ctypes.byref(cnt))
-b = buf[(buf[:, 0] >> np.uint64(63)) == 1]
+sel = np.nonzero((buf[:, 0] >> np.uint64(63)) == 1)[0]
+b = buf[sel]
+blk = (sel % 4096) % 1024 if False else (sel % 4096)
 n = len(b)
 kind = (b[:, 0] & np.uint64(0xff)).astype(np.int64); tag = ((b[:, 0] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
 st = ((b[:, 0] >> np.uint64(40)) & np.uint64(0xff)).astype(np.int64)
@@ -99,3 +101,16 @@ for t, d, k in bev:
     if t > lo and last < hi: acc += res * (min(t, hi) - max(last, lo))
     res[int(k)] += d; last = t
 print("   mean resident blocks: " + "  ".join(f"{names[i]} {acc[i]/(hi-lo):7.1f}" for i in range(3)))
+
+if slots == 1:
+    m = kind == 1
+    lb = (blk[m] - 1024); life = (te[m] - ts[m]) * tick_us
+    agg = collections.defaultdict(list)
+    for i, l in zip(lb, life): agg[int(i)].append(l)
+    mean = {i: np.mean(v) for i, v in agg.items()}
+    order = sorted(mean, key=lambda i: -mean[i])
+    print("   K1 slowest blocks (blockIdx: mean life us): " + "  ".join(f"{i}:{mean[i]:.1f}" for i in order[:24]))
+    print("   K1 fastest blocks: " + "  ".join(f"{i}:{mean[i]:.1f}" for i in order[-8:]))
+    byx = collections.defaultdict(list)
+    for i, v in mean.items(): byx[i % 8].append(v)
+    print("   K1 mean life by blockIdx % 8 (XCD): " + "  ".join(f"{x}:{np.mean(v):.2f}" for x, v in sorted(byx.items())))

@@ -566,7 +566,7 @@ __device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime s
 #define XM_STAMP(ph) do { } while (0)
 #endif
 #ifndef XM_TILE_THREADS
-#define XM_TILE_THREADS 1024
+#define XM_TILE_THREADS 512
 #endif
 constexpr int TILE_THREADS = XM_TILE_THREADS;   // 512 x 8 or 1024 x 4 events: same LDS tile, different latency/issue trade
 constexpr int TILE_EPT = 4096 / XM_TILE_THREADS;
@@ -576,7 +576,12 @@ constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;  // largest block: 4096 eve
 // switch, not a per-block branch: with both load paths in one kernel the compiler's wait-count bookkeeping at the join
 // put full vmcnt waits in front of the event loads and of the extrema reduction (seen in the ISA).
 template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
-__global__ __launch_bounds__(TILE_THREADS) void k_scatter_tiled(
+#ifdef XM_K1_WAVES_PER_EU  // experiments: cap the VGPRs so that this many waves fit a SIMD (HIP's 2nd launch-bounds argument)
+#define XM_K1_BOUNDS __launch_bounds__(TILE_THREADS, XM_K1_WAVES_PER_EU)
+#else
+#define XM_K1_BOUNDS __launch_bounds__(TILE_THREADS)
+#endif
+__global__ XM_K1_BOUNDS void k_scatter_tiled(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
     u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, unsigned char* __restrict__ dirty, int w_ts, int w_x,
