@@ -657,7 +657,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     h->k1_direct = e1 && e1[0] == '1';
     h->k2_direct = e2 && e2[0] == '1';
     if (const char* e3 = getenv("XM_K2_FLAGS")) h->k2_flags = e3[0] == '1';
-    // <= 76 KB per block lets two 1024-thread blocks (e.g. of two frames in flight) share one CU's 160 KB
+    // C-1M needs 44 KB (w_ts = 5, w_x = 16): three blocks per CU beside K2's 12 KB blocks
     size_t budget = 76 * 1024;
     if (const char* e = getenv("XM_LDS_KB")) budget = (size_t)atoi(e) * 1024;
     int w_ts = 5, w_x = 16;  // 5 time columns, 16 camera columns: 70 KB at C-1M
@@ -669,7 +669,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       const size_t win_words = cfg->view == XM_VIEW_PROJECTOR ? (size_t)wt * xmap_h : (size_t)wx * cfg->cam_height;
       const size_t win_q = (win_words + 3) / 4, lut_q = ((size_t)wx * cfg->cam_height + 3) / 4 + 1,
                    xm_q = ((size_t)wt * xmap_h + 7) / 8 + 1;
-      return 16 * (win_q + lut_q + xm_q + 1);  // +1: dummy slot for the branch-free band loads
+      return 16 * (std::max(win_q, lut_q) + xm_q + 1);  // slots and LUT band share a region; +1: dummy slot for the branch-free band loads
     };
     while (need(w_ts, w_x) > budget && (w_ts > 1 || w_x > 1)) {
       if (w_ts * xmap_h * 6 >= w_x * cfg->cam_height * 4 && w_ts > 1) w_ts -= 1;

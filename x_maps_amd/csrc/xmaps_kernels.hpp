@@ -602,13 +602,16 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     if ((long long)(pp | (u64)(long long)pi) < 0) return;
   }
 #endif
-  // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift)
+  // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift).  The LUT band and
+  // the winner slots SHARE one region: the band is only read by the first gather of the fast path, the slots only written
+  // after it -- two extra barriers buy 26 KB per block, i.e. a third resident block per CU (block residency is what bounds
+  // the pipelined frame rate: tools/block_timeline.py).
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
   const int win_q = (win_words + 3) >> 2;  // uint4 count
   const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1;
   u32* win = reinterpret_cast<u32*>(smem);
-  u32* lut_base = win + 4 * win_q;
-  int16_t* xm_base = reinterpret_cast<int16_t*>(lut_base + 4 * lut_q);
+  u32* lut_base = win;
+  int16_t* xm_base = reinterpret_cast<int16_t*>(win + 4 * max(win_q, lut_q));
   __shared__ u32 s_in, s_oob;
 
   const int tid = threadIdx.x;
@@ -837,10 +840,6 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   const auto band_src = [&](int i) -> const uint4* { return i < nq_lut ? g_lut + i : g_xm + min(i - nq_lut, nq_xm - 1); };
   const auto band_dst = [&](int i) -> uint4* { return i < nq_lut ? l_lut + i : (i < nq_all ? l_xm + (i - nq_lut) : l_dummy); };
   const uint4 bv0 = *band_src(tid), bv1 = *band_src(tid + nthreads), bv2 = *band_src(tid + 2 * nthreads);
-  {
-    uint4* l_win = reinterpret_cast<uint4*>(win);
-    for (int i = tid; i < win_q; i += nthreads) l_win[i] = make_uint4(0, 0, 0, 0);
-  }
   XM_STAMP(4);
 
   // ---- 4. with the bands in flight: unpack the events, their time columns (bit-exact with NumPy, see TimeNorm) ---------
@@ -930,11 +929,14 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   }
   XM_STAMP(11);
   XM_STAMP(12);
-  __syncthreads();  // bands + cleared slots visible
+  __syncthreads();  // bands visible
   XM_STAMP(6);
 
-  // ---- 5. fast path, BRANCH-FREE so that the four events' LDS round trips overlap: A1 + A2 out of the LDS bands with
-  //         clamped addresses, collisions resolved with ds_max_u32.
+  // ---- 5. fast path, BRANCH-FREE so that the events' LDS round trips overlap: A1 + A2 out of the LDS bands with clamped
+  //         addresses; then the LUT band's region becomes the slot array and collisions are resolved with ds_max_u32.
+  bool wr[TILE_EPT];
+  int slot[TILE_EPT];
+  u32 val[TILE_EPT];
   {
     u32 l[TILE_EPT];
 #pragma unroll
@@ -952,21 +954,30 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     for (int k = 0; k < TILE_EPT; ++k) {
       const int disp = (int)(short)(xp[k] - xr[k] - tb.x_offset);  // int16 wrap (xmd:27)
       bool write = yok[k] && disp >= 0;                               // xmd:29
-      int slot;
       if constexpr (VIEW == 0) {
         int fc = (int)(short)(xr[k] + disp);  // = xp - x_offset (calib:300)
         if (fc < 0) fc += tb.rect_w;
         const bool in_frame = fc >= 0 && fc < tb.rect_w && yr[k] < tb.rect_h;
         n_oob += __popcll(__ballot(write && !in_frame));  // NumPy IndexError
         write = write && in_frame;
-        slot = tl[k] * tb.xmap_h + yr[k];
+        slot[k] = tl[k] * tb.xmap_h + yr[k];
       } else {
-        slot = (int)y[k] * w_x + xl[k];
+        slot[k] = (int)y[k] * w_x + xl[k];
       }
-      if (write && !XM_ABL(1)) atomicMax(&win[slot], ((lidx[k] + 1) << 16) | (u32)disp);
+      wr[k] = write;
+      val[k] = ((lidx[k] + 1) << 16) | (u32)disp;
       n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
     }
   }
+  __syncthreads();  // every LUT gather has landed: the region can be reused
+  {
+    uint4* l_win = reinterpret_cast<uint4*>(win);
+    for (int i = tid; i < win_q; i += nthreads) l_win[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();  // cleared slots visible
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k)
+    if (wr[k] && !XM_ABL(1)) atomicMax(&win[slot[k]], val[k]);
   if ((tid & 63) == 0) {
     if (n_in) atomicAdd(&s_in, n_in);
     if (n_oob) atomicAdd(&s_oob, n_oob);
