@@ -461,8 +461,14 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     if ((rc = fetch_stats(h, s, ev.aos ? XM_T_INT64 : ev.t_dtype, &st))) return rc;
     if (profile) {
       const int first = s.last_sorted ? 1 : 0;  // K0 is not launched on the time-sorted path
+#ifdef XM_ABLATE  // experiment builds may skip kernels (XM_SKIP_MASK): their events were never recorded
+      for (int i = first; i < 3; ++i)
+        if (hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) != hipSuccess) (void)hipGetLastError();
+      if (hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[2 * first], h->prof_ev[5]) != hipSuccess) (void)hipGetLastError();
+#else
       for (int i = first; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
       HIP_TRY(hipEventElapsedTime(&st.gpu_ms[3], h->prof_ev[2 * first], h->prof_ev[5]));  // start of first .. end of K2
+#endif
     }
     if (st.n_unsorted && s.last_sorted) {
       // the time-sorted declaration did not hold for this frame: redo it on the general path (K0 -> K1 -> K2)
