@@ -250,7 +250,7 @@ int launch_scatter_tv(const ScatterArgs& a) {
       set = a.lds;
     }
     unsigned threads = TILE_THREADS;
-    while (threads > 256 && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;
+    while (threads > 1024 / TILE_EPT && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;  // smallest block: 1024 events
     XM_LAUNCH(kern, dim3(grid_for(n, threads * TILE_EPT)), dim3(threads), a.lds, a.stream, ev.x, ev.y,
               (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
               a.mm_lo, a.mm_hi, a.frame, a.dirty, a.w_ts, a.w_x, a.sorted ? 1 : 0);
