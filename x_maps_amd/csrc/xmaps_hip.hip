@@ -686,6 +686,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       h->w_ts = w_ts;
       h->w_x = w_x;
       h->k1_lds = need(w_ts, w_x);
+      if (const char* e = getenv("XM_K1_LDS_PAD_KB")) h->k1_lds += (size_t)atoi(e) * 1024;  // experiments: fewer blocks per CU
     } else {
       h->k1_direct = true;  // tables too tall for LDS: every event takes the direct path
     }
