@@ -38,3 +38,26 @@ def test_no_cpu_fallback_in_product_package():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg, fn)).read()
             assert "xmaps_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_header_is_plain_c_and_layouts_agree(tmp_path):
+    """include/xmaps.h must compile as C99 (the drop-in boundary is a C ABI, not C++) and the compiler's struct layout
+    must be the one the ctypes binding assumes."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xmaps.h"\n'
+                   'int main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %d %d\\n", sizeof(xm_config), sizeof(xm_frame_stats), offsetof(xm_config, p03),\n'
+                   '         offsetof(xm_config, cam_mapx_i16), XM_ERR_UNSORTED, XM_MEM_HOST_PINNED);\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "t"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out] == [ctypes.sizeof(N.xm_config), ctypes.sizeof(N.xm_frame_stats), N.xm_config.p03.offset,
+                                     N.xm_config.cam_mapx_i16.offset, N.XM_ERR_UNSORTED, N.XM_MEM_HOST_PINNED]
