@@ -251,6 +251,8 @@ int launch_scatter_tv(const ScatterArgs& a) {
     }
     unsigned threads = TILE_THREADS;
     while (threads > 1024 / TILE_EPT && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;  // smallest block: 1024 events
+    static const int force_threads = getenv("XM_K1_THREADS") ? atoi(getenv("XM_K1_THREADS")) : 0;  // experiments
+    if (force_threads >= 64 && force_threads <= TILE_THREADS && (force_threads & (force_threads - 1)) == 0) threads = force_threads;
     XM_LAUNCH(kern, dim3(grid_for(n, threads * TILE_EPT)), dim3(threads), a.lds, a.stream, ev.x, ev.y,
               (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
               a.mm_lo, a.mm_hi, a.frame, a.dirty, a.w_ts, a.w_x, a.sorted ? 1 : 0);
