@@ -1277,14 +1277,15 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   const int4 rec = tb.k2_tiles[lin_tile];  // block-uniform
   const u32 poff = in_img ? tb.k2_pix[(u32)v * (u32)tb.proj_w + (u32)u] : ~0u;
   int mx = 0, my = 0;
-  bool valid = poff != ~0u;
+  bool valid_g = false;  // generic path only; the tiled path tests poff where it needs it (after the patch loads are out:
+                         // testing it here put a full wait for this load in front of them)
   int x0 = 0, x1 = -1, y0 = 0, y1 = 0;
   if (rec.z < 0) {  // patch too large for LDS (wild map): generic path needs the map entry itself
     if (in_img) {
       const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u];
       mx = (int)(short)(m & 0xffff);
       my = (int)(short)(m >> 16);
-      valid = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;  // else BORDER_CONSTANT 0
+      valid_g = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;  // else BORDER_CONSTANT 0
     }
     x1 = 0;  // "some pixel maps into the frame": take the branch below, which falls through to the global reads
   } else if (rec.z > 0) {
@@ -1429,14 +1430,14 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
         }
       }
       __syncthreads();
-      if (valid) {
+      if (poff != ~0u) {
         const uint16_t* p = vmax + poff;
         u32 best = 0;
 #pragma unroll
         for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
         d = (float)best;
       }
-    } else if (valid) {
+    } else if (valid_g) {
       KeyCells cells{keys, tag};
       const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
       for (int xx = xa; xx <= xb; ++xx)
