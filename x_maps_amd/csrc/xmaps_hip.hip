@@ -659,7 +659,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     h->out_h = cfg->cam_height;
   }
 
-  {  // K1 LDS windows: as wide as the 160 KB LDS of a gfx950 CU allows (one 1024-thread block per CU)
+  {  // K1 LDS windows (w_ts X-map columns, w_x camera columns) within the LDS budget
     const char* e1 = getenv("XM_K1_DIRECT");
     const char* e2 = getenv("XM_K2_DIRECT");
     h->k1_direct = e1 && e1[0] == '1';
@@ -670,7 +670,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     if (const char* e = getenv("XM_LDS_KB")) budget = (size_t)atoi(e) * 1024;
     int w_ts = 5, w_x = 16;  // 5 time columns, 16 camera columns: 70 KB at C-1M
     if (const char* e = getenv("XM_W_TS")) w_ts = atoi(e);
-    if (w_ts > 64) w_ts = 64;  // s_col_used[64] in k_scatter_tiled
+    if (w_ts > 64) w_ts = 64;
     if (const char* e = getenv("XM_W_X")) w_x = atoi(e);
     auto need = [&](int wt, int wx) {
       // must mirror the carve-up at the top of k_scatter_tiled (uint4 units, +1 uint4 of alignment slack per band)

@@ -819,7 +819,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   XM_STAMP(3);
   // The bands are contiguous runs of the column-major tables: [x_lo, x_lo + w_x) x cam_h words and
   // [ts_lo, ts_lo + w_ts) x xmap_h int16.  Aligned 16-byte loads over ONE index space (LUT quads, then X-map quads), so a
-  // 1024-thread block issues 3 loads per thread, all in flight at once; the LDS copies keep the global misalignment (a
+  // full-size block issues 3 (1024 threads) or 6 (512) loads per thread, all in flight at once; the LDS copies keep the global misalignment (a
   // few elements of slack in front).  Branch-free on purpose: loads use a clamped index and out-of-range lanes store into
   // a dummy LDS slot -- any predication here turns into one basic block per load with an s_waitcnt vmcnt(0) behind it
   // (seen in the ISA), i.e. serialized L2 round trips.
@@ -836,10 +836,16 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
   uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
   uint4* l_dummy = l_xm + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
-  constexpr int UNB = 3;
+  constexpr int UNB = TILE_THREADS >= 1024 ? 3 : 6;  // 43 KB of bands = 2745 quads: one pass for the largest block
   const auto band_src = [&](int i) -> const uint4* { return i < nq_lut ? g_lut + i : g_xm + min(i - nq_lut, nq_xm - 1); };
   const auto band_dst = [&](int i) -> uint4* { return i < nq_lut ? l_lut + i : (i < nq_all ? l_xm + (i - nq_lut) : l_dummy); };
   const uint4 bv0 = *band_src(tid), bv1 = *band_src(tid + nthreads), bv2 = *band_src(tid + 2 * nthreads);
+  uint4 bv3 = make_uint4(0, 0, 0, 0), bv4 = bv3, bv5 = bv3;
+  if constexpr (UNB == 6) {
+    bv3 = *band_src(tid + 3 * nthreads);
+    bv4 = *band_src(tid + 4 * nthreads);
+    bv5 = *band_src(tid + 5 * nthreads);
+  }
   XM_STAMP(4);
 
   // ---- 4. with the bands in flight: unpack the events, their time columns (bit-exact with NumPy, see TimeNorm) ---------
@@ -920,7 +926,12 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     *band_dst(tid) = bv0;
     *band_dst(tid + nthreads) = bv1;
     *band_dst(tid + 2 * nthreads) = bv2;
-    for (int i0 = tid + UNB * nthreads; i0 < nq_all; i0 += UNB * nthreads) {  // blocks smaller than 1024 threads
+    if constexpr (UNB == 6) {
+      *band_dst(tid + 3 * nthreads) = bv3;
+      *band_dst(tid + 4 * nthreads) = bv4;
+      *band_dst(tid + 5 * nthreads) = bv5;
+    }
+    for (int i0 = tid + UNB * nthreads; i0 < nq_all; i0 += 3 * nthreads) {  // smaller blocks / taller tables
       const uint4 v0 = *band_src(i0), v1 = *band_src(i0 + nthreads), v2 = *band_src(i0 + 2 * nthreads);
       *band_dst(i0) = v0;
       *band_dst(i0 + nthreads) = v1;
