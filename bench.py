@@ -35,8 +35,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "8")),
-                    help="frames in flight per GPU (own stream + key frame each)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "4")),
+                    help="frames in flight per GPU (key frame + state each; one stream per hardware queue, 4)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames resident in HBM")
     ap.add_argument("--camera-perspective", action="store_true")
     ap.add_argument("--no-bgr", action="store_true", help="depth frame only")
@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true", help="EXPERIMENTS ONLY (ablation builds): skip the parity gate")
     ap.add_argument("--assume-sorted", action="store_true",
                     help="XM_FLAG_TIME_SORTED: extrema = t[0], t[n-1], verified on the device; the extrema pass K0 is skipped")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the extra try-sorted / declared-sorted loops")
+    ap.add_argument("--try-sorted", action="store_true",
+                    help="XM_FLAG_TRY_SORTED: no declaration; (t[0], t[n-1]) tried and verified on every frame, frames that "
+                         "fail are redone on the general path automatically")
     return ap.parse_args()
 
 
@@ -78,7 +82,8 @@ def main():
     cfg = S.C_1M
     tables = S.make_tables(cfg)
     eng = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots,
-                      assume_time_sorted=args.assume_sorted)
+                      assume_time_sorted=args.assume_sorted, try_sorted=args.try_sorted,
+                      default_priority_streams=args.graph)  # graph replays need default-priority streams (xmaps.h)
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 
@@ -265,6 +270,41 @@ def main():
             except Exception as e:  # the checker is optional for the bench
                 cpu["all_cores_c_openmp"] = {"error": str(e)[:200]}
 
+        # ---- the same loop in the engine's other extrema modes (extra information, never the headline `value`) ----
+        other_modes = None
+        if world == 1 and graph is None and not args.assume_sorted and not args.try_sorted and not args.no_other_modes:
+            other_modes = {}
+            modes = [("try_sorted", {"try_sorted": True}), ("declared_sorted", {"assume_time_sorted": True})]
+            if os.environ.get("XM_BENCH_GENERAL_AGAIN"):  # experiment: the headline mode measured again on a second engine
+                modes = [("general_again", {})] + modes + [("general_again2", {})]
+            for name, kw in modes:
+                e2 = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots, **kw)
+
+                def step2(i):
+                    fx, fy, ft = frames[i % len(frames)]
+                    o = i % n_out
+                    e2.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, depth_out[o].data_ptr(),
+                                            None if bgr_out is None else bgr_out[o].data_ptr())
+                for i in range(args.warmup):
+                    step2(i)
+                e2.sync()
+                c0 = time.perf_counter()
+                for i in range(args.steps):
+                    step2(i)
+                e2.sync()
+                dt = time.perf_counter() - c0
+                same = bool(np.array_equal(depth_out[(args.steps - 1) % n_out].cpu().numpy(),
+                                           O.process_ev_frame(tables, *[v.astype(np.int64) if v.dtype != np.int64 else v
+                                                                        for v in host_frames[(args.steps - 1) % len(frames)]],
+                                                              camera_perspective=args.camera_perspective, want_bgr=False)["depth"]))
+                other_modes[name] = {"value": round(n_ev * args.steps / dt / 1e6, 2), "unit": "Mevents/s",
+                                     "ms_per_step": round(dt / args.steps * 1e3, 5), "depth_equals_oracle": same,
+                                     "frames_redone_on_general_path": e2.sorted_fallbacks()}
+                e2.close()
+            other_modes["note"] = ("try_sorted = XM_FLAG_TRY_SORTED (no declaration: (t[0], t[n-1]) tried and verified on the device, "
+                                   "failing frames redone automatically); declared_sorted = XM_FLAG_TIME_SORTED; `value` above is "
+                                   "the general path (extrema pass K0 on every frame)")
+
         host_path = None
         if args.host_path:
             x, y, t = host_frames[0]
@@ -311,10 +351,13 @@ def main():
                        + (" (camera view)" if args.camera_perspective else " (projector view)"),
                        "events_per_frame": n_ev, "frames_in_flight": args.slots, "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
                        "launch": "hipGraph" if args.graph else "eager", "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM",
-                       "time_sorted_declared": bool(args.assume_sorted)},
+                       "time_sorted_declared": bool(args.assume_sorted), "try_sorted": bool(args.try_sorted),
+                       "frames_redone_on_general_path": eng.sorted_fallbacks()},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "host_enqueue_us_per_step": round((t_enqueued - t0) / args.steps * 1e6, 2),
         }
+        if other_modes:
+            out["other_modes"] = other_modes
         if host_path:
             out["host_path"] = host_path
         print(json.dumps(out))

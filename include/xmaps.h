@@ -56,6 +56,23 @@ extern "C" {
                                   xm_frame_stats.n_unsorted and xm_sync() -> XM_ERR_UNSORTED.  Ignored when a polarity
                                   column is given. */
 
+#define XM_FLAG_TRY_SORTED 2u  /* No promise from the caller: every frame is first run with (tmin, tmax) = (t[0], t[n-1]) (no
+                                  extrema pass) while the device checks that every event lies inside that range; a frame
+                                  for which that fails is redone on the general path automatically -- inside the call for
+                                  XM_MEM_HOST, otherwise when its slot comes round again (n_slots calls later) or in
+                                  xm_sync(), whichever is first.  Results are always exact.  Contract for asynchronous
+                                  calls: a frame's input and output buffers stay untouched by the caller until n_slots
+                                  further frames have been submitted or xm_sync() has returned (the redo reads the inputs
+                                  again and rewrites the outputs).  Ignored when XM_FLAG_TIME_SORTED is set, when a polarity
+                                  column is given, inside xm_graph_create, and for frames too sparse for the tiled kernel. */
+
+#define XM_FLAG_DEFAULT_STREAMS 4u /* Create the slots' streams at the default priority.  By default they are created at the
+                                     highest priority, which gives them hardware queues of their own (HIP multiplexes all
+                                     streams of one priority, the application's included, onto 4 queues; sharing them cost
+                                     up to 17 % of the pipelined frame rate).  hipGraph replays (xm_graph_*) however lose
+                                     their branch concurrency when the process owns non-default-priority streams: set this
+                                     flag on handles that replay graphs. */
+
 /* view (RuntimeParams.camera_perspective, depth_reprojection_processor.py:34) */
 #define XM_VIEW_PROJECTOR 0
 #define XM_VIEW_CAMERA 1
@@ -122,6 +139,9 @@ const char* xm_last_error(void);
 int xm_create(const xm_config* cfg, xm_handle** out);
 void xm_destroy(xm_handle* h);
 int xm_sync(xm_handle* h); /* wait for everything enqueued on every slot of the handle; XM_ERR_UNSORTED see above */
+/* Frames redone on the general path because a time-sorted shortcut (XM_FLAG_TIME_SORTED in synchronous calls,
+ * XM_FLAG_TRY_SORTED always) did not hold, since xm_create. */
+int xm_sorted_fallbacks(xm_handle* h, uint64_t* count);
 
 /* ---- the fused hot path: one projector frame of events -> depth frame (+ BGR) -------------------- */
 /*

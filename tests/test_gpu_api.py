@@ -446,3 +446,39 @@ def test_device_side_pause_detection_matches_numpy(golden_dir):
                 torch.cuda.synchronize()
                 assert np.array_equal(eng.find_pauses(device_ptr=dt.data_ptr(), n=len(t)), ref)
         assert np.array_equal(eng.find_pauses(t=streams[1], thresh_us=55), np.nonzero(np.diff(streams[1]) >= 55)[0])
+
+
+def test_try_sorted_mode_redoes_unsorted_frames_asynchronously():
+    """XM_FLAG_TRY_SORTED: no declaration from the caller.  Asynchronous device-pointer frames: sorted ones take the
+    shortcut, shuffled ones are redone on the general path when their slot comes round again or in xm_sync; every
+    output is exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    rng = np.random.default_rng(11)
+    frames, refs = [], []
+    for f in range(7):
+        ev = S.make_events(cfg, frame=f, n=30_000)
+        x, y, t, _ = S.to_soa(ev)
+        if f in (1, 2, 5):  # not sorted: first / last event are not the extrema
+            perm = rng.permutation(len(t))
+            x, y, t = x[perm], y[perm], t[perm]
+        refs.append(O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t))
+        frames.append(tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t)))
+    for n_slots in (1, 2, 3):
+        with XMapsEngine(tb, n_slots=n_slots, try_sorted=True) as eng:
+            outs = [torch.zeros((eng.out_h, eng.out_w), dtype=torch.float32, device=dev) for _ in frames]
+            bgrs = [torch.zeros((eng.out_h, eng.out_w, 3), dtype=torch.uint8, device=dev) for _ in frames]
+            torch.cuda.synchronize()
+            for (fx, fy, ft), o, b in zip(frames, outs, bgrs):
+                eng.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, len(ft), o.data_ptr(), b.data_ptr())
+            eng.sync()
+            assert eng.sorted_fallbacks() == 3
+            for o, b, r in zip(outs, bgrs, refs):
+                assert np.array_equal(o.cpu().numpy(), r["depth"]) and np.array_equal(b.cpu().numpy(), r["bgr"])
+            # synchronous host call in the same mode: redone inside the call
+            x, y, t = (a.cpu().numpy() for a in frames[1])
+            d, b, st = eng.process_frame(x.view(np.uint16), y.view(np.uint16), t)
+            assert st.n_unsorted > 0 and np.array_equal(d, refs[1]["depth"]) and eng.sorted_fallbacks() == 4
+            eng.sync()

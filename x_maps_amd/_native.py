@@ -21,6 +21,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY, XM_ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6
 XM_FLAG_TIME_SORTED = 1
+XM_FLAG_TRY_SORTED = 2
+XM_FLAG_DEFAULT_STREAMS = 4
 XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
 XM_MEM_HOST, XM_MEM_DEVICE, XM_MEM_HOST_PINNED = 0, 1, 2
 XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2
@@ -94,6 +96,7 @@ SYMBOLS = {
     "xm_create": (C.c_int, [C.POINTER(xm_config), C.POINTER(_P)]),
     "xm_destroy": (None, [_P]),
     "xm_sync": (C.c_int, [_P]),
+    "xm_sorted_fallbacks": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_process_frame_aos": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_last_frame_stats": (C.c_int, [_P, C.POINTER(xm_frame_stats)]),

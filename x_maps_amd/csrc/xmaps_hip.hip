@@ -6,6 +6,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -62,19 +63,6 @@ struct DevBuf {  // grow-only device scratch
   }
 };
 
-struct Slot {
-  hipStream_t stream = nullptr;
-  u64* key_frame = nullptr;
-  unsigned char* dirty = nullptr;  // projector view: one flag byte per 128-byte line of key_frame
-  SlotState* st = nullptr;  // device
-  u32 host_tag = 0;         // mirrors st->tag_a after the enqueued work has run
-  bool any_frame = false;
-  bool last_sorted = false;
-  uint64_t last_n = 0;
-  // staging for XM_MEM_HOST calls
-  DevBuf ev_x, ev_y, ev_t, ev_p, ev_aos, out_depth, out_bgr, dbg[5];
-};
-
 struct EventsView {
   const uint16_t* x = nullptr;
   const uint16_t* y = nullptr;
@@ -84,6 +72,32 @@ struct EventsView {
   size_t n = 0;
   int t_dtype = XM_T_INT64;
   bool use_p = false;
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  bool owns_stream = true;
+  // XM_FLAG_TRY_SORTED: pinned host words the kernels report to ([0] tag of the last frame whose shortcut failed, [1] tag of
+  // the last frame whose K2 has started) and what is needed to redo the slot's last asynchronous frame on the general path
+  u32* h_flags = nullptr;
+  struct Prev {
+    bool valid = false;
+    EventsView ev;
+    float* depth = nullptr;
+    uint8_t* bgr = nullptr;
+    float* host_depth = nullptr;  // XM_MEM_HOST_PINNED: where the outputs are copied to
+    uint8_t* host_bgr = nullptr;
+    u32 tag = 0;
+  } prev;
+  u64* key_frame = nullptr;
+  unsigned char* dirty = nullptr;  // projector view: one flag byte per 128-byte line of key_frame
+  SlotState* st = nullptr;  // device
+  u32 host_tag = 0;         // mirrors st->tag_a after the enqueued work has run
+  bool any_frame = false;
+  bool last_sorted = false;
+  uint64_t last_n = 0;
+  // staging for XM_MEM_HOST calls
+  DevBuf ev_x, ev_y, ev_t, ev_p, ev_aos, out_depth, out_bgr, dbg[5];
 };
 
 }  // namespace
@@ -116,7 +130,10 @@ struct xm_handle {
   bool k1_direct = false, k2_direct = false;
   bool k2_flags = false;      // XM_K2_FLAGS=1: K1 marks dirty 128-byte lines of the key frame, K2 skips clean ones.
                               // Measured: K2 fetches 37 % fewer bytes but is not faster (it is latency, not bandwidth bound)
+  std::vector<hipStream_t> gstreams;  // default-priority streams the hipGraph batches are captured on and launched from
   bool time_sorted = false;   // XM_FLAG_TIME_SORTED
+  bool try_sorted = false;    // XM_FLAG_TRY_SORTED
+  bool capturing = false;     // inside xm_graph_create's stream capture (no host-side redo possible there)
   uint64_t sorted_fallbacks = 0;
   std::vector<hipEvent_t> join_ev;
 };
@@ -160,6 +177,10 @@ int reset_slot(xm_handle* h, Slot& s) {
   hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
   HIP_TRY(hipGetLastError());
   s.host_tag = 0;
+  if (s.h_flags) {  // tags start over: forget the verdicts of the old numbering (no frame of this slot is pending here)
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.h_flags[0] = s.h_flags[1] = 0;
+  }
   return XM_OK;
 }
 
@@ -328,7 +349,8 @@ int check_events(const EventsView& ev) {
 bool sorted_path(const xm_handle* h, const EventsView& ev) {
   // the verified (t[0], t[n-1]) shortcut lives in the tiled kernel; sparse frames (direct kernel) keep K0
   const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)ev.n / (double)h->tb.xmap_w : 0.0;
-  return h->time_sorted && !ev.use_p && !h->k1_direct && h->w_ts > 0 && h->w_x > 0 && max_ev >= 1024.0;
+  return (h->time_sorted || (h->try_sorted && !h->capturing)) && !ev.use_p && !h->k1_direct && h->w_ts > 0 && h->w_x > 0 &&
+         max_ev >= 1024.0;
 }
 
 int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,
@@ -412,6 +434,37 @@ Slot& pick_slot(xm_handle* h) {
   return h->slots[h->last_slot];
 }
 
+// XM_FLAG_TRY_SORTED: did the (t[0], t[n-1]) shortcut hold for the slot's last asynchronous frame?  The kernels answer in
+// pinned host memory (no API call when the frame has finished, which it has when a slot comes round again); a frame that
+// failed is redone here on the general path, into the same output buffers, before anything else happens on the slot.
+int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
+  if (!s.prev.valid) return XM_OK;
+  s.prev.valid = false;
+  const u32 tag = s.prev.tag;
+  // still in flight?  Wait for K2's start marker by polling the pinned word: a blocking stream synchronisation costs a
+  // ~200 us wake-up, per frame, whenever the host runs ahead of the GPU (few slots); the marker is a few us away.
+  if (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+        HIP_TRY(hipStreamSynchronize(s.stream));  // something else is holding the stream up: wait properly
+        break;
+      }
+    }
+  }
+  if (__atomic_load_n(&s.h_flags[0], __ATOMIC_ACQUIRE) != tag) return XM_OK;
+  h->sorted_fallbacks += 1;
+  int rc = enqueue_frame(h, s, s.prev.ev, s.prev.depth, s.prev.bgr, nullptr, false);
+  if (rc) return rc;
+  const size_t px = (size_t)h->out_w * h->out_h;
+  if (s.prev.host_depth) HIP_TRY(hipMemcpyAsync(s.prev.host_depth, s.prev.depth, px * 4, hipMemcpyDeviceToHost, s.stream));
+  if (s.prev.host_bgr) HIP_TRY(hipMemcpyAsync(s.prev.host_bgr, s.prev.bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
+  if (redone) *redone = true;
+  return XM_OK;
+}
+
 int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats,
                    bool profile) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
@@ -421,6 +474,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
   const size_t px = (size_t)h->out_w * h->out_h;
   Slot& s = profile ? h->slots[0] : pick_slot(h);
   if (profile) h->last_slot = 0;
+  if ((rc = resolve_prev(h, s))) return rc;
   float* d_depth = depth_out;
   uint8_t* d_bgr = bgr_out;
   const bool host_in = mem == XM_MEM_HOST || mem == XM_MEM_HOST_PINNED;
@@ -456,6 +510,15 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
   if (host_in) {
     if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
     if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
+  }
+  if (h->try_sorted && s.last_sorted && mem != XM_MEM_HOST && !profile) {  // asynchronous: the verdict is read later
+    s.prev.valid = true;
+    s.prev.ev = ev;  // device pointers (the slot's staging buffers for pinned host input)
+    s.prev.depth = d_depth;
+    s.prev.bgr = d_bgr;
+    s.prev.host_depth = host_in ? depth_out : nullptr;
+    s.prev.host_bgr = host_in ? bgr_out : nullptr;
+    s.prev.tag = s.host_tag;
   }
   if (mem == XM_MEM_HOST || profile) {
     HIP_TRY(hipStreamSynchronize(s.stream));
@@ -566,6 +629,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
   h->cfg.n_slots = n_slots;
   h->time_sorted = (cfg->flags & XM_FLAG_TIME_SORTED) != 0;
+  h->try_sorted = (cfg->flags & XM_FLAG_TRY_SORTED) != 0 && !h->time_sorted;
   h->cfg.xmap_height = xmap_h;
 
 #define XM_TRY_CREATE(expr)                   \
@@ -700,15 +764,41 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   }
 #endif
   XM_TRY_CREATE(hipMalloc((void**)&h->d_states, sizeof(SlotState) * (n_slots + 1)));
+  XM_TRY_CREATE(hipMemset(h->d_states, 0, sizeof(SlotState) * (n_slots + 1)));  // host_flags = NULL
   h->aux_st = h->d_states + n_slots;
   h->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
     Slot& s = h->slots[i];
-    XM_TRY_CREATE(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    {
+      // The slots' streams get their own hardware queues: HIP multiplexes all streams of one priority onto
+      // GPU_MAX_HW_QUEUES (4) hardware queues, the application's default stream included, and how the eight slot streams
+      // happened to interleave with it cost up to 17 % of the pipelined frame rate (first engine of a process: 64 Gev/s,
+      // second: 75; tools/engine_order_probe.py).  Streams of another priority live in another queue pool.
+      static const char* pe = getenv("XM_STREAM_PRIORITY");  // experiments: high (default) / low / normal
+      int lo = 0, hi = 0;
+      XM_TRY_CREATE(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest priority (numerically lowest)
+      // one stream per hardware queue; slots beyond that share them (more streams than queues is where the runtime's
+      // stream -> queue assignment starts to matter, and it only added buffering, no overlap)
+      static const int hw_q = getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) > 0 ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+      static const int n_streams = getenv("XM_N_STREAMS") ? atoi(getenv("XM_N_STREAMS")) : hw_q;  // XM_N_STREAMS: experiments
+      if (n_streams > 0 && i >= n_streams) {
+        s.stream = h->slots[i % n_streams].stream;
+        s.owns_stream = false;
+      } else if ((pe && pe[0] == 'n') || (cfg->flags & XM_FLAG_DEFAULT_STREAMS))
+        XM_TRY_CREATE(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+      else XM_TRY_CREATE(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, pe && pe[0] == 'l' ? lo : hi));
+    }
     XM_TRY_CREATE(hipMalloc((void**)&s.key_frame, h->key_cells * sizeof(u64)));
     if (cfg->view == XM_VIEW_PROJECTOR && h->k2_flags)
       XM_TRY_CREATE(hipMalloc((void**)&s.dirty, ((h->key_cells + 15) >> 4) + 64));
     s.st = h->d_states + i;
+    if (h->try_sorted) {
+      XM_TRY_CREATE(hipHostMalloc((void**)&s.h_flags, 64, hipHostMallocMapped));
+      s.h_flags[0] = s.h_flags[1] = 0;
+      u32* d_flags = nullptr;
+      XM_TRY_CREATE(hipHostGetDevicePointer((void**)&d_flags, s.h_flags, 0));
+      XM_TRY_CREATE(hipMemcpy(&s.st->host_flags, &d_flags, sizeof d_flags, hipMemcpyHostToDevice));
+    }
     hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
     XM_TRY_CREATE(hipGetLastError());
 #ifdef XM_BLOG
@@ -742,8 +832,10 @@ void xm_destroy(xm_handle* h) {
     for (auto& d : s.dbg) d.release();
     if (s.key_frame) (void)hipFree(s.key_frame);
     if (s.dirty) (void)hipFree(s.dirty);
-    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.stream && s.owns_stream) (void)hipStreamDestroy(s.stream);
+    if (s.h_flags) (void)hipHostFree(s.h_flags);
   }
+  for (auto gs : h->gstreams) if (gs) (void)hipStreamDestroy(gs);
   for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   for (auto& e : h->join_ev) if (e) (void)hipEventDestroy(e);
@@ -759,10 +851,24 @@ void xm_destroy(xm_handle* h) {
   delete h;
 }
 
+int xm_sorted_fallbacks(xm_handle* h, uint64_t* count) {
+  if (!h || !count) return fail(XM_ERR_INVALID, "NULL argument");
+  *count = h->sorted_fallbacks;
+  return XM_OK;
+}
+
 int xm_sync(xm_handle* h) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->cfg.device));
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  if (h->try_sorted) {  // frames whose shortcut failed are redone now, then waited for
+    for (Slot& s : h->slots) {
+      bool redone = false;
+      int rc = resolve_prev(h, s, &redone);
+      if (rc) return rc;
+      if (redone) HIP_TRY(hipStreamSynchronize(s.stream));
+    }
+  }
   if (h->time_sorted) {  // any asynchronously processed frame that was not sorted after all?
     u32 bad = 0;
     for (Slot& s : h->slots) {
@@ -875,10 +981,26 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
   const size_t tsz = t_size(t_dtype);
   std::vector<u32> saved(ns);
   for (int i = 0; i < ns; ++i) saved[i] = h->slots[i].host_tag;
+  // Graphs are captured on (and launched from) default-priority streams of their own: launched from the slots'
+  // high-priority streams the replay ran its branches one after the other (28 instead of 61 Gevents/s).
+  if (h->gstreams.empty()) {
+    h->gstreams.assign(ns, nullptr);
+    for (int i = 0; i < ns; ++i) {
+      hipError_t ce = hipStreamCreateWithFlags(&h->gstreams[i], hipStreamNonBlocking);
+      if (ce != hipSuccess) {
+        delete g;
+        return fail(XM_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(ce));
+      }
+    }
+  }
+  for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);  // enqueue_frame launches on slot.stream
   hipStream_t origin = h->slots[0].stream;
   int rc = XM_OK;
+  h->capturing = true;
   hipError_t e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) {
+    h->capturing = false;
+    for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
     delete g;
     return fail(XM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
   }
@@ -910,6 +1032,8 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
     }
   } while (0);
   hipError_t e2 = hipStreamEndCapture(origin, &g->graph);
+  h->capturing = false;
+  for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
   for (int i = 0; i < ns; ++i) h->slots[i].host_tag = saved[i];
   if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
     rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
@@ -930,9 +1054,9 @@ int xm_graph_launch(xm_graph* g) {
   xm_handle* h = g->h;
   HIP_TRY(hipSetDevice(h->cfg.device));
   const int ns = (int)h->slots.size();
-  hipStream_t origin = h->slots[0].stream;
-  // order the replay after whatever the other slots are doing, and handle tag wrap per slot
-  for (int i = 1; i < ns; ++i) {
+  hipStream_t origin = h->gstreams[0];
+  // order the replay after whatever the slots are doing, and handle tag wrap per slot
+  for (int i = 0; i < ns; ++i) {
     HIP_TRY(hipEventRecord(h->join_ev[i], h->slots[i].stream));
     HIP_TRY(hipStreamWaitEvent(origin, h->join_ev[i], 0));
   }
@@ -949,10 +1073,8 @@ int xm_graph_launch(xm_graph* g) {
     h->slots[i].host_tag += g->frames_on_slot[i];
     if (g->frames_on_slot[i]) h->slots[i].any_frame = true;
   }
-  if (ns > 1) {
-    HIP_TRY(hipEventRecord(h->fork_ev, origin));
-    for (int i = 1; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0));
-  }
+  HIP_TRY(hipEventRecord(h->fork_ev, origin));  // whatever the slots do next (or xm_sync) comes after the replay
+  for (int i = 0; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0));
   return XM_OK;
 }
 

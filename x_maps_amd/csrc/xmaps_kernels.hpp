@@ -67,8 +67,16 @@ struct SlotState {
   u64 mm[2][MM_SLOTS][2];               // [parity][slot]{min, max} in order-preserving u64 encoding
   u32 cnt[2][CNT_SLOTS][CNT_STRIDE];    // [parity][slot]{used, inliers, index errors, events outside [t[0], t[n-1]]}
   u32 unsorted_sticky;                  // time-sorted mode: frames whose declaration did not hold (read by xm_sync)
-  u32 pad2[3];
+  u32 pad2;
+  // XM_FLAG_TRY_SORTED: two words of pinned host memory the kernels report to without a host round trip --
+  // [0] = tag of the last frame whose (t[0], t[n-1]) shortcut did NOT hold (written by K1), [1] = tag of the last frame whose
+  // K2 has started, i.e. whose K1 verdict is final.  NULL when the mode is off.
+  u32* host_flags;
 };
+static_assert(sizeof(SlotState) % 16 == 0, "SlotState array stride");
+
+// device -> pinned host memory, visible to the host when the kernel has finished
+__device__ inline void host_flag_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // ---- order-preserving u64 encodings so that one pair of unsigned atomics serves every t dtype ------
 template <typename T> struct TimeCodec;
@@ -871,6 +879,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     if (__ballot(bad) && (tid & 63) == 0) {
       __hip_atomic_fetch_add(&st->cnt[parity][blockIdx.x % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u32* hf = st->host_flags) host_flag_store(hf, tag);
     }
   }
   // Events outside the windows (unsorted / raster-ordered input, a noise event) take the global path -- the very functions
@@ -1162,7 +1171,10 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
     if (!tag_override && blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {  // re-arm the next frame's counters
       u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
       c[0] = c[1] = c[2] = c[3] = 0;
-      if (threadIdx.x == 0) st->tag_b = tag;
+      if (threadIdx.x == 0) {
+        st->tag_b = tag;
+        if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
+      }
     }
   }
   float d = 0.0f;
@@ -1468,7 +1480,10 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   if (!tag_override && lin_tile == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
     u32* c = st->cnt[(tag & 1) ^ 1][tid];
     c[0] = c[1] = c[2] = c[3] = 0;
-    if (tid == 0) st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
+    if (tid == 0) {
+      st->tag_b = tag;  // time-sorted mode: K1 derived the tag from tag_b without touching it
+      if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
+    }
   }
   if (depth && in_img) depth[(u32)v * (u32)tb.proj_w + (u32)u] = o.depth;
   if (bgr) {
@@ -1509,7 +1524,10 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixel
       if (!tag_override && blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {
         u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
         c[0] = c[1] = c[2] = c[3] = 0;
-        if (threadIdx.x == 0) st->tag_b = tag;
+        if (threadIdx.x == 0) {
+          st->tag_b = tag;
+          if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
+        }
       }
     }
   }

@@ -71,7 +71,7 @@ class XMapsEngine:
     """
 
     def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1,
-                 assume_time_sorted: bool = False):
+                 assume_time_sorted: bool = False, try_sorted: bool = False, default_priority_streams: bool = False):
         self._lib = N.load_library()
         self._h = C.c_void_p(None)
         mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
@@ -94,7 +94,8 @@ class XMapsEngine:
         cfg.x_offset = int(tables.get("x_offset", 4242))
         cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
         cfg.n_slots = n_slots
-        cfg.flags = N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0
+        cfg.flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0) | (N.XM_FLAG_TRY_SORTED if try_sorted else 0)
+                     | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0))
         cfg.p03 = float(tables["p03"])
         self.p03 = cfg.p03
         cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
@@ -138,6 +139,12 @@ class XMapsEngine:
 
     def sync(self):
         N.check(self._lib.xm_sync(self._h))
+
+    def sorted_fallbacks(self) -> int:
+        """Frames redone on the general path because a time-sorted shortcut did not hold."""
+        v = C.c_uint64(0)
+        N.check(self._lib.xm_sorted_fallbacks(self._h, C.byref(v)))
+        return int(v.value)
 
     def stream(self, slot: int = 0) -> int:
         return int(self._lib.xm_stream(self._h, slot) or 0)
