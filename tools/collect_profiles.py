@@ -58,7 +58,7 @@ with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of bench.py (MI355X)\n\n")
     for key, title, cmd in (("trace_proj", "projector view, 1 slot (kernels back to back, no overlap)", "python bench.py --slots 1 --steps 200 --warmup 20 --no-cpu-baseline"),
                             ("trace_cam", "camera view, 1 slot", "python bench.py --slots 1 --steps 200 --warmup 20 --no-cpu-baseline --camera-perspective"),
-                            ("trace_pipe8", "projector view, 8 frames in flight (the default bench configuration; kernels of different frames overlap, so durations stretch)", "python bench.py --slots 8 --steps 400 --no-cpu-baseline")):
+                            ("trace_pipe8", "projector view, 4 frames in flight (the default bench configuration; under the profiler the launches no longer overlap)", "python bench.py --steps 400 --no-cpu-baseline")):
         db = os.path.join(src, f"{key}_results.db")
         if os.path.exists(db):
             f.write(f"## {title}\n\n`rocprofv3 --kernel-trace --stats -- {cmd}`\n\n{trace_table(db)}\n\n")

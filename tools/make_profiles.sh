@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 BASE="python bench.py --slots 1 --steps 200 --warmup 20 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT -o trace_proj -- $BASE > $OUT/trace_proj.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT -o trace_cam -- $BASE --camera-perspective > $OUT/trace_cam.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT -o trace_pipe8 -- python bench.py --slots 8 --steps 400 --no-cpu-baseline > $OUT/trace_pipe8.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT -o trace_pipe8 -- python bench.py --steps 400 --no-cpu-baseline > $OUT/trace_pipe8.log 2>&1
 PM="python bench.py --slots 1 --steps 60 --warmup 10 --no-cpu-baseline"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
@@ -22,6 +22,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python bench.py --host-path > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --camera-perspective --no-cpu-baseline > $OUT/bench_camera.json 2>/dev/null
-python bench.py --graph --steps 60 --no-cpu-baseline > $OUT/bench_graph60.json 2>/dev/null
+python bench.py --graph --slots 8 --no-cpu-baseline > $OUT/bench_graph60.json 2>/dev/null
 python tools/scale_probe.py > $OUT/scale_probe.txt 2>/dev/null
 ls $OUT | head -50
