@@ -482,3 +482,35 @@ def test_try_sorted_mode_redoes_unsorted_frames_asynchronously():
             d, b, st = eng.process_frame(x.view(np.uint16), y.view(np.uint16), t)
             assert st.n_unsorted > 0 and np.array_equal(d, refs[1]["depth"]) and eng.sorted_fallbacks() == 4
             eng.sync()
+
+
+def test_try_sorted_mode_pinned_host_path_and_aos():
+    """XM_FLAG_TRY_SORTED through the asynchronous pinned-host path (inputs staged per slot, outputs copied back) and with
+    AoS EventCD records: shuffled frames are redone (staging buffers still hold them) and the host outputs are exact."""
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    rng = np.random.default_rng(3)
+    with XMapsEngine(tb, n_slots=2, try_sorted=True) as eng:
+        jobs = []
+        for f in range(6):
+            ev = S.make_events(cfg, frame=f, n=25_000)
+            if f % 2:
+                ev = ev[rng.permutation(len(ev))]
+            x, y, t, _ = S.to_soa(ev)
+            ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t)
+            d = eng.host_empty((eng.out_h, eng.out_w), np.float32)
+            b = eng.host_empty((eng.out_h, eng.out_w, 3), np.uint8)
+            if f < 4:
+                px, py, pt = eng.host_empty(x.shape, np.uint16), eng.host_empty(y.shape, np.uint16), eng.host_empty(t.shape, np.int64)
+                px[:], py[:], pt[:] = x, y, t
+                eng.process_frame_pinned(px, py, pt, None, d, b)
+                jobs.append((d, b, ref, (px, py, pt)))
+            else:
+                pe = eng.host_empty(ev.shape, ev.dtype)
+                pe[:] = ev
+                eng.process_events_pinned(pe, d, b)
+                jobs.append((d, b, ref, pe))
+        eng.sync()
+        assert eng.sorted_fallbacks() == 3
+        for d, b, ref, _ in jobs:
+            assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
