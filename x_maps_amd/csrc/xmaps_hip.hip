@@ -1055,6 +1055,10 @@ int xm_graph_launch(xm_graph* g) {
   HIP_TRY(hipSetDevice(h->cfg.device));
   const int ns = (int)h->slots.size();
   hipStream_t origin = h->gstreams[0];
+  for (Slot& s : h->slots) {  // XM_FLAG_TRY_SORTED: settle pending verdicts before the replay advances the slots' tags
+    int rc = resolve_prev(h, s);
+    if (rc) return rc;
+  }
   // order the replay after whatever the slots are doing, and handle tag wrap per slot
   for (int i = 0; i < ns; ++i) {
     HIP_TRY(hipEventRecord(h->join_ev[i], h->slots[i].stream));
