@@ -5,7 +5,7 @@ run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c
 cp x_maps_amd/libxmaps_hip.so /tmp/keep.so
 while read -r flags; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags x_maps_amd/csrc/xmaps_hip.hip -o x_maps_amd/libxmaps_hip.so || continue
-  echo "flags: [$flags]"; run --slots 8; run --slots 1; run --slots 8 --assume-sorted
+  echo "flags: [$flags]"; run; run --slots 1; run --assume-sorted
 done <<VARIANTS
 ${VARIANTS:-
 -DXM_TILE_THREADS=512}

@@ -191,7 +191,7 @@ void launch_minmax_t(const EventsView& ev, SlotState* st, u32 tag_override, hipS
   const bool vec2 = !AOS && sizeof(T) == 8 && std::is_same<T, long long>::value && aligned(ev.t, 16) &&
                     (!HAS_P || aligned(ev.p, 4));
   // ~2048 events per thread-block iteration keeps every CU busy without drowning the 32 atomic slots
-  const unsigned per_block = BLOCK * (vec2 ? 8 : 4);  // VEC2: 4 loads x 2 events per thread per sweep
+  const unsigned per_block = BLOCK * (vec2 ? 2 * K0_UN : 4);  // VEC2: K0_UN loads x 2 events per thread per sweep
   unsigned grid = grid_for(n, per_block);
   if (grid > 1024) grid = 1024;
   if constexpr (std::is_same<T, long long>::value && !AOS) {

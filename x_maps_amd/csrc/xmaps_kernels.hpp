@@ -241,6 +241,10 @@ __device__ inline void load_frame_minmax(const SlotState* st, u32 parity, u64& l
 //   AoS : EventCD records, one 16-byte load per event
 // Also: advances the slot's frame tag (block 0) and counts the used events.
 // =====================================================================================================
+#ifndef XM_K0_UN
+#define XM_K0_UN 8
+#endif
+constexpr int K0_UN = XM_K0_UN;  // 16-byte loads of t in flight per thread (vector path)
 template <typename T, bool AOS, bool HAS_P, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const int16_t* __restrict__ p,
                                                   const uint4* __restrict__ aos, u64 n, SlotState* st,
@@ -268,13 +272,13 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
     const u64 n2 = n >> 1;
     const longlong2* t2 = reinterpret_cast<const longlong2*>(t);
     const u32* p2 = reinterpret_cast<const u32*>(p);
-    // 4 independent 16-byte loads per thread per sweep: latency-bound otherwise (8 MB must be in flight at once)
-    for (u64 i0 = (u64)blockIdx.x * BLOCK + threadIdx.x; i0 < n2; i0 += 4 * stride) {
-      longlong2 v[4];
-      u32 pp[4];
-      bool in[4];
+    // K0_UN independent 16-byte loads per thread per sweep: latency-bound otherwise (8 MB must be in flight at once)
+    for (u64 i0 = (u64)blockIdx.x * BLOCK + threadIdx.x; i0 < n2; i0 += K0_UN * stride) {
+      longlong2 v[K0_UN];
+      u32 pp[K0_UN];
+      bool in[K0_UN];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < K0_UN; ++j) {
         const u64 i = i0 + (u64)j * stride;
         in[j] = i < n2;
         if (in[j]) {
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < K0_UN; ++j) {
         if (!in[j]) continue;
         bool ok0 = true, ok1 = true;
         if constexpr (HAS_P) {
