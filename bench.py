@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# HIP runtime (ROCclr) setting, read when the runtime initialises, i.e. before torch touches the GPU: by default every
+# stream is drained by the CPU after each 1000 commands (DEBUG_CLR_MAX_BATCH_SIZE), which showed up as a 1.5-5 ms stall of
+# the whole frame pipeline every ~1300 frames and a 7 % slower pace in between (tools/steady_probe.py).
+os.environ.setdefault("DEBUG_CLR_MAX_BATCH_SIZE", "100000")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -174,7 +174,8 @@ def test_shard_calls_merge_to_the_single_frame(camera):
             for sh, a, kf in kfs:
                 prov.scatter(sh, a, mm, tag, kf)
             eng.sync()
-            merged = torch.maximum(kfs[0][2], kfs[1][2])
+            with prov.collective_stream():  # as ShardedFrameProcessor does: the merge is ordered on the engine's stream
+                merged = torch.maximum(kfs[0][2], kfs[1][2])
             depth, bgr = prov.finish(merged, tag)
             eng.sync()
             assert np.array_equal(depth.cpu().numpy(), ref["depth"]) and np.array_equal(bgr.cpu().numpy(), ref["bgr"])

@@ -85,6 +85,7 @@ struct Slot {
     EventsView ev;
     float* depth = nullptr;
     uint8_t* bgr = nullptr;
+    bool check = false;           // the frame took the try-sorted shortcut: its verdict decides about a redo
     float* host_depth = nullptr;  // XM_MEM_HOST_PINNED: where the outputs are copied to
     uint8_t* host_bgr = nullptr;
     u32 tag = 0;
@@ -133,6 +134,7 @@ struct xm_handle {
   std::vector<hipStream_t> gstreams;  // default-priority streams the hipGraph batches are captured on and launched from
   bool time_sorted = false;   // XM_FLAG_TIME_SORTED
   bool try_sorted = false;    // XM_FLAG_TRY_SORTED
+  bool gate_slots = false;    // experiments (XM_GATE_SLOTS=1): asynchronous calls wait (polling a pinned word) until the slot's previous frame has reached K2
   bool capturing = false;     // inside xm_graph_create's stream capture (no host-side redo possible there)
   uint64_t sorted_fallbacks = 0;
   std::vector<hipEvent_t> join_ev;
@@ -444,17 +446,22 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   // still in flight?  Wait for K2's start marker by polling the pinned word: a blocking stream synchronisation costs a
   // ~200 us wake-up, per frame, whenever the host runs ahead of the GPU (few slots); the marker is a few us away.
   if (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(30);
     unsigned spins = 0;
     while (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
       __builtin_ia32_pause();
-      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-        HIP_TRY(hipStreamSynchronize(s.stream));  // something else is holding the stream up: wait properly
-        break;
+      if ((++spins & 0x3f) == 0 && std::chrono::steady_clock::now() > t_next) {
+        // not there after 30 us: make sure the runtime has really handed the slot's commands to the GPU (a query flushes
+        // anything it still holds back -- seen: a frame that sat for 20 ms until something synchronised), and stop polling
+        // once the stream itself reports completion
+        hipError_t q = hipStreamQuery(s.stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+        t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
       }
     }
   }
-  if (__atomic_load_n(&s.h_flags[0], __ATOMIC_ACQUIRE) != tag) return XM_OK;
+  if (!s.prev.check || __atomic_load_n(&s.h_flags[0], __ATOMIC_ACQUIRE) != tag) return XM_OK;
   h->sorted_fallbacks += 1;
   int rc = enqueue_frame(h, s, s.prev.ev, s.prev.depth, s.prev.bgr, nullptr, false);
   if (rc) return rc;
@@ -511,8 +518,11 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
     if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
   }
-  if (h->try_sorted && s.last_sorted && mem != XM_MEM_HOST && !profile) {  // asynchronous: the verdict is read later
+  if (s.h_flags && !h->capturing && mem != XM_MEM_HOST && !profile) {
+    // asynchronous call: the slot is not reused before this frame has reached K2 (keeps the host from running queues
+    // deep ahead of the GPU, which made the frame rate uneven), and a try-sorted verdict is read then
     s.prev.valid = true;
+    s.prev.check = h->try_sorted && s.last_sorted;
     s.prev.ev = ev;  // device pointers (the slot's staging buffers for pinned host input)
     s.prev.depth = d_depth;
     s.prev.bgr = d_bgr;
@@ -630,6 +640,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->cfg.n_slots = n_slots;
   h->time_sorted = (cfg->flags & XM_FLAG_TIME_SORTED) != 0;
   h->try_sorted = (cfg->flags & XM_FLAG_TRY_SORTED) != 0 && !h->time_sorted;
+  if (const char* e = getenv("XM_GATE_SLOTS")) h->gate_slots = e[0] != '0';
   h->cfg.xmap_height = xmap_h;
 
 #define XM_TRY_CREATE(expr)                   \
@@ -792,7 +803,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     if (cfg->view == XM_VIEW_PROJECTOR && h->k2_flags)
       XM_TRY_CREATE(hipMalloc((void**)&s.dirty, ((h->key_cells + 15) >> 4) + 64));
     s.st = h->d_states + i;
-    if (h->try_sorted) {
+    if (h->try_sorted || h->gate_slots) {
       XM_TRY_CREATE(hipHostMalloc((void**)&s.h_flags, 64, hipHostMallocMapped));
       s.h_flags[0] = s.h_flags[1] = 0;
       u32* d_flags = nullptr;
@@ -861,7 +872,7 @@ int xm_sync(xm_handle* h) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->cfg.device));
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
-  if (h->try_sorted) {  // frames whose shortcut failed are redone now, then waited for
+  if (h->try_sorted || h->gate_slots) {  // frames whose shortcut failed are redone now, then waited for
     for (Slot& s : h->slots) {
       bool redone = false;
       int rc = resolve_prev(h, s, &redone);
