@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true", help="EXPERIMENTS ONLY (ablation builds): skip the parity gate")
     ap.add_argument("--assume-sorted", action="store_true",
                     help="XM_FLAG_TIME_SORTED: extrema = t[0], t[n-1], verified on the device; the extrema pass K0 is skipped")
+    ap.add_argument("--launch-workers", action="store_true", help="XM_FLAG_LAUNCH_WORKERS: one launch thread per slot stream")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra try-sorted / declared-sorted loops")
     ap.add_argument("--try-sorted", action="store_true",
                     help="XM_FLAG_TRY_SORTED: no declaration; (t[0], t[n-1]) tried and verified on every frame, frames that "
@@ -88,7 +89,8 @@ def main():
     tables = S.make_tables(cfg)
     eng = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots,
                       assume_time_sorted=args.assume_sorted, try_sorted=args.try_sorted,
-                      default_priority_streams=args.graph)  # graph replays need default-priority streams (xmaps.h)
+                      default_priority_streams=args.graph,  # graph replays need default-priority streams (xmaps.h)
+                      launch_workers=args.launch_workers)
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 

@@ -515,3 +515,43 @@ def test_try_sorted_mode_pinned_host_path_and_aos():
         assert eng.sorted_fallbacks() == 3
         for d, b, ref, _ in jobs:
             assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+
+
+def test_launch_workers_keep_order_and_results():
+    """XM_FLAG_LAUNCH_WORKERS: asynchronous device frames are launched by one worker thread per slot stream.  Interleaved
+    with synchronous host calls, profile calls, stage calls and try-sorted redos the results stay exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    rng = np.random.default_rng(23)
+    frames, refs = [], []
+    for f in range(9):
+        ev = S.make_events(cfg, frame=f, n=28_000)
+        x, y, t, _ = S.to_soa(ev)
+        if f % 4 == 1:
+            perm = rng.permutation(len(t))
+            x, y, t = x[perm], y[perm], t[perm]
+        refs.append(O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t))
+        frames.append((x, y, t) + tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t)))
+    for try_sorted in (False, True):
+        with XMapsEngine(tb, n_slots=3, try_sorted=try_sorted, launch_workers=True) as eng:
+            outs = [torch.zeros((eng.out_h, eng.out_w), dtype=torch.float32, device=dev) for _ in frames]
+            bgrs = [torch.zeros((eng.out_h, eng.out_w, 3), dtype=torch.uint8, device=dev) for _ in frames]
+            torch.cuda.synchronize()
+            for rep in range(3):
+                for i, (x, y, t, fx, fy, ft) in enumerate(frames):
+                    eng.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, len(t), outs[i].data_ptr(), bgrs[i].data_ptr())
+                    if i == 4:  # a synchronous host call and a stage call in the middle of the asynchronous stream
+                        d, b, st = eng.process_frame(x, y, t)
+                        assert np.array_equal(d, refs[i]["depth"]) and st.n_inliers == int(refs[i]["mask"].sum())
+                        xr, yr = eng.rectify_cam_coords_i16(x[:100], y[:100])
+                        assert np.array_equal(xr, tb["cam_mapx_i16"][y[:100], x[:100]])
+                    if i == 6:
+                        st = eng.profile_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, len(t), outs[i].data_ptr(), bgrs[i].data_ptr())
+                        assert st.n_inliers == int(refs[i]["mask"].sum())
+                eng.sync()
+                for o, b, r in zip(outs, bgrs, refs):
+                    assert np.array_equal(o.cpu().numpy(), r["depth"]) and np.array_equal(b.cpu().numpy(), r["bgr"])
+            if try_sorted:
+                assert eng.sorted_fallbacks() >= 6

@@ -23,6 +23,7 @@ XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY, 
 XM_FLAG_TIME_SORTED = 1
 XM_FLAG_TRY_SORTED = 2
 XM_FLAG_DEFAULT_STREAMS = 4
+XM_FLAG_LAUNCH_WORKERS = 8
 XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
 XM_MEM_HOST, XM_MEM_DEVICE, XM_MEM_HOST_PINNED = 0, 1, 2
 XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2

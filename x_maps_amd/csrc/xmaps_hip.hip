@@ -6,12 +6,17 @@
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <algorithm>
 #include <new>
 #include <type_traits>
@@ -77,6 +82,8 @@ struct EventsView {
 struct Slot {
   hipStream_t stream = nullptr;
   bool owns_stream = true;
+  int worker = -1;    // launch worker of this slot's stream (-1: none)
+  u32 api_tag = 0;    // tag of the slot's last frame as the API thread counts them (== host_tag once the workers are idle)
   // XM_FLAG_TRY_SORTED: pinned host words the kernels report to ([0] tag of the last frame whose shortcut failed, [1] tag of
   // the last frame whose K2 has started) and what is needed to redo the slot's last asynchronous frame on the general path
   u32* h_flags = nullptr;
@@ -99,6 +106,35 @@ struct Slot {
   uint64_t last_n = 0;
   // staging for XM_MEM_HOST calls
   DevBuf ev_x, ev_y, ev_t, ev_p, ev_aos, out_depth, out_bgr, dbg[5];
+};
+
+// ---- launch workers -------------------------------------------------------------------------------------------
+// A kernel launch costs the calling thread ~2.7 us in the HIP runtime, three launches per frame; with the GPU at ~12 us per
+// frame that single thread is what bounds the asynchronous device-pointer path (tools/only_kernel_eager.sh: 3.2 us per call
+// + 2.75 us per launch, whatever the kernels do).  One worker thread per slot stream takes the launches: the API call only
+// settles the slot's previous frame, assigns the frame to a slot and posts a job (5 instead of 11.5 us per call).  The frame
+// rate does not change -- with the drain fix and own hardware queues the GPU is the bound -- so this is opt-in
+// (XM_FLAG_LAUNCH_WORKERS) for hosts whose calling thread has other work to do.
+struct Job {
+  enum Kind : int { FRAME = 0, STOP = 1 };
+  int kind = FRAME;
+  int slot = 0;
+  EventsView ev;
+  float* depth = nullptr;
+  uint8_t* bgr = nullptr;
+  bool allow_sorted = true;
+};
+
+struct Worker {
+  static constexpr unsigned CAP = 256;  // jobs in flight per stream (the producer waits when full)
+  Job ring[CAP];
+  std::atomic<unsigned long long> head{0}, tail{0}, done{0};  // produced / taken / finished
+  std::atomic<int> error{0};  // first failing return code of a job (reported by the next xm_sync)
+  std::string error_text;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<bool> sleeping{false};
+  std::thread th;
 };
 
 }  // namespace
@@ -132,6 +168,7 @@ struct xm_handle {
   bool k2_flags = false;      // XM_K2_FLAGS=1: K1 marks dirty 128-byte lines of the key frame, K2 skips clean ones.
                               // Measured: K2 fetches 37 % fewer bytes but is not faster (it is latency, not bandwidth bound)
   std::vector<hipStream_t> gstreams;  // default-priority streams the hipGraph batches are captured on and launched from
+  std::vector<std::unique_ptr<Worker>> workers;  // one per slot stream (empty: launches happen in the calling thread)
   bool time_sorted = false;   // XM_FLAG_TIME_SORTED
   bool try_sorted = false;    // XM_FLAG_TRY_SORTED
   bool gate_slots = false;    // experiments (XM_GATE_SLOTS=1): asynchronous calls wait (polling a pinned word) until the slot's previous frame has reached K2
@@ -439,6 +476,75 @@ Slot& pick_slot(xm_handle* h) {
 // XM_FLAG_TRY_SORTED: did the (t[0], t[n-1]) shortcut hold for the slot's last asynchronous frame?  The kernels answer in
 // pinned host memory (no API call when the frame has finished, which it has when a slot comes round again); a frame that
 // failed is redone here on the general path, into the same output buffers, before anything else happens on the slot.
+// ---- worker threads --------------------------------------------------------------------------------------------------
+void worker_main(xm_handle* h, Worker* w) {
+  (void)hipSetDevice(h->cfg.device);
+  for (;;) {
+    unsigned long long t = w->tail.load(std::memory_order_relaxed);
+    if (t == w->head.load(std::memory_order_acquire)) {  // empty: spin a little, then sleep
+      bool got = false;
+      for (int i = 0; i < 20000 && !got; ++i) {
+        __builtin_ia32_pause();
+        got = t != w->head.load(std::memory_order_acquire);
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->sleeping.store(true, std::memory_order_seq_cst);
+        w->cv.wait(lk, [&] { return t != w->head.load(std::memory_order_acquire); });
+        w->sleeping.store(false, std::memory_order_relaxed);
+      }
+    }
+    const Job j = w->ring[t % Worker::CAP];
+    w->tail.store(t + 1, std::memory_order_release);
+    if (j.kind == Job::STOP) {
+      w->done.store(t + 1, std::memory_order_release);
+      return;
+    }
+    const int rc = enqueue_frame(h, h->slots[j.slot], j.ev, j.depth, j.bgr, nullptr, j.allow_sorted);
+    if (rc != XM_OK && w->error.load(std::memory_order_relaxed) == 0) {
+      w->error_text = g_err;  // thread-local text of this worker
+      w->error.store(rc, std::memory_order_release);
+    }
+    w->done.store(t + 1, std::memory_order_release);
+  }
+}
+
+void post_job(Worker* w, const Job& j) {
+  const unsigned long long hd = w->head.load(std::memory_order_relaxed);
+  while (hd - w->tail.load(std::memory_order_acquire) >= Worker::CAP) __builtin_ia32_pause();  // ring full: back-pressure
+  w->ring[hd % Worker::CAP] = j;
+  w->head.store(hd + 1, std::memory_order_seq_cst);
+  if (w->sleeping.load(std::memory_order_seq_cst)) {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->cv.notify_one();
+  }
+}
+
+// wait until the workers have issued everything posted so far (the GPU may still be running it); reports a failed job
+int drain_workers(xm_handle* h, int only = -1) {
+  int rc = XM_OK;
+  for (size_t i = 0; i < h->workers.size(); ++i) {
+    if (only >= 0 && (int)i != only) continue;
+    Worker* w = h->workers[i].get();
+    const unsigned long long hd = w->head.load(std::memory_order_acquire);
+    while (w->done.load(std::memory_order_acquire) < hd) __builtin_ia32_pause();
+    const int e = w->error.load(std::memory_order_acquire);
+    if (e && rc == XM_OK) {
+      rc = fail(e, "%s (reported by the launch worker of stream %zu)", w->error_text.c_str(), i);
+      w->error.store(0, std::memory_order_release);
+    }
+  }
+  return rc;
+}
+
+// device set + launch workers idle: the entry of every call that uses the slots' streams itself
+#define XM_ENTER(h)                          \
+  do {                                       \
+    HIP_TRY(hipSetDevice((h)->cfg.device));  \
+    const int rc_enter_ = drain_workers(h);  \
+    if (rc_enter_) return rc_enter_;         \
+  } while (0)
+
 int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   if (!s.prev.valid) return XM_OK;
   s.prev.valid = false;
@@ -463,8 +569,23 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   }
   if (!s.prev.check || __atomic_load_n(&s.h_flags[0], __ATOMIC_ACQUIRE) != tag) return XM_OK;
   h->sorted_fallbacks += 1;
-  int rc = enqueue_frame(h, s, s.prev.ev, s.prev.depth, s.prev.bgr, nullptr, false);
+  if (s.worker >= 0 && !s.prev.host_depth && !s.prev.host_bgr) {  // the redo goes the way the frame went
+    Job j;
+    j.slot = (int)(&s - h->slots.data());
+    j.ev = s.prev.ev;
+    j.depth = s.prev.depth;
+    j.bgr = s.prev.bgr;
+    j.allow_sorted = false;
+    s.api_tag = s.api_tag >= KEY_MAX_TAG ? 1 : s.api_tag + 1;
+    post_job(h->workers[s.worker].get(), j);
+    if (redone) *redone = true;
+    return XM_OK;
+  }
+  int rc = s.worker >= 0 ? drain_workers(h, s.worker) : XM_OK;
   if (rc) return rc;
+  rc = enqueue_frame(h, s, s.prev.ev, s.prev.depth, s.prev.bgr, nullptr, false);
+  if (rc) return rc;
+  s.api_tag = s.host_tag;
   const size_t px = (size_t)h->out_w * h->out_h;
   if (s.prev.host_depth) HIP_TRY(hipMemcpyAsync(s.prev.host_depth, s.prev.depth, px * 4, hipMemcpyDeviceToHost, s.stream));
   if (s.prev.host_bgr) HIP_TRY(hipMemcpyAsync(s.prev.host_bgr, s.prev.bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
@@ -482,6 +603,28 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
   Slot& s = profile ? h->slots[0] : pick_slot(h);
   if (profile) h->last_slot = 0;
   if ((rc = resolve_prev(h, s))) return rc;
+  if (s.worker >= 0 && mem == XM_MEM_DEVICE && !profile && !h->capturing) {
+    // asynchronous device-pointer frame: the launches are the worker's job
+    Job j;
+    j.slot = (int)(&s - h->slots.data());
+    j.ev = ev;
+    j.depth = depth_out;
+    j.bgr = bgr_out;
+    s.api_tag = s.api_tag >= KEY_MAX_TAG ? 1 : s.api_tag + 1;
+    post_job(h->workers[s.worker].get(), j);
+    if (s.h_flags) {
+      s.prev.valid = true;
+      s.prev.check = h->try_sorted && sorted_path(h, ev);
+      s.prev.ev = ev;
+      s.prev.depth = depth_out;
+      s.prev.bgr = bgr_out;
+      s.prev.host_depth = nullptr;
+      s.prev.host_bgr = nullptr;
+      s.prev.tag = s.api_tag;
+    }
+    return XM_OK;
+  }
+  if (s.worker >= 0 && (rc = drain_workers(h, s.worker))) return rc;  // this call uses the slot's stream itself
   float* d_depth = depth_out;
   uint8_t* d_bgr = bgr_out;
   const bool host_in = mem == XM_MEM_HOST || mem == XM_MEM_HOST_PINNED;
@@ -514,6 +657,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     return fail(XM_ERR_INVALID, "mem must be XM_MEM_HOST, XM_MEM_HOST_PINNED or XM_MEM_DEVICE");
   }
   if ((rc = enqueue_frame(h, s, ev, d_depth, d_bgr, profile ? h->prof_ev : nullptr))) return rc;
+  s.api_tag = s.host_tag;
   if (host_in) {
     if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
     if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
@@ -549,6 +693,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
       // the time-sorted declaration did not hold for this frame: redo it on the general path (K0 -> K1 -> K2)
       h->sorted_fallbacks += 1;
       if ((rc = enqueue_frame(h, s, ev, d_depth, d_bgr, nullptr, false))) return rc;
+      s.api_tag = s.host_tag;
       if (mem == XM_MEM_HOST) {
         if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d_depth, px * 4, hipMemcpyDeviceToHost, s.stream));
         if (bgr_out) HIP_TRY(hipMemcpyAsync(bgr_out, d_bgr, px * 3, hipMemcpyDeviceToHost, s.stream));
@@ -828,6 +973,26 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->join_ev.resize(n_slots, nullptr);
   for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
   for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipStreamSynchronize(h->slots[i].stream));
+  {  // launch workers: one per distinct slot stream (XM_FLAG_LAUNCH_WORKERS; off: launches stay in the calling thread)
+    const char* we = getenv("XM_WORKERS");  // overrides the flag either way
+    const bool want = we ? we[0] != '0' : (cfg->flags & XM_FLAG_LAUNCH_WORKERS) != 0;
+    if (want) {
+      std::vector<hipStream_t> seen;
+      for (int i = 0; i < n_slots; ++i) {
+        Slot& s = h->slots[i];
+        int w = -1;
+        for (size_t k = 0; k < seen.size(); ++k)
+          if (seen[k] == s.stream) w = (int)k;
+        if (w < 0) {
+          w = (int)seen.size();
+          seen.push_back(s.stream);
+          h->workers.emplace_back(new Worker());
+        }
+        s.worker = w;
+      }
+      for (auto& w : h->workers) w->th = std::thread(worker_main, h, w.get());
+    }
+  }
 #undef XM_TRY_CREATE
   *out = h;
   return XM_OK;
@@ -836,6 +1001,14 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
 void xm_destroy(xm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
+  for (auto& w : h->workers) {
+    Job stop;
+    stop.kind = Job::STOP;
+    post_job(w.get(), stop);
+  }
+  for (auto& w : h->workers)
+    if (w->th.joinable()) w->th.join();
+  h->workers.clear();
   for (Slot& s : h->slots) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     s.ev_x.release(); s.ev_y.release(); s.ev_t.release(); s.ev_p.release(); s.ev_aos.release();
@@ -870,14 +1043,17 @@ int xm_sorted_fallbacks(xm_handle* h, uint64_t* count) {
 
 int xm_sync(xm_handle* h) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
   if (h->try_sorted || h->gate_slots) {  // frames whose shortcut failed are redone now, then waited for
     for (Slot& s : h->slots) {
       bool redone = false;
       int rc = resolve_prev(h, s, &redone);
       if (rc) return rc;
-      if (redone) HIP_TRY(hipStreamSynchronize(s.stream));
+      if (redone) {
+        if ((rc = drain_workers(h))) return rc;
+        HIP_TRY(hipStreamSynchronize(s.stream));
+      }
     }
   }
   if (h->time_sorted) {  // any asynchronously processed frame that was not sorted after all?
@@ -950,7 +1126,7 @@ int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
 
 int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats) {
   if (!h || !stats) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[h->last_slot];
   HIP_TRY(hipStreamSynchronize(s.stream));
   return fetch_stats(h, s, XM_T_INT64, stats);
@@ -958,7 +1134,7 @@ int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats) {
 
 int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
   if (!h || !ms_out || reps <= 0) return fail(XM_ERR_INVALID, "bad argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[0];
   std::vector<float> v;
   for (int i = 0; i < reps; ++i) {
@@ -979,7 +1155,7 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, xm_graph** out) {
   if (!h || !out || !offsets_host || n_frames <= 0) return fail(XM_ERR_INVALID, "bad argument");
   *out = nullptr;
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   const int ns = (int)h->slots.size();
   if ((u64)n_frames / ns + 1 >= KEY_MAX_TAG) return fail(XM_ERR_INVALID, "too many frames per graph");
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
@@ -1063,7 +1239,7 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
 int xm_graph_launch(xm_graph* g) {
   if (!g || !g->exec) return fail(XM_ERR_INVALID, "NULL graph");
   xm_handle* h = g->h;
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   const int ns = (int)h->slots.size();
   hipStream_t origin = h->gstreams[0];
   for (Slot& s : h->slots) {  // XM_FLAG_TRY_SORTED: settle pending verdicts before the replay advances the slots' tags
@@ -1104,7 +1280,7 @@ void xm_graph_destroy(xm_graph* g) {
 int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
                            int t_dtype, int mem, int16_t* xr, int16_t* yr, int16_t* ts, int16_t* disp, uint8_t* mask) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   EventsView ev;
   ev.x = x; ev.y = y; ev.t = t; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
   int rc = check_events(ev);
@@ -1161,7 +1337,7 @@ static int read_oob(xm_handle* h, hipStream_t stream, const char* what) {
 
 int xm_stage_rectify(xm_handle* h, const uint16_t* x, const uint16_t* y, size_t n, int16_t* xr, int16_t* yr) {
   if (!h || (n && (!x || !y || !xr || !yr))) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (n == 0) return XM_OK;
   Slot& s = h->slots[0];
   int rc;
@@ -1181,7 +1357,7 @@ int xm_stage_rectify(xm_handle* h, const uint16_t* x, const uint16_t* y, size_t 
 int xm_stage_rectify_f32(xm_handle* h, const float* mapx_f32, const float* mapy_f32, const uint16_t* x, const uint16_t* y,
                          size_t n, float* xr, float* yr) {
   if (!h || !mapx_f32 || !mapy_f32 || (n && (!x || !y || !xr || !yr))) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (n == 0) return XM_OK;
   Slot& s = h->slots[0];
   const size_t map_bytes = (size_t)h->cfg.cam_width * h->cfg.cam_height * 4;
@@ -1204,7 +1380,7 @@ int xm_stage_rectify_f32(xm_handle* h, const float* mapx_f32, const float* mapy_
 int xm_stage_point_cloud(xm_handle* h, const double* Q, const float* xpr, const float* ypr, const float* disp, size_t n,
                          float* cloud) {
   if (!h || !Q || (n && (!xpr || !ypr || !disp || !cloud))) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (n == 0) return XM_OK;
   Slot& s = h->slots[0];
   int rc;
@@ -1225,7 +1401,7 @@ int xm_stage_point_cloud(xm_handle* h, const double* Q, const float* xpr, const 
 int xm_stage_event_disparity(xm_handle* h, const int16_t* xr, const int16_t* yr, const void* t, size_t n, int t_dtype,
                              int16_t* disp, uint8_t* mask) {
   if (!h || (n && (!xr || !yr || !t || !disp || !mask))) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (n == 0) return XM_OK;
   Slot& s = h->slots[0];
   int rc;
@@ -1260,7 +1436,7 @@ int xm_stage_event_disparity(xm_handle* h, const int16_t* xr, const int16_t* yr,
 static int stage_scatter_common(xm_handle* h, int view, const void* a, const void* b, const int16_t* disp,
                                 const uint8_t* mask, size_t n, float* disp_map) {
   if (!h || !disp_map || (n && (!a || !b || !disp || !mask))) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "too many events");
   Slot& s = h->slots[0];
   int rc;
@@ -1306,7 +1482,7 @@ int xm_stage_disp_map_camera_view(xm_handle* h, const uint16_t* x, const uint16_
 int xm_stage_remap_rectified_disp_map_to_proj(xm_handle* h, const float* rect_disp, float* proj_disp) {
   if (!h || !rect_disp || !proj_disp) return fail(XM_ERR_INVALID, "NULL argument");
   if (!h->d_pmap) return fail(XM_ERR_INVALID, "handle was created without disp_proj_mapxy_i16");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[0];
   const size_t cells = (size_t)h->tb.rect_w * h->tb.rect_h, px = (size_t)h->tb.proj_w * h->tb.proj_h;
   int rc;
@@ -1323,7 +1499,7 @@ int xm_stage_remap_rectified_disp_map_to_proj(xm_handle* h, const float* rect_di
 
 static int stage_pixels(xm_handle* h, const float* disp, int height, int width, float* depth, uint8_t* bgr) {
   if (!h || !disp || height <= 0 || width <= 0) return fail(XM_ERR_INVALID, "bad argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[0];
   const size_t px = (size_t)height * width;
   int rc;
@@ -1354,7 +1530,7 @@ int xm_stage_colorize_depth_from_disp(xm_handle* h, const float* disp, int heigh
 // ---- shards -----------------------------------------------------------------------------------------------
 int xm_shard_minmax(xm_handle* h, const void* t, const int16_t* p, size_t n, int t_dtype, void* minmax_out_host) {
   if (!h || !minmax_out_host || (n && !t)) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[0];
   int rc;
   if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
@@ -1377,7 +1553,7 @@ int xm_shard_minmax(xm_handle* h, const void* t, const int16_t* p, size_t n, int
 
 int xm_shard_clear(xm_handle* h, uint64_t* key_frame) {
   if (!h || !key_frame) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   HIP_TRY(hipMemsetAsync(key_frame, 0, h->key_cells * sizeof(u64), h->slots[0].stream));
   return XM_OK;
 }
@@ -1386,7 +1562,7 @@ int xm_shard_scatter(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
                      int t_dtype, uint64_t idx_offset, const void* frame_minmax_host, uint32_t tag, uint64_t* key_frame) {
   if (!h || !key_frame || !frame_minmax_host) return fail(XM_ERR_INVALID, "NULL argument");
   if (tag == 0 || tag > KEY_MAX_TAG) return fail(XM_ERR_INVALID, "tag must be in [1, 2^19)");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (n == 0) return XM_OK;
   if (idx_offset + n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "global event index exceeds 2^%d", XM_KEY_IDX_BITS);
   EventsView ev;
@@ -1411,7 +1587,7 @@ int xm_shard_scatter(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
 int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float* depth_out, uint8_t* bgr_out) {
   if (!h || !key_frame) return fail(XM_ERR_INVALID, "NULL argument");
   if (tag == 0 || tag > KEY_MAX_TAG) return fail(XM_ERR_INVALID, "tag must be in [1, 2^19)");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   launch_frame_kernel(h, (const u64*)key_frame, h->aux_st, tag, depth_out, bgr_out, h->slots[0].stream);
   HIP_TRY(hipGetLastError());
   return XM_OK;
@@ -1426,7 +1602,7 @@ int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, cons
   if (n >= 0xffffffffull) return fail(XM_ERR_TOO_MANY, "too many events");
   *n_out = 0;
   if (n == 0 || map_height <= 0 || map_width <= 0) return XM_OK;
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[0];
   const size_t cells = (size_t)map_height * map_width;
   if (cells >= 0x7fffffffull) return fail(XM_ERR_INVALID, "map too large");
@@ -1469,7 +1645,7 @@ int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t
   if (n >= 0x7fffffffull) return fail(XM_ERR_TOO_MANY, "too many events");
   *n_out = 0;
   if (n < 2) return XM_OK;
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   Slot& s = h->slots[0];
   int rc;
   const long long* d_t = (const long long*)t;
@@ -1555,13 +1731,13 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
 // ---- pinned host memory --------------------------------------------------------------------------------------
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out) {
   if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
   return XM_OK;
 }
 int xm_host_free(xm_handle* h, void* p) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (p) HIP_TRY(hipHostFree(p));
   return XM_OK;
 }
@@ -1569,25 +1745,25 @@ int xm_host_free(xm_handle* h, void* p) {
 // ---- device memory helpers ----------------------------------------------------------------------------------
 int xm_dev_alloc(xm_handle* h, size_t bytes, void** out) {
   if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
   return XM_OK;
 }
 int xm_dev_free(xm_handle* h, void* p) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (p) HIP_TRY(hipFree(p));
   return XM_OK;
 }
 int xm_dev_upload(xm_handle* h, void* dst_dev, const void* src_host, size_t bytes) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (bytes) HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
   return XM_OK;
 }
 int xm_dev_download(xm_handle* h, void* dst_host, const void* src_dev, size_t bytes) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(h->cfg.device));
+  XM_ENTER(h);
   if (bytes) HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
   return XM_OK;
 }

@@ -71,7 +71,8 @@ class XMapsEngine:
     """
 
     def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1,
-                 assume_time_sorted: bool = False, try_sorted: bool = False, default_priority_streams: bool = False):
+                 assume_time_sorted: bool = False, try_sorted: bool = False, default_priority_streams: bool = False,
+                 launch_workers: bool = False):
         self._lib = N.load_library()
         self._h = C.c_void_p(None)
         mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
@@ -95,7 +96,8 @@ class XMapsEngine:
         cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
         cfg.n_slots = n_slots
         cfg.flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0) | (N.XM_FLAG_TRY_SORTED if try_sorted else 0)
-                     | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0))
+                     | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0)
+                     | (N.XM_FLAG_LAUNCH_WORKERS if launch_workers else 0))
         cfg.p03 = float(tables["p03"])
         self.p03 = cfg.p03
         cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
