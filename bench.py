@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "4")),
                     help="frames in flight per GPU (key frame + state each; one stream per hardware queue, 4)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames resident in HBM")
@@ -277,41 +277,6 @@ def main():
             except Exception as e:  # the checker is optional for the bench
                 cpu["all_cores_c_openmp"] = {"error": str(e)[:200]}
 
-        # ---- the same loop in the engine's other extrema modes (extra information, never the headline `value`) ----
-        other_modes = None
-        if world == 1 and graph is None and not args.assume_sorted and not args.try_sorted and not args.no_other_modes:
-            other_modes = {}
-            modes = [("try_sorted", {"try_sorted": True}), ("declared_sorted", {"assume_time_sorted": True})]
-            if os.environ.get("XM_BENCH_GENERAL_AGAIN"):  # experiment: the headline mode measured again on a second engine
-                modes = [("general_again", {})] + modes + [("general_again2", {})]
-            for name, kw in modes:
-                e2 = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots, **kw)
-
-                def step2(i):
-                    fx, fy, ft = frames[i % len(frames)]
-                    o = i % n_out
-                    e2.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, depth_out[o].data_ptr(),
-                                            None if bgr_out is None else bgr_out[o].data_ptr())
-                for i in range(args.warmup):
-                    step2(i)
-                e2.sync()
-                c0 = time.perf_counter()
-                for i in range(args.steps):
-                    step2(i)
-                e2.sync()
-                dt = time.perf_counter() - c0
-                same = bool(np.array_equal(depth_out[(args.steps - 1) % n_out].cpu().numpy(),
-                                           O.process_ev_frame(tables, *[v.astype(np.int64) if v.dtype != np.int64 else v
-                                                                        for v in host_frames[(args.steps - 1) % len(frames)]],
-                                                              camera_perspective=args.camera_perspective, want_bgr=False)["depth"]))
-                other_modes[name] = {"value": round(n_ev * args.steps / dt / 1e6, 2), "unit": "Mevents/s",
-                                     "ms_per_step": round(dt / args.steps * 1e3, 5), "depth_equals_oracle": same,
-                                     "frames_redone_on_general_path": e2.sorted_fallbacks()}
-                e2.close()
-            other_modes["note"] = ("try_sorted = XM_FLAG_TRY_SORTED (no declaration: (t[0], t[n-1]) tried and verified on the device, "
-                                   "failing frames redone automatically); declared_sorted = XM_FLAG_TIME_SORTED; `value` above is "
-                                   "the general path (extrema pass K0 on every frame)")
-
         host_path = None
         if args.host_path:
             x, y, t = host_frames[0]
@@ -349,6 +314,47 @@ def main():
                               "pcie_GBps": round(reps * bytes_per_frame / dt / 1e9, 2), "depth_equals_oracle": ok_pinned,
                               "note": "events start in (pinned) host memory, depth+BGR end in host memory; never the headline value"})
 
+        # ---- the same loop in the engine's other extrema modes (extra information, never the headline `value`) ----
+        other_modes = None
+        if graph is not None:
+            graph.close()
+            graph = None
+        frames_redone = eng.sorted_fallbacks()
+        eng.close()  # one engine at a time: two engines share the high-priority hardware queues
+        eng = None
+        if world == 1 and not args.graph and not args.assume_sorted and not args.try_sorted and not args.no_other_modes:
+            other_modes = {}
+            modes = [("try_sorted", {"try_sorted": True}), ("declared_sorted", {"assume_time_sorted": True})]
+            if os.environ.get("XM_BENCH_GENERAL_AGAIN"):  # experiment: the headline mode measured again on a second engine
+                modes = [("general_again", {})] + modes + [("general_again2", {})]
+            for name, kw in modes:
+                e2 = XMapsEngine(tables, camera_perspective=args.camera_perspective, device=local_rank, n_slots=args.slots, **kw)
+
+                def step2(i):
+                    fx, fy, ft = frames[i % len(frames)]
+                    o = i % n_out
+                    e2.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, depth_out[o].data_ptr(),
+                                            None if bgr_out is None else bgr_out[o].data_ptr())
+                for i in range(args.warmup):
+                    step2(i)
+                e2.sync()
+                c0 = time.perf_counter()
+                for i in range(args.steps):
+                    step2(i)
+                e2.sync()
+                dt = time.perf_counter() - c0
+                same = bool(np.array_equal(depth_out[(args.steps - 1) % n_out].cpu().numpy(),
+                                           O.process_ev_frame(tables, *[v.astype(np.int64) if v.dtype != np.int64 else v
+                                                                        for v in host_frames[(args.steps - 1) % len(frames)]],
+                                                              camera_perspective=args.camera_perspective, want_bgr=False)["depth"]))
+                other_modes[name] = {"value": round(n_ev * args.steps / dt / 1e6, 2), "unit": "Mevents/s",
+                                     "ms_per_step": round(dt / args.steps * 1e3, 5), "depth_equals_oracle": same,
+                                     "frames_redone_on_general_path": e2.sorted_fallbacks()}
+                e2.close()
+            other_modes["note"] = ("try_sorted = XM_FLAG_TRY_SORTED (no declaration: (t[0], t[n-1]) tried and verified on the device, "
+                                   "failing frames redone automatically); declared_sorted = XM_FLAG_TIME_SORTED; `value` above is "
+                                   "the general path (extrema pass K0 on every frame)")
+
         out = {
             "metric": "Mevents/s to depth frame, 640x480, 1M ev/frame", "value": round(value, 2), "unit": "Mevents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
@@ -359,7 +365,7 @@ def main():
                        "events_per_frame": n_ev, "frames_in_flight": args.slots, "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
                        "launch": "hipGraph" if args.graph else "eager", "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM",
                        "time_sorted_declared": bool(args.assume_sorted), "try_sorted": bool(args.try_sorted),
-                       "frames_redone_on_general_path": eng.sorted_fallbacks()},
+                       "frames_redone_on_general_path": frames_redone},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "host_enqueue_us_per_step": round((t_enqueued - t0) / args.steps * 1e6, 2),
         }
@@ -370,7 +376,8 @@ def main():
         print(json.dumps(out))
     if graph is not None:
         graph.close()
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

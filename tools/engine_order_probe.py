@@ -8,10 +8,10 @@ from x_maps_amd import XMapsEngine, synthetic as S
 dev = torch.device("cuda", 0)
 cfg = S.C_1M
 tb = S.make_tables(cfg)
-slots = 8
+slots = int(os.environ.get('SLOTS', '4'))
 order = os.environ.get("ORDER", "AB-upload-C")
 engs = {}
-def mk(name): engs[name] = XMapsEngine(tb, n_slots=slots)
+def mk(name): engs[name] = XMapsEngine(tb, n_slots=slots, try_sorted=bool(os.environ.get('TRY')))
 frames = []
 def upload():
     for f in range(8):

@@ -545,6 +545,10 @@ int drain_workers(xm_handle* h, int only = -1) {
     if (rc_enter_) return rc_enter_;         \
   } while (0)
 
+#ifndef XM_POLL_FIRST_US
+#define XM_POLL_FIRST_US 30
+#define XM_POLL_NEXT_US 100
+#endif
 int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   if (!s.prev.valid) return XM_OK;
   s.prev.valid = false;
@@ -552,7 +556,7 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   // still in flight?  Wait for K2's start marker by polling the pinned word: a blocking stream synchronisation costs a
   // ~200 us wake-up, per frame, whenever the host runs ahead of the GPU (few slots); the marker is a few us away.
   if (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
-    auto t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(30);
+    auto t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(XM_POLL_FIRST_US);
     unsigned spins = 0;
     while (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
       __builtin_ia32_pause();
@@ -563,7 +567,7 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
         hipError_t q = hipStreamQuery(s.stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) HIP_TRY(q);
-        t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+        t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(XM_POLL_NEXT_US);
       }
     }
   }
