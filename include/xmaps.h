@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XM_API_VERSION 1
+#define XM_API_VERSION 2
 
 /* error codes */
 #define XM_OK 0
@@ -56,15 +56,19 @@ extern "C" {
                                   xm_frame_stats.n_unsorted and xm_sync() -> XM_ERR_UNSORTED.  Ignored when a polarity
                                   column is given. */
 
-#define XM_FLAG_TRY_SORTED 2u  /* No promise from the caller: every frame is first run with (tmin, tmax) = (t[0], t[n-1]) (no
-                                  extrema pass) while the device checks that every event lies inside that range; a frame
-                                  for which that fails is redone on the general path automatically -- inside the call for
-                                  XM_MEM_HOST, otherwise when its slot comes round again (n_slots calls later) or in
+#define XM_FLAG_TRY_SORTED 2u  /* THE DEFAULT since API version 2 (the bit is accepted and ignored).  No promise from the caller:
+                                  every frame is first run with (tmin, tmax) = (t[0], t[n-1]) (no extrema pass, 8 B/event
+                                  less HBM traffic, one launch less) while the device checks that every event lies inside that
+                                  range; a frame for which that fails is redone on the general path automatically -- inside the
+                                  call for XM_MEM_HOST, otherwise when its slot comes round again (n_slots calls later) or in
                                   xm_sync(), whichever is first.  Results are always exact.  Contract for asynchronous
                                   calls: a frame's input and output buffers stay untouched by the caller until n_slots
                                   further frames have been submitted or xm_sync() has returned (the redo reads the inputs
-                                  again and rewrites the outputs).  Ignored when XM_FLAG_TIME_SORTED is set, when a polarity
-                                  column is given, inside xm_graph_create, and for frames too sparse for the tiled kernel. */
+                                  again and rewrites the outputs).  Not used when a polarity column is given, inside
+                                  xm_graph_create, and for frames too sparse for the tiled kernel: those run the extrema pass. */
+#define XM_FLAG_GENERAL 16u    /* Run the extrema pass (K0) on every frame instead of the verified shortcut above: one more
+                                  launch and 8 B/event more traffic, but no frame is ever run twice -- for streams that are
+                                  known to be unsorted (raster-ordered frame filters). */
 
 #define XM_FLAG_DEFAULT_STREAMS 4u /* Create the slots' streams at the default priority.  By default they are created at the
                                      highest priority, which gives them hardware queues of their own (HIP multiplexes all
@@ -183,7 +187,21 @@ int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out);
 int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
                      size_t n, int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
 
+/* ---- a group of frames in ONE set of multi-frame launches (grid = frames x tiles) ------------------- */
+/* All pointers are device pointers; frame f reads events [offsets_host[f], offsets_host[f+1]) of the SoA columns and
+ * writes depth_out + f*H*W (and bgr_out + f*H*W*3); n_frames <= n_slots (every frame of the group owns a slot = a key
+ * frame + state).  Asynchronous like XM_MEM_DEVICE calls: successive groups rotate over the handle's streams, so with
+ * n_slots >= 2 * n_frames the tail of one group overlaps the head of the next; xm_sync() to wait.  XM_FLAG_TRY_SORTED /
+ * XM_FLAG_TIME_SORTED apply per frame exactly as for single frames (a frame whose shortcut failed is redone when its
+ * slot comes round again or in xm_sync()).  Frames too sparse for the tiled kernels are run one by one on the group's
+ * stream.  Why: a single C-1M frame is 245 K1 blocks for 256 CUs, each a ~10 us dependent chain -- its launches leave
+ * the chip half idle while they ramp up and drain; a group's launch keeps every CU fed. */
+int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out);
+
 /* ---- a batch of frames captured once into a hipGraph and replayed (BASELINE config 5) ------------ */
+/* The capture uses the multi-frame launches above: with n_slots >= n_frames the whole batch is three kernel nodes;
+ * otherwise groups of n_slots / 2 frames alternate between two branches of the graph. */
 /* All pointers are device pointers that stay valid for the graph's lifetime.  Frame f reads events
  * [offsets[f], offsets[f+1]) of the SoA columns and writes depth_out + f*H*W (and bgr_out + f*H*W*3). */
 typedef struct xm_graph xm_graph;
@@ -239,6 +257,15 @@ int xm_stage_colorize_depth_from_disp(xm_handle* h, const float* disp, int heigh
 /* extrema of this shard's t (over p == 1 events when p given), written as 2 values of t's dtype to
  * minmax_out_host; synchronous.  An empty shard returns (+max, -max) sentinels of the dtype. */
 int xm_shard_minmax(xm_handle* h, const void* t, const int16_t* p, size_t n, int t_dtype, void* minmax_out_host);
+/* The same without a host round trip: the shard's extrema are left in a 16-byte DEVICE buffer as {tmin, -tmax} -- int64
+ * for XM_T_INT64, float64 for the float dtypes (exact) -- so that ONE MIN all-reduce of that buffer over the ranks gives
+ * the frame's extrema; an empty shard writes {+max, +max} resp. {+inf, +inf} (neutral).  Asynchronous on slot 0's stream. */
+int xm_shard_minmax_device(xm_handle* h, const void* t, const int16_t* p, size_t n, int t_dtype, void* mm_dev);
+/* xm_shard_scatter with the frame's {tmin, -tmax} read from that device buffer when the kernel runs (after the
+ * all-reduce, ordered on slot 0's stream): minmax -> all-reduce -> scatter -> all-reduce -> finish without a single
+ * host synchronisation. */
+int xm_shard_scatter_device(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                            int t_dtype, uint64_t idx_offset, const void* frame_mm_dev, uint32_t tag, uint64_t* key_frame);
 /* zero the key frame (once per buffer, or when the tag wraps) */
 int xm_shard_clear(xm_handle* h, uint64_t* key_frame);
 /* scatter this shard's events; idx_offset = global index of the shard's first event; frame_minmax_host

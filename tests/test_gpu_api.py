@@ -166,10 +166,21 @@ def test_shard_calls_merge_to_the_single_frame(camera):
             sh = tuple(torch.from_numpy(c[a:b].copy().view(np.int16) if c.dtype == np.uint16 else c[a:b].copy()).to(dev)
                        for c in (x, y, t)) + (None,)
             kfs.append((sh, a, prov.new_key_frame()))
-            mms.append(prov.minmax(sh))
-        assert prov.minmax((None, None, torch.zeros(0, dtype=torch.int64, device=dev), None))[0] == np.iinfo(np.int64).max
-        mm = np.array([min(m[0] for m in mms), max(m[1] for m in mms)], np.int64)
-        assert mm[0] == t.min() and mm[1] == t.max()
+            mm_r = prov.new_minmax_buffer(sh)
+            prov.minmax_into(sh, mm_r)  # {tmin, -tmax} left in device memory, no host round trip
+            mms.append(mm_r)
+        empty = (None, None, torch.zeros(0, dtype=torch.int64, device=dev), None)
+        mm_e = prov.new_minmax_buffer(empty)
+        prov.minmax_into(empty, mm_e)
+        # the host-pointer variant (xm_shard_minmax) still exists and agrees
+        mm_host = eng.shard_minmax(kfs[0][0][2].data_ptr(), None, len(kfs[0][0][2]))
+        eng.sync()
+        assert mm_e.cpu().tolist() == [np.iinfo(np.int64).max] * 2  # neutral for the MIN all-reduce
+        assert mm_host[0] == mms[0][0].item() and mm_host[1] == -mms[0][1].item()
+        with prov.collective_stream():
+            mm = torch.minimum(mms[0], mms[1])  # what the MIN all-reduce of the 16-byte buffers yields
+        eng.sync()
+        assert mm[0].item() == t.min() and -mm[1].item() == t.max()
         for tag in (1, 2):  # second round reuses the key frames without clearing them
             for sh, a, kf in kfs:
                 prov.scatter(sh, a, mm, tag, kf)

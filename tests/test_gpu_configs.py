@@ -1,0 +1,352 @@
+"""-m gpu: the BASELINE.json configurations that are more than one frame on one handle, each checked against the oracle.
+
+  config 3  ESL static seq1 full replay            -> stand-in: >= 30 consecutive ESL-like frames (real calibration geometry,
+                                                      microsecond stamps, 3.6 ms dark gaps, negative-polarity + gap noise) fed
+                                                      as packets through DepthReprojectionProcessor -> trigger finder -> GPU
+                                                      (reference caller: python/depth_reprojection.py:10-29)
+  config 4  10 M events/frame, sharded by index    -> C-10M split into 2 / 4 / 8 index shards on ONE GPU (private key frames,
+                                                      device-side extrema, element-wise max merge) == unsharded == C oracle;
+                                                      the same through ShardedFrameProcessor over a real RCCL group (one rank
+                                                      here, both all-reduces issued; every rank when > 1 GPU is visible)
+  config 5  60 frames x 1 M events, hipGraph       -> seeds 20230..20289 replayed from one captured graph,
+                                                      all 60 depth + BGR frames == C oracle; also xm_process_batch
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import xmaps_oracle as O
+from x_maps_amd import XMapsEngine
+from x_maps_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _soa_dev(torch, evs, dev):
+    x, y, t, _ = S.to_soa(evs)
+    return tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 5
+# ---------------------------------------------------------------------------------------------------------------------
+def _c1m_batch(torch, n_frames, first_seed=0):
+    """n_frames C-1M frames (rng seeds 20230 + first_seed ...) laid out back to back in HBM + their C-oracle frames."""
+    from c_oracle import COracle
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    co = COracle(tb, False, omp=True)
+    dev = torch.device("cuda", 0)
+    X = torch.empty(n_frames * cfg.n_events, dtype=torch.int16, device=dev)
+    Y = torch.empty_like(X)
+    T = torch.empty(n_frames * cfg.n_events, dtype=torch.int64, device=dev)
+    refs = []
+    for f in range(n_frames):
+        evs = S.make_events(cfg, frame=first_seed + f)
+        x, y, t, _ = S.to_soa(evs)
+        a = f * cfg.n_events
+        X[a:a + cfg.n_events] = torch.from_numpy(x.view(np.int16))
+        Y[a:a + cfg.n_events] = torch.from_numpy(y.view(np.int16))
+        T[a:a + cfg.n_events] = torch.from_numpy(t)
+        r = co.process_ev_frame(x, y, t)
+        refs.append((r["depth"].copy(), r["bgr"].copy(), int(r["n_inliers"])))
+    torch.cuda.synchronize()
+    return cfg, tb, (X, Y, T), refs
+
+
+@pytest.mark.parametrize("n_slots,sorted_decl", [(8, False), (60, False), (8, True)])
+def test_config5_graph_60_frames_of_1m_events(n_slots, sorted_decl):
+    """60 x C-1M from one hipGraph: n_slots = 8 -> 15 groups of 4 frames on two graph branches; n_slots = 60 -> the whole
+    batch is three kernel nodes.  Replayed twice (device-side tags advance), every frame == C oracle."""
+    torch = pytest.importorskip("torch")
+    F = 60
+    cfg, tb, (X, Y, T), refs = _c1m_batch(torch, F)
+    dev = X.device
+    depth = torch.zeros((F, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((F, cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    offs = np.arange(F + 1, dtype=np.uint64) * cfg.n_events
+    with XMapsEngine(tb, n_slots=n_slots, assume_time_sorted=sorted_decl, default_priority_streams=True) as eng:
+        g = eng.graph_create(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, depth.data_ptr(), bgr.data_ptr())
+        for rep in range(2):
+            g.launch()
+            eng.sync()
+            d, b = depth.cpu().numpy(), bgr.cpu().numpy()
+            for f in range(F):
+                assert np.array_equal(d[f], refs[f][0]), (rep, f)
+                assert np.array_equal(b[f], refs[f][1]), (rep, f)
+            depth.zero_()
+            bgr.zero_()
+            torch.cuda.synchronize()
+        g.close()
+        # the handle still serves eager frames afterwards
+        eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, cfg.n_events, depth[0].data_ptr(), None)
+        eng.sync()
+        assert np.array_equal(depth[0].cpu().numpy(), refs[0][0])
+        assert eng.last_frame_stats().n_inliers == refs[0][2]
+
+
+@pytest.mark.parametrize("camera", [False, True])
+@pytest.mark.parametrize("try_sorted", [False, True])
+def test_process_batch_groups_of_frames(camera, try_sorted):
+    """xm_process_batch: groups of 4 frames per set of launches over 8 slots, interleaved with single-frame calls; one
+    frame of every second group is shuffled (try-sorted mode must redo exactly those)."""
+    torch = pytest.importorskip("torch")
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    F, n = 24, 30_000
+    evs = []
+    for f in range(F):
+        e = S.make_events(cfg, frame=100 + f, n=n - 97 * (f % 5))
+        if f % 8 == 3:
+            e = e[rng.permutation(len(e))]
+        evs.append(e)
+    refs = []
+    for e in evs:
+        x, y, t, _ = S.to_soa(e)
+        refs.append(O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera))
+    offs = np.concatenate(([0], np.cumsum([len(e) for e in evs]))).astype(np.uint64)
+    cat = np.concatenate(evs)
+    X, Y, T = _soa_dev(torch, cat, dev)
+    H, W = (cfg.cam_h, cfg.cam_w) if camera else (cfg.proj_h, cfg.proj_w)
+    depth = torch.zeros((F, H, W), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((F, H, W, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb, camera_perspective=camera, n_slots=8, try_sorted=try_sorted) as eng:
+        for rep in range(2):
+            f = 0
+            while f < F:
+                if f == 12:  # a single-frame call between two groups
+                    a = int(offs[f])
+                    eng.process_frame_device(X[a:].data_ptr(), Y[a:].data_ptr(), T[a:].data_ptr(), None, len(evs[f]),
+                                             depth[f].data_ptr(), bgr[f].data_ptr())
+                    f += 1
+                    continue
+                k = min(4 if f != 13 else 3, F - f)
+                a = int(offs[f])
+                eng.process_batch_device(X[a:].data_ptr(), Y[a:].data_ptr(), T[a:].data_ptr(), None, offs[f:f + k + 1] - offs[f],
+                                         depth[f].data_ptr(), bgr[f].data_ptr())
+                f += k
+            eng.sync()
+            d, b = depth.cpu().numpy(), bgr.cpu().numpy()
+            for i in range(F):
+                assert np.array_equal(d[i], refs[i]["depth"]), (rep, i)
+                assert np.array_equal(b[i], refs[i]["bgr"]), (rep, i)
+            depth.zero_()
+            bgr.zero_()
+            torch.cuda.synchronize()
+        if try_sorted:
+            assert eng.sorted_fallbacks() == 2 * 3
+        with pytest.raises(ValueError):  # more frames than slots
+            eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs[:10], depth.data_ptr(), None)
+
+
+def test_process_batch_c1m_and_empty_frame():
+    """Full-size frames through the multi-frame launches, with an EMPTY frame in the middle of the group."""
+    torch = pytest.importorskip("torch")
+    cfg, tb, (X, Y, T), refs = _c1m_batch(torch, 3, first_seed=70)
+    dev = X.device
+    n = cfg.n_events
+    offs = np.array([0, n, n, 2 * n, 3 * n], dtype=np.uint64)  # frame 1 is empty
+    depth = torch.ones((4, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((4, cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for kw in ({}, {"try_sorted": True}):
+        with XMapsEngine(tb, n_slots=4, **kw) as eng:
+            for rep in range(2):
+                eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, depth.data_ptr(), bgr.data_ptr())
+                eng.sync()
+                d, b = depth.cpu().numpy(), bgr.cpu().numpy()
+                for i, r in ((0, 0), (2, 1), (3, 2)):
+                    assert np.array_equal(d[i], refs[r][0]) and np.array_equal(b[i], refs[r][1]), (kw, rep, i)
+                assert not d[1].any() and (b[1] == 255).all()
+                depth.fill_(1.0)
+                torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c10m():
+    torch = pytest.importorskip("torch")
+    from c_oracle import COracle
+    cfg = S.C_10M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg)
+    x, y, t, _ = S.to_soa(evs)
+    ref = COracle(tb, False, omp=True).process_ev_frame(x, y, t)
+    ref = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in ref.items()}
+    return cfg, tb, (x, y, t), ref
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config4_c10m_index_shards_on_one_gpu(c10m, world):
+    """The sharded protocol with all `world` ranks played by one GPU: per-shard extrema left in device memory, MIN over the
+    shards (what the all-reduce computes), private key frames, element-wise MAX merge, frame kernel -- no host round trip
+    anywhere.  Result == the unsharded frame == the C oracle."""
+    import torch
+    from x_maps_amd.sharded import shard_bounds
+    cfg, tb, (x, y, t), ref = c10m
+    dev = torch.device("cuda", 0)
+    X, Y, T = (torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t))
+    n = len(t)
+    with XMapsEngine(tb) as eng:
+        stream = torch.cuda.ExternalStream(eng.stream(0), device=dev)
+        depth = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+        bgr = torch.zeros((cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+        kfs = [torch.zeros(eng.key_shape, dtype=torch.int64, device=dev) for _ in range(world)]
+        mms = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for tag in (1, 2):  # two consecutive frames on the same key frames: tags separate them
+            with torch.cuda.stream(stream):
+                for r in range(world):
+                    a, b = shard_bounds(n, r, world)
+                    eng.shard_minmax_device(T[a:].data_ptr(), None, b - a, mms[r].data_ptr())
+                mm = mms.min(dim=0).values.contiguous()  # = all_reduce(MIN) of the ranks' 16-byte buffers
+                for r in range(world):
+                    a, b = shard_bounds(n, r, world)
+                    eng.shard_scatter_device(X[a:].data_ptr(), Y[a:].data_ptr(), T[a:].data_ptr(), None, b - a, a,
+                                             mm.data_ptr(), tag, kfs[r].data_ptr())
+                merged = kfs[0].clone()
+                for r in range(1, world):
+                    torch.maximum(merged, kfs[r], out=merged)  # = all_reduce(MAX) of the key frames
+                eng.shard_finish(merged.data_ptr(), tag, depth.data_ptr(), bgr.data_ptr())
+            eng.sync()
+            torch.cuda.synchronize()
+            assert mm[0].item() == t.min() and -mm[1].item() == t.max()
+            assert np.array_equal(depth.cpu().numpy(), ref["depth"]), (world, tag)
+            assert np.array_equal(bgr.cpu().numpy(), ref["bgr"]), (world, tag)
+            depth.zero_()
+            torch.cuda.synchronize()
+
+
+def test_config4_sharded_processor_over_rccl_issues_both_collectives(c10m, tmp_path):
+    """ShardedFrameProcessor + GpuShardProvider over a real RCCL group at C-10M.  One rank on this box, `always_reduce`
+    makes it issue the 16-byte MIN and the 55.8 MB MAX all-reduce anyway (RCCL kernels run, data unchanged)."""
+    import torch
+    import torch.distributed as dist
+    from x_maps_amd.sharded import GpuShardProvider, ShardedFrameProcessor
+    cfg, tb, (x, y, t), ref = c10m
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        sh = tuple(torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t)) + (None,)
+        torch.cuda.synchronize()
+        with XMapsEngine(tb) as eng:
+            proc = ShardedFrameProcessor(GpuShardProvider(eng, dev), dist, always_reduce=True)
+            for rep in range(2):
+                depth, bgr = proc.process_shard(sh, 0)
+                eng.sync()
+                torch.cuda.synchronize()
+                assert np.array_equal(depth.cpu().numpy(), ref["depth"]) and np.array_equal(bgr.cpu().numpy(), ref["bgr"])
+            assert proc.collectives_issued == 4
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from x_maps_amd.sharded import GpuShardProvider, ShardedFrameProcessor, shard_bounds
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cfg = S.C_10M
+    tb = S.make_tables(cfg)
+    x, y, t, _ = S.to_soa(S.make_events(cfg))
+    a, b = shard_bounds(len(t), rank, world)
+    sh = tuple(torch.from_numpy(v[a:b].copy()).to(dev) for v in (x.view(np.int16), y.view(np.int16), t)) + (None,)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb, device=rank) as eng:
+        proc = ShardedFrameProcessor(GpuShardProvider(eng, dev), dist)
+        depth, bgr = proc.process_shard(sh, a)
+        eng.sync()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), depth=depth.cpu().numpy(), bgr=bgr.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_config4_sharded_over_rccl_all_visible_gpus(c10m, tmp_path):
+    """Every visible GPU is a rank (skipped on a single-GPU box): the C-10M frame sharded by index, merged over RCCL/xGMI."""
+    import torch
+    import torch.multiprocessing as mp
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("one GPU visible: the multi-rank RCCL run needs >= 2 (the one-GPU shard test covers the arithmetic)")
+    cfg, tb, _, ref = c10m
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.array_equal(got["depth"], ref["depth"]) and np.array_equal(got["bgr"], ref["bgr"]), r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 3
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config3_esl_like_replay_through_the_processor():
+    """36 consecutive ESL-like frames (real calibration geometry, ~150 k events / frame, microsecond stamps, 3.6 ms gaps,
+    10 % negative-polarity events, noise events inside some gaps) as 1/4-period packets through
+    DepthReprojectionProcessor -> polarity filter -> trigger finder -> fused GPU frame -> window: >= 30 frames come out
+    (the reference's trigger finder cannot cut the first and the last frame of a stream, and drops a buffer that holds a
+    full period but only one pause, trigger_finder.py:146-189 -- a handful of frames are lost to that by design) and
+    EVERY one equals the oracle run on the events the trigger finder cut."""
+    from x_maps_amd import rig
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor, RuntimeParams
+    cp, tb, _, _ = rig.make_esl_like(row_stride=13)
+    stream, rendered = rig.render_stream(cp, tb, n_frames=36, row_stride=13, seed=3)
+    assert (np.diff(stream["t"]) >= 0).all() and 100_000 < np.mean([len(f) for f in rendered]) < 200_000
+    params = RuntimeParams(camera_width=640, camera_height=480, projector_width=1080, projector_height=1920, projector_fps=60,
+                           z_near=0.1, z_far=1.2, calib=None, projector_time_map=None, no_frame_dropping=True,
+                           camera_perspective=False, tables=tb)
+    cut, shown = [], []
+
+    class Window:
+        def should_close(self):
+            return False
+
+        def show_async(self, img):
+            shown.append(img)
+
+    with DepthReprojectionProcessor(params, window=Window()) as proc:
+        orig = proc._pipe.process_ev_frame
+
+        def spy(evs):
+            cut.append(evs.copy())
+            orig(evs)
+
+        proc._pipe.trigger_finder.frame_callback = spy
+        packet = int(1e6 / 60 / 4)
+        edges = np.arange(stream["t"][0], stream["t"][-1] + packet, packet)
+        cuts = np.searchsorted(stream["t"], edges)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            proc.process_events(stream[a:b])
+        assert proc.stats_printer.counters["processed evs"] == len(stream)
+    assert len(cut) == len(shown) >= 30
+    t_prev = -1
+    for evs, img in zip(cut, shown):
+        assert (evs["p"] == 1).all() and len(evs) > 100_000 and evs["t"][0] > t_prev
+        t_prev = evs["t"][-1]
+        x, y, t, _ = S.to_soa(evs)
+        ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t)
+        assert img.shape == (1920, 1080, 3) and np.array_equal(img, ref["bgr"])
+    # no two shown frames are the same array / the same picture (fresh array per frame, scene offset changes)
+    assert len({id(i) for i in shown}) == len(shown)

@@ -137,7 +137,13 @@ def test_golden_frame_stages(golden_dir):
         bgr = eng.colorize_depth_from_disp(g["disp"])
     u8 = O.clip_normalize_uint8_depth_frame(g["depth"], 0.1, 1.2)
     assert np.array_equal(bgr, O.generate_color_map(u8))
-    assert ((bgr == 255).all(-1) == (g["u8"] == 0)).all() or np.abs(u8.astype(int) - g["u8"].astype(int)).max() <= 1
+    # A6/A7 against the reference's own output (golden G2), two hard assertions:
+    # (1) the white mask (apply_white_mask, d2d:39-43) is where the reference's u8 frame is 0 -- exactly
+    assert np.array_equal((bgr == 255).all(-1), g["u8"] == 0)
+    # (2) u8 itself: the stub run multiplies `* 255` in f32 (NumPy 2), Numba types it as f64 -- at most 1 LSB apart, and
+    #     only on a handful of pixels (on this fixture: none)
+    du8 = np.abs(u8.astype(int) - g["u8"].astype(int))
+    assert du8.max() <= 1 and (du8 != 0).sum() <= max(1, u8.size // 100)
     tb["p03"] = float(g["p03_neg"])
     with XMapsEngine(tb) as eng:
         assert np.array_equal(eng.disparity_to_depth(g["disp"]), g["depth_neg"])

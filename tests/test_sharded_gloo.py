@@ -1,5 +1,5 @@
-"""CPU, world_size 2, gloo: the sharding protocol (index partition, (tmin,-tmax) MIN-reduce, packed-key MAX
-all-reduce, finish) reproduces the single-process frame exactly.  Compute provider = the oracle (tests only)."""
+"""CPU, world_size 2, gloo: the sharding protocol (index partition, MIN all-reduce of the {tmin, -tmax} buffer, packed-key
+MAX all-reduce, finish) reproduces the single-process frame exactly.  Compute provider = the oracle (tests only)."""
 import os
 import socket
 import sys
@@ -27,18 +27,23 @@ class OracleShardProvider:
     def clear_key_frame(self, kf):
         kf.zero_()
 
-    def minmax(self, shard):
+    def new_minmax_buffer(self, shard):
+        return torch.zeros(2, dtype=torch.int64 if np.issubdtype(shard[2].dtype, np.integer) else torch.float64)
+
+    def minmax_into(self, shard, mm):
         t = shard[2]
-        if len(t) == 0:
-            i = np.iinfo(np.int64)
-            return np.int64(i.max), np.int64(i.min)
-        return t.min(), t.max()
+        if len(t) == 0:  # neutral element of MIN for both entries, like xm_shard_minmax_device
+            big = np.iinfo(np.int64).max if mm.dtype == torch.int64 else np.inf
+            mm[0], mm[1] = big, big
+        else:
+            mm[0], mm[1] = t.min().item(), -t.max().item()
 
     def scatter(self, shard, idx_offset, mm, tag, key_frame):
         x, y, t, _ = shard
         if len(t) == 0:
             return
-        kf = self.O.key_frame(self.tb, x.astype(np.int64), y.astype(np.int64), t, mm[0], mm[1], idx_offset=idx_offset,
+        lo, hi = t.dtype.type(mm[0].item()), t.dtype.type(-mm[1].item())
+        kf = self.O.key_frame(self.tb, x.astype(np.int64), y.astype(np.int64), t, lo, hi, idx_offset=idx_offset,
                               tag=tag, camera_perspective=self.camera)
         torch.maximum(key_frame, torch.from_numpy(kf.astype(np.int64)), out=key_frame)
 

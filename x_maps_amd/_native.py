@@ -24,6 +24,7 @@ XM_FLAG_TIME_SORTED = 1
 XM_FLAG_TRY_SORTED = 2
 XM_FLAG_DEFAULT_STREAMS = 4
 XM_FLAG_LAUNCH_WORKERS = 8
+XM_FLAG_GENERAL = 16
 XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
 XM_MEM_HOST, XM_MEM_DEVICE, XM_MEM_HOST_PINNED = 0, 1, 2
 XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2
@@ -103,6 +104,7 @@ SYMBOLS = {
     "xm_last_frame_stats": (C.c_int, [_P, C.POINTER(xm_frame_stats)]),
     "xm_profile_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_profile_event_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "xm_process_batch": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P]),
     "xm_graph_create": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P, C.POINTER(_P)]),
     "xm_graph_launch": (C.c_int, [_P]),
     "xm_graph_destroy": (None, [_P]),
@@ -117,6 +119,8 @@ SYMBOLS = {
     "xm_stage_disparity_to_depth": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "xm_stage_colorize_depth_from_disp": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "xm_shard_minmax": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "xm_shard_minmax_device": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "xm_shard_scatter_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_uint64, _P, C.c_uint32, _P]),
     "xm_shard_clear": (C.c_int, [_P, _P]),
     "xm_shard_scatter": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_uint64, _P, C.c_uint32, _P]),
     "xm_shard_finish": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),

@@ -104,6 +104,11 @@ struct Slot {
   bool any_frame = false;
   bool last_sorted = false;
   uint64_t last_n = 0;
+  int last_t_dtype = XM_T_INT64;  // how xm_last_frame_stats decodes t_min / t_max
+  // the slot's last frame ran inside a multi-frame launch on ANOTHER stream: work on the slot's own stream waits for this
+  hipEvent_t pending_batch_ev = nullptr;
+  hipStream_t pending_batch_stream = nullptr;
+  bool eager_dirty = false;  // eager work was enqueued on the slot's own stream since the last synchronisation point
   // staging for XM_MEM_HOST calls
   DevBuf ev_x, ev_y, ev_t, ev_p, ev_aos, out_depth, out_bgr, dbg[5];
 };
@@ -175,6 +180,25 @@ struct xm_handle {
   bool capturing = false;     // inside xm_graph_create's stream capture (no host-side redo possible there)
   uint64_t sorted_fallbacks = 0;
   std::vector<hipEvent_t> join_ev;
+  // multi-frame launches (xm_process_batch, batched hipGraphs, ingest): frame descriptors.  Eager batches stage them
+  // through a ring of pinned host entries -> device entries (one memcpy per batch, stream-ordered before its kernels).
+  static constexpr int DESC_RING = 16;
+  FrameDesc* h_descs = nullptr;   // pinned  [DESC_RING][n_slots]
+  FrameDesc* d_descs = nullptr;   // device  [DESC_RING][n_slots]
+  hipEvent_t desc_ev[DESC_RING] = {};  // recorded after the ring entry's upload: the entry may be rewritten once it fired
+  bool desc_used[DESC_RING] = {};
+  int desc_next = 0;
+  uint64_t batch_counter = 0;
+  // an event per (stream, ring entry) recorded at the end of a batch: eager work on a slot's own stream waits for it
+  std::vector<std::vector<hipEvent_t>> batch_ev;  // [distinct stream][8]
+  std::vector<hipStream_t> streams;               // distinct slot streams
+  std::vector<int> batch_ev_next;
+  hipEvent_t graph_ev[8] = {};  // end-of-replay events (ring), recorded on the graphs' origin stream
+  unsigned graph_ev_next = 0;
+  // dynamic-LDS caps already raised on this handle's device, per kernel function (launch workers call concurrently)
+  std::mutex lds_mu;
+  std::vector<std::pair<const void*, size_t>> lds_caps;
+  int ensure_lds(const void* fn, size_t bytes);
 };
 
 struct xm_graph {
@@ -183,7 +207,23 @@ struct xm_graph {
   hipGraphExec_t exec = nullptr;
   std::vector<u32> frames_on_slot;
   int n_frames = 0;
+  std::vector<FrameDesc> h_descs;  // batched capture: the frames' descriptors (static for the graph's lifetime)
+  FrameDesc* d_descs = nullptr;
 };
+
+int xm_handle::ensure_lds(const void* fn, size_t bytes) {
+  std::lock_guard<std::mutex> lk(lds_mu);
+  for (auto& e : lds_caps)
+    if (e.first == fn) {
+      if (bytes <= e.second) return XM_OK;
+      HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      e.second = bytes;
+      return XM_OK;
+    }
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  lds_caps.emplace_back(fn, bytes);
+  return XM_OK;
+}
 
 namespace {
 
@@ -212,12 +252,14 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 
 size_t t_size(int t_dtype) { return t_dtype == XM_T_FLOAT32 ? 4 : 8; }
 
-int reset_slot(xm_handle* h, Slot& s) {
-  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
+int reset_slot(xm_handle* h, Slot& s, hipStream_t stream = nullptr) {
+  if (!stream) stream = s.stream;
+  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
   HIP_TRY(hipGetLastError());
   s.host_tag = 0;
+  s.api_tag = 0;
   if (s.h_flags) {  // tags start over: forget the verdicts of the old numbering (no frame of this slot is pending here)
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     s.h_flags[0] = s.h_flags[1] = 0;
   }
   return XM_OK;
@@ -267,12 +309,14 @@ void launch_minmax(const EventsView& ev, SlotState* st, u32 tag_override, hipStr
 }
 
 struct ScatterArgs {
+  xm_handle* h;
   const EventsView* ev;
   const DevTables* tb;
   int view;
   SlotState* st;
   u32 tag_override;
   u64 idx_offset, mm_lo, mm_hi;
+  const void* mm_ext;  // sharded mode: {tmin, -tmax} in device memory (NULL: mm_lo / mm_hi)
   u64* frame;
   unsigned char* dirty;
   hipStream_t stream;
@@ -302,12 +346,10 @@ int launch_scatter_tv(const ScatterArgs& a) {
     if constexpr (kHasVec) {
       if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, true>;
     }
-    static size_t lds_set[2] = {0, 0};  // per kernel: raise the dynamic-LDS cap once (gfx950: 160 KB / CU)
-    size_t& set = lds_set[kHasVec && vec16 ? 1 : 0];
-    if (a.lds > set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)a.lds));
-      set = a.lds;
+    // raise the kernel's dynamic-LDS cap once per (handle = device, kernel instantiation); gfx950: 160 KB / CU
+    {
+      int rc_lds = a.h->ensure_lds(reinterpret_cast<const void*>(kern), a.lds);
+      if (rc_lds) return rc_lds;
     }
     unsigned threads = TILE_THREADS;
     while (threads > 1024 / TILE_EPT && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;  // smallest block: 1024 events
@@ -315,21 +357,21 @@ int launch_scatter_tv(const ScatterArgs& a) {
     if (force_threads >= 64 && force_threads <= TILE_THREADS && (force_threads & (force_threads - 1)) == 0) threads = force_threads;
     XM_LAUNCH(kern, dim3(grid_for(n, threads * TILE_EPT)), dim3(threads), a.lds, a.stream, ev.x, ev.y,
               (const T*)ev.t, ev.p, (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-              a.mm_lo, a.mm_hi, a.frame, a.dirty, a.w_ts, a.w_x, a.sorted ? 1 : 0);
+              a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty, a.w_ts, a.w_x, a.sorted ? 1 : 0);
     return XM_OK;
   }
   if constexpr (AOS) {
     XM_LAUNCH((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream,
               (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const T*)nullptr, (const int16_t*)nullptr,
-              (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override, a.mm_lo, a.mm_hi, a.frame, a.dirty);
+              (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override, a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty);
   } else if (vec) {
     XM_LAUNCH((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, a.stream,
               ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st,
-              a.tag_override, a.mm_lo, a.mm_hi, a.frame, a.dirty);
+              a.tag_override, a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty);
   } else {
     XM_LAUNCH((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream, ev.x,
               ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-              a.mm_lo, a.mm_hi, a.frame, a.dirty);
+              a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty);
   }
   return XM_OK;
 }
@@ -340,8 +382,9 @@ int launch_scatter_t(const ScatterArgs& a) {
 }
 
 int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_override, u64 idx_offset, u64 mm_lo,
-                   u64 mm_hi, u64* frame, unsigned char* dirty, hipStream_t stream, bool sorted = false) {
-  ScatterArgs a{&ev, &h->tb, h->cfg.view, st, tag_override, idx_offset, mm_lo, mm_hi, frame, dirty, stream,
+                   u64 mm_hi, u64* frame, unsigned char* dirty, hipStream_t stream, bool sorted = false,
+                   const void* mm_ext = nullptr) {
+  ScatterArgs a{h, &ev, &h->tb, h->cfg.view, st, tag_override, idx_offset, mm_lo, mm_hi, mm_ext, frame, dirty, stream,
                 h->w_ts, h->w_x, h->k1_lds, h->k1_direct, sorted};
   if (ev.aos) return ev.use_p ? launch_scatter_t<long long, true, true>(a) : launch_scatter_t<long long, true, false>(a);
   switch (ev.t_dtype) {
@@ -393,10 +436,15 @@ bool sorted_path(const xm_handle* h, const EventsView& ev) {
 }
 
 int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,
-                  bool allow_sorted = true) {
+                  bool allow_sorted = true, hipStream_t stream_override = nullptr) {
   const bool sorted = allow_sorted && sorted_path(h, ev);
+  hipStream_t stream = stream_override ? stream_override : s.stream;
+  if (s.pending_batch_ev) {  // the slot's previous frame ran inside a multi-frame launch, maybe on another stream
+    if (s.pending_batch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s.pending_batch_ev, 0));
+    s.pending_batch_ev = nullptr;
+  }
   if (s.host_tag >= KEY_MAX_TAG) {  // tag field about to wrap: clear the frame once per 2^19 frames
-    int rc = reset_slot(h, s);
+    int rc = reset_slot(h, s, stream);
     if (rc) return rc;
   }
 #ifdef XM_ABLATE
@@ -406,23 +454,160 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 #endif
   // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the three dispatch packets
   if (prof) g_prof = ProfCtx{prof[0], prof[1]};
-  if (!(skip & 1) && !sorted) launch_minmax(ev, s.st, 0, s.stream);
+  if (!(skip & 1) && !sorted) launch_minmax(ev, s.st, 0, stream);
   if (prof) g_prof = ProfCtx{prof[2], prof[3]};
   if (!(skip & 2)) {
-    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.dirty, s.stream, sorted);
+    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.dirty, stream, sorted);
     if (rc) {
       g_prof = ProfCtx{};
       return rc;
     }
   }
   if (prof) g_prof = ProfCtx{prof[4], prof[5]};
-  if (!(skip & 4)) launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, s.stream, h->k2_flags ? s.dirty : nullptr);
+  if (!(skip & 4)) launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, stream, h->k2_flags ? s.dirty : nullptr);
   g_prof = ProfCtx{};
   HIP_TRY(hipGetLastError());
   s.host_tag += 1;
   s.any_frame = true;
   s.last_n = ev.n;
   s.last_sorted = sorted;
+  s.last_t_dtype = ev.aos ? XM_T_INT64 : ev.t_dtype;
+  if (!stream_override) s.eager_dirty = true;
+  return XM_OK;
+}
+
+// ---- multi-frame launches -------------------------------------------------------------------------------------------
+// One K0 / K1 / K2 launch each for a whole group of frames (grid = frames x tiles).  Frame f of the group runs on slot
+// slots[f] (its own key frame + state), all on ONE stream.  A single frame's launches leave the chip half empty while
+// they ramp up and drain (245 K1 blocks for 256 CUs, each a ~10 us dependent chain); a group's launch keeps every CU fed.
+template <typename T, bool AOS, bool HAS_P>
+int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
+                   hipStream_t stream) {
+  // K0: grid = (blocks of the largest frame, frames)
+  if (!sorted) {
+    const bool vec2 = !AOS && std::is_same<T, long long>::value && vec16;
+    const unsigned per_block = BLOCK * (vec2 ? 2 * K0_UN : 4);
+    unsigned gx = grid_for(n_max, per_block);
+    if (gx > 1024) gx = 1024;
+    if constexpr (std::is_same<T, long long>::value && !AOS) {
+      if (vec2) XM_LAUNCH((k_minmax_batch<T, false, HAS_P, 2>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs);
+      else XM_LAUNCH((k_minmax_batch<T, false, HAS_P, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs);
+    } else {
+      XM_LAUNCH((k_minmax_batch<T, AOS, HAS_P, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs);
+    }
+  }
+  // K1: block size from the mean frame (see launch_scatter_tv); a sparser frame of the group only sends more of its events
+  // down the direct path inside the kernel
+  const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)n_mean / (double)h->tb.xmap_w : 0.0;
+  unsigned threads = TILE_THREADS;
+  while (threads > 1024 / TILE_EPT && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;
+  const unsigned gx1 = grid_for(n_max, threads * TILE_EPT);
+  constexpr bool kHasVec = !AOS && std::is_same<T, long long>::value;
+  auto launch_k1 = [&](auto view_tag) -> int {
+    constexpr int VIEW = decltype(view_tag)::value;
+    auto kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, false>;
+    if constexpr (kHasVec) {
+      if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, true>;
+    }
+    int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), h->k1_lds);
+    if (rc) return rc;
+    XM_LAUNCH(kern, dim3(gx1, n_frames), dim3(threads), h->k1_lds, stream, d_descs, h->tb, h->w_ts, h->w_x, sorted ? 1 : 0);
+    return XM_OK;
+  };
+  int rc = h->cfg.view == XM_VIEW_PROJECTOR ? launch_k1(std::integral_constant<int, 0>{}) : launch_k1(std::integral_constant<int, 1>{});
+  if (rc) return rc;
+  // K2
+  if (h->cfg.view == XM_VIEW_PROJECTOR) {
+    XM_LAUNCH(k_frame_proj_tiled_batch, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+              (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+  } else {
+    const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
+    XM_LAUNCH(k_frame_direct_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
+  }
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// can this group of frames go through the multi-frame kernels?  (dense enough for the tiled K1, tiled K2 available)
+bool batch_path(const xm_handle* h, u64 n_mean) {
+  const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)n_mean / (double)h->tb.xmap_w : 0.0;
+  return !h->k1_direct && h->w_ts > 0 && h->w_x > 0 && max_ev >= 1024.0 && !(h->cfg.view == XM_VIEW_PROJECTOR && h->k2_direct) &&
+         !h->k2_flags;
+}
+
+// Enqueue one group: frame f = evs[f] on slot slot_idx[f], outputs depth[f] / bgr[f] (device pointers), everything on `stream`.
+// d_descs / h_descs: where the group's descriptors live (the caller owns their lifetime).  `upload`: copy them now
+// (eager) -- false when the caller uploads once (graph capture).
+int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, float* const* depth, uint8_t* const* bgr,
+                  int n_frames, hipStream_t stream, FrameDesc* h_descs, FrameDesc* d_descs, bool upload, bool allow_sorted) {
+  u64 n_max = 0, n_sum = 0;
+  bool vec16 = true;
+  for (int f = 0; f < n_frames; ++f) {
+    const EventsView& ev = evs[f];
+    n_max = std::max<u64>(n_max, ev.n);
+    n_sum += ev.n;
+    if (!ev.aos) vec16 = vec16 && aligned(ev.x, 16) && aligned(ev.y, 16) && aligned(ev.t, 16) && (!ev.use_p || aligned(ev.p, 16));
+  }
+  const u64 n_mean = n_frames ? n_sum / (u64)n_frames : 0;
+  const EventsView& e0 = evs[0];
+  bool sorted = allow_sorted && n_frames > 0;
+  for (int f = 0; f < n_frames && sorted; ++f) sorted = evs[f].n > 0 && sorted_path(h, evs[f]);
+  for (int f = 0; f < n_frames; ++f) {  // order the group after whatever its slots did last on other streams
+    Slot& s = h->slots[slot_idx[f]];
+    if (s.pending_batch_ev) {
+      if (s.pending_batch_stream != stream && !h->capturing) HIP_TRY(hipStreamWaitEvent(stream, s.pending_batch_ev, 0));
+      s.pending_batch_ev = nullptr;
+    }
+    if (s.eager_dirty && !h->capturing) {
+      if (s.stream != stream) {
+        HIP_TRY(hipEventRecord(h->join_ev[slot_idx[f]], s.stream));
+        HIP_TRY(hipStreamWaitEvent(stream, h->join_ev[slot_idx[f]], 0));
+      }
+      s.eager_dirty = false;
+    }
+  }
+  if (!batch_path(h, n_mean)) {  // sparse frames / untiled kernels: frame by frame, still on the group's stream
+    for (int f = 0; f < n_frames; ++f) {
+      int rc = enqueue_frame(h, h->slots[slot_idx[f]], evs[f], depth[f], bgr[f], nullptr, allow_sorted, stream);
+      if (rc) return rc;
+      h->slots[slot_idx[f]].api_tag = h->slots[slot_idx[f]].host_tag;
+    }
+    return XM_OK;
+  }
+  for (int f = 0; f < n_frames; ++f) {
+    Slot& s = h->slots[slot_idx[f]];
+    if (s.host_tag >= KEY_MAX_TAG && !h->capturing) {
+      int rc = reset_slot(h, s, stream);
+      if (rc) return rc;
+    }
+    FrameDesc& d = h_descs[f];
+    const EventsView& ev = evs[f];
+    d.x = ev.x; d.y = ev.y; d.t = ev.t; d.p = ev.use_p ? ev.p : nullptr; d.aos = (const uint4*)ev.aos;
+    d.n = ev.n; d.key_frame = s.key_frame; d.st = s.st; d.depth = depth[f]; d.bgr = bgr[f]; d.valid = 1; d.pad = 0;
+  }
+  if (upload) HIP_TRY(hipMemcpyAsync(d_descs, h_descs, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, stream));
+  int rc;
+  if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream)
+                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream);
+  else switch (e0.t_dtype) {
+    case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream)
+                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream); break;
+    case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream)
+                                     : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream); break;
+    default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream)
+                           : launch_batch_t<double, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream);
+  }
+  if (rc) return rc;
+  for (int f = 0; f < n_frames; ++f) {
+    Slot& s = h->slots[slot_idx[f]];
+    s.host_tag += 1;
+    s.api_tag = s.host_tag;
+    s.any_frame = true;
+    s.last_n = evs[f].n;
+    s.last_sorted = sorted;
+    s.last_t_dtype = evs[f].aos ? XM_T_INT64 : evs[f].t_dtype;
+  }
   return XM_OK;
 }
 
@@ -553,6 +738,12 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   if (!s.prev.valid) return XM_OK;
   s.prev.valid = false;
   const u32 tag = s.prev.tag;
+  // launch workers: the frame may be posted but not launched yet -- an empty stream also answers hipSuccess to the query
+  // below, which would read as "shortcut held".  Wait until the worker has issued everything posted so far.
+  if (s.worker >= 0) {
+    const int rcw = drain_workers(h, s.worker);
+    if (rcw) return rcw;
+  }
   // still in flight?  Wait for K2's start marker by polling the pinned word: a blocking stream synchronisation costs a
   // ~200 us wake-up, per frame, whenever the host runs ahead of the GPU (few slots); the marker is a few us away.
   if (__atomic_load_n(&s.h_flags[1], __ATOMIC_ACQUIRE) != tag) {
@@ -788,7 +979,10 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
   h->cfg.n_slots = n_slots;
   h->time_sorted = (cfg->flags & XM_FLAG_TIME_SORTED) != 0;
-  h->try_sorted = (cfg->flags & XM_FLAG_TRY_SORTED) != 0 && !h->time_sorted;
+  // default: the verified (t[0], t[n-1]) shortcut with automatic redo (exact for any event order); XM_FLAG_GENERAL forces the
+  // extrema pass on every frame; XM_GENERAL=1 in the environment does the same (experiments)
+  const char* eg = getenv("XM_GENERAL");
+  h->try_sorted = !h->time_sorted && !(cfg->flags & XM_FLAG_GENERAL) && !(eg && eg[0] == '1');
   if (const char* e = getenv("XM_GATE_SLOTS")) h->gate_slots = e[0] != '0';
   h->cfg.xmap_height = xmap_h;
 
@@ -899,9 +1093,14 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     auto need = [&](int wt, int wx) {
       // must mirror the carve-up at the top of k_scatter_tiled (uint4 units, +1 uint4 of alignment slack per band)
       const size_t win_words = cfg->view == XM_VIEW_PROJECTOR ? (size_t)wt * xmap_h : (size_t)wx * cfg->cam_height;
-      const size_t win_q = (win_words + 3) / 4, lut_q = ((size_t)wx * cfg->cam_height + 3) / 4 + 1,
-                   xm_q = ((size_t)wt * xmap_h + 7) / 8 + 1;
-      return 16 * (std::max(win_q, lut_q) + xm_q + 1);  // slots and LUT band share a region; +1: dummy slot for the branch-free band loads
+#ifndef XM_NO_LDS_DMA
+      constexpr size_t slack = 64;  // LDS-direct band loads write whole waves: one wave of slack behind each band
+#else
+      constexpr size_t slack = 0;
+#endif
+      const size_t win_q = (win_words + 3) / 4, lut_q = ((size_t)wx * cfg->cam_height + 3) / 4 + 1 + slack,
+                   xm_q = ((size_t)wt * xmap_h + 7) / 8 + 1 + slack;
+      return 16 * (std::max(win_q, lut_q) + xm_q + 1 + slack);  // slots and LUT band share a region; +1 (+ a wave): dump area of the band loads
     };
     while (need(w_ts, w_x) > budget && (w_ts > 1 || w_x > 1)) {
       if (w_ts * xmap_h * 6 >= w_x * cfg->cam_height * 4 && w_ts > 1) w_ts -= 1;
@@ -977,6 +1176,23 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->join_ev.resize(n_slots, nullptr);
   for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming));
   for (int i = 0; i < n_slots; ++i) XM_TRY_CREATE(hipStreamSynchronize(h->slots[i].stream));
+  {  // multi-frame launches: distinct slot streams, their end-of-batch events, the descriptor ring
+    for (int i = 0; i < n_slots; ++i) {
+      bool seen = false;
+      for (hipStream_t st : h->streams) seen = seen || st == h->slots[i].stream;
+      if (!seen) h->streams.push_back(h->slots[i].stream);
+    }
+    h->batch_ev.resize(h->streams.size());
+    h->batch_ev_next.assign(h->streams.size(), 0);
+    for (auto& ring : h->batch_ev) {
+      ring.assign(8, nullptr);
+      for (auto& e : ring) XM_TRY_CREATE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    XM_TRY_CREATE(hipHostMalloc((void**)&h->h_descs, sizeof(FrameDesc) * xm_handle::DESC_RING * n_slots, hipHostMallocDefault));
+    XM_TRY_CREATE(hipMalloc((void**)&h->d_descs, sizeof(FrameDesc) * xm_handle::DESC_RING * n_slots));
+    for (auto& e : h->desc_ev) XM_TRY_CREATE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : h->graph_ev) XM_TRY_CREATE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   {  // launch workers: one per distinct slot stream (XM_FLAG_LAUNCH_WORKERS; off: launches stay in the calling thread)
     const char* we = getenv("XM_WORKERS");  // overrides the flag either way
     const bool want = we ? we[0] != '0' : (cfg->flags & XM_FLAG_LAUNCH_WORKERS) != 0;
@@ -1013,6 +1229,7 @@ void xm_destroy(xm_handle* h) {
   for (auto& w : h->workers)
     if (w->th.joinable()) w->th.join();
   h->workers.clear();
+  for (auto gs : h->gstreams) if (gs) (void)hipStreamSynchronize(gs);
   for (Slot& s : h->slots) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     s.ev_x.release(); s.ev_y.release(); s.ev_t.release(); s.ev_p.release(); s.ev_aos.release();
@@ -1023,6 +1240,12 @@ void xm_destroy(xm_handle* h) {
     if (s.stream && s.owns_stream) (void)hipStreamDestroy(s.stream);
     if (s.h_flags) (void)hipHostFree(s.h_flags);
   }
+  for (auto& ring : h->batch_ev)
+    for (auto& e : ring) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->desc_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->graph_ev) if (e) (void)hipEventDestroy(e);
+  if (h->h_descs) (void)hipHostFree(h->h_descs);
+  if (h->d_descs) (void)hipFree(h->d_descs);
   for (auto gs : h->gstreams) if (gs) (void)hipStreamDestroy(gs);
   for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
@@ -1049,6 +1272,11 @@ int xm_sync(xm_handle* h) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
   XM_ENTER(h);
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  for (hipStream_t gs : h->gstreams) HIP_TRY(hipStreamSynchronize(gs));  // graph replays run on streams of their own
+  for (Slot& s : h->slots) {  // every stream is idle: nothing left to order against
+    s.pending_batch_ev = nullptr;
+    s.eager_dirty = false;
+  }
   if (h->try_sorted || h->gate_slots) {  // frames whose shortcut failed are redone now, then waited for
     for (Slot& s : h->slots) {
       bool redone = false;
@@ -1062,12 +1290,13 @@ int xm_sync(xm_handle* h) {
   }
   if (h->time_sorted) {  // any asynchronously processed frame that was not sorted after all?
     u32 bad = 0;
-    for (Slot& s : h->slots) {
-      u32 v = 0;
-      HIP_TRY(hipMemcpy(&v, &s.st->unsorted_sticky, sizeof v, hipMemcpyDeviceToHost));
-      if (v) {
-        bad += v;
-        HIP_TRY(hipMemset(&s.st->unsorted_sticky, 0, sizeof v));
+    // one copy of all slot states (3 KB each) instead of one synchronous 4-byte copy per slot (60 slots: 0.9 ms)
+    std::vector<SlotState> hs(h->slots.size());
+    HIP_TRY(hipMemcpy(hs.data(), h->d_states, sizeof(SlotState) * hs.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < hs.size(); ++i) {
+      if (hs[i].unsorted_sticky) {
+        bad += hs[i].unsorted_sticky;
+        HIP_TRY(hipMemset(&h->slots[i].st->unsorted_sticky, 0, sizeof(u32)));
       }
     }
     if (bad) return fail(XM_ERR_UNSORTED, "XM_FLAG_TIME_SORTED: %u wavefront(s) saw events outside [t[0], t[n-1]] -- a frame "
@@ -1132,8 +1361,12 @@ int xm_last_frame_stats(xm_handle* h, xm_frame_stats* stats) {
   if (!h || !stats) return fail(XM_ERR_INVALID, "NULL argument");
   XM_ENTER(h);
   Slot& s = h->slots[h->last_slot];
+  if (s.pending_batch_ev) {  // the slot's last frame ran inside a multi-frame launch / graph replay on another stream
+    HIP_TRY(hipEventSynchronize(s.pending_batch_ev));
+    s.pending_batch_ev = nullptr;
+  }
   HIP_TRY(hipStreamSynchronize(s.stream));
-  return fetch_stats(h, s, XM_T_INT64, stats);
+  return fetch_stats(h, s, s.last_t_dtype, stats);
 }
 
 int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
@@ -1154,7 +1387,138 @@ int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
   return XM_OK;
 }
 
+// ---- a group of frames in one set of multi-frame launches ---------------------------------------------------
+int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out) {
+  if (!h || !offsets_host || n_frames <= 0) return fail(XM_ERR_INVALID, "bad argument");
+  const int ns = (int)h->slots.size();
+  if (n_frames > ns) return fail(XM_ERR_INVALID, "a batch of %d frames needs n_slots >= %d (handle has %d)", n_frames, n_frames, ns);
+  XM_ENTER(h);
+  const size_t px = (size_t)h->out_w * h->out_h;
+  const size_t tsz = t_size(t_dtype);
+  std::vector<int> idx(n_frames);
+  std::vector<EventsView> evs(n_frames);
+  std::vector<float*> dep(n_frames);
+  std::vector<uint8_t*> bg(n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    const u64 a = offsets_host[f], b = offsets_host[f + 1];
+    if (b < a) return fail(XM_ERR_INVALID, "offsets must be non-decreasing");
+    EventsView& ev = evs[f];
+    ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
+    ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+    int rc = check_events(ev);
+    if (rc) return rc;
+    dep[f] = depth_out ? depth_out + f * px : nullptr;
+    bg[f] = bgr_out ? bgr_out + f * px * 3 : nullptr;
+  }
+  for (int f = 0; f < n_frames; ++f) {
+    idx[f] = (h->next_slot + f) % ns;
+    int rc = resolve_prev(h, h->slots[idx[f]]);  // try-sorted verdict of the slot's previous frame (may redo it)
+    if (rc) return rc;
+  }
+  h->next_slot = (h->next_slot + n_frames) % ns;
+  h->last_slot = idx[n_frames - 1];
+  // the group's stream: groups rotate over the distinct slot streams, so that the tail of one group's launches overlaps
+  // the head of the next group's (whose slots are different ones)
+  const int si = (int)(h->batch_counter++ % h->streams.size());
+  hipStream_t stream = h->streams[si];
+  const int k = h->desc_next;
+  h->desc_next = (k + 1) % xm_handle::DESC_RING;
+  if (h->desc_used[k]) HIP_TRY(hipEventSynchronize(h->desc_ev[k]));  // the ring entry's previous batch has long finished
+  FrameDesc* hd = h->h_descs + (size_t)k * ns;
+  FrameDesc* dd = h->d_descs + (size_t)k * ns;
+  int rc = enqueue_batch(h, idx.data(), evs.data(), dep.data(), bg.data(), n_frames, stream, hd, dd, true, true);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->desc_ev[k], stream));
+  h->desc_used[k] = true;
+  hipEvent_t done = h->batch_ev[si][h->batch_ev_next[si]++ % 8];
+  HIP_TRY(hipEventRecord(done, stream));
+  for (int f = 0; f < n_frames; ++f) {
+    Slot& s = h->slots[idx[f]];
+    s.pending_batch_ev = done;
+    s.pending_batch_stream = stream;
+    if (s.h_flags) {  // slot gate + try-sorted verdict, read when the slot comes round again or in xm_sync
+      s.prev.valid = true;
+      s.prev.check = h->try_sorted && s.last_sorted;
+      s.prev.ev = evs[f];
+      s.prev.depth = dep[f];
+      s.prev.bgr = bg[f];
+      s.prev.host_depth = nullptr;
+      s.prev.host_bgr = nullptr;
+      s.prev.tag = s.host_tag;
+    }
+  }
+  return XM_OK;
+}
+
 // ---- hipGraph batch ------------------------------------------------------------------------------------
+// Default: the frames are captured as GROUPS of multi-frame launches (3 kernel nodes per group instead of 3 per frame).
+// With n_slots >= n_frames the whole batch is one group; otherwise groups of n_slots / 2 frames alternate between two
+// capture streams (each half of the slots always on the same branch), so that one group's tail overlaps the next one's head.
+// XM_GRAPH_PER_FRAME=1 (experiments) keeps the round-1 form: three nodes per frame, frames forked over the slots' streams.
+static int graph_capture_batched(xm_handle* h, xm_graph* g, const uint16_t* x, const uint16_t* y, const void* t,
+                                 const int16_t* p, int t_dtype, const uint64_t* offsets_host, int n_frames,
+                                 float* depth_out, uint8_t* bgr_out) {
+  const int ns = (int)h->slots.size();
+  const size_t px = (size_t)h->out_w * h->out_h;
+  const size_t tsz = t_size(t_dtype);
+  const bool two = ns >= 2 && n_frames > ns;
+  const int G = two ? ns / 2 : std::min(ns, n_frames);
+  g->h_descs.resize(n_frames);
+  HIP_TRY(hipMalloc((void**)&g->d_descs, sizeof(FrameDesc) * n_frames));
+  hipStream_t origin = h->gstreams[0], second = two ? h->gstreams[1] : nullptr;
+  int rc = XM_OK;
+  hipError_t e = hipSuccess;
+  h->capturing = true;
+  e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    h->capturing = false;
+    return fail(XM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  }
+  do {
+    if (two) {
+      if ((e = hipEventRecord(h->fork_ev, origin)) != hipSuccess) break;
+      if ((e = hipStreamWaitEvent(second, h->fork_ev, 0)) != hipSuccess) break;
+    }
+    int gi = 0;
+    for (int f0 = 0; f0 < n_frames && rc == XM_OK; f0 += G, ++gi) {
+      const int nf = std::min(G, n_frames - f0);
+      const int half = two ? gi & 1 : 0;
+      std::vector<int> idx(nf);
+      std::vector<EventsView> evs(nf);
+      std::vector<float*> dep(nf);
+      std::vector<uint8_t*> bg(nf);
+      for (int j = 0; j < nf; ++j) {
+        const int f = f0 + j;
+        const u64 a = offsets_host[f], b = offsets_host[f + 1];
+        EventsView& ev = evs[j];
+        ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
+        ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+        if ((rc = check_events(ev))) break;
+        idx[j] = half * G + j;
+        dep[j] = depth_out ? depth_out + f * px : nullptr;
+        bg[j] = bgr_out ? bgr_out + f * px * 3 : nullptr;
+        h->slots[idx[j]].host_tag = 0;  // tags advance on the device inside a graph; no reset mid-capture
+        g->frames_on_slot[idx[j]] += 1;
+      }
+      if (rc) break;
+      rc = enqueue_batch(h, idx.data(), evs.data(), dep.data(), bg.data(), nf, half ? second : origin,
+                         g->h_descs.data() + f0, g->d_descs + f0, false, true);
+    }
+    if (two && rc == XM_OK) {
+      if ((e = hipEventRecord(h->join_ev[1], second)) != hipSuccess) break;
+      if ((e = hipStreamWaitEvent(origin, h->join_ev[1], 0)) != hipSuccess) break;
+    }
+  } while (0);
+  hipError_t e2 = hipStreamEndCapture(origin, &g->graph);
+  h->capturing = false;
+  if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
+    rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  if (rc == XM_OK)  // the descriptors are static: one upload for the graph's lifetime
+    HIP_TRY(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
+  return rc;
+}
+
 int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, xm_graph** out) {
   if (!h || !out || !offsets_host || n_frames <= 0) return fail(XM_ERR_INVALID, "bad argument");
@@ -1163,6 +1527,10 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
   const int ns = (int)h->slots.size();
   if ((u64)n_frames / ns + 1 >= KEY_MAX_TAG) return fail(XM_ERR_INVALID, "too many frames per graph");
   for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+  for (Slot& s : h->slots) {  // idle: nothing to order the capture against
+    s.pending_batch_ev = nullptr;
+    s.eager_dirty = false;
+  }
   xm_graph* g = new (std::nothrow) xm_graph();
   if (!g) return fail(XM_ERR_NOMEM, "out of host memory");
   g->h = h;
@@ -1170,66 +1538,86 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
   g->frames_on_slot.assign(ns, 0);
   const size_t px = (size_t)h->out_w * h->out_h;
   const size_t tsz = t_size(t_dtype);
-  std::vector<u32> saved(ns);
-  for (int i = 0; i < ns; ++i) saved[i] = h->slots[i].host_tag;
+  struct Saved {
+    u32 host_tag, api_tag;
+    bool any_frame, last_sorted;
+    uint64_t last_n;
+    int last_t_dtype;
+  };
+  std::vector<Saved> saved(ns);
+  for (int i = 0; i < ns; ++i) {
+    const Slot& s = h->slots[i];
+    saved[i] = Saved{s.host_tag, s.api_tag, s.any_frame, s.last_sorted, s.last_n, s.last_t_dtype};
+  }
   // Graphs are captured on (and launched from) default-priority streams of their own: launched from the slots'
   // high-priority streams the replay ran its branches one after the other (28 instead of 61 Gevents/s).
   if (h->gstreams.empty()) {
-    h->gstreams.assign(ns, nullptr);
-    for (int i = 0; i < ns; ++i) {
-      hipError_t ce = hipStreamCreateWithFlags(&h->gstreams[i], hipStreamNonBlocking);
+    h->gstreams.assign(std::max(ns, 2), nullptr);
+    for (auto& gs : h->gstreams) {
+      hipError_t ce = hipStreamCreateWithFlags(&gs, hipStreamNonBlocking);
       if (ce != hipSuccess) {
         delete g;
         return fail(XM_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(ce));
       }
     }
   }
-  for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);  // enqueue_frame launches on slot.stream
-  hipStream_t origin = h->slots[0].stream;
+  static const bool per_frame = getenv("XM_GRAPH_PER_FRAME") && getenv("XM_GRAPH_PER_FRAME")[0] == '1';
   int rc = XM_OK;
-  h->capturing = true;
-  hipError_t e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) {
+  if (!per_frame) {
+    rc = graph_capture_batched(h, g, x, y, t, p, t_dtype, offsets_host, n_frames, depth_out, bgr_out);
+  } else {
+    for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);  // enqueue_frame launches on slot.stream
+    hipStream_t origin = h->slots[0].stream;
+    h->capturing = true;
+    hipError_t e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+      h->capturing = false;
+      for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
+      delete g;
+      return fail(XM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    }
+    do {
+      if (ns > 1) {
+        if ((e = hipEventRecord(h->fork_ev, origin)) != hipSuccess) break;
+        for (int i = 1; i < ns; ++i)
+          if ((e = hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0)) != hipSuccess) break;
+        if (e != hipSuccess) break;
+      }
+      for (int f = 0; f < n_frames && rc == XM_OK; ++f) {
+        Slot& s = h->slots[f % ns];
+        EventsView ev;
+        const u64 a = offsets_host[f], b = offsets_host[f + 1];
+        ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
+        ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+        if ((rc = check_events(ev))) break;
+        // tags inside a graph advance on the device; keep the host mirror from triggering a reset mid-capture
+        s.host_tag = 0;
+        rc = enqueue_frame(h, s, ev, depth_out ? depth_out + f * px : nullptr, bgr_out ? bgr_out + f * px * 3 : nullptr,
+                           nullptr);
+        g->frames_on_slot[f % ns] += 1;
+      }
+      if (ns > 1) {
+        for (int i = 1; i < ns; ++i) {
+          if ((e = hipEventRecord(h->join_ev[i], h->slots[i].stream)) != hipSuccess) break;
+          if ((e = hipStreamWaitEvent(origin, h->join_ev[i], 0)) != hipSuccess) break;
+        }
+      }
+    } while (0);
+    hipError_t e2 = hipStreamEndCapture(origin, &g->graph);
     h->capturing = false;
     for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
-    delete g;
-    return fail(XM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
+      rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   }
-  do {
-    if (ns > 1) {
-      if ((e = hipEventRecord(h->fork_ev, origin)) != hipSuccess) break;
-      for (int i = 1; i < ns; ++i)
-        if ((e = hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0)) != hipSuccess) break;
-      if (e != hipSuccess) break;
-    }
-    for (int f = 0; f < n_frames && rc == XM_OK; ++f) {
-      Slot& s = h->slots[f % ns];
-      EventsView ev;
-      const u64 a = offsets_host[f], b = offsets_host[f + 1];
-      ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
-      ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
-      if ((rc = check_events(ev))) break;
-      // tags inside a graph advance on the device; keep the host mirror from triggering a reset mid-capture
-      s.host_tag = 0;
-      rc = enqueue_frame(h, s, ev, depth_out ? depth_out + f * px : nullptr, bgr_out ? bgr_out + f * px * 3 : nullptr,
-                         nullptr);
-      g->frames_on_slot[f % ns] += 1;
-    }
-    if (ns > 1) {
-      for (int i = 1; i < ns; ++i) {
-        if ((e = hipEventRecord(h->join_ev[i], h->slots[i].stream)) != hipSuccess) break;
-        if ((e = hipStreamWaitEvent(origin, h->join_ev[i], 0)) != hipSuccess) break;
-      }
-    }
-  } while (0);
-  hipError_t e2 = hipStreamEndCapture(origin, &g->graph);
-  h->capturing = false;
-  for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
-  for (int i = 0; i < ns; ++i) h->slots[i].host_tag = saved[i];
-  if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
-    rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  for (int i = 0; i < ns; ++i) {  // capture only recorded launches: the slots are where they were
+    Slot& s = h->slots[i];
+    s.host_tag = saved[i].host_tag; s.api_tag = saved[i].api_tag; s.any_frame = saved[i].any_frame;
+    s.last_sorted = saved[i].last_sorted; s.last_n = saved[i].last_n; s.last_t_dtype = saved[i].last_t_dtype;
+    s.pending_batch_ev = nullptr;
+    s.eager_dirty = false;
+  }
   if (rc == XM_OK) {
-    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    hipError_t e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) rc = fail(XM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   }
   if (rc != XM_OK) {
@@ -1246,30 +1634,52 @@ int xm_graph_launch(xm_graph* g) {
   XM_ENTER(h);
   const int ns = (int)h->slots.size();
   hipStream_t origin = h->gstreams[0];
-  for (Slot& s : h->slots) {  // XM_FLAG_TRY_SORTED: settle pending verdicts before the replay advances the slots' tags
-    int rc = resolve_prev(h, s);
-    if (rc) return rc;
+  if (h->try_sorted || h->gate_slots)
+    for (Slot& s : h->slots) {  // settle pending try-sorted verdicts before the replay advances the slots' tags
+      int rc = resolve_prev(h, s);
+      if (rc) return rc;
+    }
+  // order the replay after whatever the slots did last -- per distinct stream, and only where something is pending (a
+  // handle that only replays graphs pays one hipGraphLaunch + one hipEventRecord per replay, not 3 API calls per slot)
+  for (size_t si = 0; si < h->streams.size(); ++si) {
+    bool dirty = false;
+    for (Slot& s : h->slots)
+      if (s.stream == h->streams[si] && s.eager_dirty) dirty = true;
+    if (dirty) {
+      HIP_TRY(hipEventRecord(h->join_ev[si % h->join_ev.size()], h->streams[si]));
+      HIP_TRY(hipStreamWaitEvent(origin, h->join_ev[si % h->join_ev.size()], 0));
+    }
   }
-  // order the replay after whatever the slots are doing, and handle tag wrap per slot
-  for (int i = 0; i < ns; ++i) {
-    HIP_TRY(hipEventRecord(h->join_ev[i], h->slots[i].stream));
-    HIP_TRY(hipStreamWaitEvent(origin, h->join_ev[i], 0));
+  for (Slot& s : h->slots) {
+    s.eager_dirty = false;
+    if (s.pending_batch_ev) {
+      if (s.pending_batch_stream != origin) HIP_TRY(hipStreamWaitEvent(origin, s.pending_batch_ev, 0));
+      s.pending_batch_ev = nullptr;
+    }
   }
-  for (int i = 0; i < ns; ++i) {
+  for (int i = 0; i < ns; ++i) {  // tag wrap per slot
     Slot& s = h->slots[i];
     if ((u64)s.host_tag + g->frames_on_slot[i] >= KEY_MAX_TAG) {
       hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, origin, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
       HIP_TRY(hipGetLastError());
       s.host_tag = 0;
+      s.api_tag = 0;
     }
   }
   HIP_TRY(hipGraphLaunch(g->exec, origin));
+  // whatever a slot does next on its own stream waits for the replay (lazily, see enqueue_frame / enqueue_batch)
+  hipEvent_t done = h->graph_ev[h->graph_ev_next++ % 8];
+  HIP_TRY(hipEventRecord(done, origin));
   for (int i = 0; i < ns; ++i) {
-    h->slots[i].host_tag += g->frames_on_slot[i];
-    if (g->frames_on_slot[i]) h->slots[i].any_frame = true;
+    Slot& s = h->slots[i];
+    s.host_tag += g->frames_on_slot[i];
+    s.api_tag = s.host_tag;  // the worker path derives the next frame's tag from api_tag
+    if (g->frames_on_slot[i]) {
+      s.any_frame = true;
+      s.pending_batch_ev = done;
+      s.pending_batch_stream = origin;
+    }
   }
-  HIP_TRY(hipEventRecord(h->fork_ev, origin));  // whatever the slots do next (or xm_sync) comes after the replay
-  for (int i = 0; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0));
   return XM_OK;
 }
 
@@ -1277,6 +1687,7 @@ void xm_graph_destroy(xm_graph* g) {
   if (!g) return;
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
+  if (g->d_descs) (void)hipFree(g->d_descs);
   delete g;
 }
 
@@ -1552,6 +1963,44 @@ int xm_shard_minmax(xm_handle* h, const void* t, const int16_t* p, size_t n, int
     case XM_T_FLOAT64: host_minmax_out<double>(hs, minmax_out_host); break;
     default: return fail(XM_ERR_INVALID, "unknown t_dtype");
   }
+  return XM_OK;
+}
+
+int xm_shard_minmax_device(xm_handle* h, const void* t, const int16_t* p, size_t n, int t_dtype, void* mm_dev) {
+  if (!h || !mm_dev || (n && !t)) return fail(XM_ERR_INVALID, "NULL argument");
+  if (t_dtype != XM_T_INT64 && t_dtype != XM_T_FLOAT32 && t_dtype != XM_T_FLOAT64) return fail(XM_ERR_INVALID, "unknown t_dtype");
+  XM_ENTER(h);
+  Slot& s = h->slots[0];
+  int rc;
+  if ((rc = rearm_aux(h, s.stream, nullptr, 0))) return rc;
+  EventsView ev;
+  ev.t = n ? t : (const void*)h->d_lut; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  ev.x = (const uint16_t*)h->d_lut; ev.y = ev.x;
+  launch_minmax(ev, h->aux_st, 2, s.stream);
+  switch (t_dtype) {
+    case XM_T_INT64: hipLaunchKernelGGL(k_minmax_export<long long>, dim3(1), dim3(64), 0, s.stream, h->aux_st, 2u, mm_dev); break;
+    case XM_T_FLOAT32: hipLaunchKernelGGL(k_minmax_export<float>, dim3(1), dim3(64), 0, s.stream, h->aux_st, 2u, mm_dev); break;
+    default: hipLaunchKernelGGL(k_minmax_export<double>, dim3(1), dim3(64), 0, s.stream, h->aux_st, 2u, mm_dev);
+  }
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_shard_scatter_device(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                            int t_dtype, uint64_t idx_offset, const void* frame_mm_dev, uint32_t tag, uint64_t* key_frame) {
+  if (!h || !key_frame || !frame_mm_dev) return fail(XM_ERR_INVALID, "NULL argument");
+  if (tag == 0 || tag > KEY_MAX_TAG) return fail(XM_ERR_INVALID, "tag must be in [1, 2^19)");
+  XM_ENTER(h);
+  if (n == 0) return XM_OK;
+  if (idx_offset + n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "global event index exceeds 2^%d", XM_KEY_IDX_BITS);
+  EventsView ev;
+  ev.x = x; ev.y = y; ev.t = t; ev.p = p; ev.n = n; ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+  int rc = check_events(ev);
+  if (rc) return rc;
+  if ((rc = launch_scatter(h, ev, h->aux_st, tag, idx_offset, 0, 0, (u64*)key_frame, nullptr, h->slots[0].stream, false,
+                           frame_mm_dev)))
+    return rc;
+  HIP_TRY(hipGetLastError());
   return XM_OK;
 }
 

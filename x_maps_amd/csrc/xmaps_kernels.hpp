@@ -75,6 +75,26 @@ struct SlotState {
 };
 static_assert(sizeof(SlotState) % 16 == 0, "SlotState array stride");
 
+// One frame of a MULTI-FRAME launch (grid = frames x tiles), in device memory.  Written by the host (xm_process_batch, the
+// hipGraph batch) or by the ingest kernels (device-side frame segmentation: the frame's event range never visits the
+// host).  valid == 0: every kernel of the frame exits at once (no frame was cut).  n == 0 with valid != 0: a defined
+// empty frame (tags advance, outputs are written empty).
+struct FrameDesc {
+  const uint16_t* x;
+  const uint16_t* y;
+  const void* t;
+  const int16_t* p;
+  const uint4* aos;
+  u64 n;
+  u64* key_frame;
+  SlotState* st;
+  float* depth;
+  uint8_t* bgr;
+  u32 valid;
+  u32 pad;
+};
+static_assert(sizeof(FrameDesc) == 88, "FrameDesc layout");
+
 // device -> pinned host memory, visible to the host when the kernel has finished
 __device__ inline void host_flag_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -246,19 +266,17 @@ __device__ inline void load_frame_minmax(const SlotState* st, u32 parity, u64& l
 #endif
 constexpr int K0_UN = XM_K0_UN;  // 16-byte loads of t in flight per thread (vector path)
 template <typename T, bool AOS, bool HAS_P, int VEC>
-__global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const int16_t* __restrict__ p,
-                                                  const uint4* __restrict__ aos, u64 n, SlotState* st,
-                                                  u32 tag_override) {
+__device__ __forceinline__ void minmax_body(const T* __restrict__ t, const int16_t* __restrict__ p,
+                                            const uint4* __restrict__ aos, u64 n, SlotState* st, u32 tag_override,
+                                            const u32 blk, const u32 nblk) {
   XM_BLOG_BEGIN();
-  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
-  if ((long long)((u64)t | (u64)p | (u64)aos | (u64)st | n | (u64)tag_override) < 0) return;
   // the frame tag is only needed for the final atomics: its load (kernarg -> st -> tag_b, a dependent scalar chain) must
   // not sit in front of the event loads
   u64 lo = MM_INIT_MIN, hi = MM_INIT_MAX;
   u32 used = 0;
-  const u64 stride = (u64)gridDim.x * BLOCK;
+  const u64 stride = (u64)nblk * BLOCK;
   if constexpr (AOS) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    for (u64 i = (u64)blk * BLOCK + threadIdx.x; i < n; i += stride) {
       uint4 r = aos[i];
       bool ok = !HAS_P || (short)(r.y & 0xffff) == 1;
       if (ok) {
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
     const longlong2* t2 = reinterpret_cast<const longlong2*>(t);
     const u32* p2 = reinterpret_cast<const u32*>(p);
     // K0_UN independent 16-byte loads per thread per sweep: latency-bound otherwise (8 MB must be in flight at once)
-    for (u64 i0 = (u64)blockIdx.x * BLOCK + threadIdx.x; i0 < n2; i0 += K0_UN * stride) {
+    for (u64 i0 = (u64)blk * BLOCK + threadIdx.x; i0 < n2; i0 += K0_UN * stride) {
       longlong2 v[K0_UN];
       u32 pp[K0_UN];
       bool in[K0_UN];
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
         }
       }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((n & 1) && blk == 0 && threadIdx.x == 0) {
       u64 i = n - 1;
       if (!HAS_P || p[i] == 1) {
         u64 e = TimeCodec<T>::enc(t[i]);
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
       }
     }
   } else {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    for (u64 i = (u64)blk * BLOCK + threadIdx.x; i < n; i += stride) {
       if (!HAS_P || p[i] == 1) {
         u64 e = TimeCodec<T>::enc(t[i]);
         lo = e < lo ? e : lo;
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
 
   const u32 tag = tag_override ? tag_override : st->tag_b + 1;
   const u32 parity = tag & 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->tag_a = tag;
+  if (blk == 0 && threadIdx.x == 0) st->tag_a = tag;
   // wave -> block -> one pair of fire-and-forget atomics per block, spread over MM_SLOTS addresses.  The three wave
   // reductions advance together: 6 dependent cross-lane steps instead of 18.
 #pragma unroll
@@ -359,14 +377,53 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
       u += s_used[w];
     }
     if (u) {
-      const int slot = blockIdx.x % MM_SLOTS;
+      const int slot = blk % MM_SLOTS;
       __hip_atomic_fetch_min(&st->mm[parity][slot][0], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_max(&st->mm[parity][slot][1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&st->cnt[parity][blockIdx.x % CNT_SLOTS][CNT_USED], u, __ATOMIC_RELAXED,
+      __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_USED], u, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   XM_BLOG_END(0, st, tag);
+}
+
+template <typename T, bool AOS, bool HAS_P, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const int16_t* __restrict__ p,
+                                                  const uint4* __restrict__ aos, u64 n, SlotState* st,
+                                                  u32 tag_override) {
+  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
+  if ((long long)((u64)t | (u64)p | (u64)aos | (u64)st | n | (u64)tag_override) < 0) return;
+  minmax_body<T, AOS, HAS_P, VEC>(t, p, aos, n, st, tag_override, blockIdx.x, gridDim.x);
+}
+
+// multi-frame launch: grid = (blocks per frame, frames); frame f = descs[f]
+template <typename T, bool AOS, bool HAS_P, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_minmax_batch(const FrameDesc* __restrict__ descs) {
+  const FrameDesc d = descs[blockIdx.y];
+  if (!d.valid) return;
+  minmax_body<T, AOS, HAS_P, VEC>((const T*)d.t, d.p, d.aos, d.n, d.st, 0u, blockIdx.x, gridDim.x);
+}
+
+// Sharded frames: a shard's extrema as K0 left them (parity of `tag`) -> {tmin, -tmax} in a 16-byte device buffer of a
+// reduction-friendly type (int64 for int64 t, f64 for float t: both exact), so that ONE MIN all-reduce of that buffer over
+// the ranks yields the frame's extrema without any host round trip.  Empty shard -> {+max, +max} (neutral for MIN).
+template <typename T>
+__global__ __launch_bounds__(64) void k_minmax_export(const SlotState* __restrict__ st, u32 tag, void* __restrict__ out) {
+  u64 lo, hi;
+  load_frame_minmax(st, tag & 1, lo, hi);
+  if (threadIdx.x != 0) return;
+  const bool empty = lo == MM_INIT_MIN && hi == MM_INIT_MAX;
+  if constexpr (std::is_same<T, long long>::value) {
+    long long* o = static_cast<long long*>(out);
+    const long long big = 0x7fffffffffffffffll;
+    const long long tmax = TimeCodec<T>::dec(hi);
+    o[0] = empty ? big : TimeCodec<T>::dec(lo);
+    o[1] = empty || tmax == (-big - 1) ? big : -tmax;
+  } else {
+    double* o = static_cast<double*>(out);
+    o[0] = empty ? __builtin_inf() : (double)TimeCodec<T>::dec(lo);
+    o[1] = empty ? __builtin_inf() : -(double)TimeCodec<T>::dec(hi);
+  }
 }
 
 // =====================================================================================================
@@ -426,20 +483,32 @@ __device__ inline bool event_cell(const DevTables& tb, const EventResult& r, u32
 // EPT = events per thread: 4 (vector loads: 8 B of x, 8 B of y, 2 x 16 B of t, 8 B of p per thread;
 // needs 8/8/16/8-byte aligned columns) or 1 (any alignment).  AOS: one 16-B record per thread.
 template <typename T, bool AOS, bool HAS_P, int EPT, int VIEW>
-__global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
-                                                   const T* __restrict__ ts, const int16_t* __restrict__ ps,
-                                                   const uint4* __restrict__ aos, u64 n, u64 idx_offset,
-                                                   DevTables tb, SlotState* st, u32 tag_override, u64 mm_lo,
-                                                   u64 mm_hi, u64* __restrict__ frame, unsigned char* __restrict__ dirty) {
+__device__ __forceinline__ void scatter_direct_body(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                    const T* __restrict__ ts, const int16_t* __restrict__ ps,
+                                                    const uint4* __restrict__ aos, u64 n, u64 idx_offset,
+                                                    const DevTables& tb, SlotState* st, u32 tag_override, u64 mm_lo,
+                                                    u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
+                                                    unsigned char* __restrict__ dirty, const u32 blk) {
   const u32 tag = tag_override ? tag_override : st->tag_a;
   const u32 parity = tag & 1;
   u64 lo, hi;
-  if (tag_override) {  // sharded mode: the FRAME's extrema come from the host-side all-reduce
+  if (tag_override) {  // sharded mode: the FRAME's extrema come from the all-reduce of the shards' extrema
     lo = mm_lo;
     hi = mm_hi;
+    if (mm_ext) {  // {tmin, -tmax} in device memory (see scatter_tiled_body)
+      if constexpr (std::is_same<T, long long>::value) {
+        const long long* m = static_cast<const long long*>(mm_ext);
+        lo = TimeCodec<T>::enc(m[0]);
+        hi = TimeCodec<T>::enc(-m[1]);
+      } else {
+        const double* m = static_cast<const double*>(mm_ext);
+        lo = TimeCodec<T>::enc((T)m[0]);
+        hi = TimeCodec<T>::enc((T)(-m[1]));
+      }
+    }
   } else {
     load_frame_minmax(st, parity, lo, hi);
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
       if (threadIdx.x == 0) st->tag_b = tag;
       // re-arm the other parity's min/max slots for the next frame on this slot
       if (threadIdx.x < MM_SLOTS) {
@@ -454,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
   u32 x[EPT], y[EPT];
   T t[EPT];
   bool used[EPT];
-  const u64 base = ((u64)blockIdx.x * BLOCK + threadIdx.x) * EPT;
+  const u64 base = ((u64)blk * BLOCK + threadIdx.x) * EPT;
   if constexpr (AOS) {
     static_assert(EPT == 1, "AoS: one record per thread");
     used[0] = base < n;
@@ -541,10 +610,32 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    u32* c = st->cnt[parity][blockIdx.x % CNT_SLOTS];
+    u32* c = st->cnt[parity][blk % CNT_SLOTS];
     if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+template <typename T, bool AOS, bool HAS_P, int EPT, int VIEW>
+__global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys,
+                                                   const T* __restrict__ ts, const int16_t* __restrict__ ps,
+                                                   const uint4* __restrict__ aos, u64 n, u64 idx_offset,
+                                                   DevTables tb, SlotState* st, u32 tag_override, u64 mm_lo,
+                                                   u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
+                                                   unsigned char* __restrict__ dirty) {
+  scatter_direct_body<T, AOS, HAS_P, EPT, VIEW>(xs, ys, ts, ps, aos, n, idx_offset, tb, st, tag_override, mm_lo, mm_hi, mm_ext,
+                                                frame, dirty, blockIdx.x);
+}
+
+// one thread per event, frame from a descriptor in device memory (sparse frames of a device-resident stream: ingest);
+// grid = (blocks for the largest frame the host allows for, frames); a frame without events still does block 0's bookkeeping
+template <typename T, bool AOS, bool HAS_P, int VIEW>
+__global__ __launch_bounds__(BLOCK) void k_scatter_direct_batch(const FrameDesc* __restrict__ descs, DevTables tb) {
+  const FrameDesc d = descs[blockIdx.y];
+  if (!d.valid) return;
+  if (blockIdx.x != 0 && (u64)blockIdx.x * BLOCK >= d.n) return;
+  scatter_direct_body<T, AOS, HAS_P, 1, VIEW>(d.x, d.y, (const T*)d.t, d.p, d.aos, d.n, 0ull, tb, d.st, 0u, 0ull, 0ull, nullptr,
+                                              d.key_frame, nullptr, blockIdx.x);
 }
 
 
@@ -587,40 +678,36 @@ constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;  // largest block: 4096 eve
 // VEC: SoA columns 16-byte aligned -> each thread loads TILE_EPT consecutive events with 8/16-byte loads.  A compile-time
 // switch, not a per-block branch: with both load paths in one kernel the compiler's wait-count bookkeeping at the join
 // put full vmcnt waits in front of the event loads and of the extrema reduction (seen in the ISA).
-template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
 #ifdef XM_K1_WAVES_PER_EU  // experiments: cap the VGPRs so that this many waves fit a SIMD (HIP's 2nd launch-bounds argument)
 #define XM_K1_BOUNDS __launch_bounds__(TILE_THREADS, XM_K1_WAVES_PER_EU)
 #else
 #define XM_K1_BOUNDS __launch_bounds__(TILE_THREADS)
 #endif
-__global__ XM_K1_BOUNDS void k_scatter_tiled(
+// blk / nblk = this block's index among the frame's blocks / their number (blockIdx.x, gridDim.x of a single-frame launch).
+// mm_ext (sharded mode, tag_override != 0): the FRAME's extrema in device memory as {tmin, -tmax} (int64 for int64 t, f64
+// for float t) -- the buffer the ranks MIN-all-reduce -- read here so that no host round trip sits between the collective
+// and this kernel; NULL: mm_lo / mm_hi carry the encoded extrema.
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
+__device__ __forceinline__ void scatter_tiled_body(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
-    const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
-    u32 tag_override, u64 mm_lo, u64 mm_hi, u64* __restrict__ frame, unsigned char* __restrict__ dirty, int w_ts, int w_x,
-    int sorted_mode) {
+    const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, const DevTables& tb, SlotState* st,
+    u32 tag_override, u64 mm_lo, u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
+    unsigned char* __restrict__ dirty, int w_ts, int w_x, int sorted_mode, const u32 blk, const u32 nblk) {
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XM_BLOG_BEGIN();
-#ifndef XM_NO_KERNARG_BATCH
-  // All kernel arguments into SGPRs in ONE scalar-load round trip: a test that needs every one of them, placed first.
-  // Left alone the compiler fetches them lazily, block by block -- eight dependent s_load -> s_waitcnt pairs along the
-  // critical chain of every block (seen in the ISA).  (Inline asm would do it too, but makes every later uniform load a
-  // vector load.)  Never true: sizes are non-negative and device addresses have bit 63 clear.
-  {
-    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)ps | (u64)aos | (u64)tb.lut | (u64)tb.xmap | (u64)st | (u64)frame |
-                   (u64)dirty | n | idx_offset;
-    const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.t_px_scale | tb.x_offset | tb.rect_w | tb.rect_h |
-                   (int)tag_override | w_ts | w_x | sorted_mode;
-    if ((long long)(pp | (u64)(long long)pi) < 0) return;
-  }
-#endif
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift).  The LUT band and
   // the winner slots SHARE one region: the band is only read by the first gather of the fast path, the slots only written
   // after it -- two extra barriers buy 26 KB per block, i.e. a third resident block per CU (block residency is what bounds
   // the pipelined frame rate: tools/block_timeline.py).
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
   const int win_q = (win_words + 3) >> 2;  // uint4 count
+#ifndef XM_NO_LDS_DMA
+  // LDS-direct band loads write whole waves (64 x 16 B): each band keeps one wave of slack behind it (k1_lds_bytes())
+  const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1 + 64;
+#else
   const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1;
+#endif
   u32* win = reinterpret_cast<u32*>(smem);
   u32* lut_base = win;
   int16_t* xm_base = reinterpret_cast<int16_t*>(win + 4 * max(win_q, lut_q));
@@ -633,7 +720,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share
   // almost all of their LUT band and a column of their X-map band, so XCD k takes the k-th CONTIGUOUS eighth of the
   // frame's tiles: the bands then come out of that XCD's L2 instead of being fetched over the fabric once per block.
-  const u32 tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const u32 tile = xcd_contiguous(blk, nblk);
   const u64 block_base = (u64)tile * ev_per_block;  // < n: the host launches ceil(n / ev_per_block) blocks, n > 0
 
   // ---- 1. Every load that depends on nothing is ISSUED here, small ones first, and nothing is consumed before the
@@ -771,9 +858,20 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   const u32 tag = tag_override ? tag_override : (sorted_mode ? st->tag_b + 1 : st->tag_a);
   const u32 parity = tag & 1;
   u64 lo, hi;
-  if (tag_override) {  // sharded mode: the FRAME's extrema come from the host-side all-reduce
+  if (tag_override) {  // sharded mode: the FRAME's extrema come from the all-reduce of the shards' extrema
     lo = mm_lo;
     hi = mm_hi;
+    if (mm_ext) {  // {tmin, -tmax} left in device memory by the collective (uniform loads)
+      if constexpr (std::is_same<T, long long>::value) {
+        const long long* m = static_cast<const long long*>(mm_ext);
+        lo = TimeCodec<T>::enc(m[0]);
+        hi = TimeCodec<T>::enc(-m[1]);
+      } else {
+        const double* m = static_cast<const double*>(mm_ext);
+        lo = TimeCodec<T>::enc((T)m[0]);
+        hi = TimeCodec<T>::enc((T)(-m[1]));
+      }
+    }
   } else {
     if (sorted_mode) {
       lo = TimeCodec<T>::enc(t_first);
@@ -790,7 +888,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
       lo = uniform_u64(a);
       hi = uniform_u64(b);
     }
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
       if (tid == 0) {
         if (sorted_mode) {
           st->tag_a = tag;  // K2 reads tag_a and copies it to tag_b
@@ -847,6 +945,37 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   const int nq_all = nq_lut + nq_xm;
   uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
   uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
+#ifndef XM_NO_LDS_DMA
+  // LDS-DIRECT loads (global_load_lds_dwordx4, gfx950): the bands go L2 -> LDS without passing through VGPRs -- no 24
+  // registers of band data held across the event arithmetic, no ds_write_b128, nothing to wait for until the gathers.
+  // Lane l of a wave writes 16 B at M0 + 16 l, so a wave's 64 quads land contiguously: LDS quad index == band quad index,
+  // as before.  Waves entirely past the end of a band skip the load (wave-uniform branch); the last, partial wave of a
+  // band re-reads the band's last quad for its surplus lanes and writes it into the wave of slack behind the band.
+  // A FIXED number of loads per wave is issued here (enough for the C-1M bands), so that the wait for the thread's own
+  // events further down can be a counted one (vmcnt(6)) and the bands stay in flight during the time-column arithmetic;
+  // taller tables / smaller blocks fetch the rest after that arithmetic (dynamic trip count = full wait, seen in the ISA).
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int UL_L = TILE_THREADS >= 1024 ? 2 : 4, UL_X = TILE_THREADS >= 1024 ? 1 : 2;
+  const int dma_q0 = tid & ~63;  // first band quad of this wave in pass 0
+  const int dma_lane = tid & 63;
+  uint4* l_dmy = l_xm + (((w_ts * tb.xmap_h + 7) >> 3) + 1 + 64);  // where waves past the end of a band dump their load
+  {
+#pragma unroll
+    for (int k = 0; k < UL_L; ++k) {
+      const int q0 = dma_q0 + k * nthreads;
+      __builtin_amdgcn_global_load_lds((glb_void*)(g_lut + min(q0 + dma_lane, nq_lut - 1)),
+                                       (lds_void*)(q0 < nq_lut ? l_lut + q0 : l_dmy), 16, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < UL_X; ++k) {
+      const int q0 = dma_q0 + k * nthreads;
+      __builtin_amdgcn_global_load_lds((glb_void*)(g_xm + min(q0 + dma_lane, nq_xm - 1)),
+                                       (lds_void*)(q0 < nq_xm ? l_xm + q0 : l_dmy), 16, 0, 0);
+    }
+    (void)nq_all;
+  }
+#else
   uint4* l_dummy = l_xm + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
   constexpr int UNB = TILE_THREADS >= 1024 ? 3 : 6;  // 43 KB of bands = 2745 quads: one pass for the largest block
   const auto band_src = [&](int i) -> const uint4* { return i < nq_lut ? g_lut + i : g_xm + min(i - nq_lut, nq_xm - 1); };
@@ -858,6 +987,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     bv4 = *band_src(tid + 4 * nthreads);
     bv5 = *band_src(tid + 5 * nthreads);
   }
+#endif
   XM_STAMP(4);
 
   // ---- 4. with the bands in flight: unpack the events, their time columns (bit-exact with NumPy, see TimeNorm) ---------
@@ -881,7 +1011,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
       bad = bad || (used[k] && (e < lo || e > hi));
     }
     if (__ballot(bad) && (tid & 63) == 0) {
-      __hip_atomic_fetch_add(&st->cnt[parity][blockIdx.x % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (u32* hf = st->host_flags) host_flag_store(hf, tag);
     }
@@ -935,6 +1065,14 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     n_oob += __popcll(__ballot(oob));
   }
   XM_STAMP(5);
+#ifndef XM_NO_LDS_DMA
+  for (int q0 = dma_q0 + UL_L * nthreads; q0 < nq_lut; q0 += nthreads)  // taller tables / smaller blocks: the rest
+    __builtin_amdgcn_global_load_lds((glb_void*)(g_lut + min(q0 + dma_lane, nq_lut - 1)), (lds_void*)(l_lut + q0), 16, 0, 0);
+  for (int q0 = dma_q0 + UL_X * nthreads; q0 < nq_xm; q0 += nthreads)
+    __builtin_amdgcn_global_load_lds((glb_void*)(g_xm + min(q0 + dma_lane, nq_xm - 1)), (lds_void*)(l_xm + q0), 16, 0, 0);
+  // the LDS-direct loads are tracked by vmcnt like any vector load: all of them landed before the barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   {
     *band_dst(tid) = bv0;
     *band_dst(tid + nthreads) = bv1;
@@ -951,6 +1089,7 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
       *band_dst(i0 + 2 * nthreads) = v2;
     }
   }
+#endif
   XM_STAMP(11);
   XM_STAMP(12);
   __syncthreads();  // bands visible
@@ -1064,12 +1203,73 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
   }
   XM_STAMP(9);
   if (tid == 0) {
-    u32* c = st->cnt[parity][blockIdx.x % CNT_SLOTS];
+    u32* c = st->cnt[parity][blk % CNT_SLOTS];
     if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   XM_STAMP(10);
   XM_BLOG_END(1, st, tag);
+}
+
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
+__global__ XM_K1_BOUNDS void k_scatter_tiled(
+    const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
+    const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
+    u32 tag_override, u64 mm_lo, u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
+    unsigned char* __restrict__ dirty, int w_ts, int w_x, int sorted_mode) {
+#ifndef XM_NO_KERNARG_BATCH
+  // All kernel arguments into SGPRs in ONE scalar-load round trip: a test that needs every one of them, placed first.
+  // Left alone the compiler fetches them lazily, block by block -- eight dependent s_load -> s_waitcnt pairs along the
+  // critical chain of every block (seen in the ISA).  (Inline asm would do it too, but makes every later uniform load a
+  // vector load.)  Never true: sizes are non-negative and device addresses have bit 63 clear.
+  {
+    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)ps | (u64)aos | (u64)tb.lut | (u64)tb.xmap | (u64)st | (u64)frame |
+                   (u64)dirty | (u64)mm_ext | n | idx_offset;
+    const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.t_px_scale | tb.x_offset | tb.rect_w | tb.rect_h |
+                   (int)tag_override | w_ts | w_x | sorted_mode;
+    if ((long long)(pp | (u64)(long long)pi) < 0) return;
+  }
+#endif
+  scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC>(xs, ys, ts, ps, aos, n, idx_offset, tb, st, tag_override, mm_lo, mm_hi, mm_ext,
+                                               frame, dirty, w_ts, w_x, sorted_mode, blockIdx.x, gridDim.x);
+}
+
+// A frame without events inside a multi-frame launch: only the slot bookkeeping K1's block 0 does.
+__device__ inline void scatter_empty_frame(SlotState* st, int sorted_mode) {
+  const u32 tag = sorted_mode ? st->tag_b + 1 : st->tag_a;
+  const u32 parity = tag & 1;
+  if (threadIdx.x == 0) {
+    if (sorted_mode) {
+      st->tag_a = tag;
+      st->mm[parity][0][0] = MM_INIT_MIN;
+      st->mm[parity][0][1] = MM_INIT_MAX;
+    } else {
+      st->tag_b = tag;
+    }
+  }
+  for (int i = threadIdx.x; i < MM_SLOTS; i += blockDim.x) {
+    st->mm[parity ^ 1][i][0] = MM_INIT_MIN;
+    st->mm[parity ^ 1][i][1] = MM_INIT_MAX;
+  }
+}
+
+// Multi-frame launch: grid = (tiles of the largest frame, frames).  One launch exposes frames x tiles blocks to the chip
+// (60 frames: 14 700 blocks instead of 245): no per-frame launch ramp, the CUs always have a next block to pick up.  Every
+// frame owns a key frame + state (FrameDesc), so blocks of different frames never meet.  The frame's size comes from
+// device memory: the same launch serves frames cut out of a device-resident stream (ingest) whose length the host never saw.
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
+__global__ XM_K1_BOUNDS void k_scatter_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb, int w_ts, int w_x,
+                                                   int sorted_mode) {
+  const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
+  if (!d.valid) return;
+  const u32 evb = blockDim.x * TILE_EPT;
+  const u32 nblk = (u32)((d.n + evb - 1) / evb);
+  if (blockIdx.x >= nblk) {
+    if (d.n == 0 && blockIdx.x == 0) scatter_empty_frame(d.st, sorted_mode);
+    return;
+  }
+  scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC>(d.x, d.y, (const T*)d.t, d.p, d.aos, d.n, 0ull, tb, d.st, 0u, 0ull, 0ull, nullptr,
+                                               d.key_frame, nullptr, w_ts, w_x, sorted_mode, blockIdx.x, nblk);
 }
 
 // =====================================================================================================
@@ -1269,12 +1469,12 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
   if (in_img) pix[(u32)v * (u32)tb.proj_w + (u32)u] = off;
 }
 
-__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
-                                                                  SlotState* st, u32 tag_override,
-                                                                  const unsigned char* __restrict__ dirty,
-                                                                  const ulonglong2* __restrict__ zero16,
-                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr,
-                                                                  int tile_cap) {
+// blk_lin / grid_x / grid_y = linear block index inside the frame's tile grid and that grid's shape
+__device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ keys, const DevTables& tb, SlotState* st,
+                                                      u32 tag_override, const unsigned char* __restrict__ dirty,
+                                                      const ulonglong2* __restrict__ zero16, float* __restrict__ depth,
+                                                      uint8_t* __restrict__ bgr, int tile_cap, const u32 blk_lin,
+                                                      const u32 grid_x, const u32 grid_y) {
   // Dynamic LDS sized to the largest patch of THIS rig (tile_cap cells, a multiple of 8, <= K2_TILE_MAX; set in xm_create):
   // how many blocks fit beside K1's 70 KB blocks on a CU is what bounds the pipelined frame rate, and the static
   // worst case (2 x 10 KB) was twice what C-1M's 50 x 56 patches need.
@@ -1287,15 +1487,9 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
   XM_BLOG_BEGIN();
-  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
-  if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
-                  (u64)zero16 | (u64)depth | (u64)bgr |
-                  (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
-    return;
   // XCD-aware tile order (see xcd_contiguous): each XCD takes a contiguous run of the tile raster, so the halos that
   // neighbouring tiles share (3 of 22 patch columns each side, boundary cache lines above/below) hit in its own L2.
-  const u32 grid_x = gridDim.x;
-  const u32 lin_tile = xcd_contiguous(blockIdx.y * grid_x + blockIdx.x, grid_x * gridDim.y);
+  const u32 lin_tile = xcd_contiguous(blk_lin, grid_x * grid_y);
   const u32 tile_y = lin_tile / grid_x, tile_x = lin_tile - tile_y * grid_x;
   const u32 tag = tag_override ? tag_override : st->tag_a;  // first needed when the patch is decoded
   const int u = tile_x * K2_TX + tx, v = tile_y * K2_TY + ty;
@@ -1514,6 +1708,31 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
   XM_BLOG_END(2, st, tag);
 }
 
+__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
+                                                                  SlotState* st, u32 tag_override,
+                                                                  const unsigned char* __restrict__ dirty,
+                                                                  const ulonglong2* __restrict__ zero16,
+                                                                  float* __restrict__ depth, uint8_t* __restrict__ bgr,
+                                                                  int tile_cap) {
+  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
+  if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
+                  (u64)zero16 | (u64)depth | (u64)bgr |
+                  (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
+    return;
+  frame_proj_tiled_body(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap, blockIdx.y * gridDim.x + blockIdx.x,
+                        gridDim.x, gridDim.y);
+}
+
+// multi-frame launch: grid = (tiles_x, tiles_y, frames)
+__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb,
+                                                                        const ulonglong2* __restrict__ zero16,
+                                                                        int tile_cap) {
+  const FrameDesc d = descs[blockIdx.z];
+  if (!d.valid) return;
+  frame_proj_tiled_body(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
+                        blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
+}
+
 // camera view / plain per-pixel conversion of a frame of n_pixels cells -> depth + BGR
 template <typename Cells>
 __global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixels, double p03, float z_near,
@@ -1547,6 +1766,29 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct(Cells cells, u64 n_pixel
   }
   if (depth && pixel < n_pixels) depth[pixel] = o.depth;
   if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, o.bgr);
+}
+
+// multi-frame launch of the camera-view frame kernel: grid = (blocks per frame, frames)
+__global__ __launch_bounds__(BLOCK) void k_frame_direct_batch(const FrameDesc* __restrict__ descs, u64 n_pixels,
+                                                              const uint2* __restrict__ dlut) {
+  const FrameDesc d = descs[blockIdx.y];
+  if (!d.valid) return;
+  SlotState* st = d.st;
+  const u32 tag = st->tag_a;
+  if (blockIdx.x == 0 && threadIdx.x < CNT_SLOTS) {
+    u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
+    c[0] = c[1] = c[2] = c[3] = 0;
+    if (threadIdx.x == 0) {
+      st->tag_b = tag;
+      if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
+    }
+  }
+  const u64 pixel = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  u32 dsp = 0;
+  if (pixel < n_pixels) dsp = key_disp(d.key_frame[pixel], tag);
+  const uint2 e = dlut[dsp];
+  if (d.depth && pixel < n_pixels) d.depth[pixel] = __uint_as_float(e.x);
+  if (d.bgr) store_bgr_block(d.bgr, (u64)blockIdx.x * BLOCK, n_pixels, e.y);
 }
 
 // packed-key frame -> f32 disparity frame (stage A3 / A3' output)
@@ -1905,7 +2147,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __rest
     if (threadIdx.x == 0) {
       st->tag_a = 0;
       st->tag_b = 0;
-      st->unsorted_sticky = 0;
+      // unsorted_sticky is NOT cleared here: this kernel also runs on tag wrap, and a violation recorded since the last
+      // xm_sync must still be reported; it starts at 0 (xm_create zeroes the states) and xm_sync clears it
     }
     for (int i = threadIdx.x; i < 2 * MM_SLOTS; i += BLOCK) {
       st->mm[i / MM_SLOTS][i % MM_SLOTS][0] = MM_INIT_MIN;

@@ -71,8 +71,11 @@ class XMapsEngine:
     """
 
     def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1,
-                 assume_time_sorted: bool = False, try_sorted: bool = False, default_priority_streams: bool = False,
-                 launch_workers: bool = False):
+                 assume_time_sorted: bool = False, try_sorted: bool = True, default_priority_streams: bool = False,
+                 launch_workers: bool = False, force_general: bool = False):
+        """Extrema of t: by default the verified (t[0], t[n-1]) shortcut with automatic redo (exact for any order, the
+        library's default); force_general=True (or try_sorted=False) runs the extrema pass K0 on every frame;
+        assume_time_sorted=True declares the frames sorted (verified, reported instead of redone for asynchronous calls)."""
         self._lib = N.load_library()
         self._h = C.c_void_p(None)
         mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
@@ -95,7 +98,8 @@ class XMapsEngine:
         cfg.x_offset = int(tables.get("x_offset", 4242))
         cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
         cfg.n_slots = n_slots
-        cfg.flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0) | (N.XM_FLAG_TRY_SORTED if try_sorted else 0)
+        cfg.flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0)
+                     | (N.XM_FLAG_GENERAL if (force_general or not try_sorted) else 0)
                      | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0)
                      | (N.XM_FLAG_LAUNCH_WORKERS if launch_workers else 0))
         cfg.p03 = float(tables["p03"])
@@ -215,6 +219,16 @@ class XMapsEngine:
         st = N.xm_frame_stats()
         N.check(self._lib.xm_last_frame_stats(self._h, C.byref(st)))
         return FrameStats.from_c(st)
+
+    # ---- a group of frames in one set of multi-frame launches ------------------------------------------
+    def process_batch_device(self, x_ptr, y_ptr, t_ptr, p_ptr, offsets, depth_ptr=None, bgr_ptr=None,
+                             t_dtype=N.XM_T_INT64):
+        """Frames [offsets[f], offsets[f+1]) of device-resident SoA columns -> depth_ptr + f*H*W (bgr_ptr + f*H*W*3);
+        len(offsets) - 1 <= n_slots; asynchronous (sync() to wait)."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        N.check(self._lib.xm_process_batch(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), t_dtype,
+                                           offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1,
+                                           _ptr(depth_ptr), _ptr(bgr_ptr)))
 
     # ---- hipGraph batch ----------------------------------------------------------------------------
     def graph_create(self, x_ptr, y_ptr, t_ptr, p_ptr, offsets, depth_ptr=None, bgr_ptr=None,
@@ -366,6 +380,15 @@ class XMapsEngine:
         out = np.zeros(2, np_dt)
         N.check(self._lib.xm_shard_minmax(self._h, _ptr(t_ptr), _ptr(p_ptr), n, t_dtype, _ptr(out)))
         return out
+
+    def shard_minmax_device(self, t_ptr, p_ptr, n, mm_dev_ptr, t_dtype=N.XM_T_INT64):
+        """Shard extrema -> {tmin, -tmax} (int64 / float64) in a 16-byte device buffer; no host synchronisation."""
+        N.check(self._lib.xm_shard_minmax_device(self._h, _ptr(t_ptr), _ptr(p_ptr), n, t_dtype, _ptr(mm_dev_ptr)))
+
+    def shard_scatter_device(self, x_ptr, y_ptr, t_ptr, p_ptr, n, idx_offset, mm_dev_ptr, tag, key_ptr,
+                             t_dtype=N.XM_T_INT64):
+        N.check(self._lib.xm_shard_scatter_device(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), n, t_dtype,
+                                                  int(idx_offset), _ptr(mm_dev_ptr), int(tag), _ptr(key_ptr)))
 
     def shard_clear(self, key_ptr):
         N.check(self._lib.xm_shard_clear(self._h, _ptr(key_ptr)))

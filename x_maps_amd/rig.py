@@ -74,3 +74,36 @@ def make_esl_like(calib_npz: str | None = None, device: int = 0, **kw):
     tables = C.build_tables(cp, device=device)
     evs, gt = render_events(cp, tables, **kw)
     return cp, tables, evs, gt
+
+
+def render_stream(cp: C.CamProjCalibrationParams, tables: dict, n_frames: int, period_us: int = 16_600, scan_us: int = 13_000,
+                  row_stride: int = 13, t_start_us: int = 2_000_000, neg_fraction: float = 0.1, gap_noise_every: int = 5,
+                  seed: int = 0):
+    """BASELINE config 3 stand-in: `n_frames` consecutive ESL-like projector frames as ONE EventCD stream with real-looking
+    microsecond stamps -- a ~13 ms scan, then a ~3.6 ms dark gap (period 16.6 ms, 60 Hz) -- plus what a camera adds:
+    `neg_fraction` negative-polarity events sprinkled over the scans (the polarity filter removes them, pipe:43,114) and a
+    lone positive noise event inside every `gap_noise_every`-th gap (the trigger finder then cuts that frame at the noise
+    event, trigger_finder.py:158-172).  Returns (stream, frames) with frames = the rendered per-frame event arrays."""
+    rng = np.random.default_rng(seed)
+    chunks, frames = [], []
+    for f in range(n_frames):
+        t0 = t_start_us + f * period_us
+        evs, _ = render_events(cp, tables, row_stride=row_stride, t0_us=t0, scan_us=scan_us, seed=seed * 1000 + f)
+        frames.append(evs)
+        parts = [evs]
+        if neg_fraction > 0:
+            k = int(len(evs) * neg_fraction)
+            neg = np.zeros(k, EVENT_CD_DTYPE)
+            neg["t"] = rng.integers(t0, t0 + scan_us, k)
+            neg["x"] = rng.integers(0, cp.camera_width, k)
+            neg["y"] = rng.integers(0, cp.camera_height, k)
+            neg["p"] = 0
+            parts.append(neg)
+        if gap_noise_every and f % gap_noise_every == gap_noise_every - 1:
+            nz = np.zeros(1, EVENT_CD_DTYPE)
+            nz["t"] = t0 + scan_us + 1_500
+            nz["x"], nz["y"], nz["p"] = rng.integers(0, cp.camera_width), rng.integers(0, cp.camera_height), 1
+            parts.append(nz)
+        c = np.concatenate(parts)
+        chunks.append(c[np.argsort(c["t"], kind="stable")])
+    return np.concatenate(chunks), frames

@@ -13,11 +13,16 @@ so a signed int64 MAX (what torch/RCCL offer) orders keys like the unsigned comp
 The only other coupling is (tmin, tmax) of the whole frame (python/x_maps_disparity.py:12-13): a 16-byte
 MIN all-reduce of (tmin, -tmax).
 
-The collective is torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  Compute is
-behind a small provider protocol so that the sharding logic itself is testable without a GPU:
-  provider.minmax(shard)                  -> (tmin, tmax) of the shard's t (dtype-typed NumPy scalars)
-  provider.scatter(shard, idx_offset, (tmin, tmax), tag, key_frame)   (in place)
-  provider.finish(key_frame, tag)         -> (depth, bgr)
+The collective is torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  Nothing on the frame's
+critical path visits the host: the shard's extrema are left in a 16-byte device tensor as {tmin, -tmax}
+(xm_shard_minmax_device), that tensor is MIN-all-reduced in place, the scatter kernel reads it from device memory
+(xm_shard_scatter_device), the key frame is MAX-all-reduced in place and the frame kernel runs on it -- five enqueues on one
+stream, zero synchronisations.  Compute is behind a small provider protocol so that the sharding logic itself is testable
+without a GPU:
+  provider.new_minmax_buffer(shard)          -> 2-element tensor (int64 for int64 t, float64 for float t)
+  provider.minmax_into(shard, mm)            mm <- {tmin, -tmax} of the shard ({+max, +max} when empty)
+  provider.scatter(shard, idx_offset, mm, tag, key_frame)   mm = the FRAME's {tmin, -tmax} after the MIN-reduce (in place)
+  provider.finish(key_frame, tag)            -> (depth, bgr)
 `GpuShardProvider` is the product implementation (C-ABI xm_shard_* on device tensors).
 """
 from __future__ import annotations
@@ -50,15 +55,27 @@ class GpuShardProvider:
     def clear_key_frame(self, kf):
         self.eng.shard_clear(kf.data_ptr())
 
-    def minmax(self, shard):
-        x, y, t, p = shard
-        return self.eng.shard_minmax(t.data_ptr() if len(t) else None, None if p is None else p.data_ptr(), len(t))
+    def new_minmax_buffer(self, shard):
+        t = shard[2]
+        dt = self.torch.int64 if t.dtype == self.torch.int64 else self.torch.float64
+        return self.torch.zeros(2, dtype=dt, device=self.device)
 
-    def scatter(self, shard, idx_offset, frame_minmax, tag, key_frame):
+    @staticmethod
+    def _t_dtype(t):
+        import torch
+        return {torch.int64: 0, torch.float32: 1, torch.float64: 2}[t.dtype]
+
+    def minmax_into(self, shard, mm):
+        x, y, t, p = shard
+        self.eng.shard_minmax_device(t.data_ptr() if len(t) else None, None if p is None else p.data_ptr(), len(t),
+                                     mm.data_ptr(), t_dtype=self._t_dtype(t))
+
+    def scatter(self, shard, idx_offset, mm, tag, key_frame):
         x, y, t, p = shard
         if len(t):
-            self.eng.shard_scatter(x.data_ptr(), y.data_ptr(), t.data_ptr(), None if p is None else p.data_ptr(),
-                                   len(t), idx_offset, frame_minmax, tag, key_frame.data_ptr())
+            self.eng.shard_scatter_device(x.data_ptr(), y.data_ptr(), t.data_ptr(), None if p is None else p.data_ptr(),
+                                          len(t), idx_offset, mm.data_ptr(), tag, key_frame.data_ptr(),
+                                          t_dtype=self._t_dtype(t))
 
     def finish(self, key_frame, tag, want_bgr=True):
         torch = self.torch
@@ -75,16 +92,22 @@ class GpuShardProvider:
 
 
 class ShardedFrameProcessor:
-    """Drives one rank of the sharded frame.  `dist` = torch.distributed (already initialised)."""
+    """Drives one rank of the sharded frame.  `dist` = torch.distributed (already initialised).
+    always_reduce: issue the two all-reduces even when world_size == 1 (exercises the RCCL path on a single-GPU box;
+    a one-rank all-reduce leaves the data unchanged)."""
 
-    def __init__(self, provider, dist, group=None):
+    def __init__(self, provider, dist, group=None, always_reduce=False):
         self.p = provider
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.key_frame = provider.new_key_frame()
+        self.always_reduce = always_reduce
+        self.mm = None
+        self._mm_for = None
         self.tag = 0
+        self.collectives_issued = 0
 
     def _next_tag(self):
         if self.tag >= KEY_MAX_TAG:
@@ -93,40 +116,28 @@ class ShardedFrameProcessor:
         self.tag += 1
         return self.tag
 
+    def _all_reduce(self, tensor, op):
+        if self.world > 1 or self.always_reduce:
+            self.dist.all_reduce(self.p.as_tensor(tensor), op=op, group=self.group)
+            self.collectives_issued += 1
+
     def process_shard(self, shard, idx_offset: int, want_bgr=True, finish_on_all_ranks=True):
         """shard = (x, y, t, p|None) of THIS rank's events; idx_offset = global index of its first event.
-        Returns (depth, bgr) of the whole frame (on every rank, or only rank 0)."""
+        Returns (depth, bgr) of the whole frame (on every rank, or only rank 0).  Asynchronous on the provider's stream."""
         import contextlib
-        torch_like = self.dist
         tag = self._next_tag()
+        if self.mm is None or self._mm_for != shard[2].dtype:
+            self.mm = self.p.new_minmax_buffer(shard)
+            self._mm_for = shard[2].dtype
         ctx = self.p.collective_stream() if hasattr(self.p, "collective_stream") else contextlib.nullcontext()
         with ctx:
-            # 1. frame extrema: MIN-reduce (tmin, -tmax)
-            tmin, tmax = self.p.minmax(shard)
-            mm = self._reduce_minmax(tmin, tmax)
-            # 2. private scatter, 3. merge
-            self.p.scatter(shard, idx_offset, mm, tag, self.key_frame)
-            if self.world > 1:
-                torch_like.all_reduce(self.p.as_tensor(self.key_frame), op=torch_like.ReduceOp.MAX, group=self.group)
+            # 1. frame extrema: MIN-reduce {tmin, -tmax}, on the device
+            self.p.minmax_into(shard, self.mm)
+            self._all_reduce(self.mm, self.dist.ReduceOp.MIN)
+            # 2. private scatter (reads the reduced extrema from device memory), 3. merge
+            self.p.scatter(shard, idx_offset, self.mm, tag, self.key_frame)
+            self._all_reduce(self.key_frame, self.dist.ReduceOp.MAX)
             # 4. frame kernel on the merged keys
             if finish_on_all_ranks or self.rank == 0:
                 return self.p.finish(self.key_frame, tag, want_bgr)
         return None, None
-
-    def _reduce_minmax(self, tmin, tmax):
-        import torch
-        dt = np.asarray(tmin).dtype
-        if np.issubdtype(dt, np.integer):
-            info = np.iinfo(dt)
-            neg = info.max if tmax == info.min else -int(tmax)
-            v = torch.tensor([int(tmin), neg], dtype=torch.int64)
-        else:
-            v = torch.tensor([float(tmin), -float(tmax)], dtype=torch.float64)
-        if self.world > 1:
-            dev = getattr(self.p, "device", None)
-            if dev is not None:
-                v = v.to(dev)
-            self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN, group=self.group)
-            v = v.cpu()
-        lo, hi = v[0].item(), -v[1].item()
-        return np.array([lo, hi], dtype=dt)
