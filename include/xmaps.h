@@ -307,6 +307,53 @@ int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, cons
 int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t n, int mem, int64_t thresh_us,
                    uint32_t* idx_out, size_t idx_capacity, size_t* n_out);
 
+/* ---- device-side ingest ("next" row N2): raw camera packets -> frames, the stream never leaves HBM ----------------------- */
+/* Replaces, per packet, what depth_reprojection_pipe.py:110-119 + trigger_finder.py:128-189 do on the host: polarity filter
+ * (p == 1), activity-noise filter, buffering, pause detection (diff(t) >= 40 us), frame cut (> 1/2 period, <= 1 period,
+ * > 1000 events, 2 events trimmed on both sides) -- all as kernels over a device-resident event buffer.  The cut frame is
+ * described by a record in DEVICE memory that the frame kernels read (K0 -> K1 -> K2, grids sized for the host's upper
+ * bound): no index and no event count ever travels to the host.  xm_ingest_push only copies the packet H2D (pinned staging
+ * ring) and enqueues a fixed sequence of launches; finished frames appear in a ring of pinned host buffers and are picked
+ * up with xm_ingest_poll.  One frame at most is cut per push, exactly like RobustTriggerFinder.process_events.
+ * Activity filter: Metavision's ActivityNoiseFilterAlgorithm is closed source; the rule implemented here (own definition,
+ * same in oracle/ingest_oracle.py): an event is kept iff an EARLIER event of the stream at one of its 8 neighbouring
+ * pixels has t - t' <= activity_thresh_us; every (positive) event then becomes its pixel's latest event. */
+typedef struct xm_ingest xm_ingest;
+typedef struct xm_ingest_config {
+  uint32_t struct_size;            /* = sizeof(xm_ingest_config) */
+  int32_t projector_fps;           /* frame period = 1e6 / fps us (RuntimeParams.projector_fps) */
+  int32_t use_polarity;            /* != 0: only events with p == 1 (PolarityFilterAlgorithm(1), pipe:43,114) */
+  int32_t activity_filter;         /* != 0: the activity rule above */
+  int64_t activity_thresh_us;      /* 0 => int(1e6 / fps) (pipe:65-68) */
+  int64_t pause_thresh_us;         /* 0 => 40 (trigger_finder.py:98) */
+  int32_t min_events_per_frame;    /* 0 => 1000 (trigger_finder.py:8) */
+  int32_t result_ring;             /* finished frames kept in pinned host memory before they are overwritten; 0 => 8 */
+  uint64_t capacity_events;        /* resident stream buffer, events (two buffers of this size); 0 => 2^21 */
+  uint64_t max_packet_events;      /* largest packet xm_ingest_push accepts; 0 => 2^19 */
+  uint64_t expected_events_per_frame; /* hint for the first frames' kernel choice (0: one thread per event until a frame
+                                         has been delivered; afterwards the stream's own density decides) */
+  int32_t want_depth, want_bgr;    /* which outputs the result ring holds */
+} xm_ingest_config;
+typedef struct xm_ingest_frame {
+  uint64_t seq;                    /* frame number, from 0 */
+  uint64_t n_events;               /* events of the cut frame */
+  int64_t t_first, t_last;         /* its first / last time stamp */
+  uint64_t n_inliers, n_index_errors;
+  uint64_t live_after;             /* events left in the device buffer after the cut */
+  uint32_t overflow;               /* events dropped so far because the device buffer was full */
+  uint32_t lost;                   /* != 0: the ring was lapped, frames between the previous one and this were overwritten */
+  const float* depth;              /* f32 [H][W] in the pinned ring (NULL if !want_depth); valid until result_ring - 1 */
+  const uint8_t* bgr;              /* u8 [H][W][3]                   further frames have been produced                 */
+} xm_ingest_frame;
+int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out);
+void xm_ingest_destroy(xm_ingest* g);
+/* one packet of raw EventCD records (host memory, any polarity, time-ordered as the camera delivers them); asynchronous */
+int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n);
+/* next finished frame, if any: returns 1 and fills *out, 0 if none is ready (never blocks), < 0 on error */
+int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
+int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */
+int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events */
+
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out);
 int xm_host_free(xm_handle* h, void* p);

@@ -1,0 +1,78 @@
+"""CPU restatement of the ingest chain in front of the hot path -- TEST INFRASTRUCTURE ONLY (see xmaps_oracle.py).
+
+  polarity_filter        PolarityFilterAlgorithm(1) as the reference uses it (python/depth_reprojection_pipe.py:43,114)
+  activity_filter        OWN DEFINITION (Metavision's ActivityNoiseFilterAlgorithm is closed source): an event
+                         is kept iff an EARLIER event of the (positive) stream at one of its 8 neighbouring pixels has
+                         t - t' <= thresh (thresh = int(1e6 / fps), pipe:65-68); every event, kept or not, then becomes its
+                         pixel's latest event.  Sequential by construction; the device evaluates the same rule in parallel.
+  TriggerFinderOracle    find_trigger / process_events of python/trigger_finder.py:128-189 written out over plain arrays
+                         (pinned by tests/golden/g5_trigger.npz in tests/test_oracle_ingest.py)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def polarity_filter(evs):
+    return evs[evs["p"] == 1]
+
+
+class ActivityFilterOracle:
+    def __init__(self, width, height, thresh_us):
+        self.w, self.h, self.thresh = int(width), int(height), int(thresh_us)
+        self.last = np.full((self.h, self.w), np.iinfo(np.int64).min, np.int64)
+        self.has = np.zeros((self.h, self.w), bool)
+
+    def process(self, evs):
+        """evs: positive events in stream order -> the kept ones."""
+        keep = np.zeros(len(evs), bool)
+        xs, ys, ts = evs["x"].astype(np.int64), evs["y"].astype(np.int64), evs["t"].astype(np.int64)
+        last, has, w, h, T = self.last, self.has, self.w, self.h, self.thresh
+        for i in range(len(evs)):
+            x, y, t = xs[i], ys[i], ts[i]
+            y0, y1, x0, x1 = max(y - 1, 0), min(y + 1, h - 1), max(x - 1, 0), min(x + 1, w - 1)
+            k = False
+            for yy in range(y0, y1 + 1):
+                for xx in range(x0, x1 + 1):
+                    if (yy != y or xx != x) and has[yy, xx] and t - last[yy, xx] <= T:
+                        k = True
+            keep[i] = k
+            if not has[y, x] or t > last[y, x]:
+                last[y, x] = t
+            has[y, x] = True
+        return evs[keep]
+
+
+class TriggerFinderOracle:
+    """python/trigger_finder.py:91-189 without the buffer-pool plumbing (no frame dropping: should_drop is never set when
+    RuntimeParams.no_frame_dropping is True, the default of this build)."""
+
+    def __init__(self, projector_fps, pause_thresh_us=40, min_events=1000):
+        self.period = 1e6 / projector_fps
+        self.pause, self.min_events = pause_thresh_us, min_events
+        self.buf = None
+        self.frames = []
+        self.ok = self.fail = 0
+
+    def process_events(self, evs):
+        if len(evs):
+            self.buf = evs if self.buf is None or len(self.buf) == 0 else np.concatenate((self.buf, evs))
+        if self.buf is None or len(self.buf) == 0:
+            return
+        if self.buf["t"][-1] - self.buf["t"][0] < self.period:
+            return
+        evs, self.buf = self.buf, None
+        t = evs["t"]
+        pauses = np.nonzero(np.diff(t) >= self.pause)[0]
+        for prev, nxt in zip(pauses[:-1], pauses[1:]):
+            gap = t[nxt] - t[prev]
+            if gap > self.period / 2:
+                if gap <= self.period and nxt - prev > self.min_events:
+                    self.frames.append(evs[prev + 2:nxt - 2].copy())
+                    self.buf = evs[nxt - 2:]
+                    self.ok += 1
+                else:
+                    self.buf = evs[nxt:]
+                    self.fail += 1
+                return
+        self.fail += 1

@@ -52,12 +52,15 @@ def test_header_is_plain_c_and_layouts_agree(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xmaps.h"\n'
                    'int main(void) {\n'
-                   '  printf("%zu %zu %zu %zu %d %d\\n", sizeof(xm_config), sizeof(xm_frame_stats), offsetof(xm_config, p03),\n'
-                   '         offsetof(xm_config, cam_mapx_i16), XM_ERR_UNSORTED, XM_MEM_HOST_PINNED);\n'
+                   '  printf("%zu %zu %zu %zu %d %d %zu %zu %zu %zu\\n", sizeof(xm_config), sizeof(xm_frame_stats), offsetof(xm_config, p03),\n'
+                   '         offsetof(xm_config, cam_mapx_i16), XM_ERR_UNSORTED, XM_MEM_HOST_PINNED, sizeof(xm_ingest_config),\n'
+                   '         sizeof(xm_ingest_frame), offsetof(xm_ingest_config, capacity_events), offsetof(xm_ingest_frame, depth));\n'
                    '  return 0;\n}\n')
     exe = tmp_path / "t"
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert [int(v) for v in out] == [ctypes.sizeof(N.xm_config), ctypes.sizeof(N.xm_frame_stats), N.xm_config.p03.offset,
-                                     N.xm_config.cam_mapx_i16.offset, N.XM_ERR_UNSORTED, N.XM_MEM_HOST_PINNED]
+                                     N.xm_config.cam_mapx_i16.offset, N.XM_ERR_UNSORTED, N.XM_MEM_HOST_PINNED,
+                                     ctypes.sizeof(N.xm_ingest_config), ctypes.sizeof(N.xm_ingest_frame),
+                                     N.xm_ingest_config.capacity_events.offset, N.xm_ingest_frame.depth.offset]

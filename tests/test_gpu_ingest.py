@@ -1,0 +1,177 @@
+"""-m gpu: device-side ingest (xm_ingest_*): raw packets -> polarity / activity filter -> pause detection -> frame cut ->
+K0/K1/K2 on the cut frame, all on the device, against the CPU chain oracle/ingest_oracle.py (+ the hot-path oracle) and the
+reference's own trigger-finder run (golden G5)."""
+import os
+
+import numpy as np
+import pytest
+
+import ingest_oracle as IO
+import xmaps_oracle as O
+from x_maps_amd import XMapsEngine
+from x_maps_amd import synthetic as S
+from x_maps_amd.ingest import DeviceIngest
+
+pytestmark = pytest.mark.gpu
+
+
+def _packets(stream, packet_us):
+    edges = np.arange(stream["t"][0], stream["t"][-1] + packet_us, packet_us)
+    cuts = np.searchsorted(stream["t"], edges)
+    return [stream[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def _tiny_stream(n_frames, seed, per_frame=2600, neg=0.1, gap_noise=3):
+    cfg = S.C_TINY
+    rng = np.random.default_rng(seed)
+    chunks = []
+    for f in range(n_frames):
+        start = 2_000_000 + f * 16_600
+        tt = np.unique(np.concatenate((np.sort(rng.integers(0, 13_000, per_frame)) + start, np.arange(start, start + 13_000, 25))))
+        ev = np.zeros(len(tt), S.EVENT_CD_DTYPE)
+        ev["t"] = tt
+        ev["x"] = np.clip((tt - start) / 13_000 * cfg.cam_w + rng.normal(0, 1.5, len(tt)), 0, cfg.cam_w - 1).astype(np.uint16)
+        ev["y"] = rng.integers(0, cfg.cam_h, len(tt))
+        ev["p"] = rng.random(len(tt)) >= neg
+        parts = [ev]
+        if gap_noise and f % gap_noise == gap_noise - 1:
+            nz = np.zeros(1, S.EVENT_CD_DTYPE)
+            nz["t"], nz["x"], nz["y"], nz["p"] = start + 14_500, 5, 5, 1
+            parts.append(nz)
+        chunks.append(np.concatenate(parts))
+    return np.concatenate(chunks)
+
+
+def _check_frames(tb, got, want_frames, camera=False):
+    assert len(got) == len(want_frames), (len(got), len(want_frames))
+    for fr, evs in zip(got, want_frames):
+        assert (fr.n_events, fr.t_first, fr.t_last) == (len(evs), int(evs["t"][0]), int(evs["t"][-1])), fr.seq
+        x, y, t, _ = S.to_soa(evs)
+        ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
+        assert fr.n_inliers == int(ref["mask"].sum()) and fr.n_index_errors == 0 and not fr.lost and fr.overflow == 0
+        assert np.array_equal(fr.depth, ref["depth"]) and np.array_equal(fr.bgr, ref["bgr"]), fr.seq
+
+
+def test_golden_trigger_stream_is_cut_on_the_device_like_the_reference(golden_dir):
+    """The reference's own RobustTriggerFinder run (golden G5: packets, frames' first/last t and lengths) reproduced by the
+    device-side segmentation; every frame's depth/BGR == oracle on those events."""
+    g = np.load(os.path.join(golden_dir, "g5_trigger.npz"))
+    ev = np.zeros(len(g["t"]), S.EVENT_CD_DTYPE)
+    ev["x"], ev["y"], ev["t"], ev["p"] = g["x"], g["y"], g["t"], 1
+    tb = S.make_tables(S.C_TINY)
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, int(g["fps"]), capacity_events=1 << 16, max_packet_events=1 << 13) as ing:
+        got = []
+        cuts = g["packet_cuts"]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ing.push(ev[a:b])
+            got += ing.poll()
+        ing.flush()
+        got += ing.poll()
+    assert len(got) == int(g["n_frames"])
+    assert [f.n_events for f in got] == list(g["frame_len"])
+    assert [f.t_first for f in got] == list(g["frame_first_t"]) and [f.t_last for f in got] == list(g["frame_last_t"])
+    tf = IO.TriggerFinderOracle(int(g["fps"]))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        tf.process_events(ev[a:b])
+    _check_frames(tb, got, tf.frames)
+
+
+@pytest.mark.parametrize("camera", [False, True])
+@pytest.mark.parametrize("activity", [False, True])
+def test_filters_and_segmentation_match_the_cpu_chain(camera, activity):
+    """Polarity filter + (own-definition) activity filter + segmentation on the device == the sequential CPU chain, on a
+    stream with negative events, gap noise and a buffer small enough to force several compactions."""
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(14, seed=7 + activity)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    tf = IO.TriggerFinderOracle(60)
+    act = IO.ActivityFilterOracle(S.C_TINY.cam_w, S.C_TINY.cam_h, int(1e6 / 60))
+    for p in pk:
+        pos = IO.polarity_filter(p)
+        tf.process_events(act.process(pos) if activity else pos)
+    assert len(tf.frames) >= 4  # the reference finder loses lock easily (a buffer with a single pause is dropped): by design
+    with XMapsEngine(tb, camera_perspective=camera) as eng, \
+            DeviceIngest(eng, 60, activity_filter=activity, capacity_events=1 << 13, max_packet_events=1 << 11) as ing:
+        got = []
+        for p in pk:
+            ing.push(p)
+            got += ing.poll()
+        ing.flush()
+        got += ing.poll()
+    _check_frames(tb, got, tf.frames, camera)
+
+
+def test_activity_filter_with_packets_longer_than_its_threshold():
+    """Packets spanning several thresholds are split into sub-packets on the way in; the result is the same rule."""
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(10, seed=21)
+    tf = IO.TriggerFinderOracle(60)
+    act = IO.ActivityFilterOracle(S.C_TINY.cam_w, S.C_TINY.cam_h, 2_000)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    for p in pk:
+        tf.process_events(act.process(IO.polarity_filter(p)))
+    assert len(tf.frames) >= 2
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, activity_filter=True, activity_thresh_us=2_000,
+                                              capacity_events=1 << 14, max_packet_events=1 << 12) as ing:
+        got = []
+        for p in pk:  # 4.2 ms packets against a 2 ms threshold
+            ing.push(p)
+        ing.flush()
+        got += ing.poll()
+    _check_frames(tb, got, tf.frames)
+
+
+def test_esl_like_stream_stays_on_the_device():
+    """BASELINE config 3 stand-in through the device-side ingest: ~150 k events / frame, negative events, gap noise; frames
+    go through the one-thread-per-event K1 first and the tiled one once the stream's density is known."""
+    from x_maps_amd import rig
+    cp, tb, _, _ = rig.make_esl_like(row_stride=13)
+    stream, _ = rig.render_stream(cp, tb, n_frames=12, row_stride=13, seed=5)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    tf = IO.TriggerFinderOracle(60)
+    for p in pk:
+        tf.process_events(IO.polarity_filter(p))
+    assert len(tf.frames) >= 4
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 20, max_packet_events=1 << 17) as ing:
+        got = []
+        for p in pk:
+            ing.push(p)
+            got += ing.poll()
+        ing.flush()
+        got += ing.poll()
+    _check_frames(tb, got, tf.frames)
+
+
+def test_pipe_with_device_ingest_calls_back_with_the_same_frames():
+    """DepthReprojectionProcessor(params) with device_ingest=True: process_events(packet) pushes the RAW packet; the frames
+    handed to the window equal those of the host path (polarity filter + host trigger finder + fused frame)."""
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor, RuntimeParams
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    stream = _tiny_stream(9, seed=3)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+
+    def run(device_ingest):
+        shown = []
+
+        class Window:
+            def should_close(self):
+                return False
+
+            def show_async(self, img):
+                shown.append(img)
+
+        params = RuntimeParams(camera_width=cfg.cam_w, camera_height=cfg.cam_h, projector_width=cfg.proj_w,
+                               projector_height=cfg.proj_h, projector_fps=60, z_near=0.1, z_far=1.2, calib=None,
+                               projector_time_map=None, no_frame_dropping=True, camera_perspective=False, tables=tb,
+                               device_ingest=device_ingest)
+        with DepthReprojectionProcessor(params, window=Window()) as proc:
+            for p in pk:
+                proc.process_events(p)
+            proc.flush()
+        return shown
+
+    a, b = run(False), run(True)
+    assert len(a) == len(b) >= 3
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

@@ -90,6 +90,24 @@ class xm_frame_stats(C.Structure):
     ]
 
 
+class xm_ingest_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("projector_fps", C.c_int32), ("use_polarity", C.c_int32), ("activity_filter", C.c_int32),
+        ("activity_thresh_us", C.c_int64), ("pause_thresh_us", C.c_int64),
+        ("min_events_per_frame", C.c_int32), ("result_ring", C.c_int32),
+        ("capacity_events", C.c_uint64), ("max_packet_events", C.c_uint64), ("expected_events_per_frame", C.c_uint64),
+        ("want_depth", C.c_int32), ("want_bgr", C.c_int32),
+    ]
+
+
+class xm_ingest_frame(C.Structure):
+    _fields_ = [
+        ("seq", C.c_uint64), ("n_events", C.c_uint64), ("t_first", C.c_int64), ("t_last", C.c_int64),
+        ("n_inliers", C.c_uint64), ("n_index_errors", C.c_uint64), ("live_after", C.c_uint64),
+        ("overflow", C.c_uint32), ("lost", C.c_uint32), ("depth", C.c_void_p), ("bgr", C.c_void_p),
+    ]
+
+
 # every symbol include/xmaps.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -126,6 +144,12 @@ SYMBOLS = {
     "xm_shard_finish": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
     "xm_frame_event_filter": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
     "xm_find_pauses": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "xm_ingest_create": (C.c_int, [_P, C.POINTER(xm_ingest_config), C.POINTER(_P)]),
+    "xm_ingest_destroy": (None, [_P]),
+    "xm_ingest_push": (C.c_int, [_P, _P, C.c_size_t]),
+    "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
+    "xm_ingest_flush": (C.c_int, [_P]),
+    "xm_ingest_reset": (C.c_int, [_P]),
     "xm_build_x_map": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "xm_stream": (_P, [_P, C.c_int]),
     "xm_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

@@ -76,9 +76,32 @@ class DepthReprojectionPipe:
         self.ev_filter_proc = FrameEventFilterProcessor(self.calib_maps.engine)
         self.trigger_finder = RobustTriggerFinder(projector_fps=p.projector_fps, stats=self.stats_printer,
                                                   frame_callback=self.process_ev_frame)
+        # device-side ingest (row N2): raw packets go to the GPU, which filters, buffers, cuts frames and runs the hot path on
+        # them without the event stream (or any index into it) coming back to the host
+        self.ingest = None
+        if getattr(p, "device_ingest", False):
+            from .ingest import DeviceIngest
+            self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
+                                       activity_filter=getattr(p, "activity_filter", False), want_depth=False)
 
     # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------
+    def _deliver_ingest_frames(self):
+        for fr in self.ingest.poll():
+            self.stats_printer.count("trig ✅")
+            self.stats_printer.add_metric("frame len [ms]", (fr.t_last - fr.t_first) / 1000)
+            self.last_ingest_frame = fr
+            self.frame_callback(fr.bgr)  # a fresh array, copied out of the pinned result ring
+
+    def flush(self):
+        if self.ingest is not None:
+            self.ingest.flush()
+            self._deliver_ingest_frames()
+
     def process_events(self, evs):
+        if self.ingest is not None:
+            self.ingest.push(evs)
+            self._deliver_ingest_frames()
+            return
         pos = evs[evs["p"] == 1]  # PolarityFilterAlgorithm(1), pipe:43,114
         if self.activity_filter is not None:
             pos = self.activity_filter(pos)
@@ -133,6 +156,10 @@ class DepthReprojectionPipe:
 
     def reset(self):
         self.trigger_finder.reset()
+        if self.ingest is not None:
+            self.ingest.reset()
 
     def close(self):
+        if self.ingest is not None:
+            self.ingest.close()
         self.calib_maps.engine.close()

@@ -42,6 +42,8 @@ class RuntimeParams:
     # additions of this build (defaults keep the reference's positional signature valid)
     tables: Optional[dict] = None  # pre-built tables instead of `calib`
     device: int = 0
+    device_ingest: bool = False  # polarity / activity filter + frame segmentation on the GPU (x_maps_amd/ingest.py)
+    activity_filter: bool = False  # device ingest only: the own-definition activity-noise rule (see xmaps_ingest.hpp)
 
     @property
     def should_drop_frames(self):
@@ -112,6 +114,10 @@ class DepthReprojectionProcessor:
         self.stats_printer.count("processed evs", len(evs))
         self._pipe.process_events(evs)
         self.stats_printer.print_stats_if_needed()
+
+    def flush(self):
+        """Device ingest: wait for the packets pushed so far and deliver the frames they produced."""
+        self._pipe.flush()
 
     def reset(self):
         self._pipe.reset()

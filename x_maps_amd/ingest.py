@@ -1,0 +1,118 @@
+"""Device-side ingest ("next" row N2): raw camera packets in, finished frames out, the event stream stays in HBM.
+
+    ing = DeviceIngest(engine, projector_fps=60, activity_filter=True)
+    for packet in camera:                    # EventCD records, any polarity
+        ing.push(packet)                     # H2D + a fixed sequence of launches, asynchronous
+        for frame in ing.poll():             # frames finished since the last call
+            show(frame.bgr)                  # fresh NumPy arrays (copied out of the pinned ring)
+    ing.flush(); frames = ing.poll()
+
+Replaces the host side of python/depth_reprojection_pipe.py:110-119 (PolarityFilterAlgorithm, ActivityNoiseFilterAlgorithm) and
+python/trigger_finder.py:128-189 (RobustTriggerFinder) with kernels (x_maps_amd/csrc/xmaps_ingest.hpp); the frame that is cut
+is handed to the fused K0 -> K1 -> K2 launches through a descriptor in device memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+from .synthetic import EVENT_CD_DTYPE
+
+
+@dataclass
+class IngestFrame:
+    seq: int
+    n_events: int
+    t_first: int
+    t_last: int
+    n_inliers: int
+    n_index_errors: int
+    live_after: int
+    overflow: int
+    lost: bool
+    depth: np.ndarray | None
+    bgr: np.ndarray | None
+
+
+class DeviceIngest:
+    def __init__(self, engine, projector_fps: int, use_polarity: bool = True, activity_filter: bool = False,
+                 activity_thresh_us: int = 0, capacity_events: int = 0, max_packet_events: int = 0, result_ring: int = 8,
+                 expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True):
+        self._e = engine
+        self._lib = engine._lib
+        cfg = N.xm_ingest_config()
+        cfg.struct_size = C.sizeof(N.xm_ingest_config)
+        cfg.projector_fps = int(projector_fps)
+        cfg.use_polarity = int(use_polarity)
+        cfg.activity_filter = int(activity_filter)
+        cfg.activity_thresh_us = int(activity_thresh_us)
+        cfg.pause_thresh_us = 0
+        cfg.min_events_per_frame = 0
+        cfg.result_ring = int(result_ring)
+        cfg.capacity_events = int(capacity_events)
+        cfg.max_packet_events = int(max_packet_events)
+        cfg.expected_events_per_frame = int(expected_events_per_frame)
+        cfg.want_depth, cfg.want_bgr = int(want_depth), int(want_bgr)
+        self._g = C.c_void_p(None)
+        N.check(self._lib.xm_ingest_create(engine._h, C.byref(cfg), C.byref(self._g)))
+        self.max_packet = int(max_packet_events) or (1 << 19)
+        self.shape = (engine.out_h, engine.out_w)
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            self._lib.xm_ingest_destroy(self._g)
+            self._g = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def push(self, evs: np.ndarray):
+        """One packet of EventCD records; larger packets are split (every piece is a packet of its own for the trigger
+        finder's once-per-packet decision, like feeding the reference smaller packets)."""
+        if evs.dtype != EVENT_CD_DTYPE:
+            evs = evs.astype(EVENT_CD_DTYPE)
+        evs = np.ascontiguousarray(evs)
+        if len(evs) == 0:
+            N.check(self._lib.xm_ingest_push(self._g, None, 0))
+            return
+        for a in range(0, len(evs), self.max_packet):
+            part = evs[a:a + self.max_packet]
+            N.check(self._lib.xm_ingest_push(self._g, C.c_void_p(part.ctypes.data), len(part)))
+
+    def poll(self) -> list[IngestFrame]:
+        out = []
+        fr = N.xm_ingest_frame()
+        h, w = self.shape
+        while True:
+            rc = self._lib.xm_ingest_poll(self._g, C.byref(fr))
+            if rc < 0:
+                N.check(rc)
+            if rc == 0:
+                break
+            depth = bgr = None
+            if fr.depth:
+                depth = np.ctypeslib.as_array(C.cast(fr.depth, C.POINTER(C.c_float)), shape=(h, w)).copy()
+            if fr.bgr:
+                bgr = np.ctypeslib.as_array(C.cast(fr.bgr, C.POINTER(C.c_uint8)), shape=(h, w, 3)).copy()
+            out.append(IngestFrame(int(fr.seq), int(fr.n_events), int(fr.t_first), int(fr.t_last), int(fr.n_inliers),
+                                   int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), bool(fr.lost), depth, bgr))
+        return out
+
+    def flush(self):
+        N.check(self._lib.xm_ingest_flush(self._g))
+
+    def reset(self):
+        N.check(self._lib.xm_ingest_reset(self._g))
