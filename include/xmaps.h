@@ -285,6 +285,18 @@ void* xm_stream(xm_handle* h, int slot);
 int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
                    int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out);
 
+/* ---- evaluation metrics ("next" row N4), python/eval/create_evaluation_table.py:14-63 --------------------------------- */
+/* evaluation_stats(estimate, groundtruth) on two f32 depth maps [height][width] (host pointers, synchronous, no handle):
+ * fill rate, RMSE, % of pixels off by more than 1 / 5 / 10 (the script's unit is cm), and the margin (1 % of the mean
+ * ground-truth depth).  filter != 0 first applies load_and_filter(estimate, gt, min_depth, max_depth) (:57-62). */
+typedef struct xm_eval_result {
+  double fillrate, rmse, perc_1, perc_5, perc_10, margin;
+  uint64_t n_valid;   /* pixels with gt > 0 and estimate > 0 (the RMSE's support) */
+  uint64_t n_gt_zero; /* pixels without ground truth */
+} xm_eval_result;
+int xm_eval_stats(int device, const float* estimate, const float* groundtruth, int height, int width, int filter,
+                  float min_depth, float max_depth, xm_eval_result* out);
+
 /* ---- per-frame de-duplication filters ("next" row N3), frame_event_filter.py:19-128 --------------------------- */
 #define XM_FILTER_FIRST_PER_YT 1      /* FirstEventPerYTFilter          (:68-97)  cell = (y, xp[i])          */
 #define XM_FILTER_FIRST_PER_XY 2      /* FirstEventPerXYFilter          (:43-65)  cell = (y, x)              */
@@ -349,6 +361,9 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
 void xm_ingest_destroy(xm_ingest* g);
 /* one packet of raw EventCD records (host memory, any polarity, time-ordered as the camera delivers them); asynchronous */
 int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n);
+/* the same from PINNED host memory (xm_host_alloc / hipHostMalloc): no staging copy on the host; the packet must stay
+ * untouched until 4 further packets have been pushed or xm_ingest_flush() has returned */
+int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n);
 /* next finished frame, if any: returns 1 and fills *out, 0 if none is ready (never blocks), < 0 on error */
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
 int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */

@@ -360,3 +360,28 @@ def compute_x_map_from_time_map(time_map, x_map_width, t_px_scale, x_offset, num
         x_map[yy, keep] = (best[keep] + x_offset).astype(np.int16)
         t_diffs[yy, keep] = dmin[keep].astype(np.float32)
     return x_map, t_diffs
+
+
+# ---- N4: evaluation metrics (python/eval/create_evaluation_table.py:14-63) ---------------------------------------------------
+def load_and_filter(result, gt, min_depth, max_depth):
+    result = np.array(result, copy=True)
+    result[result >= max_depth] = 0
+    result[result <= min_depth] = 0
+    result[gt == 0] = 0
+    return result
+
+
+def evaluation_stats(estimate, groundtruth):
+    """-> dict(fillrate, rmse, perc_1, perc_5, perc_10, margin), the arithmetic of class evaluation_stats."""
+    gt, est = np.asarray(groundtruth), np.asarray(estimate)
+    with np.errstate(all="ignore"):
+        margin = 0.01 * np.sum(gt[gt > 0]) / np.sum(gt > 0)
+        diff = np.abs(gt - est)
+        diff[gt == 0] = 0
+        fillrate = (np.sum(diff < margin) - np.sum(gt == 0)) / (diff.shape[0] * diff.shape[1] - np.sum(gt == 0))
+        diff_sq = pow(gt - est, 2)
+        valid = (gt > 0) & (est > 0)
+        rmse = np.sqrt(np.sum(diff_sq[valid]) / np.sum(valid)) if np.sum(valid) > 0 else 0
+        n = diff.shape[0] * diff.shape[1]
+    return {"fillrate": float(fillrate), "rmse": float(rmse), "perc_1": float(100 * np.sum(diff > 1) / n),
+            "perc_5": float(100 * np.sum(diff > 5) / n), "perc_10": float(100 * np.sum(diff > 10) / n), "margin": float(margin)}

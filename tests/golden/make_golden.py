@@ -322,7 +322,42 @@ def g5_trigger_and_filters(ref):
     save("g5_filters.npz", x=fe["x"], y=fe["y"], t=fe["t"], p=fe["p"], xp=xp, **out)
 
 
+def g8_eval_metrics():
+    """The evaluation metrics of python/eval/create_evaluation_table.py:14-63 (class evaluation_stats, load_and_filter) run on
+    synthetic depth maps in centimetres (the script's unit: min 20, max 120).  The module imports esl_utilities (which pulls
+    cv2 / matplotlib) at its top: stubbed -- the two functions captured here do not touch it."""
+    _stub("esl_utilities", utils=object)
+    sys.path.insert(0, os.path.join(REF, "eval"))
+    import create_evaluation_table as cet
+    rng = np.random.default_rng(88)
+    cases = {}
+    for name, (h, w, hole_gt, hole_est, noise) in {"a": (48, 64, 0.2, 0.3, 0.4), "b": (120, 160, 0.35, 0.25, 2.5),
+                                                      "c": (31, 47, 0.0, 0.0, 8.0)}.items():
+        yy, xx = np.mgrid[0:h, 0:w]
+        gt = (60 + 25 * np.sin(xx / 37.0) + 15 * np.cos(yy / 23.0)).astype(np.float32)
+        gt[rng.random(gt.shape) < hole_gt] = 0
+        est_raw = (gt + rng.normal(0, noise, gt.shape)).astype(np.float32)
+        est_raw[rng.random(gt.shape) < hole_est] = 0
+        est_raw[rng.random(gt.shape) < 0.02] = 150  # beyond max_depth
+        est_raw[rng.random(gt.shape) < 0.02] = 5    # below min_depth
+        path = os.path.join("/tmp", f"g8_{name}.npy")
+        np.save(path, est_raw)
+        est = cet.load_and_filter(path, gt, 20, 120)
+        st = cet.evaluation_stats(est, gt)
+        cases[name] = dict(gt=gt, est_raw=est_raw, est=est,
+                           res=np.array([st.fillrate, st.rmse, st.perc_1, st.perc_5, st.perc_10, st.margin], np.float64))
+    # degenerate: estimate empty -> rmse branch "no valid values" (0)
+    gt = cases["a"]["gt"]
+    st = cet.evaluation_stats(np.zeros_like(gt), gt)
+    save("g8_eval_metrics.npz", min_depth=np.array(20.0), max_depth=np.array(120.0),
+         empty_res=np.array([st.fillrate, st.rmse, st.perc_1, st.perc_5, st.perc_10, st.margin], np.float64),
+         **{f"{k}_{f}": v[f] for k, v in cases.items() for f in v})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8_eval_metrics()
+        sys.exit(0)
     assert os.path.isdir(REF), "needs /root/reference (build container only)"
     ref = import_reference()
     g1_event_path(ref)

@@ -144,3 +144,16 @@ def test_eval_caller_matches_reference(golden_dir):
     assert cloud.dtype == np.float32 and cloud.shape == g["cloud"].shape
     assert np.array_equal(cloud, g["cloud"], equal_nan=True)
     assert np.isfinite(cloud).all() == bool((disp != 0).all())
+
+
+def test_eval_metrics_oracle_matches_reference(golden_dir):
+    """G8: class evaluation_stats + load_and_filter of python/eval/create_evaluation_table.py."""
+    g = np.load(os.path.join(golden_dir, "g8_eval_metrics.npz"))
+    for k in "abc":
+        est = O.load_and_filter(g[f"{k}_est_raw"], g[f"{k}_gt"], float(g["min_depth"]), float(g["max_depth"]))
+        assert np.array_equal(est, g[f"{k}_est"])
+        r = O.evaluation_stats(est, g[f"{k}_gt"])
+        got = np.array([r["fillrate"], r["rmse"], r["perc_1"], r["perc_5"], r["perc_10"], r["margin"]])
+        np.testing.assert_allclose(got, g[f"{k}_res"], rtol=1e-12, atol=0)
+    r = O.evaluation_stats(np.zeros_like(g["a_gt"]), g["a_gt"])
+    assert r["rmse"] == 0 and r["fillrate"] == g["empty_res"][0]

@@ -108,6 +108,11 @@ class xm_ingest_frame(C.Structure):
     ]
 
 
+class xm_eval_result(C.Structure):
+    _fields_ = [("fillrate", C.c_double), ("rmse", C.c_double), ("perc_1", C.c_double), ("perc_5", C.c_double),
+                ("perc_10", C.c_double), ("margin", C.c_double), ("n_valid", C.c_uint64), ("n_gt_zero", C.c_uint64)]
+
+
 # every symbol include/xmaps.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -147,9 +152,11 @@ SYMBOLS = {
     "xm_ingest_create": (C.c_int, [_P, C.POINTER(xm_ingest_config), C.POINTER(_P)]),
     "xm_ingest_destroy": (None, [_P]),
     "xm_ingest_push": (C.c_int, [_P, _P, C.c_size_t]),
+    "xm_ingest_push_pinned": (C.c_int, [_P, _P, C.c_size_t]),
     "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
     "xm_ingest_flush": (C.c_int, [_P]),
     "xm_ingest_reset": (C.c_int, [_P]),
+    "xm_eval_stats": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(xm_eval_result)]),
     "xm_build_x_map": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "xm_stream": (_P, [_P, C.c_int]),
     "xm_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

@@ -37,6 +37,33 @@ def open_calibration_data(path: str) -> dict:
         return yaml.safe_load(f)
 
 
+def read_opencv_filestorage(path: str) -> dict:
+    """cv2.FileStorage(path, FILE_STORAGE_READ) for the YAML flavour OpenCV writes (`%YAML:1.0` directive, matrices tagged
+    `!!opencv-matrix` with rows / cols / dt / data) -- what the ESL dataset's calibration files are
+    (python/cam_proj_calibration.py:119-125 reads cam_K, cam_kc, proj_K, proj_kc, R, T from one).  Returns name -> ndarray
+    (matrices) or plain Python values."""
+    import yaml
+
+    class _Loader(yaml.SafeLoader):
+        pass
+
+    def _matrix(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        dt = str(m.get("dt", "d"))
+        np_dt = {"d": np.float64, "f": np.float32, "i": np.int32, "u": np.uint8, "s": np.int16, "w": np.uint16, "c": np.int8}[dt[-1]]
+        ch = int(dt[:-1]) if len(dt) > 1 else 1
+        a = np.array(m["data"], dtype=np_dt)
+        return a.reshape(int(m["rows"]), int(m["cols"])) if ch == 1 else a.reshape(int(m["rows"]), int(m["cols"]), ch)
+
+    _Loader.add_constructor("tag:yaml.org,2002:opencv-matrix", _matrix)
+    with open(path, "r") as f:
+        text = f.read()
+    lines = text.splitlines()
+    if lines and lines[0].startswith("%YAML"):  # OpenCV writes "%YAML:1.0", which is not a valid YAML directive
+        lines = lines[1:]
+    return yaml.load("\n".join(lines), Loader=_Loader) or {}
+
+
 # ---- small geometry kit ----------------------------------------------------------------------------------
 def rodrigues(v) -> np.ndarray:
     """rotation vector (3,) -> matrix, or matrix (3,3) -> vector (cv::Rodrigues)."""
@@ -239,15 +266,40 @@ class CamProjCalibrationParams:
             read_cv_matrix(data, "relative_rotation"), read_cv_matrix(data, "relative_translation"))
 
 
+    @staticmethod
+    def from_ESL_yaml(path, camera_width, camera_height, projector_width, projector_height, rectification_scale=3):
+        """python/cam_proj_calibration.py:110-140: the ESL dataset's OpenCV-FileStorage calibration (cam_K, cam_kc, proj_K,
+        proj_kc, R, T); the rectified frame is 3 x the PROJECTOR size; the projector's distortion is kept."""
+        fs = read_opencv_filestorage(path)
+        need = ("cam_K", "cam_kc", "proj_K", "proj_kc", "R", "T")
+        missing = [k for k in need if k not in fs]
+        if missing:
+            raise ValueError(f"{path}: missing node(s) {missing}")
+        return CamProjCalibrationParams(
+            camera_width, camera_height, projector_width, projector_height,
+            round(projector_width * rectification_scale), round(projector_height * rectification_scale),
+            np.asarray(fs["cam_K"], np.float64), np.asarray(fs["cam_kc"], np.float64),
+            np.asarray(fs["proj_K"], np.float64), np.asarray(fs["proj_kc"], np.float64),
+            np.asarray(fs["R"], np.float64), np.asarray(fs["T"], np.float64))
+
+
+def build_eval_tables(cp: CamProjCalibrationParams, **kw) -> dict:
+    """The table configuration of the offline evaluation (python/eval/compute_depth_x_maps.py:57-77): CamProjMaps(calib,
+    zero_undistort_proj_map=True) and ProjectorTimeMap.from_calib(scan_upwards=False, remap_border_mode=BORDER_CONSTANT)."""
+    return build_tables(cp, scan_upwards=False, zero_undistort_proj_map=True, time_map_border="constant", **kw)
+
+
 def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwards=True, device: int = 0,
-                 x_map_on_gpu: bool = True, projector_time_map_rectified: Optional[np.ndarray] = None) -> dict:
+                 x_map_on_gpu: bool = True, projector_time_map_rectified: Optional[np.ndarray] = None,
+                 zero_undistort_proj_map: bool = False, time_map_border: str = "replicate") -> dict:
     """Everything DepthReprojectionPipe.__post_init__ builds (python/depth_reprojection_pipe.py:69-99), as the
     tables dict XMapsEngine / RuntimeParams.tables take.  Projector = camera 1 of the stereo pair (calib:194-217)."""
     size = (cp.rect_image_width, cp.rect_image_height)
     R1, R2, P1, P2, Q = stereo_rectify(cp.projector_K, cp.projector_D, cp.camera_K, cp.camera_D, size, cp.cam2proj_R,
                                        cp.cam2proj_T)
     # forward maps (rectified pixel -> source pixel) for the projector: used to rectify the time map
-    pmx, pmy = init_undistort_rectify_map(cp.projector_K, cp.projector_D, R2, P2, size)
+    # "ESL compatibility: projector distortion is ignored here, but still used in cv2.stereoRectify" (calib:229-230)
+    pmx, pmy = init_undistort_rectify_map(cp.projector_K, np.zeros(5) if zero_undistort_proj_map else cp.projector_D, R2, P2, size)
     # inverse maps (source pixel -> rectified coords), rounded to int16: the per-event LUT and the projector map
     cmx, cmy = init_undistort_rectify_map_inverse(cp.camera_K, cp.camera_D, R1, P1, (cp.camera_width, cp.camera_height))
     qmx, qmy = init_undistort_rectify_map_inverse(cp.projector_K, cp.projector_D, R2, P2,
@@ -256,7 +308,7 @@ def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwar
         time_map_rect = np.ascontiguousarray(projector_time_map_rectified, dtype=np.float32)
     else:                                         # ProjectorTimeMap.from_calib (:36-44)
         time_map = generate_linear_projector_time_map(cp.projector_width, cp.projector_height, scan_upwards)
-        time_map_rect = remap_nearest(time_map, pmx, pmy, "replicate")
+        time_map_rect = remap_nearest(time_map, pmx, pmy, time_map_border)  # BORDER_REPLICATE live, BORDER_CONSTANT in eval
     x_off, xw = 4242, cp.projector_width
     if x_map_on_gpu:
         from .x_map import compute_x_map_from_time_map
@@ -272,4 +324,6 @@ def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwar
         "z_near": z_near, "z_far": z_far,
         # kept for tests / rigs
         "R1": R1, "R2": R2, "P1": P1, "P2": P2, "Q": Q, "time_map_rect": time_map_rect,
+        # float rectify maps of the camera: rectify_cam_coords_f32 / the point cloud of the evaluation caller (calib:238-245)
+        "cam_mapx_f32": cmx, "cam_mapy_f32": cmy,
     }

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <limits>
 #include <memory>
 #include <algorithm>
@@ -2352,7 +2353,11 @@ void xm_ingest_destroy(xm_ingest* g) {
   delete g;
 }
 
-int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n) {
+static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinned);
+int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n) { return ingest_push(g, eventcd16, n, false); }
+int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n) { return ingest_push(g, eventcd16_pinned, n, true); }
+
+static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinned) {
   if (!g || (n && !eventcd16)) return fail(XM_ERR_INVALID, "NULL argument");
   xm_handle* h = g->h;
   HIP_TRY(hipSetDevice(h->cfg.device));
@@ -2360,10 +2365,11 @@ int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n) {
   hipStream_t s = g->stream;
   const int k = g->pkt_next;
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
+  const uint4* hp = pinned ? (const uint4*)eventcd16 : g->h_pkt[k];
   if (n) {
     if (g->pkt_used[k]) HIP_TRY(hipEventSynchronize(g->pkt_ev[k]));  // the staging entry's previous packet has been consumed
-    memcpy(g->h_pkt[k], eventcd16, n * 16);
-    HIP_TRY(hipMemcpyAsync(g->d_pkt[k], g->h_pkt[k], n * 16, hipMemcpyHostToDevice, s));
+    if (!pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
+    HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, s));
   }
   // room for this packet behind the write cursor (device-side decision; the live part moves to the other buffer)
   hipLaunchKernelGGL(k_ing_compact, dim3(256), dim3(BLOCK), 0, s, g->st, g->buf[0], g->buf[1], g->capacity, (u64)g->max_packet);
@@ -2372,7 +2378,6 @@ int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n) {
   const int cw = h->tb.cam_w, ch = h->tb.cam_h;
   // sub-packets whose time span (max - min) stays within the activity threshold (see xmaps_ingest.hpp)
   size_t a = 0;
-  const uint4* hp = g->h_pkt[k];
   while (a < n) {
     size_t b = n;
     if (act) {
@@ -2517,6 +2522,54 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
   if (d_x) (void)hipFree(d_x);
   if (d_d) (void)hipFree(d_d);
   return rc;
+}
+
+// ---- N4: evaluation metrics -------------------------------------------------------------------------------------
+int xm_eval_stats(int device, const float* estimate, const float* groundtruth, int height, int width, int filter,
+                  float min_depth, float max_depth, xm_eval_result* out) {
+  if (!estimate || !groundtruth || !out || height <= 0 || width <= 0) return fail(XM_ERR_INVALID, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(XM_ERR_HIP, "no HIP device visible");
+  HIP_TRY(hipSetDevice(device));
+  const u64 n = (u64)height * width;
+  float *d_e = nullptr, *d_g = nullptr;
+  EvalAcc* d_a = nullptr;
+  int rc = XM_OK;
+  EvalAcc a;
+  memset(&a, 0, sizeof a);
+  do {
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_e, n * 4)) != hipSuccess || (e = hipMalloc((void**)&d_g, n * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_a, sizeof(EvalAcc))) != hipSuccess ||
+        (e = hipMemcpy(d_e, estimate, n * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_g, groundtruth, n * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemset(d_a, 0, sizeof(EvalAcc))) != hipSuccess) {
+      rc = fail(XM_ERR_HIP, "xm_eval_stats: %s", hipGetErrorString(e));
+      break;
+    }
+    unsigned grid = grid_for(n, BLOCK * 8);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((k_eval_stats<1>), dim3(grid), dim3(BLOCK), 0, 0, (const float*)d_e, (const float*)d_g, n, filter, min_depth, max_depth, d_a);
+    hipLaunchKernelGGL((k_eval_stats<2>), dim3(grid), dim3(BLOCK), 0, 0, (const float*)d_e, (const float*)d_g, n, filter, min_depth, max_depth, d_a);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(&a, d_a, sizeof a, hipMemcpyDeviceToHost)) != hipSuccess) {
+      rc = fail(XM_ERR_HIP, "xm_eval_stats: %s", hipGetErrorString(e));
+      break;
+    }
+  } while (0);
+  if (d_e) (void)hipFree(d_e);
+  if (d_g) (void)hipFree(d_g);
+  if (d_a) (void)hipFree(d_a);
+  if (rc) return rc;
+  const double hw = (double)n;
+  out->margin = 0.01 * a.sum_gt / (double)a.n_gt_pos;
+  out->fillrate = ((double)a.n_close - (double)a.n_gt_zero) / (hw - (double)a.n_gt_zero);
+  out->rmse = a.n_valid ? std::sqrt(a.sum_sq / (double)a.n_valid) : 0.0;
+  out->perc_1 = 100.0 * (double)a.n1 / hw;
+  out->perc_5 = 100.0 * (double)a.n5 / hw;
+  out->perc_10 = 100.0 * (double)a.n10 / hw;
+  out->n_valid = a.n_valid;
+  out->n_gt_zero = a.n_gt_zero;
+  return XM_OK;
 }
 
 // ---- pinned host memory --------------------------------------------------------------------------------------

@@ -2136,6 +2136,80 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_pause_emit(const u32* __restrict
   if (i < n && flags[i]) out[sums[blockIdx.x] + pos[i]] = i;
 }
 
+// =====================================================================================================
+// N4: evaluation metrics of the reference's table script (python/eval/create_evaluation_table.py:14-63):
+//   load_and_filter : est >= max_depth -> 0, est <= min_depth -> 0, est[gt == 0] = 0
+//   evaluation_stats: margin = 0.01 * mean(gt[gt > 0]); fill rate = (#(|gt - est| < margin, with the difference zeroed where
+//   gt == 0) - #(gt == 0)) / (H W - #(gt == 0)); RMSE over (gt > 0) & (est > 0); % of pixels whose error exceeds 1 / 5 / 10
+//   (error zeroed where gt == 0).  Differences are taken in f32 like NumPy does on f32 maps; sums are accumulated in f64
+//   (the reference's f32 pairwise sums agree to ~1e-7 relative).  Two passes: pass 1 the margin's sum / count, pass 2 the rest.
+// =====================================================================================================
+struct EvalAcc {
+  double sum_gt, sum_sq;
+  u64 n_gt_pos, n_gt_zero, n_close, n_valid, n1, n5, n10;
+};
+
+__device__ inline float eval_filtered(float est, float gt, int filter, float min_d, float max_d) {
+  if (filter) {
+    if (est >= max_d) est = 0.0f;
+    if (est <= min_d) est = 0.0f;
+    if (gt == 0.0f) est = 0.0f;
+  }
+  return est;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void k_eval_stats(const float* __restrict__ est, const float* __restrict__ gt, u64 n,
+                                                      int filter, float min_d, float max_d, EvalAcc* acc) {
+  double s = 0.0;
+  u64 c[7] = {0, 0, 0, 0, 0, 0, 0};
+  double margin = 0.0;
+  if (PASS == 2) margin = 0.01 * acc->sum_gt / (double)acc->n_gt_pos;  // NaN when no gt > 0, like NumPy's 0 / 0
+  const u64 stride = (u64)gridDim.x * BLOCK;
+  for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const float g = gt[i];
+    if (PASS == 1) {
+      if (g > 0.0f) {
+        s += (double)g;
+        c[0] += 1;
+      }
+    } else {
+      const float e = eval_filtered(est[i], g, filter, min_d, max_d);
+      const float d = g - e;
+      const float a = g == 0.0f ? 0.0f : fabsf(d);
+      c[1] += g == 0.0f;
+      c[2] += (double)a < margin;
+      if (g > 0.0f && e > 0.0f) {
+        c[3] += 1;
+        s += (double)(d * d);  // pow(gt - est, 2) on f32 arrays is an f32 product
+      }
+      c[4] += a > 1.0f;
+      c[5] += a > 5.0f;
+      c[6] += a > 10.0f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) c[k] += __shfl_xor(c[k], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (PASS == 1) {
+      atomicAdd(&acc->sum_gt, s);
+      atomicAdd((unsigned long long*)&acc->n_gt_pos, (unsigned long long)c[0]);
+    } else {
+      atomicAdd(&acc->sum_sq, s);
+      atomicAdd((unsigned long long*)&acc->n_gt_zero, (unsigned long long)c[1]);
+      atomicAdd((unsigned long long*)&acc->n_close, (unsigned long long)c[2]);
+      atomicAdd((unsigned long long*)&acc->n_valid, (unsigned long long)c[3]);
+      atomicAdd((unsigned long long*)&acc->n1, (unsigned long long)c[4]);
+      atomicAdd((unsigned long long*)&acc->n5, (unsigned long long)c[5]);
+      atomicAdd((unsigned long long*)&acc->n10, (unsigned long long)c[6]);
+    }
+  }
+}
+
 // slot (re)initialisation: zero the key frame, arm min/max + counters, tag = 0
 __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __restrict__ frame, u64 n_cells,
                                                       unsigned char* __restrict__ dirty) {

@@ -1,0 +1,180 @@
+"""Prophesee EVT 3.0 RAW decoder ("next" row N4): the reader in front of the pipe, without the Metavision SDK.
+
+The reference reads its recordings through Metavision's closed readers (python/bias_events_iterator.py:53-96:
+RawReaderBase(input_filename, delta_t).load_delta_t(-1) yields EventCD packets).  EVT 3.0 itself is a public, documented
+format: an ASCII header (lines starting with '%'), then little-endian 16-bit words whose top 4 bits are the type:
+
+    0x0 EVT_ADDR_Y    y[10:0]                          (bit 11: camera id)      sets the current row
+    0x2 EVT_ADDR_X    x[10:0], polarity bit 11                                  ONE event at (x, current y, current t)
+    0x3 VECT_BASE_X   x[10:0], polarity bit 11                                  base column + polarity of the vectors below
+    0x4 VECT_12       12 valid bits                                             events at base + i for every set bit; base += 12
+    0x5 VECT_8        8 valid bits                                              same with 8; base += 8
+    0x6 EVT_TIME_LOW  t[11:0]          0x8 EVT_TIME_HIGH  t[23:12]              current time (us), 24 bits, wraps every 16.8 s
+    0xA EXT_TRIGGER, 0xE OTHERS, 0x7 / 0xF CONTINUED                            skipped here
+
+The decoder is a state machine over the words; `decode_evt3` evaluates it for a whole buffer at once with forward fills
+(np.maximum.accumulate of "index of the last word of type T") -- the same shape a device kernel would have (scan + gather).
+PARITY: unpinned against Metavision (closed, and no recording ships with the reference); pinned by a round trip through the
+encoder below and by hand-built word sequences (tests/test_evt3.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .synthetic import EVENT_CD_DTYPE
+
+T_ADDR_Y, T_ADDR_X, T_VECT_BASE_X, T_VECT_12, T_VECT_8, T_TIME_LOW, T_TIME_HIGH = 0x0, 0x2, 0x3, 0x4, 0x5, 0x6, 0x8
+
+
+def split_raw_header(blob: bytes) -> tuple[dict, int]:
+    """ASCII header of a .raw file: lines '% key value'; returns (fields, offset of the first data byte)."""
+    off, fields = 0, {}
+    while off < len(blob) and blob[off:off + 1] == b"%":
+        end = blob.find(b"\n", off)
+        if end < 0:
+            break
+        line = blob[off + 1:end].decode("ascii", "replace").strip()
+        off = end + 1
+        if line == "end":
+            break
+        k, _, v = line.partition(" ")
+        fields[k] = v
+    return fields, off
+
+
+def _ffill_index(mask: np.ndarray) -> np.ndarray:
+    """index of the last True at or before each position (-1 if none)"""
+    idx = np.where(mask, np.arange(len(mask)), -1)
+    return np.maximum.accumulate(idx)
+
+
+class Evt3Decoder:
+    """Streaming decoder: feed chunks of words, get EventCD arrays; state (row, base column, time, overflow count) carries over."""
+
+    def __init__(self):
+        self.y = 0
+        self.base_x = 0
+        self.base_p = 0
+        self.t_low = 0
+        self.t_high = 0
+        self.t_loops = 0  # number of 24-bit wrap-arounds seen
+        self.have_time = False
+
+    def decode(self, words: np.ndarray) -> np.ndarray:
+        w = np.ascontiguousarray(words, dtype="<u2").astype(np.int64)
+        n = len(w)
+        if n == 0:
+            return np.zeros(0, EVENT_CD_DTYPE)
+        typ = w >> 12
+        pos = np.arange(n)
+        # ---- time: last TIME_HIGH / TIME_LOW before each word; 24-bit wrap-arounds counted on the TIME_HIGH sequence ----
+        ih, il = _ffill_index(typ == T_TIME_HIGH), _ffill_index(typ == T_TIME_LOW)
+        hi_words = np.nonzero(typ == T_TIME_HIGH)[0]
+        th_seq = w[hi_words] & 0xfff
+        prev = np.concatenate(([self.t_high], th_seq[:-1])) if len(th_seq) else th_seq
+        # a wrap: the 12-bit high field falls back by (much) more than jitter would explain
+        wraps = np.cumsum((prev - th_seq) > 0x800) if len(th_seq) else np.zeros(0, np.int64)
+        loops_at = np.full(n, self.t_loops, np.int64)
+        if len(hi_words):
+            loops_at = np.where(ih >= 0, self.t_loops + wraps[np.searchsorted(hi_words, np.maximum(ih, 0))], self.t_loops)
+        t_high = np.where(ih >= 0, w[np.maximum(ih, 0)] & 0xfff, self.t_high)
+        t_low = np.where(il >= 0, w[np.maximum(il, 0)] & 0xfff, self.t_low)
+        t = (loops_at << 24) | (t_high << 12) | t_low
+        # ---- row: last ADDR_Y ----
+        iy = _ffill_index(typ == T_ADDR_Y)
+        y = np.where(iy >= 0, w[np.maximum(iy, 0)] & 0x7ff, self.y)
+        # ---- single events ----
+        sx = np.nonzero(typ == T_ADDR_X)[0]
+        # ---- vector events: base column of each VECT word = last VECT_BASE_X + what earlier VECT words since it consumed ----
+        adv = np.where(typ == T_VECT_12, 12, np.where(typ == T_VECT_8, 8, 0))
+        cum = np.cumsum(adv)
+        ib = _ffill_index(typ == T_VECT_BASE_X)
+        base = np.where(ib >= 0, w[np.maximum(ib, 0)] & 0x7ff, self.base_x)
+        pol = np.where(ib >= 0, (w[np.maximum(ib, 0)] >> 11) & 1, self.base_p)
+        cum_at_base = np.where(ib >= 0, cum[np.maximum(ib, 0)], 0)
+        vbase = base + (cum - adv - cum_at_base)
+        vw = np.nonzero(adv > 0)[0]
+        bits = (w[vw, None] >> np.arange(12)[None, :]) & 1
+        bits[typ[vw] == T_VECT_8, 8:] = 0
+        vr, vb = np.nonzero(bits)
+        vi = vw[vr]
+        # ---- merge in word order (a vector word's events in ascending column order) ----
+        n_ev = len(sx) + len(vi)
+        out = np.zeros(n_ev, EVENT_CD_DTYPE)
+        order_key = np.concatenate((sx * 16, vi * 16 + vb))
+        order = np.argsort(order_key, kind="stable")
+        xs = np.concatenate((w[sx] & 0x7ff, vbase[vi] + vb))[order]
+        ys = np.concatenate((y[sx], y[vi]))[order]
+        ps = np.concatenate(((w[sx] >> 11) & 1, pol[vi]))[order]
+        ts = np.concatenate((t[sx], t[vi]))[order]
+        out["x"], out["y"], out["p"], out["t"] = xs, ys, ps, ts
+        # ---- carry the state over to the next chunk ----
+        self.y = int(y[-1])
+        self.t_high, self.t_low = int(t_high[-1]), int(t_low[-1])
+        self.t_loops = int(loops_at[-1])
+        if ib[-1] >= 0 or len(vw):
+            self.base_x = int(base[-1] + (cum[-1] - cum_at_base[-1]))
+            self.base_p = int(pol[-1])
+        return out
+
+
+def decode_evt3(words: np.ndarray) -> np.ndarray:
+    return Evt3Decoder().decode(words)
+
+
+def read_raw(path: str, chunk_words: int = 1 << 22):
+    """Yields EventCD packets of a .raw file (EVT 3.0)."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    fields, off = split_raw_header(blob)
+    fmt = fields.get("evt", fields.get("format", "3.0"))
+    if "3" not in fmt:
+        raise ValueError(f"{path}: only EVT 3.0 is supported (header says {fmt!r})")
+    words = np.frombuffer(blob, dtype="<u2", offset=off, count=(len(blob) - off) // 2)
+    dec = Evt3Decoder()
+    for a in range(0, len(words), chunk_words):
+        ev = dec.decode(words[a:a + chunk_words])
+        if len(ev):
+            yield ev
+
+
+def encode_evt3(evs: np.ndarray, use_vectors: bool = True) -> np.ndarray:
+    """EventCD (time-ordered) -> EVT 3.0 words.  Test helper / file writer: runs of events that share (t, y, p) and have
+    increasing columns within a 12-column window become VECT_BASE_X + VECT_12, everything else EVT_ADDR_X."""
+    words = []
+    cur_y = cur_hi = cur_lo = None
+    x, y, p, t = (evs[k].astype(np.int64) for k in ("x", "y", "p", "t"))
+    n, i = len(evs), 0
+    while i < n:
+        hi, lo = (t[i] >> 12) & 0xfff, t[i] & 0xfff
+        if hi != cur_hi:
+            words.append((T_TIME_HIGH << 12) | hi)
+            cur_hi = hi
+        if lo != cur_lo:
+            words.append((T_TIME_LOW << 12) | lo)
+            cur_lo = lo
+        if y[i] != cur_y:
+            words.append((T_ADDR_Y << 12) | (y[i] & 0x7ff))
+            cur_y = y[i]
+        j = i + 1
+        while (use_vectors and j < n and t[j] == t[i] and y[j] == y[i] and p[j] == p[i] and x[j] > x[j - 1]
+               and x[j] - x[i] < 12):
+            j += 1
+        if j - i >= 2:
+            mask = 0
+            for k in range(i, j):
+                mask |= 1 << int(x[k] - x[i])
+            words.append((T_VECT_BASE_X << 12) | ((p[i] & 1) << 11) | (x[i] & 0x7ff))
+            words.append((T_VECT_12 << 12) | mask)
+        else:
+            words.append((T_ADDR_X << 12) | ((p[i] & 1) << 11) | (x[i] & 0x7ff))
+            j = i + 1
+        i = j
+    return np.array(words, dtype="<u2")
+
+
+def write_raw(path: str, evs: np.ndarray, width: int = 640, height: int = 480):
+    hdr = f"% evt 3.0\n% format EVT3;height={height};width={width}\n% geometry {width}x{height}\n% end\n".encode("ascii")
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(encode_evt3(evs).tobytes())

@@ -92,6 +92,13 @@ class DeviceIngest:
             part = evs[a:a + self.max_packet]
             N.check(self._lib.xm_ingest_push(self._g, C.c_void_p(part.ctypes.data), len(part)))
 
+    def push_pinned(self, evs: np.ndarray):
+        """A packet that already lives in pinned host memory (XMapsEngine.host_empty): no staging copy."""
+        assert evs.dtype == EVENT_CD_DTYPE and evs.flags.c_contiguous
+        for a in range(0, len(evs), self.max_packet):
+            part = evs[a:a + self.max_packet]
+            N.check(self._lib.xm_ingest_push_pinned(self._g, C.c_void_p(part.ctypes.data), len(part)))
+
     def poll(self) -> list[IngestFrame]:
         out = []
         fr = N.xm_ingest_frame()
