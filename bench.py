@@ -70,7 +70,9 @@ def parse_args():
     ap.add_argument("--general", action="store_true", help="XM_FLAG_GENERAL: extrema pass K0 on every frame")
     ap.add_argument("--assume-sorted", action="store_true",
                     help="XM_FLAG_TIME_SORTED: extrema = t[0], t[n-1], verified on the device, violations reported")
-    ap.add_argument("--launch-workers", action="store_true", help="XM_FLAG_LAUNCH_WORKERS: one launch thread per slot stream")
+    ap.add_argument("--no-launch-workers", action="store_true",
+                    help="launch from the calling thread (default: XM_FLAG_LAUNCH_WORKERS, one launch thread per slot stream -- the "
+                         "two kernel launches of a frame cost a Python caller ~10 us, about what the GPU needs for the frame)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra loops (forced general, declared sorted, ...)")
     ap.add_argument("--single-block", action="store_true", help="one timed block of K steps (no repetition)")
     return ap.parse_args()
@@ -273,7 +275,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     slots = args.slots or (max(4, 2 * args.batch) if args.batch else 4)
     mode_kw = {"force_general": args.general, "assume_time_sorted": args.assume_sorted}
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots,
-                      launch_workers=args.launch_workers, **mode_kw)
+                      launch_workers=not args.no_launch_workers, **mode_kw)
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 
@@ -311,11 +313,15 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
                                        offs, depth_out[o].data_ptr(), None if bgr_out is None else bgr_out[o].data_ptr())
             return step_group
 
+        # raw device pointers are taken once (a host holds them anyway); the step itself is one C-ABI call
+        fptr = [(fx.data_ptr(), fy.data_ptr(), ft.data_ptr()) for fx, fy, ft in frames]
+        optr = [(depth_out[o].data_ptr(), None if bgr_out is None else bgr_out[o].data_ptr()) for o in range(n_out)]
+        call = e.process_frame_device
+
         def step(i):
-            fx, fy, ft = frames[i % nf]
-            o = i % n_out
-            e.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, depth_out[o].data_ptr(),
-                                   None if bgr_out is None else bgr_out[o].data_ptr())
+            fx, fy, ft = fptr[i % nf]
+            d, b = optr[i % n_out]
+            call(fx, fy, ft, None, n_ev, d, b)
         return step
 
     def run_steps(step, k, start=0):
@@ -447,6 +453,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     if world == 1 and not args.no_other_modes and not args.batch:
         other_modes = {}
         modes = []
+        if not args.no_launch_workers:
+            modes.append(("launches_from_the_calling_thread", dict(mode_kw), camera, 0))
         if not args.general:
             modes.append(("forced_general", {"force_general": True}, camera, 0))
         if not args.assume_sorted:
@@ -456,7 +464,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             modes.append(("camera_view", dict(mode_kw), True, 0))
         for name, kw, cam, B in modes:
             nsl = max(slots, 2 * B) if B else slots
-            e2 = XMapsEngine(tables, camera_perspective=cam, device=local_rank, n_slots=nsl, **kw)
+            e2 = XMapsEngine(tables, camera_perspective=cam, device=local_rank, n_slots=nsl,
+                             launch_workers=(not args.no_launch_workers) and name != "launches_from_the_calling_thread", **kw)
             H2, W2 = e2.out_h, e2.out_w
             d2 = torch.empty((max(nsl, 1), H2, W2), dtype=torch.float32, device=dev)
             b2 = None if bgr_out is None else torch.empty((max(nsl, 1), H2, W2, 3), dtype=torch.uint8, device=dev)
@@ -496,7 +505,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             if same is not None:
                 other_modes[name]["depth_equals_oracle"] = same
             e2.close()
-        other_modes["note"] = ("forced_general = XM_FLAG_GENERAL (extrema pass K0 on every frame, what round 1 reported as the "
+        other_modes["note"] = ("launches_from_the_calling_thread = the same without XM_FLAG_LAUNCH_WORKERS; forced_general = XM_FLAG_GENERAL (extrema pass K0 on every frame, what round 1 reported as the "
                                "headline); declared_sorted = XM_FLAG_TIME_SORTED; batched_groups_of_8 = xm_process_batch, 8 "
                                "frames per set of multi-frame launches, two groups in flight; camera_view = "
                                "--camera-perspective with the default flags; `value` above = library defaults, one frame "
@@ -510,13 +519,14 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         "config": {"workload": "C-1M: synthetic 1M events/frame, 640x480 cam/proj, rect 1760x1320, 1xMI355X fused kernels"
                    + (" (camera view)" if camera else " (projector view)"),
                    "events_per_frame": n_ev, "frames_in_flight": slots, "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
-                   "launch": f"eager, groups of {args.batch} frames per call (xm_process_batch)" if args.batch else "eager, one frame per call",
+                   "launch": (f"eager, groups of {args.batch} frames per call (xm_process_batch)" if args.batch else "eager, one frame per call")
+                             + ("" if args.no_launch_workers else "; XM_FLAG_LAUNCH_WORKERS (a launch thread per slot stream)"),
                    "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM",
                    "distinct_frames_resident": nf, "resident_set_MB": round(resident_mb, 1),
                    "resident_set_vs_infinity_cache": "exceeds the 256 MiB MALL" if resident_mb > 268.4 else "fits the 256 MiB MALL",
                    "extrema": "XM_FLAG_GENERAL (K0 every frame)" if args.general else
                               ("XM_FLAG_TIME_SORTED" if args.assume_sorted else
-                               "library default: (t[0], t[n-1]) verified on the device, failing frames redone with K0"),
+                               "library default: (t[0], t[n-1]) verified on the device + compact 32-bit key frame, failing frames redone with K0 on the 64-bit path"),
                    "frames_redone_on_general_path": frames_redone},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
                    "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6),

@@ -18,3 +18,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_touches_the_gpu_first():
+    """PyTorch bundles its own HIP runtime; libxmaps_hip.so links the system one.  Whichever is loaded first serves both
+    (same SONAME), and torch only finds the GPU through its own copy: let torch initialise before the first handle is
+    created (INTEGRATION.md says the same for hosts that share a process with PyTorch)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield

@@ -56,13 +56,17 @@ def pmc_rows(pattern):
 
 with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of bench.py (MI355X)\n\n")
-    for key, title, cmd in (("trace_proj", "projector view, 1 slot (kernels back to back, no overlap)", "python bench.py --slots 1 --steps 200 --warmup 20 --no-cpu-baseline"),
-                            ("trace_cam", "camera view, 1 slot", "python bench.py --slots 1 --steps 200 --warmup 20 --no-cpu-baseline --camera-perspective"),
-                            ("trace_pipe8", "projector view, 4 frames in flight (the default bench configuration; under the profiler the launches no longer overlap)", "python bench.py --steps 400 --no-cpu-baseline")):
+    for key, title, cmd in (("trace_proj", "projector view, 1 slot, library defaults (kernels back to back, no overlap; no K0: verified (t[0], t[n-1]) shortcut)", "python bench.py --slots 1 --steps 200 --warmup 20 --no-cpu-baseline --no-other-modes --no-host-path"),
+                            ("trace_general", "projector view, 1 slot, XM_FLAG_GENERAL (K0 on every frame)", "... --general"),
+                            ("trace_cam", "camera view, 1 slot", "... --camera-perspective"),
+                            ("trace_pipe8", "projector view, 4 frames in flight (round-1 name)", "python bench.py --steps 400 --no-cpu-baseline"),
+                            ("trace_pipe", "projector view, 4 frames in flight (the default bench configuration; under the profiler the launches no longer overlap)", "python bench.py --steps 400 --no-cpu-baseline --no-other-modes --no-host-path"),
+                            ("trace_batch60", "multi-frame launches: 60 x C-1M frames per kernel launch (grid = frames x tiles), general path", "python tools/batch_probe.py 60 4"),
+                            ("trace_batch60_sorted", "multi-frame launches, 60 frames, declared time-sorted (no K0)", "python tools/batch_probe.py 60 4 1")):
         db = os.path.join(src, f"{key}_results.db")
         if os.path.exists(db):
             f.write(f"## {title}\n\n`rocprofv3 --kernel-trace --stats -- {cmd}`\n\n{trace_table(db)}\n\n")
-    for j in ("bench_default", "bench_camera", "bench_graph60"):
+    for j in ("bench_default", "bench_steps20", "bench_steps8000", "bench_camera", "bench_graph60", "bench_graph60_slots8", "bench_sharded"):
         p = os.path.join(src, j + ".json")
         if os.path.exists(p) and os.path.getsize(p):
             f.write(f"## {j}.json (un-profiled run on the same box)\n\n```json\n{open(p).read().strip()}\n```\n\n")
@@ -76,7 +80,8 @@ with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
     f.write("FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read\n"
             "(MI355X_MICROARCH.md section HBM; confirmed here: k_minmax reads exactly 8.0 MB of t and shows ~3.9 MB), so\n"
             "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE.\n\n")
-    for view, pat in (("projector", "pmc_proj_*_results.db"), ("camera", "pmc_cam_*_results.db")):
+    for view, pat in (("projector", "pmc_proj_*_results.db"), ("projector_general", "pmc_gen_*_results.db"),
+                      ("camera", "pmc_cam_*_results.db"), ("batch60", "pmc_batch_*_results.db")):
         rows = pmc_rows(pat)
         if not rows:
             continue
@@ -92,6 +97,9 @@ with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
             if lg and fs is not None and ws is not None:
                 traffic[view][lg] = {"kernel": k, "FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1),
                                      "hbm_bytes_per_launch": round((2 * fs + ws) * 1024)}
+if "projector" in traffic and "projector_general" in traffic:  # K0 only runs on the general path: its traffic comes from there
+    for k, v in traffic["projector_general"].items():
+        traffic["projector"].setdefault(k, v)
 if traffic:
     traffic["_note"] = ("per-launch HBM bytes of the C-1M bench workload from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
                         "2*FETCH_SIZE + WRITE_SIZE per the gfx950 calibration; source gpurun_out/%s, summary profiles/%s_pmc.md" % (tag, tag))

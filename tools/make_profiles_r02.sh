@@ -1,0 +1,47 @@
+#!/bin/bash
+# Runs on the MI355X box (gpurun): kernel traces + PMC passes of the round-2 bench workloads.  Every profiler run is bounded
+# by its own timeout; every --pmc group is its own run with --kernel-trace only (FETCH_SIZE and WRITE_SIZE separately).
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export XM_BENCH_PREWARM_S=0.05
+Q="--no-cpu-baseline --no-other-modes --no-host-path"
+T="timeout 240"
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_proj -- python bench.py --slots 1 --steps 200 --warmup 20 $Q > $OUT/trace_proj.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_general -- python bench.py --slots 1 --steps 200 --warmup 20 --general $Q > $OUT/trace_general.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_cam -- python bench.py --slots 1 --steps 200 --warmup 20 --camera-perspective $Q > $OUT/trace_cam.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_pipe -- python bench.py --steps 400 $Q > $OUT/trace_pipe.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_batch60 -- python tools/batch_probe.py 60 4 > $OUT/trace_batch60.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_batch60_sorted -- python tools/batch_probe.py 60 4 1 > $OUT/trace_batch60_sorted.log 2>&1
+PM="python bench.py --slots 1 --steps 40 --warmup 5 $Q"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "GRBM_GUI_ACTIVE TA_TA_BUSY_sum"; do
+  i=$((i+1))
+  $T rocprofv3 --kernel-trace --pmc $set -d $OUT -o pmc_proj_$i -- $PM > $OUT/pmc_proj_$i.log 2>&1 || echo "pmc_proj pass $i failed: $set"
+done
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  $T rocprofv3 --kernel-trace --pmc $set -d $OUT -o pmc_gen_$i -- $PM --general > $OUT/pmc_gen_$i.log 2>&1 || echo "pmc_gen pass $i failed"
+  $T rocprofv3 --kernel-trace --pmc $set -d $OUT -o pmc_cam_$i -- $PM --camera-perspective > $OUT/pmc_cam_$i.log 2>&1 || echo "pmc_cam pass $i failed"
+done
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "GRBM_GUI_ACTIVE TA_TA_BUSY_sum"; do
+  i=$((i+1))
+  $T rocprofv3 --kernel-trace --pmc $set -d $OUT -o pmc_batch_$i -- python tools/batch_probe.py 60 3 > $OUT/pmc_batch_$i.log 2>&1 || echo "pmc_batch pass $i failed: $set"
+done
+unset XM_BENCH_PREWARM_S
+timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 200 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+timeout 200 python bench.py --steps 8000 --no-cpu-baseline --no-other-modes --no-host-path > $OUT/bench_steps8000.json 2> $OUT/bench_steps8000.err
+timeout 200 python bench.py --graph > $OUT/bench_graph60.json 2> $OUT/bench_graph60.err
+timeout 200 python bench.py --graph --slots 8 --no-cpu-baseline > $OUT/bench_graph60_slots8.json 2> $OUT/bench_graph60_slots8.err
+timeout 200 python bench.py --sharded > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
+timeout 200 python bench.py --camera-perspective --no-cpu-baseline --no-other-modes > $OUT/bench_camera.json 2> $OUT/bench_camera.err
+ls $OUT | wc -l

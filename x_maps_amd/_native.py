@@ -175,6 +175,15 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    alt = os.environ.get("XM_LIB")  # experiments: an alternative build of the library (e.g. an ablation / prototype build)
+    if alt:
+        lib = C.CDLL(os.path.abspath(alt))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
     if build_if_missing and needs_build():
         if _hipcc() is not None:
             build_native()

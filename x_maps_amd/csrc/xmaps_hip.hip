@@ -100,6 +100,10 @@ struct Slot {
     u32 tag = 0;
   } prev;
   u64* key_frame = nullptr;
+  u32* key32 = nullptr;            // compact key frame of the verified-sorted projector-view path (see key32_tag)
+  u32 key32_valid_from = 0;        // tag of the frame before which key32 was last cleared: every key in it has a tag in
+                                   // [valid_from, valid_from + 15), so the 4-bit tag field is unambiguous
+  bool last_key32 = false;
   unsigned char* dirty = nullptr;  // projector view: one flag byte per 128-byte line of key_frame
   SlotState* st = nullptr;  // device
   u32 host_tag = 0;         // mirrors st->tag_a after the enqueued work has run
@@ -176,6 +180,9 @@ struct xm_handle {
                               // Measured: K2 fetches 37 % fewer bytes but is not faster (it is latency, not bandwidth bound)
   std::vector<hipStream_t> gstreams;  // default-priority streams the hipGraph batches are captured on and launched from
   std::vector<std::unique_ptr<Worker>> workers;  // one per slot stream (empty: launches happen in the calling thread)
+  bool key32_ok = false;      // the rig qualifies for the compact key frame (projector view, rect_h % 4 == 0, disparities < 4096)
+  int key32_score = 0;        // raised by frames that failed the compact path, decays with every frame that took it
+  int key32_pause = 0;        // frames for which the compact path stays switched off (it kept failing: sparse / noisy stream)
   bool time_sorted = false;   // XM_FLAG_TIME_SORTED
   bool try_sorted = false;    // XM_FLAG_TRY_SORTED
   bool gate_slots = false;    // experiments (XM_GATE_SLOTS=1): asynchronous calls wait (polling a pinned word) until the slot's previous frame has reached K2
@@ -259,6 +266,8 @@ int reset_slot(xm_handle* h, Slot& s, hipStream_t stream = nullptr) {
   if (!stream) stream = s.stream;
   hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
   HIP_TRY(hipGetLastError());
+  if (s.key32) HIP_TRY(hipMemsetAsync(s.key32, 0, h->key_cells * sizeof(u32), stream));
+  s.key32_valid_from = 0;
   s.host_tag = 0;
   s.api_tag = 0;
   if (s.h_flags) {  // tags start over: forget the verdicts of the old numbering (no frame of this slot is pending here)
@@ -327,6 +336,7 @@ struct ScatterArgs {
   size_t lds;
   bool direct;
   bool sorted;
+  bool key32;
 };
 
 template <typename T, bool AOS, bool HAS_P, int VIEW>
@@ -348,6 +358,14 @@ int launch_scatter_tv(const ScatterArgs& a) {
     auto kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, false>;
     if constexpr (kHasVec) {
       if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, true>;
+    }
+    if constexpr (VIEW == 0) {
+      if (a.key32) {  // compact key frame (a.frame points at it)
+        kern = k_scatter_tiled<T, AOS, HAS_P, 0, false, true>;
+        if constexpr (kHasVec) {
+          if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, 0, true, true>;
+        }
+      }
     }
     // raise the kernel's dynamic-LDS cap once per (handle = device, kernel instantiation); gfx950: 160 KB / CU
     {
@@ -386,9 +404,9 @@ int launch_scatter_t(const ScatterArgs& a) {
 
 int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_override, u64 idx_offset, u64 mm_lo,
                    u64 mm_hi, u64* frame, unsigned char* dirty, hipStream_t stream, bool sorted = false,
-                   const void* mm_ext = nullptr) {
+                   const void* mm_ext = nullptr, bool key32 = false) {
   ScatterArgs a{h, &ev, &h->tb, h->cfg.view, st, tag_override, idx_offset, mm_lo, mm_hi, mm_ext, frame, dirty, stream,
-                h->w_ts, h->w_x, h->k1_lds, h->k1_direct, sorted};
+                h->w_ts, h->w_x, h->k1_lds, h->k1_direct, sorted, key32};
   if (ev.aos) return ev.use_p ? launch_scatter_t<long long, true, true>(a) : launch_scatter_t<long long, true, false>(a);
   switch (ev.t_dtype) {
     case XM_T_INT64: return ev.use_p ? launch_scatter_t<long long, false, true>(a) : launch_scatter_t<long long, false, false>(a);
@@ -398,10 +416,14 @@ int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_ov
 }
 
 void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 tag_override, float* depth,
-                         uint8_t* bgr, hipStream_t stream, const unsigned char* dirty = nullptr) {
+                         uint8_t* bgr, hipStream_t stream, const unsigned char* dirty = nullptr, bool key32 = false) {
   KeyCells cells{key_frame, 0};
-  if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
-    XM_LAUNCH(k_frame_proj_tiled, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+  if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && key32) {
+    XM_LAUNCH(k_frame_proj_tiled<true>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
+              tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
+  } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
+    XM_LAUNCH(k_frame_proj_tiled<false>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
               dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
               tag_override, dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
@@ -438,9 +460,38 @@ bool sorted_path(const xm_handle* h, const EventsView& ev) {
          max_ev >= 1024.0;
 }
 
+// may this (sorted-path) frame use the compact key frame?  Needs the automatic redo (try-sorted mode, not inside a capture)
+bool key32_path(const xm_handle* h, const EventsView& ev, bool sorted) {
+  if (!sorted || !h->key32_ok || !h->try_sorted || h->capturing || h->key32_pause > 0 || h->k2_direct || h->k2_flags) return false;
+  return ev.n / (u64)(1024 / TILE_EPT * TILE_EPT) < (1ull << KEY32_TILE_BITS);  // tiles of >= 1024 events
+}
+
+// keep the slot's compact frame unambiguous for a frame with tag `tag` (4-bit tags repeat every 15 frames)
+int key32_prepare(xm_handle* h, Slot& s, u32 tag, hipStream_t stream) {
+  if (tag - s.key32_valid_from >= 15u || tag < s.key32_valid_from) {
+    HIP_TRY(hipMemsetAsync(s.key32, 0, h->key_cells * sizeof(u32), stream));
+    s.key32_valid_from = tag;
+  }
+  return XM_OK;
+}
+
+void key32_note(xm_handle* h, bool failed) {
+  if (failed) {
+    h->key32_score += 8;
+    if (h->key32_score >= 24) {  // the stream keeps producing events outside the LDS time window (sparse / bursty frames)
+      h->key32_pause = 512;
+      h->key32_score = 0;
+    }
+  } else if (h->key32_score > 0) {
+    h->key32_score -= 1;
+  }
+}
+
 int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,
                   bool allow_sorted = true, hipStream_t stream_override = nullptr) {
   const bool sorted = allow_sorted && sorted_path(h, ev);
+  const bool use32 = key32_path(h, ev, sorted);
+  if (h->key32_pause > 0) h->key32_pause -= 1;
   hipStream_t stream = stream_override ? stream_override : s.stream;
   if (s.pending_batch_ev) {  // the slot's previous frame ran inside a multi-frame launch, maybe on another stream
     if (s.pending_batch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s.pending_batch_ev, 0));
@@ -458,18 +509,27 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
   // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the three dispatch packets
   if (prof) g_prof = ProfCtx{prof[0], prof[1]};
   if (!(skip & 1) && !sorted) launch_minmax(ev, s.st, 0, stream);
+  if (use32) {
+    int rc = key32_prepare(h, s, s.host_tag + 1, stream);
+    if (rc) return rc;
+  }
   if (prof) g_prof = ProfCtx{prof[2], prof[3]};
   if (!(skip & 2)) {
-    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, s.key_frame, s.dirty, stream, sorted);
+    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame, s.dirty, stream, sorted,
+                            nullptr, use32);
     if (rc) {
       g_prof = ProfCtx{};
       return rc;
     }
   }
   if (prof) g_prof = ProfCtx{prof[4], prof[5]};
-  if (!(skip & 4)) launch_frame_kernel(h, s.key_frame, s.st, 0, depth, bgr, stream, h->k2_flags ? s.dirty : nullptr);
+  if (!(skip & 4))
+    launch_frame_kernel(h, use32 ? reinterpret_cast<const u64*>(s.key32) : s.key_frame, s.st, 0, depth, bgr, stream,
+                        h->k2_flags ? s.dirty : nullptr, use32);
   g_prof = ProfCtx{};
   HIP_TRY(hipGetLastError());
+  s.last_key32 = use32;
+  if (use32) key32_note(h, false);
   s.host_tag += 1;
   s.any_frame = true;
   s.last_n = ev.n;
@@ -485,7 +545,7 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 // they ramp up and drain (245 K1 blocks for 256 CUs, each a ~10 us dependent chain); a group's launch keeps every CU fed.
 template <typename T, bool AOS, bool HAS_P>
 int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
-                   hipStream_t stream) {
+                   hipStream_t stream, bool key32 = false) {
   // K0: grid = (blocks of the largest frame, frames)
   if (!sorted) {
     const bool vec2 = !AOS && std::is_same<T, long long>::value && vec16;
@@ -512,6 +572,14 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
     if constexpr (kHasVec) {
       if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, true>;
     }
+    if constexpr (VIEW == 0) {
+      if (key32) {
+        kern = k_scatter_tiled_batch<T, AOS, HAS_P, 0, false, true>;
+        if constexpr (kHasVec) {
+          if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, 0, true, true>;
+        }
+      }
+    }
     int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), h->k1_lds);
     if (rc) return rc;
     XM_LAUNCH(kern, dim3(gx1, n_frames), dim3(threads), h->k1_lds, stream, d_descs, h->tb, h->w_ts, h->w_x, sorted ? 1 : 0);
@@ -521,9 +589,14 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   if (rc) return rc;
   // K2
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
-    XM_LAUNCH(k_frame_proj_tiled_batch, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
-              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
-              (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+    if (key32)
+      XM_LAUNCH(k_frame_proj_tiled_batch<true>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+    else
+      XM_LAUNCH(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     XM_LAUNCH(k_frame_direct_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
@@ -578,28 +651,36 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     }
     return XM_OK;
   }
+  bool use32 = sorted;
+  for (int f = 0; f < n_frames && use32; ++f) use32 = key32_path(h, evs[f], sorted);
+  if (h->key32_pause > 0) h->key32_pause = std::max(0, h->key32_pause - n_frames);
   for (int f = 0; f < n_frames; ++f) {
     Slot& s = h->slots[slot_idx[f]];
     if (s.host_tag >= KEY_MAX_TAG && !h->capturing) {
       int rc = reset_slot(h, s, stream);
       if (rc) return rc;
     }
+    if (use32) {
+      int rc = key32_prepare(h, s, s.host_tag + 1, stream);
+      if (rc) return rc;
+    }
     FrameDesc& d = h_descs[f];
     const EventsView& ev = evs[f];
     d.x = ev.x; d.y = ev.y; d.t = ev.t; d.p = ev.use_p ? ev.p : nullptr; d.aos = (const uint4*)ev.aos;
-    d.n = ev.n; d.key_frame = s.key_frame; d.st = s.st; d.depth = depth[f]; d.bgr = bgr[f]; d.valid = 1; d.pad = 0;
+    d.n = ev.n; d.key_frame = use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame; d.st = s.st; d.depth = depth[f];
+    d.bgr = bgr[f]; d.valid = 1; d.pad = 0;
   }
   if (upload) HIP_TRY(hipMemcpyAsync(d_descs, h_descs, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, stream));
   int rc;
-  if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream)
-                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream);
+  if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32)
+                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32);
   else switch (e0.t_dtype) {
-    case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream)
-                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream); break;
-    case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream)
-                                     : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream); break;
-    default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream)
-                           : launch_batch_t<double, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream);
+    case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
+                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
+    case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
+                                     : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
+    default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
+                           : launch_batch_t<double, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32);
   }
   if (rc) return rc;
   for (int f = 0; f < n_frames; ++f) {
@@ -609,7 +690,9 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     s.any_frame = true;
     s.last_n = evs[f].n;
     s.last_sorted = sorted;
+    s.last_key32 = use32;
     s.last_t_dtype = evs[f].aos ? XM_T_INT64 : evs[f].t_dtype;
+    if (use32) key32_note(h, false);
   }
   return XM_OK;
 }
@@ -767,6 +850,7 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
   }
   if (!s.prev.check || __atomic_load_n(&s.h_flags[0], __ATOMIC_ACQUIRE) != tag) return XM_OK;
   h->sorted_fallbacks += 1;
+  if (s.last_key32) key32_note(h, true);
   if (s.worker >= 0 && !s.prev.host_depth && !s.prev.host_bgr) {  // the redo goes the way the frame went
     Job j;
     j.slot = (int)(&s - h->slots.data());
@@ -890,6 +974,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     if (st.n_unsorted && s.last_sorted) {
       // the time-sorted declaration did not hold for this frame: redo it on the general path (K0 -> K1 -> K2)
       h->sorted_fallbacks += 1;
+      if (s.last_key32) key32_note(h, true);
       if ((rc = enqueue_frame(h, s, ev, d_depth, d_bgr, nullptr, false))) return rc;
       s.api_tag = s.host_tag;
       if (mem == XM_MEM_HOST) {
@@ -1070,6 +1155,15 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       h->k2_tile_cap = std::min((cap + 7) & ~7, (int)K2_TILE_MAX);
     }
   }
+  {  // does the rig qualify for the compact (32-bit) key frame?  (see key32_tag in xmaps_kernels.hpp)
+    int xr_min = 32767, xp_max = 0;
+    for (size_t i = 0; i < cam_px; ++i) xr_min = std::min<int>(xr_min, cfg->cam_mapx_i16[i]);
+    for (size_t i = 0; i < xm_cells; ++i) xp_max = std::max<int>(xp_max, cfg->proj_x_map[i]);
+    const long max_disp = std::max<long>((long)xp_max - xr_min - cfg->x_offset, (long)0 - xr_min - cfg->x_offset);
+    const char* e32 = getenv("XM_KEY32");
+    h->key32_ok = cfg->view == XM_VIEW_PROJECTOR && (cfg->rect_height & 3) == 0 && max_disp < (1l << KEY32_DISP_BITS) &&
+                  !(e32 && e32[0] == '0');
+  }
   if (cfg->view == XM_VIEW_PROJECTOR) {
     h->key_cells = (size_t)cfg->rect_width * cfg->rect_height;
     h->out_w = cfg->proj_width;
@@ -1151,6 +1245,10 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       else XM_TRY_CREATE(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, pe && pe[0] == 'l' ? lo : hi));
     }
     XM_TRY_CREATE(hipMalloc((void**)&s.key_frame, h->key_cells * sizeof(u64)));
+    if (h->key32_ok) {
+      XM_TRY_CREATE(hipMalloc((void**)&s.key32, h->key_cells * sizeof(u32)));
+      XM_TRY_CREATE(hipMemset(s.key32, 0, h->key_cells * sizeof(u32)));
+    }
     if (cfg->view == XM_VIEW_PROJECTOR && h->k2_flags)
       XM_TRY_CREATE(hipMalloc((void**)&s.dirty, ((h->key_cells + 15) >> 4) + 64));
     s.st = h->d_states + i;
@@ -1239,6 +1337,7 @@ void xm_destroy(xm_handle* h) {
     s.out_depth.release(); s.out_bgr.release();
     for (auto& d : s.dbg) d.release();
     if (s.key_frame) (void)hipFree(s.key_frame);
+    if (s.key32) (void)hipFree(s.key32);
     if (s.dirty) (void)hipFree(s.dirty);
     if (s.stream && s.owns_stream) (void)hipStreamDestroy(s.stream);
     if (s.h_flags) (void)hipHostFree(s.h_flags);
@@ -2215,7 +2314,7 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   }
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (!h->k2_direct) {
-      hipLaunchKernelGGL(k_frame_proj_tiled_batch, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), 1),
+      hipLaunchKernelGGL(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), 1),
                          dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), s, (const FrameDesc*)g->desc,
                          h->tb, (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
     } else {

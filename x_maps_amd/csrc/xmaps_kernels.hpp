@@ -128,6 +128,22 @@ template <> struct TimeCodec<float> {  // f32 -> f64 is exact and monotone
 // (tags repeat every 255 frames) is only a false positive -- the line is fetched and its keys' full tags decide.
 __host__ __device__ inline unsigned char dirty_byte(u32 tag) { return (unsigned char)(tag % 255u + 1u); }
 
+// ---- compact (32-bit) key frame of the verified-sorted projector-view path ------------------------------------------------
+//   tag4:4 | tile:16 | disparity:12        (tag4 = tag % 15 + 1; 0 = cleared cell)
+// Half the bytes per cell means twice as many winners per 64-byte L2 atomic request and half of K2's key-frame read: K1
+// at full occupancy is bound by the chip's L2 atomic rate (~23 G requests/s measured: profiles/r02*_pmc.md), K2 by the
+// read.  The order field is the TILE index, not the event index: inside a tile the last writer is resolved exactly in LDS
+// (slot value = local index | disparity), across tiles a higher tile = later events.  That is exact as long as EVERY
+// event of the tile goes through the LDS slots: an event whose time column falls outside the tile's LDS window cannot, so it
+// marks the frame as failed -- the same flag, and the same automatic redo on the 64-bit general path, as an event outside
+// [t[0], t[n-1]].  Events outside the LUT window only (x noise) fetch their LUT entry from global memory and then use
+// the slots like everybody else.  Preconditions checked by the host (xm_create): projector view, rect_h % 4 == 0, every
+// possible disparity < 4096, tiles per frame < 65536; the 4-bit tag is kept unambiguous by clearing the frame at least
+// every 15 frames of the slot (9.3 MB memset per 15 frames at C-1M).
+constexpr u32 KEY32_DISP_BITS = 12, KEY32_TILE_BITS = 16;
+__host__ __device__ inline u32 key32_tag(u32 tag) { return (tag % 15u + 1u) << 28; }
+__device__ inline uint16_t key_disp32(u32 k, u32 tag4) { return (k & 0xf0000000u) == tag4 ? (uint16_t)(k & 0xfffu) : (uint16_t)0; }
+
 constexpr u64 MM_INIT_MIN = ~0ull;
 constexpr u64 MM_INIT_MAX = 0ull;
 
@@ -687,13 +703,14 @@ constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;  // largest block: 4096 eve
 // mm_ext (sharded mode, tag_override != 0): the FRAME's extrema in device memory as {tmin, -tmax} (int64 for int64 t, f64
 // for float t) -- the buffer the ranks MIN-all-reduce -- read here so that no host round trip sits between the collective
 // and this kernel; NULL: mm_lo / mm_hi carry the encoded extrema.
-template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC, bool KEY32 = false>
 __device__ __forceinline__ void scatter_tiled_body(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, const DevTables& tb, SlotState* st,
     u32 tag_override, u64 mm_lo, u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
     unsigned char* __restrict__ dirty, int w_ts, int w_x, int sorted_mode, const u32 blk, const u32 nblk) {
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
+  static_assert(!KEY32 || VIEW == 0, "the compact key frame is a projector-view format");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XM_BLOG_BEGIN();
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift).  The LUT band and
@@ -1032,6 +1049,45 @@ __device__ __forceinline__ void scatter_tiled_body(
     smask |= used[k] && !fast[k] ? 1u << k : 0u;
   }
   u32 n_in = 0, n_oob = 0;
+  u32 ovr = 0;  // KEY32: bit k = event k's LUT entry was fetched from global memory and sits in xl[k]
+  if constexpr (KEY32) {
+    // Every event must be resolved in the LDS slots (the key's order field is only the tile).  An event outside the LUT window
+    // (x noise) but inside the time window fetches its LUT entry from global memory here and joins the fast path below; an
+    // event outside the TIME window cannot use the slots: the frame is marked as failed and redone on the 64-bit path.
+    bool bad = false;
+    while (__ballot(smask != 0)) {
+      const bool act = smask != 0;
+      const int ks = act ? __builtin_ctz(smask) : 0;
+      smask &= smask - 1;
+      u32 ex = x[0], ey = y[0];
+      int et = tl[0];
+#pragma unroll
+      for (int kk = 1; kk < TILE_EPT; ++kk) {
+        const bool sel = ks == kk;
+        ex = sel ? x[kk] : ex;
+        ey = sel ? y[kk] : ey;
+        et = sel ? tl[kk] : et;
+      }
+      bool oob = false;
+      if (act) {
+        if (ex >= (u32)tb.cam_w || ey >= (u32)tb.cam_h) {
+          oob = true;  // map[y, x] IndexError (calib:279-280): dropped and counted, as on the other paths
+        } else if ((u32)et >= (u32)wts_eff) {
+          bad = true;
+        } else {
+          const u32 l = tb.lut[ex * (u32)tb.cam_h + ey];
+#pragma unroll
+          for (int kk = 0; kk < TILE_EPT; ++kk) xl[kk] = ks == kk ? (int)l : xl[kk];
+          ovr |= 1u << ks;
+        }
+      }
+      n_oob += __popcll(__ballot(oob));
+    }
+    if (__ballot(bad) && (tid & 63) == 0) {
+      __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u32* hf = st->host_flags) host_flag_store(hf, tag);
+    }
+  } else
   while (__ballot(smask != 0)) {
     const bool act = smask != 0;
     const int ks = act ? __builtin_ctz(smask) : 0;
@@ -1103,7 +1159,14 @@ __device__ __forceinline__ void scatter_tiled_body(
   {
     u32 l[TILE_EPT];
 #pragma unroll
-    for (int k = 0; k < TILE_EPT; ++k) l[k] = lut_t[fast[k] ? xl[k] * tb.cam_h + (int)y[k] : 0];
+    for (int k = 0; k < TILE_EPT; ++k) {
+      const bool o_k = KEY32 && ((ovr >> k) & 1u);
+      l[k] = lut_t[fast[k] ? xl[k] * tb.cam_h + (int)y[k] : 0];
+      if constexpr (KEY32) {
+        l[k] = o_k ? (u32)xl[k] : l[k];
+        fast[k] = fast[k] || o_k;
+      }
+    }
     int xr[TILE_EPT], yr[TILE_EPT], xp[TILE_EPT];
     bool yok[TILE_EPT];
 #pragma unroll
@@ -1195,8 +1258,13 @@ __device__ __forceinline__ void scatter_tiled_body(
           } else {  // q = camera row, r = x - x_lo
             cell = (u32)q * (u32)tb.cam_w + (u32)(x_lo + r);
           }
-          if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);  // consecutive lanes = consecutive rows
+          if constexpr (KEY32) {  // tag4 | tile | disparity into the compact frame (see key32_tag)
+            __hip_atomic_fetch_max(reinterpret_cast<u32*>(frame) + cell, key32_tag(tag) | (tile << KEY32_DISP_BITS) | (v[j] & 0xfffu),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);  // consecutive lanes = consecutive rows
+          }
         }
       }
     }
@@ -1211,7 +1279,7 @@ __device__ __forceinline__ void scatter_tiled_body(
   XM_BLOG_END(1, st, tag);
 }
 
-template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC, bool KEY32 = false>
 __global__ XM_K1_BOUNDS void k_scatter_tiled(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const T* __restrict__ ts,
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
@@ -1230,8 +1298,8 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     if ((long long)(pp | (u64)(long long)pi) < 0) return;
   }
 #endif
-  scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC>(xs, ys, ts, ps, aos, n, idx_offset, tb, st, tag_override, mm_lo, mm_hi, mm_ext,
-                                               frame, dirty, w_ts, w_x, sorted_mode, blockIdx.x, gridDim.x);
+  scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC, KEY32>(xs, ys, ts, ps, aos, n, idx_offset, tb, st, tag_override, mm_lo, mm_hi, mm_ext,
+                                                      frame, dirty, w_ts, w_x, sorted_mode, blockIdx.x, gridDim.x);
 }
 
 // A frame without events inside a multi-frame launch: only the slot bookkeeping K1's block 0 does.
@@ -1257,7 +1325,7 @@ __device__ inline void scatter_empty_frame(SlotState* st, int sorted_mode) {
 // (60 frames: 14 700 blocks instead of 245): no per-frame launch ramp, the CUs always have a next block to pick up.  Every
 // frame owns a key frame + state (FrameDesc), so blocks of different frames never meet.  The frame's size comes from
 // device memory: the same launch serves frames cut out of a device-resident stream (ingest) whose length the host never saw.
-template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC>
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC, bool KEY32 = false>
 __global__ XM_K1_BOUNDS void k_scatter_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb, int w_ts, int w_x,
                                                    int sorted_mode) {
   const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
@@ -1268,8 +1336,8 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled_batch(const FrameDesc* __restrict__
     if (d.n == 0 && blockIdx.x == 0) scatter_empty_frame(d.st, sorted_mode);
     return;
   }
-  scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC>(d.x, d.y, (const T*)d.t, d.p, d.aos, d.n, 0ull, tb, d.st, 0u, 0ull, 0ull, nullptr,
-                                               d.key_frame, nullptr, w_ts, w_x, sorted_mode, blockIdx.x, nblk);
+  scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC, KEY32>(d.x, d.y, (const T*)d.t, d.p, d.aos, d.n, 0ull, tb, d.st, 0u, 0ull, 0ull,
+                                                      nullptr, d.key_frame, nullptr, w_ts, w_x, sorted_mode, blockIdx.x, nblk);
 }
 
 // =====================================================================================================
@@ -1459,7 +1527,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
   int4 rec = make_int4(0, 0, 0, 0);
   u32 off = ~0u;
   if (x1 >= x0) {
-    const int bx = x0 - 3, by = (y0 - 3) & ~1;
+    const int bx = x0 - 3, by = (y0 - 3) & ~3;  // rows start on a multiple of 4: 16-byte loads of 2 (u64) or 4 (u32) keys
     const int cols = x1 + 3 - bx + 1, rows = y1 + 3 - by + 1, rows_p = (rows + 7) & ~7;
     const bool fits = cols * rows_p <= K2_TILE_MAX;
     rec = make_int4(bx, by, fits ? cols : -1, rows_p);
@@ -1470,6 +1538,8 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
 }
 
 // blk_lin / grid_x / grid_y = linear block index inside the frame's tile grid and that grid's shape
+// KEY32: `keys` is the compact 32-bit key frame of the verified-sorted path (see key32_tag)
+template <bool KEY32 = false>
 __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ keys, const DevTables& tb, SlotState* st,
                                                       u32 tag_override, const unsigned char* __restrict__ dirty,
                                                       const ulonglong2* __restrict__ zero16, float* __restrict__ depth,
@@ -1535,7 +1605,59 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         }
         __syncthreads();
       }
-      if ((tb.rect_h & 1) == 0) {
+      if constexpr (KEY32) {
+        const u32* keys32 = reinterpret_cast<const u32*>(keys);
+        const u32 tag4 = key32_tag(tag);
+        const bool interior = bx >= 0 && by >= 0 && bx + cols <= tb.rect_w && by + rows_p <= tb.rect_h;  // rect_h % 4 == 0 (host)
+        if (interior) {  // 16-byte loads of 4 consecutive rows, (column, row quad) advanced incrementally
+          const int quarter = rows_p >> 2, total = cols * quarter;
+          const int dq = NT / quarter, dr = NT - dq * quarter;
+          int c_i = (int)((float)tid * (1.0f / (float)quarter)), rq_i = tid - c_i * quarter;
+          if (rq_i < 0) { c_i -= 1; rq_i += quarter; }
+          if (rq_i >= quarter) { c_i += 1; rq_i -= quarter; }
+          u32 cell = (u32)(bx + c_i) * (u32)tb.rect_h + (u32)(by + 4 * rq_i);
+          const u32 cell_origin = (u32)bx * (u32)tb.rect_h + (u32)by;
+          const u32 dcell = (u32)dq * (u32)tb.rect_h + 4u * (u32)dr, carry = (u32)tb.rect_h - 4u * (u32)quarter;
+          auto pass = [&](auto un_tag) {
+            constexpr int UL = decltype(un_tag)::value;
+            for (int i0 = tid; i0 < total; i0 += UL * NT) {
+              uint4 k[UL];
+#pragma unroll
+              for (int j = 0; j < UL; ++j) {
+                k[j] = *reinterpret_cast<const uint4*>(keys32 + (i0 + j * NT < total ? cell : cell_origin));
+                cell += dcell;
+                rq_i += dr;
+                if (rq_i >= quarter) { rq_i -= quarter; cell += carry; }
+              }
+#pragma unroll
+              for (int j = 0; j < UL; ++j) {
+                const int i = i0 + j * NT;
+                if (i < total)
+                  reinterpret_cast<uint2*>(tile)[i] =
+                      make_uint2((u32)key_disp32(k[j].x, tag4) | ((u32)key_disp32(k[j].y, tag4) << 16),
+                                 (u32)key_disp32(k[j].z, tag4) | ((u32)key_disp32(k[j].w, tag4) << 16));
+              }
+            }
+          };
+          const int need = (total + NT - 1) / NT;
+          if (need <= 1) pass(std::integral_constant<int, 1>{});
+          else if (need <= 2) pass(std::integral_constant<int, 2>{});
+          else if (need <= 3) pass(std::integral_constant<int, 3>{});
+          else pass(std::integral_constant<int, 4>{});
+        } else {  // patches that stick out of the frame (tiles along the border): cell by cell
+          const int total = cols * rows_p;
+          const float inv_rows = 1.0f / (float)rows_p;
+          for (int i = tid; i < total; i += NT) {
+            int c = (int)((float)i * inv_rows), r = i - c * rows_p;
+            if (r < 0) { c -= 1; r += rows_p; }
+            if (r >= rows_p) { c += 1; r -= rows_p; }
+            const int gx = bx + c, gy = by + r;
+            const bool inside = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
+            const u32 kk = keys32[(u32)min(max(gx, 0), tb.rect_w - 1) * (u32)tb.rect_h + (u32)min(max(gy, 0), tb.rect_h - 1)];
+            tile[i] = inside ? key_disp32(kk, tag4) : (uint16_t)0;
+          }
+        }
+      } else if ((tb.rect_h & 1) == 0) {
         const int half = rows_p >> 1, total = cols * half;
         // (c, rp) = divmod(i, half) advanced incrementally: i -> i + NT is (c + dq, rp + dr) with one carry
         const int dq = NT / half, dr = NT - dq * half;
@@ -1659,10 +1781,17 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         d = (float)best;
       }
     } else if (valid_g) {
-      KeyCells cells{keys, tag};
       const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
-      for (int xx = xa; xx <= xb; ++xx)
-        for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, cells.at(tb, xx, yy));
+      if constexpr (KEY32) {
+        const u32* keys32 = reinterpret_cast<const u32*>(keys);
+        const u32 tag4 = key32_tag(tag);
+        for (int xx = xa; xx <= xb; ++xx)
+          for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, (float)key_disp32(keys32[(u32)xx * (u32)tb.rect_h + (u32)yy], tag4));
+      } else {
+        KeyCells cells{keys, tag};
+        for (int xx = xa; xx <= xb; ++xx)
+          for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, cells.at(tb, xx, yy));
+      }
     }
   }
   PixelOut o;
@@ -1708,6 +1837,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   XM_BLOG_END(2, st, tag);
 }
 
+template <bool KEY32 = false>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
                                                                   SlotState* st, u32 tag_override,
                                                                   const unsigned char* __restrict__ dirty,
@@ -1719,18 +1849,19 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
                   (u64)zero16 | (u64)depth | (u64)bgr |
                   (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
     return;
-  frame_proj_tiled_body(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap, blockIdx.y * gridDim.x + blockIdx.x,
-                        gridDim.x, gridDim.y);
+  frame_proj_tiled_body<KEY32>(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap, blockIdx.y * gridDim.x + blockIdx.x,
+                               gridDim.x, gridDim.y);
 }
 
 // multi-frame launch: grid = (tiles_x, tiles_y, frames)
+template <bool KEY32 = false>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb,
                                                                         const ulonglong2* __restrict__ zero16,
                                                                         int tile_cap) {
   const FrameDesc d = descs[blockIdx.z];
   if (!d.valid) return;
-  frame_proj_tiled_body(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
-                        blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
+  frame_proj_tiled_body<KEY32>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
+                               blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
 }
 
 // camera view / plain per-pixel conversion of a frame of n_pixels cells -> depth + BGR
