@@ -11,7 +11,10 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", tag)
-out = os.path.join(ROOT, "profiles")
+# on the GPU box the databases are too large to travel back (64 MiB cap): `--to-scratch` writes the summaries next to them,
+# under gpurun_out/<tag>_profiles/, from where they are copied into profiles/ once merged back
+out = os.path.join(ROOT, "gpurun_out", tag + "_profiles") if "--to-scratch" in sys.argv else os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
 
 
 def short(name):
@@ -62,7 +65,8 @@ with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
                             ("trace_pipe8", "projector view, 4 frames in flight (round-1 name)", "python bench.py --steps 400 --no-cpu-baseline"),
                             ("trace_pipe", "projector view, 4 frames in flight (the default bench configuration; under the profiler the launches no longer overlap)", "python bench.py --steps 400 --no-cpu-baseline --no-other-modes --no-host-path"),
                             ("trace_batch60", "multi-frame launches: 60 x C-1M frames per kernel launch (grid = frames x tiles), general path", "python tools/batch_probe.py 60 4"),
-                            ("trace_batch60_sorted", "multi-frame launches, 60 frames, declared time-sorted (no K0)", "python tools/batch_probe.py 60 4 1")):
+                            ("trace_batch60_sorted", "multi-frame launches, 60 frames, declared time-sorted (no K0, 64-bit key frame)", "python tools/batch_probe.py 60 4 1"),
+                            ("trace_batch60_default", "multi-frame launches, 60 frames, library defaults (verified shortcut + compact 32-bit key frame)", "python tools/batch_probe.py 60 4 2")):
         db = os.path.join(src, f"{key}_results.db")
         if os.path.exists(db):
             f.write(f"## {title}\n\n`rocprofv3 --kernel-trace --stats -- {cmd}`\n\n{trace_table(db)}\n\n")
@@ -81,7 +85,8 @@ with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
             "(MI355X_MICROARCH.md section HBM; confirmed here: k_minmax reads exactly 8.0 MB of t and shows ~3.9 MB), so\n"
             "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE.\n\n")
     for view, pat in (("projector", "pmc_proj_*_results.db"), ("projector_general", "pmc_gen_*_results.db"),
-                      ("camera", "pmc_cam_*_results.db"), ("batch60", "pmc_batch_*_results.db")):
+                      ("camera", "pmc_cam_*_results.db"), ("batch60", "pmc_batch_*_results.db"),
+                      ("batch60_default", "pmc_bdef_*_results.db")):
         rows = pmc_rows(pat)
         if not rows:
             continue

@@ -13,6 +13,7 @@ $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_cam -- python bench.py --sl
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_pipe -- python bench.py --steps 400 $Q > $OUT/trace_pipe.log 2>&1
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_batch60 -- python tools/batch_probe.py 60 4 > $OUT/trace_batch60.log 2>&1
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_batch60_sorted -- python tools/batch_probe.py 60 4 1 > $OUT/trace_batch60_sorted.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_batch60_default -- python tools/batch_probe.py 60 4 2 > $OUT/trace_batch60_default.log 2>&1
 PM="python bench.py --slots 1 --steps 40 --warmup 5 $Q"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
@@ -35,6 +36,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_A
            "GRBM_GUI_ACTIVE TA_TA_BUSY_sum"; do
   i=$((i+1))
   $T rocprofv3 --kernel-trace --pmc $set -d $OUT -o pmc_batch_$i -- python tools/batch_probe.py 60 3 > $OUT/pmc_batch_$i.log 2>&1 || echo "pmc_batch pass $i failed: $set"
+  $T rocprofv3 --kernel-trace --pmc $set -d $OUT -o pmc_bdef_$i -- python tools/batch_probe.py 60 3 2 > $OUT/pmc_bdef_$i.log 2>&1 || echo "pmc_bdef pass $i failed: $set"
 done
 unset XM_BENCH_PREWARM_S
 timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -44,4 +46,6 @@ timeout 200 python bench.py --graph > $OUT/bench_graph60.json 2> $OUT/bench_grap
 timeout 200 python bench.py --graph --slots 8 --no-cpu-baseline > $OUT/bench_graph60_slots8.json 2> $OUT/bench_graph60_slots8.err
 timeout 200 python bench.py --sharded > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
 timeout 200 python bench.py --camera-perspective --no-cpu-baseline --no-other-modes > $OUT/bench_camera.json 2> $OUT/bench_camera.err
-ls $OUT | wc -l
+python tools/collect_profiles.py $TAG --to-scratch > $OUT/collect.log 2>&1
+rm -f $OUT/*.db $OUT/*.csv
+ls $OUT | wc -l; du -sh $OUT gpurun_out/${TAG}_profiles

@@ -2245,6 +2245,8 @@ struct xm_ingest {
   xm_handle* h = nullptr;
   xm_ingest_config cfg{};
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of packet k+1 runs beside the kernels of packet k
+  hipEvent_t copied_ev[4] = {};       // per staging entry: its H2D has finished (the compute stream waits for it)
   u64 capacity = 0, max_packet = 0;
   double period = 0.0;
   long long act_thresh = 0;
@@ -2368,6 +2370,10 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   int lo = 0, hi = 0;
   ING_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   ING_TRY(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, hi));
+  if (!(getenv("XM_INGEST_ONE_STREAM") && getenv("XM_INGEST_ONE_STREAM")[0] == '1')) {
+    ING_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+    for (auto& e : g->copied_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   for (int i = 0; i < 2; ++i) ING_TRY(hipMalloc((void**)&g->buf[i], g->capacity * 16));
   ING_TRY(hipMalloc((void**)&g->first_idx, cam_px * 4));
   ING_TRY(hipMalloc((void**)&g->last_ts, cam_px * 8));
@@ -2448,6 +2454,11 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->h_status) (void)hipHostFree(g->h_status);
   for (auto p : g->h_depth) if (p) (void)hipHostFree(p);
   for (auto p : g->h_bgr) if (p) (void)hipHostFree(p);
+  if (g->copy_stream) {
+    (void)hipStreamSynchronize(g->copy_stream);
+    (void)hipStreamDestroy(g->copy_stream);
+  }
+  for (auto& e : g->copied_ev) if (e) (void)hipEventDestroy(e);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -2468,7 +2479,13 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   if (n) {
     if (g->pkt_used[k]) HIP_TRY(hipEventSynchronize(g->pkt_ev[k]));  // the staging entry's previous packet has been consumed
     if (!pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
-    HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, s));
+    if (g->copy_stream) {  // the copy overlaps the previous packets' kernels; the kernels of this packet wait for it
+      HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
+      HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
+      HIP_TRY(hipStreamWaitEvent(s, g->copied_ev[k], 0));
+    } else {
+      HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, s));
+    }
   }
   // room for this packet behind the write cursor (device-side decision; the live part moves to the other buffer)
   hipLaunchKernelGGL(k_ing_compact, dim3(256), dim3(BLOCK), 0, s, g->st, g->buf[0], g->buf[1], g->capacity, (u64)g->max_packet);
@@ -2563,6 +2580,7 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
 int xm_ingest_flush(xm_ingest* g) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(g->h->cfg.device));
+  if (g->copy_stream) HIP_TRY(hipStreamSynchronize(g->copy_stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
   return XM_OK;
 }
