@@ -181,8 +181,9 @@ struct xm_handle {
   std::vector<hipStream_t> gstreams;  // default-priority streams the hipGraph batches are captured on and launched from
   std::vector<std::unique_ptr<Worker>> workers;  // one per slot stream (empty: launches happen in the calling thread)
   bool key32_ok = false;      // the rig qualifies for the compact key frame (projector view, rect_h % 4 == 0, disparities < 4096)
-  int key32_score = 0;        // raised by frames that failed the compact path, decays with every frame that took it
-  int key32_pause = 0;        // frames for which the compact path stays switched off (it kept failing: sparse / noisy stream)
+  // (atomics: with XM_FLAG_LAUNCH_WORKERS the launch threads and the API thread all pass through enqueue_frame)
+  std::atomic<int> key32_score{0};  // raised by frames that failed the compact path, decays with every frame that took it
+  std::atomic<int> key32_pause{0};  // frames for which the compact path stays switched off (it kept failing: sparse / noisy stream)
   bool time_sorted = false;   // XM_FLAG_TIME_SORTED
   bool try_sorted = false;    // XM_FLAG_TRY_SORTED
   bool gate_slots = false;    // experiments (XM_GATE_SLOTS=1): asynchronous calls wait (polling a pinned word) until the slot's previous frame has reached K2
@@ -462,7 +463,9 @@ bool sorted_path(const xm_handle* h, const EventsView& ev) {
 
 // may this (sorted-path) frame use the compact key frame?  Needs the automatic redo (try-sorted mode, not inside a capture)
 bool key32_path(const xm_handle* h, const EventsView& ev, bool sorted) {
-  if (!sorted || !h->key32_ok || !h->try_sorted || h->capturing || h->key32_pause > 0 || h->k2_direct || h->k2_flags) return false;
+  if (!sorted || !h->key32_ok || !h->try_sorted || h->capturing || h->key32_pause.load(std::memory_order_relaxed) > 0 ||
+      h->k2_direct || h->k2_flags)
+    return false;
   return ev.n / (u64)(1024 / TILE_EPT * TILE_EPT) < (1ull << KEY32_TILE_BITS);  // tiles of >= 1024 events
 }
 
@@ -477,13 +480,14 @@ int key32_prepare(xm_handle* h, Slot& s, u32 tag, hipStream_t stream) {
 
 void key32_note(xm_handle* h, bool failed) {
   if (failed) {
-    h->key32_score += 8;
-    if (h->key32_score >= 24) {  // the stream keeps producing events outside the LDS time window (sparse / bursty frames)
-      h->key32_pause = 512;
-      h->key32_score = 0;
+    if (h->key32_score.fetch_add(8, std::memory_order_relaxed) + 8 >= 24) {  // the stream keeps producing events outside the
+      h->key32_pause.store(512, std::memory_order_relaxed);                  // LDS time window (sparse / bursty frames)
+      h->key32_score.store(0, std::memory_order_relaxed);
     }
-  } else if (h->key32_score > 0) {
-    h->key32_score -= 1;
+  } else {
+    int v = h->key32_score.load(std::memory_order_relaxed);
+    while (v > 0 && !h->key32_score.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {
+    }
   }
 }
 
@@ -491,7 +495,11 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
                   bool allow_sorted = true, hipStream_t stream_override = nullptr) {
   const bool sorted = allow_sorted && sorted_path(h, ev);
   const bool use32 = key32_path(h, ev, sorted);
-  if (h->key32_pause > 0) h->key32_pause -= 1;
+  {
+    int v = h->key32_pause.load(std::memory_order_relaxed);
+    while (v > 0 && !h->key32_pause.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {
+    }
+  }
   hipStream_t stream = stream_override ? stream_override : s.stream;
   if (s.pending_batch_ev) {  // the slot's previous frame ran inside a multi-frame launch, maybe on another stream
     if (s.pending_batch_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s.pending_batch_ev, 0));
@@ -653,7 +661,11 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   }
   bool use32 = sorted;
   for (int f = 0; f < n_frames && use32; ++f) use32 = key32_path(h, evs[f], sorted);
-  if (h->key32_pause > 0) h->key32_pause = std::max(0, h->key32_pause - n_frames);
+  {
+    int v = h->key32_pause.load(std::memory_order_relaxed);
+    while (v > 0 && !h->key32_pause.compare_exchange_weak(v, std::max(0, v - n_frames), std::memory_order_relaxed)) {
+    }
+  }
   for (int f = 0; f < n_frames; ++f) {
     Slot& s = h->slots[slot_idx[f]];
     if (s.host_tag >= KEY_MAX_TAG && !h->capturing) {

@@ -1758,17 +1758,22 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         for (int t = tid; t < tasks; t += NT) {
           const uint4 a = *reinterpret_cast<const uint4*>(tile + t * 8);  // task t covers tile[t*8 .. t*8+7] (c*rows_p + 8*seg)
           const uint4 b = *reinterpret_cast<const uint4*>(tile + t * 8 + 8);
-          u32 e[16];
-          e[0] = a.x & 0xffff; e[1] = a.x >> 16; e[2] = a.y & 0xffff; e[3] = a.y >> 16;
-          e[4] = a.z & 0xffff; e[5] = a.z >> 16; e[6] = a.w & 0xffff; e[7] = a.w >> 16;
-          e[8] = b.x & 0xffff; e[9] = b.x >> 16; e[10] = b.y & 0xffff; e[11] = b.y >> 16;
-          e[12] = b.z & 0xffff; e[13] = b.z >> 16; e[14] = 0; e[15] = 0;
-          u32 o[8];
+          // packed 16-bit arithmetic (v_pk_max_u16): P_k = (e[2k], e[2k+1]) as loaded, S_k = (e[2k+1], e[2k+2]) by a 16-bit
+          // funnel shift; outputs (o[2j], o[2j+1]) = max(P_j, S_j, P_j+1, S_j+1, P_j+2, S_j+2, P_j+3): 24 instructions instead
+          // of 72 for unpack + 48 scalar maxima + pack
+          typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+          const auto pk = [](u32 v) { u16x2 r; __builtin_memcpy(&r, &v, 4); return r; };
+          const auto up = [](u16x2 v) { u32 r; __builtin_memcpy(&r, &v, 4); return r; };
+          const auto mx = [](u16x2 x, u16x2 y) { return __builtin_elementwise_max(x, y); };
+          const u32 P[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+          u16x2 M[6];
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            o[i] = max(max(max(e[i], e[i + 1]), max(e[i + 2], e[i + 3])), max(max(e[i + 4], e[i + 5]), e[i + 6]));
+          for (int k = 0; k < 6; ++k) M[k] = mx(pk(P[k]), pk(__builtin_amdgcn_alignbit(P[k + 1], P[k], 16)));
           uint4 w;
-          w.x = o[0] | (o[1] << 16); w.y = o[2] | (o[3] << 16); w.z = o[4] | (o[5] << 16); w.w = o[6] | (o[7] << 16);
+          w.x = up(mx(mx(M[0], M[1]), mx(M[2], pk(P[3]))));
+          w.y = up(mx(mx(M[1], M[2]), mx(M[3], pk(P[4]))));
+          w.z = up(mx(mx(M[2], M[3]), mx(M[4], pk(P[5]))));
+          w.w = up(mx(mx(M[3], M[4]), mx(M[5], pk(P[6]))));
           *reinterpret_cast<uint4*>(vmax + t * 8) = w;
         }
       }
