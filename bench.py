@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--sharded", action="store_true", help="config 4: C-10M sharded by event index over the ranks (RCCL)")
     ap.add_argument("--esl", action="store_true",
                     help="configs 1/3 stand-in: ESL-like frames (real calibration geometry, ~150 k events, projector 1080x1920)")
+    ap.add_argument("--merge", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
+                    help="--sharded: how the shards' key frames are merged (x_maps_amd/sharded.py)")
     ap.add_argument("--batch", type=int, default=0, help="submit the steps in groups of B frames (xm_process_batch)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -853,18 +855,20 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         shards.append(tuple(torch.from_numpy(v[a:b].copy()).to(dev) for v in (x.view(np.int16), y.view(np.int16), t)) + (None,))
     torch.cuda.synchronize()
     prov = GpuShardProvider(eng, dev)
-    proc = ShardedFrameProcessor(prov, dist, always_reduce=True)  # world 1: the collectives are issued all the same
+    proc = ShardedFrameProcessor(prov, dist, always_reduce=True, merge=args.merge)  # world 1: the collectives are issued all the same
 
     # collective time: torch events on the engine's stream around the two all-reduces
     ev_pairs = []
-    orig_ar = proc._all_reduce
+    orig = {"_all_reduce": proc._all_reduce, "_reduce_scatter_max": proc._reduce_scatter_max, "_all_gather": proc._all_gather}
 
-    def timed_all_reduce(tensor, op):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()  # current stream = the engine's stream (process_shard runs under provider.collective_stream())
-        orig_ar(tensor, op)
-        e1.record()
-        ev_pairs.append((e0, e1))
+    def timed(fn):
+        def wrapped(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()  # current stream = the engine's stream (process_shard runs under provider.collective_stream())
+            fn(*a)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        return wrapped
 
     def sync():
         eng.sync()
@@ -900,13 +904,16 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     elapsed = float(np.median(el))
     value = float(n_ev) * steps / elapsed / 1e6  # the frame is shared by all ranks: strong scaling
     # collective time, measured in a separate short pass (event records between the enqueues cost host time)
-    proc._all_reduce = timed_all_reduce
+    for k, f in orig.items():
+        setattr(proc, k, timed(f))
     for i in range(20):
         step(i)
     sync()
-    proc._all_reduce = orig_ar
-    coll = np.array([e0.elapsed_time(e1) for e0, e1 in ev_pairs]).reshape(-1, 2)
-    coll_ms = torch.tensor([float(np.median(coll[:, 0])), float(np.median(coll[:, 1]))], dtype=torch.float64, device=dev)
+    for k, f in orig.items():
+        setattr(proc, k, f)
+    per_frame = 2 if args.merge == "all_reduce" else 3  # extrema + key frame | extrema + reduce-scatter + all-gather
+    coll = np.array([e0.elapsed_time(e1) for e0, e1 in ev_pairs]).reshape(-1, per_frame)
+    coll_ms = torch.tensor([float(np.median(coll[:, 0])), float(np.median(coll[:, 1:].sum(axis=1)))], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(coll_ms, op=dist.ReduceOp.MAX)
     if rank != 0:
@@ -936,8 +943,11 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                                (" (camera view)" if camera else " (projector view)"),
                    "events_per_frame": n_ev, "events_per_rank": b - a, "key_frame_MB": round(kshape[0] * kshape[1] * 8 / 1e6, 1),
                    "host_synchronisations_per_frame": 0,
-                   "collectives_per_frame": ["all_reduce MIN int64[2] (frame extrema)", "all_reduce MAX int64[key frame]"]},
-        "collective_ms": {"extrema_min_all_reduce": round(float(coll_ms[0]), 4), "key_frame_max_all_reduce": round(float(coll_ms[1]), 4),
+                   "merge": args.merge,
+                   "collectives_per_frame": ["all_reduce MIN int64[2] (frame extrema)"] +
+                                            (["all_reduce MAX int64[key frame]"] if args.merge == "all_reduce" else
+                                             ["reduce_scatter MAX int64[key frame]", "all_gather u16[key frame] (decoded disparities)"])},
+        "collective_ms": {"extrema_min_all_reduce": round(float(coll_ms[0]), 4), "key_frame_merge": round(float(coll_ms[1]), 4),
                           "note": "median over 20 frames, torch events on the engine's stream around each all-reduce, max over ranks; "
                                   "with one rank RCCL still runs its kernels (always_reduce) but nothing crosses xGMI"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),

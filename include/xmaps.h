@@ -275,6 +275,13 @@ int xm_shard_scatter(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
                      uint64_t* key_frame);
 /* key frame (after the reduce) -> depth / BGR device buffers */
 int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float* depth_out, uint8_t* bgr_out);
+/* Cheaper exchange for many ranks: instead of all-reducing the whole 8-byte key frame, REDUCE-SCATTER it (MAX; rank r gets
+ * cells [r*C, (r+1)*C) reduced), decode the own chunk to u16 disparities (xm_shard_decode_u16: 0 where the tag differs),
+ * ALL-GATHER the u16 chunks (2 bytes per cell) and run the frame kernel on the plain disparity frame
+ * (xm_shard_finish_u16; same cell order as the key frame).  Per rank (W-1)/W * (8 + 2) bytes per cell cross the links
+ * instead of (W-1)/W * 16.  All asynchronous on slot 0's stream. */
+int xm_shard_decode_u16(xm_handle* h, const uint64_t* key_cells, size_t n_cells, uint32_t tag, uint16_t* disp_out);
+int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_out, uint8_t* bgr_out);
 /* the stream the shard calls run on (hipStream_t as void*), so the caller can order its collective */
 void* xm_stream(xm_handle* h, int slot);
 

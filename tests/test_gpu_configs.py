@@ -228,6 +228,83 @@ def test_config4_c10m_index_shards_on_one_gpu(c10m, world):
             torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_config4_reduce_scatter_merge_on_one_gpu(c10m, world):
+    """The cheaper exchange (reduce-scatter of the key frame, decode of the own chunk to u16, all-gather of the u16 chunks,
+    frame kernel on the plain disparity frame) with every rank played by one GPU: chunks of the padded flat key frame are
+    max-merged and decoded one by one (what each rank does with its chunk), concatenated (the all-gather), finished."""
+    import torch
+    from x_maps_amd.sharded import shard_bounds
+    cfg, tb, (x, y, t), ref = c10m
+    dev = torch.device("cuda", 0)
+    X, Y, T = (torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t))
+    n = len(t)
+    with XMapsEngine(tb) as eng:
+        stream = torch.cuda.ExternalStream(eng.stream(0), device=dev)
+        cells = eng.key_shape[0] * eng.key_shape[1]
+        padded = (cells + world - 1) // world * world
+        chunk = padded // world
+        depth = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+        bgr = torch.zeros((cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+        kfs = [torch.zeros(padded, dtype=torch.int64, device=dev) for _ in range(world)]
+        mms = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+        u16 = torch.zeros(padded, dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        tag = 5
+        with torch.cuda.stream(stream):
+            for r in range(world):
+                a, b = shard_bounds(n, r, world)
+                eng.shard_minmax_device(T[a:].data_ptr(), None, b - a, mms[r].data_ptr())
+            mm = mms.min(dim=0).values.contiguous()
+            for r in range(world):
+                a, b = shard_bounds(n, r, world)
+                eng.shard_scatter_device(X[a:].data_ptr(), Y[a:].data_ptr(), T[a:].data_ptr(), None, b - a, a, mm.data_ptr(), tag,
+                                         kfs[r].data_ptr())
+            for r in range(world):  # rank r's part of the reduce-scatter + its decode
+                red = kfs[0][r * chunk:(r + 1) * chunk].clone()
+                for q in range(1, world):
+                    torch.maximum(red, kfs[q][r * chunk:(r + 1) * chunk], out=red)
+                eng.shard_decode_u16(red.data_ptr(), chunk, tag, u16[r * chunk:].data_ptr())
+            eng.shard_finish_u16(u16.data_ptr(), depth.data_ptr(), bgr.data_ptr())
+        eng.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(depth.cpu().numpy(), ref["depth"]) and np.array_equal(bgr.cpu().numpy(), ref["bgr"])
+
+
+@pytest.mark.parametrize("camera", [False, True])
+def test_reduce_scatter_merge_through_the_processor_over_rccl(camera, tmp_path):
+    """ShardedFrameProcessor(merge="reduce_scatter") over a real RCCL group (one rank here, the collectives are issued all the
+    same), both views, incl. border tiles of the u16 frame kernel."""
+    import torch
+    import torch.distributed as dist
+    from x_maps_amd.sharded import GpuShardProvider, ShardedFrameProcessor
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        with XMapsEngine(tb, camera_perspective=camera) as eng:
+            proc = ShardedFrameProcessor(GpuShardProvider(eng, dev), dist, always_reduce=True, merge="reduce_scatter")
+            for f in range(3):
+                evs = S.make_events(cfg, frame=60 + f, n=2500 + 400 * f, shuffled=(f == 1))
+                sh = _soa_dev(torch, evs, dev) + (None,)
+                torch.cuda.synchronize()
+                depth, bgr = proc.process_shard(sh, 0)
+                eng.sync()
+                torch.cuda.synchronize()
+                x, y, t, _ = S.to_soa(evs)
+                r = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
+                assert np.array_equal(depth.cpu().numpy(), r["depth"]) and np.array_equal(bgr.cpu().numpy(), r["bgr"]), f
+            assert proc.collectives_issued == 3 * 3
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_config4_sharded_processor_over_rccl_issues_both_collectives(c10m, tmp_path):
     """ShardedFrameProcessor + GpuShardProvider over a real RCCL group at C-10M.  One rank on this box, `always_reduce`
     makes it issue the 16-byte MIN and the 55.8 MB MAX all-reduce anyway (RCCL kernels run, data unchanged)."""

@@ -21,8 +21,29 @@ class OracleShardProvider:
         self.O, self.tb, self.camera = O, tables, camera
         self.shape = (tables["cam_h"], tables["cam_w"]) if camera else (tables["rect_h"], tables["rect_w"])
 
-    def new_key_frame(self):
-        return torch.zeros(self.shape, dtype=torch.int64)
+    def new_key_frame(self, pad_to=1):
+        cells = self.shape[0] * self.shape[1]
+        return torch.zeros((cells + pad_to - 1) // pad_to * pad_to, dtype=torch.int64)
+
+    def _frame(self, kf):
+        return kf[:self.shape[0] * self.shape[1]].view(self.shape)
+
+    def new_u16(self, n):
+        return torch.zeros(n, dtype=torch.int16)
+
+    def decode_u16(self, key_chunk, tag, out_chunk):
+        k = key_chunk.numpy().astype(np.uint64)
+        d = np.where((k >> np.uint64(44)) == np.uint64(tag), k & np.uint64(0xffff), np.uint64(0)).astype(np.uint16)
+        out_chunk.copy_(torch.from_numpy(d.view(np.int16)))
+
+    def finish_u16(self, disp_frame, want_bgr=True):
+        O = self.O
+        d = self._frame(disp_frame).numpy().view(np.uint16).astype(np.float32)
+        if not self.camera:
+            d = O.remap_rectified_disp_map_to_proj(d, self.tb["disp_proj_mapxy_i16"])
+        depth = O.disparity_to_depth_rectified(d, self.tb["p03"])
+        bgr = O.generate_color_map(O.clip_normalize_uint8_depth_frame(depth, self.tb["z_near"], self.tb["z_far"]))
+        return depth, bgr
 
     def clear_key_frame(self, kf):
         kf.zero_()
@@ -45,11 +66,12 @@ class OracleShardProvider:
         lo, hi = t.dtype.type(mm[0].item()), t.dtype.type(-mm[1].item())
         kf = self.O.key_frame(self.tb, x.astype(np.int64), y.astype(np.int64), t, lo, hi, idx_offset=idx_offset,
                               tag=tag, camera_perspective=self.camera)
-        torch.maximum(key_frame, torch.from_numpy(kf.astype(np.int64)), out=key_frame)
+        view = self._frame(key_frame)
+        torch.maximum(view, torch.from_numpy(kf.astype(np.int64)), out=view)
 
     def finish(self, key_frame, tag, want_bgr=True):
         O = self.O
-        d = O.decode_key_frame(key_frame.numpy().astype(np.uint64), tag)
+        d = O.decode_key_frame(self._frame(key_frame).numpy().astype(np.uint64), tag)
         if not self.camera:
             d = O.remap_rectified_disp_map_to_proj(d, self.tb["disp_proj_mapxy_i16"])
         depth = O.disparity_to_depth_rectified(d, self.tb["p03"])
@@ -60,7 +82,7 @@ class OracleShardProvider:
         return a
 
 
-def _worker(rank, world, port, camera, out_dir):
+def _worker(rank, world, port, camera, out_dir, merge):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -69,7 +91,7 @@ def _worker(rank, world, port, camera, out_dir):
     from x_maps_amd import synthetic as S
     from x_maps_amd.sharded import ShardedFrameProcessor, shard_bounds
     tb = S.make_tables(S.C_TINY)
-    proc = ShardedFrameProcessor(OracleShardProvider(tb, camera), dist)
+    proc = ShardedFrameProcessor(OracleShardProvider(tb, camera), dist, merge=merge)
     for frame, n in ((0, 4000), (1, 2501), (2, 1)):  # incl. an odd split and a frame with an EMPTY shard
         evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(frame == 1))
         x, y, t, _ = S.to_soa(evs)
@@ -79,13 +101,14 @@ def _worker(rank, world, port, camera, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("merge", ["all_reduce", "reduce_scatter"])
 @pytest.mark.parametrize("camera", [False, True])
-def test_two_rank_shards_equal_single_process(tmp_path, camera):
+def test_two_rank_shards_equal_single_process(tmp_path, camera, merge):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, camera, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, camera, str(tmp_path), merge), nprocs=2, join=True)
     import xmaps_oracle as O
     from x_maps_amd import synthetic as S
     tb = S.make_tables(S.C_TINY)

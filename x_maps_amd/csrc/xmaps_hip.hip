@@ -2160,6 +2160,34 @@ int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float
   return XM_OK;
 }
 
+int xm_shard_decode_u16(xm_handle* h, const uint64_t* key_cells, size_t n_cells, uint32_t tag, uint16_t* disp_out) {
+  if (!h || (n_cells && (!key_cells || !disp_out))) return fail(XM_ERR_INVALID, "NULL argument");
+  if (tag == 0 || tag > KEY_MAX_TAG) return fail(XM_ERR_INVALID, "tag must be in [1, 2^19)");
+  XM_ENTER(h);
+  if (n_cells == 0) return XM_OK;
+  hipLaunchKernelGGL(k_decode_keys_u16, dim3(grid_for(n_cells, BLOCK)), dim3(BLOCK), 0, h->slots[0].stream, (const u64*)key_cells,
+                     (u64)n_cells, tag, disp_out);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_out, uint8_t* bgr_out) {
+  if (!h || !disp_frame) return fail(XM_ERR_INVALID, "NULL argument");
+  XM_ENTER(h);
+  hipStream_t stream = h->slots[0].stream;
+  if (h->cfg.view == XM_VIEW_PROJECTOR) {
+    if (h->k2_direct) return fail(XM_ERR_INVALID, "xm_shard_finish_u16 needs the tiled frame kernel (XM_K2_DIRECT is set)");
+    hipLaunchKernelGGL(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)), dim3(K2_TX * K2_TY),
+                       (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, reinterpret_cast<const u64*>(disp_frame), h->tb,
+                       h->aux_st, 1u, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth_out, bgr_out, h->k2_tile_cap);
+  } else {
+    const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
+    hipLaunchKernelGGL(k_frame_direct_u16, dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, disp_frame, px, h->tb.dlut, depth_out, bgr_out);
+  }
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
 // ---- N3: frame event filters ------------------------------------------------------------------------------------
 int xm_frame_event_filter(xm_handle* h, int filter, int intended_semantics, const void* eventcd16_in, size_t n,
                           const int16_t* xp_i16, int map_height, int map_width, void* eventcd16_out, size_t* n_out) {

@@ -1538,8 +1538,9 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
 }
 
 // blk_lin / grid_x / grid_y = linear block index inside the frame's tile grid and that grid's shape
-// KEY32: `keys` is the compact 32-bit key frame of the verified-sorted path (see key32_tag)
-template <bool KEY32 = false>
+// FMT: what `keys` points at -- 0: the 64-bit packed-key frame; 1: the compact 32-bit key frame of the verified-sorted path
+// (see key32_tag); 2: a plain u16 disparity frame, no tags (sharded frames after reduce-scatter + all-gather, xm_shard_finish_u16)
+template <int FMT = 0>
 __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ keys, const DevTables& tb, SlotState* st,
                                                       u32 tag_override, const unsigned char* __restrict__ dirty,
                                                       const ulonglong2* __restrict__ zero16, float* __restrict__ depth,
@@ -1548,6 +1549,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   // Dynamic LDS sized to the largest patch of THIS rig (tile_cap cells, a multiple of 8, <= K2_TILE_MAX; set in xm_create):
   // how many blocks fit beside K1's 70 KB blocks on a CU is what bounds the pipelined frame rate, and the static
   // worst case (2 x 10 KB) was twice what C-1M's 50 x 56 patches need.
+  constexpr bool KEY32 = FMT == 1, U16 = FMT == 2;
   extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
   uint16_t* tile = k2_lds;                  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
   uint16_t* vmax = k2_lds + tile_cap + 16;  // [tile_cap]
@@ -1605,7 +1607,40 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         }
         __syncthreads();
       }
-      if constexpr (KEY32) {
+      if constexpr (U16) {  // plain disparities: 8-byte loads of 4 rows copied straight into the LDS patch
+        const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
+        const bool interior = bx >= 0 && by >= 0 && bx + cols <= tb.rect_w && by + rows_p <= tb.rect_h && (tb.rect_h & 3) == 0;
+        if (interior) {
+          const int quarter = rows_p >> 2, total = cols * quarter;
+          const float inv_q = 1.0f / (float)quarter;
+          for (int i0 = tid; i0 < total; i0 += 4 * NT) {
+            uint2 k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = min(i0 + j * NT, total - 1);
+              int c = (int)((float)i * inv_q), rq = i - c * quarter;
+              if (rq < 0) { c -= 1; rq += quarter; }
+              if (rq >= quarter) { c += 1; rq -= quarter; }
+              k[j] = *reinterpret_cast<const uint2*>(d16 + (u32)(bx + c) * (u32)tb.rect_h + (u32)(by + 4 * rq));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (i0 + j * NT < total) reinterpret_cast<uint2*>(tile)[i0 + j * NT] = k[j];
+          }
+        } else {
+          const int total = cols * rows_p;
+          const float inv_rows = 1.0f / (float)rows_p;
+          for (int i = tid; i < total; i += NT) {
+            int c = (int)((float)i * inv_rows), r = i - c * rows_p;
+            if (r < 0) { c -= 1; r += rows_p; }
+            if (r >= rows_p) { c += 1; r -= rows_p; }
+            const int gx = bx + c, gy = by + r;
+            const bool inside = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
+            const uint16_t v = d16[(u32)min(max(gx, 0), tb.rect_w - 1) * (u32)tb.rect_h + (u32)min(max(gy, 0), tb.rect_h - 1)];
+            tile[i] = inside ? v : (uint16_t)0;
+          }
+        }
+      } else if constexpr (KEY32) {
         const u32* keys32 = reinterpret_cast<const u32*>(keys);
         const u32 tag4 = key32_tag(tag);
         const bool interior = bx >= 0 && by >= 0 && bx + cols <= tb.rect_w && by + rows_p <= tb.rect_h;  // rect_h % 4 == 0 (host)
@@ -1787,7 +1822,11 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       }
     } else if (valid_g) {
       const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
-      if constexpr (KEY32) {
+      if constexpr (U16) {
+        const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
+        for (int xx = xa; xx <= xb; ++xx)
+          for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, (float)d16[(u32)xx * (u32)tb.rect_h + (u32)yy]);
+      } else if constexpr (KEY32) {
         const u32* keys32 = reinterpret_cast<const u32*>(keys);
         const u32 tag4 = key32_tag(tag);
         for (int xx = xa; xx <= xb; ++xx)
@@ -1842,7 +1881,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   XM_BLOG_END(2, st, tag);
 }
 
-template <bool KEY32 = false>
+template <int FMT = 0>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
                                                                   SlotState* st, u32 tag_override,
                                                                   const unsigned char* __restrict__ dirty,
@@ -1854,18 +1893,18 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
                   (u64)zero16 | (u64)depth | (u64)bgr |
                   (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
     return;
-  frame_proj_tiled_body<KEY32>(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap, blockIdx.y * gridDim.x + blockIdx.x,
-                               gridDim.x, gridDim.y);
+  frame_proj_tiled_body<FMT>(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x, gridDim.y);
 }
 
 // multi-frame launch: grid = (tiles_x, tiles_y, frames)
-template <bool KEY32 = false>
+template <int FMT = 0>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb,
                                                                         const ulonglong2* __restrict__ zero16,
                                                                         int tile_cap) {
   const FrameDesc d = descs[blockIdx.z];
   if (!d.valid) return;
-  frame_proj_tiled_body<KEY32>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
+  frame_proj_tiled_body<FMT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
                                blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
 }
 
@@ -1925,6 +1964,23 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct_batch(const FrameDesc* _
   const uint2 e = dlut[dsp];
   if (d.depth && pixel < n_pixels) d.depth[pixel] = __uint_as_float(e.x);
   if (d.bgr) store_bgr_block(d.bgr, (u64)blockIdx.x * BLOCK, n_pixels, e.y);
+}
+
+// Sharded frames: a chunk of the (reduced) packed-key frame -> u16 disparities (0 where the tag differs): 2 instead of 8
+// bytes per cell for the all-gather that follows the reduce-scatter
+__global__ __launch_bounds__(BLOCK) void k_decode_keys_u16(const u64* __restrict__ f, u64 n_cells, u32 tag, uint16_t* __restrict__ out) {
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n_cells) out[i] = key_disp(f[i], tag);
+}
+
+// camera view on a plain u16 disparity frame
+__global__ __launch_bounds__(BLOCK) void k_frame_direct_u16(const uint16_t* __restrict__ disp, u64 n_pixels,
+                                                            const uint2* __restrict__ dlut, float* __restrict__ depth,
+                                                            uint8_t* __restrict__ bgr) {
+  const u64 pixel = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  const uint2 e = dlut[pixel < n_pixels ? (u32)disp[pixel] : 0u];
+  if (depth && pixel < n_pixels) depth[pixel] = __uint_as_float(e.x);
+  if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, e.y);
 }
 
 // packed-key frame -> f32 disparity frame (stage A3 / A3' output)

@@ -403,6 +403,12 @@ class XMapsEngine:
     def shard_finish(self, key_ptr, tag, depth_ptr=None, bgr_ptr=None):
         N.check(self._lib.xm_shard_finish(self._h, _ptr(key_ptr), int(tag), _ptr(depth_ptr), _ptr(bgr_ptr)))
 
+    def shard_decode_u16(self, key_ptr, n_cells, tag, out_ptr):
+        N.check(self._lib.xm_shard_decode_u16(self._h, _ptr(key_ptr), int(n_cells), int(tag), _ptr(out_ptr)))
+
+    def shard_finish_u16(self, disp_ptr, depth_ptr=None, bgr_ptr=None):
+        N.check(self._lib.xm_shard_finish_u16(self._h, _ptr(disp_ptr), _ptr(depth_ptr), _ptr(bgr_ptr)))
+
     # ---- pinned host memory + asynchronous host path ---------------------------------------------------------
     def host_empty(self, shape, dtype) -> np.ndarray:
         """NumPy array backed by pinned host memory (freed with the engine).  For process_frame_pinned."""

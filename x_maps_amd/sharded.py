@@ -47,10 +47,27 @@ class GpuShardProvider:
         self.device = device
         self.stream = torch.cuda.ExternalStream(engine.stream(0), device=device)
 
-    def new_key_frame(self):
-        kf = self.torch.zeros(self.eng.key_shape, dtype=self.torch.int64, device=self.device)
+    def new_key_frame(self, pad_to: int = 1):
+        """int64 key frame, flat, padded with zero cells to a multiple of `pad_to` (the reduce-scatter wants equal chunks); the
+        engine only ever touches the first key_shape[0] * key_shape[1] cells."""
+        cells = self.eng.key_shape[0] * self.eng.key_shape[1]
+        padded = (cells + pad_to - 1) // pad_to * pad_to
+        kf = self.torch.zeros(padded, dtype=self.torch.int64, device=self.device)
         self.torch.cuda.current_stream(self.device).synchronize()
-        return kf
+        return kf.view(self.eng.key_shape) if padded == cells and pad_to == 1 else kf
+
+    def decode_u16(self, key_chunk, tag, out_chunk):
+        self.eng.shard_decode_u16(key_chunk.data_ptr(), key_chunk.numel(), tag, out_chunk.data_ptr())
+
+    def new_u16(self, n):
+        return self.torch.zeros(n, dtype=self.torch.int16, device=self.device)
+
+    def finish_u16(self, disp_frame, want_bgr=True):
+        torch = self.torch
+        depth = torch.empty((self.eng.out_h, self.eng.out_w), dtype=torch.float32, device=self.device)
+        bgr = torch.empty((self.eng.out_h, self.eng.out_w, 3), dtype=torch.uint8, device=self.device) if want_bgr else None
+        self.eng.shard_finish_u16(disp_frame.data_ptr(), depth.data_ptr(), None if bgr is None else bgr.data_ptr())
+        return depth, bgr
 
     def clear_key_frame(self, kf):
         self.eng.shard_clear(kf.data_ptr())
@@ -96,13 +113,24 @@ class ShardedFrameProcessor:
     always_reduce: issue the two all-reduces even when world_size == 1 (exercises the RCCL path on a single-GPU box;
     a one-rank all-reduce leaves the data unchanged)."""
 
-    def __init__(self, provider, dist, group=None, always_reduce=False):
+    def __init__(self, provider, dist, group=None, always_reduce=False, merge="all_reduce"):
+        """merge: "all_reduce" -- MAX all-reduce of the whole 8-byte key frame (2 (W-1)/W x 8 bytes per cell and rank);
+        "reduce_scatter" -- MAX reduce-scatter of the key frame, the own chunk decoded to u16 disparities, all-gather of
+        the u16 chunks, frame kernel on the plain disparity frame ((W-1)/W x (8 + 2) bytes per cell): 37 % less traffic,
+        and the frame kernel reads 2 instead of 8 bytes per cell."""
+        assert merge in ("all_reduce", "reduce_scatter")
         self.p = provider
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.key_frame = provider.new_key_frame()
+        self.merge = merge
+        self.key_frame = provider.new_key_frame(self.world) if merge == "reduce_scatter" else provider.new_key_frame()
+        if merge == "reduce_scatter":
+            chunk = self.key_frame.numel() // self.world
+            self.kf_chunk = self.key_frame.new_zeros(chunk)
+            self.u16_chunk = provider.new_u16(chunk)
+            self.u16_full = provider.new_u16(chunk * self.world)
         self.always_reduce = always_reduce
         self.mm = None
         self._mm_for = None
@@ -136,8 +164,38 @@ class ShardedFrameProcessor:
             self._all_reduce(self.mm, self.dist.ReduceOp.MIN)
             # 2. private scatter (reads the reduced extrema from device memory), 3. merge
             self.p.scatter(shard, idx_offset, self.mm, tag, self.key_frame)
+            if self.merge == "reduce_scatter":
+                self._reduce_scatter_max(self.key_frame, self.kf_chunk)
+                self.p.decode_u16(self.kf_chunk, tag, self.u16_chunk)
+                self._all_gather(self.u16_full, self.u16_chunk)
+                if finish_on_all_ranks or self.rank == 0:
+                    return self.p.finish_u16(self.u16_full, want_bgr)
+                return None, None
             self._all_reduce(self.key_frame, self.dist.ReduceOp.MAX)
             # 4. frame kernel on the merged keys
             if finish_on_all_ranks or self.rank == 0:
                 return self.p.finish(self.key_frame, tag, want_bgr)
         return None, None
+
+    def _reduce_scatter_max(self, full, chunk):
+        """chunk <- MAX over ranks of full[rank * len(chunk) : (rank + 1) * len(chunk)]."""
+        n = chunk.numel()
+        if self.world > 1 or self.always_reduce:
+            try:
+                self.dist.reduce_scatter_tensor(self.p.as_tensor(chunk), self.p.as_tensor(full), op=self.dist.ReduceOp.MAX,
+                                                group=self.group)
+            except (RuntimeError, NotImplementedError):  # backends without reduce-scatter (gloo): all-reduce, keep the own chunk
+                self.dist.all_reduce(self.p.as_tensor(full), op=self.dist.ReduceOp.MAX, group=self.group)
+                chunk.copy_(full[self.rank * n:(self.rank + 1) * n])
+            self.collectives_issued += 1
+        else:
+            chunk.copy_(full[:n])
+
+    def _all_gather(self, full, chunk):
+        if self.world > 1 or self.always_reduce:
+            import torch  # bytes on the wire: every backend gathers uint8 (gloo has no int16)
+            self.dist.all_gather_into_tensor(self.p.as_tensor(full).view(torch.uint8), self.p.as_tensor(chunk).view(torch.uint8),
+                                             group=self.group)
+            self.collectives_issued += 1
+        else:
+            full[:chunk.numel()].copy_(chunk)
