@@ -171,6 +171,39 @@ def test_process_batch_c1m_and_empty_frame():
                 torch.cuda.synchronize()
 
 
+def test_process_batch_verdicts_are_read_from_the_groups_stream():
+    """Two groups of 8 full-size frames back to back on the SAME 8 slots, one frame of each group shuffled: when the second
+    call settles the first group's verdicts the group's launches are still running (K1 of 8 frames, then K2) -- on the group's
+    stream, not on the slots' own streams.  The shuffled frames must be found and redone (regression: the wait looked at
+    the slot's own, idle stream and took 'nothing pending' for 'shortcut held')."""
+    torch = pytest.importorskip("torch")
+    from c_oracle import COracle
+    cfg, tb, (X, Y, T), refs = _c1m_batch(torch, 8, first_seed=90)
+    dev = X.device
+    n = cfg.n_events
+    rng = np.random.default_rng(2)
+    perm = torch.from_numpy(rng.permutation(n)).to(dev)
+    a = 3 * n
+    X[a:a + n], Y[a:a + n], T[a:a + n] = X[a:a + n][perm].clone(), Y[a:a + n][perm].clone(), T[a:a + n][perm].clone()
+    torch.cuda.synchronize()
+    r3 = COracle(tb, False, omp=True).process_ev_frame(X[a:a + n].cpu().numpy().view(np.uint16), Y[a:a + n].cpu().numpy().view(np.uint16),
+                                                       T[a:a + n].cpu().numpy())
+    refs[3] = (r3["depth"].copy(), r3["bgr"].copy(), int(r3["n_inliers"]))
+    offs = np.arange(9, dtype=np.uint64) * n
+    d1 = torch.zeros((8, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    d2 = torch.zeros_like(d1)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb, n_slots=8) as eng:
+        eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, d1.data_ptr(), None)
+        eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, d2.data_ptr(), None)
+        eng.sync()
+        assert eng.sorted_fallbacks() == 2
+        for d in (d1, d2):
+            h = d.cpu().numpy()
+            for f in range(8):
+                assert np.array_equal(h[f], refs[f][0]), f
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # config 4
 # ---------------------------------------------------------------------------------------------------------------------

@@ -98,6 +98,7 @@ struct Slot {
     float* host_depth = nullptr;  // XM_MEM_HOST_PINNED: where the outputs are copied to
     uint8_t* host_bgr = nullptr;
     u32 tag = 0;
+    hipStream_t stream = nullptr;  // the stream the frame's launches went to (the group's stream for xm_process_batch)
   } prev;
   u64* key_frame = nullptr;
   u32* key32 = nullptr;            // compact key frame of the verified-sorted projector-view path (see key32_tag)
@@ -853,7 +854,7 @@ int resolve_prev(xm_handle* h, Slot& s, bool* redone = nullptr) {
         // not there after 30 us: make sure the runtime has really handed the slot's commands to the GPU (a query flushes
         // anything it still holds back -- seen: a frame that sat for 20 ms until something synchronised), and stop polling
         // once the stream itself reports completion
-        hipError_t q = hipStreamQuery(s.stream);
+        hipError_t q = hipStreamQuery(s.prev.stream ? s.prev.stream : s.stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) HIP_TRY(q);
         t_next = std::chrono::steady_clock::now() + std::chrono::microseconds(XM_POLL_NEXT_US);
@@ -915,6 +916,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
       s.prev.host_depth = nullptr;
       s.prev.host_bgr = nullptr;
       s.prev.tag = s.api_tag;
+      s.prev.stream = s.stream;
     }
     return XM_OK;
   }
@@ -967,6 +969,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     s.prev.host_depth = host_in ? depth_out : nullptr;
     s.prev.host_bgr = host_in ? bgr_out : nullptr;
     s.prev.tag = s.host_tag;
+    s.prev.stream = s.stream;
   }
   if (mem == XM_MEM_HOST || profile) {
     HIP_TRY(hipStreamSynchronize(s.stream));
@@ -1560,6 +1563,7 @@ int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
       s.prev.host_depth = nullptr;
       s.prev.host_bgr = nullptr;
       s.prev.tag = s.host_tag;
+      s.prev.stream = stream;
     }
   }
   return XM_OK;
