@@ -1385,11 +1385,34 @@ int xm_sorted_fallbacks(xm_handle* h, uint64_t* count) {
   return XM_OK;
 }
 
+// Wait for a stream: poll it for a while before blocking.  A blocking hipStreamSynchronize wakes up tens of microseconds
+// after the stream has drained (interrupt path); the hot loop's frames are ~10 us, so a caller that brackets short bursts with
+// xm_sync() (bench.py --steps 20: 0.2 ms of work) would spend a quarter of its time asleep.
+static int wait_stream(hipStream_t st) {
+  const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+  unsigned spins = 0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return XM_OK;
+    if (q != hipErrorNotReady) HIP_TRY(q);
+    __builtin_ia32_pause();
+    if ((++spins & 0xff) == 0 && std::chrono::steady_clock::now() > give_up) break;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return XM_OK;
+}
+
 int xm_sync(xm_handle* h) {
   if (!h) return fail(XM_ERR_INVALID, "NULL handle");
   XM_ENTER(h);
-  for (Slot& s : h->slots) HIP_TRY(hipStreamSynchronize(s.stream));
-  for (hipStream_t gs : h->gstreams) HIP_TRY(hipStreamSynchronize(gs));  // graph replays run on streams of their own
+  for (hipStream_t st : h->streams) {
+    int rcw = wait_stream(st);
+    if (rcw) return rcw;
+  }
+  for (hipStream_t gs : h->gstreams) {  // graph replays run on streams of their own
+    int rcw = wait_stream(gs);
+    if (rcw) return rcw;
+  }
   for (Slot& s : h->slots) {  // every stream is idle: nothing left to order against
     s.pending_batch_ev = nullptr;
     s.eager_dirty = false;
@@ -2321,6 +2344,10 @@ struct xm_ingest {
   uint64_t next_seq = 0;     // frames delivered through xm_ingest_poll so far
   uint64_t pushed = 0;       // events handed in
   uint64_t pushes = 0;
+  // Upper bound of the live part of the device buffer (its real size is known to the device only): grows with every push,
+  // shrinks when a delivered frame reports how much was left after its cut.  Sizes the grids of the segmentation / frame kernels.
+  uint64_t ub_live = 0;
+  std::vector<std::pair<uint64_t, uint64_t>> recent;  // (push number, events) of the pushes a frame may still report on
   uint64_t est_frame_events = 0;
 };
 
@@ -2573,8 +2600,11 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   }
   g->pushed += n;
   g->pushes += 1;
+  g->ub_live = std::min<u64>(g->capacity, g->ub_live + n);
+  g->recent.emplace_back(g->pushes, (uint64_t)n);
+  if (g->recent.size() > 4096) g->recent.erase(g->recent.begin(), g->recent.begin() + 2048);
   // segmentation over the live part (its size is known to the device only: the grids cover the host's upper bound)
-  const u64 bound64 = std::min<u64>(g->capacity, g->pushed);
+  const u64 bound64 = g->ub_live;
   const u32 n_bound = (u32)bound64;
   hipLaunchKernelGGL(k_ing_begin, dim3(1), dim3(1), 0, s, g->st, (const uint4*)g->buf[0], (const uint4*)g->buf[1], g->period, g->desc);
   if (n_bound >= 2) {
@@ -2592,7 +2622,7 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
     const u64 est = g->est_frame_events ? g->est_frame_events : 0;
     int rc = batch_path(h, est) ? ingest_launch_frame<false>(g, bound64, est) : ingest_launch_frame<true>(g, bound64, est);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->st, (const FrameDesc*)g->desc, g->h_status);
+    hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->st, (const FrameDesc*)g->desc, g->h_status, (u64)g->pushes);
   }
   HIP_TRY(hipGetLastError());
   return XM_OK;
@@ -2617,6 +2647,17 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->depth = g->h_depth[slot];
   out->bgr = g->h_bgr[slot];
   g->est_frame_events = st->n_events;  // the next frames' K1 variant / block size follow the stream's density
+  {  // after that frame's cut `live_after` events were left; everything pushed since may have been appended
+    uint64_t later = 0;
+    size_t keep_from = g->recent.size();
+    for (size_t i = g->recent.size(); i-- > 0;) {
+      if (g->recent[i].first <= st->push_seq) break;
+      later += g->recent[i].second;
+      keep_from = i;
+    }
+    g->recent.erase(g->recent.begin(), g->recent.begin() + keep_from);
+    g->ub_live = std::min<uint64_t>(g->capacity, st->live_after + later);
+  }
   g->next_seq = out->lost ? seq : g->next_seq + 1;
   return 1;
 }
@@ -2637,6 +2678,8 @@ int xm_ingest_reset(xm_ingest* g) {
   HIP_TRY(hipMemcpy(&z, g->st, sizeof z, hipMemcpyDeviceToHost));
   z.buf_start = z.write = 0;  // RobustTriggerFinder.reset(): the buffered events are discarded (trigger_finder.py:116-119)
   HIP_TRY(hipMemcpy(g->st, &z, sizeof z, hipMemcpyHostToDevice));
+  g->ub_live = 0;
+  g->recent.clear();
   return XM_OK;
 }
 

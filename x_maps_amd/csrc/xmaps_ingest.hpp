@@ -41,6 +41,7 @@ struct IngestStatus {     // pinned host ring entry, written by k_ing_publish wh
   long long t_first, t_last;
   u64 n_inliers, n_index_errors, n_used;
   u64 live_after;         // events left in the buffer after the cut
+  u64 push_seq;           // number of the xm_ingest_push call whose launches cut this frame (the host tightens its bounds with it)
   u32 overflow;
   u32 pad;
 };
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(BLOCK) void k_ing_segment(IngestState* st, const ui
 }
 
 // after the frame kernels: statistics + sequence number into the pinned ring (system scope: the host polls it)
-__global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const FrameDesc* __restrict__ desc, IngestStatus* ring_status) {
+__global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const FrameDesc* __restrict__ desc, IngestStatus* ring_status,
+                                                    u64 push_seq) {
   if (!desc->valid) return;
   const SlotState* s = desc->st;
   const u32 tag = s->tag_a, parity = tag & 1;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
   out->n_index_errors = oob;
   out->n_used = used;
   out->live_after = st->write - st->buf_start;
+  out->push_seq = push_seq;
   out->overflow = st->overflow;
   st->frames += 1;
   __threadfence_system();
