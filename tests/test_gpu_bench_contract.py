@@ -1,0 +1,51 @@
+"""-m gpu: bench.py keeps its contract with the driver -- the LAST stdout line is one JSON object carrying metric / value /
+unit / n_gpus / steps / warmup / ms_per_step / roofline / cpu_baseline, for the default workload and for the other
+BASELINE configurations' modes.  Runs the real script in a subprocess with short settings."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    env = dict(os.environ, XM_BENCH_PREWARM_S="0.05")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    return json.loads(last)
+
+
+def test_default_line_as_the_driver_calls_it():
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1", "--no-other-modes")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["value"] > 1000 and d["unit"] == "Mevents/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel"] == "k_scatter"
+    assert 0.05 < r["frac"] < 1.0 and r["avg_launch_us"]["k_scatter"] > 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["parity"]["depth_bit_exact"] and d["parity"]["bgr_equal"]
+    assert abs(d["value"] - 1e6 * 20 / (d["ms_per_step"] * 20 * 1e-3) / 1e6) / d["value"] < 0.01  # value == events / time
+    assert d["host_path"]["meets_north_star_1_Gevent_per_s_end_to_end"] and d["ingest_path"]["first_frame_depth_equals_oracle"]
+
+
+@pytest.mark.parametrize("flags,workload", [(("--graph", "--steps", "60"), "C-60x1M"), (("--sharded", "--steps", "10"), "C-10M"),
+                                            (("--esl", "--steps", "50", "--no-host-path"), "C-ESL")])
+def test_other_configurations_print_one_json_line(flags, workload):
+    d = _run(*flags, "--no-cpu-baseline")
+    assert workload in d["config"]["workload"] and d["value"] > 100 and d["ms_per_step"] > 0
+    if "--graph" in flags:
+        assert d["latency_us"]["batch_of_60_frames"]["p99"] >= d["latency_us"]["batch_of_60_frames"]["p50"] > 0
+        assert all(v["depth_bit_exact"] for v in d["parity"].values())
+    if "--sharded" in flags:
+        assert d["scaling"] == "strong" and d["config"]["host_synchronisations_per_frame"] == 0 and d["parity"]["depth_bit_exact"]
