@@ -16,7 +16,8 @@ torch.cuda.synchronize()
 lib = N.load_library()
 names = ["0 start", "1 event+sample loads issued", "2 extrema loaded, TimeNorm", "3 window from samples", "4 bands loaded+stored, slots zeroed",
          "5 time columns computed", "6 barrier1", "7 fast + slow pass done", "8 barrier2", "9 flush issued", "10 end",
-         "11 (bands stored to LDS)", "12 (slow gather 2 issued, before barrier1)"]
+         "11 (bands stored to LDS)", "12 (slow gather 2 issued, before barrier1)",
+         "13 (LUT + X-map gathers consumed, before the slot-reuse barrier)", "14 (slots cleared, second barrier passed)"]
 acc = []
 acc_raw = []
 for it in range(30):
@@ -26,7 +27,7 @@ for it in range(30):
     lib.xm_debug_timeline(ctypes.c_void_p(buf.ctypes.data))
     if it >= 5:
         acc_raw.append(buf.astype(np.float64))
-        acc.append((buf[:, :13].astype(np.int64) - buf[:, :1].astype(np.int64)))
+        acc.append((buf[:, :15].astype(np.int64) - buf[:, :1].astype(np.int64)))
 a = np.mean(acc, axis=0)  # [block][phase] in s_memtime ticks (100 MHz constant clock on gfx9: 10 ns)
 print("phase                          mean over blocks 0..63   (s_memtime ticks; scale with the kernel duration printed below)")
 prev = 0

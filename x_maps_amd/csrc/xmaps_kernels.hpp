@@ -153,28 +153,57 @@ constexpr u64 MM_INIT_MAX = 0ull;
 template <typename T> struct TimeNorm;
 template <> struct TimeNorm<long long> {
   long long tmin;
-  double den, scale, rinv;
-  bool degenerate, small;
+  double den, scale, rs;
+  bool degenerate, fast_frame;
   __device__ TimeNorm(long long lo, long long hi, int S)
       : tmin(lo), den((double)(hi - lo)), scale((double)S), degenerate(hi == lo) {
-    small = (u64)(hi - lo) <= 0xffffffffull;  // a frame spans microseconds: always true in practice
-    rinv = 1.0 / den;
+    // a frame spans microseconds: (hi - lo) < 2^32 always holds in practice; everything else takes the exact path
+    fast_frame = (u64)(hi - lo) <= 0xffffffffull && !degenerate;
+    rs = (1.0 / den) * scale;
   }
-  // Reference: rint(fl(fl(a / den) * S)), a = t - tmin.  Fast path: e = fl(fl(a * fl(1/den)) * S) differs from the
-  // reference's product by < 5 ulp (< 2e-11 for columns <= 32767); whenever e is further than 1e-6 from a rounding
-  // boundary (x.5) both round to the same integer, so rint(e) IS the reference result.  Closer than that (exact
-  // ties such as golden g1d_rint_ties land here) the IEEE divide below decides.  ~8 instructions instead of ~50.
-  // Straight-line on purpose (K1 is bound by instruction issue): the fast value is computed for every lane from the low
-  // 32 bits of a, and ONE rare branch covers everything else (a >= 2^32, near-tie, degenerate frame).
-  __device__ int column(long long t) const {
+  // Reference: rint(fl(fl(a / den) * S)), a = t - tmin.  Fast value: e = fl(a * fl(fl(1/den) * S)) differs from the
+  // reference's product by < 4 ulp (< 2e-12 for columns <= 32767); whenever e is further than 1e-6 from a rounding
+  // boundary (x.5) both round to the same integer, so rint(e) IS the reference result.  Closer than that (exact ties such
+  // as golden g1d_rint_ties land here) the IEEE divide of column_exact decides.
+  // Branch-free and built from full-rate FP64 adds only (K1 as a single launch is bound by this dependent chain; the
+  // conversions and v_rndne_f64 are quarter rate): u32 -> double and double -> nearest-even integer both go through the
+  // 2^52 trick -- bits(2^52) | a IS 2^52 + a, and the low word of fl(e + 2^52) IS rint(e) for 0 <= e < 2^32.
+  // `ok` = the value may be used; callers OR the failures of a batch together and take ONE rare branch.
+  __device__ int column_fast(long long t, bool& ok) const {
+    constexpr double M = 4503599627370496.0;  // 2^52
     const u64 a = (u64)(t - tmin);
-    const double e = (__uint2double_rn((u32)a) * rinv) * scale;  // meaningful only when a < 2^32
-    const double r = rint(e);
-    const bool fast_ok = small && !degenerate && (u32)(a >> 32) == 0u && fabs(fabs(e - r) - 0.5) > 1e-6;
-    if (__builtin_expect(fast_ok, 1)) return (int)(short)(int)r;
+    const double ad = __hiloint2double(0x43300000, (int)(u32)a) - M;  // (double)(u32)a, exact
+    const double e = ad * rs;
+    const double m = e + M;  // low word = rint(e), ties to even
+    const double d = e - (m - M);  // e - rint(e), exact (Sterbenz)
+    ok = ((u32)(a >> 32) == 0u) & (fabs(d) < 0.5 - 1e-6);
+    return (int)(short)__double2loint(m);
+  }
+  __device__ int column_exact(long long t) const {
     if (degenerate) return 0;  // 0/0 = NaN -> int16 cast = 0 (what NumPy yields on x86-64)
     const double tn = (double)(t - tmin) / den;
     return (int)(short)(int)rint(tn * scale);
+  }
+  __device__ int column(long long t) const {
+    bool ok;
+    const int c = column_fast(t, ok);
+    return __builtin_expect(ok && fast_frame, 1) ? c : column_exact(t);
+  }
+  // N columns at once: straight-line fast values (N independent chains for the scheduler to interleave), one rare branch
+  template <int N> __device__ void columns(const long long (&t)[N], int (&col)[N]) const {
+    u32 redo = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      bool ok;
+      col[k] = column_fast(t[k], ok);
+      redo |= ok ? 0u : (1u << k);
+    }
+    if (!fast_frame) redo = (1u << N) - 1;
+    if (__builtin_expect(redo != 0, 0)) {
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if ((redo >> k) & 1) col[k] = column_exact(t[k]);
+    }
   }
 };
 template <> struct TimeNorm<double> {
@@ -186,6 +215,10 @@ template <> struct TimeNorm<double> {
     double tn = (t - tmin) / den;
     return (int)(short)(int)rint(tn * scale);
   }
+  template <int N> __device__ void columns(const double (&t)[N], int (&col)[N]) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) col[k] = column(t[k]);
+  }
 };
 template <> struct TimeNorm<float> {  // eval caller with an f32 time surface: NumPy stays in f32
   float tmin, den, scale;
@@ -195,6 +228,10 @@ template <> struct TimeNorm<float> {  // eval caller with an f32 time surface: N
     if (degenerate) return 0;
     float tn = (t - tmin) / den;
     return (int)(short)(int)rintf(tn * scale);
+  }
+  template <int N> __device__ void columns(const float (&t)[N], int (&col)[N]) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) col[k] = column(t[k]);
   }
 };
 
@@ -688,7 +725,11 @@ __device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime s
 #define XM_TILE_THREADS 512
 #endif
 constexpr int TILE_THREADS = XM_TILE_THREADS;   // 512 x 8 or 1024 x 4 events: same LDS tile, different latency/issue trade
+#ifdef XM_TILE_EPT  // experiments: events per thread decoupled from the block size (smaller tiles)
+constexpr int TILE_EPT = XM_TILE_EPT;
+#else
 constexpr int TILE_EPT = 4096 / XM_TILE_THREADS;
+#endif
 constexpr int TILE_EVENTS = TILE_THREADS * TILE_EPT;  // largest block: 4096 events (the LDS slots hold (local idx + 1) << 16)
 
 // VEC: SoA columns 16-byte aligned -> each thread loads TILE_EPT consecutive events with 8/16-byte loads.  A compile-time
@@ -971,6 +1012,16 @@ __device__ __forceinline__ void scatter_tiled_body(
   // A FIXED number of loads per wave is issued here (enough for the C-1M bands), so that the wait for the thread's own
   // events further down can be a counted one (vmcnt(6)) and the bands stay in flight during the time-column arithmetic;
   // taller tables / smaller blocks fetch the rest after that arithmetic (dynamic trip count = full wait, seen in the ISA).
+  // The compiler waits with vmcnt(0) before the first use of a register loaded BEFORE an LDS-direct load (seen in the ISA:
+  // it does not count past them), i.e. the time-column arithmetic below would wait for the bands too.  Touch the event
+  // registers here instead: the wait lands in front of the band loads, where only the events are outstanding (they were
+  // issued ~1 us ago and the samples behind them have already arrived), and the bands then fly during the arithmetic.
+#ifndef XM_NO_EVENT_PIN
+#pragma unroll
+  for (int q = 0; q < TILE_EPT / 2; ++q) asm volatile("" : "+v"(xw[q]), "+v"(yw[q]), "+v"(pw[q]));
+#pragma unroll
+  for (int k = 0; k < TILE_EPT; ++k) asm volatile("" : "+v"(tt[k]));
+#endif
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   constexpr int UL_L = TILE_THREADS >= 1024 ? 2 : 4, UL_X = TILE_THREADS >= 1024 ? 1 : 2;
@@ -1018,8 +1069,8 @@ __device__ __forceinline__ void scatter_tiled_body(
     used[k] = (inb >> k) & 1;
     if constexpr (HAS_P) used[k] = used[k] && (short)((pw[k >> 1] >> ((k & 1) * 16)) & 0xffff) == 1;
     lidx[k] = VEC ? (u32)tid * TILE_EPT + k : (u32)k * nthreads + tid;
-    col[k] = XM_ABL(3) ? ts_lo + 2 : tn.column(tt[k]);  // every lane; `used` masks the event below
   }
+  tn.columns(tt, col);  // every lane; `used` masks the event below
   if (sorted_mode) {  // verify the time-sorted declaration: 2 compares per event
     bool bad = false;
 #pragma unroll
@@ -1195,12 +1246,14 @@ __device__ __forceinline__ void scatter_tiled_body(
       n_in += __popcll(__ballot(write));  // wavefront ballots instead of per-lane counters
     }
   }
+  XM_STAMP(13);
   __syncthreads();  // every LUT gather has landed: the region can be reused
   {
     uint4* l_win = reinterpret_cast<uint4*>(win);
     for (int i = tid; i < win_q; i += nthreads) l_win[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();  // cleared slots visible
+  XM_STAMP(14);
 #pragma unroll
   for (int k = 0; k < TILE_EPT; ++k)
     if (wr[k] && !XM_ABL(1)) atomicMax(&win[slot[k]], val[k]);
