@@ -151,6 +151,10 @@ int xm_sync(xm_handle* h); /* wait for everything enqueued on every slot of the 
 /* Frames redone on the general path because a time-sorted shortcut (XM_FLAG_TIME_SORTED in synchronous calls,
  * XM_FLAG_TRY_SORTED always) did not hold, since xm_create. */
 int xm_sorted_fallbacks(xm_handle* h, uint64_t* count);
+/* Frames enqueued per K1 variant since xm_create: counts[0] general (K0 + 64-bit packed keys), counts[1] verified-sorted
+ * shortcut on the 64-bit key frame, counts[2] compact 32-bit key frame, counts[3] column tiles + plain u16 disparity frame
+ * (no atomics; needs an injective X-map -> frame-cell relation, checked in xm_create).  A redone frame counts twice. */
+int xm_path_counts(xm_handle* h, uint64_t counts[4]);
 
 /* ---- the fused hot path: one projector frame of events -> depth frame (+ BGR) -------------------- */
 /*

@@ -1,0 +1,264 @@
+"""-m gpu: the column-tile K1 (x_maps_amd/csrc/xmaps_k1cols.hpp) -- a tile = W X-map time columns and the index range of the
+sorted stream that falls into them (found by a search over t), last-writer-wins resolved entirely in the tile's LDS slots,
+the flush a plain store of every live slot into a plain u16 disparity frame that K2 reads untagged.  Exactness rests on:
+the injectivity check of xm_create, every event being verified against its tile's columns (failures -> automatic redo on
+the general path), empty slots being stored as zeros (no stale cells from earlier frames), and the search being a
+deterministic function of (stream, column).  Each is exercised here against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import xmaps_oracle as O
+from x_maps_amd import XMapsEngine
+from x_maps_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(tb, evs, **kw):
+    x, y, t, _ = S.to_soa(evs)
+    return O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, **kw)
+
+
+def _run(eng, evs):
+    x, y, t, _ = S.to_soa(evs)
+    return eng.process_frame(x, y, t)
+
+
+def _same(got, ref):
+    d, b, st = got
+    return np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]) and st.n_inliers == int(ref["mask"].sum())
+
+
+def test_dense_frames_take_the_column_tiles_and_match_the_oracle():
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    with XMapsEngine(tb) as eng:
+        for f in range(3):
+            evs = S.make_events(cfg, frame=f)
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        pc = eng.path_counts()
+        assert pc["cols"] == 3 and pc["key32"] == 0 and pc["general"] == 0 and eng.sorted_fallbacks() == 0
+
+
+def test_no_stale_cells_when_the_content_changes_from_frame_to_frame():
+    """Consecutive frames of very different coverage on ONE slot: there is no tag and no clear, every tile stores its empty
+    slots as zeros -- a frame whose scan covers only part of the time axis must not show the previous frame's cells."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    with XMapsEngine(tb, n_slots=1) as eng:
+        for f in range(24):
+            evs = S.make_events(cfg, frame=f % 3, n=500_000 + 100_000 * (f % 4))
+            if f % 3 == 1:  # events only in the first third of the scan's time range (t[0], t[n-1] shrink with it)
+                evs = evs[: len(evs) // 3]
+            if f % 3 == 2:  # a hole in the middle of the scan: whole tiles without a single event
+                t = evs["t"].astype(np.int64)
+                evs = evs[(t < t[0] + 4_000) | (t > t[0] + 9_000)]
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] >= 20  # (the sparsest frames go to the direct kernel)
+
+
+def test_uneven_event_rate_defeats_the_interpolated_guess_not_the_result():
+    """80 % of the events in the first fifth of the scan: the interpolation window of the boundary search misses, the 64-ary
+    search over the whole stream finds the same boundaries; overfull tiles take more than one pass."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    rng = np.random.default_rng(5)
+    n = 900_000
+    evs = S.make_events(cfg, frame=3, n=n)
+    t_rel = np.sort(np.concatenate([rng.integers(0, 2_600, int(n * 0.8)), rng.integers(2_600, 13_000, n - int(n * 0.8))]))
+    evs["t"] = 5_000_000 + t_rel
+    evs["x"] = np.clip(np.rint(t_rel / 13_000 * cfg.cam_w + rng.normal(0.0, 2.0, n)), 0, cfg.cam_w - 1).astype(np.uint16)
+    with XMapsEngine(tb) as eng:
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 1
+
+
+def test_x_noise_and_duplicates_are_ordered_exactly_inside_the_tile():
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    rng = np.random.default_rng(9)
+    evs = S.make_events(cfg, frame=11, n=700_000)
+    noisy = rng.random(len(evs)) < 0.02
+    evs["x"][noisy] = rng.integers(0, cfg.cam_w, int(noisy.sum()))
+    idx = np.nonzero(noisy)[0][::7]
+    idx = idx[idx + 1 < len(evs)]
+    evs["x"][idx + 1], evs["y"][idx + 1] = evs["x"][idx], evs["y"][idx]  # same pixel right behind a noisy event
+    with XMapsEngine(tb) as eng:
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 1
+
+
+def test_ties_across_tile_boundaries():
+    """Coarse time stamps: thousands of events share one stamp, stamps sit exactly on column boundaries (rint ties)."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=4, n=800_000)
+    t = evs["t"].astype(np.int64)
+    evs["t"] = t[0] + (t - t[0]) // 16 * 16
+    with XMapsEngine(tb) as eng:
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        assert eng.sorted_fallbacks() == 0
+
+
+@pytest.mark.parametrize("kind", ["swapped_blocks", "one_late_event", "reversed"])
+def test_unsorted_streams_fail_the_tiles_and_are_redone_exactly(kind):
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=6, n=600_000)
+    if kind == "swapped_blocks":  # two far-apart blocks of the stream exchanged; t[0] and t[n-1] still the extrema
+        a, b = evs[100_000:110_000].copy(), evs[400_000:410_000].copy()
+        evs[100_000:110_000], evs[400_000:410_000] = b, a
+    elif kind == "one_late_event":  # a single event delivered 3 ms late
+        e = evs[50_000].copy()
+        evs[50_000:200_000] = evs[50_001:200_001]
+        evs[200_000] = e
+    else:
+        evs = evs[::-1].copy()
+    ref = _ref(tb, evs)
+    with XMapsEngine(tb) as eng:
+        d, b, st = _run(eng, evs)
+        assert st.n_unsorted > 0 and eng.sorted_fallbacks() == 1
+        assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]) and st.n_inliers == int(ref["mask"].sum())
+
+
+def test_a_burst_in_one_time_column_overflows_the_tile_and_is_redone():
+    """100 k events with one time stamp: more than a tile's 16-bit local index holds -> the tile objects, the frame is redone."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=7, n=500_000)
+    evs["t"][200_000:300_000] = evs["t"][200_000]
+    ref = _ref(tb, evs)
+    with XMapsEngine(tb) as eng:
+        d, b, st = _run(eng, evs)
+        assert eng.sorted_fallbacks() == 1
+        assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+
+
+def test_asynchronous_frames_with_failures_in_between():
+    torch = pytest.importorskip("torch")
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    good = [S.make_events(cfg, frame=20 + i, n=400_000 + 100_000 * i) for i in range(3)]
+    bad = S.make_events(cfg, frame=30, n=500_000)
+    a, b = bad[10_000:20_000].copy(), bad[300_000:310_000].copy()
+    bad[10_000:20_000], bad[300_000:310_000] = b, a
+    seq = [good[0], bad, good[1], good[2], bad, good[0], good[1]]
+    refs = [_ref(tb, e, want_bgr=False)["depth"] for e in seq]
+    dev = torch.device("cuda", 0)
+    with XMapsEngine(tb, n_slots=3) as eng:
+        bufs = []
+        for e in seq:
+            x, y, t, _ = S.to_soa(e)
+            X, Y, T = (torch.from_numpy(v).to(dev) for v in (x.view(np.int16), y.view(np.int16), t))
+            bufs.append((X, Y, T, torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)))
+        torch.cuda.synchronize()
+        for X, Y, T, out in bufs:
+            eng.process_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(T), out.data_ptr(), None)
+        eng.sync()
+        assert eng.sorted_fallbacks() == 2
+        for i, ((_, _, _, out), r) in enumerate(zip(bufs, refs)):
+            assert np.array_equal(out.cpu().numpy(), r), i
+
+
+def test_groups_of_frames_in_one_launch():
+    torch = pytest.importorskip("torch")
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    B = 4
+    frames = [S.make_events(cfg, frame=40 + i, n=600_000) for i in range(B)]
+    n = 600_000
+    dev = torch.device("cuda", 0)
+    X = torch.empty(B * n, dtype=torch.int16, device=dev)
+    Y = torch.empty_like(X)
+    T = torch.empty(B * n, dtype=torch.int64, device=dev)
+    for i, e in enumerate(frames):
+        x, y, t, _ = S.to_soa(e)
+        X[i * n:(i + 1) * n] = torch.from_numpy(x.view(np.int16))
+        Y[i * n:(i + 1) * n] = torch.from_numpy(y.view(np.int16))
+        T[i * n:(i + 1) * n] = torch.from_numpy(t)
+    depth = torch.zeros((B, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((B, cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+    offs = np.arange(B + 1, dtype=np.uint64) * n
+    with XMapsEngine(tb, n_slots=2 * B) as eng:
+        for rep in range(3):
+            eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, depth.data_ptr(), bgr.data_ptr())
+        eng.sync()
+        assert eng.path_counts()["cols"] == 3 * B and eng.sorted_fallbacks() == 0
+    for i, e in enumerate(frames):
+        ref = _ref(tb, e)
+        assert np.array_equal(depth[i].cpu().numpy(), ref["depth"]) and np.array_equal(bgr[i].cpu().numpy(), ref["bgr"]), i
+
+
+def test_eventcd_records_and_unaligned_columns():
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=8, n=700_001)
+    ref = _ref(tb, evs)
+    with XMapsEngine(tb) as eng:
+        d, b, st = eng.process_events(evs)  # 16-byte AoS records
+        assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+        x, y, t, _ = S.to_soa(evs)
+        xo, yo = np.empty(len(x) + 1, np.uint16)[1:], np.empty(len(y) + 3, np.uint16)[3:]  # 2-byte aligned only
+        xo[:], yo[:] = x, y
+        d2, b2, _ = eng.process_frame(xo, yo, t)
+        assert np.array_equal(d2, ref["depth"]) and np.array_equal(b2, ref["bgr"])
+        assert eng.path_counts()["cols"] == 2 and eng.sorted_fallbacks() == 0
+
+
+def test_a_non_injective_x_map_keeps_the_keyed_paths():
+    """Two time columns of a row that map to the same frame cell: xm_create must notice and leave the column tiles off."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    xm = tb["proj_x_map"].copy()
+    xm[400:900, 301] = xm[400:900, 300]
+    tb["proj_x_map"] = xm
+    evs = S.make_events(cfg, frame=9, n=600_000)
+    with XMapsEngine(tb) as eng:
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        pc = eng.path_counts()  # neither compact path: the tile-ordered 32-bit keys need the same property
+        assert pc["cols"] == 0 and pc["key32"] == 0 and pc["sorted_key64"] == 1
+
+
+def test_switch_off_gives_the_same_frames(monkeypatch):
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=15)
+    with XMapsEngine(tb) as eng:
+        d0, b0, s0 = _run(eng, evs)
+        assert eng.path_counts()["cols"] == 1
+    monkeypatch.setenv("XM_COLS", "0")
+    with XMapsEngine(tb) as eng:
+        d1, b1, s1 = _run(eng, evs)
+        assert eng.path_counts()["cols"] == 0
+    assert np.array_equal(d0, d1) and np.array_equal(b0, b1) and s0.n_inliers == s1.n_inliers
+
+
+def test_index_errors_are_counted_like_the_reference():
+    """Events outside the camera and events whose frame column leaves the rectified frame: dropped and counted."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=10, n=600_000)
+    evs["x"][1000::50_000] = cfg.cam_w + 3
+    evs["y"][2000::60_000] = cfg.cam_h
+    x, y, t, _ = S.to_soa(evs)
+    with XMapsEngine(tb) as eng:
+        d, b, st = eng.process_frame(x, y, t, raise_on_index_error=False)
+        assert st.n_index_errors > 0 and eng.path_counts()["cols"] == 1
+        ok = (x < cfg.cam_w) & (y < cfg.cam_h)
+        ref = _ref(tb, evs[ok])  # the reference raises; without the offending events it yields the same frame
+        # (t[0] and t[n-1] are unchanged by the removal)
+        assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+
+
+def test_c10m_tiles_of_one_column_and_several_passes():
+    """C-10M: 7 800 events per time column -> W = 1, two passes per tile; against the C oracle."""
+    from c_oracle import COracle
+    cfg = S.C_10M
+    tb = S.make_tables(cfg)
+    evs = S.make_events(cfg, frame=0)
+    x, y, t, _ = S.to_soa(evs)
+    ref = COracle(tb, False, omp=True).process_ev_frame(x, y, t, want_events=False)
+    with XMapsEngine(tb) as eng:
+        d, b, st = eng.process_frame(x, y, t)
+        assert eng.path_counts()["cols"] == 1 and eng.sorted_fallbacks() == 0
+    assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])

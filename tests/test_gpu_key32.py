@@ -13,6 +13,12 @@ from x_maps_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _keyed_path_only(monkeypatch):
+    """The column tiles (tests/test_gpu_cols.py) take precedence on rigs that qualify for both: switch them off here."""
+    monkeypatch.setenv("XM_COLS", "0")
+
+
 def _ref(tb, evs):
     x, y, t, _ = S.to_soa(evs)
     return O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t)

@@ -4,7 +4,7 @@
 # every run is bounded by its own timeout.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${1:-pmc_batch}; mkdir -p $OUT
-CMD="python tools/batch_probe.py 60 4"
+CMD="python tools/batch_probe.py 60 4 ${XM_PROBE_MODE:-0}"
 timeout 120 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace failed"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \

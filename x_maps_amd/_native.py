@@ -122,6 +122,7 @@ SYMBOLS = {
     "xm_destroy": (None, [_P]),
     "xm_sync": (C.c_int, [_P]),
     "xm_sorted_fallbacks": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "xm_path_counts": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_process_frame_aos": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_last_frame_stats": (C.c_int, [_P, C.POINTER(xm_frame_stats)]),

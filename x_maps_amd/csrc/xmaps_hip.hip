@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared xmaps_hip.hip -o libxmaps_hip.so
 // -ffp-contract=off keeps the time normalisation (divide, multiply, rint) unfused = bit-exact with NumPy.
 #include "xmaps_kernels.hpp"
+#include "xmaps_k1cols.hpp"
 #include "xmaps_ingest.hpp"
 
 #include <hip/hip_ext.h>
@@ -104,7 +105,9 @@ struct Slot {
   u32* key32 = nullptr;            // compact key frame of the verified-sorted projector-view path (see key32_tag)
   u32 key32_valid_from = 0;        // tag of the frame before which key32 was last cleared: every key in it has a tag in
                                    // [valid_from, valid_from + 15), so the 4-bit tag field is unambiguous
-  bool last_key32 = false;
+  bool last_key32 = false;         // the slot's last frame took a compact path (key32 or column tiles): a failure counts against it
+  bool last_cols = false;          // ... the column tiles (K0b was launched in K0's place)
+  uint16_t* frame16 = nullptr;     // plain u16 disparity frame of the column-tile path (xmaps_k1cols.hpp): rewritten by every frame
   unsigned char* dirty = nullptr;  // projector view: one flag byte per 128-byte line of key_frame
   SlotState* st = nullptr;  // device
   u32 host_tag = 0;         // mirrors st->tag_a after the enqueued work has run
@@ -182,6 +185,11 @@ struct xm_handle {
   std::vector<hipStream_t> gstreams;  // default-priority streams the hipGraph batches are captured on and launched from
   std::vector<std::unique_ptr<Worker>> workers;  // one per slot stream (empty: launches happen in the calling thread)
   bool key32_ok = false;      // the rig qualifies for the compact key frame (projector view, rect_h % 4 == 0, disparities < 4096)
+  // column-tile K1 (xmaps_k1cols.hpp): the rig qualifies (projector view, cell(row, column) injective, no int16 wrap in the
+  // disparity arithmetic), smallest rectified x of the LUT, widest tile the LDS budget allows, events a tile should hold
+  bool cols_ok = false;
+  int cols_xr_min = 0, cols_w_max = 0, cols_target = 3700;
+  std::atomic<uint64_t> path_counts[4] = {};  // frames enqueued per K1 variant (xm_path_counts)
   // (atomics: with XM_FLAG_LAUNCH_WORKERS the launch threads and the API thread all pass through enqueue_frame)
   std::atomic<int> key32_score{0};  // raised by frames that failed the compact path, decays with every frame that took it
   std::atomic<int> key32_pause{0};  // frames for which the compact path stays switched off (it kept failing: sparse / noisy stream)
@@ -417,10 +425,68 @@ int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_ov
   }
 }
 
+// ---- column-tile K1 (xmaps_k1cols.hpp) ------------------------------------------------------------------------------------------
+// kmode of a frame: 0 = 64-bit key frame (general), 1 = compact 32-bit key frame, 2 = column tiles + plain u16 frame
+enum { KM_KEY64 = 0, KM_KEY32 = 1, KM_COLS = 2 };
+
+size_t cols_lds_bytes(const xm_handle* h, int W) {  // mirrors the carve-up at the top of scatter_cols_body
+  const size_t lut_q = ((size_t)h->w_x * h->tb.cam_h + 3) / 4 + 1 + 64, xm_q = ((size_t)W * h->tb.xmap_h + 7) / 8 + 1 + 64,
+               slot_q = ((size_t)W * h->tb.xmap_h + 3) / 4;
+  return 16 * (lut_q + xm_q + slot_q);
+}
+
+// time columns per tile for frames of n events: about cols_target events per tile, within the LDS budget; 0 = not this path
+int cols_width(const xm_handle* h, u64 n) {
+  if (!h->cols_ok || h->cols_w_max < 1 || h->tb.xmap_w < 1 || n == 0 || n >= (1ull << 28)) return 0;
+  const double per_col = (double)n / (double)h->tb.xmap_w;
+  int W = (int)((double)h->cols_target / per_col);
+  W = std::max(1, std::min(W, h->cols_w_max));
+  if (per_col * W < 1024.0) return 0;  // sparse frames: the band copies and the slot scan would dominate (direct kernel instead)
+  return W;
+}
+
+unsigned cols_threads(const xm_handle* h, u64 n, int W) {
+  static const int force = getenv("XM_COLS_THREADS") ? atoi(getenv("XM_COLS_THREADS")) : 0;  // experiments
+  if (force >= 64 && force <= COLS_MAX_THREADS && force % 64 == 0) return (unsigned)force;
+  const double per_tile = (double)n / (double)h->tb.xmap_w * W;
+  // one pass for a tile 12 % above the mean (Poisson spread of an evenly filled scan); fuller tiles take a second pass
+  unsigned t = ((unsigned)(per_tile * 1.12 / COLS_EPT) + 63u) / 64u * 64u;
+  return std::max(128u, std::min(t, (unsigned)COLS_MAX_THREADS));
+}
+
+// K0b: the tile boundaries + column thresholds of the frame (one wave per boundary), left behind the slot's u16 frame
+void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
+  const unsigned nb = grid_for(h->tb.xmap_w, W);
+  if (ev.aos)
+    XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_WAVES)), dim3(64 * COLS_BOUNDS_WAVES), 0, stream, ev.x,
+              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16);
+  else
+    XM_LAUNCH(k_cols_bounds<false>, dim3(grid_for(nb + 1, COLS_BOUNDS_WAVES)), dim3(64 * COLS_BOUNDS_WAVES), 0, stream, ev.x,
+              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16);
+}
+
+int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint16_t* frame16, int W, hipStream_t stream) {
+  const bool vec16 = !ev.aos && aligned(ev.x, 16) && aligned(ev.y, 16) && aligned(ev.t, 16);
+  auto kern = k_scatter_cols<false, false>;
+  if (ev.aos) kern = k_scatter_cols<true, false>;
+  else if (vec16) kern = k_scatter_cols<false, true>;
+  const size_t lds = cols_lds_bytes(h, W);
+  int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
+  if (rc) return rc;
+  XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, W)), dim3(cols_threads(h, ev.n, W)), lds, stream, ev.x, ev.y, (const long long*)ev.t,
+            (const uint4*)ev.aos, (u32)ev.n, h->tb, st, frame16, W, h->w_x, h->cols_xr_min);
+  return XM_OK;
+}
+
 void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 tag_override, float* depth,
-                         uint8_t* bgr, hipStream_t stream, const unsigned char* dirty = nullptr, bool key32 = false) {
+                         uint8_t* bgr, hipStream_t stream, const unsigned char* dirty = nullptr, int kmode = KM_KEY64) {
   KeyCells cells{key_frame, 0};
-  if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && key32) {
+  const bool key32 = kmode == KM_KEY32;
+  if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && kmode == KM_COLS) {
+    XM_LAUNCH(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
+              tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
+  } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && key32) {
     XM_LAUNCH(k_frame_proj_tiled<true>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
               dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
               tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
@@ -470,6 +536,15 @@ bool key32_path(const xm_handle* h, const EventsView& ev, bool sorted) {
   return ev.n / (u64)(1024 / TILE_EPT * TILE_EPT) < (1ull << KEY32_TILE_BITS);  // tiles of >= 1024 events
 }
 
+// may this (sorted-path) frame use the column tiles?  Same preconditions as the compact key frame (automatic redo at hand)
+// + int64 time stamps; returns the tile width W (0: no)
+int cols_path(const xm_handle* h, const EventsView& ev, bool sorted) {
+  if (!sorted || !h->cols_ok || !h->try_sorted || h->capturing || h->key32_pause.load(std::memory_order_relaxed) > 0 ||
+      h->k2_direct || h->k2_flags || ev.use_p || (!ev.aos && ev.t_dtype != XM_T_INT64))
+    return 0;
+  return cols_width(h, ev.n);
+}
+
 // keep the slot's compact frame unambiguous for a frame with tag `tag` (4-bit tags repeat every 15 frames)
 int key32_prepare(xm_handle* h, Slot& s, u32 tag, hipStream_t stream) {
   if (tag - s.key32_valid_from >= 15u || tag < s.key32_valid_from) {
@@ -495,7 +570,8 @@ void key32_note(xm_handle* h, bool failed) {
 int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,
                   bool allow_sorted = true, hipStream_t stream_override = nullptr) {
   const bool sorted = allow_sorted && sorted_path(h, ev);
-  const bool use32 = key32_path(h, ev, sorted);
+  const int cols_w = cols_path(h, ev, sorted);
+  const bool use32 = !cols_w && key32_path(h, ev, sorted);
   {
     int v = h->key32_pause.load(std::memory_order_relaxed);
     while (v > 0 && !h->key32_pause.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {
@@ -518,14 +594,16 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
   // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the three dispatch packets
   if (prof) g_prof = ProfCtx{prof[0], prof[1]};
   if (!(skip & 1) && !sorted) launch_minmax(ev, s.st, 0, stream);
+  if (!(skip & 1) && cols_w) launch_cols_bounds(h, ev, s.frame16, cols_w, stream);  // K0b takes K0's place (and its profile events)
   if (use32) {
     int rc = key32_prepare(h, s, s.host_tag + 1, stream);
     if (rc) return rc;
   }
   if (prof) g_prof = ProfCtx{prof[2], prof[3]};
   if (!(skip & 2)) {
-    int rc = launch_scatter(h, ev, s.st, 0, 0, 0, 0, use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame, s.dirty, stream, sorted,
-                            nullptr, use32);
+    int rc = cols_w ? launch_scatter_cols(h, ev, s.st, s.frame16, cols_w, stream)
+                    : launch_scatter(h, ev, s.st, 0, 0, 0, 0, use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame, s.dirty, stream,
+                                     sorted, nullptr, use32);
     if (rc) {
       g_prof = ProfCtx{};
       return rc;
@@ -533,12 +611,14 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
   }
   if (prof) g_prof = ProfCtx{prof[4], prof[5]};
   if (!(skip & 4))
-    launch_frame_kernel(h, use32 ? reinterpret_cast<const u64*>(s.key32) : s.key_frame, s.st, 0, depth, bgr, stream,
-                        h->k2_flags ? s.dirty : nullptr, use32);
+    launch_frame_kernel(h, cols_w ? reinterpret_cast<const u64*>(s.frame16) : use32 ? reinterpret_cast<const u64*>(s.key32) : s.key_frame,
+                        s.st, 0, depth, bgr, stream, h->k2_flags ? s.dirty : nullptr, cols_w ? KM_COLS : use32 ? KM_KEY32 : KM_KEY64);
   g_prof = ProfCtx{};
   HIP_TRY(hipGetLastError());
-  s.last_key32 = use32;
-  if (use32) key32_note(h, false);
+  s.last_key32 = use32 || cols_w;
+  s.last_cols = cols_w != 0;
+  h->path_counts[cols_w ? 3 : use32 ? 2 : sorted ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
+  if (use32 || cols_w) key32_note(h, false);
   s.host_tag += 1;
   s.any_frame = true;
   s.last_n = ev.n;
@@ -554,7 +634,27 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 // they ramp up and drain (245 K1 blocks for 256 CUs, each a ~10 us dependent chain); a group's launch keeps every CU fed.
 template <typename T, bool AOS, bool HAS_P>
 int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
-                   hipStream_t stream, bool key32 = false) {
+                   hipStream_t stream, bool key32 = false, int cols_w = 0) {
+  if constexpr (std::is_same<T, long long>::value && !HAS_P) {
+    if (cols_w) {  // column tiles: K1 grid = (tiles, frames), K2 on the plain u16 frames
+      auto kern = k_scatter_cols_batch<AOS, false>;
+      if constexpr (!AOS) {
+        if (vec16) kern = k_scatter_cols_batch<false, true>;
+      }
+      const size_t lds = cols_lds_bytes(h, cols_w);
+      int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
+      if (rc) return rc;
+      XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_WAVES), n_frames),
+                dim3(64 * COLS_BOUNDS_WAVES), 0, stream, d_descs, h->tb, cols_w);
+      XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
+                cols_w, h->w_x, h->cols_xr_min);
+      XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      HIP_TRY(hipGetLastError());
+      return XM_OK;
+    }
+  }
   // K0: grid = (blocks of the largest frame, frames)
   if (!sorted) {
     const bool vec2 = !AOS && std::is_same<T, long long>::value && vec16;
@@ -660,7 +760,10 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     }
     return XM_OK;
   }
-  bool use32 = sorted;
+  int cols_w = sorted ? cols_width(h, n_mean) : 0;  // one tile width for the group (from its mean frame)
+  for (int f = 0; f < n_frames && cols_w; ++f)
+    if (!cols_path(h, evs[f], sorted) || (evs[f].aos != nullptr) != (e0.aos != nullptr)) cols_w = 0;
+  bool use32 = sorted && !cols_w;
   for (int f = 0; f < n_frames && use32; ++f) use32 = key32_path(h, evs[f], sorted);
   {
     int v = h->key32_pause.load(std::memory_order_relaxed);
@@ -680,16 +783,17 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     FrameDesc& d = h_descs[f];
     const EventsView& ev = evs[f];
     d.x = ev.x; d.y = ev.y; d.t = ev.t; d.p = ev.use_p ? ev.p : nullptr; d.aos = (const uint4*)ev.aos;
-    d.n = ev.n; d.key_frame = use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame; d.st = s.st; d.depth = depth[f];
+    d.n = ev.n; d.key_frame = cols_w ? reinterpret_cast<u64*>(s.frame16) : use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame;
+    d.st = s.st; d.depth = depth[f];
     d.bgr = bgr[f]; d.valid = 1; d.pad = 0;
   }
   if (upload) HIP_TRY(hipMemcpyAsync(d_descs, h_descs, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, stream));
   int rc;
   if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32)
-                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32);
+                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w);
   else switch (e0.t_dtype) {
     case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
-                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
+                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w); break;
     case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
                                      : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
     default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
@@ -703,9 +807,11 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     s.any_frame = true;
     s.last_n = evs[f].n;
     s.last_sorted = sorted;
-    s.last_key32 = use32;
+    s.last_key32 = use32 || cols_w;
+    s.last_cols = cols_w != 0;
+    h->path_counts[cols_w ? 3 : use32 ? 2 : sorted ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
     s.last_t_dtype = evs[f].aos ? XM_T_INT64 : evs[f].t_dtype;
-    if (use32) key32_note(h, false);
+    if (use32 || cols_w) key32_note(h, false);
   }
   return XM_OK;
 }
@@ -976,7 +1082,7 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     xm_frame_stats st;
     if ((rc = fetch_stats(h, s, ev.aos ? XM_T_INT64 : ev.t_dtype, &st))) return rc;
     if (profile) {
-      const int first = s.last_sorted ? 1 : 0;  // K0 is not launched on the time-sorted path
+      const int first = s.last_sorted && !s.last_cols ? 1 : 0;  // K0 is not launched on the time-sorted path (column tiles: K0b in its place)
 #ifdef XM_ABLATE  // experiment builds may skip kernels (XM_SKIP_MASK): their events were never recorded
       for (int i = first; i < 3; ++i)
         if (hipEventElapsedTime(&st.gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) != hipSuccess) (void)hipGetLastError();
@@ -1179,6 +1285,41 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     h->key32_ok = cfg->view == XM_VIEW_PROJECTOR && (cfg->rect_height & 3) == 0 && max_disp < (1l << KEY32_DISP_BITS) &&
                   !(e32 && e32[0] == '0');
   }
+  {  // does the rig qualify for the column-tile K1?  (xmaps_k1cols.hpp)
+    int xr_min = 32767, xr_max = -32768, xp_min = 32767, xp_max = -32768;
+    for (size_t i = 0; i < cam_px; ++i) {
+      xr_min = std::min<int>(xr_min, cfg->cam_mapx_i16[i]);
+      xr_max = std::max<int>(xr_max, cfg->cam_mapx_i16[i]);
+    }
+    for (size_t i = 0; i < xm_cells; ++i) {
+      xp_min = std::min<int>(xp_min, cfg->proj_x_map[i]);
+      xp_max = std::max<int>(xp_max, cfg->proj_x_map[i]);
+    }
+    const char* ec = getenv("XM_COLS");
+    // the reference's int16 wrap-around in disp = xp - xr - x_offset (xmd:27) must never trigger on this rig: then
+    // disp >= 0 <=> xp - x_offset >= xr, which is what makes "dead" X-map cells recognisable
+    const bool no_wrap = (long)xp_max - xr_min - cfg->x_offset <= 32767 && (long)xp_min - xr_max - cfg->x_offset >= -32768;
+    h->cols_xr_min = xr_min;
+    bool injective = false;
+    if (cfg->view == XM_VIEW_PROJECTOR && no_wrap && cfg->rect_width <= 65536) {
+      u32* d_dup = nullptr;
+      XM_TRY_CREATE(hipMalloc((void**)&d_dup, sizeof(u32)));
+      XM_TRY_CREATE(hipMemset(d_dup, 0, sizeof(u32)));
+      const int rows = std::min(xmap_h - 1, cfg->rect_height);
+      if (rows > 0) hipLaunchKernelGGL(k_cols_check, dim3(rows), dim3(BLOCK), 0, 0, h->tb, xr_min, d_dup);
+      u32 dup = 1;
+      const hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(&dup, d_dup, sizeof dup, hipMemcpyDeviceToHost);
+      (void)hipFree(d_dup);
+      XM_TRY_CREATE(e1);
+      XM_TRY_CREATE(e2);
+      injective = dup == 0;  // every frame cell has at most one (row, time column) that can write it
+    }
+    h->cols_ok = injective && h->d_pmap && !(ec && ec[0] == '0');
+    // the compact key frame orders the writers of a cell by TILE only: two time columns of one tile that share a cell would be
+    // ordered by their disparity bits -- it needs the same property (the 64-bit keys carry the full event index and do not)
+    h->key32_ok = h->key32_ok && injective;
+    if (const char* e = getenv("XM_COLS_TARGET")) h->cols_target = std::max(256, atoi(e));
+  }
   if (cfg->view == XM_VIEW_PROJECTOR) {
     h->key_cells = (size_t)cfg->rect_width * cfg->rect_height;
     h->out_w = cfg->proj_width;
@@ -1227,6 +1368,13 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     } else {
       h->k1_direct = true;  // tables too tall for LDS: every event takes the direct path
     }
+    // column tiles: the widest tile whose bands + slots fit the same budget (the LUT band is the tiled kernel's)
+    if (h->cols_ok && !h->k1_direct && h->w_x > 0) {
+      int wm = 0;
+      while (wm < 16 && cols_lds_bytes(h, wm + 1) <= budget) wm += 1;
+      h->cols_w_max = wm;
+    }
+    if (h->cols_w_max < 1) h->cols_ok = false;
   }
 #ifdef XM_ABLATE
   if (const char* e = getenv("XM_ABLATE")) {
@@ -1263,6 +1411,11 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     if (h->key32_ok) {
       XM_TRY_CREATE(hipMalloc((void**)&s.key32, h->key_cells * sizeof(u32)));
       XM_TRY_CREATE(hipMemset(s.key32, 0, h->key_cells * sizeof(u32)));
+    }
+    if (h->cols_ok) {  // cells no (row, column) pair maps to are never written: they stay 0 from here on
+      const size_t bytes = cols_frame_bytes(h->key_cells, cfg->xmap_width);  // frame + K0b's bounds and thresholds
+      XM_TRY_CREATE(hipMalloc((void**)&s.frame16, bytes));
+      XM_TRY_CREATE(hipMemset(s.frame16, 0, bytes));
     }
     if (cfg->view == XM_VIEW_PROJECTOR && h->k2_flags)
       XM_TRY_CREATE(hipMalloc((void**)&s.dirty, ((h->key_cells + 15) >> 4) + 64));
@@ -1353,6 +1506,7 @@ void xm_destroy(xm_handle* h) {
     for (auto& d : s.dbg) d.release();
     if (s.key_frame) (void)hipFree(s.key_frame);
     if (s.key32) (void)hipFree(s.key32);
+    if (s.frame16) (void)hipFree(s.frame16);
     if (s.dirty) (void)hipFree(s.dirty);
     if (s.stream && s.owns_stream) (void)hipStreamDestroy(s.stream);
     if (s.h_flags) (void)hipHostFree(s.h_flags);
@@ -1377,6 +1531,12 @@ void xm_destroy(xm_handle* h) {
   if (h->d_k2_pix) (void)hipFree(h->d_k2_pix);
   if (h->d_zero16) (void)hipFree(h->d_zero16);
   delete h;
+}
+
+int xm_path_counts(xm_handle* h, uint64_t counts[4]) {
+  if (!h || !counts) return fail(XM_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < 4; ++i) counts[i] = h->path_counts[i].load(std::memory_order_relaxed);
+  return XM_OK;
 }
 
 int xm_sorted_fallbacks(xm_handle* h, uint64_t* count) {

@@ -1,0 +1,578 @@
+// xmaps_k1cols.hpp -- K1 "column tiles": the fused per-event kernel of the verified-sorted projector-view path without
+// atomics and without a key.  (gfx950 / MI355X; included by xmaps_hip.hip after xmaps_kernels.hpp)
+//
+// What the tiled K1 (k_scatter_tiled) pays for at full occupancy is the chip's L2 atomic request rate: its tiles are
+// runs of 4096 consecutive EVENTS, so a time column of the X-map is flushed by ~1.4 tiles and the frame cell of a
+// (time column, rectified row) pair must be resolved ACROSS tiles -- an atomic max on a packed (order | disparity) key,
+// a tag per cell, a clear every 15 frames.  Here a tile is a run of W consecutive X-map TIME COLUMNS instead:
+//
+//   * cell(row, column) = (X[row, column] - x_offset, row) depends on the pair only (cam_proj_calibration.py:299-303 with
+//     xpr = xr + disp = xp - x_offset).  If that map is injective (checked once in xm_create, k_cols_check) every frame cell
+//     has exactly ONE (row, column) that can write it, hence exactly one owner tile: last-writer-wins is resolved entirely
+//     in the tile's LDS slots (ds_max on (local index + 1) << 16 | disparity, as before) and the flush is a PLAIN STORE.
+//   * every tile stores ALL of its live slots, winners and empties (0) alike: the frame is a plain u16 disparity frame
+//     [rect_w][rect_h] (column-major) that is completely rewritten by every frame -- no tag, no clear, 2 bytes per cell
+//     (K2 reads 4.6 MB instead of 9.3 MB at C-1M).  Cells that no (row, column) pair maps to are never written and stay
+//     0 from xm_create.  A slot whose pair can never hold a winner (xp - x_offset < the smallest rectified x of the LUT:
+//     the X-map's undefined cells) is "dead" and is skipped by the check and by the flush alike.
+//   * the tile's events are the index range [lb(c0), lb(c0 + W)) of the time-sorted stream, lb(c) = first event whose time
+//     column is >= c, found by a small kernel of its own (k_cols_bounds: one wave per boundary, 64-ary search over t, an
+//     interpolated window first = two dependent round trips for an evenly filled scan).  lb() is a deterministic function
+//     of (stream, c), so neighbouring tiles share their boundary whatever the stream looks like; a non-monotone pair marks
+//     the frame as failed.
+//   * exactness for ANY input: every event a tile loads is checked -- t inside [t[0], t[n-1]] and its column inside the
+//     tile's columns.  The ranges of the tiles partition [0, n), so if no tile objects every event went through the slots
+//     of the tile that owns its column.  Otherwise the frame is marked as failed through the very flag of the sorted-order
+//     verification and redone on the general 64-bit path (K0 -> k_scatter_tiled -> K2), automatically, like an unsorted frame.
+//   * the X-map band is exactly the tile's W columns (no slack columns), the slot array W x xmap_h words: at C-1M (W = 2)
+//     2640 slots are cleared / scanned per 3125 events instead of 6600 per 4096.
+// Algorithmic bytes are those of K1: 24 B/event.
+#pragma once
+#include "xmaps_kernels.hpp"
+
+namespace xm {
+
+// Pointers of these kernels carry the global address space in their TYPE: a pointer read from a frame descriptor in memory
+// is generic to the compiler otherwise (flat loads with 64-bit vector addresses instead of scalar base + 32-bit offset:
+// 125 instead of 89 VGPRs in the multi-frame kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XM_GLOBAL __attribute__((address_space(1)))
+#else
+#define XM_GLOBAL  // host pass: the bodies are only parsed (HIP's host-side vector types do not take qualified references)
+#endif
+typedef const XM_GLOBAL uint16_t* gp_u16;
+typedef const XM_GLOBAL long long* gp_i64;
+typedef const XM_GLOBAL uint4* gp_u4;
+typedef const XM_GLOBAL int4* gp_i4;
+typedef XM_GLOBAL SlotState* gp_state;
+
+constexpr int COLS_EPT = 8;          // events per thread and pass
+constexpr u32 COLS_MAX_TILE_EVENTS = 65535u - 8u;  // the slot value carries (local index + 1) in 16 bits
+
+// ---- xm_create: is cell(row, column) injective over the live pairs?  One block per rectified row. -----------------------
+// live  = xp - x_offset >= xr_min (some LUT entry can give disp >= 0; the host has checked that xp - xr - x_offset never
+//         leaves the int16 range, so the reference's wrap-around arithmetic is plain arithmetic on this rig)
+// cell  = column (xp - x_offset), one negative wrap like NumPy, inside the frame
+__device__ inline bool cols_cell(const DevTables& tb, int xp, int r, int xr_min, u32& cell) {
+  const int fu = xp - tb.x_offset;
+  if (fu < xr_min) return false;
+  int fc = (int)(short)fu;
+  if (fc < 0) fc += tb.rect_w;
+  if (fc < 0 || fc >= tb.rect_w || r >= tb.rect_h) return false;
+  cell = (u32)fc * (u32)tb.rect_h + (u32)r;
+  return true;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cols_check(DevTables tb, int xr_min, u32* __restrict__ n_dup) {
+  __shared__ u32 bits[2048];  // rect_w <= 65536 columns
+  const int r = blockIdx.x;   // rows 0 .. min(xmap_h - 1, rect_h) - 1 (the last X-map row never holds a winner: xmd:23)
+  for (int i = threadIdx.x; i < 2048; i += BLOCK) bits[i] = 0;
+  __syncthreads();
+  u32 dup = 0;
+  for (int c = threadIdx.x; c < tb.xmap_w; c += BLOCK) {
+    const int xp = (int)tb.xmap[(u32)c * (u32)tb.xmap_h + (u32)r];
+    u32 cell;
+    if (!cols_cell(tb, xp, r, xr_min, cell)) continue;
+    const u32 fc = cell / (u32)tb.rect_h, bit = 1u << (fc & 31);
+    if (atomicOr(&bits[fc >> 5], bit) & bit) dup += 1;
+  }
+  if (dup) atomicAdd(n_dup, dup);
+}
+
+// ---- the event-range search (one wave per boundary) -----------------------------------------------------------
+template <bool AOS>
+__device__ __forceinline__ long long cols_t_at(gp_i64 ts, gp_u4 aos, int i) {
+  if constexpr (AOS) {
+    const uint4 r = aos[i];
+    return (long long)(((u64)r.w << 32) | r.z);
+  } else {
+    return ts[i];
+  }
+}
+
+// K1 never converts a time stamp: for int64 stamps the X-map column is a step function of a = t - tmin, so the frame's
+// columns are described exactly by THRESHOLDS  thr[c] = the smallest a in [0, span + 1] with column(tmin + a) >= c
+// (span = tmax - tmin; span + 1 = "no such a"), computed here with the very conversion that is bit-exact with NumPy
+// (TimeNorm, xmaps_kernels.hpp).  Then  column(t) = #{c' >= 1 : thr[c'] <= a}  and, for a tile of columns [c0, c1):
+// event in tile <=> thr[c0] <= a < thr[c1]; its column = c0 + #{interior c' : thr[c'] <= a}: a few 32-bit compares per event
+// instead of the FP64 chain, and half the registers.
+__device__ inline u32 cols_threshold(const TimeNorm<long long>& tn, const long long tmin, const u32 span, const int c, const int S) {
+  if (c <= 0) return 0u;
+  const auto col_at = [&](long long a) { return tn.column(tmin + a); };
+  // column c starts where (a / span) * S = c - 0.5
+  const double est = ((double)c - 0.5) * (double)span / (double)max(S, 1);
+  long long a = (long long)fmin(fmax(est, 0.0), (double)span);
+  int guard = 0;
+  while (a > 0 && guard < 16 && col_at(a - 1) >= c) { --a; ++guard; }
+  while (a <= (long long)span && guard < 32 && col_at(a) < c) { ++a; ++guard; }
+  const bool settled = (a == 0 || col_at(a - 1) < c) && (a > (long long)span || col_at(a) >= c);
+  if (!settled) {  // (never seen; the conversion is monotone, so a bisection over [0, span + 1] is exact)
+    long long lo = -1, hi = (long long)span + 1;  // column(lo) < c (virtual at -1), column(hi) >= c (virtual at span + 1)
+    while (hi - lo > 1) {
+      const long long mid = lo + ((hi - lo) >> 1);
+      if (col_at(mid) >= c) hi = mid; else lo = mid;
+    }
+    a = hi;
+  }
+  return (u32)a;
+}
+
+// One narrowing round for the boundary of threshold A: lb = first event with (u64)(t - tmin) >= A.  State: event lo is below
+// (or lo == -1), event hi is at or past it (or hi == n); the answer is hi once hi - lo == 1.  `first`: the interpolated window
+// (64 probes, 64 events apart, centred on the guess) instead of an even split of (lo, hi).  For a stream that is not sorted
+// this is still a deterministic function of (stream, A): neighbouring tiles read the same boundary, and the per-event
+// verification of K1 catches the rest.
+template <bool AOS>
+__device__ __forceinline__ void cols_search_round(gp_i64 ts, gp_u4 aos, const int n, const long long tmin, const u32 A, int& lo,
+                                                  int& hi, const int guess, const bool first) {
+  const int lane = threadIdx.x & 63;
+  const int span = hi - lo - 1;  // unknown positions lo+1 .. hi-1 (> 0: the caller loops while hi - lo > 1)
+  int p;
+  bool act;
+  if (first) {
+    p = min(max(guess + (lane - 32) * 64, 0), n - 1);
+    act = true;
+  } else {
+    const int stride = (span + 63) >> 6;
+    p = lo + (lane + 1) * stride;
+    act = p < hi;
+  }
+  const long long tv = cols_t_at<AOS>(ts, aos, act ? p : 0);
+  const bool pr = act && (u64)(tv - tmin) >= (u64)A;
+  const u64 bal = __ballot(pr), bact = __ballot(act);
+  if (bal == 0) {  // every probe is still below the boundary: lo = the largest probe
+    const int top = 63 - __builtin_clzll(bact);
+    lo = max(lo, __shfl(p, top, 64));
+  } else {
+    const int j = __builtin_ctzll(bal);  // first probe at or past the boundary (probes are non-decreasing in the lane)
+    hi = __shfl(p, j, 64);
+    if (j > 0) lo = max(lo, __shfl(p, j - 1, 64));
+  }
+}
+
+// ---- K0b: the tile boundaries of one frame, one wave per boundary ----------------------------------------------------------------
+// bounds[j] = {lb(j * W), median x of the three events at / behind it, median x of the three events in front of it, 0} for
+// j = 0 .. nb (nb = ceil(xmap_w / W) tiles; bounds[nb].x = n), thr[c] for c = 0 .. xmap_w (see cols_threshold).  Tile j of K1
+// owns events [bounds[j].x, bounds[j+1].x) and centres its camera-column window between bounds[j].y and bounds[j+1].z.
+// Kept out of K1 on purpose: inside K1 the search is two to three dependent round trips at the head of every tile's chain,
+// with the tile's other waves parked at a barrier.  A frame that spans 2^32 us or more gets bounds[j].x = -1: K1 objects.
+constexpr int COLS_BOUNDS_WAVES = 4;
+
+// where the bounds and the thresholds live: behind the slot's u16 frame (one allocation, one pointer in the frame descriptor)
+__host__ __device__ inline size_t cols_bounds_offset(size_t key_cells) { return (key_cells * 2 + 63) & ~(size_t)63; }
+__host__ __device__ inline size_t cols_thr_offset(size_t key_cells, int xmap_w) {
+  return cols_bounds_offset(key_cells) + sizeof(int4) * ((size_t)xmap_w + 2);
+}
+__host__ __device__ inline size_t cols_frame_bytes(size_t key_cells, int xmap_w) {
+  return cols_thr_offset(key_cells, xmap_w) + sizeof(u32) * ((size_t)xmap_w + 2) + 64;
+}
+
+template <bool AOS>
+__device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos, const int n, const DevTables& tb, const int W,
+                                                 XM_GLOBAL unsigned char* frame_base, const u32 blk) {
+  typedef long long T;
+  const size_t key_cells = (size_t)tb.rect_w * (size_t)tb.rect_h;
+  XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
+  XM_GLOBAL u32* thr = (XM_GLOBAL u32*)(frame_base + cols_thr_offset(key_cells, tb.xmap_w));
+  const int lane = threadIdx.x & 63;
+  const int nb = (tb.xmap_w + W - 1) / W;
+  const int j = (int)blk * COLS_BOUNDS_WAVES + (int)(threadIdx.x >> 6);
+  if (j > nb) return;  // wave-uniform
+  T t_first, t_last;
+  if constexpr (AOS) {
+    const uint4 a = aos[0], b = aos[n - 1];
+    t_first = (T)(((u64)a.w << 32) | a.z);
+    t_last = (T)(((u64)b.w << 32) | b.z);
+  } else {
+    t_first = ts[0];
+    t_last = ts[n - 1];
+  }
+  if (t_last < t_first) t_last = t_first;  // not sorted at all: keep the arithmetic defined; K1's verification flags the frame
+  const u64 span64 = (u64)(t_last - t_first);
+  if (span64 >= 0xffffffffull) {  // a - tmin does not fit 32 bits: not this path
+    if (lane == 0) bounds[j] = make_int4(-1, 0, 0, 0);
+    return;
+  }
+  const u32 span = (u32)span64;
+  const TimeNorm<T> tn(t_first, t_last, tb.t_px_scale);
+  // thresholds of this boundary's column and of the interior columns behind it (lane l: column j W + l)
+  const int c = min(j * W, tb.xmap_w);
+  u32 A = 0;
+  if (lane < W && c + lane <= tb.xmap_w && (lane == 0 || j < nb)) {
+    A = cols_threshold(tn, t_first, span, c + lane, tb.t_px_scale);
+    thr[c + lane] = A;
+  }
+  A = __shfl(A, 0, 64);
+  int lo = -1, hi = n;
+  if (c <= 0) hi = 0;
+  if (c >= tb.xmap_w) lo = n - 1;  // the last tile takes whatever is left
+  if (hi - lo > 1) {
+    // an evenly filled scan has the first event of column c near n A / span
+    const double g = (double)A / (double)max(span, 1u) * (double)n;
+    cols_search_round<AOS>(ts, aos, n, t_first, A, lo, hi, (int)fmin(fmax(g, 0.0), (double)(n - 1)), true);
+    while (hi - lo > 1) cols_search_round<AOS>(ts, aos, n, t_first, A, lo, hi, 0, false);
+  }
+  const int lb = hi;
+  int xv = 0;
+  if (lane < 6) {
+    const int i = lane < 3 ? min(lb + lane, n - 1) : max(lb - 1 - (lane - 3), 0);
+    if constexpr (AOS) xv = (int)(aos[i].x & 0xffff);
+    else xv = (int)xs[i];
+  }
+  const int a0 = __shfl(xv, 0, 64), a1 = __shfl(xv, 1, 64), a2 = __shfl(xv, 2, 64);
+  const int e0 = __shfl(xv, 3, 64), e1 = __shfl(xv, 4, 64), e2 = __shfl(xv, 5, 64);
+  if (lane == 0)
+    bounds[j] = make_int4(lb, max(min(a0, a1), min(max(a0, a1), a2)), max(min(e0, e1), min(max(e0, e1), e2)), 0);
+}
+
+template <bool AOS>
+__global__ __launch_bounds__(64 * COLS_BOUNDS_WAVES) void k_cols_bounds(const uint16_t* __restrict__ xs, const long long* __restrict__ ts,
+                                                                        const uint4* __restrict__ aos, u32 n, DevTables tb, int W,
+                                                                        uint16_t* __restrict__ frame16) {
+  cols_bounds_body<AOS>((gp_u16)xs, (gp_i64)ts, (gp_u4)aos, (int)n, tb, W, (XM_GLOBAL unsigned char*)frame16, blockIdx.x);
+}
+
+template <bool AOS>
+__global__ __launch_bounds__(64 * COLS_BOUNDS_WAVES) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W) {
+  const FrameDesc d = descs[blockIdx.y];
+  if (!d.valid || d.n == 0) return;
+  cols_bounds_body<AOS>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x);
+}
+
+// ---- the kernel body ---------------------------------------------------------------------------------------------------------
+// blk / nblk: this block's index among the frame's ceil(xmap_w / W) blocks.  frame16: the slot's plain u16 disparity frame,
+// followed by what k_cols_bounds left for this frame (bounds, thresholds).
+template <bool AOS, bool VEC>
+__device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 ts, gp_u4 aos, const u32 n_ev, const DevTables& tb,
+                                                  gp_state st, XM_GLOBAL uint16_t* frame16, const int W, const int w_x,
+                                                  const int xr_min, const u32 blk, const u32 nblk) {
+  typedef long long T;
+  static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
+  constexpr int EPT = COLS_EPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ u32 s_in, s_oob, s_sentinel;
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63;
+  const int n = (int)n_ev;
+  const int cap = nthreads * EPT;  // events per pass
+  const size_t key_cells = (size_t)tb.rect_w * (size_t)tb.rect_h;
+  gp_i4 bounds = (gp_i4)((const XM_GLOBAL unsigned char*)frame16 + cols_bounds_offset(key_cells));
+  const XM_GLOBAL u32* thr = (const XM_GLOBAL u32*)((const XM_GLOBAL unsigned char*)frame16 + cols_thr_offset(key_cells, tb.xmap_w));
+  // LDS carve-up (uint4 units; each band keeps 1 quad of alignment slack in front and a wave of slack behind it for the
+  // LDS-direct loads, which write whole waves).  Mirrored by cols_lds_bytes() on the host.
+  const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1 + 64;
+  const int xm_q = ((W * tb.xmap_h + 7) >> 3) + 1 + 64;
+  const int slot_q = (W * tb.xmap_h + 3) >> 2;
+  u32* lut_base = reinterpret_cast<u32*>(smem);
+  int16_t* xm_base = reinterpret_cast<int16_t*>(lut_base + 4 * lut_q);
+  u32* slots = reinterpret_cast<u32*>(xm_base + 8 * xm_q);
+  uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
+  uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int dma_q0 = tid & ~63;
+
+  const u32 tile = xcd_contiguous(blk, nblk);
+  const int c0 = (int)tile * W;
+  const int Wc = min(W, tb.xmap_w - c0);  // >= 1: nblk = ceil(xmap_w / W)
+  const int nslots = Wc * tb.xmap_h;
+
+  // ---- 1. everything that locates the tile, as uniform loads in one round trip: its event range and camera-column window,
+  //         the thresholds of its first and one-past-last column (k_cols_bounds), the frame's first / last time stamp, the tag
+  const int4 b_lo = bounds[tile], b_hi = bounds[tile + 1];
+  const u32 A_lo = thr[c0], A_hi = thr[c0 + Wc];
+  T t_first, t_last;
+  if constexpr (AOS) {
+    const uint4 a = aos[0], b = aos[n - 1];
+    t_first = (T)(((u64)a.w << 32) | a.z);
+    t_last = (T)(((u64)b.w << 32) | b.z);
+  } else {
+    t_first = ts[0];
+    t_last = ts[n - 1];
+  }
+  const u32 tag = st->tag_b + 1;
+  // the tile's X-map band (exactly its columns) needs none of that: L2 -> LDS with LDS-direct loads, issued at once
+  const u32 xm_start = (u32)c0 * (u32)tb.xmap_h, xm_shift = xm_start & 7u;  // in int16
+  const int16_t* xm_t = xm_base + xm_shift;
+  const uint4* g_xm = reinterpret_cast<const uint4*>(tb.xmap + (xm_start - xm_shift));
+  const int nq_xm = (int)((xm_shift + (u32)nslots + 7u) >> 3);
+  for (int q0 = dma_q0; q0 < nq_xm; q0 += nthreads)
+    __builtin_amdgcn_global_load_lds((glb_void*)(g_xm + min(q0 + lane, nq_xm - 1)), (lds_void*)(l_xm + q0), 16, 0, 0);
+  {  // winner slots
+    uint4* l_slots = reinterpret_cast<uint4*>(slots);
+    for (int i = tid; i < slot_q; i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);
+  }
+  if (tid == 0) {
+    s_in = 0;
+    s_oob = 0;
+    s_sentinel = 0x80000000u;  // a LUT word with yr = -32768: what an event outside the tile / window "reads" (fails xmd:23)
+  }
+
+  int lb_s = b_lo.x, lb_e = b_hi.x;
+  bool bad = false;  // this tile objects: the frame is redone on the general path
+  if (lb_s < 0 || lb_e > n || lb_e < lb_s || (u32)(lb_e - lb_s) > COLS_MAX_TILE_EVENTS) {
+    bad = true;  // boundaries out of order (a stream that is not sorted), a frame of >= 2^32 us, or more events than the
+    lb_s = lb_e = 0;  // slots' 16-bit order holds.  Skip the events: the frame's result is discarded anyway
+  }
+  const int x_lo = min(max(((b_lo.y + b_hi.z) >> 1) - w_x / 2, 0), max(tb.cam_w - w_x, 0));
+
+  // ---- 2. the first pass' events (cap = nthreads * EPT per pass).  VEC: 16-byte loads of 8 consecutive events from an
+  //         8-aligned start (events in front of lb_s / behind lb_e are masked); otherwise lane-strided loads from lb_s.
+  const int a0 = VEC ? (lb_s & ~(EPT - 1)) : lb_s;
+  const int n_pass = lb_e > lb_s ? (lb_e - a0 + cap - 1) / cap : 0;
+  u32 xw[EPT / 2], yw[EPT / 2];
+  T tt[EPT];
+  const auto load_events = [&](const int pass) {
+    if constexpr (VEC) {
+      const int base_true = a0 + pass * cap + tid * EPT;
+      const int last_grp = (n - 1) & ~(EPT - 1);
+      const int base = min(base_true, last_grp);  // a thread past the end re-reads the last group (masked)
+      const uint4 xv = *(gp_u4)(xs + base);
+      const uint4 yv = *(gp_u4)(ys + base);
+      xw[0] = xv.x; xw[1] = xv.y; xw[2] = xv.z; xw[3] = xv.w;
+      yw[0] = yv.x; yw[1] = yv.y; yw[2] = yv.z; yw[3] = yv.w;
+#pragma unroll
+      for (int q = 0; q < EPT / 2; ++q) {  // a pair that starts past the end is redirected to the group's first pair
+        const longlong2 a = *(const XM_GLOBAL longlong2*)(ts + (base + 2 * q < n ? base + 2 * q : base));
+        tt[2 * q] = a.x;
+        tt[2 * q + 1] = a.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT / 2; ++q) xw[q] = yw[q] = 0;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int i = lb_s + pass * cap + k * nthreads + tid;
+        const int ic = i < lb_e ? i : lb_s;
+        if constexpr (AOS) {
+          const uint4 r = aos[ic];
+          xw[k >> 1] |= (r.x & 0xffff) << ((k & 1) * 16);
+          yw[k >> 1] |= (r.x >> 16) << ((k & 1) * 16);
+          tt[k] = (T)(((u64)r.w << 32) | r.z);
+        } else {
+          xw[k >> 1] |= (u32)xs[ic] << ((k & 1) * 16);
+          yw[k >> 1] |= (u32)ys[ic] << ((k & 1) * 16);
+          tt[k] = ts[ic];
+        }
+      }
+    }
+  };
+  if (n_pass > 0) {
+    load_events(0);
+    // the compiler waits with vmcnt(0) before the first use of a register loaded BEFORE an LDS-direct load: touch the event
+    // registers here, so that the wait sits in front of the LUT band's loads and the band flies during the event arithmetic
+#pragma unroll
+    for (int q = 0; q < EPT / 2; ++q) asm volatile("" : "+v"(xw[q]), "+v"(yw[q]));
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) asm volatile("" : "+v"(tt[k]));
+  }
+  // ---- 3. the LUT band (w_x camera columns around the range's x) -> LDS ---------------------------------------------------------
+  const int wx_eff = min(w_x, tb.cam_w);
+  const u32 lut_start = (u32)x_lo * (u32)tb.cam_h, lut_shift = lut_start & 3u;  // in words
+  const u32* lut_t = lut_base + lut_shift;
+  const uint4* g_lut = reinterpret_cast<const uint4*>(tb.lut + (lut_start - lut_shift));
+  const int nq_lut = (int)((lut_shift + (u32)wx_eff * (u32)tb.cam_h + 3u) >> 2);
+  if (n_pass > 0)
+    for (int q0 = dma_q0; q0 < nq_lut; q0 += nthreads)
+      __builtin_amdgcn_global_load_lds((glb_void*)(g_lut + min(q0 + lane, nq_lut - 1)), (lds_void*)(l_lut + q0), 16, 0, 0);
+
+  // ---- 4. frame extrema = (t[0], t[n-1]), verified per event below; slot bookkeeping by block 0 (as k_scatter_tiled does in
+  //         its time-sorted mode: K2 reads tag_a and copies it to tag_b)
+  const u32 parity = tag & 1;
+  if (t_last < t_first) t_last = t_first;  // not sorted at all (k_cols_bounds did the same): the verification flags the frame
+  if (blk == 0) {
+    if (tid == 0) {
+      st->tag_a = tag;
+      st->mm[parity][0][0] = TimeCodec<T>::enc(t_first);  // xm_frame_stats.t_min / t_max
+      st->mm[parity][0][1] = TimeCodec<T>::enc(t_last);
+    }
+    for (int i = tid; i < MM_SLOTS; i += nthreads) {
+      st->mm[parity ^ 1][i][0] = MM_INIT_MIN;
+      st->mm[parity ^ 1][i][1] = MM_INIT_MAX;
+    }
+  }
+
+  u32 n_in = 0, n_oob = 0;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    if (pass > 0) load_events(pass);
+    int e0;  // order of the thread's event 0 inside the tile (event index - a0); event k: + k (VEC) / + k * nthreads
+    if constexpr (VEC) e0 = pass * cap + tid * EPT;
+    else e0 = pass * cap + tid;
+    // the event's column inside the tile and the verification, in integers: a = t - tmin against the columns' thresholds
+    u32 av[EPT];
+    int tl[EPT];
+    bool live[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u64 a64 = (u64)(tt[k] - t_first);
+      av[k] = (u32)a64;
+      bool used;
+      if constexpr (VEC) used = a0 + e0 + k >= lb_s && a0 + e0 + k < lb_e;
+      else used = lb_s + e0 + k * nthreads < lb_e;
+      const bool in_tile = (u32)(a64 >> 32) == 0u && av[k] >= A_lo && av[k] < A_hi;
+      bad = bad || (used && !in_tile);
+      live[k] = used && in_tile;
+      tl[k] = 0;
+    }
+    for (int j = 1; j < Wc; ++j) {  // interior columns of the tile (W - 1 of them: one at C-1M)
+      const u32 A_j = thr[c0 + j];  // uniform load
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) tl[k] += av[k] >= A_j ? 1 : 0;
+    }
+    u32 smask = 0;
+    int xl[EPT];
+    bool fast[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u32 xk = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff, yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+      xl[k] = (int)xk - x_lo;
+      fast[k] = live[k] && (u32)xl[k] < (u32)wx_eff && yk < (u32)tb.cam_h;
+      smask |= live[k] && !fast[k] ? 1u << k : 0u;
+    }
+    // events outside the LUT window (x noise) fetch their LUT entry from global memory and join the slots; x / y outside the
+    // camera = map[y, x] IndexError in the reference (calib:279-280): dropped and counted
+    u32 ovr = 0;
+    while (__ballot(smask != 0)) {
+      const bool act = smask != 0;
+      const int ks = act ? __builtin_ctz(smask) : 0;
+      smask &= smask - 1;
+      u32 exw = xw[0], eyw = yw[0];  // (select chains: a dynamic index would put the arrays into scratch memory)
+#pragma unroll
+      for (int q = 1; q < EPT / 2; ++q) {
+        exw = (ks >> 1) == q ? xw[q] : exw;
+        eyw = (ks >> 1) == q ? yw[q] : eyw;
+      }
+      const u32 ex = (exw >> ((ks & 1) * 16)) & 0xffff, ey = (eyw >> ((ks & 1) * 16)) & 0xffff;
+      bool oob = false;
+      if (act) {
+        if (ex >= (u32)tb.cam_w || ey >= (u32)tb.cam_h) {
+          oob = true;
+        } else {
+          const u32 l = tb.lut[ex * (u32)tb.cam_h + ey];
+#pragma unroll
+          for (int kk = 0; kk < EPT; ++kk) xl[kk] = ks == kk ? (int)l : xl[kk];
+          ovr |= 1u << ks;
+        }
+      }
+      n_oob += __popcll(__ballot(oob));
+    }
+    if (pass == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct band loads are tracked by vmcnt
+      __syncthreads();                                   // bands (and the cleared slots) visible
+    }
+    // branch-free: A1 + A2 out of the LDS bands; an event that is not live reads the sentinel (yr < 0) and drops out at xmd:23
+    u32 l[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u32 yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+      const u32* src = fast[k] ? lut_t + (xl[k] * tb.cam_h + (int)yk) : &s_sentinel;
+      l[k] = *src;
+    }
+    const bool any_ovr = __ballot(ovr != 0) != 0;  // (wave-uniform: most waves have no x-noise event)
+    int slot[EPT], xp[EPT];
+    bool yok[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (any_ovr) l[k] = (ovr >> k) & 1u ? (u32)xl[k] : l[k];
+      const int yr = (int)(short)(l[k] >> 16);
+      yok[k] = (u32)yr < (u32)(tb.xmap_h - 1);  // 0 <= yr < H - 1 (xmd:23)
+      slot[k] = yok[k] ? tl[k] * tb.xmap_h + yr : 0;
+      xp[k] = (int)xm_t[slot[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int xr = (int)(short)(l[k] & 0xffff), yr = (int)(short)(l[k] >> 16);
+      const int fu = xp[k] - tb.x_offset;                   // the frame column, = xr + disp (calib:300); no int16 wrap on this rig
+      const int disp = fu - xr;                             // (xm_create has checked the range: xmd:27's wrap never triggers)
+      bool write = yok[k] && disp >= 0;                     // xmd:29
+      const bool in_frame = ((u32)fu < (u32)tb.rect_w || (u32)(fu + tb.rect_w) < (u32)tb.rect_w) && yr < tb.rect_h;
+      n_oob += __popcll(__ballot(write && !in_frame));  // NumPy IndexError (one negative wrap is legal)
+      write = write && in_frame;
+      n_in += __popcll(__ballot(write));
+      const int ek = e0 + (VEC ? k : k * nthreads);
+      if (write) atomicMax(&slots[slot[k]], ((u32)(ek + 1) << 16) | (u32)disp);
+    }
+  }
+  if (n_pass == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the X-map band is needed by the flush
+  }
+  if (__ballot(bad) && lane == 0) {
+    __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (u32* hf = st->host_flags) host_flag_store(hf, tag);
+  }
+  if (lane == 0) {
+    if (n_in) atomicAdd(&s_in, n_in);
+    if (n_oob) atomicAdd(&s_oob, n_oob);
+  }
+  __syncthreads();
+
+  // ---- 5. flush: every live slot of the tile -> its frame cell, winners and empties alike (plain 2-byte stores; lanes walk
+  //         consecutive rows of one time column = consecutive rows of one frame column where the X-map is smooth)
+  {
+    constexpr int FL = 4;
+    const int per = tb.xmap_h;
+    const int dq = nthreads / per, dr = nthreads - dq * per;
+    int r_i;
+    {
+      int q_i = (int)((float)tid * (1.0f / (float)per));
+      r_i = tid - q_i * per;
+      if (r_i < 0) r_i += per;
+      if (r_i >= per) r_i -= per;
+    }
+    for (int i0 = tid; i0 < nslots; i0 += FL * nthreads) {
+      u32 v[FL];
+      int xv[FL], rs[FL];
+#pragma unroll
+      for (int j = 0; j < FL; ++j) {
+        const int i = min(i0 + j * nthreads, nslots - 1);
+        v[j] = slots[i];
+        xv[j] = (int)xm_t[i];
+        rs[j] = r_i;
+        r_i += dr;
+        if (r_i >= per) r_i -= per;
+      }
+#pragma unroll
+      for (int j = 0; j < FL; ++j) {
+        u32 cell;
+        if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && cols_cell(tb, xv[j], rs[j], xr_min, cell))
+          frame16[cell] = (uint16_t)(v[j] & 0xffffu);
+      }
+    }
+  }
+  if (tid == 0) {
+    XM_GLOBAL u32* c = st->cnt[parity][blk % CNT_SLOTS];
+    if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+constexpr int COLS_MAX_THREADS = 512;
+#ifndef XM_COLS_WAVES_PER_EU
+#define XM_COLS_WAVES_PER_EU 6
+#endif
+
+template <bool AOS, bool VEC>
+__global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scatter_cols(
+    const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts, const uint4* __restrict__ aos,
+    u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int w_x, int xr_min) {
+  {  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
+    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)aos | (u64)tb.lut | (u64)tb.xmap | (u64)st | (u64)frame16;
+    const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.t_px_scale | tb.x_offset | tb.rect_w | tb.rect_h | W | w_x;
+    if ((long long)(pp | (u64)(long long)pi) < 0) return;
+  }
+  scatter_cols_body<AOS, VEC>((gp_u16)xs, (gp_u16)ys, (gp_i64)ts, (gp_u4)aos, n, tb, (gp_state)st, (XM_GLOBAL uint16_t*)frame16, W,
+                              w_x, xr_min, blockIdx.x, gridDim.x);
+}
+
+// multi-frame launch: grid = (tiles, frames); FrameDesc.key_frame points at the frame's u16 disparity frame (+ bounds)
+template <bool AOS, bool VEC>
+__global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scatter_cols_batch(const FrameDesc* __restrict__ descs,
+                                                                                                DevTables tb, int W, int w_x,
+                                                                                                int xr_min) {
+  const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
+  if (!d.valid || d.n == 0) return;       // (the host sends frames without events down the general path)
+  scatter_cols_body<AOS, VEC>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
+                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x);
+}
+
+}  // namespace xm

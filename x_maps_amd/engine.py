@@ -152,6 +152,12 @@ class XMapsEngine:
         N.check(self._lib.xm_sorted_fallbacks(self._h, C.byref(v)))
         return int(v.value)
 
+    def path_counts(self) -> dict:
+        """Frames enqueued per K1 variant since the engine was created (a redone frame counts twice)."""
+        v = (C.c_uint64 * 4)()
+        N.check(self._lib.xm_path_counts(self._h, v))
+        return {"general": int(v[0]), "sorted_key64": int(v[1]), "key32": int(v[2]), "cols": int(v[3])}
+
     def stream(self, slot: int = 0) -> int:
         return int(self._lib.xm_stream(self._h, slot) or 0)
 
