@@ -5,10 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Default workload = BASELINE.json configs[1] (C-1M): a "step" = one pass of the hot path (K1 fused per-event scatter ->
-K2 frame kernel; the extrema pass K0 only for frames whose verified (t[0], t[n-1]) shortcut fails) over one frame of
-1 000 000 events (camera = projector = 640x480, rectified frame 1760x1320) whose SoA event columns are already resident
-in HBM; the result is the f32 depth frame + the BGR u8 frame in HBM.  The engine runs with the library's default flags.
+Default workload = BASELINE.json configs[1] (C-1M): a "step" = one pass of the hot path over one batch of synthetic input =
+ONE GROUP of 16 frames of 1 000 000 events each (camera = projector = 640x480, rectified frame 1760x1320) through one
+xm_process_batch call, i.e. one set of multi-frame launches (boundary pass K0b -> K1 column tiles -> K2 frame kernel, grid =
+frames x tiles; K0 + the 64-bit key path only for frames whose verified (t[0], t[n-1]) shortcut fails).  The frames' SoA
+event columns are already resident in HBM; the result is the f32 depth frame + the BGR u8 frame per frame in HBM.  The engine
+runs with the library's default flags.  `--batch 0`: a step = one frame through one asynchronous call (round 2's mode).
 N > 1: every rank runs the same workload on its own GPU with its own frames (the path shards by frame with no data-path
 collective) -> "scaling": "weak"; value = events of all ranks / max-over-ranks time.
 
@@ -51,8 +53,8 @@ TARGET_TIMED_S = 0.30  # the R timed blocks together
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps per block; a step = one group of --batch frames")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "0")),
                     help="frames in flight per GPU (key frame + state each); default 4 (one stream per hardware queue), "
                          "60 with --graph")
@@ -66,7 +68,11 @@ def parse_args():
                     help="configs 1/3 stand-in: ESL-like frames (real calibration geometry, ~150 k events, projector 1080x1920)")
     ap.add_argument("--merge", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
                     help="--sharded: how the shards' key frames are merged (x_maps_amd/sharded.py)")
-    ap.add_argument("--batch", type=int, default=0, help="submit the steps in groups of B frames (xm_process_batch)")
+    ap.add_argument("--batch", type=int, default=16,
+                    help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
+                         "launches, grid = frames x tiles); 0 = a step is one frame through one asynchronous call (round 2's "
+                         "headline mode, reported under other_modes by default)")
+    ap.add_argument("--groups-in-flight", type=int, default=2, help="with --batch: slots = groups x B (default 2)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host->host figures")
@@ -185,28 +191,35 @@ def cpu_baseline_leg(args, O, tables, host_frame, n_ev, camera, want_bgr):
     return cpu
 
 
-def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world):
-    """Per-kernel launch durations from HIP events attached to each dispatch: 300 serial frames, median of the last 200."""
-    n_prof = 300
+def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=None):
+    """Per-kernel launch durations from HIP events attached to each dispatch.  One frame per launch: 300 serial frames, median
+    of the last 200.  group = (B, call): 60 serial groups of B frames (multi-frame launches), median of the last 40."""
+    B = group[0] if group else 1
+    n_prof, skip = (60, 20) if group else (300, 100)
     prof = np.zeros((n_prof, 4))
     for i in range(n_prof):
-        fx, fy, ft = frames[i % len(frames)]
-        st = eng.profile_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, outs[0], outs[1])
-        prof[i] = st.gpu_ms
-    k_ms = np.median(prof[100:], axis=0)
+        if group:
+            prof[i] = group[1](i)
+        else:
+            fx, fy, ft = frames[i % len(frames)]
+            st = eng.profile_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, outs[0], outs[1])
+            prof[i] = st.gpu_ms
+    k_ms = np.median(prof[skip:], axis=0)
     rw, rh, pw, ph, cw, ch = (tables[k] for k in ("rect_w", "rect_h", "proj_w", "proj_h", "cam_w", "cam_h"))
     # algorithmic bytes per launch (SURVEY.md section 8(d)); K0 is charged nothing (it is an extra pass)
     frame_bytes = (12 + bgr_b) * cw * ch if camera else 8 * rw * rh + (8 + bgr_b) * pw * ph
-    alg = {"k_minmax": 0.0, "k_scatter": 24.0 * n_ev, "k_frame": float(frame_bytes)}
+    # per LAUNCH: the per-frame figures x the frames one launch processes
+    alg = {"k_minmax": 0.0, "k_scatter": 24.0 * n_ev * B, "k_frame": float(frame_bytes) * B}
     names = ["k_minmax", "k_scatter", "k_frame"]
     dom = 1 if k_ms[1] >= k_ms[2] else 2  # never the helper pass
     ach = alg[names[dom]] / (k_ms[dom] * 1e-3) / 1e9
     traffic = pt = None
-    wl = "camera" if camera else "projector"
-    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json)
+    wl = ("camera" if camera else "projector") + ("_groups" if group else "")
+    try:  # HBM bytes from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
-        traffic = pt[wl][names[dom]]["hbm_bytes_per_launch"]
+        e = pt[wl][names[dom]]
+        traffic = int(e["hbm_bytes_per_frame"] * B) if "hbm_bytes_per_frame" in e else e["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
     return {
@@ -214,15 +227,19 @@ def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world):
         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
                            "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE calibration, MI355X_MICROARCH.md)") if traffic else None,
-        "algorithmic_bytes_per_launch": alg[names[dom]],
+        "algorithmic_bytes_per_launch": alg[names[dom]], "frames_per_launch": B,
         "avg_launch_us": {n: round(float(k_ms[i]) * 1e3, 2) for i, n in enumerate(names)},
-        "launch_us_p10_p90": {n: [round(float(np.percentile(prof[100:, i], q)) * 1e3, 2) for q in (10, 90)]
+        "launch_us_p10_p90": {n: [round(float(np.percentile(prof[skip:, i], q)) * 1e3, 2) for q in (10, 90)]
                               for i, n in enumerate(names)},
-        "timing": "HIP start/stop events attached to each dispatch (hipExtLaunchKernelGGL) on the stream it runs on; 300 serial "
-                  "frames after the pre-warm and BEFORE the timed blocks, median of the last 200; k_minmax = 0: not launched "
-                  "(default flags: verified (t[0], t[n-1]) shortcut)",
+        "timing": ("HIP start/stop events attached to each dispatch (hipExtLaunchKernelGGL) on the stream it runs on; "
+                   + (f"{n_prof} serial groups of {B} frames (multi-frame launches, grid = frames x tiles) after the pre-warm and "
+                      f"BEFORE the timed blocks, median of the last {n_prof - skip}; k_minmax = the helper pass in front of K1: the "
+                      "boundary pass k_cols_bounds of the column-tile path (or the extrema pass K0 on the general path)"
+                      if group else
+                      "300 serial frames after the pre-warm and BEFORE the timed blocks, median of the last 200; k_minmax = 0: "
+                      "not launched (verified (t[0], t[n-1]) shortcut)")),
         "empty_event_pair_us": round(eng.profile_event_overhead_ms(15) * 1e3, 2),
-        "frame_us_serial": round(float(k_ms[3]) * 1e3, 2),
+        ("group_us_serial" if group else "frame_us_serial"): round(float(k_ms[3]) * 1e3, 2),
     }, alg, pt, wl
 
 
@@ -286,24 +303,29 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     cfg = S.C_1M
     tables = S.make_tables(cfg)
     camera = args.camera_perspective
-    slots = args.slots or (max(4, 2 * args.batch) if args.batch else 4)
+    B = args.batch
+    slots = args.slots or (max(4, args.groups_in_flight * B) if B else 4)
     mode_kw = {"force_general": args.general, "assume_time_sorted": args.assume_sorted}
+    # groups are launched by the calling thread (three launches per GROUP); the one-frame-per-call mode uses the launch workers
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots,
-                      launch_workers=not args.no_launch_workers, **mode_kw)
+                      launch_workers=(not args.no_launch_workers) and not B, **mode_kw)
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 
     # ---- synthetic frames -> HBM (SoA columns, the layout K1 reads), laid out back to back ------------------------
     nf = args.frames
+    if B and (nf % B or slots % B):
+        raise SystemExit("--batch must divide --frames and the number of slots")
     X = torch.empty(nf * n_ev, dtype=torch.int16, device=dev)
     Y = torch.empty_like(X)
     T = torch.empty(nf * n_ev, dtype=torch.int64, device=dev)
-    host_frames = []
+    host_frames = {}
+    keep = {0, 1, 2, 3, max(B - 1, 0)}  # frames kept on the host for the parity checks
     for f in range(nf):
         evs = S.make_events(cfg, frame=rank * nf + f)
         x, y, t, _ = S.to_soa(evs)
-        if f < 4:
-            host_frames.append((x, y, t))
+        if f in keep:
+            host_frames[f] = (x, y, t)
         X[f * n_ev:(f + 1) * n_ev] = torch.from_numpy(x.view(np.int16))
         Y[f * n_ev:(f + 1) * n_ev] = torch.from_numpy(y.view(np.int16))
         T[f * n_ev:(f + 1) * n_ev] = torch.from_numpy(t)
@@ -313,63 +335,64 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     bgr_out = None if args.no_bgr else torch.empty((n_out, H, W, 3), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     bgr_b = 0 if bgr_out is None else 3
-    resident_mb = (nf * n_ev * 12 + slots * eng.key_shape[0] * eng.key_shape[1] * 8 + n_out * H * W * (4 + bgr_b)) / 1e6
+    key_mb = eng.key_shape[0] * eng.key_shape[1] * (8 + 4 + 2) / 1e6  # 64-bit + compact key frame + u16 disparity frame per slot
+    resident_mb = nf * n_ev * 12 / 1e6 + slots * key_mb + n_out * H * W * (4 + bgr_b) / 1e6
+    fps = B or 1  # frames per step
 
-    def make_step(e):
-        if args.batch:
-            B = args.batch
-            offs = np.arange(B + 1, dtype=np.uint64) * n_ev
+    def oracle_frame(f, cam, want_bgr):
+        hx, hy, ht = host_frames[f]
+        return O.process_ev_frame(tables, hx.astype(np.int64), hy.astype(np.int64), ht, camera_perspective=cam, want_bgr=want_bgr)
 
-            def step_group(i):  # frames i .. i+B-1 (consecutive resident frames, wrapping at a multiple of B)
-                f0 = (i % nf) // B * B if nf >= B else 0
-                o = (i // B) % max(n_out // B, 1) * B
-                e.process_batch_device(X[f0 * n_ev:].data_ptr(), Y[f0 * n_ev:].data_ptr(), T[f0 * n_ev:].data_ptr(), None,
-                                       offs, depth_out[o].data_ptr(), None if bgr_out is None else bgr_out[o].data_ptr())
+    def make_step(e, d_out, b_out, nsl, Bm):
+        """step(i): the i-th step = group i of Bm consecutive resident frames (Bm > 0) or frame i (Bm == 0)."""
+        if Bm:
+            offs = np.arange(Bm + 1, dtype=np.uint64) * n_ev
+            gptr = [(X[g * Bm * n_ev:].data_ptr(), Y[g * Bm * n_ev:].data_ptr(), T[g * Bm * n_ev:].data_ptr()) for g in range(nf // Bm)]
+            optr = [(d_out[o * Bm].data_ptr(), None if b_out is None else b_out[o * Bm].data_ptr()) for o in range(nsl // Bm)]
+            call = e.process_batch_device
+
+            def step_group(i):
+                gx, gy, gt = gptr[i % len(gptr)]
+                d, b = optr[i % len(optr)]
+                call(gx, gy, gt, None, offs, d, b)
             return step_group
 
         # raw device pointers are taken once (a host holds them anyway); the step itself is one C-ABI call
         fptr = [(fx.data_ptr(), fy.data_ptr(), ft.data_ptr()) for fx, fy, ft in frames]
-        optr = [(depth_out[o].data_ptr(), None if bgr_out is None else bgr_out[o].data_ptr()) for o in range(n_out)]
+        optr = [(d_out[o].data_ptr(), None if b_out is None else b_out[o].data_ptr()) for o in range(nsl)]
         call = e.process_frame_device
 
         def step(i):
             fx, fy, ft = fptr[i % nf]
-            d, b = optr[i % n_out]
+            d, b = optr[i % nsl]
             call(fx, fy, ft, None, n_ev, d, b)
         return step
 
     def run_steps(step, k, start=0):
-        if args.batch:
-            assert k % args.batch == 0
-            for i in range(start, start + k, args.batch):
-                step(i)
-        else:
-            for i in range(start, start + k):
-                step(i)
+        for i in range(start, start + k):
+            step(i)
 
-    if args.batch and (args.steps % args.batch or nf % args.batch):
-        raise SystemExit("--batch must divide --steps and --frames")
-    step = make_step(eng)
+    step = make_step(eng, depth_out, bgr_out, n_out, B)
 
-    # ---- parity gate before any timing: frame 0 against the CPU oracle (rank 0) ----------------------------------
+    # ---- parity gate before any timing: first (and last) frame of step 0 against the CPU oracle (rank 0) ----------------
     parity = None
     O = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import xmaps_oracle as O  # checker + cpu_baseline only
-        run_steps(step, args.batch or 1)
+        step(0)
         eng.sync()
-        x, y, t = host_frames[0]
-        ref = O.process_ev_frame(tables, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera,
-                                 want_bgr=bgr_out is not None)
+        ref = oracle_frame(0, camera, bgr_out is not None)
         parity = depth_parity(depth_out[0].cpu().numpy(), ref["depth"])
         if bgr_out is not None:
             parity["bgr_equal"] = bool(np.array_equal(bgr_out[0].cpu().numpy(), ref["bgr"]))
-        if not args.batch:
-            st = eng.last_frame_stats()
-            parity["n_inliers_equal"] = bool(st.n_inliers == int(ref["mask"].sum()))
-        ok = (parity["depth_max_rel_err"] <= 1e-4 and parity["empty_mask_equal"] and parity.get("n_inliers_equal", True)
-              and parity.get("bgr_equal", True))
+        if B > 1:
+            refl = oracle_frame(B - 1, camera, False)
+            parity["last_frame_of_the_group_depth_bit_exact"] = bool(np.array_equal(depth_out[B - 1].cpu().numpy(), refl["depth"]))
+        st = eng.last_frame_stats()  # (the group's last frame)
+        parity["n_inliers_equal"] = bool(st.n_inliers == int((refl if B > 1 else ref)["mask"].sum()))
+        ok = (parity["depth_max_rel_err"] <= 1e-4 and parity["empty_mask_equal"] and parity["n_inliers_equal"]
+              and parity.get("bgr_equal", True) and parity.get("last_frame_of_the_group_depth_bit_exact", True))
         if not ok and args.no_parity:
             parity["IGNORED"] = True
         elif not ok:
@@ -377,37 +400,47 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             sys.exit(1)
 
     tm = Timer(torch, dist, dev, eng.sync)
-    unit = args.batch or 1
     # ---- W warm-up steps, fixed pre-warm, per-kernel profile pass, short re-warm, R timed blocks of exactly K steps ----
-    run_steps(step, (args.warmup + unit - 1) // unit * unit)
-    est = tm.prewarm(lambda i: step(i * unit), PREWARM_S) / unit
+    run_steps(step, args.warmup)
+    est = tm.prewarm(step, PREWARM_S)
     roofline = alg = pt = wl = None
     if rank == 0:
+        group = None
+        if B:
+            offs_p = np.arange(B + 1, dtype=np.uint64) * n_ev
+
+            def prof_group(i):
+                g = i % (nf // B)
+                return eng.profile_batch_device(X[g * B * n_ev:].data_ptr(), Y[g * B * n_ev:].data_ptr(), T[g * B * n_ev:].data_ptr(),
+                                                None, offs_p, depth_out[0].data_ptr(), None if bgr_out is None else bgr_out[0].data_ptr())
+            group = (B, prof_group)
         roofline, alg, pt, wl = roofline_of(eng, frames, n_ev,
                                             (depth_out[0].data_ptr(), None if bgr_out is None else bgr_out[0].data_ptr()),
-                                            tables, camera, bgr_b, world)
-    est = tm.agree(tm.prewarm(lambda i: step(i * unit), 0.1) / unit)
+                                            tables, camera, bgr_b, world, group)
+    est = tm.agree(tm.prewarm(step, 0.1))
     R = n_blocks_for(args, est)
     el, enq = tm.blocks(lambda: run_steps(step, args.steps), R)
     elapsed = float(np.median(el))
-    total_events = float(n_ev) * args.steps * world
+    total_events = float(n_ev) * fps * args.steps * world
     value = total_events / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
+    paths = eng.path_counts()
     if rank != 0:
         eng.close()
         return None
 
-    frame_alg = alg["k_scatter"] + alg["k_frame"]
+    s_frame = elapsed / (args.steps * fps)  # seconds per frame, pipelined
+    frame_alg = (alg["k_scatter"] + alg["k_frame"]) / fps
     roofline["whole_frame"] = {"algorithmic_bytes": frame_alg,
-                               "achieved_GBps_pipelined": round(frame_alg / (elapsed / args.steps) / 1e9, 2),
-                               "frac_of_peak_pipelined": round(frame_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+                               "achieved_GBps_pipelined": round(frame_alg / s_frame / 1e9, 2),
+                               "frac_of_peak_pipelined": round(frame_alg / s_frame / 1e9 / HBM_PEAK_GBS, 5)}
     roofline["event_stream_read_roofline_frac"] = round(value * 1e6 / world * 14 / 1e9 / HBM_PEAK_GBS, 5)
     try:
-        names = ["k_scatter", "k_frame"] + ([] if eng.sorted_fallbacks() == 0 and not args.general else ["k_minmax"])
-        tot = sum(pt[wl][k]["hbm_bytes_per_launch"] for k in names)
+        names = ["k_scatter", "k_frame"] + (["k_minmax"] if (paths["general"] or paths["cols"] or args.general) else [])
+        tot = sum(pt[wl][k].get("hbm_bytes_per_frame", pt[wl][k].get("hbm_bytes_per_launch")) for k in names)
         roofline["pipeline_hbm_traffic"] = {"hbm_bytes_per_frame_all_kernels": tot, "kernels": names,
-                                            "GBps_at_measured_step_time": round(tot / (elapsed / args.steps) / 1e9, 1),
-                                            "frac_of_peak": round(tot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+                                            "GBps_at_measured_step_time": round(tot / s_frame / 1e9, 1),
+                                            "frac_of_peak": round(tot / s_frame / 1e9 / HBM_PEAK_GBS, 4)}
     except Exception:
         pass
     frames_redone = eng.sorted_fallbacks()
@@ -417,91 +450,80 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline_leg(args, O, tables, host_frames[0], n_ev, camera, bgr_out is not None)
 
-    # ---- the same loop with other engine settings (extra information, never the headline `value`) -----------------------
+    # ---- the same frames with other engine settings (extra information, never the headline `value`) -----------------------
     eng.close()  # one engine at a time: two engines would share the high-priority hardware queues
     other_modes = None
-    if world == 1 and not args.no_other_modes and not args.batch:
+    if world == 1 and not args.no_other_modes:
         other_modes = {}
-        modes = []
-        if not args.no_launch_workers:
-            modes.append(("launches_from_the_calling_thread", dict(mode_kw), camera, 0))
+        modes = []  # (name, engine flags, camera view, frames per call, launch workers)
+        if B:
+            modes.append(("one_frame_per_call", dict(mode_kw), camera, 0, not args.no_launch_workers))
+        else:
+            modes.append(("groups_of_16_frames_per_call", dict(mode_kw), camera, 16, False))
+            if not args.no_launch_workers:
+                modes.append(("launches_from_the_calling_thread", dict(mode_kw), camera, 0, False))
         if not args.general:
-            modes.append(("forced_general", {"force_general": True}, camera, 0))
-        if not args.assume_sorted:
-            modes.append(("declared_sorted", {"assume_time_sorted": True}, camera, 0))
-        modes.append(("batched_groups_of_8", dict(mode_kw), camera, 8))
+            modes.append(("forced_general", {"force_general": True}, camera, B, (not args.no_launch_workers) and not B))
         if not camera:
-            modes.append(("camera_view", dict(mode_kw), True, 0))
-        for name, kw, cam, B in modes:
-            nsl = max(slots, 2 * B) if B else slots
-            e2 = XMapsEngine(tables, camera_perspective=cam, device=local_rank, n_slots=nsl,
-                             launch_workers=(not args.no_launch_workers) and name != "launches_from_the_calling_thread", **kw)
+            modes.append(("camera_view", dict(mode_kw), True, B, (not args.no_launch_workers) and not B))
+        for name, kw, cam, Bm, workers in modes:
+            nsl = max(4, args.groups_in_flight * Bm) if Bm else 4
+            e2 = XMapsEngine(tables, camera_perspective=cam, device=local_rank, n_slots=nsl, launch_workers=workers, **kw)
             H2, W2 = e2.out_h, e2.out_w
-            d2 = torch.empty((max(nsl, 1), H2, W2), dtype=torch.float32, device=dev)
-            b2 = None if bgr_out is None else torch.empty((max(nsl, 1), H2, W2, 3), dtype=torch.uint8, device=dev)
+            d2 = torch.empty((nsl, H2, W2), dtype=torch.float32, device=dev)
+            b2 = None if bgr_out is None else torch.empty((nsl, H2, W2, 3), dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
-            if B:
-                offs = np.arange(B + 1, dtype=np.uint64) * n_ev
-
-                def step2(i, e2=e2, d2=d2, b2=b2, B=B, offs=offs, nsl=nsl):
-                    f0 = (i * B) % (nf // B * B)
-                    o = (i % (nsl // B)) * B
-                    e2.process_batch_device(X[f0 * n_ev:].data_ptr(), Y[f0 * n_ev:].data_ptr(), T[f0 * n_ev:].data_ptr(), None,
-                                            offs, d2[o].data_ptr(), None if b2 is None else b2[o].data_ptr())
-                per, last_frame = B, lambda i: ((i * B) % (nf // B * B) + B - 1, (i % (nsl // B)) * B + B - 1)
-            else:
-                def step2(i, e2=e2, d2=d2, b2=b2, nsl=nsl):
-                    fx, fy, ft = frames[i % nf]
-                    o = i % nsl
-                    e2.process_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, d2[o].data_ptr(),
-                                            None if b2 is None else b2[o].data_ptr())
-                per, last_frame = 1, lambda i: (i % nf, i % nsl)
+            step2 = make_step(e2, d2, b2, nsl, Bm)
+            per = Bm or 1
             tm2 = Timer(torch, None, dev, e2.sync)
-            est2 = tm2.prewarm(step2, PREWARM_S) / per
-            k2 = (args.steps + per - 1) // per
-            R2 = int(min(200, max(3, round(0.2 / max(k2 * per * est2, 1e-6)))))
-            el2, _ = tm2.blocks(lambda: [step2(i) for i in range(k2)], R2)
+            est2 = tm2.prewarm(step2, PREWARM_S)
+            k2 = max(1, args.steps * fps // per)  # the same number of frames as a timed block of the headline
+            R2 = int(min(200, max(3, round(0.2 / max(k2 * est2, 1e-6)))))
+            el2, _ = tm2.blocks(lambda: run_steps(step2, k2), R2)
             dt = float(np.median(el2))
-            fi, oi = last_frame(k2 - 1)
+            # the last step's last frame against the oracle (when that frame is one of those kept on the host)
+            li = k2 - 1
+            fi = (li % (nf // per)) * per + per - 1
+            oi = (li % (nsl // per)) * per + per - 1
             same = None
-            if fi < len(host_frames):
-                hf = host_frames[fi]
-                same = bool(np.array_equal(d2[oi].cpu().numpy(),
-                                           O.process_ev_frame(tables, hf[0].astype(np.int64), hf[1].astype(np.int64), hf[2],
-                                                              camera_perspective=cam, want_bgr=False)["depth"]))
+            if fi in host_frames:
+                same = bool(np.array_equal(d2[oi].cpu().numpy(), oracle_frame(fi, cam, False)["depth"]))
             other_modes[name] = {"value": round(n_ev * k2 * per / dt / 1e6, 2), "unit": "Mevents/s",
-                                 "ms_per_step": round(dt / (k2 * per) * 1e3, 5), "blocks": R2,
+                                 "ms_per_frame": round(dt / (k2 * per) * 1e3, 5), "blocks": R2, "k1_paths": e2.path_counts(),
                                  "frames_redone_on_general_path": e2.sorted_fallbacks()}
             if same is not None:
                 other_modes[name]["depth_equals_oracle"] = same
             e2.close()
-        other_modes["note"] = ("launches_from_the_calling_thread = the same without XM_FLAG_LAUNCH_WORKERS; forced_general = XM_FLAG_GENERAL (extrema pass K0 on every frame, what round 1 reported as the "
-                               "headline); declared_sorted = XM_FLAG_TIME_SORTED; batched_groups_of_8 = xm_process_batch, 8 "
-                               "frames per set of multi-frame launches, two groups in flight; camera_view = "
-                               "--camera-perspective with the default flags; `value` above = library defaults, one frame "
-                               "per call")
+        other_modes["note"] = ("one_frame_per_call = every frame through its own asynchronous call (xm_process_frame, 4 frames in "
+                               "flight, a launch thread per slot stream): round 2's headline mode; forced_general = "
+                               "XM_FLAG_GENERAL (extrema pass K0 + 64-bit packed keys on every frame: round 1's headline "
+                               "mode); camera_view = --camera-perspective; `value` above = library defaults, groups of "
+                               f"{B} frames per call" if B else
+                               "groups_of_16_frames_per_call = xm_process_batch; launches_from_the_calling_thread = no launch "
+                               "workers; forced_general = XM_FLAG_GENERAL; camera_view = --camera-perspective")
 
     # (these legs run LAST, on an engine of their own: their pinned allocations and extra streams change how the runtime maps
     #  streams to hardware queues for whatever engine comes next -- seen: the following loop at half its rate)
-    eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots, **mode_kw) \
+    eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=4, **mode_kw) \
         if (not args.no_host_path and world == 1) else None
+    hf4 = [host_frames[f] for f in range(4)]
     # ---- PCIe-inclusive figures: events start in host memory, depth + BGR end in host memory (never `value`) ------
     host_path = None
     if not args.no_host_path and world == 1:
         x, y, t = host_frames[0]
-        for _ in range(max(3, slots + 1)):  # every slot allocates its staging buffers on first use
+        for _ in range(max(3, 4 + 1)):  # every slot allocates its staging buffers on first use
             eng.process_frame(x, y, t, want_bgr=bgr_out is not None)
         c0 = time.perf_counter()
         for _ in range(20):
             eng.process_frame(x, y, t, want_bgr=bgr_out is not None)
         host_path = {"Mevents_per_s_pageable_synchronous": round(20 * n_ev / (time.perf_counter() - c0) / 1e6, 2)}
         pin = []
-        for (hx, hy, ht) in host_frames[:4]:
+        for (hx, hy, ht) in hf4:
             px_, py_, pt_ = eng.host_empty(hx.shape, np.uint16), eng.host_empty(hy.shape, np.uint16), eng.host_empty(ht.shape, np.int64)
             px_[:], py_[:], pt_[:] = hx, hy, ht
             pin.append((px_, py_, pt_))
         outs = [(eng.host_empty((H, W), np.float32), None if bgr_out is None else eng.host_empty((H, W, 3), np.uint8))
-                for _ in range(max(slots, 1))]
+                for _ in range(4)]
         reps = 200
         for i in range(16):
             a = pin[i % len(pin)]
@@ -513,7 +535,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             eng.process_frame_pinned(a[0], a[1], a[2], None, outs[i % len(outs)][0], outs[i % len(outs)][1])
         eng.sync()
         dt = time.perf_counter() - c0
-        hf = host_frames[(reps - 1) % len(pin)]
+        hf = hf4[(reps - 1) % len(pin)]
         ok_pinned = bool(np.array_equal(outs[(reps - 1) % len(outs)][0],
                                         O.process_ev_frame(tables, hf[0].astype(np.int64), hf[1].astype(np.int64), hf[2],
                                                            camera_perspective=camera, want_bgr=False)["depth"]))
@@ -527,7 +549,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     # ---- end to end with the device-side ingest: RAW camera packets (all polarities) in host memory -> frames in host memory ----
     ingest_path = None
     if not args.no_host_path and world == 1:
-        ingest_path = ingest_leg(eng, host_frames, n_ev, O, tables, camera)
+        ingest_path = ingest_leg(eng, hf4, n_ev, O, tables, camera)
 
     if eng is not None:
         eng.close()
@@ -538,20 +560,26 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         "data": "synthetic",
         "config": {"workload": "C-1M: synthetic 1M events/frame, 640x480 cam/proj, rect 1760x1320, 1xMI355X fused kernels"
                    + (" (camera view)" if camera else " (projector view)"),
-                   "events_per_frame": n_ev, "frames_in_flight": slots, "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
-                   "launch": (f"eager, groups of {args.batch} frames per call (xm_process_batch)" if args.batch else "eager, one frame per call")
-                             + ("" if args.no_launch_workers else "; XM_FLAG_LAUNCH_WORKERS (a launch thread per slot stream)"),
+                   "events_per_frame": n_ev, "frames_per_step": fps, "events_per_step": n_ev * fps, "frames_in_flight": slots,
+                   "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
+                   "launch": (f"eager; a step = one group of {B} frames through ONE call (xm_process_batch: one set of multi-frame "
+                              f"launches, grid = frames x tiles), {slots // B} groups in flight, launches from the calling thread"
+                              if B else "eager, one frame per call"
+                              + ("" if args.no_launch_workers else "; XM_FLAG_LAUNCH_WORKERS (a launch thread per slot stream)")),
                    "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM",
                    "distinct_frames_resident": nf, "resident_set_MB": round(resident_mb, 1),
                    "resident_set_vs_infinity_cache": "exceeds the 256 MiB MALL" if resident_mb > 268.4 else "fits the 256 MiB MALL",
+                   "k1_paths_frames": paths,
                    "extrema": "XM_FLAG_GENERAL (K0 every frame)" if args.general else
                               ("XM_FLAG_TIME_SORTED" if args.assume_sorted else
-                               "library default: (t[0], t[n-1]) verified on the device + compact 32-bit key frame, failing frames redone with K0 on the 64-bit path"),
+                               "library default: (t[0], t[n-1]) verified on the device; groups take the column-tile K1 (boundary "
+                               "pass + plain-store u16 frame), single frames the compact 32-bit key frame; failing frames are "
+                               "redone with K0 on the 64-bit path"),
                    "frames_redone_on_general_path": frames_redone},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
                    "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6),
                    "note": "R blocks of exactly `steps` steps, each bracketed by barrier + synchronize, max over ranks per block, "
-                           "median block reported"},
+                           "median block reported; ms_per_step = one step = frames_per_step frames"},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "host_enqueue_us_per_step": round(float(np.median(enq)) / args.steps * 1e6, 2),
     }

@@ -202,6 +202,11 @@ int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
  * the chip half idle while they ramp up and drain; a group's launch keeps every CU fed. */
 int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
                      const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out);
+/* The same group, synchronously, with start / stop events attached to the dispatch packets of its launches (the time
+ * stamps rocprofv3 --kernel-trace reports): gpu_ms[0] = the extrema pass K0 (general path) or the boundary pass K0b
+ * (column tiles), 0 when neither ran; [1] = K1; [2] = K2; [3] = start of the first .. end of the last. */
+int xm_profile_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, float gpu_ms[4]);
 
 /* ---- a batch of frames captured once into a hipGraph and replayed (BASELINE config 5) ------------ */
 /* The capture uses the multi-frame launches above: with n_slots >= n_frames the whole batch is three kernel nodes;

@@ -35,8 +35,18 @@ def test_default_line_as_the_driver_calls_it():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["parity"]["depth_bit_exact"] and d["parity"]["bgr_equal"]
-    assert abs(d["value"] - 1e6 * 20 / (d["ms_per_step"] * 20 * 1e-3) / 1e6) / d["value"] < 0.01  # value == events / time
+    fps = d["config"]["frames_per_step"]  # a step = one group of frames through one xm_process_batch call
+    assert fps == 16 and d["config"]["events_per_step"] == 16_000_000 and r["frames_per_launch"] == fps
+    assert r["algorithmic_bytes_per_launch"] == 24.0 * 1e6 * fps and d["parity"]["last_frame_of_the_group_depth_bit_exact"]
+    assert d["config"]["k1_paths_frames"]["cols"] > 0  # the groups took the column-tile K1
+    assert abs(d["value"] - 1e6 * fps * 20 / (d["ms_per_step"] * 20 * 1e-3) / 1e6) / d["value"] < 0.01  # value == events / time
     assert d["host_path"]["meets_north_star_1_Gevent_per_s_end_to_end"] and d["ingest_path"]["first_frame_depth_equals_oracle"]
+
+
+def test_one_frame_per_call_mode_still_prints_the_line():
+    d = _run("--batch", "0", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
+    assert d["config"]["frames_per_step"] == 1 and d["roofline"]["frames_per_launch"] == 1 and d["value"] > 1000
+    assert d["parity"]["depth_bit_exact"] and d["config"]["k1_paths_frames"]["key32"] > 0
 
 
 @pytest.mark.parametrize("flags,workload", [(("--graph", "--steps", "60"), "C-60x1M"), (("--sharded", "--steps", "10"), "C-10M"),

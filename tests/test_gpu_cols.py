@@ -14,6 +14,13 @@ from x_maps_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _column_tiles_for_single_frames_too(monkeypatch):
+    """By default only groups of frames (xm_process_batch) take the column tiles -- a single frame's boundary pass is a third
+    dependent launch; XM_COLS=2 sends single-frame calls there as well, which is how most cases below reach the kernel."""
+    monkeypatch.setenv("XM_COLS", "2")
+
+
 def _ref(tb, evs, **kw):
     x, y, t, _ = S.to_soa(evs)
     return O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, **kw)
@@ -219,18 +226,37 @@ def test_a_non_injective_x_map_keeps_the_keyed_paths():
         assert pc["cols"] == 0 and pc["key32"] == 0 and pc["sorted_key64"] == 1
 
 
-def test_switch_off_gives_the_same_frames(monkeypatch):
+def test_switches(monkeypatch):
+    """XM_COLS=2: every qualifying frame; default: groups only (single frames keep the compact key frame); 0: off."""
+    torch = pytest.importorskip("torch")
     cfg = S.C_1M
     tb = S.make_tables(cfg)
     evs = S.make_events(cfg, frame=15)
-    with XMapsEngine(tb) as eng:
-        d0, b0, s0 = _run(eng, evs)
-        assert eng.path_counts()["cols"] == 1
-    monkeypatch.setenv("XM_COLS", "0")
-    with XMapsEngine(tb) as eng:
-        d1, b1, s1 = _run(eng, evs)
-        assert eng.path_counts()["cols"] == 0
-    assert np.array_equal(d0, d1) and np.array_equal(b0, b1) and s0.n_inliers == s1.n_inliers
+    x, y, t, _ = S.to_soa(evs)
+    dev = torch.device("cuda", 0)
+    X, Y, T = (torch.from_numpy(v).to(dev) for v in (np.tile(x.view(np.int16), 2), np.tile(y.view(np.int16), 2), np.tile(t, 2)))
+    out = torch.zeros((2, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    offs = np.array([0, len(t), 2 * len(t)], dtype=np.uint64)
+    res = {}
+    for mode in ("2", None, "0"):
+        if mode is None:
+            monkeypatch.delenv("XM_COLS")
+        else:
+            monkeypatch.setenv("XM_COLS", mode)
+        with XMapsEngine(tb) as eng:
+            d, b, st = _run(eng, evs)
+            single = eng.path_counts()
+            eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, out.data_ptr(), None)
+            eng.sync()
+            both = eng.path_counts()
+            res[mode] = (d, b, st.n_inliers, single, both, out.cpu().numpy().copy())
+    assert res["2"][3]["cols"] == 1 and res["2"][4]["cols"] == 3
+    assert res[None][3]["cols"] == 0 and res[None][3]["key32"] == 1 and res[None][4]["cols"] == 2
+    assert res["0"][4]["cols"] == 0 and res["0"][4]["key32"] == 3
+    for mode in (None, "0"):
+        assert np.array_equal(res["2"][0], res[mode][0]) and np.array_equal(res["2"][1], res[mode][1])
+        assert res["2"][2] == res[mode][2] and np.array_equal(res["2"][5], res[mode][5])
+    assert np.array_equal(res["2"][5][0], res["2"][0]) and np.array_equal(res["2"][5][1], res["2"][0])
 
 
 def test_index_errors_are_counted_like_the_reference():

@@ -188,6 +188,8 @@ struct xm_handle {
   // column-tile K1 (xmaps_k1cols.hpp): the rig qualifies (projector view, cell(row, column) injective, no int16 wrap in the
   // disparity arithmetic), smallest rectified x of the LUT, widest tile the LDS budget allows, events a tile should hold
   bool cols_ok = false;
+  bool cols_single = false;  // XM_COLS=2: also for single-frame calls (default: groups of frames only -- a single frame's third
+                             // launch, the boundary pass, costs the pipelined one-frame-per-call path more than the tiles save)
   int cols_xr_min = 0, cols_w_max = 0, cols_target = 3700;
   std::atomic<uint64_t> path_counts[4] = {};  // frames enqueued per K1 variant (xm_path_counts)
   // (atomics: with XM_FLAG_LAUNCH_WORKERS the launch threads and the API thread all pass through enqueue_frame)
@@ -449,8 +451,12 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W) {
   static const int force = getenv("XM_COLS_THREADS") ? atoi(getenv("XM_COLS_THREADS")) : 0;  // experiments
   if (force >= 64 && force <= COLS_MAX_THREADS && force % 64 == 0) return (unsigned)force;
   const double per_tile = (double)n / (double)h->tb.xmap_w * W;
-  // one pass for a tile 12 % above the mean (Poisson spread of an evenly filled scan); fuller tiles take a second pass
+  // one pass for a tile 12 % above the mean (Poisson spread of an evenly filled scan); fuller tiles take a second pass.
+  // Tiles of more than 2048 events get the full 512 threads even when 448 would hold them: three blocks per CU are then
+  // 24 waves = every wave slot the kernel's 80 VGPRs allow (measured at C-1M, 3125 events per tile: 4.35 instead of 4.63 us
+  // per frame at full occupancy; 384 threads = two passes: 5.9 us)
   unsigned t = ((unsigned)(per_tile * 1.12 / COLS_EPT) + 63u) / 64u * 64u;
+  if (t > 256u) t = COLS_MAX_THREADS;
   return std::max(128u, std::min(t, (unsigned)COLS_MAX_THREADS));
 }
 
@@ -538,7 +544,8 @@ bool key32_path(const xm_handle* h, const EventsView& ev, bool sorted) {
 
 // may this (sorted-path) frame use the column tiles?  Same preconditions as the compact key frame (automatic redo at hand)
 // + int64 time stamps; returns the tile width W (0: no)
-int cols_path(const xm_handle* h, const EventsView& ev, bool sorted) {
+int cols_path(const xm_handle* h, const EventsView& ev, bool sorted, bool group = true) {
+  if (!group && !h->cols_single) return 0;
   if (!sorted || !h->cols_ok || !h->try_sorted || h->capturing || h->key32_pause.load(std::memory_order_relaxed) > 0 ||
       h->k2_direct || h->k2_flags || ev.use_p || (!ev.aos && ev.t_dtype != XM_T_INT64))
     return 0;
@@ -570,7 +577,7 @@ void key32_note(xm_handle* h, bool failed) {
 int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uint8_t* bgr, hipEvent_t* prof,
                   bool allow_sorted = true, hipStream_t stream_override = nullptr) {
   const bool sorted = allow_sorted && sorted_path(h, ev);
-  const int cols_w = cols_path(h, ev, sorted);
+  const int cols_w = cols_path(h, ev, sorted, false);
   const bool use32 = !cols_w && key32_path(h, ev, sorted);
   {
     int v = h->key32_pause.load(std::memory_order_relaxed);
@@ -634,7 +641,12 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 // they ramp up and drain (245 K1 blocks for 256 CUs, each a ~10 us dependent chain); a group's launch keeps every CU fed.
 template <typename T, bool AOS, bool HAS_P>
 int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
-                   hipStream_t stream, bool key32 = false, int cols_w = 0) {
+                   hipStream_t stream, bool key32 = false, int cols_w = 0, hipEvent_t* prof = nullptr) {
+  // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the dispatch packets of K0 / K0b, K1, K2
+  struct ProfReset {
+    ~ProfReset() { g_prof = ProfCtx{}; }
+  } prof_reset;
+  const auto prof_slot = [&](int i) { if (prof) g_prof = ProfCtx{prof[2 * i], prof[2 * i + 1]}; };
   if constexpr (std::is_same<T, long long>::value && !HAS_P) {
     if (cols_w) {  // column tiles: K1 grid = (tiles, frames), K2 on the plain u16 frames
       auto kern = k_scatter_cols_batch<AOS, false>;
@@ -644,10 +656,13 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       const size_t lds = cols_lds_bytes(h, cols_w);
       int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
       if (rc) return rc;
+      prof_slot(0);
       XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_WAVES), n_frames),
                 dim3(64 * COLS_BOUNDS_WAVES), 0, stream, d_descs, h->tb, cols_w);
+      prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                 cols_w, h->w_x, h->cols_xr_min);
+      prof_slot(2);
       XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
                 dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
@@ -656,6 +671,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
     }
   }
   // K0: grid = (blocks of the largest frame, frames)
+  prof_slot(0);
   if (!sorted) {
     const bool vec2 = !AOS && std::is_same<T, long long>::value && vec16;
     const unsigned per_block = BLOCK * (vec2 ? 2 * K0_UN : 4);
@@ -691,12 +707,14 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
     }
     int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), h->k1_lds);
     if (rc) return rc;
+    prof_slot(1);
     XM_LAUNCH(kern, dim3(gx1, n_frames), dim3(threads), h->k1_lds, stream, d_descs, h->tb, h->w_ts, h->w_x, sorted ? 1 : 0);
     return XM_OK;
   };
   int rc = h->cfg.view == XM_VIEW_PROJECTOR ? launch_k1(std::integral_constant<int, 0>{}) : launch_k1(std::integral_constant<int, 1>{});
   if (rc) return rc;
   // K2
+  prof_slot(2);
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (key32)
       XM_LAUNCH(k_frame_proj_tiled_batch<true>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
@@ -725,7 +743,8 @@ bool batch_path(const xm_handle* h, u64 n_mean) {
 // d_descs / h_descs: where the group's descriptors live (the caller owns their lifetime).  `upload`: copy them now
 // (eager) -- false when the caller uploads once (graph capture).
 int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, float* const* depth, uint8_t* const* bgr,
-                  int n_frames, hipStream_t stream, FrameDesc* h_descs, FrameDesc* d_descs, bool upload, bool allow_sorted) {
+                  int n_frames, hipStream_t stream, FrameDesc* h_descs, FrameDesc* d_descs, bool upload, bool allow_sorted,
+                  hipEvent_t* prof = nullptr, int* kinds = nullptr) {
   u64 n_max = 0, n_sum = 0;
   bool vec16 = true;
   for (int f = 0; f < n_frames; ++f) {
@@ -790,16 +809,20 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   if (upload) HIP_TRY(hipMemcpyAsync(d_descs, h_descs, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, stream));
   int rc;
   if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32)
-                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w);
+                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w, prof);
   else switch (e0.t_dtype) {
     case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
-                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w); break;
+                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w, prof); break;
     case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
                                      : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
     default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
                            : launch_batch_t<double, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32);
   }
   if (rc) return rc;
+  if (kinds) {  // which launches the group consisted of: {K0 general / K0b bounds / none, K1 variant}
+    kinds[0] = cols_w ? 2 : sorted ? 0 : 1;
+    kinds[1] = cols_w ? KM_COLS : use32 ? KM_KEY32 : KM_KEY64;
+  }
   for (int f = 0; f < n_frames; ++f) {
     Slot& s = h->slots[slot_idx[f]];
     s.host_tag += 1;
@@ -1315,6 +1338,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       injective = dup == 0;  // every frame cell has at most one (row, time column) that can write it
     }
     h->cols_ok = injective && h->d_pmap && !(ec && ec[0] == '0');
+    h->cols_single = ec && ec[0] == '2';
     // the compact key frame orders the writers of a cell by TILE only: two time columns of one tile that share a cell would be
     // ordered by their disparity bits -- it needs the same property (the 64-bit keys carry the full event index and do not)
     h->key32_ok = h->key32_ok && injective;
@@ -1688,8 +1712,8 @@ int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
 }
 
 // ---- a group of frames in one set of multi-frame launches ---------------------------------------------------
-int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
-                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out) {
+static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                              const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, float* gpu_ms) {
   if (!h || !offsets_host || n_frames <= 0) return fail(XM_ERR_INVALID, "bad argument");
   const int ns = (int)h->slots.size();
   if (n_frames > ns) return fail(XM_ERR_INVALID, "a batch of %d frames needs n_slots >= %d (handle has %d)", n_frames, n_frames, ns);
@@ -1727,7 +1751,9 @@ int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
   if (h->desc_used[k]) HIP_TRY(hipEventSynchronize(h->desc_ev[k]));  // the ring entry's previous batch has long finished
   FrameDesc* hd = h->h_descs + (size_t)k * ns;
   FrameDesc* dd = h->d_descs + (size_t)k * ns;
-  int rc = enqueue_batch(h, idx.data(), evs.data(), dep.data(), bg.data(), n_frames, stream, hd, dd, true, true);
+  int kinds[2] = {0, 0};
+  int rc = enqueue_batch(h, idx.data(), evs.data(), dep.data(), bg.data(), n_frames, stream, hd, dd, true, true,
+                         gpu_ms ? h->prof_ev : nullptr, kinds);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->desc_ev[k], stream));
   h->desc_used[k] = true;
@@ -1749,7 +1775,29 @@ int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
       s.prev.stream = stream;
     }
   }
+  if (gpu_ms) {  // profile mode: durations of the group's dispatches (the events were attached to the dispatch packets)
+    HIP_TRY(hipStreamSynchronize(stream));
+    gpu_ms[0] = gpu_ms[1] = gpu_ms[2] = gpu_ms[3] = 0.0f;
+    const int first = kinds[0] ? 0 : 1;  // no K0 / K0b launch on the verified-sorted keyed paths
+    u64 n_sum = 0;
+    for (int f = 0; f < n_frames; ++f) n_sum += evs[f].n;
+    if (batch_path(h, n_sum / (u64)n_frames)) {  // (frame-by-frame fallback for sparse frames: nothing was attached)
+      for (int i = first; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+      HIP_TRY(hipEventElapsedTime(&gpu_ms[3], h->prof_ev[2 * first], h->prof_ev[5]));
+    }
+  }
   return XM_OK;
+}
+
+int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out) {
+  return process_batch_impl(h, x, y, t, p, t_dtype, offsets_host, n_frames, depth_out, bgr_out, nullptr);
+}
+
+int xm_profile_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
+                     const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, float gpu_ms[4]) {
+  if (!gpu_ms) return fail(XM_ERR_INVALID, "NULL argument");
+  return process_batch_impl(h, x, y, t, p, t_dtype, offsets_host, n_frames, depth_out, bgr_out, gpu_ms);
 }
 
 // ---- hipGraph batch ------------------------------------------------------------------------------------

@@ -46,6 +46,15 @@ typedef const XM_GLOBAL uint4* gp_u4;
 typedef const XM_GLOBAL int4* gp_i4;
 typedef XM_GLOBAL SlotState* gp_state;
 
+#ifdef XM_ABLATE  // experiments (tools/cols_timeline.py): s_memtime stamps of thread 0 of the first 64 tiles of frame XM_CSTAMP_FRAME
+#ifndef XM_CSTAMP_FRAME
+#define XM_CSTAMP_FRAME 30
+#endif
+#define XM_CSTAMP(ph) do { if (threadIdx.x == 0 && blockIdx.y == XM_CSTAMP_FRAME && blockIdx.x < 64) g_timeline[blockIdx.x][ph] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XM_CSTAMP(ph) do { } while (0)
+#endif
+
 constexpr int COLS_EPT = 8;          // events per thread and pass
 constexpr u32 COLS_MAX_TILE_EVENTS = 65535u - 8u;  // the slot value carries (local index + 1) in 16 bits
 
@@ -275,6 +284,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   const int c0 = (int)tile * W;
   const int Wc = min(W, tb.xmap_w - c0);  // >= 1: nblk = ceil(xmap_w / W)
   const int nslots = Wc * tb.xmap_h;
+  XM_CSTAMP(0);
 
   // ---- 1. everything that locates the tile, as uniform loads in one round trip: its event range and camera-column window,
   //         the thresholds of its first and one-past-last column (k_cols_bounds), the frame's first / last time stamp, the tag
@@ -314,6 +324,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     lb_s = lb_e = 0;  // slots' 16-bit order holds.  Skip the events: the frame's result is discarded anyway
   }
   const int x_lo = min(max(((b_lo.y + b_hi.z) >> 1) - w_x / 2, 0), max(tb.cam_w - w_x, 0));
+  XM_CSTAMP(1);
 
   // ---- 2. the first pass' events (cap = nthreads * EPT per pass).  VEC: 16-byte loads of 8 consecutive events from an
   //         8-aligned start (events in front of lb_s / behind lb_e are masked); otherwise lane-strided loads from lb_s.
@@ -365,6 +376,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 #pragma unroll
     for (int k = 0; k < EPT; ++k) asm volatile("" : "+v"(tt[k]));
   }
+  XM_CSTAMP(2);
   // ---- 3. the LUT band (w_x camera columns around the range's x) -> LDS ---------------------------------------------------------
   const int wx_eff = min(w_x, tb.cam_w);
   const u32 lut_start = (u32)x_lo * (u32)tb.cam_h, lut_shift = lut_start & 3u;  // in words
@@ -456,8 +468,11 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       n_oob += __popcll(__ballot(oob));
     }
     if (pass == 0) {
+      XM_CSTAMP(3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct band loads are tracked by vmcnt
+      XM_CSTAMP(4);
       __syncthreads();                                   // bands (and the cleared slots) visible
+      XM_CSTAMP(5);
     }
     // branch-free: A1 + A2 out of the LDS bands; an event that is not live reads the sentinel (yr < 0) and drops out at xmd:23
     u32 l[EPT];
@@ -492,6 +507,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       if (write) atomicMax(&slots[slot[k]], ((u32)(ek + 1) << 16) | (u32)disp);
     }
   }
+  XM_CSTAMP(6);
   if (n_pass == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the X-map band is needed by the flush
   }
@@ -505,9 +521,12 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     if (n_oob) atomicAdd(&s_oob, n_oob);
   }
   __syncthreads();
+  XM_CSTAMP(7);
 
   // ---- 5. flush: every live slot of the tile -> its frame cell, winners and empties alike (plain 2-byte stores; lanes walk
-  //         consecutive rows of one time column = consecutive rows of one frame column where the X-map is smooth)
+  //         consecutive rows of one time column = consecutive rows of one frame column where the X-map is smooth).
+  //         live: xp - x_offset >= xr_min (cols_cell); with xr_min >= 0 and rect_h >= xmap_h - 1 (the usual rig) neither the
+  //         negative wrap nor the row test can trigger: the lean variant.
   {
     constexpr int FL = 4;
     const int per = tb.xmap_h;
@@ -519,6 +538,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       if (r_i < 0) r_i += per;
       if (r_i >= per) r_i -= per;
     }
+    const bool lean = xr_min >= 0 && tb.rect_h >= tb.xmap_h - 1;  // uniform
     for (int i0 = tid; i0 < nslots; i0 += FL * nthreads) {
       u32 v[FL];
       int xv[FL], rs[FL];
@@ -531,14 +551,24 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
         r_i += dr;
         if (r_i >= per) r_i -= per;
       }
+      if (lean) {
 #pragma unroll
-      for (int j = 0; j < FL; ++j) {
-        u32 cell;
-        if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && cols_cell(tb, xv[j], rs[j], xr_min, cell))
-          frame16[cell] = (uint16_t)(v[j] & 0xffffu);
+        for (int j = 0; j < FL; ++j) {
+          const int fu = xv[j] - tb.x_offset;
+          if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && fu >= xr_min && fu < tb.rect_w)
+            frame16[(u32)fu * (u32)tb.rect_h + (u32)rs[j]] = (uint16_t)(v[j] & 0xffffu);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+          u32 cell;
+          if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && cols_cell(tb, xv[j], rs[j], xr_min, cell))
+            frame16[cell] = (uint16_t)(v[j] & 0xffffu);
+        }
       }
     }
   }
+  XM_CSTAMP(8);
   if (tid == 0) {
     XM_GLOBAL u32* c = st->cnt[parity][blk % CNT_SLOTS];
     if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -236,6 +236,16 @@ class XMapsEngine:
                                            offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1,
                                            _ptr(depth_ptr), _ptr(bgr_ptr)))
 
+    def profile_batch_device(self, x_ptr, y_ptr, t_ptr, p_ptr, offsets, depth_ptr=None, bgr_ptr=None,
+                             t_dtype=N.XM_T_INT64):
+        """The same group, synchronously, timed per launch: (K0 or K0b, K1, K2, first start .. last stop) in ms."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ms = (C.c_float * 4)()
+        N.check(self._lib.xm_profile_batch(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), t_dtype,
+                                           offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1,
+                                           _ptr(depth_ptr), _ptr(bgr_ptr), ms))
+        return tuple(float(v) for v in ms)
+
     # ---- hipGraph batch ----------------------------------------------------------------------------
     def graph_create(self, x_ptr, y_ptr, t_ptr, p_ptr, offsets, depth_ptr=None, bgr_ptr=None,
                      t_dtype=N.XM_T_INT64) -> "XMapsGraph":
