@@ -243,7 +243,7 @@ def test_switches(monkeypatch):
             monkeypatch.delenv("XM_COLS")
         else:
             monkeypatch.setenv("XM_COLS", mode)
-        with XMapsEngine(tb) as eng:
+        with XMapsEngine(tb, n_slots=2) as eng:
             d, b, st = _run(eng, evs)
             single = eng.path_counts()
             eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, out.data_ptr(), None)
