@@ -1580,7 +1580,8 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
   int4 rec = make_int4(0, 0, 0, 0);
   u32 off = ~0u;
   if (x1 >= x0) {
-    const int bx = x0 - 3, by = (y0 - 3) & ~3;  // rows start on a multiple of 4: 16-byte loads of 2 (u64) or 4 (u32) keys
+    // rows start on a multiple of 8: 16-byte loads of 2 (u64 keys), 4 (u32 keys) or 8 (u16 disparities) rows
+    const int bx = x0 - 3, by = (y0 - 3) & ~7;
     const int cols = x1 + 3 - bx + 1, rows = y1 + 3 - by + 1, rows_p = (rows + 7) & ~7;
     const bool fits = cols * rows_p <= K2_TILE_MAX;
     rec = make_int4(bx, by, fits ? cols : -1, rows_p);
@@ -1663,7 +1664,26 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       if constexpr (U16) {  // plain disparities: 8-byte loads of 4 rows copied straight into the LDS patch
         const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
         const bool interior = bx >= 0 && by >= 0 && bx + cols <= tb.rect_w && by + rows_p <= tb.rect_h && (tb.rect_h & 3) == 0;
-        if (interior) {
+        if (interior && (tb.rect_h & 7) == 0) {
+          // 16-byte loads of 8 rows (the patch starts on a multiple of 8 rows and rows_p is one), copied as they are: LDS quad
+          // index == patch (column, row octet) index.  A 50 x 56 patch is 350 quads: two loads per thread.
+          const int oct = rows_p >> 3, total = cols * oct;
+          const float inv_o = 1.0f / (float)oct;
+          for (int i0 = tid; i0 < total; i0 += 2 * NT) {
+            uint4 k[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int i = min(i0 + j * NT, total - 1);
+              int c = (int)((float)i * inv_o), ro = i - c * oct;
+              if (ro < 0) { c -= 1; ro += oct; }
+              if (ro >= oct) { c += 1; ro -= oct; }
+              k[j] = *reinterpret_cast<const uint4*>(d16 + (u32)(bx + c) * (u32)tb.rect_h + (u32)(by + 8 * ro));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (i0 + j * NT < total) reinterpret_cast<uint4*>(tile)[i0 + j * NT] = k[j];
+          }
+        } else if (interior) {
           const int quarter = rows_p >> 2, total = cols * quarter;
           const float inv_q = 1.0f / (float)quarter;
           for (int i0 = tid; i0 < total; i0 += 4 * NT) {

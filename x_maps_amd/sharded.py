@@ -59,8 +59,16 @@ class GpuShardProvider:
     def decode_u16(self, key_chunk, tag, out_chunk):
         self.eng.shard_decode_u16(key_chunk.data_ptr(), key_chunk.numel(), tag, out_chunk.data_ptr())
 
+    def _zeros(self, n, dtype):
+        """torch fills on ITS current stream; the engine's streams are non-blocking ones, so the fill is waited for here --
+        otherwise it can land after a kernel of the engine has already written the buffer (seen once: a shard's extrema
+        overwritten with zeros)."""
+        z = self.torch.zeros(n, dtype=dtype, device=self.device)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return z
+
     def new_u16(self, n):
-        return self.torch.zeros(n, dtype=self.torch.int16, device=self.device)
+        return self._zeros(n, self.torch.int16)
 
     def finish_u16(self, disp_frame, want_bgr=True):
         torch = self.torch
@@ -75,7 +83,7 @@ class GpuShardProvider:
     def new_minmax_buffer(self, shard):
         t = shard[2]
         dt = self.torch.int64 if t.dtype == self.torch.int64 else self.torch.float64
-        return self.torch.zeros(2, dtype=dt, device=self.device)
+        return self._zeros(2, dt)
 
     @staticmethod
     def _t_dtype(t):
