@@ -68,7 +68,7 @@ __device__ inline bool cols_cell(const DevTables& tb, int xp, int r, int xr_min,
   int fc = (int)(short)fu;
   if (fc < 0) fc += tb.rect_w;
   if (fc < 0 || fc >= tb.rect_w || r >= tb.rect_h) return false;
-  cell = (u32)fc * (u32)tb.rect_h + (u32)r;
+  cell = __umul24((u32)fc, (u32)tb.rect_h) + (u32)r;  // (24-bit multiplies are full rate, v_mul_lo_u32 is a quarter)
   return true;
 }
 
@@ -459,13 +459,13 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
         if (ex >= (u32)tb.cam_w || ey >= (u32)tb.cam_h) {
           oob = true;
         } else {
-          const u32 l = tb.lut[ex * (u32)tb.cam_h + ey];
+          const u32 l = tb.lut[__umul24(ex, (u32)tb.cam_h) + ey];
 #pragma unroll
           for (int kk = 0; kk < EPT; ++kk) xl[kk] = ks == kk ? (int)l : xl[kk];
           ovr |= 1u << ks;
         }
       }
-      n_oob += __popcll(__ballot(oob));
+      n_oob += __popcll(__builtin_amdgcn_ballot_w64(oob));
     }
     if (pass == 0) {
       XM_CSTAMP(3);
@@ -479,7 +479,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u32 yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
-      const u32* src = fast[k] ? lut_t + (xl[k] * tb.cam_h + (int)yk) : &s_sentinel;
+      const u32* src = fast[k] ? lut_t + (__mul24(xl[k], tb.cam_h) + (int)yk) : &s_sentinel;
       l[k] = *src;
     }
     const bool any_ovr = __ballot(ovr != 0) != 0;  // (wave-uniform: most waves have no x-noise event)
@@ -490,7 +490,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       if (any_ovr) l[k] = (ovr >> k) & 1u ? (u32)xl[k] : l[k];
       const int yr = (int)(short)(l[k] >> 16);
       yok[k] = (u32)yr < (u32)(tb.xmap_h - 1);  // 0 <= yr < H - 1 (xmd:23)
-      slot[k] = yok[k] ? tl[k] * tb.xmap_h + yr : 0;
+      slot[k] = yok[k] ? __mul24(tl[k], tb.xmap_h) + yr : 0;
       xp[k] = (int)xm_t[slot[k]];
     }
 #pragma unroll
@@ -500,9 +500,9 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       const int disp = fu - xr;                             // (xm_create has checked the range: xmd:27's wrap never triggers)
       bool write = yok[k] && disp >= 0;                     // xmd:29
       const bool in_frame = ((u32)fu < (u32)tb.rect_w || (u32)(fu + tb.rect_w) < (u32)tb.rect_w) && yr < tb.rect_h;
-      n_oob += __popcll(__ballot(write && !in_frame));  // NumPy IndexError (one negative wrap is legal)
+      n_oob += __popcll(__builtin_amdgcn_ballot_w64(write && !in_frame));  // NumPy IndexError (one negative wrap is legal)
       write = write && in_frame;
-      n_in += __popcll(__ballot(write));
+      n_in += __popcll(__builtin_amdgcn_ballot_w64(write));
       const int ek = e0 + (VEC ? k : k * nthreads);
       if (write) atomicMax(&slots[slot[k]], ((u32)(ek + 1) << 16) | (u32)disp);
     }
@@ -556,7 +556,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
         for (int j = 0; j < FL; ++j) {
           const int fu = xv[j] - tb.x_offset;
           if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && fu >= xr_min && fu < tb.rect_w)
-            frame16[(u32)fu * (u32)tb.rect_h + (u32)rs[j]] = (uint16_t)(v[j] & 0xffffu);
+            frame16[__umul24((u32)fu, (u32)tb.rect_h) + (u32)rs[j]] = (uint16_t)(v[j] & 0xffffu);
         }
       } else {
 #pragma unroll

@@ -1622,7 +1622,8 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   const bool in_img = u < tb.proj_w && v < tb.proj_h;
   // the tile's patch rectangle and the pixel's offset into it were computed once in xm_create (k_build_k2_tables)
   const int4 rec = tb.k2_tiles[lin_tile];  // block-uniform
-  const u32 poff = in_img ? tb.k2_pix[(u32)v * (u32)tb.proj_w + (u32)u] : ~0u;
+  const u32 pix_i = __umul24((u32)v, (u32)tb.proj_w) + (u32)u;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
+  const u32 poff = in_img ? tb.k2_pix[pix_i] : ~0u;
   int mx = 0, my = 0;
   bool valid_g = false;  // generic path only; the tiled path tests poff where it needs it (after the patch loads are out:
                          // testing it here put a full wait for this load in front of them)
@@ -1638,7 +1639,8 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   } else if (rec.z > 0) {
     x1 = 0;
   }
-  float d = 0.0f;
+  float d = 0.0f;  // generic path (a patch too large for LDS)
+  u32 di = 0;      // tiled path: the integer disparity itself (no int -> float -> int round trip: conversions are quarter rate)
   if (x1 >= x0) {  // at least one pixel of the tile maps into the frame
     const int bx = rec.x, by = rec.y;                    // patch origin (rows start on an even row: 16-byte aligned pairs)
     const int cols = rec.z, rows_p = rec.w;              // column stride in LDS: 16-byte aligned runs
@@ -1668,16 +1670,16 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
           // 16-byte loads of 8 rows (the patch starts on a multiple of 8 rows and rows_p is one), copied as they are: LDS quad
           // index == patch (column, row octet) index.  A 50 x 56 patch is 350 quads: two loads per thread.
           const int oct = rows_p >> 3, total = cols * oct;
-          const float inv_o = 1.0f / (float)oct;
+          const float inv_o = __builtin_amdgcn_rcpf((float)oct);  // (approximate: the +-1 fix-ups below absorb it)
           for (int i0 = tid; i0 < total; i0 += 2 * NT) {
             uint4 k[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int i = min(i0 + j * NT, total - 1);
-              int c = (int)((float)i * inv_o), ro = i - c * oct;
+              int c = (int)((float)i * inv_o), ro = i - __mul24(c, oct);
               if (ro < 0) { c -= 1; ro += oct; }
               if (ro >= oct) { c += 1; ro -= oct; }
-              k[j] = *reinterpret_cast<const uint4*>(d16 + (u32)(bx + c) * (u32)tb.rect_h + (u32)(by + 8 * ro));
+              k[j] = *reinterpret_cast<const uint4*>(d16 + __umul24((u32)(bx + c), (u32)tb.rect_h) + (u32)(by + 8 * ro));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -1685,16 +1687,16 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
           }
         } else if (interior) {
           const int quarter = rows_p >> 2, total = cols * quarter;
-          const float inv_q = 1.0f / (float)quarter;
+          const float inv_q = __builtin_amdgcn_rcpf((float)quarter);
           for (int i0 = tid; i0 < total; i0 += 4 * NT) {
             uint2 k[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int i = min(i0 + j * NT, total - 1);
-              int c = (int)((float)i * inv_q), rq = i - c * quarter;
+              int c = (int)((float)i * inv_q), rq = i - __mul24(c, quarter);
               if (rq < 0) { c -= 1; rq += quarter; }
               if (rq >= quarter) { c += 1; rq -= quarter; }
-              k[j] = *reinterpret_cast<const uint2*>(d16 + (u32)(bx + c) * (u32)tb.rect_h + (u32)(by + 4 * rq));
+              k[j] = *reinterpret_cast<const uint2*>(d16 + __umul24((u32)(bx + c), (u32)tb.rect_h) + (u32)(by + 4 * rq));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1891,7 +1893,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         u32 best = 0;
 #pragma unroll
         for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
-        d = (float)best;
+        di = best;
       }
     } else if (valid_g) {
       const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
@@ -1914,12 +1916,14 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   PixelOut o;
 #ifndef XM_K2_NO_DLUT
   {
-    const uint2 e = tb.dlut[(u32)d & 0xffffu];  // d is an integer disparity here (max of u16 key fields)
+    if (rec.z <= 0) di = (u32)d;  // d is an integer disparity here (max of u16 key fields)
+    // (byte offset off the table's base: a scalar-base + 32-bit-offset load instead of a 64-bit multiply-add per pixel)
+    const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tb.dlut) + ((di & 0xffffu) << 3));
     o.depth = __uint_as_float(e.x);
     o.bgr = e.y;
   }
 #else
-  o = disparity_pixel(d, tb.p03, tb.z_near, tb.z_far);
+  o = disparity_pixel(rec.z > 0 ? (float)di : d, tb.p03, tb.z_near, tb.z_far);
 #endif
   if (!tag_override && lin_tile == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
     u32* c = st->cnt[(tag & 1) ^ 1][tid];
@@ -1929,7 +1933,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
     }
   }
-  if (depth && in_img) depth[(u32)v * (u32)tb.proj_w + (u32)u] = o.depth;
+  if (depth && in_img) depth[pix_i] = o.depth;
   if (bgr) {
     const bool full_rows = (tb.proj_w & 3) == 0 && (tile_x + 1) * K2_TX <= tb.proj_w;
     if (full_rows) {  // 96 contiguous bytes per tile row: assemble in LDS, store as dwords
@@ -1941,7 +1945,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       if (tid < K2_TY * DW) {
         const int r = tid / DW, q = tid - r * DW, vv = tile_y * K2_TY + r;
         if (vv < tb.proj_h)
-          reinterpret_cast<u32*>(bgr + ((u64)vv * tb.proj_w + (u64)tile_x * K2_TX) * 3)[q] =
+          reinterpret_cast<u32*>(bgr + (size_t)((__umul24((u32)vv, (u32)tb.proj_w) + tile_x * K2_TX) * 3u))[q] =
               reinterpret_cast<const u32*>(&s_bgr[r][0])[q];
       }
     } else if (in_img) {
