@@ -367,7 +367,14 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       }
     }
   };
-  if (n_pass > 0) {
+  // A wave whose first event of a pass lies behind the range has nothing to do in that pass (at C-1M, 3125 events for 512 x 8
+  // slots: the tile's last wave always, the one before it mostly): it skips the loads and the per-event work -- an eighth of
+  // the kernel's instruction issue -- and only keeps the barriers, the band copies, the clear and the flush company.
+  const auto wave_on = [&](const int pass) {  // wave-uniform
+    const int w0 = VEC ? a0 + pass * cap + (tid & ~63) * EPT : lb_s + pass * cap + (tid & ~63);
+    return w0 < lb_e;
+  };
+  if (n_pass > 0 && wave_on(0)) {
     load_events(0);
     // the compiler waits with vmcnt(0) before the first use of a register loaded BEFORE an LDS-direct load: touch the event
     // registers here, so that the wait sits in front of the LUT band's loads and the band flies during the event arithmetic
@@ -405,13 +412,23 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 
   u32 n_in = 0, n_oob = 0;
   for (int pass = 0; pass < n_pass; ++pass) {
-    if (pass > 0) load_events(pass);
+    const bool on = wave_on(pass);
+    if (pass > 0 && on) load_events(pass);
     int e0;  // order of the thread's event 0 inside the tile (event index - a0); event k: + k (VEC) / + k * nthreads
     if constexpr (VEC) e0 = pass * cap + tid * EPT;
     else e0 = pass * cap + tid;
+    int tl[EPT], xl[EPT];
+    bool fast[EPT];
+    u32 ovr = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      tl[k] = 0;
+      xl[k] = 0;
+      fast[k] = false;
+    }
+    if (on) {
     // the event's column inside the tile and the verification, in integers: a = t - tmin against the columns' thresholds
     u32 av[EPT];
-    int tl[EPT];
     bool live[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -431,8 +448,6 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       for (int k = 0; k < EPT; ++k) tl[k] += av[k] >= A_j ? 1 : 0;
     }
     u32 smask = 0;
-    int xl[EPT];
-    bool fast[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u32 xk = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff, yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
@@ -442,7 +457,6 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     }
     // events outside the LUT window (x noise) fetch their LUT entry from global memory and join the slots; x / y outside the
     // camera = map[y, x] IndexError in the reference (calib:279-280): dropped and counted
-    u32 ovr = 0;
     while (__ballot(smask != 0)) {
       const bool act = smask != 0;
       const int ks = act ? __builtin_ctz(smask) : 0;
@@ -467,6 +481,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       }
       n_oob += __popcll(__builtin_amdgcn_ballot_w64(oob));
     }
+    }
     if (pass == 0) {
       XM_CSTAMP(3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct band loads are tracked by vmcnt
@@ -474,6 +489,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       __syncthreads();                                   // bands (and the cleared slots) visible
       XM_CSTAMP(5);
     }
+    if (on) {
     // branch-free: A1 + A2 out of the LDS bands; an event that is not live reads the sentinel (yr < 0) and drops out at xmd:23
     u32 l[EPT];
 #pragma unroll
@@ -506,6 +522,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       const int ek = e0 + (VEC ? k : k * nthreads);
       if (write) atomicMax(&slots[slot[k]], ((u32)(ek + 1) << 16) | (u32)disp);
     }
+    }
   }
   XM_CSTAMP(6);
   if (n_pass == 0) {
@@ -528,7 +545,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   //         live: xp - x_offset >= xr_min (cols_cell); with xr_min >= 0 and rect_h >= xmap_h - 1 (the usual rig) neither the
   //         negative wrap nor the row test can trigger: the lean variant.
   {
-    constexpr int FL = 4;
+    constexpr int FL = 3;  // (2640 slots at C-1M: two sweeps of 512 x 3)
     const int per = tb.xmap_h;
     const int dq = nthreads / per, dr = nthreads - dq * per;
     int r_i;
