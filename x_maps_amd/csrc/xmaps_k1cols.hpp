@@ -417,6 +417,8 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     int e0;  // order of the thread's event 0 inside the tile (event index - a0); event k: + k (VEC) / + k * nthreads
     if constexpr (VEC) e0 = pass * cap + tid * EPT;
     else e0 = pass * cap + tid;
+    const u32 used_n = (u32)(lb_e - lb_s), A_span = A_hi - A_lo;  // (thresholds are non-decreasing in the column)
+    const int u0 = VEC ? a0 + e0 - lb_s : e0;                      // (index of the thread's event 0) - lb_s
     int tl[EPT], xl[EPT];
     bool fast[EPT];
     u32 ovr = 0;
@@ -434,10 +436,9 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     for (int k = 0; k < EPT; ++k) {
       const u64 a64 = (u64)(tt[k] - t_first);
       av[k] = (u32)a64;
-      bool used;
-      if constexpr (VEC) used = a0 + e0 + k >= lb_s && a0 + e0 + k < lb_e;
-      else used = lb_s + e0 + k * nthreads < lb_e;
-      const bool in_tile = (u32)(a64 >> 32) == 0u && av[k] >= A_lo && av[k] < A_hi;
+      // one unsigned compare each: (event index - lb_s) < count, (a - thr[c0]) < (thr[c1] - thr[c0]) (+ the high word)
+      const bool used = (u32)(u0 + (VEC ? k : k * nthreads)) < used_n;
+      const bool in_tile = (u32)(a64 >> 32) == 0u && av[k] - A_lo < A_span;
       bad = bad || (used && !in_tile);
       live[k] = used && in_tile;
       tl[k] = 0;
