@@ -463,7 +463,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             if not args.no_launch_workers:
                 modes.append(("launches_from_the_calling_thread", dict(mode_kw), camera, 0, False))
         if not args.general:
-            modes.append(("forced_general", {"force_general": True}, camera, B, (not args.no_launch_workers) and not B))
+            # (one frame per call, as rounds 1 and 2 reported it)
+            modes.append(("forced_general", {"force_general": True}, camera, 0, not args.no_launch_workers))
         if not camera:
             modes.append(("camera_view", dict(mode_kw), True, B, (not args.no_launch_workers) and not B))
         for name, kw, cam, Bm, workers in modes:
@@ -496,8 +497,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             e2.close()
         other_modes["note"] = ("one_frame_per_call = every frame through its own asynchronous call (xm_process_frame, 4 frames in "
                                "flight, a launch thread per slot stream): round 2's headline mode; forced_general = "
-                               "XM_FLAG_GENERAL (extrema pass K0 + 64-bit packed keys on every frame: round 1's headline "
-                               "mode); camera_view = --camera-perspective; `value` above = library defaults, groups of "
+                               "XM_FLAG_GENERAL (extrema pass K0 + 64-bit packed keys on every frame, one frame per call: round 1's "
+                               "headline mode); camera_view = --camera-perspective; `value` above = library defaults, groups of "
                                f"{B} frames per call" if B else
                                "groups_of_16_frames_per_call = xm_process_batch; launches_from_the_calling_thread = no launch "
                                "workers; forced_general = XM_FLAG_GENERAL; camera_view = --camera-perspective")
