@@ -679,6 +679,7 @@ def bench_graph(args, torch, dist, dev, rank, local_rank, world):
     offs = np.arange(F + 1, dtype=np.uint64) * n_ev
     graph = eng.graph_create(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, depth.data_ptr(),
                              None if bgr is None else bgr.data_ptr())
+    paths = eng.path_counts()  # which K1 the frames were captured with
     one = eng.graph_create(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs[:2], depth.data_ptr(),
                            None if bgr is None else bgr.data_ptr())
     parity = None
@@ -738,9 +739,14 @@ def bench_graph(args, torch, dist, dev, rank, local_rank, world):
         "config": {"workload": "C-60x1M: 60 frames x 1M events (seeds 20230..20289), 640x480 cam/proj, one captured hipGraph, "
                                "1xMI355X" + (" (camera view)" if camera else " (projector view)"),
                    "events_per_frame": n_ev, "frames_per_graph": F, "key_frames": slots,
-                   "graph_nodes": "3 multi-frame kernel nodes (K0, K1, K2: grid = 60 frames x tiles)" if slots >= F else
-                                  f"groups of {slots // 2} frames, 3 kernel nodes each, alternating between two graph branches",
-                   "extrema": "XM_FLAG_TIME_SORTED (no K0)" if args.assume_sorted else "extrema pass K0 (no host redo inside a graph)",
+                   "graph_nodes": ("7 multi-frame kernel nodes, grid = 60 frames x tiles: K0b, K1 column tiles, K2 on the u16 frame (frames "
+                                   "whose tiles held) + counters reset, K0, K1, K2 on the 64-bit key frame (frames whose tiles objected; "
+                                   "every other block returns at once)" if paths["cols"] else
+                                   "3 multi-frame kernel nodes (K0, K1, K2: grid = 60 frames x tiles)") if slots >= F else
+                                  f"groups of {slots // 2} frames, alternating between two graph branches",
+                   "k1_paths_frames_captured": paths,
+                   "extrema": "XM_FLAG_TIME_SORTED (no K0)" if args.assume_sorted else
+                              "column tiles with the redo decided on the device (no host at hand inside a graph); XM_COLS=0: extrema pass K0 + 64-bit keys",
                    "steps_note": f"a step = one frame; --steps rounded up to {replays} replay(s) of the 60-frame graph",
                    "launch": "hipGraph"},
         "latency_us": {"batch_of_60_frames": {"p50": round(float(np.percentile(lat, 50)), 1), "p99": round(float(np.percentile(lat, 99)), 1),

@@ -288,3 +288,58 @@ def test_c10m_tiles_of_one_column_and_several_passes():
         d, b, st = eng.process_frame(x, y, t)
         assert eng.path_counts()["cols"] == 1 and eng.sorted_fallbacks() == 0
     assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+
+
+@pytest.mark.parametrize("n_slots", [3, 4, 8])
+def test_hipgraph_batches_redo_failed_frames_on_the_device(n_slots):
+    """Inside a captured batch no host is at hand to redo a frame: the graph carries the column tiles AND the 64-bit path, and
+    the kernels decide per frame on the device (frame_attempt_failed).  Frames whose tiles object -- blocks of the stream
+    swapped, a burst in one time column -- come out exact next to frames that take the tiles, replay after replay."""
+    torch = pytest.importorskip("torch")
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    n = 600_000
+    frames = [S.make_events(cfg, frame=50 + i, n=n) for i in range(6)]
+    a, b = frames[1][100_000:110_000].copy(), frames[1][400_000:410_000].copy()
+    frames[1][100_000:110_000], frames[1][400_000:410_000] = b, a  # not sorted
+    frames[4]["t"][200_000:300_000] = frames[4]["t"][200_000]       # 100 k events in one time column
+    F = len(frames)
+    dev = torch.device("cuda", 0)
+    X = torch.empty(F * n, dtype=torch.int16, device=dev)
+    Y = torch.empty_like(X)
+    T = torch.empty(F * n, dtype=torch.int64, device=dev)
+    refs = []
+    for i, e in enumerate(frames):
+        x, y, t, _ = S.to_soa(e)
+        X[i * n:(i + 1) * n] = torch.from_numpy(x.view(np.int16))
+        Y[i * n:(i + 1) * n] = torch.from_numpy(y.view(np.int16))
+        T[i * n:(i + 1) * n] = torch.from_numpy(t)
+        refs.append(_ref(tb, e))
+    depth = torch.zeros((F, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((F, cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    offs = np.arange(F + 1, dtype=np.uint64) * n
+    with XMapsEngine(tb, n_slots=n_slots, default_priority_streams=True) as eng:
+        g = eng.graph_create(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, depth.data_ptr(), bgr.data_ptr())
+        # groups of >= 2 frames are captured with the tiles in front; 3 slots = groups of one frame: K0 -> K1 -> K2 (64-bit keys)
+        assert eng.path_counts()["cols"] == (F if n_slots >= 4 else 0)
+        for rep in range(3):
+            g.launch()
+            eng.sync()
+            d, bb = depth.cpu().numpy(), bgr.cpu().numpy()
+            for f in range(F):
+                assert np.array_equal(d[f], refs[f]["depth"]), (rep, f)
+                assert np.array_equal(bb[f], refs[f]["bgr"]), (rep, f)
+            depth.zero_()
+            bgr.zero_()
+            torch.cuda.synchronize()
+        g.close()
+        # eager groups and single frames on the same handle afterwards (host-side redo again)
+        eng.process_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs[:3], depth.data_ptr(), None)
+        eng.sync()
+        for f in range(2):
+            assert np.array_equal(depth[f].cpu().numpy(), refs[f]["depth"]), f
+        assert eng.sorted_fallbacks() == 1
+        x, y, t, _ = S.to_soa(frames[5])
+        d5, _, st5 = eng.process_frame(x, y, t)
+        assert np.array_equal(d5, refs[5]["depth"]) and st5.n_inliers == int(refs[5]["mask"].sum())

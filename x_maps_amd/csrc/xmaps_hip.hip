@@ -641,7 +641,8 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 // they ramp up and drain (245 K1 blocks for 256 CUs, each a ~10 us dependent chain); a group's launch keeps every CU fed.
 template <typename T, bool AOS, bool HAS_P>
 int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
-                   hipStream_t stream, bool key32 = false, int cols_w = 0, hipEvent_t* prof = nullptr) {
+                   hipStream_t stream, bool key32 = false, int cols_w = 0, hipEvent_t* prof = nullptr,
+                   const FrameDesc* d_descs_redo = nullptr) {
   // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the dispatch packets of K0 / K0b, K1, K2
   struct ProfReset {
     ~ProfReset() { g_prof = ProfCtx{}; }
@@ -661,10 +662,51 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
                 dim3(64 * COLS_BOUNDS_WAVES), 0, stream, d_descs, h->tb, cols_w);
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
-                cols_w, h->w_x, h->cols_xr_min);
+                cols_w, h->w_x, h->cols_xr_min, d_descs_redo ? 1 : 0);
       prof_slot(2);
-      XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+      if (!d_descs_redo) {
+        XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+                  dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                  (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+        HIP_TRY(hipGetLastError());
+        return XM_OK;
+      }
+      // Captured batch (hipGraph): no host at hand to redo a frame whose tiles objected, so the graph carries both paths and the
+      // kernels decide per frame on the device (frame_attempt_failed): K2 on the u16 frame only where the attempt held, then --
+      // for the frames where it did not, and for those only: every other block returns at once -- the counters cleared and
+      // K0 -> K1 -> K2 on the 64-bit key frame (d_descs_redo = the same frames with key_frame = the slots' 64-bit frames).
+      XM_LAUNCH((k_frame_proj_tiled_batch<2, 2>), dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
                 dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      g_prof = ProfCtx{};
+      XM_LAUNCH(k_redo_prepare_batch, dim3(n_frames), dim3(64), 0, stream, d_descs_redo);
+      {
+        const bool vec2 = !AOS && vec16;
+        const unsigned per_block = BLOCK * (vec2 ? 2 * K0_UN : 4);
+        unsigned gx = grid_for(n_max, per_block);
+        if (gx > 1024) gx = 1024;
+        if constexpr (!AOS) {
+          if (vec2) XM_LAUNCH((k_minmax_batch<T, false, false, 2, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs_redo);
+          else XM_LAUNCH((k_minmax_batch<T, false, false, 1, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs_redo);
+        } else {
+          XM_LAUNCH((k_minmax_batch<T, true, false, 1, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs_redo);
+        }
+      }
+      {
+        const double max_ev = (h->w_ts - 1.5) * (double)n_mean / (double)h->tb.xmap_w;
+        unsigned threads = TILE_THREADS;
+        while (threads > 1024 / TILE_EPT && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;
+        auto k1 = k_scatter_tiled_batch<T, AOS, false, 0, false, false, 1>;
+        if constexpr (!AOS) {
+          if (vec16) k1 = k_scatter_tiled_batch<T, false, false, 0, true, false, 1>;
+        }
+        rc = h->ensure_lds(reinterpret_cast<const void*>(k1), h->k1_lds);
+        if (rc) return rc;
+        XM_LAUNCH(k1, dim3(grid_for(n_max, threads * TILE_EPT), n_frames), dim3(threads), h->k1_lds, stream, d_descs_redo, h->tb,
+                  h->w_ts, h->w_x, 0);
+      }
+      XM_LAUNCH((k_frame_proj_tiled_batch<0, 1>), dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs_redo, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
       HIP_TRY(hipGetLastError());
       return XM_OK;
@@ -744,7 +786,8 @@ bool batch_path(const xm_handle* h, u64 n_mean) {
 // (eager) -- false when the caller uploads once (graph capture).
 int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, float* const* depth, uint8_t* const* bgr,
                   int n_frames, hipStream_t stream, FrameDesc* h_descs, FrameDesc* d_descs, bool upload, bool allow_sorted,
-                  hipEvent_t* prof = nullptr, int* kinds = nullptr) {
+                  hipEvent_t* prof = nullptr, int* kinds = nullptr, FrameDesc* h_descs_redo = nullptr,
+                  FrameDesc* d_descs_redo = nullptr) {
   u64 n_max = 0, n_sum = 0;
   bool vec16 = true;
   for (int f = 0; f < n_frames; ++f) {
@@ -782,6 +825,17 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   int cols_w = sorted ? cols_width(h, n_mean) : 0;  // one tile width for the group (from its mean frame)
   for (int f = 0; f < n_frames && cols_w; ++f)
     if (!cols_path(h, evs[f], sorted) || (evs[f].aos != nullptr) != (e0.aos != nullptr)) cols_w = 0;
+  // a batch that is being captured into a hipGraph: the column tiles with the redo decided on the device (launch_batch_t)
+  // (groups of >= 2 frames: a lone frame's seven launches -- four of them returning at once -- take longer than K0 -> K1 -> K2)
+  const bool dev_redo = h->capturing && !cols_w && d_descs_redo && h->cols_ok && !h->k2_direct && !h->k2_flags && n_frames >= 2;
+  if (dev_redo) {
+    cols_w = cols_width(h, n_mean);
+    for (int f = 0; f < n_frames && cols_w; ++f)
+      if (evs[f].n == 0 || evs[f].use_p || (!evs[f].aos && evs[f].t_dtype != XM_T_INT64) || !cols_width(h, evs[f].n) ||
+          (evs[f].aos != nullptr) != (e0.aos != nullptr))
+        cols_w = 0;
+  }
+  const bool redo_descs = dev_redo && cols_w;
   bool use32 = sorted && !cols_w;
   for (int f = 0; f < n_frames && use32; ++f) use32 = key32_path(h, evs[f], sorted);
   {
@@ -805,14 +859,18 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     d.n = ev.n; d.key_frame = cols_w ? reinterpret_cast<u64*>(s.frame16) : use32 ? reinterpret_cast<u64*>(s.key32) : s.key_frame;
     d.st = s.st; d.depth = depth[f];
     d.bgr = bgr[f]; d.valid = 1; d.pad = 0;
+    if (redo_descs) {  // the same frame on the slot's 64-bit key frame
+      h_descs_redo[f] = d;
+      h_descs_redo[f].key_frame = s.key_frame;
+    }
   }
   if (upload) HIP_TRY(hipMemcpyAsync(d_descs, h_descs, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, stream));
   int rc;
   if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32)
-                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w, prof);
+                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w, prof, redo_descs ? d_descs_redo : nullptr);
   else switch (e0.t_dtype) {
     case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
-                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w, prof); break;
+                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w, prof, redo_descs ? d_descs_redo : nullptr); break;
     case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
                                      : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
     default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
@@ -820,7 +878,7 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   }
   if (rc) return rc;
   if (kinds) {  // which launches the group consisted of: {K0 general / K0b bounds / none, K1 variant}
-    kinds[0] = cols_w ? 2 : sorted ? 0 : 1;
+    kinds[0] = cols_w ? 2 : sorted ? 0 : 1;  // (K0 runs whenever the frames are not on a sorted path)
     kinds[1] = cols_w ? KM_COLS : use32 ? KM_KEY32 : KM_KEY64;
   }
   for (int f = 0; f < n_frames; ++f) {
@@ -829,7 +887,7 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     s.api_tag = s.host_tag;
     s.any_frame = true;
     s.last_n = evs[f].n;
-    s.last_sorted = sorted;
+    s.last_sorted = sorted || cols_w != 0;
     s.last_key32 = use32 || cols_w;
     s.last_cols = cols_w != 0;
     h->path_counts[cols_w ? 3 : use32 ? 2 : sorted ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
@@ -1813,8 +1871,9 @@ static int graph_capture_batched(xm_handle* h, xm_graph* g, const uint16_t* x, c
   const size_t tsz = t_size(t_dtype);
   const bool two = ns >= 2 && n_frames > ns;
   const int G = two ? ns / 2 : std::min(ns, n_frames);
-  g->h_descs.resize(n_frames);
-  HIP_TRY(hipMalloc((void**)&g->d_descs, sizeof(FrameDesc) * n_frames));
+  g->h_descs.resize(2 * (size_t)n_frames);  // [n_frames] the frames, [n_frames] the same frames on their slots' 64-bit key frames
+  for (auto& d : g->h_descs) d = FrameDesc{};  // (valid = 0: unused entries are skipped by every kernel)
+  HIP_TRY(hipMalloc((void**)&g->d_descs, sizeof(FrameDesc) * 2 * n_frames));
   hipStream_t origin = h->gstreams[0], second = two ? h->gstreams[1] : nullptr;
   int rc = XM_OK;
   hipError_t e = hipSuccess;
@@ -1852,7 +1911,8 @@ static int graph_capture_batched(xm_handle* h, xm_graph* g, const uint16_t* x, c
       }
       if (rc) break;
       rc = enqueue_batch(h, idx.data(), evs.data(), dep.data(), bg.data(), nf, half ? second : origin,
-                         g->h_descs.data() + f0, g->d_descs + f0, false, true);
+                         g->h_descs.data() + f0, g->d_descs + f0, false, true, nullptr, nullptr,
+                         g->h_descs.data() + n_frames + f0, g->d_descs + n_frames + f0);
     }
     if (two && rc == XM_OK) {
       if ((e = hipEventRecord(h->join_ev[1], second)) != hipSuccess) break;
@@ -1864,7 +1924,7 @@ static int graph_capture_batched(xm_handle* h, xm_graph* g, const uint16_t* x, c
   if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
     rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   if (rc == XM_OK)  // the descriptors are static: one upload for the graph's lifetime
-    HIP_TRY(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->d_descs, g->h_descs.data(), sizeof(FrameDesc) * 2 * n_frames, hipMemcpyHostToDevice));
   return rc;
 }
 

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * COLS_BOUNDS_WAVES) void k_cols_bounds_batch(co
 template <bool AOS, bool VEC>
 __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 ts, gp_u4 aos, const u32 n_ev, const DevTables& tb,
                                                   gp_state st, XM_GLOBAL uint16_t* frame16, const int W, const int w_x,
-                                                  const int xr_min, const u32 blk, const u32 nblk) {
+                                                  const int xr_min, const u32 blk, const u32 nblk, const bool device_redo = false) {
   typedef long long T;
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
   constexpr int EPT = COLS_EPT;
@@ -530,9 +530,13 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the X-map band is needed by the flush
   }
   if (__ballot(bad) && lane == 0) {
-    __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (u32* hf = st->host_flags) host_flag_store(hf, tag);
+    if (device_redo) {  // inside a hipGraph: the redo kernels behind this one in the graph look at this word (frame_attempt_failed)
+      st->pad[1] = tag;
+    } else {
+      __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u32* hf = st->host_flags) host_flag_store(hf, tag);
+    }
   }
   if (lane == 0) {
     if (n_in) atomicAdd(&s_in, n_in);
@@ -616,11 +620,11 @@ __global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scat
 template <bool AOS, bool VEC>
 __global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scatter_cols_batch(const FrameDesc* __restrict__ descs,
                                                                                                 DevTables tb, int W, int w_x,
-                                                                                                int xr_min) {
+                                                                                                int xr_min, int device_redo) {
   const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
   if (!d.valid || d.n == 0) return;       // (the host sends frames without events down the general path)
   scatter_cols_body<AOS, VEC>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
-                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x);
+                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x, device_redo != 0);
 }
 
 }  // namespace xm

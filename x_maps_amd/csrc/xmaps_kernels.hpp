@@ -95,6 +95,17 @@ struct FrameDesc {
 };
 static_assert(sizeof(FrameDesc) == 88, "FrameDesc layout");
 
+// Conditional frames of a captured batch (hipGraph): no host is at hand there to redo a frame whose column-tile attempt
+// failed (xmaps_k1cols.hpp), so the graph carries BOTH paths and the kernels decide per frame on the device.  A failing
+// tile leaves the frame's tag in SlotState.pad[1]; COND = 1 kernels run a frame only if its attempt failed, COND = 2 only
+// if it held, COND = 0 always.  (tag_a holds the frame's tag from the attempt's K1 on, and K0 of the redo recomputes the
+// very same value from tag_b, which only a K2 advances.)
+__device__ inline bool frame_attempt_failed(const SlotState* st) { return st->pad[1] == st->tag_a; }
+template <int COND> __device__ inline bool frame_skipped(const SlotState* st) {
+  if constexpr (COND == 0) return false;
+  else return frame_attempt_failed(st) != (COND == 1);
+}
+
 // device -> pinned host memory, visible to the host when the kernel has finished
 __device__ inline void host_flag_store(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -450,10 +461,10 @@ __global__ __launch_bounds__(BLOCK) void k_minmax(const T* __restrict__ t, const
 }
 
 // multi-frame launch: grid = (blocks per frame, frames); frame f = descs[f]
-template <typename T, bool AOS, bool HAS_P, int VEC>
+template <typename T, bool AOS, bool HAS_P, int VEC, int COND = 0>
 __global__ __launch_bounds__(BLOCK) void k_minmax_batch(const FrameDesc* __restrict__ descs) {
   const FrameDesc d = descs[blockIdx.y];
-  if (!d.valid) return;
+  if (!d.valid || frame_skipped<COND>(d.st)) return;
   minmax_body<T, AOS, HAS_P, VEC>((const T*)d.t, d.p, d.aos, d.n, d.st, 0u, blockIdx.x, gridDim.x);
 }
 
@@ -1378,11 +1389,11 @@ __device__ inline void scatter_empty_frame(SlotState* st, int sorted_mode) {
 // (60 frames: 14 700 blocks instead of 245): no per-frame launch ramp, the CUs always have a next block to pick up.  Every
 // frame owns a key frame + state (FrameDesc), so blocks of different frames never meet.  The frame's size comes from
 // device memory: the same launch serves frames cut out of a device-resident stream (ingest) whose length the host never saw.
-template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC, bool KEY32 = false>
+template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC, bool KEY32 = false, int COND = 0>
 __global__ XM_K1_BOUNDS void k_scatter_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb, int w_ts, int w_x,
                                                    int sorted_mode) {
   const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
-  if (!d.valid) return;
+  if (!d.valid || frame_skipped<COND>(d.st)) return;
   const u32 evb = blockDim.x * TILE_EPT;
   const u32 nblk = (u32)((d.n + evb - 1) / evb);
   if (blockIdx.x >= nblk) {
@@ -1975,12 +1986,12 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
 }
 
 // multi-frame launch: grid = (tiles_x, tiles_y, frames)
-template <int FMT = 0>
+template <int FMT = 0, int COND = 0>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb,
                                                                         const ulonglong2* __restrict__ zero16,
                                                                         int tile_cap) {
   const FrameDesc d = descs[blockIdx.z];
-  if (!d.valid) return;
+  if (!d.valid || frame_skipped<COND>(d.st)) return;
   frame_proj_tiled_body<FMT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
                                blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
 }
@@ -2499,6 +2510,15 @@ __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __rest
     }
     for (int i = threadIdx.x; i < 2 * CNT_SLOTS * CNT_STRIDE; i += BLOCK) (&st->cnt[0][0][0])[i] = 0;
   }
+}
+
+// A frame of a captured batch whose column-tile attempt failed: forget what the attempt counted (same tag, same parity) before
+// K0 / K1 / K2 of the 64-bit path run on it.  grid = frames.
+__global__ __launch_bounds__(64) void k_redo_prepare_batch(const FrameDesc* __restrict__ descs) {
+  const FrameDesc d = descs[blockIdx.x];
+  if (!d.valid || !frame_attempt_failed(d.st)) return;
+  const u32 parity = d.st->tag_a & 1;
+  for (int i = threadIdx.x; i < CNT_SLOTS * CNT_STRIDE; i += 64) (&d.st->cnt[parity][0][0])[i] = 0;
 }
 
 }  // namespace xm
