@@ -343,3 +343,31 @@ def test_hipgraph_batches_redo_failed_frames_on_the_device(n_slots):
         x, y, t, _ = S.to_soa(frames[5])
         d5, _, st5 = eng.process_frame(x, y, t)
         assert np.array_equal(d5, refs[5]["depth"]) and st5.n_inliers == int(refs[5]["mask"].sum())
+
+
+def test_live_cells_outside_the_frame_are_index_errors():
+    """An X-map whose entries in a band of rows point past the right edge of the rectified frame: xm_create sees live pairs
+    without a cell, the kernel keeps its per-event cell test (the other rigs of this file skip it), and an event that lands
+    there is dropped and counted -- NumPy's IndexError in `frame[rows, cols] = values` (cam_proj_calibration.py:299-303)."""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    xm = tb["proj_x_map"].copy()
+    band = slice(300, 320)
+    xm[band, 1:] = np.int16(S.X_OFFSET + cfg.rect_w + 7)  # frame column rect_w + 7: outside (and not a legal negative wrap)
+    tb["proj_x_map"] = xm
+    evs = S.make_events(cfg, frame=12, n=600_000)
+    x, y, t, _ = S.to_soa(evs)
+    xr, yr = O.rectify_cam_coords_i16(tb["cam_mapx_i16"], tb["cam_mapy_i16"], x.astype(np.int64), y.astype(np.int64))
+    offending = (yr >= band.start) & (yr < band.stop)  # every such event has disp = rect_w + 7 - xr >= 0: an inlier without a cell
+    offending[0] = offending[-1] = False                # (keep t[0], t[n-1])
+    keep = ~offending
+    ts = O.time_to_xmap_column(t, tb["t_px_scale"])
+    n_err = int((offending & (ts >= 1)).sum())          # column 0 of the X-map is undefined (0): disp < 0 there, no write
+    with XMapsEngine(tb) as eng:
+        d, b, st = eng.process_frame(x, y, t, raise_on_index_error=False)
+        assert eng.path_counts()["cols"] == 1 and eng.sorted_fallbacks() == 0
+    kept = evs[keep]
+    # the kept stream has the same first / last stamp, hence the same columns; the offending events are simply absent
+    ref = _ref(tb, kept)
+    assert st.n_index_errors == n_err and n_err > 1000
+    assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])

@@ -191,6 +191,7 @@ struct xm_handle {
   bool cols_single = false;  // XM_COLS=2: also for single-frame calls (default: groups of frames only -- a single frame's third
                              // launch, the boundary pass, costs the pipelined one-frame-per-call path more than the tiles save)
   int cols_xr_min = 0, cols_w_max = 0, cols_target = 3700;
+  int cols_flags = 0;  // COLS_F_ALL_IN_FRAME when no live (row, column) pair of the rig maps outside the frame
   std::atomic<uint64_t> path_counts[4] = {};  // frames enqueued per K1 variant (xm_path_counts)
   // (atomics: with XM_FLAG_LAUNCH_WORKERS the launch threads and the API thread all pass through enqueue_frame)
   std::atomic<int> key32_score{0};  // raised by frames that failed the compact path, decays with every frame that took it
@@ -480,7 +481,7 @@ int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint1
   int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
   if (rc) return rc;
   XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, W)), dim3(cols_threads(h, ev.n, W)), lds, stream, ev.x, ev.y, (const long long*)ev.t,
-            (const uint4*)ev.aos, (u32)ev.n, h->tb, st, frame16, W, h->w_x, h->cols_xr_min);
+            (const uint4*)ev.aos, (u32)ev.n, h->tb, st, frame16, W, h->w_x, h->cols_xr_min, h->cols_flags);
   return XM_OK;
 }
 
@@ -662,7 +663,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
                 dim3(64 * COLS_BOUNDS_WAVES), 0, stream, d_descs, h->tb, cols_w);
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
-                cols_w, h->w_x, h->cols_xr_min, d_descs_redo ? 1 : 0);
+                cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
       prof_slot(2);
       if (!d_descs_redo) {
         XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
@@ -1384,16 +1385,18 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     bool injective = false;
     if (cfg->view == XM_VIEW_PROJECTOR && no_wrap && cfg->rect_width <= 65536) {
       u32* d_dup = nullptr;
-      XM_TRY_CREATE(hipMalloc((void**)&d_dup, sizeof(u32)));
-      XM_TRY_CREATE(hipMemset(d_dup, 0, sizeof(u32)));
+      XM_TRY_CREATE(hipMalloc((void**)&d_dup, 2 * sizeof(u32)));
+      XM_TRY_CREATE(hipMemset(d_dup, 0, 2 * sizeof(u32)));
       const int rows = std::min(xmap_h - 1, cfg->rect_height);
       if (rows > 0) hipLaunchKernelGGL(k_cols_check, dim3(rows), dim3(BLOCK), 0, 0, h->tb, xr_min, d_dup);
-      u32 dup = 1;
-      const hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(&dup, d_dup, sizeof dup, hipMemcpyDeviceToHost);
+      u32 dup[2] = {1, 1};
+      const hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(dup, d_dup, sizeof dup, hipMemcpyDeviceToHost);
       (void)hipFree(d_dup);
       XM_TRY_CREATE(e1);
       XM_TRY_CREATE(e2);
-      injective = dup == 0;  // every frame cell has at most one (row, time column) that can write it
+      injective = dup[0] == 0;  // every frame cell has at most one (row, time column) that can write it
+      // every live pair has its cell inside the frame and every row an event can land in was looked at: no per-event cell test
+      if (dup[1] == 0 && cfg->rect_height >= xmap_h - 1) h->cols_flags |= COLS_F_ALL_IN_FRAME;
     }
     h->cols_ok = injective && h->d_pmap && !(ec && ec[0] == '0');
     h->cols_single = ec && ec[0] == '2';

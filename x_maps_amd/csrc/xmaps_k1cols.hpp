@@ -56,6 +56,7 @@ typedef XM_GLOBAL SlotState* gp_state;
 #endif
 
 constexpr int COLS_EPT = 8;          // events per thread and pass
+enum { COLS_F_DEVICE_REDO = 1, COLS_F_ALL_IN_FRAME = 2 };
 constexpr u32 COLS_MAX_TILE_EVENTS = 65535u - 8u;  // the slot value carries (local index + 1) in 16 bits
 
 // ---- xm_create: is cell(row, column) injective over the live pairs?  One block per rectified row. -----------------------
@@ -72,20 +73,26 @@ __device__ inline bool cols_cell(const DevTables& tb, int xp, int r, int xr_min,
   return true;
 }
 
+// n_dup[0]: live pairs that share a cell with another one; n_dup[1]: live pairs whose cell lies outside the frame (an event there
+// is an IndexError in the reference: when there are none, K1 need not test the cell of every event)
 __global__ __launch_bounds__(BLOCK) void k_cols_check(DevTables tb, int xr_min, u32* __restrict__ n_dup) {
   __shared__ u32 bits[2048];  // rect_w <= 65536 columns
   const int r = blockIdx.x;   // rows 0 .. min(xmap_h - 1, rect_h) - 1 (the last X-map row never holds a winner: xmd:23)
   for (int i = threadIdx.x; i < 2048; i += BLOCK) bits[i] = 0;
   __syncthreads();
-  u32 dup = 0;
+  u32 dup = 0, outside = 0;
   for (int c = threadIdx.x; c < tb.xmap_w; c += BLOCK) {
     const int xp = (int)tb.xmap[(u32)c * (u32)tb.xmap_h + (u32)r];
     u32 cell;
-    if (!cols_cell(tb, xp, r, xr_min, cell)) continue;
+    if (!cols_cell(tb, xp, r, xr_min, cell)) {
+      outside += xp - tb.x_offset >= xr_min ? 1u : 0u;  // live, but no cell
+      continue;
+    }
     const u32 fc = cell / (u32)tb.rect_h, bit = 1u << (fc & 31);
     if (atomicOr(&bits[fc >> 5], bit) & bit) dup += 1;
   }
   if (dup) atomicAdd(n_dup, dup);
+  if (outside) atomicAdd(n_dup + 1, outside);
 }
 
 // ---- the event-range search (one wave per boundary) -----------------------------------------------------------
@@ -254,7 +261,11 @@ __global__ __launch_bounds__(64 * COLS_BOUNDS_WAVES) void k_cols_bounds_batch(co
 template <bool AOS, bool VEC>
 __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 ts, gp_u4 aos, const u32 n_ev, const DevTables& tb,
                                                   gp_state st, XM_GLOBAL uint16_t* frame16, const int W, const int w_x,
-                                                  const int xr_min, const u32 blk, const u32 nblk, const bool device_redo = false) {
+                                                  const int xr_min, const u32 blk, const u32 nblk, const int flags = 0) {
+  // flags: COLS_F_DEVICE_REDO = inside a hipGraph (a failing tile leaves the frame's tag in SlotState.pad[1] for the redo kernels
+  // behind this one instead of telling the host); COLS_F_ALL_IN_FRAME = every live (row, column) pair of this rig has its cell
+  // inside the frame (xm_create), so an event that passes xmd:29 cannot be an IndexError: no per-event cell test
+  const bool device_redo = flags & COLS_F_DEVICE_REDO, all_in = flags & COLS_F_ALL_IN_FRAME;
   typedef long long T;
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
   constexpr int EPT = COLS_EPT;
@@ -410,7 +421,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     }
   }
 
-  u32 n_in = 0, n_oob = 0;
+  u32 n_in = 0, n_oob = 0;  // per-lane counters (summed over the wave at the end: no ballot + popcount per event)
   for (int pass = 0; pass < n_pass; ++pass) {
     const bool on = wave_on(pass);
     if (pass > 0 && on) load_events(pass);
@@ -421,7 +432,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     const int u0 = VEC ? a0 + e0 - lb_s : e0;                      // (index of the thread's event 0) - lb_s
     int tl[EPT], xl[EPT];
     bool fast[EPT];
-    u32 ovr = 0;
+    u32 smask = 0;  // events outside the LUT window (x noise)
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       tl[k] = 0;
@@ -448,39 +459,12 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 #pragma unroll
       for (int k = 0; k < EPT; ++k) tl[k] += av[k] >= A_j ? 1 : 0;
     }
-    u32 smask = 0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u32 xk = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff, yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
       xl[k] = (int)xk - x_lo;
       fast[k] = live[k] && (u32)xl[k] < (u32)wx_eff && yk < (u32)tb.cam_h;
       smask |= live[k] && !fast[k] ? 1u << k : 0u;
-    }
-    // events outside the LUT window (x noise) fetch their LUT entry from global memory and join the slots; x / y outside the
-    // camera = map[y, x] IndexError in the reference (calib:279-280): dropped and counted
-    while (__ballot(smask != 0)) {
-      const bool act = smask != 0;
-      const int ks = act ? __builtin_ctz(smask) : 0;
-      smask &= smask - 1;
-      u32 exw = xw[0], eyw = yw[0];  // (select chains: a dynamic index would put the arrays into scratch memory)
-#pragma unroll
-      for (int q = 1; q < EPT / 2; ++q) {
-        exw = (ks >> 1) == q ? xw[q] : exw;
-        eyw = (ks >> 1) == q ? yw[q] : eyw;
-      }
-      const u32 ex = (exw >> ((ks & 1) * 16)) & 0xffff, ey = (eyw >> ((ks & 1) * 16)) & 0xffff;
-      bool oob = false;
-      if (act) {
-        if (ex >= (u32)tb.cam_w || ey >= (u32)tb.cam_h) {
-          oob = true;
-        } else {
-          const u32 l = tb.lut[__umul24(ex, (u32)tb.cam_h) + ey];
-#pragma unroll
-          for (int kk = 0; kk < EPT; ++kk) xl[kk] = ks == kk ? (int)l : xl[kk];
-          ovr |= 1u << ks;
-        }
-      }
-      n_oob += __popcll(__builtin_amdgcn_ballot_w64(oob));
     }
     }
     if (pass == 0) {
@@ -491,7 +475,8 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       XM_CSTAMP(5);
     }
     if (on) {
-    // branch-free: A1 + A2 out of the LDS bands; an event that is not live reads the sentinel (yr < 0) and drops out at xmd:23
+    // branch-free: A1 + A2 out of the LDS bands; an event that is not in the LUT window reads the sentinel (yr < 0) and drops
+    // out at xmd:23.  Three sweeps, so that the eight LDS round trips of each overlap.
     u32 l[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -499,29 +484,64 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       const u32* src = fast[k] ? lut_t + (__mul24(xl[k], tb.cam_h) + (int)yk) : &s_sentinel;
       l[k] = *src;
     }
-    const bool any_ovr = __ballot(ovr != 0) != 0;  // (wave-uniform: most waves have no x-noise event)
-    int slot[EPT], xp[EPT];
-    bool yok[EPT];
+    int slot[EPT], fu[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (any_ovr) l[k] = (ovr >> k) & 1u ? (u32)xl[k] : l[k];
       const int yr = (int)(short)(l[k] >> 16);
-      yok[k] = (u32)yr < (u32)(tb.xmap_h - 1);  // 0 <= yr < H - 1 (xmd:23)
-      slot[k] = yok[k] ? __mul24(tl[k], tb.xmap_h) + yr : 0;
-      xp[k] = (int)xm_t[slot[k]];
+      slot[k] = (u32)yr < (u32)(tb.xmap_h - 1) ? __mul24(tl[k], tb.xmap_h) + yr : -1;  // 0 <= yr < H - 1 (xmd:23); -1: dropped
+      fu[k] = (int)xm_t[max(slot[k], 0)] - tb.x_offset;  // the frame column, = xr + disp (calib:300); no int16 wrap on this rig
     }
+    if (all_in) {
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int xr = (int)(short)(l[k] & 0xffff), yr = (int)(short)(l[k] >> 16);
-      const int fu = xp[k] - tb.x_offset;                   // the frame column, = xr + disp (calib:300); no int16 wrap on this rig
-      const int disp = fu - xr;                             // (xm_create has checked the range: xmd:27's wrap never triggers)
-      bool write = yok[k] && disp >= 0;                     // xmd:29
-      const bool in_frame = ((u32)fu < (u32)tb.rect_w || (u32)(fu + tb.rect_w) < (u32)tb.rect_w) && yr < tb.rect_h;
-      n_oob += __popcll(__builtin_amdgcn_ballot_w64(write && !in_frame));  // NumPy IndexError (one negative wrap is legal)
+      for (int k = 0; k < EPT; ++k) {
+        const int disp = fu[k] - (int)(short)(l[k] & 0xffff);  // (xm_create has checked the range: xmd:27's wrap never triggers)
+        const bool write = slot[k] >= 0 && disp >= 0;          // xmd:29
+        n_in += write ? 1u : 0u;
+        if (write) atomicMax(&slots[slot[k]], ((u32)(e0 + (VEC ? k : k * nthreads) + 1) << 16) | (u32)disp);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int xr = (int)(short)(l[k] & 0xffff), yr = (int)(short)(l[k] >> 16);
+        const int disp = fu[k] - xr;
+        bool write = slot[k] >= 0 && disp >= 0;
+        const bool in_frame = ((u32)fu[k] < (u32)tb.rect_w || (u32)(fu[k] + tb.rect_w) < (u32)tb.rect_w) && yr < tb.rect_h;
+        n_oob += write && !in_frame ? 1u : 0u;  // NumPy IndexError (one negative wrap is legal)
+        write = write && in_frame;
+        n_in += write ? 1u : 0u;
+        if (write) atomicMax(&slots[slot[k]], ((u32)(e0 + (VEC ? k : k * nthreads) + 1) << 16) | (u32)disp);
+      }
+    }
+    // events outside the LUT window (x noise), one by one behind the fast path: the LUT entry from global memory, then the same
+    // A2 + A3 -- the slot's ds_max orders them against the others whatever the order of processing.  x / y outside the camera
+    // = map[y, x] IndexError in the reference (calib:279-280): dropped and counted
+    while (__ballot(smask != 0)) {
+      const bool act = smask != 0;
+      const int ks = act ? __builtin_ctz(smask) : 0;
+      smask &= smask - 1;
+      u32 exw = xw[0], eyw = yw[0];  // (select chains: a dynamic index would put the arrays into scratch memory)
+      int etl = tl[0];
+#pragma unroll
+      for (int q = 1; q < EPT / 2; ++q) {
+        exw = (ks >> 1) == q ? xw[q] : exw;
+        eyw = (ks >> 1) == q ? yw[q] : eyw;
+      }
+#pragma unroll
+      for (int kk = 1; kk < EPT; ++kk) etl = ks == kk ? tl[kk] : etl;
+      const u32 ex = (exw >> ((ks & 1) * 16)) & 0xffff, ey = (eyw >> ((ks & 1) * 16)) & 0xffff;
+      const bool inside = act && ex < (u32)tb.cam_w && ey < (u32)tb.cam_h;
+      n_oob += act && !inside ? 1u : 0u;
+      const u32 le = inside ? tb.lut[__umul24(ex, (u32)tb.cam_h) + ey] : 0x80000000u;
+      const int xr = (int)(short)(le & 0xffff), yr = (int)(short)(le >> 16);
+      const bool yok = (u32)yr < (u32)(tb.xmap_h - 1);
+      const int sl = yok ? __mul24(etl, tb.xmap_h) + yr : 0;
+      const int fue = (int)xm_t[sl] - tb.x_offset, disp = fue - xr;
+      bool write = yok && disp >= 0;
+      const bool in_frame = ((u32)fue < (u32)tb.rect_w || (u32)(fue + tb.rect_w) < (u32)tb.rect_w) && yr < tb.rect_h;
+      n_oob += write && !in_frame ? 1u : 0u;
       write = write && in_frame;
-      n_in += __popcll(__builtin_amdgcn_ballot_w64(write));
-      const int ek = e0 + (VEC ? k : k * nthreads);
-      if (write) atomicMax(&slots[slot[k]], ((u32)(ek + 1) << 16) | (u32)disp);
+      n_in += write ? 1u : 0u;
+      if (write) atomicMax(&slots[sl], ((u32)(e0 + (VEC ? ks : ks * nthreads) + 1) << 16) | (u32)disp);
     }
     }
   }
@@ -538,9 +558,14 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       if (u32* hf = st->host_flags) host_flag_store(hf, tag);
     }
   }
-  if (lane == 0) {
-    if (n_in) atomicAdd(&s_in, n_in);
-    if (n_oob) atomicAdd(&s_oob, n_oob);
+  {  // both counters in one word (a lane counts <= 8 events per pass, a tile holds <= 65527 events)
+    u32 cnt2 = n_in | (n_oob << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt2 += __shfl_xor(cnt2, o, 64);
+    if (lane == 0) {
+      if (cnt2 & 0xffffu) atomicAdd(&s_in, cnt2 & 0xffffu);
+      if (cnt2 >> 16) atomicAdd(&s_oob, cnt2 >> 16);
+    }
   }
   __syncthreads();
   XM_CSTAMP(7);
@@ -606,25 +631,25 @@ constexpr int COLS_MAX_THREADS = 512;
 template <bool AOS, bool VEC>
 __global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scatter_cols(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts, const uint4* __restrict__ aos,
-    u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int w_x, int xr_min) {
+    u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int w_x, int xr_min, int flags) {
   {  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
     const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)aos | (u64)tb.lut | (u64)tb.xmap | (u64)st | (u64)frame16;
     const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.t_px_scale | tb.x_offset | tb.rect_w | tb.rect_h | W | w_x;
     if ((long long)(pp | (u64)(long long)pi) < 0) return;
   }
   scatter_cols_body<AOS, VEC>((gp_u16)xs, (gp_u16)ys, (gp_i64)ts, (gp_u4)aos, n, tb, (gp_state)st, (XM_GLOBAL uint16_t*)frame16, W,
-                              w_x, xr_min, blockIdx.x, gridDim.x);
+                              w_x, xr_min, blockIdx.x, gridDim.x, flags);
 }
 
 // multi-frame launch: grid = (tiles, frames); FrameDesc.key_frame points at the frame's u16 disparity frame (+ bounds)
 template <bool AOS, bool VEC>
 __global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scatter_cols_batch(const FrameDesc* __restrict__ descs,
                                                                                                 DevTables tb, int W, int w_x,
-                                                                                                int xr_min, int device_redo) {
+                                                                                                int xr_min, int flags) {
   const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
   if (!d.valid || d.n == 0) return;       // (the host sends frames without events down the general path)
   scatter_cols_body<AOS, VEC>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
-                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x, device_redo != 0);
+                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x, flags);
 }
 
 }  // namespace xm
