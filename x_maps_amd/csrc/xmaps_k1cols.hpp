@@ -340,7 +340,10 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   // ---- 2. the first pass' events (cap = nthreads * EPT per pass).  VEC: 16-byte loads of 8 consecutive events from an
   //         8-aligned start (events in front of lb_s / behind lb_e are masked); otherwise lane-strided loads from lb_s.
   const int a0 = VEC ? (lb_s & ~(EPT - 1)) : lb_s;
-  const int n_pass = lb_e > lb_s ? (lb_e - a0 + cap - 1) / cap : 0;
+  // passes = ceil((lb_e - a0) / cap), by subtraction (<= 16 for the largest tile the slots' order field holds: an integer
+  // division is ~25 instructions, several of them quarter rate)
+  int n_pass = 0;
+  for (int left = lb_e > lb_s ? lb_e - a0 : 0; left > 0; left -= cap) n_pass += 1;
   u32 xw[EPT / 2], yw[EPT / 2];
   T tt[EPT];
   const auto load_events = [&](const int pass) {
@@ -575,17 +578,13 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   //         live: xp - x_offset >= xr_min (cols_cell); with xr_min >= 0 and rect_h >= xmap_h - 1 (the usual rig) neither the
   //         negative wrap nor the row test can trigger: the lean variant.
   {
+    const bool lean = xr_min >= 0 && tb.rect_h >= tb.xmap_h - 1;  // uniform
+    // (two rows per lane with one 4-byte store where both map to the same frame column was tried: no faster)
     constexpr int FL = 3;  // (2640 slots at C-1M: two sweeps of 512 x 3)
     const int per = tb.xmap_h;
-    const int dq = nthreads / per, dr = nthreads - dq * per;
-    int r_i;
-    {
-      int q_i = (int)((float)tid * (1.0f / (float)per));
-      r_i = tid - q_i * per;
-      if (r_i < 0) r_i += per;
-      if (r_i >= per) r_i -= per;
-    }
-    const bool lean = xr_min >= 0 && tb.rect_h >= tb.xmap_h - 1;  // uniform
+    int dr = nthreads, r_i = tid;  // nthreads % per, tid % per (a few subtractions on small rigs, none on large ones)
+    while (dr >= per) dr -= per;
+    while (r_i >= per) r_i -= per;
     for (int i0 = tid; i0 < nslots; i0 += FL * nthreads) {
       u32 v[FL];
       int xv[FL], rs[FL];
