@@ -371,3 +371,26 @@ def test_live_cells_outside_the_frame_are_index_errors():
     ref = _ref(tb, kept)
     assert st.n_index_errors == n_err and n_err > 1000
     assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"])
+
+
+@pytest.mark.parametrize("dims", [(80, 60, 80, 60), (96, 50, 96, 50), (128, 64, 100, 70), (64, 48, 64, 48), (200, 37, 150, 41)])
+def test_small_and_odd_rigs(dims):
+    """Rectified heights that are odd / not a multiple of 4 or 8 (K2's 16-byte, 8-byte and cell-by-cell loaders of the u16
+    frame), X-maps shorter than a block has threads, tiles of up to 16 columns, AoS and SoA, several frames per slot."""
+    cw, ch, pw, ph = dims
+    rng = np.random.default_rng(cw * 1000 + ch)
+    cfg = S.RigConfig(f"t{cw}x{ch}", cw, ch, pw, ph, 0)
+    tb = S.make_tables(cfg)
+    with XMapsEngine(tb, n_slots=2) as eng:
+        for f in range(5):
+            n = int(rng.integers(30_000, 90_000))
+            evs = S.make_events(cfg, frame=f, n=n)
+            ref = _ref(tb, evs)
+            if f % 2:
+                d, b, st = eng.process_events(evs)
+            else:
+                d, b, st = _run(eng, evs)
+            assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]) and st.n_inliers == int(ref["mask"].sum()), f
+        pc = eng.path_counts()
+        assert pc["cols"] + pc["key32"] + pc["sorted_key64"] + pc["general"] == 5 + eng.sorted_fallbacks()
+        assert pc["cols"] >= 4, pc  # these rigs qualify (affine X-map: injective); a frame may still fail a tile and be redone
