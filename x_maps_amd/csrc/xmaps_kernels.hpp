@@ -1543,6 +1543,11 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 #define XM_K2_TX 16
 #define XM_K2_TY 16
 #endif
+#ifdef XM_ABLATE  // experiments (tools/k2_timeline.py): s_memtime stamps of thread 0 of 64 tiles in the middle of frame 30's K2
+#define XM_K2STAMP(ph) do { if (threadIdx.x == 0 && blockIdx.z == 30 && blockIdx.y == 15 && blockIdx.x < 40) g_timeline[blockIdx.x][9 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)  /* columns 9..15: K1's stamps keep 0..8 */
+#else
+#define XM_K2STAMP(ph) do { } while (0)
+#endif
 constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX;  // 2 x 10 KB of u16: >= 6 blocks per CU, so all
                                                                     // 1200 blocks of a 640x480 frame are resident at once
 
@@ -1624,6 +1629,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
   XM_BLOG_BEGIN();
+  XM_K2STAMP(0);
   // XCD-aware tile order (see xcd_contiguous): each XCD takes a contiguous run of the tile raster, so the halos that
   // neighbouring tiles share (3 of 22 patch columns each side, boundary cache lines above/below) hit in its own L2.
   const u32 lin_tile = xcd_contiguous(blk_lin, grid_x * grid_y);
@@ -1873,7 +1879,9 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
           }
         }
       }
+      XM_K2STAMP(1);
       __syncthreads();
+      XM_K2STAMP(2);
       {  // 7-tap max along the rows of every patch column: 8 outputs per task from 14 inputs (two 16-byte LDS reads)
         const int nseg = rows_p >> 3, tasks = cols * nseg;
         for (int t = tid; t < tasks; t += NT) {
@@ -1898,7 +1906,9 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
           *reinterpret_cast<uint4*>(vmax + t * 8) = w;
         }
       }
+      XM_K2STAMP(3);
       __syncthreads();
+      XM_K2STAMP(4);
       if (poff != ~0u) {
         const uint16_t* p = vmax + poff;
         u32 best = 0;
@@ -1924,6 +1934,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       }
     }
   }
+  XM_K2STAMP(5);
   PixelOut o;
 #ifndef XM_K2_NO_DLUT
   {
@@ -1966,6 +1977,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       b[2] = (uint8_t)((o.bgr >> 16) & 0xff);
     }
   }
+  XM_K2STAMP(6);
   XM_BLOG_END(2, st, tag);
 }
 
