@@ -1615,7 +1615,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
                                                       u32 tag_override, const unsigned char* __restrict__ dirty,
                                                       const ulonglong2* __restrict__ zero16, float* __restrict__ depth,
                                                       uint8_t* __restrict__ bgr, int tile_cap, const u32 blk_lin,
-                                                      const u32 grid_x, const u32 grid_y) {
+                                                      const u32 grid_x, const u32 grid_y, const int4* rec_pre = nullptr) {
   // Dynamic LDS sized to the largest patch of THIS rig (tile_cap cells, a multiple of 8, <= K2_TILE_MAX; set in xm_create):
   // how many blocks fit beside K1's 70 KB blocks on a CU is what bounds the pipelined frame rate, and the static
   // worst case (2 x 10 KB) was twice what C-1M's 50 x 56 patches need.
@@ -1638,7 +1638,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   const int u = tile_x * K2_TX + tx, v = tile_y * K2_TY + ty;
   const bool in_img = u < tb.proj_w && v < tb.proj_h;
   // the tile's patch rectangle and the pixel's offset into it were computed once in xm_create (k_build_k2_tables)
-  const int4 rec = tb.k2_tiles[lin_tile];  // block-uniform
+  const int4 rec = rec_pre ? *rec_pre : tb.k2_tiles[lin_tile];  // block-uniform
   const u32 pix_i = __umul24((u32)v, (u32)tb.proj_w) + (u32)u;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
   const u32 poff = in_img ? tb.k2_pix[pix_i] : ~0u;
   int mx = 0, my = 0;
@@ -2002,10 +2002,17 @@ template <int FMT = 0, int COND = 0>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb,
                                                                         const ulonglong2* __restrict__ zero16,
                                                                         int tile_cap) {
+  // The tile's patch record does not depend on the frame: its load goes out together with the frame descriptor's (a block of
+  // K2 is a chain of dependent round trips -- descriptor, record, patch -- and 55 % of its lifetime at full occupancy is spent
+  // before the patch has arrived: tools/k2_timeline.py).  The never-true test keeps the compiler from sinking the load
+  // behind the branch.
+  const u32 blk_lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int4 rec = tb.k2_tiles[xcd_contiguous(blk_lin, gridDim.x * gridDim.y)];
   const FrameDesc d = descs[blockIdx.z];
-  if (!d.valid || frame_skipped<COND>(d.st)) return;
-  frame_proj_tiled_body<FMT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap,
-                               blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
+  if (!d.valid || rec.w < 0) return;
+  if (frame_skipped<COND>(d.st)) return;
+  frame_proj_tiled_body<FMT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap, blk_lin, gridDim.x, gridDim.y,
+                             &rec);
 }
 
 // camera view / plain per-pixel conversion of a frame of n_pixels cells -> depth + BGR
