@@ -2520,6 +2520,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset_slot(SlotState* st, u64* __rest
     if (threadIdx.x == 0) {
       st->tag_a = 0;
       st->tag_b = 0;
+      st->pad[1] = 0;  // (frame_attempt_failed: tags start over, a stale tag of the old numbering must not match a new one)
       // unsorted_sticky is NOT cleared here: this kernel also runs on tag wrap, and a violation recorded since the last
       // xm_sync must still be reported; it starts at 0 (xm_create zeroes the states) and xm_sync clears it
     }
