@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 Default workload = BASELINE.json configs[1] (C-1M): a "step" = one pass of the hot path over one batch of synthetic input =
-ONE GROUP of 16 frames of 1 000 000 events each (camera = projector = 640x480, rectified frame 1760x1320) through one
+ONE GROUP of 32 frames of 1 000 000 events each (camera = projector = 640x480, rectified frame 1760x1320) through one
 xm_process_batch call, i.e. one set of multi-frame launches (boundary pass K0b -> K1 column tiles -> K2 frame kernel, grid =
 frames x tiles; K0 + the 64-bit key path only for frames whose verified (t[0], t[n-1]) shortcut fails).  The frames' SoA
 event columns are already resident in HBM; the result is the f32 depth frame + the BGR u8 frame per frame in HBM.  The engine
@@ -58,8 +58,10 @@ def parse_args():
     ap.add_argument("--slots", type=int, default=int(os.environ.get("XM_SLOTS", "0")),
                     help="frames in flight per GPU (key frame + state each); default 4 (one stream per hardware queue), "
                          "60 with --graph")
-    ap.add_argument("--frames", type=int, default=32,
-                    help="distinct synthetic frames resident in HBM (32 x 12 MB + key frames > the 256 MiB Infinity Cache)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="distinct synthetic frames resident in HBM; default: one distinct group per group in flight (3 x 32 frames = "
+                         "1.15 GB of events: no group re-reads what another one has just pulled into the 256 MiB Infinity Cache), "
+                         "32 with --batch 0")
     ap.add_argument("--camera-perspective", action="store_true")
     ap.add_argument("--no-bgr", action="store_true", help="depth frame only")
     ap.add_argument("--graph", action="store_true", help="config 5: 60 x C-1M frames replayed from one captured hipGraph")
@@ -68,11 +70,11 @@ def parse_args():
                     help="configs 1/3 stand-in: ESL-like frames (real calibration geometry, ~150 k events, projector 1080x1920)")
     ap.add_argument("--merge", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
                     help="--sharded: how the shards' key frames are merged (x_maps_amd/sharded.py)")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=32,
                     help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
                          "launches, grid = frames x tiles); 0 = a step is one frame through one asynchronous call (round 2's "
                          "headline mode, reported under other_modes by default)")
-    ap.add_argument("--groups-in-flight", type=int, default=2, help="with --batch: slots = groups x B (default 2)")
+    ap.add_argument("--groups-in-flight", type=int, default=3, help="with --batch: slots = groups x B (default 3)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host->host figures")
@@ -162,7 +164,7 @@ def cpu_baseline_leg(args, O, tables, host_frame, n_ev, camera, want_bgr):
     x, y, t = host_frame
     xi, yi = x.astype(np.int64), y.astype(np.int64)
     reps, spent, best = 0, 0.0, 1e9
-    while spent < args.cpu_seconds and reps < 50:
+    while spent < args.cpu_seconds and reps < 400:
         c0 = time.perf_counter()
         O.process_ev_frame(tables, xi, yi, t, camera_perspective=camera, want_bgr=want_bgr)
         dt = time.perf_counter() - c0
@@ -313,7 +315,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     n_ev = cfg.n_events
 
     # ---- synthetic frames -> HBM (SoA columns, the layout K1 reads), laid out back to back ------------------------
-    nf = args.frames
+    nf = args.frames or (args.groups_in_flight * B if B else 32)
     if B and (nf % B or slots % B):
         raise SystemExit("--batch must divide --frames and the number of slots")
     X = torch.empty(nf * n_ev, dtype=torch.int16, device=dev)
@@ -459,7 +461,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         if B:
             modes.append(("one_frame_per_call", dict(mode_kw), camera, 0, not args.no_launch_workers))
         else:
-            modes.append(("groups_of_16_frames_per_call", dict(mode_kw), camera, 16, False))
+            modes.append(("groups_of_32_frames_per_call", dict(mode_kw), camera, 32, False))
             if not args.no_launch_workers:
                 modes.append(("launches_from_the_calling_thread", dict(mode_kw), camera, 0, False))
         if not args.general:
@@ -500,7 +502,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
                                "XM_FLAG_GENERAL (extrema pass K0 + 64-bit packed keys on every frame, one frame per call: round 1's "
                                "headline mode); camera_view = --camera-perspective; `value` above = library defaults, groups of "
                                f"{B} frames per call" if B else
-                               "groups_of_16_frames_per_call = xm_process_batch; launches_from_the_calling_thread = no launch "
+                               "groups_of_32_frames_per_call = xm_process_batch; launches_from_the_calling_thread = no launch "
                                "workers; forced_general = XM_FLAG_GENERAL; camera_view = --camera-perspective")
 
     # (these legs run LAST, on an engine of their own: their pinned allocations and extra streams change how the runtime maps
@@ -885,7 +887,7 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     tables = S.make_tables(cfg)
     camera = args.camera_perspective
     n_ev = cfg.n_events
-    nf = min(args.frames, 4)
+    nf = min(args.frames or 4, 4)
     a, b = shard_bounds(n_ev, rank, world)
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank)
     shards, host0 = [], None

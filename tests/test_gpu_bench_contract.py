@@ -36,7 +36,7 @@ def test_default_line_as_the_driver_calls_it():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["parity"]["depth_bit_exact"] and d["parity"]["bgr_equal"]
     fps = d["config"]["frames_per_step"]  # a step = one group of frames through one xm_process_batch call
-    assert fps == 16 and d["config"]["events_per_step"] == 16_000_000 and r["frames_per_launch"] == fps
+    assert fps == 32 and d["config"]["events_per_step"] == 32_000_000 and r["frames_per_launch"] == fps
     assert r["algorithmic_bytes_per_launch"] == 24.0 * 1e6 * fps and d["parity"]["last_frame_of_the_group_depth_bit_exact"]
     assert d["config"]["k1_paths_frames"]["cols"] > 0  # the groups took the column-tile K1
     assert abs(d["value"] - 1e6 * fps * 20 / (d["ms_per_step"] * 20 * 1e-3) / 1e6) / d["value"] < 0.01  # value == events / time

@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02b"
 src = os.path.join(ROOT, "gpurun_out", tag)
 out = os.path.join(ROOT, "gpurun_out", tag + "_profiles") if "--to-scratch" in sys.argv else os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
-FRAMES_PER_LAUNCH = 16
+FRAMES_PER_LAUNCH = 32
 
 
 def short(name):
@@ -60,11 +60,11 @@ def pmc_rows(pattern):
 Q = "--no-cpu-baseline --no-other-modes --no-host-path"
 with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of bench.py (MI355X), end of round 2\n\n"
-            "A bench step = one group of 16 C-1M frames through xm_process_batch: ONE launch each of k_cols_bounds_batch (K0b),\n"
+            "A bench step = one group of 32 C-1M frames through xm_process_batch: ONE launch each of k_cols_bounds_batch (K0b),\n"
             "k_scatter_cols_batch (K1, column tiles) and k_frame_proj_tiled_batch<2> (K2 on the u16 frame), grid = frames x tiles.\n"
-            "Per-frame cost = avg us / 16.\n\n")
+            "Per-frame cost = avg us / 32.\n\n")
     for key, title, cmd in (
-            ("trace_groups", "the default bench command (projector view, 2 groups in flight)", f"python bench.py {Q}"),
+            ("trace_groups", "the default bench command (projector view, 3 groups in flight)", f"python bench.py {Q}"),
             ("trace_serial", "one group at a time (launches back to back, nothing overlaps): what bench.py's roofline pass times", f"python bench.py --groups-in-flight 1 {Q}"),
             ("trace_single", "one frame per call, 1 slot (single-frame launches: compact 32-bit key frame path)", f"python bench.py --batch 0 --slots 1 --steps 200 --warmup 20 {Q}"),
             ("trace_cam", "camera view, one group at a time", f"python bench.py --groups-in-flight 1 --camera-perspective {Q}"),
@@ -80,7 +80,7 @@ with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
 
 traffic = {}
 with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
-    f.write(f"# {tag}: rocprofv3 PMC counters per kernel (averages per dispatch of a 16-frame launch; one --pmc group per run)\n\n"
+    f.write(f"# {tag}: rocprofv3 PMC counters per kernel (averages per dispatch of a 32-frame launch; one --pmc group per run)\n\n"
             "FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read\n"
             "(MI355X_MICROARCH.md section HBM), so HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE.\n\n")
     for view, pat in (("projector_groups", "pmc_groups_*_results.db"), ("camera_groups", "pmc_camg_*_results.db")):
@@ -105,7 +105,7 @@ if traffic:
         if os.path.exists(base):
             old = json.load(open(base))
         old.update(traffic)
-        old["_note_groups"] = ("*_groups: 16-frame launches (bench.py default since the end of round 2), rocprofv3 --pmc FETCH_SIZE / "
+        old["_note_groups"] = ("*_groups: 32-frame launches (bench.py default since the end of round 2), rocprofv3 --pmc FETCH_SIZE / "
                                "WRITE_SIZE in separate passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 calibration; source gpurun_out/%s, "
                                "summary profiles/%s_pmc.md" % (tag, tag))
         with open(os.path.join(out, "pmc_traffic.json"), "w") as g:
