@@ -1687,6 +1687,27 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
           // 16-byte loads of 8 rows (the patch starts on a multiple of 8 rows and rows_p is one), copied as they are: LDS quad
           // index == patch (column, row octet) index.  A 50 x 56 patch is 350 quads: two loads per thread.
           const int oct = rows_p >> 3, total = cols * oct;
+          if (oct <= 8) {
+            // patches of <= 64 rows: thread slot s -> (column s >> 3, row octet s & 7) by shift and mask (slots with an octet
+            // past the patch idle); K2 is issue bound and the divide by `oct` below is ~12 instructions per load
+            const int nslot = cols << 3;
+            for (int s0 = tid; s0 < nslot; s0 += 2 * NT) {
+              uint4 k[2];
+              bool has[2];
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int sj = s0 + j * NT, c = sj >> 3, ro = sj & 7;
+                has[j] = sj < nslot && ro < oct;
+                k[j] = *reinterpret_cast<const uint4*>(d16 + (has[j] ? __umul24((u32)(bx + c), (u32)tb.rect_h) + (u32)(by + 8 * ro)
+                                                                     : __umul24((u32)bx, (u32)tb.rect_h) + (u32)by));
+              }
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int sj = s0 + j * NT;
+                if (has[j]) reinterpret_cast<uint4*>(tile)[__mul24(sj >> 3, oct) + (sj & 7)] = k[j];
+              }
+            }
+          } else {
           const float inv_o = __builtin_amdgcn_rcpf((float)oct);  // (approximate: the +-1 fix-ups below absorb it)
           for (int i0 = tid; i0 < total; i0 += 2 * NT) {
             uint4 k[2];
@@ -1701,6 +1722,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               if (i0 + j * NT < total) reinterpret_cast<uint4*>(tile)[i0 + j * NT] = k[j];
+          }
           }
         } else if (interior) {
           const int quarter = rows_p >> 2, total = cols * quarter;
