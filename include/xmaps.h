@@ -202,6 +202,12 @@ int xm_profile_frame(xm_handle* h, const uint16_t* x, const uint16_t* y, const v
  * the chip half idle while they ramp up and drain; a group's launch keeps every CU fed. */
 int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
                      const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out);
+/* The same for Metavision EventCD records (16-byte AoS, `python/frame_event_filter.py:33-37`) resident in device memory: frame f
+ * = records [offsets_host[f], offsets_host[f+1]); every event is used (no polarity selection).  What an offline replay of a
+ * recording feeds: `DepthReprojectionPipe.process_ev_frames` in x_maps_amd/depth_reprojection_pipe.py stages a list of host
+ * frames and calls this. */
+int xm_process_batch_aos(xm_handle* h, const void* eventcd16, const uint64_t* offsets_host, int n_frames, float* depth_out,
+                         uint8_t* bgr_out);
 /* The same group, synchronously, with start / stop events attached to the dispatch packets of its launches (the time
  * stamps rocprofv3 --kernel-trace reports): gpu_ms[0] = the extrema pass K0 (general path) or the boundary pass K0b
  * (column tiles), 0 when neither ran; [1] = K1; [2] = K2; [3] = start of the first .. end of the last. */

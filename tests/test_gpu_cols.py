@@ -394,3 +394,37 @@ def test_small_and_odd_rigs(dims):
         pc = eng.path_counts()
         assert pc["cols"] + pc["key32"] + pc["sorted_key64"] + pc["general"] == 5 + eng.sorted_fallbacks()
         assert pc["cols"] >= 4, pc  # these rigs qualify (affine X-map: injective); a frame may still fail a tile and be redone
+
+
+def test_offline_replay_of_event_frames_through_groups(monkeypatch):
+    """DepthReprojectionPipe.process_ev_frames: a list of EventCD frames (as the trigger finder cuts them) through groups of
+    multi-frame launches, one callback per frame, the same frames as process_ev_frame gives one by one -- an unsorted frame in
+    the middle included (redone on the general path)."""
+    monkeypatch.delenv("XM_COLS")  # library defaults: groups take the column tiles
+    from x_maps_amd.depth_reprojection_pipe import DepthReprojectionPipe
+    from x_maps_amd.depth_reprojection_processor import RuntimeParams
+    from x_maps_amd.stats import StatsPrinter
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    frames = [S.make_events(cfg, frame=60 + i, n=300_000 + 40_000 * i) for i in range(7)]
+    a, b = frames[3][10_000:20_000].copy(), frames[3][200_000:210_000].copy()
+    frames[3][10_000:20_000], frames[3][200_000:210_000] = b, a
+    params = RuntimeParams(camera_width=cfg.cam_w, camera_height=cfg.cam_h, projector_width=cfg.proj_w, projector_height=cfg.proj_h,
+                           projector_fps=60, z_near=0.1, z_far=1.2, calib=None, projector_time_map=None, no_frame_dropping=True,
+                           camera_perspective=False, tables=tb)
+    got = []
+    pipe = DepthReprojectionPipe(params, StatsPrinter(), got.append)
+    pipe.replay_group = 4  # 7 frames: a group of 4 and one of 3
+    try:
+        pipe.process_ev_frames(frames)
+        assert len(got) == len(frames)
+        for f, (evs, bgr) in enumerate(zip(frames, got)):
+            assert np.array_equal(bgr, _ref(tb, evs)["bgr"]), f
+        pc = pipe._replay_engine.path_counts()
+        assert pc["cols"] == 7 and pipe._replay_engine.sorted_fallbacks() == 1
+        one = []
+        pipe.frame_callback = one.append
+        pipe.process_ev_frame(frames[5])
+        assert np.array_equal(one[0], got[5])
+    finally:
+        pipe.close()

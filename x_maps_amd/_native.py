@@ -129,6 +129,7 @@ SYMBOLS = {
     "xm_profile_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_profile_event_overhead": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "xm_process_batch": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P]),
+    "xm_process_batch_aos": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.c_int, _P, _P]),
     "xm_profile_batch": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P, C.POINTER(C.c_float)]),
     "xm_graph_create": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P, C.POINTER(_P)]),
     "xm_graph_launch": (C.c_int, [_P]),

@@ -1774,7 +1774,8 @@ int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
 
 // ---- a group of frames in one set of multi-frame launches ---------------------------------------------------
 static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
-                              const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, float* gpu_ms) {
+                              const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, float* gpu_ms,
+                              const void* aos = nullptr) {
   if (!h || !offsets_host || n_frames <= 0) return fail(XM_ERR_INVALID, "bad argument");
   const int ns = (int)h->slots.size();
   if (n_frames > ns) return fail(XM_ERR_INVALID, "a batch of %d frames needs n_slots >= %d (handle has %d)", n_frames, n_frames, ns);
@@ -1789,8 +1790,14 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
     const u64 a = offsets_host[f], b = offsets_host[f + 1];
     if (b < a) return fail(XM_ERR_INVALID, "offsets must be non-decreasing");
     EventsView& ev = evs[f];
-    ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
-    ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+    if (aos) {  // Metavision EventCD records (16 bytes each), every event used
+      ev.aos = (const char*)aos + a * 16;
+      ev.t_dtype = XM_T_INT64;
+    } else {
+      ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
+      ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
+    }
+    ev.n = (size_t)(b - a);
     int rc = check_events(ev);
     if (rc) return rc;
     dep[f] = depth_out ? depth_out + f * px : nullptr;
@@ -1853,6 +1860,13 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
 int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
                      const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out) {
   return process_batch_impl(h, x, y, t, p, t_dtype, offsets_host, n_frames, depth_out, bgr_out, nullptr);
+}
+
+int xm_process_batch_aos(xm_handle* h, const void* eventcd16, const uint64_t* offsets_host, int n_frames, float* depth_out,
+                         uint8_t* bgr_out) {
+  if (!eventcd16) return fail(XM_ERR_INVALID, "NULL event buffer");
+  return process_batch_impl(h, nullptr, nullptr, nullptr, nullptr, XM_T_INT64, offsets_host, n_frames, depth_out, bgr_out, nullptr,
+                            eventcd16);
 }
 
 int xm_profile_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,

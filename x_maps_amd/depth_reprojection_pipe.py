@@ -125,6 +125,26 @@ class DepthReprojectionPipe:
         self.last_stats = st
         self.frame_callback(bgr)
 
+    def process_ev_frames(self, frames):
+        """Offline replay: a list of event frames (what the trigger finder would hand to process_ev_frame one by one) through
+        the engine's multi-frame launches, `frame_callback(bgr)` once per frame, in order.  Same frames as calling
+        process_ev_frame on each (no frame event filter selected); the kernels of a group keep the chip full, which a single
+        frame's launches do not (groups take the column-tile K1)."""
+        if not self.fused or not isinstance(self.ev_filter_proc.selected_filter(), NoFilter):
+            for evs in frames:
+                self.process_ev_frame(evs)
+            return
+        if getattr(self, "_replay_engine", None) is None:
+            # an engine of its own with the library's default flags (verified shortcut with automatic redo: the mode in which
+            # groups take the column tiles) and enough slots for a group; the per-frame engine declares its frames sorted
+            from .engine import XMapsEngine
+            self._replay_engine = XMapsEngine(self.calib_maps.tables, camera_perspective=self.params.camera_perspective,
+                                              device=getattr(self.params, "device", 0), n_slots=self.replay_group)
+        with self.stats_printer.measure_time("x-maps frames (fused, groups)"):
+            outs = self._replay_engine.process_event_frames(list(frames), want_depth=False)
+        for _, bgr in outs:
+            self.frame_callback(bgr)
+
     def depth_frame(self, evs):
         """Same frame as process_ev_frame but returning the f32 depth map (A5 output) instead of calling back."""
         depth, _, st = self.calib_maps.engine.process_events(evs, want_bgr=False)
@@ -159,7 +179,12 @@ class DepthReprojectionPipe:
         if self.ingest is not None:
             self.ingest.reset()
 
+    replay_group = 16  # frames per group of process_ev_frames
+
     def close(self):
+        if getattr(self, "_replay_engine", None) is not None:
+            self._replay_engine.close()
+            self._replay_engine = None
         if self.ingest is not None:
             self.ingest.close()
         self.calib_maps.engine.close()

@@ -236,6 +236,48 @@ class XMapsEngine:
                                            offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1,
                                            _ptr(depth_ptr), _ptr(bgr_ptr)))
 
+    def process_events_batch_device(self, aos_ptr, offsets, depth_ptr=None, bgr_ptr=None):
+        """Frames [offsets[f], offsets[f+1]) of device-resident EventCD records (16-byte AoS); asynchronous."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        N.check(self._lib.xm_process_batch_aos(self._h, _ptr(aos_ptr), offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1,
+                                               _ptr(depth_ptr), _ptr(bgr_ptr)))
+
+    def process_event_frames(self, frames, want_depth=True, want_bgr=True):
+        """A list of EventCD frames (host arrays, as the trigger finder cuts them) in groups of <= n_slots frames through the
+        multi-frame launches: [(depth | None, bgr | None)] per frame.  Synchronous; what an offline replay uses instead of one
+        call per frame (the kernels of a group keep the chip full: DESIGN.md section 3)."""
+        from .synthetic import EVENT_CD_DTYPE
+        out = []
+        px = self.out_h * self.out_w
+        G = max(1, self.n_slots)
+        for g0 in range(0, len(frames), G):
+            grp = [np.ascontiguousarray(f if f.dtype == EVENT_CD_DTYPE else f.astype(EVENT_CD_DTYPE)) for f in frames[g0:g0 + G]]
+            if any(len(f) == 0 for f in grp):
+                raise ValueError("empty frame in a group (t.min() of an empty frame raises in the reference)")
+            offs = np.zeros(len(grp) + 1, np.uint64)
+            offs[1:] = np.cumsum([len(f) for f in grp])
+            rec = np.empty(int(offs[-1]), EVENT_CD_DTYPE)  # (np.concatenate would hand back the packed 14-byte layout under NumPy 2)
+            for i, f in enumerate(grp):
+                rec[int(offs[i]):int(offs[i + 1])] = f
+            d_rec = self.to_device(rec)
+            d_depth = self.dev_alloc(len(grp) * px * 4) if want_depth else None
+            d_bgr = self.dev_alloc(len(grp) * px * 3) if want_bgr else None
+            try:
+                self.process_events_batch_device(d_rec, offs, d_depth, d_bgr)
+                self.sync()  # (also redoes frames whose verified shortcut failed)
+                depth = np.empty((len(grp), self.out_h, self.out_w), np.float32) if want_depth else None
+                bgr = np.empty((len(grp), self.out_h, self.out_w, 3), np.uint8) if want_bgr else None
+                if want_depth:
+                    self.dev_download(depth, d_depth)
+                if want_bgr:
+                    self.dev_download(bgr, d_bgr)
+            finally:
+                for ptr in (d_rec, d_depth, d_bgr):
+                    if ptr:
+                        self.dev_free(ptr)
+            out += [(None if depth is None else depth[i], None if bgr is None else bgr[i]) for i in range(len(grp))]
+        return out
+
     def profile_batch_device(self, x_ptr, y_ptr, t_ptr, p_ptr, offsets, depth_ptr=None, bgr_ptr=None,
                              t_dtype=N.XM_T_INT64):
         """The same group, synchronously, timed per launch: (K0 or K0b, K1, K2, first start .. last stop) in ms."""
