@@ -622,7 +622,10 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   }
 }
 
-constexpr int COLS_MAX_THREADS = 512;
+#ifndef XM_COLS_MAX_THREADS
+#define XM_COLS_MAX_THREADS 512
+#endif
+constexpr int COLS_MAX_THREADS = XM_COLS_MAX_THREADS;
 #ifndef XM_COLS_WAVES_PER_EU
 #define XM_COLS_WAVES_PER_EU 6
 #endif
