@@ -428,3 +428,68 @@ def test_offline_replay_of_event_frames_through_groups(monkeypatch):
         assert np.array_equal(one[0], got[5])
     finally:
         pipe.close()
+
+
+def _random_tile_case(seed):
+    """Random rig with an injective X-map (slope > 1 frame column per time column), LUT entries outside the frame, undefined
+    X-map cells, a projector map that partly points outside; a dense stream: sorted or not, with ties, x noise, duplicates."""
+    rng = np.random.default_rng(7000 + seed)
+    cam_w, cam_h = int(rng.integers(24, 120)), int(rng.integers(16, 90))
+    rect_w, rect_h = int(rng.integers(2 * cam_w, 3 * cam_w + 8)), int(rng.integers(cam_h + 2, 3 * cam_h + 8))
+    proj_w, proj_h = int(rng.integers(8, 90)), int(rng.integers(8, 70))
+    xmap_w = int(rng.integers(8, 64))
+    ys, xs = np.mgrid[0:cam_h, 0:cam_w]
+    sx, sy = rect_w / cam_w, rect_h / cam_h
+    mapx = np.rint(rng.uniform(0.5, 0.9) * sx * xs + rng.uniform(0, 6) + rng.uniform(-0.05, 0.05) * ys).astype(np.int16)
+    mapy = np.rint(rng.uniform(0.7, 1.1) * sy * ys + rng.uniform(-5, 3) + rng.uniform(-0.1, 0.1) * xs).astype(np.int16)
+    xmap_h = max(3, rect_h + int(rng.integers(-3, 4)))
+    yr, tc = np.mgrid[0:xmap_h, 0:xmap_w]
+    slope = rng.uniform(1.05, 0.9 * rect_w / xmap_w)  # > 1: two time columns of a row never share a frame column
+    xmap = np.rint(4242 + rng.uniform(0, 0.08) * rect_w + tc * slope + rng.uniform(-0.05, 0.05) * yr).astype(np.int16)
+    xmap[rng.random(xmap.shape) < rng.uniform(0, 0.2)] = 0
+    if rng.random() < 0.5:
+        xmap[:, 0] = 0
+    vs, us = np.mgrid[0:proj_h, 0:proj_w]
+    pm = np.stack((np.rint(us * rect_w / proj_w * rng.uniform(0.8, 1.2) + rng.uniform(-5, 5)),
+                   np.rint(vs * rect_h / proj_h * rng.uniform(0.8, 1.2) + rng.uniform(-5, 5))), -1).astype(np.int16)
+    tb = {"cam_w": cam_w, "cam_h": cam_h, "proj_w": proj_w, "proj_h": proj_h, "rect_w": rect_w, "rect_h": rect_h,
+          "cam_mapx_i16": mapx, "cam_mapy_i16": mapy, "proj_x_map": np.ascontiguousarray(xmap),
+          "disp_proj_mapxy_i16": np.ascontiguousarray(pm), "t_px_scale": xmap_w - 1, "x_offset": 4242,
+          "p03": float(rng.uniform(5, 300)), "z_near": 0.1, "z_far": float(rng.uniform(0.5, 3.0))}
+    n = int(rng.integers(1100 * xmap_w // 2, 2500 * xmap_w))
+    span = int(rng.integers(50, 30_000))
+    t_rel = np.sort(rng.integers(0, span, n))
+    kind = rng.random()
+    if kind < 0.15:
+        t_rel = rng.permutation(t_rel)
+    elif kind < 0.3:  # a few late events
+        idx = rng.integers(0, n, 5)
+        t_rel[idx] = t_rel[np.minimum(idx + n // 3, n - 1)]
+    x = np.clip(np.rint(t_rel / span * cam_w + rng.normal(0, rng.uniform(0.5, 6), n)), 0, cam_w - 1)
+    evs = np.zeros(n, S.EVENT_CD_DTYPE)
+    evs["x"], evs["y"] = x, rng.integers(0, cam_h, n)
+    evs["t"] = int(rng.integers(0, 2 ** 40)) + t_rel
+    evs["p"] = 1
+    return tb, evs
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_rigs_and_streams_on_the_tiles(seed):
+    tb, evs = _random_tile_case(seed)
+    x, y, t, _ = S.to_soa(evs)
+    try:
+        ref, ref_err = _ref(tb, evs), None
+    except IndexError:
+        ref, ref_err = None, IndexError
+    with XMapsEngine(tb, n_slots=2) as eng:
+        if ref_err is IndexError:
+            with pytest.raises(IndexError):
+                eng.process_frame(x, y, t)
+            return
+        for aos in (False, True):
+            d, b, st = eng.process_events(evs) if aos else eng.process_frame(x, y, t)
+            assert st.n_inliers == int(ref["mask"].sum()), aos
+            assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]), aos
+        pc = eng.path_counts()
+        # sorted streams on these rigs take the tiles; a failing frame is redone on the general path (still exact)
+        assert pc["cols"] + pc["key32"] + pc["sorted_key64"] + pc["general"] == 2 + eng.sorted_fallbacks()
