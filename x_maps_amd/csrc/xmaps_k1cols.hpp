@@ -301,6 +301,12 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   //         the thresholds of its first and one-past-last column (k_cols_bounds), the frame's first / last time stamp, the tag
   const int4 b_lo = bounds[tile], b_hi = bounds[tile + 1];
   const u32 A_lo = thr[c0], A_hi = thr[c0 + Wc];
+  // the first interior thresholds ride along (W = 2 at C-1M: one): fetched inside the event arithmetic they were a scalar
+  // round trip in the middle of it
+  constexpr int A_PRE = 3;
+  u32 A_in[A_PRE];
+#pragma unroll
+  for (int i = 0; i < A_PRE; ++i) A_in[i] = thr[c0 + min(1 + i, Wc)];
   T t_first, t_last;
   if constexpr (AOS) {
     const uint4 a = aos[0], b = aos[n - 1];
@@ -457,8 +463,14 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
       live[k] = used && in_tile;
       tl[k] = 0;
     }
-    for (int j = 1; j < Wc; ++j) {  // interior columns of the tile (W - 1 of them: one at C-1M)
-      const u32 A_j = thr[c0 + j];  // uniform load
+#pragma unroll
+    for (int i = 0; i < A_PRE; ++i)  // interior columns of the tile (W - 1 of them: one at C-1M)
+      if (1 + i < Wc) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) tl[k] += av[k] >= A_in[i] ? 1 : 0;
+      }
+    for (int j = 1 + A_PRE; j < Wc; ++j) {  // wide tiles (sparse frames): the rest, one uniform load each
+      const u32 A_j = thr[c0 + j];
 #pragma unroll
       for (int k = 0; k < EPT; ++k) tl[k] += av[k] >= A_j ? 1 : 0;
     }
