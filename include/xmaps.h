@@ -231,6 +231,10 @@ void xm_graph_destroy(xm_graph* g);
  *   xr, yr  : rectify_cam_coords_i16            ts : X-map column (t_scaled, xmd:19)
  *   disp    : xp - xr - x_offset (int16 wrap), defined where the y-mask holds, else 0
  *   mask    : final inlier mask (u8 0/1), y-mask & disp >= 0 (& p == 1 when p given)              */
+/* tests: the column-tile path's exact integer time thresholds thr[0 .. xmap_width] of a frame whose first / last stamps are
+ * t_first / t_last: thr[c] = the smallest a in [0, t_last - t_first + 1] with column(t_first + a) >= c, column() being
+ * `rint(((t - tmin) / (tmax - tmin)) * (xmap_width - 1))` in float64 exactly as python/x_maps_disparity.py:16-19 computes it. */
+int xm_debug_cols_thresholds(xm_handle* h, long long t_first, long long t_last, uint32_t* out_host);
 int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
                            size_t n, int t_dtype, int mem, int16_t* xr, int16_t* yr, int16_t* ts, int16_t* disp,
                            uint8_t* mask);

@@ -493,3 +493,32 @@ def test_random_rigs_and_streams_on_the_tiles(seed):
         pc = eng.path_counts()
         # sorted streams on these rigs take the tiles; a failing frame is redone on the general path (still exact)
         assert pc["cols"] + pc["key32"] + pc["sorted_key64"] + pc["general"] == 2 + eng.sorted_fallbacks()
+
+
+@pytest.mark.parametrize("xmap_w", [2, 7, 64, 640, 1080])
+def test_integer_thresholds_reproduce_the_float64_column_of_every_time_stamp(xmap_w):
+    """K1 never converts a time stamp: it compares a = t - tmin with thr[c].  For spans small enough to enumerate, thr[] must
+    reproduce NumPy's column of EVERY integer stamp in [tmin, tmax] (rint ties included); larger spans are checked at the
+    thresholds themselves and their neighbours."""
+    cfg = S.RigConfig("thr", 64, 48, xmap_w, 48, 0)
+    tb = S.make_tables(cfg)
+    assert tb["proj_x_map"].shape[1] == xmap_w
+    rng = np.random.default_rng(xmap_w)
+    with XMapsEngine(tb) as eng:
+        spans = [0, 1, 2, xmap_w - 1, 2 * (xmap_w - 1), 3 * (xmap_w - 1) + 1, 12_999, 16_600, 99_991] + \
+                [int(v) for v in rng.integers(1, 200_000, 6)]
+        for span in spans:
+            for t0 in (0, 5_000_000, int(rng.integers(0, 2 ** 40)), -12_345):
+                thr = eng.debug_cols_thresholds(t0, t0 + span)
+                a = np.arange(span + 1, dtype=np.int64)
+                col = O.time_to_xmap_column(t0 + a, xmap_w - 1).astype(np.int64)  # tmin, tmax = the array's first / last element
+                want = np.searchsorted(col, np.arange(xmap_w + 1), side="left")    # first a with column >= c; span + 1 if none
+                assert np.array_equal(thr, want.astype(np.uint32)), (span, t0)
+        for span in (2 ** 31 + 12_345, 4_000_000_000, 999_999_937):  # too long to enumerate: check around every threshold
+            t0 = 7_777
+            thr = eng.debug_cols_thresholds(t0, t0 + span).astype(np.int64)
+            probe = np.unique(np.clip(np.concatenate([thr - 1, thr, thr + 1, [0, span]]), 0, span))
+            col = O.time_to_xmap_column(np.concatenate([[t0], t0 + probe, [t0 + span]]), xmap_w - 1).astype(np.int64)[1:-1]
+            for c in range(xmap_w + 1):
+                below, at = probe < thr[c], probe >= thr[c]
+                assert (col[below] < c).all() and (col[at] >= c).all(), (span, c)

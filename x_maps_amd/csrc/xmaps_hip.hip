@@ -1712,6 +1712,25 @@ int xm_debug_timeline(unsigned long long* out /*[64][16]*/) {
 }
 #endif
 
+// tests: the column-tile path's integer time thresholds of a frame with the given first / last stamp (thr[0 .. xmap_w])
+int xm_debug_cols_thresholds(xm_handle* h, long long t_first, long long t_last, uint32_t* out_host) {
+  if (!h || !out_host) return fail(XM_ERR_INVALID, "NULL argument");
+  if ((unsigned long long)(t_last - t_first) >= 0xffffffffull && t_last >= t_first)
+    return fail(XM_ERR_INVALID, "frames of 2^32 us or more do not take the column tiles");
+  XM_ENTER(h);
+  const int n = h->tb.xmap_w + 1;
+  u32* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, sizeof(u32) * n));
+  hipLaunchKernelGGL(k_debug_cols_thresholds, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, h->slots[0].stream, t_first, t_last,
+                     h->tb.t_px_scale, h->tb.xmap_w, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(h->slots[0].stream);
+  if (e == hipSuccess) e = hipMemcpy(out_host, d, sizeof(u32) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return XM_OK;
+}
+
 void* xm_stream(xm_handle* h, int slot) {
   if (!h || slot < 0 || slot >= (int)h->slots.size()) return nullptr;
   return (void*)h->slots[slot].stream;

@@ -133,6 +133,17 @@ __device__ inline u32 cols_threshold(const TimeNorm<long long>& tn, const long l
   return (u32)a;
 }
 
+// debug / tests: thr[c] for c = 0 .. xmap_w of a frame whose first / last stamps are t_first / t_last (what k_cols_bounds writes
+// behind the frame), one thread per column
+__global__ __launch_bounds__(BLOCK) void k_debug_cols_thresholds(long long t_first, long long t_last, int S, int xmap_w,
+                                                                 u32* __restrict__ out) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c > xmap_w) return;
+  if (t_last < t_first) t_last = t_first;
+  const TimeNorm<long long> tn(t_first, t_last, S);
+  out[c] = cols_threshold(tn, t_first, (u32)(t_last - t_first), c, S);
+}
+
 // One narrowing round for the boundary of threshold A: lb = first event with (u64)(t - tmin) >= A.  State: event lo is below
 // (or lo == -1), event hi is at or past it (or hi == n); the answer is hi once hi - lo == 1.  `first`: the interpolated window
 // (64 probes, 64 events apart, centred on the guess) instead of an even split of (lo, hi).  For a stream that is not sorted

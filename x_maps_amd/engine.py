@@ -298,6 +298,12 @@ class XMapsEngine:
                                           _ptr(depth_ptr), _ptr(bgr_ptr), C.byref(g)))
         return XMapsGraph(self, g, len(offs) - 1)
 
+    def debug_cols_thresholds(self, t_first: int, t_last: int) -> np.ndarray:
+        """thr[0 .. xmap_w] of the column-tile path for a frame with these first / last stamps (tests)."""
+        out = np.zeros(self.t_px_scale + 2, np.uint32)
+        N.check(self._lib.xm_debug_cols_thresholds(self._h, int(t_first), int(t_last), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
     # ---- debug: every per-event intermediate -------------------------------------------------------
     def debug_event_outputs(self, x, y, t, p=None):
         x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
