@@ -490,15 +490,15 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
   KeyCells cells{key_frame, 0};
   const bool key32 = kmode == KM_KEY32;
   if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && kmode == KM_COLS) {
-    XM_LAUNCH(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+    XM_LAUNCH(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
               dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
               tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && key32) {
-    XM_LAUNCH(k_frame_proj_tiled<true>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+    XM_LAUNCH(k_frame_proj_tiled<true>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
               dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
               tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
-    XM_LAUNCH(k_frame_proj_tiled<false>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)),
+    XM_LAUNCH(k_frame_proj_tiled<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
               dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
               tag_override, dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
@@ -666,7 +666,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
       prof_slot(2);
       if (!d_descs_redo) {
-        XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+        XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
                   dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
                   (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
         HIP_TRY(hipGetLastError());
@@ -676,7 +676,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       // kernels decide per frame on the device (frame_attempt_failed): K2 on the u16 frame only where the attempt held, then --
       // for the frames where it did not, and for those only: every other block returns at once -- the counters cleared and
       // K0 -> K1 -> K2 on the 64-bit key frame (d_descs_redo = the same frames with key_frame = the slots' 64-bit frames).
-      XM_LAUNCH((k_frame_proj_tiled_batch<2, 2>), dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+      XM_LAUNCH((k_frame_proj_tiled_batch<2, 2>), dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
                 dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
       g_prof = ProfCtx{};
@@ -706,7 +706,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         XM_LAUNCH(k1, dim3(grid_for(n_max, threads * TILE_EPT), n_frames), dim3(threads), h->k1_lds, stream, d_descs_redo, h->tb,
                   h->w_ts, h->w_x, 0);
       }
-      XM_LAUNCH((k_frame_proj_tiled_batch<0, 1>), dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+      XM_LAUNCH((k_frame_proj_tiled_batch<0, 1>), dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
                 dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs_redo, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
       HIP_TRY(hipGetLastError());
@@ -760,11 +760,11 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   prof_slot(2);
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (key32)
-      XM_LAUNCH(k_frame_proj_tiled_batch<true>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+      XM_LAUNCH(k_frame_proj_tiled_batch<true>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
                 dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
     else
-      XM_LAUNCH(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), n_frames),
+      XM_LAUNCH(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
                 dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
   } else {
@@ -1341,7 +1341,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->tb.z_near = cfg->z_near;
   h->tb.z_far = cfg->z_far;
   if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets
-    const unsigned tiles_x = grid_for(cfg->proj_width, K2_TX), tiles_y = grid_for(cfg->proj_height, K2_TY);
+    const unsigned tiles_x = grid_for(cfg->proj_width, K2_TW), tiles_y = grid_for(cfg->proj_height, K2_TY);
     XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_tiles, (size_t)tiles_x * tiles_y * sizeof(int4)));
     XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix, (size_t)cfg->proj_width * cfg->proj_height * sizeof(u32)));
     hipLaunchKernelGGL(k_build_k2_tables, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles, h->d_k2_pix);
@@ -2508,7 +2508,7 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
   hipStream_t stream = h->slots[0].stream;
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (h->k2_direct) return fail(XM_ERR_INVALID, "xm_shard_finish_u16 needs the tiled frame kernel (XM_K2_DIRECT is set)");
-    hipLaunchKernelGGL(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY)), dim3(K2_TX * K2_TY),
+    hipLaunchKernelGGL(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)), dim3(K2_TX * K2_TY),
                        (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, reinterpret_cast<const u64*>(disp_frame), h->tb,
                        h->aux_st, 1u, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth_out, bgr_out, h->k2_tile_cap);
   } else {
@@ -2691,7 +2691,7 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   }
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (!h->k2_direct) {
-      hipLaunchKernelGGL(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TX), grid_for(h->tb.proj_h, K2_TY), 1),
+      hipLaunchKernelGGL(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), 1),
                          dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), s, (const FrameDesc*)g->desc,
                          h->tb, (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
     } else {

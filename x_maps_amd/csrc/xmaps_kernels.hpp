@@ -1536,8 +1536,11 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 //   3. every pixel then needs 7 LDS reads (one per window column) instead of 49.
 // PMC on the 49-tap version: SQ_LDS_IDX_ACTIVE 3.1 M cycles / dispatch -- it was LDS-bound.
 // Falls back to global reads when the patch does not fit (wild maps).
+#ifndef XM_K2_PPT
+#define XM_K2_PPT 2
+#endif
 #ifndef XM_K2_TILE_MAX
-#define XM_K2_TILE_MAX 5120
+#define XM_K2_TILE_MAX (5120 * XM_K2_PPT)
 #endif
 #ifndef XM_K2_TX
 #define XM_K2_TX 16
@@ -1548,6 +1551,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 #else
 #define XM_K2STAMP(ph) do { } while (0)
 #endif
+constexpr int K2_PPT = XM_K2_PPT;  // pixels per thread: a block's tile is K2_TW x K2_TY pixels, thread (tx, ty) takes columns tx + j * K2_TX
+constexpr int K2_TW = XM_K2_TX * K2_PPT;
 constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX;  // 2 x 10 KB of u16: >= 6 blocks per CU, so all
                                                                     // 1200 blocks of a 640x480 frame are resident at once
 
@@ -1561,17 +1566,29 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ int s_box[NW][4];
   const int tid = threadIdx.x, tx = tid % K2_TX, ty = tid / K2_TX;
-  const int u = blockIdx.x * K2_TX + tx, v = blockIdx.y * K2_TY + ty;
-  const bool in_img = u < tb.proj_w && v < tb.proj_h;
-  int mx = 0, my = 0;
-  bool valid = false;
-  if (in_img) {
-    const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u];
-    mx = (int)(short)(m & 0xffff);
-    my = (int)(short)(m >> 16);
-    valid = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;
+  const int v = blockIdx.y * K2_TY + ty;
+  int u[K2_PPT], mx[K2_PPT], my[K2_PPT];
+  bool in_img[K2_PPT], valid[K2_PPT];
+  int x0 = 0x7fffffff, x1 = -0x7fffffff, y0 = 0x7fffffff, y1 = -0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < K2_PPT; ++j) {
+    u[j] = blockIdx.x * K2_TW + tx + j * K2_TX;
+    in_img[j] = u[j] < tb.proj_w && v < tb.proj_h;
+    mx[j] = my[j] = 0;
+    valid[j] = false;
+    if (in_img[j]) {
+      const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u[j]];
+      mx[j] = (int)(short)(m & 0xffff);
+      my[j] = (int)(short)(m >> 16);
+      valid[j] = mx[j] >= 0 && mx[j] < tb.rect_w && my[j] >= 0 && my[j] < tb.rect_h;
+    }
+    if (valid[j]) {
+      x0 = min(x0, mx[j]);
+      x1 = max(x1, mx[j]);
+      y0 = min(y0, my[j]);
+      y1 = max(y1, my[j]);
+    }
   }
-  int x0 = valid ? mx : 0x7fffffff, x1 = valid ? mx : -0x7fffffff, y0 = valid ? my : 0x7fffffff, y1 = valid ? my : -0x7fffffff;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     x0 = min(x0, __shfl_xor(x0, o, 64));
@@ -1594,17 +1611,23 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
     y1 = max(y1, s_box[w][3]);
   }
   int4 rec = make_int4(0, 0, 0, 0);
-  u32 off = ~0u;
+  u32 off[K2_PPT];
+#pragma unroll
+  for (int j = 0; j < K2_PPT; ++j) off[j] = ~0u;
   if (x1 >= x0) {
     // rows start on a multiple of 8: 16-byte loads of 2 (u64 keys), 4 (u32 keys) or 8 (u16 disparities) rows
     const int bx = x0 - 3, by = (y0 - 3) & ~7;
     const int cols = x1 + 3 - bx + 1, rows = y1 + 3 - by + 1, rows_p = (rows + 7) & ~7;
     const bool fits = cols * rows_p <= K2_TILE_MAX;
     rec = make_int4(bx, by, fits ? cols : -1, rows_p);
-    if (valid && fits) off = (u32)((mx - 3 - bx) * rows_p + (my - 3 - by));
+#pragma unroll
+    for (int j = 0; j < K2_PPT; ++j)
+      if (valid[j] && fits) off[j] = (u32)((mx[j] - 3 - bx) * rows_p + (my[j] - 3 - by));
   }
   if (tid == 0) tiles[blockIdx.y * gridDim.x + blockIdx.x] = rec;
-  if (in_img) pix[(u32)v * (u32)tb.proj_w + (u32)u] = off;
+#pragma unroll
+  for (int j = 0; j < K2_PPT; ++j)
+    if (in_img[j]) pix[(u32)v * (u32)tb.proj_w + (u32)u[j]] = off[j];
 }
 
 // blk_lin / grid_x / grid_y = linear block index inside the frame's tile grid and that grid's shape
@@ -1624,7 +1647,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   uint16_t* tile = k2_lds;                  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
   uint16_t* vmax = k2_lds + tile_cap + 16;  // [tile_cap]
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
-  __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TX * 3];
+  __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TW * 3];
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
@@ -1635,29 +1658,33 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   const u32 lin_tile = xcd_contiguous(blk_lin, grid_x * grid_y);
   const u32 tile_y = lin_tile / grid_x, tile_x = lin_tile - tile_y * grid_x;
   const u32 tag = tag_override ? tag_override : st->tag_a;  // first needed when the patch is decoded
-  const int u = tile_x * K2_TX + tx, v = tile_y * K2_TY + ty;
-  const bool in_img = u < tb.proj_w && v < tb.proj_h;
+  const int v = tile_y * K2_TY + ty;
   // the tile's patch rectangle and the pixel's offset into it were computed once in xm_create (k_build_k2_tables)
   const int4 rec = rec_pre ? *rec_pre : tb.k2_tiles[lin_tile];  // block-uniform
-  const u32 pix_i = __umul24((u32)v, (u32)tb.proj_w) + (u32)u;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
-  const u32 poff = in_img ? tb.k2_pix[pix_i] : ~0u;
-  int mx = 0, my = 0;
-  bool valid_g = false;  // generic path only; the tiled path tests poff where it needs it (after the patch loads are out:
-                         // testing it here put a full wait for this load in front of them)
-  int x0 = 0, x1 = -1, y0 = 0, y1 = 0;
-  if (rec.z < 0) {  // patch too large for LDS (wild map): generic path needs the map entry itself
-    if (in_img) {
-      const u32 m = tb.pmap[(u32)v * (u32)tb.proj_w + (u32)u];
-      mx = (int)(short)(m & 0xffff);
-      my = (int)(short)(m >> 16);
-      valid_g = mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h;  // else BORDER_CONSTANT 0
-    }
-    x1 = 0;  // "some pixel maps into the frame": take the branch below, which falls through to the global reads
+  bool in_img[K2_PPT];
+  u32 pix_i[K2_PPT], poff[K2_PPT];
+#pragma unroll
+  for (int j = 0; j < K2_PPT; ++j) {
+    const int u = tile_x * K2_TW + tx + j * K2_TX;
+    in_img[j] = u < tb.proj_w && v < tb.proj_h;
+    pix_i[j] = __umul24((u32)v, (u32)tb.proj_w) + (u32)u;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
+    poff[j] = in_img[j] ? tb.k2_pix[pix_i[j]] : ~0u;
+  }
+  // generic path only; the tiled path tests poff where it needs it (after the patch loads are out: testing it here put a
+  // full wait for this load in front of them)
+  int x0 = 0, x1 = -1;
+  if (rec.z < 0) {  // patch too large for LDS (wild map): generic path needs the map entries themselves
+    x1 = 0;         // "some pixel maps into the frame": take the branch below, which falls through to the global reads
   } else if (rec.z > 0) {
     x1 = 0;
   }
-  float d = 0.0f;  // generic path (a patch too large for LDS)
-  u32 di = 0;      // tiled path: the integer disparity itself (no int -> float -> int round trip: conversions are quarter rate)
+  float d[K2_PPT];  // generic path (a patch too large for LDS)
+  u32 di[K2_PPT];   // tiled path: the integer disparity itself (no int -> float -> int round trip: conversions are quarter rate)
+#pragma unroll
+  for (int j = 0; j < K2_PPT; ++j) {
+    d[j] = 0.0f;
+    di[j] = 0;
+  }
   if (x1 >= x0) {  // at least one pixel of the tile maps into the frame
     const int bx = rec.x, by = rec.y;                    // patch origin (rows start on an even row: 16-byte aligned pairs)
     const int cols = rec.z, rows_p = rec.w;              // column stride in LDS: 16-byte aligned runs
@@ -1931,44 +1958,55 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       XM_K2STAMP(3);
       __syncthreads();
       XM_K2STAMP(4);
-      if (poff != ~0u) {
-        const uint16_t* p = vmax + poff;
-        u32 best = 0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
-        di = best;
-      }
-    } else if (valid_g) {
-      const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
-      if constexpr (U16) {
-        const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
-        for (int xx = xa; xx <= xb; ++xx)
-          for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, (float)d16[(u32)xx * (u32)tb.rect_h + (u32)yy]);
-      } else if constexpr (KEY32) {
-        const u32* keys32 = reinterpret_cast<const u32*>(keys);
-        const u32 tag4 = key32_tag(tag);
-        for (int xx = xa; xx <= xb; ++xx)
-          for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, (float)key_disp32(keys32[(u32)xx * (u32)tb.rect_h + (u32)yy], tag4));
-      } else {
-        KeyCells cells{keys, tag};
-        for (int xx = xa; xx <= xb; ++xx)
-          for (int yy = ya; yy <= yb; ++yy) d = fmaxf(d, cells.at(tb, xx, yy));
+      for (int q = 0; q < K2_PPT; ++q)
+        if (poff[q] != ~0u) {
+          const uint16_t* p = vmax + poff[q];
+          u32 best = 0;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
+          di[q] = best;
+        }
+    } else {
+      for (int q = 0; q < K2_PPT; ++q) {
+        if (!in_img[q]) continue;
+        const u32 m = tb.pmap[pix_i[q]];
+        const int mx = (int)(short)(m & 0xffff), my = (int)(short)(m >> 16);
+        if (!(mx >= 0 && mx < tb.rect_w && my >= 0 && my < tb.rect_h)) continue;  // BORDER_CONSTANT 0
+        const int ya = max(my - 3, 0), yb = min(my + 3, tb.rect_h - 1), xa = max(mx - 3, 0), xb = min(mx + 3, tb.rect_w - 1);
+        float dq = 0.0f;
+        if constexpr (U16) {
+          const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
+          for (int xx = xa; xx <= xb; ++xx)
+            for (int yy = ya; yy <= yb; ++yy) dq = fmaxf(dq, (float)d16[(u32)xx * (u32)tb.rect_h + (u32)yy]);
+        } else if constexpr (KEY32) {
+          const u32* keys32 = reinterpret_cast<const u32*>(keys);
+          const u32 tag4 = key32_tag(tag);
+          for (int xx = xa; xx <= xb; ++xx)
+            for (int yy = ya; yy <= yb; ++yy) dq = fmaxf(dq, (float)key_disp32(keys32[(u32)xx * (u32)tb.rect_h + (u32)yy], tag4));
+        } else {
+          KeyCells cells{keys, tag};
+          for (int xx = xa; xx <= xb; ++xx)
+            for (int yy = ya; yy <= yb; ++yy) dq = fmaxf(dq, cells.at(tb, xx, yy));
+        }
+        d[q] = dq;
       }
     }
   }
   XM_K2STAMP(5);
-  PixelOut o;
+  PixelOut o[K2_PPT];
+#pragma unroll
+  for (int q = 0; q < K2_PPT; ++q) {
 #ifndef XM_K2_NO_DLUT
-  {
-    if (rec.z <= 0) di = (u32)d;  // d is an integer disparity here (max of u16 key fields)
+    if (rec.z <= 0) di[q] = (u32)d[q];  // d is an integer disparity here (max of u16 key fields)
     // (byte offset off the table's base: a scalar-base + 32-bit-offset load instead of a 64-bit multiply-add per pixel)
-    const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tb.dlut) + ((di & 0xffffu) << 3));
-    o.depth = __uint_as_float(e.x);
-    o.bgr = e.y;
-  }
+    const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tb.dlut) + ((di[q] & 0xffffu) << 3));
+    o[q].depth = __uint_as_float(e.x);
+    o[q].bgr = e.y;
 #else
-  o = disparity_pixel(rec.z > 0 ? (float)di : d, tb.p03, tb.z_near, tb.z_far);
+    o[q] = disparity_pixel(rec.z > 0 ? (float)di[q] : d[q], tb.p03, tb.z_near, tb.z_far);
 #endif
+  }
   if (!tag_override && lin_tile == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
     u32* c = st->cnt[(tag & 1) ^ 1][tid];
     c[0] = c[1] = c[2] = c[3] = 0;
@@ -1977,26 +2015,41 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
     }
   }
-  if (depth && in_img) depth[pix_i] = o.depth;
+  if (depth) {
+#pragma unroll
+    for (int q = 0; q < K2_PPT; ++q)
+      if (in_img[q]) depth[pix_i[q]] = o[q].depth;
+  }
   if (bgr) {
-    const bool full_rows = (tb.proj_w & 3) == 0 && (tile_x + 1) * K2_TX <= tb.proj_w;
-    if (full_rows) {  // 96 contiguous bytes per tile row: assemble in LDS, store as dwords
-      s_bgr[ty][tx * 3 + 0] = (uint8_t)(o.bgr & 0xff);
-      s_bgr[ty][tx * 3 + 1] = (uint8_t)((o.bgr >> 8) & 0xff);
-      s_bgr[ty][tx * 3 + 2] = (uint8_t)((o.bgr >> 16) & 0xff);
-      __syncthreads();
-      constexpr int DW = K2_TX * 3 / 4;  // 24 dwords per row
-      if (tid < K2_TY * DW) {
-        const int r = tid / DW, q = tid - r * DW, vv = tile_y * K2_TY + r;
-        if (vv < tb.proj_h)
-          reinterpret_cast<u32*>(bgr + (size_t)((__umul24((u32)vv, (u32)tb.proj_w) + tile_x * K2_TX) * 3u))[q] =
-              reinterpret_cast<const u32*>(&s_bgr[r][0])[q];
+    const bool full_rows = (tb.proj_w & 3) == 0 && (tile_x + 1) * K2_TW <= tb.proj_w;
+    if (full_rows) {  // 3 * K2_TW contiguous bytes per tile row: assemble in LDS, store as dwords
+#pragma unroll
+      for (int q = 0; q < K2_PPT; ++q) {
+        s_bgr[ty][(tx + q * K2_TX) * 3 + 0] = (uint8_t)(o[q].bgr & 0xff);
+        s_bgr[ty][(tx + q * K2_TX) * 3 + 1] = (uint8_t)((o[q].bgr >> 8) & 0xff);
+        s_bgr[ty][(tx + q * K2_TX) * 3 + 2] = (uint8_t)((o[q].bgr >> 16) & 0xff);
       }
-    } else if (in_img) {
-      uint8_t* b = bgr + ((u64)v * tb.proj_w + u) * 3;
-      b[0] = (uint8_t)(o.bgr & 0xff);
-      b[1] = (uint8_t)((o.bgr >> 8) & 0xff);
-      b[2] = (uint8_t)((o.bgr >> 16) & 0xff);
+      __syncthreads();
+      constexpr int DW = K2_TW * 3 / 4;  // dwords per row
+#pragma unroll
+      for (int i0 = 0; i0 < K2_TY * DW; i0 += NT) {
+        const int i = i0 + tid;
+        if (i < K2_TY * DW) {
+          const int r = i / DW, q = i - r * DW, vv = tile_y * K2_TY + r;
+          if (vv < tb.proj_h)
+            reinterpret_cast<u32*>(bgr + (size_t)((__umul24((u32)vv, (u32)tb.proj_w) + tile_x * K2_TW) * 3u))[q] =
+                reinterpret_cast<const u32*>(&s_bgr[r][0])[q];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < K2_PPT; ++q)
+        if (in_img[q]) {
+          uint8_t* b = bgr + (u64)pix_i[q] * 3;
+          b[0] = (uint8_t)(o[q].bgr & 0xff);
+          b[1] = (uint8_t)((o[q].bgr >> 8) & 0xff);
+          b[2] = (uint8_t)((o[q].bgr >> 16) & 0xff);
+        }
     }
   }
   XM_K2STAMP(6);
