@@ -643,7 +643,7 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
 template <typename T, bool AOS, bool HAS_P>
 int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
                    hipStream_t stream, bool key32 = false, int cols_w = 0, hipEvent_t* prof = nullptr,
-                   const FrameDesc* d_descs_redo = nullptr) {
+                   const FrameDesc* d_descs_redo = nullptr, bool direct_k1 = false) {
   // prof = 6 events {start0, stop0, start1, stop1, start2, stop2} attached to the dispatch packets of K0 / K0b, K1, K2
   struct ProfReset {
     ~ProfReset() { g_prof = ProfCtx{}; }
@@ -736,6 +736,12 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   constexpr bool kHasVec = !AOS && std::is_same<T, long long>::value;
   auto launch_k1 = [&](auto view_tag) -> int {
     constexpr int VIEW = decltype(view_tag)::value;
+    if (direct_k1) {  // frames too sparse for the tiles: one thread per event, grid = (blocks of the largest frame, frames)
+      prof_slot(1);
+      XM_LAUNCH((k_scatter_direct_batch<T, AOS, HAS_P, VIEW>), dim3(std::max(1u, grid_for(n_max, BLOCK)), n_frames), dim3(BLOCK), 0,
+                stream, d_descs, h->tb);
+      return XM_OK;
+    }
     auto kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, false>;
     if constexpr (kHasVec) {
       if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, true>;
@@ -815,7 +821,12 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
       s.eager_dirty = false;
     }
   }
-  if (!batch_path(h, n_mean)) {  // sparse frames / untiled kernels: frame by frame, still on the group's stream
+  // frames too sparse for the tiled K1 (the reference's own recordings: ~150 k events over 1080 time columns): the multi-frame
+  // K0 and K2 with the one-thread-per-event K1 in between -- three launches per group instead of three per frame
+  const bool direct_k1 = !batch_path(h, n_mean) && !(h->cfg.view == XM_VIEW_PROJECTOR && (h->k2_direct || !h->d_k2_tiles)) &&
+                         !h->k2_flags && n_frames >= 2 && n_max < (1ull << 31);
+  if (direct_k1) sorted = false;  // (t[0], t[n-1]) is verified by the tiled kernels only: K0 runs
+  if (!batch_path(h, n_mean) && !direct_k1) {  // untiled K2: frame by frame, still on the group's stream
     for (int f = 0; f < n_frames; ++f) {
       int rc = enqueue_frame(h, h->slots[slot_idx[f]], evs[f], depth[f], bgr[f], nullptr, allow_sorted, stream);
       if (rc) return rc;
@@ -828,7 +839,7 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
     if (!cols_path(h, evs[f], sorted) || (evs[f].aos != nullptr) != (e0.aos != nullptr)) cols_w = 0;
   // a batch that is being captured into a hipGraph: the column tiles with the redo decided on the device (launch_batch_t)
   // (groups of >= 2 frames: a lone frame's seven launches -- four of them returning at once -- take longer than K0 -> K1 -> K2)
-  const bool dev_redo = h->capturing && !cols_w && d_descs_redo && h->cols_ok && !h->k2_direct && !h->k2_flags && n_frames >= 2;
+  const bool dev_redo = h->capturing && !cols_w && !direct_k1 && d_descs_redo && h->cols_ok && !h->k2_direct && !h->k2_flags && n_frames >= 2;
   if (dev_redo) {
     cols_w = cols_width(h, n_mean);
     for (int f = 0; f < n_frames && cols_w; ++f)
@@ -867,15 +878,15 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   }
   if (upload) HIP_TRY(hipMemcpyAsync(d_descs, h_descs, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, stream));
   int rc;
-  if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32)
-                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w, prof, redo_descs ? d_descs_redo : nullptr);
+  if (e0.aos) rc = e0.use_p ? launch_batch_t<long long, true, true>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, 0, nullptr, nullptr, direct_k1)
+                            : launch_batch_t<long long, true, false>(h, d_descs, n_frames, n_max, n_mean, false, sorted, stream, use32, cols_w, prof, redo_descs ? d_descs_redo : nullptr, direct_k1);
   else switch (e0.t_dtype) {
-    case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
-                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w, prof, redo_descs ? d_descs_redo : nullptr); break;
-    case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
-                                     : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32); break;
-    default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32)
-                           : launch_batch_t<double, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32);
+    case XM_T_INT64: rc = e0.use_p ? launch_batch_t<long long, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, 0, nullptr, nullptr, direct_k1)
+                                   : launch_batch_t<long long, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, cols_w, prof, redo_descs ? d_descs_redo : nullptr, direct_k1); break;
+    case XM_T_FLOAT32: rc = e0.use_p ? launch_batch_t<float, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, 0, nullptr, nullptr, direct_k1)
+                                     : launch_batch_t<float, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, 0, nullptr, nullptr, direct_k1); break;
+    default: rc = e0.use_p ? launch_batch_t<double, false, true>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, 0, nullptr, nullptr, direct_k1)
+                           : launch_batch_t<double, false, false>(h, d_descs, n_frames, n_max, n_mean, vec16, sorted, stream, use32, 0, nullptr, nullptr, direct_k1);
   }
   if (rc) return rc;
   if (kinds) {  // which launches the group consisted of: {K0 general / K0b bounds / none, K1 variant}

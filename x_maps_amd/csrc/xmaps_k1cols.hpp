@@ -150,22 +150,13 @@ __global__ __launch_bounds__(BLOCK) void k_debug_cols_thresholds(long long t_fir
 // this is still a deterministic function of (stream, A): neighbouring tiles read the same boundary, and the per-event
 // verification of K1 catches the rest.
 template <bool AOS>
-__device__ __forceinline__ void cols_search_round(gp_i64 ts, gp_u4 aos, const int n, const long long tmin, const u32 A, int& lo,
-                                                  int& hi, const int guess, const bool first) {
-  const int lane = threadIdx.x & 63;
-  const int span = hi - lo - 1;  // unknown positions lo+1 .. hi-1 (> 0: the caller loops while hi - lo > 1)
-  int p;
-  bool act;
-  if (first) {
-    p = min(max(guess + (lane - 32) * 64, 0), n - 1);
-    act = true;
-  } else {
-    const int stride = (span + 63) >> 6;
-    p = lo + (lane + 1) * stride;
-    act = p < hi;
-  }
-  const long long tv = cols_t_at<AOS>(ts, aos, act ? p : 0);
-  const bool pr = act && (u64)(tv - tmin) >= (u64)A;
+__device__ __forceinline__ int cols_x_at(gp_u16 xs, gp_u4 aos, int i) {
+  if constexpr (AOS) return (int)(aos[i].x & 0xffff);
+  else return (int)xs[i];
+}
+
+// the verdict of one round of probes: lane's probe p (active: act) is at or past the boundary: pr
+__device__ __forceinline__ void cols_narrow(const int p, const bool act, const bool pr, int& lo, int& hi) {
   const u64 bal = __ballot(pr), bact = __ballot(act);
   if (bal == 0) {  // every probe is still below the boundary: lo = the largest probe
     const int top = 63 - __builtin_clzll(bact);
@@ -175,6 +166,30 @@ __device__ __forceinline__ void cols_search_round(gp_i64 ts, gp_u4 aos, const in
     hi = __shfl(p, j, 64);
     if (j > 0) lo = max(lo, __shfl(p, j - 1, 64));
   }
+}
+
+// One narrowing round for the boundary of threshold A: lb = first event with (u64)(t - tmin) >= A.  State: event lo is below
+// (or lo == -1), event hi is at or past it (or hi == n); the answer is hi once hi - lo == 1.  An even split of (lo, hi) into 64
+// probes.  For a stream that is not sorted this is still a deterministic function of (stream, A): neighbouring tiles read the
+// same boundary, and the per-event verification of K1 catches the rest.  A round of consecutive probes (the last one) also
+// fetches their x: x_base = the position of lane 0's probe (else -1), x_cnt probes, xp the lane's x.
+template <bool AOS>
+__device__ __forceinline__ void cols_search_round(gp_u16 xs, gp_i64 ts, gp_u4 aos, const long long tmin, const u32 A, int& lo, int& hi,
+                                                  int& x_base, int& x_cnt, int& xp) {
+  const int lane = threadIdx.x & 63;
+  const int span = hi - lo - 1;  // unknown positions lo+1 .. hi-1 (> 0: the caller loops while hi - lo > 1)
+  const int stride = (span + 63) >> 6;
+  const int p = lo + (lane + 1) * stride;
+  const bool act = p < hi;
+  const long long tv = cols_t_at<AOS>(ts, aos, act ? p : 0);
+  if (stride == 1) {
+    xp = cols_x_at<AOS>(xs, aos, act ? p : 0);
+    x_base = lo + 1;
+    x_cnt = span;
+  } else {
+    x_base = -1;
+  }
+  cols_narrow(p, act, act && (u64)(tv - tmin) >= (u64)A, lo, hi);
 }
 
 // ---- K0b: the tile boundaries of one frame, one wave per boundary ----------------------------------------------------------------
@@ -214,6 +229,20 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
     t_first = ts[0];
     t_last = ts[n - 1];
   }
+  // The first round of probes goes out together with the frame's first / last stamp: an evenly filled scan has the first
+  // event of column c near n (c - 1/2) / S (the threshold itself is (c - 1/2) span / S rounded), so where to probe does not
+  // depend on anything loaded -- 64 probes, 64 events apart, centred on the guess.  A wave of this kernel is a chain of
+  // dependent round trips at loaded-memory latency (its arithmetic hides behind them): stamps -> probes -> probes -> x was four
+  // of them, now it is two (the last round's probes fetch their x as well).
+  const int c = min(j * W, tb.xmap_w);
+  const bool search = c > 0 && c < tb.xmap_w;  // else: boundary 0 is event 0, the last tile takes whatever is left
+  int p1 = 0;
+  T tv1 = 0;
+  if (search) {
+    const double g = ((double)c - 0.5) / (double)max(tb.t_px_scale, 1) * (double)n;
+    p1 = min(max((int)fmin(fmax(g, 0.0), (double)(n - 1)) + (lane - 32) * 64, 0), n - 1);
+    tv1 = cols_t_at<AOS>(ts, aos, p1);
+  }
   if (t_last < t_first) t_last = t_first;  // not sorted at all: keep the arithmetic defined; K1's verification flags the frame
   const u64 span64 = (u64)(t_last - t_first);
   if (span64 >= 0xffffffffull) {  // a - tmin does not fit 32 bits: not this path
@@ -223,7 +252,6 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   const u32 span = (u32)span64;
   const TimeNorm<T> tn(t_first, t_last, tb.t_px_scale);
   // thresholds of this boundary's column and of the interior columns behind it (lane l: column j W + l)
-  const int c = min(j * W, tb.xmap_w);
   u32 A = 0;
   if (lane < W && c + lane <= tb.xmap_w && (lane == 0 || j < nb)) {
     A = cols_threshold(tn, t_first, span, c + lane, tb.t_px_scale);
@@ -232,20 +260,20 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   A = __shfl(A, 0, 64);
   int lo = -1, hi = n;
   if (c <= 0) hi = 0;
-  if (c >= tb.xmap_w) lo = n - 1;  // the last tile takes whatever is left
+  if (c >= tb.xmap_w) lo = n - 1;
+  int x_base = -1, x_cnt = 0, xp = 0;
   if (hi - lo > 1) {
-    // an evenly filled scan has the first event of column c near n A / span
-    const double g = (double)A / (double)max(span, 1u) * (double)n;
-    cols_search_round<AOS>(ts, aos, n, t_first, A, lo, hi, (int)fmin(fmax(g, 0.0), (double)(n - 1)), true);
-    while (hi - lo > 1) cols_search_round<AOS>(ts, aos, n, t_first, A, lo, hi, 0, false);
+    cols_narrow(p1, true, (u64)(tv1 - t_first) >= (u64)A, lo, hi);
+    while (hi - lo > 1) cols_search_round<AOS>(xs, ts, aos, t_first, A, lo, hi, x_base, x_cnt, xp);
   }
   const int lb = hi;
-  int xv = 0;
-  if (lane < 6) {
-    const int i = lane < 3 ? min(lb + lane, n - 1) : max(lb - 1 - (lane - 3), 0);
-    if constexpr (AOS) xv = (int)(aos[i].x & 0xffff);
-    else xv = (int)xs[i];
-  }
+  // median x of the three events at / behind the boundary and of the three in front of it: from the last round's probes where
+  // they cover them (63 of 64 boundaries), else loaded now
+  const int i = lane < 3 ? min(lb + lane, n - 1) : max(lb - 1 - (lane - 3), 0);
+  const int src = i - x_base;
+  const bool from_probe = x_base >= 0 && src >= 0 && src < x_cnt;
+  int xv = __shfl(xp, src & 63, 64);
+  if (lane < 6 && !from_probe) xv = cols_x_at<AOS>(xs, aos, i);
   const int a0 = __shfl(xv, 0, 64), a1 = __shfl(xv, 1, 64), a2 = __shfl(xv, 2, 64);
   const int e0 = __shfl(xv, 3, 64), e1 = __shfl(xv, 4, 64), e2 = __shfl(xv, 5, 64);
   if (lane == 0)
