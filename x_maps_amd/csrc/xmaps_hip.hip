@@ -465,10 +465,10 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W) {
 void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
   const unsigned nb = grid_for(h->tb.xmap_w, W);
   if (ev.aos)
-    XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_WAVES)), dim3(64 * COLS_BOUNDS_WAVES), 0, stream, ev.x,
+    XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
               (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16);
   else
-    XM_LAUNCH(k_cols_bounds<false>, dim3(grid_for(nb + 1, COLS_BOUNDS_WAVES)), dim3(64 * COLS_BOUNDS_WAVES), 0, stream, ev.x,
+    XM_LAUNCH(k_cols_bounds<false>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
               (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16);
 }
 
@@ -659,8 +659,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
       if (rc) return rc;
       prof_slot(0);
-      XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_WAVES), n_frames),
-                dim3(64 * COLS_BOUNDS_WAVES), 0, stream, d_descs, h->tb, cols_w);
+      XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
+                dim3(256), 0, stream, d_descs, h->tb, cols_w);
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));

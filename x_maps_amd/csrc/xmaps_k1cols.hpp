@@ -144,61 +144,63 @@ __global__ __launch_bounds__(BLOCK) void k_debug_cols_thresholds(long long t_fir
   out[c] = cols_threshold(tn, t_first, (u32)(t_last - t_first), c, S);
 }
 
-// One narrowing round for the boundary of threshold A: lb = first event with (u64)(t - tmin) >= A.  State: event lo is below
-// (or lo == -1), event hi is at or past it (or hi == n); the answer is hi once hi - lo == 1.  `first`: the interpolated window
-// (64 probes, 64 events apart, centred on the guess) instead of an even split of (lo, hi).  For a stream that is not sorted
-// this is still a deterministic function of (stream, A): neighbouring tiles read the same boundary, and the per-event
-// verification of K1 catches the rest.
 template <bool AOS>
 __device__ __forceinline__ int cols_x_at(gp_u16 xs, gp_u4 aos, int i) {
   if constexpr (AOS) return (int)(aos[i].x & 0xffff);
   else return (int)xs[i];
 }
 
-// the verdict of one round of probes: lane's probe p (active: act) is at or past the boundary: pr
-__device__ __forceinline__ void cols_narrow(const int p, const bool act, const bool pr, int& lo, int& hi) {
-  const u64 bal = __ballot(pr), bact = __ballot(act);
-  if (bal == 0) {  // every probe is still below the boundary: lo = the largest probe
-    const int top = 63 - __builtin_clzll(bact);
-    lo = max(lo, __shfl(p, top, 64));
-  } else {
-    const int j = __builtin_ctzll(bal);  // first probe at or past the boundary (probes are non-decreasing in the lane)
-    hi = __shfl(p, j, 64);
-    if (j > 0) lo = max(lo, __shfl(p, j - 1, 64));
+// ---- K0b's search: COLS_BOUNDS_LANES lanes per boundary ------------------------------------------------------------------------
+// lb = first event with (u64)(t - tmin) >= A.  State per boundary: event lo is below (or lo == -1), event hi is at or past it (or
+// hi == n); the answer is hi once hi - lo == 1.  Round 1: G probes, G * FIN events apart, centred on where an evenly filled scan
+// has the boundary (known before anything is loaded).  Last round (<= G * FIN unknown positions): every lane takes FIN consecutive
+// events, t and x -- the boundary AND the six x values around it (the camera-column window of K1) come out of one round trip.
+// In between (a guess that missed by more than G * FIN * G / 2 events: bursts, unsorted streams): even splits into G probes.
+// For a stream that is not sorted the result is still a deterministic function of (stream, A): neighbouring tiles read the same
+// boundary, and the per-event verification of K1 catches the rest.
+constexpr int COLS_BOUNDS_LANES = 32, COLS_BOUNDS_FIN = 4;
+constexpr int COLS_BOUNDS_PER_BLOCK = 256 / COLS_BOUNDS_LANES;
+
+// probes of one round, FIN per lane in probing order (lane-major), act[k] / pr[k] = probed / at or past the boundary, q[k] their
+// positions (non-decreasing in probing order): narrow (lo, hi).  Executed by the whole wave; gl = the group's first lane.
+__device__ __forceinline__ void cols_narrow(const int (&q)[COLS_BOUNDS_FIN], const bool (&act)[COLS_BOUNDS_FIN],
+                                            const bool (&pr)[COLS_BOUNDS_FIN], const int gl, int& lo, int& hi) {
+  constexpr int G = COLS_BOUNDS_LANES, FIN = COLS_BOUNDS_FIN;
+  int kk = FIN, last_q = -1;  // the lane's first probe at or past the boundary; its last probe
+  bool any_act = false;
+#pragma unroll
+  for (int k = FIN - 1; k >= 0; --k) {
+    if (pr[k]) kk = k;
+    if (act[k] && last_q < 0) last_q = q[k];
+    any_act = any_act || act[k];
+  }
+  int pos = q[0], prev = -1;  // position of that probe, and of the lane's probe in front of it (-1: it is the lane's first)
+#pragma unroll
+  for (int k = 1; k < FIN; ++k)
+    if (kk == k) {
+      pos = q[k];
+      prev = q[k - 1];
+    }
+  const u64 group_mask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  const u64 gb = (__ballot(kk < FIN) >> gl) & group_mask, ga = (__ballot(any_act) >> gl) & group_mask;
+  const int jj = gb ? __builtin_ctzll(gb) : 0, top = ga ? 63 - __builtin_clzll(ga) : 0;
+  const int p_hit = __shfl(pos, gl + jj, 64), p_prev = __shfl(prev, gl + jj, 64);
+  const int p_before = __shfl(last_q, gl + max(jj - 1, 0), 64), p_top = __shfl(last_q, gl + top, 64);
+  if (gb) {
+    hi = p_hit;
+    if (p_prev >= 0) lo = max(lo, p_prev);
+    else if (jj > 0) lo = max(lo, p_before);
+  } else if (ga) {
+    lo = max(lo, p_top);  // every probe is still below the boundary
   }
 }
 
-// One narrowing round for the boundary of threshold A: lb = first event with (u64)(t - tmin) >= A.  State: event lo is below
-// (or lo == -1), event hi is at or past it (or hi == n); the answer is hi once hi - lo == 1.  An even split of (lo, hi) into 64
-// probes.  For a stream that is not sorted this is still a deterministic function of (stream, A): neighbouring tiles read the
-// same boundary, and the per-event verification of K1 catches the rest.  A round of consecutive probes (the last one) also
-// fetches their x: x_base = the position of lane 0's probe (else -1), x_cnt probes, xp the lane's x.
-template <bool AOS>
-__device__ __forceinline__ void cols_search_round(gp_u16 xs, gp_i64 ts, gp_u4 aos, const long long tmin, const u32 A, int& lo, int& hi,
-                                                  int& x_base, int& x_cnt, int& xp) {
-  const int lane = threadIdx.x & 63;
-  const int span = hi - lo - 1;  // unknown positions lo+1 .. hi-1 (> 0: the caller loops while hi - lo > 1)
-  const int stride = (span + 63) >> 6;
-  const int p = lo + (lane + 1) * stride;
-  const bool act = p < hi;
-  const long long tv = cols_t_at<AOS>(ts, aos, act ? p : 0);
-  if (stride == 1) {
-    xp = cols_x_at<AOS>(xs, aos, act ? p : 0);
-    x_base = lo + 1;
-    x_cnt = span;
-  } else {
-    x_base = -1;
-  }
-  cols_narrow(p, act, act && (u64)(tv - tmin) >= (u64)A, lo, hi);
-}
-
-// ---- K0b: the tile boundaries of one frame, one wave per boundary ----------------------------------------------------------------
+// ---- K0b: the tile boundaries of one frame, half a wave per boundary ----------------------------------------------------------------
 // bounds[j] = {lb(j * W), median x of the three events at / behind it, median x of the three events in front of it, 0} for
 // j = 0 .. nb (nb = ceil(xmap_w / W) tiles; bounds[nb].x = n), thr[c] for c = 0 .. xmap_w (see cols_threshold).  Tile j of K1
 // owns events [bounds[j].x, bounds[j+1].x) and centres its camera-column window between bounds[j].y and bounds[j+1].z.
 // Kept out of K1 on purpose: inside K1 the search is two to three dependent round trips at the head of every tile's chain,
 // with the tile's other waves parked at a barrier.  A frame that spans 2^32 us or more gets bounds[j].x = -1: K1 objects.
-constexpr int COLS_BOUNDS_WAVES = 4;
 
 // where the bounds and the thresholds live: behind the slot's u16 frame (one allocation, one pointer in the frame descriptor)
 __host__ __device__ inline size_t cols_bounds_offset(size_t key_cells) { return (key_cells * 2 + 63) & ~(size_t)63; }
@@ -216,10 +218,13 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   const size_t key_cells = (size_t)tb.rect_w * (size_t)tb.rect_h;
   XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
   XM_GLOBAL u32* thr = (XM_GLOBAL u32*)(frame_base + cols_thr_offset(key_cells, tb.xmap_w));
-  const int lane = threadIdx.x & 63;
+  constexpr int G = COLS_BOUNDS_LANES, FIN = COLS_BOUNDS_FIN;
+  const int lane = threadIdx.x & 63, sl = lane & (G - 1), gl = lane & ~(G - 1);
   const int nb = (tb.xmap_w + W - 1) / W;
-  const int j = (int)blk * COLS_BOUNDS_WAVES + (int)(threadIdx.x >> 6);
-  if (j > nb) return;  // wave-uniform
+  const int j_raw = (int)blk * COLS_BOUNDS_PER_BLOCK + (int)threadIdx.x / G;
+  const bool live = j_raw <= nb;  // (a group past the last boundary runs along with its wave and stores nothing)
+  if (!__any(live)) return;       // wave-uniform
+  const int j = min(j_raw, nb);
   T t_first, t_last;
   if constexpr (AOS) {
     const uint4 a = aos[0], b = aos[n - 1];
@@ -231,64 +236,103 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   }
   // The first round of probes goes out together with the frame's first / last stamp: an evenly filled scan has the first
   // event of column c near n (c - 1/2) / S (the threshold itself is (c - 1/2) span / S rounded), so where to probe does not
-  // depend on anything loaded -- 64 probes, 64 events apart, centred on the guess.  A wave of this kernel is a chain of
-  // dependent round trips at loaded-memory latency (its arithmetic hides behind them): stamps -> probes -> probes -> x was four
-  // of them, now it is two (the last round's probes fetch their x as well).
+  // depend on anything loaded.  A wave of this kernel is a chain of dependent round trips at loaded-memory latency (its
+  // arithmetic hides behind them): stamps -> probes -> probes -> x was four of them, now it is two.
   const int c = min(j * W, tb.xmap_w);
-  const bool search = c > 0 && c < tb.xmap_w;  // else: boundary 0 is event 0, the last tile takes whatever is left
-  int p1 = 0;
-  T tv1 = 0;
+  const bool search = live && c > 0 && c < tb.xmap_w;  // else: boundary 0 is event 0, the last tile takes whatever is left
+  int q[FIN];
+  bool act[FIN], pr[FIN];
+  T tv[FIN];
+#pragma unroll
+  for (int k = 0; k < FIN; ++k) {
+    q[k] = 0;
+    act[k] = pr[k] = false;
+    tv[k] = 0;
+  }
   if (search) {
     const double g = ((double)c - 0.5) / (double)max(tb.t_px_scale, 1) * (double)n;
-    p1 = min(max((int)fmin(fmax(g, 0.0), (double)(n - 1)) + (lane - 32) * 64, 0), n - 1);
-    tv1 = cols_t_at<AOS>(ts, aos, p1);
+    q[0] = min(max((int)fmin(fmax(g, 0.0), (double)(n - 1)) + (sl - G / 2) * (G * FIN), 0), n - 1);
+    tv[0] = cols_t_at<AOS>(ts, aos, q[0]);
   }
   if (t_last < t_first) t_last = t_first;  // not sorted at all: keep the arithmetic defined; K1's verification flags the frame
   const u64 span64 = (u64)(t_last - t_first);
   if (span64 >= 0xffffffffull) {  // a - tmin does not fit 32 bits: not this path
-    if (lane == 0) bounds[j] = make_int4(-1, 0, 0, 0);
+    if (sl == 0 && live) bounds[j] = make_int4(-1, 0, 0, 0);
     return;
   }
   const u32 span = (u32)span64;
   const TimeNorm<T> tn(t_first, t_last, tb.t_px_scale);
-  // thresholds of this boundary's column and of the interior columns behind it (lane l: column j W + l)
+  // thresholds of this boundary's column and of the interior columns behind it (lane l of the group: column j W + l)
   u32 A = 0;
-  if (lane < W && c + lane <= tb.xmap_w && (lane == 0 || j < nb)) {
-    A = cols_threshold(tn, t_first, span, c + lane, tb.t_px_scale);
-    thr[c + lane] = A;
+  if (live && sl < W && c + sl <= tb.xmap_w && (sl == 0 || j < nb)) {
+    A = cols_threshold(tn, t_first, span, c + sl, tb.t_px_scale);
+    thr[c + sl] = A;
   }
-  A = __shfl(A, 0, 64);
+  A = __shfl(A, gl, 64);
   int lo = -1, hi = n;
-  if (c <= 0) hi = 0;
-  if (c >= tb.xmap_w) lo = n - 1;
-  int x_base = -1, x_cnt = 0, xp = 0;
-  if (hi - lo > 1) {
-    cols_narrow(p1, true, (u64)(tv1 - t_first) >= (u64)A, lo, hi);
-    while (hi - lo > 1) cols_search_round<AOS>(xs, ts, aos, t_first, A, lo, hi, x_base, x_cnt, xp);
+  if (c <= 0 || !live) hi = 0;
+  else if (c >= tb.xmap_w) lo = n - 1;
+  if (hi - lo > 1) {  // == search
+    act[0] = true;
+    pr[0] = (u64)(tv[0] - t_first) >= (u64)A;
+  }
+  cols_narrow(q, act, pr, gl, lo, hi);
+  int x_base = -1, x_cnt = 0;
+  u64 x4 = 0;  // the lane's FIN x values of the last round, 16 bits each
+  while (__any(hi - lo > 1)) {
+    const bool need = hi - lo > 1;
+    const int unknown = hi - lo - 1;          // positions lo + 1 .. hi - 1
+    const bool fin = unknown <= G * FIN;      // consecutive events: this round settles the boundary
+    const int stride = (unknown + G - 1) / G;
+    u32 xk[FIN];
+#pragma unroll
+    for (int k = 0; k < FIN; ++k) {
+      q[k] = fin ? lo + 1 + FIN * sl + k : lo + (sl + 1) * stride;
+      act[k] = need && q[k] < hi && (fin || k == 0);
+      xk[k] = 0;
+      if constexpr (AOS) {
+        const uint4 r = aos[act[k] ? q[k] : 0];
+        tv[k] = (T)(((u64)r.w << 32) | r.z);
+        xk[k] = r.x & 0xffffu;
+      } else {
+        tv[k] = ts[act[k] ? q[k] : 0];
+        if (fin) xk[k] = xs[act[k] ? q[k] : 0];
+      }
+      pr[k] = act[k] && (u64)(tv[k] - t_first) >= (u64)A;
+    }
+    if (need) {
+      x_base = fin ? lo + 1 : -1;
+      x_cnt = unknown;
+      x4 = 0;
+#pragma unroll
+      for (int k = 0; k < FIN; ++k) x4 |= (u64)xk[k] << (16 * k);
+    }
+    cols_narrow(q, act, pr, gl, lo, hi);
   }
   const int lb = hi;
   // median x of the three events at / behind the boundary and of the three in front of it: from the last round's probes where
-  // they cover them (63 of 64 boundaries), else loaded now
-  const int i = lane < 3 ? min(lb + lane, n - 1) : max(lb - 1 - (lane - 3), 0);
+  // they cover them, else loaded now
+  const int i = sl < 3 ? min(lb + sl, n - 1) : max(lb - 1 - (sl - 3), 0);
   const int src = i - x_base;
   const bool from_probe = x_base >= 0 && src >= 0 && src < x_cnt;
-  int xv = __shfl(xp, src & 63, 64);
-  if (lane < 6 && !from_probe) xv = cols_x_at<AOS>(xs, aos, i);
-  const int a0 = __shfl(xv, 0, 64), a1 = __shfl(xv, 1, 64), a2 = __shfl(xv, 2, 64);
-  const int e0 = __shfl(xv, 3, 64), e1 = __shfl(xv, 4, 64), e2 = __shfl(xv, 5, 64);
-  if (lane == 0)
+  const u64 got = __shfl(x4, gl + ((src >> 2) & (G - 1)), 64);
+  int xv = (int)((got >> (16 * (src & 3))) & 0xffffull);
+  if (sl < 6 && live && !from_probe) xv = cols_x_at<AOS>(xs, aos, i);
+  const int a0 = __shfl(xv, gl + 0, 64), a1 = __shfl(xv, gl + 1, 64), a2 = __shfl(xv, gl + 2, 64);
+  const int e0 = __shfl(xv, gl + 3, 64), e1 = __shfl(xv, gl + 4, 64), e2 = __shfl(xv, gl + 5, 64);
+  if (sl == 0 && live)
     bounds[j] = make_int4(lb, max(min(a0, a1), min(max(a0, a1), a2)), max(min(e0, e1), min(max(e0, e1), e2)), 0);
 }
 
 template <bool AOS>
-__global__ __launch_bounds__(64 * COLS_BOUNDS_WAVES) void k_cols_bounds(const uint16_t* __restrict__ xs, const long long* __restrict__ ts,
+__global__ __launch_bounds__(256) void k_cols_bounds(const uint16_t* __restrict__ xs, const long long* __restrict__ ts,
                                                                         const uint4* __restrict__ aos, u32 n, DevTables tb, int W,
                                                                         uint16_t* __restrict__ frame16) {
   cols_bounds_body<AOS>((gp_u16)xs, (gp_i64)ts, (gp_u4)aos, (int)n, tb, W, (XM_GLOBAL unsigned char*)frame16, blockIdx.x);
 }
 
 template <bool AOS>
-__global__ __launch_bounds__(64 * COLS_BOUNDS_WAVES) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W) {
+__global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W) {
   const FrameDesc d = descs[blockIdx.y];
   if (!d.valid || d.n == 0) return;
   cols_bounds_body<AOS>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x);
