@@ -1630,6 +1630,27 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, 
     if (in_img[j]) pix[(u32)v * (u32)tb.proj_w + (u32)u[j]] = off[j];
 }
 
+// 7-tap max along 8 consecutive rows of a patch column: inputs e[0..13] = the 16 bytes a (rows r .. r+7) and b (rows r+8 .. r+15),
+// outputs o[j] = max(e[j] .. e[j+6]), j = 0..7.  Packed 16-bit arithmetic (v_pk_max_u16): P_k = (e[2k], e[2k+1]) as loaded,
+// S_k = (e[2k+1], e[2k+2]) by a 16-bit funnel shift; (o[2j], o[2j+1]) = max(P_j, S_j, P_j+1, S_j+1, P_j+2, S_j+2, P_j+3):
+// 24 instructions instead of 72 for unpack + 48 scalar maxima + pack
+__device__ __forceinline__ uint4 k2_rowmax8(const uint4 a, const uint4 b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const auto pk = [](u32 v) { u16x2 r; __builtin_memcpy(&r, &v, 4); return r; };
+  const auto up = [](u16x2 v) { u32 r; __builtin_memcpy(&r, &v, 4); return r; };
+  const auto mx = [](u16x2 x, u16x2 y) { return __builtin_elementwise_max(x, y); };
+  const u32 P[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+  u16x2 M[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) M[k] = mx(pk(P[k]), pk(__builtin_amdgcn_alignbit(P[k + 1], P[k], 16)));
+  uint4 w;
+  w.x = up(mx(mx(M[0], M[1]), mx(M[2], pk(P[3]))));
+  w.y = up(mx(mx(M[1], M[2]), mx(M[3], pk(P[4]))));
+  w.z = up(mx(mx(M[2], M[3]), mx(M[4], pk(P[5]))));
+  w.w = up(mx(mx(M[3], M[4]), mx(M[5], pk(P[6]))));
+  return w;
+}
+
 // blk_lin / grid_x / grid_y = linear block index inside the frame's tile grid and that grid's shape
 // FMT: what `keys` points at -- 0: the 64-bit packed-key frame; 1: the compact 32-bit key frame of the verified-sorted path
 // (see key32_tag); 2: a plain u16 disparity frame, no tags (sharded frames after reduce-scatter + all-gather, xm_shard_finish_u16)
@@ -1931,29 +1952,13 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       XM_K2STAMP(1);
       __syncthreads();
       XM_K2STAMP(2);
-      {  // 7-tap max along the rows of every patch column: 8 outputs per task from 14 inputs (two 16-byte LDS reads)
+      {  // 7-tap max along the rows of every patch column: 8 outputs per task from 14 inputs (two 16-byte LDS reads).
+        // (Tried: taking them in registers straight from two global loads per thread, no tile buffer and one barrier less --
+        // the kernel alone is as fast, the pipelined frame rate 4 % lower: twice the vector-memory requests.)
         const int nseg = rows_p >> 3, tasks = cols * nseg;
-        for (int t = tid; t < tasks; t += NT) {
-          const uint4 a = *reinterpret_cast<const uint4*>(tile + t * 8);  // task t covers tile[t*8 .. t*8+7] (c*rows_p + 8*seg)
-          const uint4 b = *reinterpret_cast<const uint4*>(tile + t * 8 + 8);
-          // packed 16-bit arithmetic (v_pk_max_u16): P_k = (e[2k], e[2k+1]) as loaded, S_k = (e[2k+1], e[2k+2]) by a 16-bit
-          // funnel shift; outputs (o[2j], o[2j+1]) = max(P_j, S_j, P_j+1, S_j+1, P_j+2, S_j+2, P_j+3): 24 instructions instead
-          // of 72 for unpack + 48 scalar maxima + pack
-          typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-          const auto pk = [](u32 v) { u16x2 r; __builtin_memcpy(&r, &v, 4); return r; };
-          const auto up = [](u16x2 v) { u32 r; __builtin_memcpy(&r, &v, 4); return r; };
-          const auto mx = [](u16x2 x, u16x2 y) { return __builtin_elementwise_max(x, y); };
-          const u32 P[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
-          u16x2 M[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) M[k] = mx(pk(P[k]), pk(__builtin_amdgcn_alignbit(P[k + 1], P[k], 16)));
-          uint4 w;
-          w.x = up(mx(mx(M[0], M[1]), mx(M[2], pk(P[3]))));
-          w.y = up(mx(mx(M[1], M[2]), mx(M[3], pk(P[4]))));
-          w.z = up(mx(mx(M[2], M[3]), mx(M[4], pk(P[5]))));
-          w.w = up(mx(mx(M[3], M[4]), mx(M[5], pk(P[6]))));
-          *reinterpret_cast<uint4*>(vmax + t * 8) = w;
-        }
+        for (int t = tid; t < tasks; t += NT)  // task t covers tile[t*8 .. t*8+7] (c*rows_p + 8*seg)
+          *reinterpret_cast<uint4*>(vmax + t * 8) = k2_rowmax8(*reinterpret_cast<const uint4*>(tile + t * 8),
+                                                                *reinterpret_cast<const uint4*>(tile + t * 8 + 8));
       }
       XM_K2STAMP(3);
       __syncthreads();
