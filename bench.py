@@ -613,8 +613,13 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
     packet = int(1e6 / 60 / 4)
     edges = np.arange(stream["t"][0], stream["t"][-1] + packet, packet)
     cuts = np.searchsorted(stream["t"], edges)
-    cut_frames = []
-    tf = RobustTriggerFinder(60, lambda e: cut_frames.append((int(e["t"][0]), len(e))))
+    cut_frames, first_cut = [], []
+
+    def on_frame(e):
+        if not cut_frames:
+            first_cut.append(np.array(e))  # the events themselves: (t_first, n) does not say which of several equal stamps is first
+        cut_frames.append((int(e["t"][0]), len(e)))
+    tf = RobustTriggerFinder(60, on_frame)
     for a, b in zip(cuts[:-1], cuts[1:]):
         tf.process_events(stream[a:b])
     with DeviceIngest(eng, 60, capacity_events=1 << 22, max_packet_events=1 << 20, expected_events_per_frame=n_ev,
@@ -632,10 +637,9 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
         dt = time.perf_counter() - c0
     same_cut = [(f.t_first, f.n_events) for f in got] == cut_frames
     ok = None
-    if got:
+    if got and same_cut:
         f0 = got[0]
-        i0 = int(np.searchsorted(stream["t"], f0.t_first))
-        ev0 = stream[i0:i0 + f0.n_events]
+        ev0 = first_cut[0]  # the host trigger finder's frame (same first stamp and length as the device's: same_cut)
         ref = O.process_ev_frame(tables, ev0["x"].astype(np.int64), ev0["y"].astype(np.int64), np.ascontiguousarray(ev0["t"]),
                                  camera_perspective=camera, want_bgr=False)
         ok = bool(np.array_equal(f0.depth, ref["depth"]))

@@ -3,7 +3,7 @@
 # group of 16 frames through xm_process_batch; K1 = column tiles).  Every profiler run is bounded by its own timeout; every
 # --pmc group is its own run with --kernel-trace only (FETCH_SIZE and WRITE_SIZE separately).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r02b}
+TAG=${1:-r02c}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export XM_BENCH_PREWARM_S=0.05
 Q="--no-cpu-baseline --no-other-modes --no-host-path"
