@@ -461,7 +461,7 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W) {
   return std::max(128u, std::min(t, (unsigned)COLS_MAX_THREADS));
 }
 
-// K0b: the tile boundaries + column thresholds of the frame (one wave per boundary), left behind the slot's u16 frame
+// K0b: the tile boundaries + column thresholds of the frame (half a wave per boundary), left behind the slot's u16 frame
 void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
   const unsigned nb = grid_for(h->tb.xmap_w, W);
   if (ev.aos)

@@ -16,8 +16,8 @@
 //     0 from xm_create.  A slot whose pair can never hold a winner (xp - x_offset < the smallest rectified x of the LUT:
 //     the X-map's undefined cells) is "dead" and is skipped by the check and by the flush alike.
 //   * the tile's events are the index range [lb(c0), lb(c0 + W)) of the time-sorted stream, lb(c) = first event whose time
-//     column is >= c, found by a small kernel of its own (k_cols_bounds: one wave per boundary, 64-ary search over t, an
-//     interpolated window first = two dependent round trips for an evenly filled scan).  lb() is a deterministic function
+//     column is >= c, found by a small kernel of its own (k_cols_bounds: half a wave per boundary, 32 probes around the
+//     interpolated position, then 4 consecutive events per lane = two dependent round trips for an evenly filled scan).  lb() is a deterministic function
 //     of (stream, c), so neighbouring tiles share their boundary whatever the stream looks like; a non-monotone pair marks
 //     the frame as failed.
 //   * exactness for ANY input: every event a tile loads is checked -- t inside [t[0], t[n-1]] and its column inside the
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void k_cols_check(DevTables tb, int xr_min, 
   if (outside) atomicAdd(n_dup + 1, outside);
 }
 
-// ---- the event-range search (one wave per boundary) -----------------------------------------------------------
+// ---- the event-range search (half a wave per boundary) -----------------------------------------------------------
 template <bool AOS>
 __device__ __forceinline__ long long cols_t_at(gp_i64 ts, gp_u4 aos, int i) {
   if constexpr (AOS) {

@@ -1525,8 +1525,10 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 }
 
 
-// K2 (tiled, projector view, fused path): one block = a 16 x 16 tile of projector pixels (measured best of 32x8, 16x16,
-// 16x32, 32x16, 8x32: least patch overlap + cache-line waste).  Their map targets span a (16*sx+6) x (16*sy+6) patch of
+// K2 (tiled, projector view, fused path): one block of 16 x 16 threads = a 32 x 16 tile of projector pixels, two per thread
+// (K2_PPT: a K2 wave is a chain of dependent round trips -- descriptor, tile record, patch, table -- and what it costs is
+// resident waves x lifetime, so each wave carries two pixels' worth of loads through that chain; measured against 1, 3, 4
+// pixels per thread and 64x8 / 16x32 tiles: DESIGN.md section 3).  Their map targets span a (32*sx+6) x (16*sy+6) patch of
 // the rectified key frame (sx, sy ~ 2.75):
 //   0. the patch rectangle of the tile and every pixel's offset into it are static (the maps never change): they come
 //      from tables built once in xm_create (k_build_k2_tables), so the loads below start right after one uniform load;
