@@ -432,6 +432,15 @@ int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_ov
 // kmode of a frame: 0 = 64-bit key frame (general), 1 = compact 32-bit key frame, 2 = column tiles + plain u16 frame
 enum { KM_KEY64 = 0, KM_KEY32 = 1, KM_COLS = 2 };
 
+// K2's dynamic LDS: the tile's patch of u16 disparities (the row maxima replace it in place) + the overrun of its last read
+size_t k2_lds_bytes(const xm_handle* h) {
+#ifdef XM_K2_TWO_BUFFERS
+  return (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t);
+#else
+  return (size_t)(h->k2_tile_cap + 32) * sizeof(uint16_t);
+#endif
+}
+
 size_t cols_lds_bytes(const xm_handle* h, int W) {  // mirrors the carve-up at the top of scatter_cols_body
   const size_t lut_q = ((size_t)h->w_x * h->tb.cam_h + 3) / 4 + 1 + 64, xm_q = ((size_t)W * h->tb.xmap_h + 7) / 8 + 1 + 64,
                slot_q = ((size_t)W * h->tb.xmap_h + 3) / 4;
@@ -491,15 +500,15 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
   const bool key32 = kmode == KM_KEY32;
   if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && kmode == KM_COLS) {
     XM_LAUNCH(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
+              dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, key_frame, h->tb, st,
               tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && key32) {
     XM_LAUNCH(k_frame_proj_tiled<true>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
+              dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, key_frame, h->tb, st,
               tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
     XM_LAUNCH(k_frame_proj_tiled<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, key_frame, h->tb, st,
+              dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, key_frame, h->tb, st,
               tag_override, dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
     const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
@@ -667,7 +676,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       prof_slot(2);
       if (!d_descs_redo) {
         XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                  dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                  dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
                   (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
         HIP_TRY(hipGetLastError());
         return XM_OK;
@@ -677,7 +686,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       // for the frames where it did not, and for those only: every other block returns at once -- the counters cleared and
       // K0 -> K1 -> K2 on the 64-bit key frame (d_descs_redo = the same frames with key_frame = the slots' 64-bit frames).
       XM_LAUNCH((k_frame_proj_tiled_batch<2, 2>), dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
       g_prof = ProfCtx{};
       XM_LAUNCH(k_redo_prepare_batch, dim3(n_frames), dim3(64), 0, stream, d_descs_redo);
@@ -707,7 +716,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
                   h->w_ts, h->w_x, 0);
       }
       XM_LAUNCH((k_frame_proj_tiled_batch<0, 1>), dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs_redo, h->tb,
+                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs_redo, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
       HIP_TRY(hipGetLastError());
       return XM_OK;
@@ -767,11 +776,11 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (key32)
       XM_LAUNCH(k_frame_proj_tiled_batch<true>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
     else
       XM_LAUNCH(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, d_descs, h->tb,
+                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
                 (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
@@ -2520,7 +2529,7 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (h->k2_direct) return fail(XM_ERR_INVALID, "xm_shard_finish_u16 needs the tiled frame kernel (XM_K2_DIRECT is set)");
     hipLaunchKernelGGL(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)), dim3(K2_TX * K2_TY),
-                       (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), stream, reinterpret_cast<const u64*>(disp_frame), h->tb,
+                       k2_lds_bytes(h), stream, reinterpret_cast<const u64*>(disp_frame), h->tb,
                        h->aux_st, 1u, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth_out, bgr_out, h->k2_tile_cap);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
@@ -2703,7 +2712,7 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (!h->k2_direct) {
       hipLaunchKernelGGL(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), 1),
-                         dim3(K2_TX * K2_TY), (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t), s, (const FrameDesc*)g->desc,
+                         dim3(K2_TX * K2_TY), k2_lds_bytes(h), s, (const FrameDesc*)g->desc,
                          h->tb, (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
     } else {
       return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");

@@ -1667,8 +1667,12 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   // worst case (2 x 10 KB) was twice what C-1M's 50 x 56 patches need.
   constexpr bool KEY32 = FMT == 1, U16 = FMT == 2;
   extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
-  uint16_t* tile = k2_lds;                  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
+  uint16_t* tile = k2_lds;  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
+#ifdef XM_K2_TWO_BUFFERS
   uint16_t* vmax = k2_lds + tile_cap + 16;  // [tile_cap]
+#else
+  uint16_t* vmax = tile;  // the row maxima replace the patch IN PLACE: half the LDS per block = more blocks per CU
+#endif
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TW * 3];
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
@@ -1957,10 +1961,32 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       {  // 7-tap max along the rows of every patch column: 8 outputs per task from 14 inputs (two 16-byte LDS reads).
         // (Tried: taking them in registers straight from two global loads per thread, no tile buffer and one barrier less --
         // the kernel alone is as fast, the pipelined frame rate 4 % lower: twice the vector-memory requests.)
+        // Task t covers tile[t*8 .. t*8+7] (c*rows_p + 8*seg) and reads 6 cells of task t + 1.  In place: a chunk of 4 NT
+        // consecutive tasks is computed into registers, a barrier, then stored over its own inputs; the next chunk's inputs
+        // lie behind everything this one wrote.
         const int nseg = rows_p >> 3, tasks = cols * nseg;
-        for (int t = tid; t < tasks; t += NT)  // task t covers tile[t*8 .. t*8+7] (c*rows_p + 8*seg)
+#ifdef XM_K2_TWO_BUFFERS
+        for (int t = tid; t < tasks; t += NT)
           *reinterpret_cast<uint4*>(vmax + t * 8) = k2_rowmax8(*reinterpret_cast<const uint4*>(tile + t * 8),
                                                                 *reinterpret_cast<const uint4*>(tile + t * 8 + 8));
+#else
+        constexpr int CH = 4;
+        for (int t0 = 0; t0 < tasks; t0 += CH * NT) {  // (block-uniform trip count)
+          uint4 w[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int t = t0 + j * NT + tid;
+            if (t < tasks)
+              w[j] = k2_rowmax8(*reinterpret_cast<const uint4*>(tile + t * 8), *reinterpret_cast<const uint4*>(tile + t * 8 + 8));
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int t = t0 + j * NT + tid;
+            if (t < tasks) *reinterpret_cast<uint4*>(vmax + t * 8) = w[j];
+          }
+        }
+#endif
       }
       XM_K2STAMP(3);
       __syncthreads();
