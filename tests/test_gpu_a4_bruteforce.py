@@ -76,7 +76,10 @@ def sparse_frame(rng, rect_w, rect_h, fill):
     return rect
 
 
-CASES = [(176, 132, 64, 48, 0.05), (151, 101, 50, 37, 0.3), (97, 64, 33, 70, 0.02), (40, 23, 19, 17, 0.5)]
+CASES = [(176, 132, 64, 48, 0.05), (151, 101, 50, 37, 0.3), (97, 64, 33, 70, 0.02), (40, 23, 19, 17, 0.5),
+         # projector widths around K2's 32-pixel tile (two pixels per thread: columns tx and tx + 16), heights around its 16 rows
+         (60, 44, 16, 9, 0.3), (60, 44, 17, 16, 0.3), (66, 40, 31, 20, 0.2), (90, 48, 32, 16, 0.2), (90, 48, 96, 5, 0.1),
+         (30, 20, 4, 5, 0.5), (352, 264, 128, 96, 0.4)]
 
 
 @pytest.mark.parametrize("rect_w,rect_h,proj_w,proj_h,fill", CASES)
@@ -113,6 +116,30 @@ def test_fused_k2_equals_the_49_tap_definition(rect_w, rect_h, proj_w, proj_h, f
         bgr = torch.zeros((proj_h, proj_w, 3), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         eng.shard_finish(kf.data_ptr(), tag, depth.data_ptr(), bgr.data_ptr())
+        eng.sync()
+        got = depth.cpu().numpy()
+        got_bgr = bgr.cpu().numpy()
+    assert np.array_equal(got, want_depth)
+    u8 = O.clip_normalize_uint8_depth_frame(want_depth, tb["z_near"], tb["z_far"])
+    assert np.array_equal(got_bgr, O.generate_color_map(u8))
+
+
+@pytest.mark.parametrize("rect_w,rect_h,proj_w,proj_h,fill", CASES)
+def test_fused_k2_on_a_plain_u16_frame_equals_the_49_tap_definition(rect_w, rect_h, proj_w, proj_h, fill):
+    """The same kernel on the untagged 2-byte disparity frame (what the column tiles and the reduce-scatter merge hand it):
+    16-byte loads of 8 rows when rect_h % 8 == 0, 8-byte loads of 4 rows when % 4, cell by cell otherwise and along the border."""
+    torch = pytest.importorskip("torch")
+    tb, rng = border_tables(rect_w, rect_h, proj_w, proj_h, seed=2000 + rect_w)
+    rect = sparse_frame(rng, rect_w, rect_h, fill)
+    want_disp = brute_dilate_remap(rect, tb["disp_proj_mapxy_i16"])
+    want_depth = O.disparity_to_depth_rectified(want_disp, tb["p03"])
+    dev = torch.device("cuda", 0)
+    with XMapsEngine(tb) as eng:
+        d16 = torch.from_numpy(np.ascontiguousarray(rect.T).astype(np.uint16).view(np.int16)).to(dev)  # column-major [col][row]
+        depth = torch.zeros((proj_h, proj_w), dtype=torch.float32, device=dev)
+        bgr = torch.zeros((proj_h, proj_w, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.shard_finish_u16(d16.data_ptr(), depth.data_ptr(), bgr.data_ptr())
         eng.sync()
         got = depth.cpu().numpy()
         got_bgr = bgr.cpu().numpy()
