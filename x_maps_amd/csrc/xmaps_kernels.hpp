@@ -1555,8 +1555,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 #endif
 constexpr int K2_PPT = XM_K2_PPT;  // pixels per thread: a block's tile is K2_TW x K2_TY pixels, thread (tx, ty) takes columns tx + j * K2_TX
 constexpr int K2_TW = XM_K2_TX * K2_PPT;
-constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX;  // 2 x 10 KB of u16: >= 6 blocks per CU, so all
-                                                                    // 1200 blocks of a 640x480 frame are resident at once
+constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX;  // at most 20 KB of u16 per block (the rig's
+                                                                    // largest patch sizes the dynamic LDS: 10.5 KB at C-1M)
 
 __device__ inline uint16_t key_disp(u64 k, u32 tag) { return (u32)(k >> KEY_TAG_SHIFT) == tag ? (uint16_t)(k & 0xffff) : (uint16_t)0; }
 
@@ -1664,7 +1664,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
                                                       const u32 grid_x, const u32 grid_y, const int4* rec_pre = nullptr) {
   // Dynamic LDS sized to the largest patch of THIS rig (tile_cap cells, a multiple of 8, <= K2_TILE_MAX; set in xm_create):
   // how many blocks fit beside K1's 70 KB blocks on a CU is what bounds the pipelined frame rate, and the static
-  // worst case (2 x 10 KB) was twice what C-1M's 50 x 56 patches need.
+  // worst case was several times what C-1M's 94 x 56 patches need.
   constexpr bool KEY32 = FMT == 1, U16 = FMT == 2;
   extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
   uint16_t* tile = k2_lds;  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
