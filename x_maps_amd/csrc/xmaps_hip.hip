@@ -161,9 +161,11 @@ struct xm_handle {
   int16_t* d_xmap = nullptr;
   u32* d_pmap = nullptr;
   uint2* d_dlut = nullptr;
-  int4* d_k2_tiles = nullptr;
-  int k2_tile_cap = K2_TILE_MAX;  // cells of the largest K2 patch (multiple of 8)
-  u32* d_k2_pix = nullptr;
+  // K2's static per-tile / per-pixel tables for its two geometries: [0] one pixel per thread (16 x 16 tiles), [1] two (32 x 16)
+  int4* d_k2_tiles[2] = {nullptr, nullptr};
+  u32* d_k2_pix[2] = {nullptr, nullptr};
+  int k2_tile_cap[2] = {K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
+  int k2_force_ppt = 0;                             // XM_K2_PPT=1/2: experiments
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
   SlotState* aux_st = nullptr;
@@ -432,13 +434,52 @@ int launch_scatter(xm_handle* h, const EventsView& ev, SlotState* st, u32 tag_ov
 // kmode of a frame: 0 = 64-bit key frame (general), 1 = compact 32-bit key frame, 2 = column tiles + plain u16 frame
 enum { KM_KEY64 = 0, KM_KEY32 = 1, KM_COLS = 2 };
 
+// ---- K2 launches (tiled frame kernel, projector view) -----------------------------------------------------------------------
+// Pixels per thread of a launch over n_frames frames: two (32 x 16-pixel tiles) when the launch fills the chip several times
+// over -- a K2 wave is a chain of dependent round trips, what it costs there is resident waves x lifetime, so each wave carries
+// two pixels through the chain --, one (16 x 16) for a lone small frame, where the chain's length IS the kernel's duration and
+// twice the blocks start at once (C-1M, one frame: 7.3 us with one pixel per thread, 12.3 with two).
+int k2_ppt(const xm_handle* h, int n_frames) {
+  if (h->k2_force_ppt == 1 || h->k2_force_ppt == 2) return h->k2_force_ppt;
+  const u64 blocks2 = (u64)grid_for(h->tb.proj_w, 2 * K2_TX) * grid_for(h->tb.proj_h, K2_TY) * (u64)std::max(n_frames, 1);
+  // measured at C-1M (600 blocks of 32 x 16 pixels per frame, tools/ppt_threshold.sh), K2 us per launch with one / two pixels per
+  // thread: 1 frame 5.3 / 7.2, 2 frames 8.7 / 8.6, 3: 11.1 / 10.6, 8: 23.4 / 21.3, 16: 47.5 / 41.1 -- the crossover is at about
+  // four blocks per CU
+  return blocks2 >= 1024 ? 2 : 1;
+}
+
 // K2's dynamic LDS: the tile's patch of u16 disparities (the row maxima replace it in place) + the overrun of its last read
-size_t k2_lds_bytes(const xm_handle* h) {
+size_t k2_lds_bytes(const xm_handle* h, int ppt) {
 #ifdef XM_K2_TWO_BUFFERS
-  return (size_t)(2 * h->k2_tile_cap + 16) * sizeof(uint16_t);
+  return (size_t)(2 * h->k2_tile_cap[ppt - 1] + 16) * sizeof(uint16_t);
 #else
-  return (size_t)(h->k2_tile_cap + 32) * sizeof(uint16_t);
+  return (size_t)(h->k2_tile_cap[ppt - 1] + 32) * sizeof(uint16_t);
 #endif
+}
+
+template <int FMT>
+void launch_k2(xm_handle* h, hipStream_t stream, const u64* key_frame, SlotState* st, u32 tag_override, const unsigned char* dirty,
+               float* depth, uint8_t* bgr) {
+  const int ppt = k2_ppt(h, 1);
+  const dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY));
+  if (ppt == 1)
+    XM_LAUNCH((k_frame_proj_tiled<FMT, 1>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 1), stream, key_frame, h->tb, st, tag_override,
+              dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[0]);
+  else
+    XM_LAUNCH((k_frame_proj_tiled<FMT, 2>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 2), stream, key_frame, h->tb, st, tag_override,
+              dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[1]);
+}
+
+template <int FMT, int COND = 0>
+void launch_k2_batch(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
+  const int ppt = k2_ppt(h, n_frames);
+  const dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY), n_frames);
+  if (ppt == 1)
+    XM_LAUNCH((k_frame_proj_tiled_batch<FMT, COND, 1>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 1), stream, d_descs, h->tb,
+              (const ulonglong2*)h->d_zero16, h->k2_tile_cap[0]);
+  else
+    XM_LAUNCH((k_frame_proj_tiled_batch<FMT, COND, 2>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 2), stream, d_descs, h->tb,
+              (const ulonglong2*)h->d_zero16, h->k2_tile_cap[1]);
 }
 
 size_t cols_lds_bytes(const xm_handle* h, int W) {  // mirrors the carve-up at the top of scatter_cols_body
@@ -499,17 +540,11 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
   KeyCells cells{key_frame, 0};
   const bool key32 = kmode == KM_KEY32;
   if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && kmode == KM_COLS) {
-    XM_LAUNCH(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, key_frame, h->tb, st,
-              tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
+    launch_k2<2>(h, stream, key_frame, st, tag_override, nullptr, depth, bgr);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct && key32) {
-    XM_LAUNCH(k_frame_proj_tiled<true>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, key_frame, h->tb, st,
-              tag_override, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
+    launch_k2<1>(h, stream, key_frame, st, tag_override, nullptr, depth, bgr);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR && !h->k2_direct) {
-    XM_LAUNCH(k_frame_proj_tiled<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)),
-              dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, key_frame, h->tb, st,
-              tag_override, dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap);
+    launch_k2<0>(h, stream, key_frame, st, tag_override, dirty, depth, bgr);
   } else if (h->cfg.view == XM_VIEW_PROJECTOR) {
     const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
     XM_LAUNCH((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
@@ -675,9 +710,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
       prof_slot(2);
       if (!d_descs_redo) {
-        XM_LAUNCH(k_frame_proj_tiled_batch<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                  dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
-                  (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+        launch_k2_batch<2>(h, stream, d_descs, n_frames);
         HIP_TRY(hipGetLastError());
         return XM_OK;
       }
@@ -685,9 +718,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       // kernels decide per frame on the device (frame_attempt_failed): K2 on the u16 frame only where the attempt held, then --
       // for the frames where it did not, and for those only: every other block returns at once -- the counters cleared and
       // K0 -> K1 -> K2 on the 64-bit key frame (d_descs_redo = the same frames with key_frame = the slots' 64-bit frames).
-      XM_LAUNCH((k_frame_proj_tiled_batch<2, 2>), dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
-                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      launch_k2_batch<2, 2>(h, stream, d_descs, n_frames);
       g_prof = ProfCtx{};
       XM_LAUNCH(k_redo_prepare_batch, dim3(n_frames), dim3(64), 0, stream, d_descs_redo);
       {
@@ -715,9 +746,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         XM_LAUNCH(k1, dim3(grid_for(n_max, threads * TILE_EPT), n_frames), dim3(threads), h->k1_lds, stream, d_descs_redo, h->tb,
                   h->w_ts, h->w_x, 0);
       }
-      XM_LAUNCH((k_frame_proj_tiled_batch<0, 1>), dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs_redo, h->tb,
-                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      launch_k2_batch<0, 1>(h, stream, d_descs_redo, n_frames);
       HIP_TRY(hipGetLastError());
       return XM_OK;
     }
@@ -775,13 +804,9 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   prof_slot(2);
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (key32)
-      XM_LAUNCH(k_frame_proj_tiled_batch<true>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
-                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      launch_k2_batch<1>(h, stream, d_descs, n_frames);
     else
-      XM_LAUNCH(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), n_frames),
-                dim3(K2_TX * K2_TY), k2_lds_bytes(h), stream, d_descs, h->tb,
-                (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      launch_k2_batch<0>(h, stream, d_descs, n_frames);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     XM_LAUNCH(k_frame_direct_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
@@ -832,7 +857,7 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   }
   // frames too sparse for the tiled K1 (the reference's own recordings: ~150 k events over 1080 time columns): the multi-frame
   // K0 and K2 with the one-thread-per-event K1 in between -- three launches per group instead of three per frame
-  const bool direct_k1 = !batch_path(h, n_mean) && !(h->cfg.view == XM_VIEW_PROJECTOR && (h->k2_direct || !h->d_k2_tiles)) &&
+  const bool direct_k1 = !batch_path(h, n_mean) && !(h->cfg.view == XM_VIEW_PROJECTOR && (h->k2_direct || !h->d_k2_tiles[1])) &&
                          !h->k2_flags && n_frames >= 2 && n_max < (1ull << 31);
   if (direct_k1) sorted = false;  // (t[0], t[n-1]) is verified by the tiled kernels only: K0 runs
   if (!batch_path(h, n_mean) && !direct_k1) {  // untiled K2: frame by frame, still on the group's stream
@@ -1360,23 +1385,28 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->tb.p03 = cfg->p03;
   h->tb.z_near = cfg->z_near;
   h->tb.z_far = cfg->z_far;
-  if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets
-    const unsigned tiles_x = grid_for(cfg->proj_width, K2_TW), tiles_y = grid_for(cfg->proj_height, K2_TY);
-    XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_tiles, (size_t)tiles_x * tiles_y * sizeof(int4)));
-    XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix, (size_t)cfg->proj_width * cfg->proj_height * sizeof(u32)));
-    hipLaunchKernelGGL(k_build_k2_tables, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles, h->d_k2_pix);
-    XM_TRY_CREATE(hipGetLastError());
-    XM_TRY_CREATE(hipDeviceSynchronize());
-    h->tb.k2_tiles = h->d_k2_tiles;
-    h->tb.k2_pix = h->d_k2_pix;
-    {  // largest LDS patch any tile of this rig needs -> K2's dynamic LDS
+  if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets, for both of its geometries
+    if (const char* e = getenv("XM_K2_PPT")) h->k2_force_ppt = atoi(e);
+    for (int g = 0; g < 2; ++g) {
+      const unsigned tiles_x = grid_for(cfg->proj_width, K2_TX * (g + 1)), tiles_y = grid_for(cfg->proj_height, K2_TY);
+      XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_tiles[g], (size_t)tiles_x * tiles_y * sizeof(int4)));
+      XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix[g], (size_t)cfg->proj_width * cfg->proj_height * sizeof(u32)));
+      if (g == 0) hipLaunchKernelGGL(k_build_k2_tables<1>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
+      else hipLaunchKernelGGL(k_build_k2_tables<2>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
+      XM_TRY_CREATE(hipGetLastError());
+      XM_TRY_CREATE(hipDeviceSynchronize());
+      // largest LDS patch any tile of this rig needs -> K2's dynamic LDS
       std::vector<int4> tiles((size_t)tiles_x * tiles_y);
-      XM_TRY_CREATE(hipMemcpy(tiles.data(), h->d_k2_tiles, tiles.size() * sizeof(int4), hipMemcpyDeviceToHost));
+      XM_TRY_CREATE(hipMemcpy(tiles.data(), h->d_k2_tiles[g], tiles.size() * sizeof(int4), hipMemcpyDeviceToHost));
       int cap = 8;
       for (const int4& r : tiles)
         if (r.z > 0) cap = std::max(cap, r.z * r.w);
-      h->k2_tile_cap = std::min((cap + 7) & ~7, (int)K2_TILE_MAX);
+      h->k2_tile_cap[g] = std::min((cap + 7) & ~7, (int)K2_TILE_MAX);
     }
+    h->tb.k2_tiles1 = h->d_k2_tiles[0];
+    h->tb.k2_pix1 = h->d_k2_pix[0];
+    h->tb.k2_tiles = h->d_k2_tiles[1];
+    h->tb.k2_pix = h->d_k2_pix[1];
   }
   {  // does the rig qualify for the compact (32-bit) key frame?  (see key32_tag in xmaps_kernels.hpp)
     int xr_min = 32767, xp_max = 0;
@@ -1632,8 +1662,10 @@ void xm_destroy(xm_handle* h) {
   if (h->d_xmap) (void)hipFree(h->d_xmap);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
-  if (h->d_k2_tiles) (void)hipFree(h->d_k2_tiles);
-  if (h->d_k2_pix) (void)hipFree(h->d_k2_pix);
+  for (int g = 0; g < 2; ++g) {
+    if (h->d_k2_tiles[g]) (void)hipFree(h->d_k2_tiles[g]);
+    if (h->d_k2_pix[g]) (void)hipFree(h->d_k2_pix[g]);
+  }
   if (h->d_zero16) (void)hipFree(h->d_zero16);
   delete h;
 }
@@ -2528,9 +2560,7 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
   hipStream_t stream = h->slots[0].stream;
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (h->k2_direct) return fail(XM_ERR_INVALID, "xm_shard_finish_u16 needs the tiled frame kernel (XM_K2_DIRECT is set)");
-    hipLaunchKernelGGL(k_frame_proj_tiled<2>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY)), dim3(K2_TX * K2_TY),
-                       k2_lds_bytes(h), stream, reinterpret_cast<const u64*>(disp_frame), h->tb,
-                       h->aux_st, 1u, (const unsigned char*)nullptr, (const ulonglong2*)h->d_zero16, depth_out, bgr_out, h->k2_tile_cap);
+    launch_k2<2>(h, stream, reinterpret_cast<const u64*>(disp_frame), h->aux_st, 1u, nullptr, depth_out, bgr_out);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     hipLaunchKernelGGL(k_frame_direct_u16, dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, disp_frame, px, h->tb.dlut, depth_out, bgr_out);
@@ -2711,9 +2741,7 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   }
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (!h->k2_direct) {
-      hipLaunchKernelGGL(k_frame_proj_tiled_batch<false>, dim3(grid_for(h->tb.proj_w, K2_TW), grid_for(h->tb.proj_h, K2_TY), 1),
-                         dim3(K2_TX * K2_TY), k2_lds_bytes(h), s, (const FrameDesc*)g->desc,
-                         h->tb, (const ulonglong2*)h->d_zero16, h->k2_tile_cap);
+      launch_k2_batch<0>(h, s, (const FrameDesc*)g->desc, 1);
     } else {
       return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");
     }

@@ -52,6 +52,8 @@ struct DevTables {
                         //   its pixels maps into the frame; cols < 0: patch too large for LDS -> generic path), precomputed
   const u32* k2_pix;    // [proj_h][proj_w] offset of the pixel's 7-tap column run inside its tile's LDS patch, ~0u = the
                         //   pixel maps outside the frame (BORDER_CONSTANT 0)
+  const int4* k2_tiles1;  // the same two tables for K2's one-pixel-per-thread geometry (16 x 16 tiles: lone frames, whose
+  const u32* k2_pix1;     //   launch is too small to fill the chip with 32 x 16 tiles; see frame_proj_tiled_body)
   int cam_w, cam_h, proj_w, proj_h, rect_w, rect_h, xmap_w, xmap_h;
   int x_offset, t_px_scale;
   double p03;
@@ -1538,11 +1540,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 //   3. every pixel then needs 7 LDS reads (one per window column) instead of 49.
 // PMC on the 49-tap version: SQ_LDS_IDX_ACTIVE 3.1 M cycles / dispatch -- it was LDS-bound.
 // Falls back to global reads when the patch does not fit (wild maps).
-#ifndef XM_K2_PPT
-#define XM_K2_PPT 2
-#endif
 #ifndef XM_K2_TILE_MAX
-#define XM_K2_TILE_MAX (5120 * XM_K2_PPT)
+#define XM_K2_TILE_MAX 10240
 #endif
 #ifndef XM_K2_TX
 #define XM_K2_TX 16
@@ -1553,8 +1552,8 @@ __global__ __launch_bounds__(BLOCK) void k_frame_proj(Cells cells, DevTables tb,
 #else
 #define XM_K2STAMP(ph) do { } while (0)
 #endif
-constexpr int K2_PPT = XM_K2_PPT;  // pixels per thread: a block's tile is K2_TW x K2_TY pixels, thread (tx, ty) takes columns tx + j * K2_TX
-constexpr int K2_TW = XM_K2_TX * K2_PPT;
+// pixels per thread (template parameter PPT of the K2 kernels: 2 for launches that fill the chip, 1 for a lone frame): a block's
+// tile is K2_TX * PPT x K2_TY pixels, thread (tx, ty) takes columns tx + j * K2_TX
 constexpr int K2_TX = XM_K2_TX, K2_TY = XM_K2_TY, K2_TILE_MAX = XM_K2_TILE_MAX;  // at most 20 KB of u16 per block (the rig's
                                                                     // largest patch sizes the dynamic LDS: 10.5 KB at C-1M)
 
@@ -1563,8 +1562,10 @@ __device__ inline uint16_t key_disp(u64 k, u32 tag) { return (u32)(k >> KEY_TAG_
 // One-off (xm_create): per K2 tile, the bounding box of its pixels' map targets (+3 cells of dilate margin, rows starting
 // on an even row and padded to 8) and, per pixel, where its window starts inside that patch.  The maps are static, so
 // K2 no longer decodes the map, reduces a bounding box over the block and synchronises before it can issue its loads.
+template <int PPT>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_build_k2_tables(DevTables tb, int4* __restrict__ tiles,
                                                                  u32* __restrict__ pix) {
+  constexpr int K2_PPT = PPT, K2_TW = K2_TX * PPT;
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ int s_box[NW][4];
   const int tid = threadIdx.x, tx = tid % K2_TX, ty = tid / K2_TX;
@@ -1656,7 +1657,7 @@ __device__ __forceinline__ uint4 k2_rowmax8(const uint4 a, const uint4 b) {
 // blk_lin / grid_x / grid_y = linear block index inside the frame's tile grid and that grid's shape
 // FMT: what `keys` points at -- 0: the 64-bit packed-key frame; 1: the compact 32-bit key frame of the verified-sorted path
 // (see key32_tag); 2: a plain u16 disparity frame, no tags (sharded frames after reduce-scatter + all-gather, xm_shard_finish_u16)
-template <int FMT = 0>
+template <int FMT = 0, int PPT = 2>
 __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ keys, const DevTables& tb, SlotState* st,
                                                       u32 tag_override, const unsigned char* __restrict__ dirty,
                                                       const ulonglong2* __restrict__ zero16, float* __restrict__ depth,
@@ -1666,6 +1667,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   // how many blocks fit beside K1's 70 KB blocks on a CU is what bounds the pipelined frame rate, and the static
   // worst case was several times what C-1M's 94 x 56 patches need.
   constexpr bool KEY32 = FMT == 1, U16 = FMT == 2;
+  constexpr int K2_PPT = PPT, K2_TW = K2_TX * PPT;
   extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
   uint16_t* tile = k2_lds;  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
 #ifdef XM_K2_TWO_BUFFERS
@@ -1687,7 +1689,8 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   const u32 tag = tag_override ? tag_override : st->tag_a;  // first needed when the patch is decoded
   const int v = tile_y * K2_TY + ty;
   // the tile's patch rectangle and the pixel's offset into it were computed once in xm_create (k_build_k2_tables)
-  const int4 rec = rec_pre ? *rec_pre : tb.k2_tiles[lin_tile];  // block-uniform
+  const int4 rec = rec_pre ? *rec_pre : (PPT == 1 ? tb.k2_tiles1 : tb.k2_tiles)[lin_tile];  // block-uniform
+  const u32* __restrict__ k2_pix = PPT == 1 ? tb.k2_pix1 : tb.k2_pix;
   bool in_img[K2_PPT];
   u32 pix_i[K2_PPT], poff[K2_PPT];
 #pragma unroll
@@ -1695,7 +1698,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
     const int u = tile_x * K2_TW + tx + j * K2_TX;
     in_img[j] = u < tb.proj_w && v < tb.proj_h;
     pix_i[j] = __umul24((u32)v, (u32)tb.proj_w) + (u32)u;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
-    poff[j] = in_img[j] ? tb.k2_pix[pix_i[j]] : ~0u;
+    poff[j] = in_img[j] ? k2_pix[pix_i[j]] : ~0u;
   }
   // generic path only; the tiled path tests poff where it needs it (after the patch loads are out: testing it here put a
   // full wait for this load in front of them)
@@ -2089,7 +2092,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   XM_BLOG_END(2, st, tag);
 }
 
-template <int FMT = 0>
+template <int FMT = 0, int PPT = 2>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __restrict__ keys, DevTables tb,
                                                                   SlotState* st, u32 tag_override,
                                                                   const unsigned char* __restrict__ dirty,
@@ -2097,16 +2100,16 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
                                                                   float* __restrict__ depth, uint8_t* __restrict__ bgr,
                                                                   int tile_cap) {
   // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
-  if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
+  if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.k2_tiles1 | (u64)tb.k2_pix1 | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
                   (u64)zero16 | (u64)depth | (u64)bgr |
                   (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
     return;
-  frame_proj_tiled_body<FMT>(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap, blockIdx.y * gridDim.x + blockIdx.x,
-                             gridDim.x, gridDim.y);
+  frame_proj_tiled_body<FMT, PPT>(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap,
+                                  blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
 }
 
 // multi-frame launch: grid = (tiles_x, tiles_y, frames)
-template <int FMT = 0, int COND = 0>
+template <int FMT = 0, int COND = 0, int PPT = 2>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const FrameDesc* __restrict__ descs, DevTables tb,
                                                                         const ulonglong2* __restrict__ zero16,
                                                                         int tile_cap) {
@@ -2115,12 +2118,12 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const F
   // before the patch has arrived: tools/k2_timeline.py).  The never-true test keeps the compiler from sinking the load
   // behind the branch.
   const u32 blk_lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int4 rec = tb.k2_tiles[xcd_contiguous(blk_lin, gridDim.x * gridDim.y)];
+  const int4 rec = (PPT == 1 ? tb.k2_tiles1 : tb.k2_tiles)[xcd_contiguous(blk_lin, gridDim.x * gridDim.y)];
   const FrameDesc d = descs[blockIdx.z];
   if (!d.valid || rec.w < 0) return;
   if (frame_skipped<COND>(d.st)) return;
-  frame_proj_tiled_body<FMT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap, blk_lin, gridDim.x, gridDim.y,
-                             &rec);
+  frame_proj_tiled_body<FMT, PPT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap, blk_lin, gridDim.x,
+                                  gridDim.y, &rec);
 }
 
 // camera view / plain per-pixel conversion of a frame of n_pixels cells -> depth + BGR
