@@ -141,3 +141,36 @@ def test_sparse_groups_inside_a_hipgraph():
             depth.zero_()
             torch.cuda.synchronize()
         g.close()
+
+
+@pytest.mark.parametrize("camera", [False, True])
+@pytest.mark.parametrize("aos", [False, True])
+def test_sparse_frames_take_the_verified_shortcut_and_unsorted_ones_are_redone(camera, aos):
+    """Sparse frames skip K0 as well: the one-thread-per-event K1 takes (t[0], t[n-1]) and verifies every event against them; a
+    frame that is not sorted (its extrema sit in the middle) is detected and redone with K0, automatically, exactly once."""
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    rng = np.random.default_rng(21)
+    frames = []
+    for f in range(8):
+        e = S.make_events(cfg, frame=500 + f, n=int(rng.integers(2, 6000)))
+        if f in (2, 5):
+            e = e[rng.permutation(len(e))]
+        if f == 6:  # only the LAST stamp is too small: every other event lies inside [t[0], t[n-1]]... except that t[n-1] < t[0]
+            e["t"][-1] = e["t"][0] - 5
+        frames.append(e)
+    with XMapsEngine(tb, camera_perspective=camera, n_slots=3) as eng:
+        for rep in range(2):
+            for i, e in enumerate(frames):
+                if aos:
+                    d, b, st = eng.process_events(e)
+                else:
+                    x, y, t, _ = S.to_soa(e)
+                    d, b, st = eng.process_frame(x, y, t)
+                x, y, t, _ = S.to_soa(e)
+                r = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
+                assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), (rep, i)
+                assert st.n_inliers == int(r["mask"].sum()) and st.t_min == float(t.min()) and st.t_max == float(t.max()), (rep, i)
+        assert eng.sorted_fallbacks() == 2 * 3
+        pc = eng.path_counts()
+        assert pc["sorted_key64"] >= 2 * 8 and pc["key32"] == 0 and pc["cols"] == 0

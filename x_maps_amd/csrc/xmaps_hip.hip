@@ -399,15 +399,16 @@ int launch_scatter_tv(const ScatterArgs& a) {
   if constexpr (AOS) {
     XM_LAUNCH((k_scatter<T, true, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream,
               (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const T*)nullptr, (const int16_t*)nullptr,
-              (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override, a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty);
+              (const uint4*)ev.aos, n, a.idx_offset, *a.tb, a.st, a.tag_override, a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty,
+              a.sorted ? 1 : 0);
   } else if (vec) {
     XM_LAUNCH((k_scatter<T, false, HAS_P, 4, VIEW>), dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, a.stream,
               ev.x, ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st,
-              a.tag_override, a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty);
+              a.tag_override, a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty, a.sorted ? 1 : 0);
   } else {
     XM_LAUNCH((k_scatter<T, false, HAS_P, 1, VIEW>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, a.stream, ev.x,
               ev.y, (const T*)ev.t, ev.p, (const uint4*)nullptr, n, a.idx_offset, *a.tb, a.st, a.tag_override,
-              a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty);
+              a.mm_lo, a.mm_hi, a.mm_ext, a.frame, a.dirty, a.sorted ? 1 : 0);
   }
   return XM_OK;
 }
@@ -572,17 +573,21 @@ int check_events(const EventsView& ev) {
 }
 
 // enqueue K0 -> K1 -> K2 for one frame on a slot.  All pointers are device pointers.
+// dense enough for the tiled K1?  (the same rule as launch_scatter_tv)
+bool tiled_path(const xm_handle* h, u64 n) {
+  const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)n / (double)h->tb.xmap_w : 0.0;
+  return !h->k1_direct && h->w_ts > 0 && h->w_x > 0 && max_ev >= 1024.0;
+}
+
 bool sorted_path(const xm_handle* h, const EventsView& ev) {
-  // the verified (t[0], t[n-1]) shortcut lives in the tiled kernel; sparse frames (direct kernel) keep K0
-  const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)ev.n / (double)h->tb.xmap_w : 0.0;
-  return (h->time_sorted || (h->try_sorted && !h->capturing)) && !ev.use_p && !h->k1_direct && h->w_ts > 0 && h->w_x > 0 &&
-         max_ev >= 1024.0;
+  // the verified (t[0], t[n-1]) shortcut: both K1 kernels take it (tiled, and one thread per event for sparse frames)
+  return (h->time_sorted || (h->try_sorted && !h->capturing)) && !ev.use_p && ev.n > 0;
 }
 
 // may this (sorted-path) frame use the compact key frame?  Needs the automatic redo (try-sorted mode, not inside a capture)
 bool key32_path(const xm_handle* h, const EventsView& ev, bool sorted) {
   if (!sorted || !h->key32_ok || !h->try_sorted || h->capturing || h->key32_pause.load(std::memory_order_relaxed) > 0 ||
-      h->k2_direct || h->k2_flags)
+      h->k2_direct || h->k2_flags || !tiled_path(h, ev.n))
     return false;
   return ev.n / (u64)(1024 / TILE_EPT * TILE_EPT) < (1ull << KEY32_TILE_BITS);  // tiles of >= 1024 events
 }
@@ -777,7 +782,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
     if (direct_k1) {  // frames too sparse for the tiles: one thread per event, grid = (blocks of the largest frame, frames)
       prof_slot(1);
       XM_LAUNCH((k_scatter_direct_batch<T, AOS, HAS_P, VIEW>), dim3(std::max(1u, grid_for(n_max, BLOCK)), n_frames), dim3(BLOCK), 0,
-                stream, d_descs, h->tb);
+                stream, d_descs, h->tb, sorted ? 1 : 0);
       return XM_OK;
     }
     auto kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, false>;
@@ -859,7 +864,6 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
   // K0 and K2 with the one-thread-per-event K1 in between -- three launches per group instead of three per frame
   const bool direct_k1 = !batch_path(h, n_mean) && !(h->cfg.view == XM_VIEW_PROJECTOR && (h->k2_direct || !h->d_k2_tiles[1])) &&
                          !h->k2_flags && n_frames >= 2 && n_max < (1ull << 31);
-  if (direct_k1) sorted = false;  // (t[0], t[n-1]) is verified by the tiled kernels only: K0 runs
   if (!batch_path(h, n_mean) && !direct_k1) {  // untiled K2: frame by frame, still on the group's stream
     for (int f = 0; f < n_frames; ++f) {
       int rc = enqueue_frame(h, h->slots[slot_idx[f]], evs[f], depth[f], bgr[f], nullptr, allow_sorted, stream);
@@ -882,7 +886,7 @@ int enqueue_batch(xm_handle* h, const int* slot_idx, const EventsView* evs, floa
         cols_w = 0;
   }
   const bool redo_descs = dev_redo && cols_w;
-  bool use32 = sorted && !cols_w;
+  bool use32 = sorted && !cols_w && !direct_k1;
   for (int f = 0; f < n_frames && use32; ++f) use32 = key32_path(h, evs[f], sorted);
   {
     int v = h->key32_pause.load(std::memory_order_relaxed);
@@ -2720,9 +2724,9 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   if constexpr (DIRECT) {
     const unsigned gx = grid_for(n_bound, BLOCK);
     if (h->cfg.view == XM_VIEW_PROJECTOR)
-      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 0>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, h->tb);
+      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 0>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, h->tb, 0);
     else
-      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, h->tb);
+      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, h->tb, 0);
   } else {
     const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)est_n / (double)h->tb.xmap_w : 0.0;
     unsigned threads = TILE_THREADS;

@@ -554,8 +554,12 @@ __device__ __forceinline__ void scatter_direct_body(const uint16_t* __restrict__
                                                     const uint4* __restrict__ aos, u64 n, u64 idx_offset,
                                                     const DevTables& tb, SlotState* st, u32 tag_override, u64 mm_lo,
                                                     u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
-                                                    unsigned char* __restrict__ dirty, const u32 blk) {
-  const u32 tag = tag_override ? tag_override : st->tag_a;
+                                                    unsigned char* __restrict__ dirty, const u32 blk, const int sorted_mode = 0) {
+  // sorted_mode (never with a polarity column): the caller expects the frame sorted by t -- extrema = t[0], t[n-1], K0 is not
+  // launched, and every event is verified against them below exactly as k_scatter_tiled does (a failure marks the frame: it is
+  // redone with K0).  The reference's own recordings are frames of this kind: ~150 k sorted events, too sparse for the tiles.
+  const bool srt = sorted_mode != 0 && !tag_override && !HAS_P && n > 0;
+  const u32 tag = tag_override ? tag_override : (srt ? st->tag_b + 1 : st->tag_a);
   const u32 parity = tag & 1;
   u64 lo, hi;
   if (tag_override) {  // sharded mode: the FRAME's extrema come from the all-reduce of the shards' extrema
@@ -570,6 +574,30 @@ __device__ __forceinline__ void scatter_direct_body(const uint16_t* __restrict__
         const double* m = static_cast<const double*>(mm_ext);
         lo = TimeCodec<T>::enc((T)m[0]);
         hi = TimeCodec<T>::enc((T)(-m[1]));
+      }
+    }
+  } else if (srt) {
+    T t_first, t_last;
+    if constexpr (AOS) {
+      const uint4 a = aos[0], b = aos[n - 1];
+      t_first = (T)(long long)(((u64)a.w << 32) | a.z);
+      t_last = (T)(long long)(((u64)b.w << 32) | b.z);
+    } else {
+      t_first = ts[0];
+      t_last = ts[n - 1];
+    }
+    lo = TimeCodec<T>::enc(t_first);
+    hi = TimeCodec<T>::enc(t_last);
+    if (hi < lo) hi = lo;  // not sorted at all: keep the arithmetic defined; the verification flags the frame
+    if (blk == 0) {
+      if (threadIdx.x == 0) {
+        st->tag_a = tag;            // K2 reads tag_a and copies it to tag_b
+        st->mm[parity][0][0] = lo;  // for xm_frame_stats.t_min / t_max
+        st->mm[parity][0][1] = hi;
+      }
+      if (threadIdx.x < MM_SLOTS) {
+        st->mm[parity ^ 1][threadIdx.x][0] = MM_INIT_MIN;
+        st->mm[parity ^ 1][threadIdx.x][1] = MM_INIT_MAX;
       }
     }
   } else {
@@ -644,6 +672,19 @@ __device__ __forceinline__ void scatter_direct_body(const uint16_t* __restrict__
     }
   }
 
+  if (srt) {  // verify the expectation: 2 compares per event
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u64 e = TimeCodec<T>::enc(used[k] ? t[k] : TimeCodec<T>::dec(lo));
+      bad = bad || e < lo || e > hi;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) {
+      __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u32* hf = st->host_flags) host_flag_store(hf, tag);
+    }
+  }
   u32 n_in = 0, n_oob = 0;
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
@@ -688,20 +729,26 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const uint16_t* __restrict__ 
                                                    const uint4* __restrict__ aos, u64 n, u64 idx_offset,
                                                    DevTables tb, SlotState* st, u32 tag_override, u64 mm_lo,
                                                    u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
-                                                   unsigned char* __restrict__ dirty) {
+                                                   unsigned char* __restrict__ dirty, int sorted_mode) {
   scatter_direct_body<T, AOS, HAS_P, EPT, VIEW>(xs, ys, ts, ps, aos, n, idx_offset, tb, st, tag_override, mm_lo, mm_hi, mm_ext,
-                                                frame, dirty, blockIdx.x);
+                                                frame, dirty, blockIdx.x, sorted_mode);
 }
+
+__device__ inline void scatter_empty_frame(SlotState* st, int sorted_mode);
 
 // one thread per event, frame from a descriptor in device memory (sparse frames of a device-resident stream: ingest);
 // grid = (blocks for the largest frame the host allows for, frames); a frame without events still does block 0's bookkeeping
 template <typename T, bool AOS, bool HAS_P, int VIEW>
-__global__ __launch_bounds__(BLOCK) void k_scatter_direct_batch(const FrameDesc* __restrict__ descs, DevTables tb) {
+__global__ __launch_bounds__(BLOCK) void k_scatter_direct_batch(const FrameDesc* __restrict__ descs, DevTables tb, int sorted_mode) {
   const FrameDesc d = descs[blockIdx.y];
   if (!d.valid) return;
   if (blockIdx.x != 0 && (u64)blockIdx.x * BLOCK >= d.n) return;
+  if (d.n == 0 && sorted_mode) {  // (only block 0 gets here) nothing to take the extrema from: what the tiled kernel does
+    scatter_empty_frame(d.st, sorted_mode);
+    return;
+  }
   scatter_direct_body<T, AOS, HAS_P, 1, VIEW>(d.x, d.y, (const T*)d.t, d.p, d.aos, d.n, 0ull, tb, d.st, 0u, 0ull, 0ull, nullptr,
-                                              d.key_frame, nullptr, blockIdx.x);
+                                              d.key_frame, nullptr, blockIdx.x, sorted_mode);
 }
 
 
