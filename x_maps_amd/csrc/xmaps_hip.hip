@@ -374,12 +374,10 @@ int launch_scatter_tv(const ScatterArgs& a) {
     if constexpr (kHasVec) {
       if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, true>;
     }
-    if constexpr (VIEW == 0) {
-      if (a.key32) {  // compact key frame (a.frame points at it)
-        kern = k_scatter_tiled<T, AOS, HAS_P, 0, false, true>;
-        if constexpr (kHasVec) {
-          if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, 0, true, true>;
-        }
+    if (a.key32) {  // compact key frame (a.frame points at it)
+      kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, false, true>;
+      if constexpr (kHasVec) {
+        if (vec16) kern = k_scatter_tiled<T, AOS, HAS_P, VIEW, true, true>;
       }
     }
     // raise the kernel's dynamic-LDS cap once per (handle = device, kernel instantiation); gfx950: 160 KB / CU
@@ -550,6 +548,10 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
     const u64 px = (u64)h->tb.proj_w * h->tb.proj_h;
     XM_LAUNCH((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
               tag_override, depth, bgr);
+  } else if (key32) {  // camera view, compact frame: (event index + 1) << 12 | disparity, zeroed as it is read
+    const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
+    XM_LAUNCH(k_frame_cam32, dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, reinterpret_cast<u32*>(const_cast<u64*>(key_frame)), px, st,
+              h->tb.dlut, depth, bgr);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     XM_LAUNCH((k_frame_direct<KeyCells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, px,
@@ -589,6 +591,7 @@ bool key32_path(const xm_handle* h, const EventsView& ev, bool sorted) {
   if (!sorted || !h->key32_ok || !h->try_sorted || h->capturing || h->key32_pause.load(std::memory_order_relaxed) > 0 ||
       h->k2_direct || h->k2_flags || !tiled_path(h, ev.n))
     return false;
+  if (h->cfg.view != XM_VIEW_PROJECTOR) return ev.n <= (u64)CAM32_MAX_EVENTS;  // the key's order field is the event index
   return ev.n / (u64)(1024 / TILE_EPT * TILE_EPT) < (1ull << KEY32_TILE_BITS);  // tiles of >= 1024 events
 }
 
@@ -604,6 +607,7 @@ int cols_path(const xm_handle* h, const EventsView& ev, bool sorted, bool group 
 
 // keep the slot's compact frame unambiguous for a frame with tag `tag` (4-bit tags repeat every 15 frames)
 int key32_prepare(xm_handle* h, Slot& s, u32 tag, hipStream_t stream) {
+  if (h->cfg.view != XM_VIEW_PROJECTOR) return XM_OK;  // camera view: no tag -- the frame kernel zeroes every pixel it reads
   if (tag - s.key32_valid_from >= 15u || tag < s.key32_valid_from) {
     HIP_TRY(hipMemsetAsync(s.key32, 0, h->key_cells * sizeof(u32), stream));
     s.key32_valid_from = tag;
@@ -789,12 +793,10 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
     if constexpr (kHasVec) {
       if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, true>;
     }
-    if constexpr (VIEW == 0) {
-      if (key32) {
-        kern = k_scatter_tiled_batch<T, AOS, HAS_P, 0, false, true>;
-        if constexpr (kHasVec) {
-          if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, 0, true, true>;
-        }
+    if (key32) {
+      kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, false, true>;
+      if constexpr (kHasVec) {
+        if (vec16) kern = k_scatter_tiled_batch<T, AOS, HAS_P, VIEW, true, true>;
       }
     }
     int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), h->k1_lds);
@@ -814,7 +816,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       launch_k2_batch<0>(h, stream, d_descs, n_frames);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
-    XM_LAUNCH(k_frame_direct_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
+    if (key32) XM_LAUNCH(k_frame_cam32_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
+    else XM_LAUNCH(k_frame_direct_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
   }
   HIP_TRY(hipGetLastError());
   return XM_OK;
@@ -1418,7 +1421,8 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     for (size_t i = 0; i < xm_cells; ++i) xp_max = std::max<int>(xp_max, cfg->proj_x_map[i]);
     const long max_disp = std::max<long>((long)xp_max - xr_min - cfg->x_offset, (long)0 - xr_min - cfg->x_offset);
     const char* e32 = getenv("XM_KEY32");
-    h->key32_ok = cfg->view == XM_VIEW_PROJECTOR && (cfg->rect_height & 3) == 0 && max_disp < (1l << KEY32_DISP_BITS) &&
+    // (camera view: (event index + 1) << 12 | disparity on the camera frame -- only the disparity range matters)
+    h->key32_ok = (cfg->view != XM_VIEW_PROJECTOR || (cfg->rect_height & 3) == 0) && max_disp < (1l << KEY32_DISP_BITS) &&
                   !(e32 && e32[0] == '0');
   }
   {  // does the rig qualify for the column-tile K1?  (xmaps_k1cols.hpp)
@@ -1456,7 +1460,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     h->cols_single = ec && ec[0] == '2';
     // the compact key frame orders the writers of a cell by TILE only: two time columns of one tile that share a cell would be
     // ordered by their disparity bits -- it needs the same property (the 64-bit keys carry the full event index and do not)
-    h->key32_ok = h->key32_ok && injective;
+    if (cfg->view == XM_VIEW_PROJECTOR) h->key32_ok = h->key32_ok && injective;
     if (const char* e = getenv("XM_COLS_TARGET")) h->cols_target = std::max(256, atoi(e));
   }
   if (cfg->view == XM_VIEW_PROJECTOR) {

@@ -153,7 +153,10 @@ __host__ __device__ inline unsigned char dirty_byte(u32 tag) { return (unsigned 
 // the slots like everybody else.  Preconditions checked by the host (xm_create): projector view, rect_h % 4 == 0, every
 // possible disparity < 4096, tiles per frame < 65536; the 4-bit tag is kept unambiguous by clearing the frame at least
 // every 15 frames of the slot (9.3 MB memset per 15 frames at C-1M).
-constexpr u32 KEY32_DISP_BITS = 12, KEY32_TILE_BITS = 16;
+// Camera view (VIEW == 1 with KEY32): the cell is the event's own pixel, written by events of ANY tile, so the order field is the
+// event itself: key = (event index + 1) << 12 | disparity -- exact for every frame of < 2^20 events whatever their order, strays
+// included; no tag: the frame kernel, which reads every pixel of the 1.2 MB frame exactly once, zeroes what it has read.
+constexpr u32 KEY32_DISP_BITS = 12, KEY32_TILE_BITS = 16, CAM32_MAX_EVENTS = (1u << 20) - 1u;
 __host__ __device__ inline u32 key32_tag(u32 tag) { return (tag % 15u + 1u) << 28; }
 __device__ inline uint16_t key_disp32(u32 k, u32 tag4) { return (k & 0xf0000000u) == tag4 ? (uint16_t)(k & 0xfffu) : (uint16_t)0; }
 
@@ -811,7 +814,7 @@ __device__ __forceinline__ void scatter_tiled_body(
     u32 tag_override, u64 mm_lo, u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
     unsigned char* __restrict__ dirty, int w_ts, int w_x, int sorted_mode, const u32 blk, const u32 nblk) {
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
-  static_assert(!KEY32 || VIEW == 0, "the compact key frame is a projector-view format");
+  constexpr bool PROJ32 = KEY32 && VIEW == 0, CAM32 = KEY32 && VIEW == 1;  // (see KEY32_DISP_BITS)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   XM_BLOG_BEGIN();
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift).  The LUT band and
@@ -1160,8 +1163,8 @@ __device__ __forceinline__ void scatter_tiled_body(
     smask |= used[k] && !fast[k] ? 1u << k : 0u;
   }
   u32 n_in = 0, n_oob = 0;
-  u32 ovr = 0;  // KEY32: bit k = event k's LUT entry was fetched from global memory and sits in xl[k]
-  if constexpr (KEY32) {
+  u32 ovr = 0;  // PROJ32: bit k = event k's LUT entry was fetched from global memory and sits in xl[k]
+  if constexpr (PROJ32) {
     // Every event must be resolved in the LDS slots (the key's order field is only the tile).  An event outside the LUT window
     // (x noise) but inside the time window fetches its LUT entry from global memory here and joins the fast path below; an
     // event outside the TIME window cannot use the slots: the frame is marked as failed and redone on the 64-bit path.
@@ -1223,9 +1226,15 @@ __device__ __forceinline__ void scatter_tiled_body(
         oob = true;
       }
       if (write) {
-        const u64 key = key_hi | ((idx_offset + block_base + el) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
-        __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
+        if constexpr (CAM32) {
+          __hip_atomic_fetch_max(reinterpret_cast<u32*>(frame) + cell,
+                                 ((u32)(idx_offset + block_base + el + 1) << KEY32_DISP_BITS) | ((u32)r.disp & 0xfffu),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const u64 key = key_hi | ((idx_offset + block_base + el) << KEY_IDX_SHIFT) | (u64)(u32)r.disp;
+          __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (VIEW == 0 && dirty) dirty[cell >> 4] = dirty_byte(tag);
+        }
       }
     }
     n_in += __popcll(__ballot(write));
@@ -1271,9 +1280,9 @@ __device__ __forceinline__ void scatter_tiled_body(
     u32 l[TILE_EPT];
 #pragma unroll
     for (int k = 0; k < TILE_EPT; ++k) {
-      const bool o_k = KEY32 && ((ovr >> k) & 1u);
+      const bool o_k = PROJ32 && ((ovr >> k) & 1u);
       l[k] = lut_t[fast[k] ? xl[k] * tb.cam_h + (int)y[k] : 0];
-      if constexpr (KEY32) {
+      if constexpr (PROJ32) {
         l[k] = o_k ? (u32)xl[k] : l[k];
         fast[k] = fast[k] || o_k;
       }
@@ -1371,8 +1380,12 @@ __device__ __forceinline__ void scatter_tiled_body(
           } else {  // q = camera row, r = x - x_lo
             cell = (u32)q * (u32)tb.cam_w + (u32)(x_lo + r);
           }
-          if constexpr (KEY32) {  // tag4 | tile | disparity into the compact frame (see key32_tag)
+          if constexpr (PROJ32) {  // tag4 | tile | disparity into the compact frame (see key32_tag)
             __hip_atomic_fetch_max(reinterpret_cast<u32*>(frame) + cell, key32_tag(tag) | (tile << KEY32_DISP_BITS) | (v[j] & 0xfffu),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if constexpr (CAM32) {  // (event index + 1) | disparity; the slot holds ((local index + 1) << 16) | disparity
+            __hip_atomic_fetch_max(reinterpret_cast<u32*>(frame) + cell,
+                                   (((u32)(idx_offset + block_base) + (v[j] >> 16)) << KEY32_DISP_BITS) | (v[j] & 0xfffu),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else {
             if (!XM_ABL(0)) __hip_atomic_fetch_max(&frame[cell], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2229,6 +2242,43 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct_batch(const FrameDesc* _
   const uint2 e = dlut[dsp];
   if (d.depth && pixel < n_pixels) d.depth[pixel] = __uint_as_float(e.x);
   if (d.bgr) store_bgr_block(d.bgr, (u64)blockIdx.x * BLOCK, n_pixels, e.y);
+}
+
+// camera view on the compact key frame ((event index + 1) << 12 | disparity, 0 = no event): the pixel is zeroed once read, so
+// the next frame of the slot starts from an empty frame without a clear of its own
+__device__ __forceinline__ void frame_cam32_body(u32* __restrict__ frame32, u64 n_pixels, SlotState* st, const uint2* __restrict__ dlut,
+                                                 float* __restrict__ depth, uint8_t* __restrict__ bgr, const u32 blk) {
+  const u32 tag = st->tag_a;
+  if (blk == 0 && threadIdx.x < CNT_SLOTS) {
+    u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
+    c[0] = c[1] = c[2] = c[3] = 0;
+    if (threadIdx.x == 0) {
+      st->tag_b = tag;
+      if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
+    }
+  }
+  const u64 pixel = (u64)blk * BLOCK + threadIdx.x;
+  u32 k = 0;
+  if (pixel < n_pixels) {
+    k = frame32[pixel];
+    if (k) frame32[pixel] = 0u;
+  }
+  const uint2 e = dlut[k & 0xfffu];
+  if (depth && pixel < n_pixels) depth[pixel] = __uint_as_float(e.x);
+  if (bgr) store_bgr_block(bgr, (u64)blk * BLOCK, n_pixels, e.y);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_frame_cam32(u32* __restrict__ frame32, u64 n_pixels, SlotState* st,
+                                                       const uint2* __restrict__ dlut, float* __restrict__ depth,
+                                                       uint8_t* __restrict__ bgr) {
+  frame_cam32_body(frame32, n_pixels, st, dlut, depth, bgr, blockIdx.x);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_frame_cam32_batch(const FrameDesc* __restrict__ descs, u64 n_pixels,
+                                                             const uint2* __restrict__ dlut) {
+  const FrameDesc d = descs[blockIdx.y];
+  if (!d.valid) return;
+  frame_cam32_body(reinterpret_cast<u32*>(d.key_frame), n_pixels, d.st, dlut, d.depth, d.bgr, blockIdx.x);
 }
 
 // Sharded frames: a chunk of the (reduced) packed-key frame -> u16 disparities (0 where the tag differs): 2 instead of 8
