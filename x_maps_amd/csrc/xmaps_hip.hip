@@ -472,7 +472,8 @@ void launch_k2(xm_handle* h, hipStream_t stream, const u64* key_frame, SlotState
 template <int FMT, int COND = 0>
 void launch_k2_batch(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
   const int ppt = k2_ppt(h, n_frames);
-  const dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY), n_frames);
+  dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY), n_frames);
+  if (COND == 1) grid = dim3(std::min(grid.x * grid.y, 32u), 1, n_frames);  // redo node: a few blocks per frame walk its tiles
   if (ppt == 1)
     XM_LAUNCH((k_frame_proj_tiled_batch<FMT, COND, 1>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 1), stream, d_descs, h->tb,
               (const ulonglong2*)h->d_zero16, h->k2_tile_cap[0]);
@@ -734,7 +735,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         const bool vec2 = !AOS && vec16;
         const unsigned per_block = BLOCK * (vec2 ? 2 * K0_UN : 4);
         unsigned gx = grid_for(n_max, per_block);
-        if (gx > 1024) gx = 1024;
+        if (gx > 64) gx = 64;  // (grid-stride kernel; a redo node: usually every block returns at once)
         if constexpr (!AOS) {
           if (vec2) XM_LAUNCH((k_minmax_batch<T, false, false, 2, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs_redo);
           else XM_LAUNCH((k_minmax_batch<T, false, false, 1, 1>), dim3(gx, n_frames), dim3(BLOCK), 0, stream, d_descs_redo);
@@ -752,8 +753,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         }
         rc = h->ensure_lds(reinterpret_cast<const void*>(k1), h->k1_lds);
         if (rc) return rc;
-        XM_LAUNCH(k1, dim3(grid_for(n_max, threads * TILE_EPT), n_frames), dim3(threads), h->k1_lds, stream, d_descs_redo, h->tb,
-                  h->w_ts, h->w_x, 0);
+        XM_LAUNCH(k1, dim3(std::min(grid_for(n_max, threads * TILE_EPT), 32u), n_frames), dim3(threads), h->k1_lds, stream, d_descs_redo,
+                  h->tb, h->w_ts, h->w_x, 0);
       }
       launch_k2_batch<0, 1>(h, stream, d_descs_redo, n_frames);
       HIP_TRY(hipGetLastError());

@@ -1458,6 +1458,21 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled_batch(const FrameDesc* __restrict__
   if (!d.valid || frame_skipped<COND>(d.st)) return;
   const u32 evb = blockDim.x * TILE_EPT;
   const u32 nblk = (u32)((d.n + evb - 1) / evb);
+  if constexpr (COND == 1) {
+    // The redo node of a captured batch: launched with a FEW blocks per frame, which walk the frame's tiles when the frame's
+    // attempt failed -- in the usual case (it held) the node costs a handful of blocks that read two words and return, not a
+    // block per tile (each with the tiled kernel's LDS to allocate: 10 us per 60-frame replay)
+    if (d.n == 0) {
+      if (blockIdx.x == 0) scatter_empty_frame(d.st, sorted_mode);
+      return;
+    }
+    for (u32 b = blockIdx.x; b < nblk; b += gridDim.x) {
+      scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC, KEY32>(d.x, d.y, (const T*)d.t, d.p, d.aos, d.n, 0ull, tb, d.st, 0u, 0ull, 0ull,
+                                                          nullptr, d.key_frame, nullptr, w_ts, w_x, sorted_mode, b, nblk);
+      __syncthreads();  // the next tile clears the LDS this one's flush has just read
+    }
+    return;
+  }
   if (blockIdx.x >= nblk) {
     if (d.n == 0 && blockIdx.x == 0) scatter_empty_frame(d.st, sorted_mode);
     return;
@@ -2177,6 +2192,16 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled_batch(const F
   // K2 is a chain of dependent round trips -- descriptor, record, patch -- and 55 % of its lifetime at full occupancy is spent
   // before the patch has arrived: tools/k2_timeline.py).  The never-true test keeps the compiler from sinking the load
   // behind the branch.
+  if constexpr (COND == 1) {  // redo node of a captured batch: a few blocks per frame walk the frame's tiles (see k_scatter_tiled_batch)
+    const FrameDesc d = descs[blockIdx.z];
+    if (!d.valid || frame_skipped<COND>(d.st)) return;
+    const u32 gx = ((u32)tb.proj_w + K2_TX * PPT - 1) / (K2_TX * PPT), gy = ((u32)tb.proj_h + K2_TY - 1) / K2_TY;
+    for (u32 b = blockIdx.y * gridDim.x + blockIdx.x; b < gx * gy; b += gridDim.x * gridDim.y) {
+      frame_proj_tiled_body<FMT, PPT>(d.key_frame, tb, d.st, 0u, nullptr, zero16, d.depth, d.bgr, tile_cap, b, gx, gy);
+      __syncthreads();  // the next tile's patch overwrites the LDS this one's pixels have just read
+    }
+    return;
+  }
   const u32 blk_lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int4 rec = (PPT == 1 ? tb.k2_tiles1 : tb.k2_tiles)[xcd_contiguous(blk_lin, gridDim.x * gridDim.y)];
   const FrameDesc d = descs[blockIdx.z];
