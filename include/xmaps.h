@@ -155,6 +155,18 @@ int xm_sorted_fallbacks(xm_handle* h, uint64_t* count);
  * shortcut on the 64-bit key frame, counts[2] compact 32-bit key frame, counts[3] column tiles + plain u16 disparity frame
  * (no atomics; needs an injective X-map -> frame-cell relation, checked in xm_create).  A redone frame counts twice. */
 int xm_path_counts(xm_handle* h, uint64_t counts[4]);
+/* Which no-atomics K1 the rig qualified for in xm_create, and its geometry: info[0] = 0 none (sparse / wild tables: packed
+ * keys only), 1 column tiles (injective X-map), 2 owner tiles (several time columns per frame cell -- the reference's own
+ * calibration, python/cam_proj_calibration.py:299-303 with X_MAP_WIDTH = projector_width, python/x_maps_disparity.py:58-59);
+ * owner tiles: info[1] = time columns per tile, [2] = halo columns read behind them, [3] = widest cell band of a tile
+ * (sheared frame columns), [4] = shear per 8-row group in 1/4096 columns, [5] = extra frame columns of the sheared
+ * u16 frame, [6] = first row / [7] = rows the rectify LUT can reach, [8] = owner cells outside their tile's band ("extras":
+ * one slot each, flushed one by one), [9] = the most extras of one tile; [10], [11] = 0. */
+int xm_cols_info(xm_handle* h, int32_t info[12]);
+/* The owner-tile analysis of xm_create on its own (host code, no device needed): would this rig's tables qualify?  info as
+ * xm_cols_info (info[0] = 2 or 0), plus [10] = the largest distance of a time column from its cell's first column, [11] = LDS
+ * bytes per tile.  (The injective case, info[0] = 1, is decided on the device in xm_create.) */
+int xm_own_plan_info(const xm_config* cfg, int32_t info[12]);
 
 /* ---- the fused hot path: one projector frame of events -> depth frame (+ BGR) -------------------- */
 /*

@@ -1,0 +1,233 @@
+"""-m gpu: the owner-tile K1 (x_maps_amd/csrc/xmaps_k1own.hpp) -- rigs on which several X-map time columns of a row share one
+cell of the rectified frame (the reference's own calibration: X_MAP_WIDTH = projector_width, python/x_maps_disparity.py:58-59,
+scattered through python/cam_proj_calibration.py:299-303).  A cell belongs to the tile of the FIRST column that maps to it;
+tiles read a halo of the next columns' events; last-writer-wins is resolved in LDS slots indexed by the (sheared) cell; the
+flush is a plain store of every owned cell.  Checked here against the CPU oracle, bit for bit: duplicates across neighbouring
+columns and across tile boundaries, stale cells, x noise, unsorted streams (redo), groups, AoS, tile widths, shear on / off,
+and the ESL-like rig (real calibration geometry)."""
+import numpy as np
+import pytest
+
+import xmaps_oracle as O
+from x_maps_amd import XMapsEngine
+from x_maps_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _tiles_for_single_frames_too(monkeypatch):
+    monkeypatch.setenv("XM_COLS", "2")  # single-frame calls take the tiles as well (default: groups only)
+
+
+def _ref(tb, evs, **kw):
+    x, y, t, _ = S.to_soa(evs)
+    return O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, **kw)
+
+
+def _run(eng, evs):
+    x, y, t, _ = S.to_soa(evs)
+    return eng.process_frame(x, y, t)
+
+
+def _same(got, ref):
+    d, b, st = got
+    return np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]) and st.n_inliers == int(ref["mask"].sum())
+
+
+def test_shared_cell_rig_qualifies_and_matches_the_oracle():
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    with XMapsEngine(tb) as eng:
+        info = eng.cols_info()
+        assert info["mode"] == "own" and info["halo"] >= 4 and info["shear_m"] != 0, info
+        for f in range(4):
+            evs = S.make_events(cfg, frame=f)
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        pc = eng.path_counts()
+        assert pc["cols"] == 4 and pc["general"] == 0 and eng.sorted_fallbacks() == 0, pc
+
+
+@pytest.mark.parametrize("w", ["4", "12", "16"])
+def test_tile_widths(monkeypatch, w):
+    monkeypatch.setenv("XM_OWN_W", w)
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    with XMapsEngine(tb) as eng:
+        info = eng.cols_info()
+        assert info["mode"] == "own" and info["w"] == int(w), info
+        for f in range(2):
+            evs = S.make_events(cfg, frame=10 + f, n=60_000)
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        assert eng.path_counts()["cols"] == 2 and eng.sorted_fallbacks() == 0
+
+
+def test_unsheared_frame(monkeypatch):
+    """XM_OWN_SHEAR=0: the frame keeps its plain [rect_w][rect_h] layout; the bands of the (tile, 8-row group)s absorb the slant
+    on their own (the shear only makes the flush's stores fall into fewer frame columns)."""
+    monkeypatch.setenv("XM_OWN_SHEAR", "0")
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    with XMapsEngine(tb) as eng:
+        info = eng.cols_info()
+        assert info["mode"] == "own" and info["shear_m"] == 0 and info["shear_extra"] == 0, info
+        for f in range(2):
+            evs = S.make_events(cfg, frame=f)
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        assert eng.path_counts()["cols"] == 2
+
+
+@pytest.mark.parametrize("cpc,slant", [(2.0, 0.35), (4.6, -0.7), (1.4, 0.0), (7.5, -0.2)])
+def test_other_rig_shapes(cpc, slant):
+    """1.4 .. 7.5 time columns per cell (halo 4 or 8), slanted either way or not at all."""
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg, cols_per_cell=cpc, slant=slant)
+    with XMapsEngine(tb) as eng:
+        info = eng.cols_info()
+        assert info["mode"] == "own", info
+        assert info["halo"] == (8 if cpc > 5 else 4), info
+        for f in range(2):
+            evs = S.make_events(cfg, frame=20 + f)
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        assert eng.path_counts()["cols"] == 2 and eng.sorted_fallbacks() == 0
+
+
+def test_more_than_eight_columns_per_cell_keeps_the_packed_keys():
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg, cols_per_cell=9.5)
+    with XMapsEngine(tb) as eng:
+        assert eng.cols_info()["mode"] == "none"
+        evs = S.make_events(cfg, frame=1)
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        assert eng.path_counts()["cols"] == 0
+
+
+def test_no_stale_cells_when_the_content_changes_from_frame_to_frame():
+    """No tag, no clear: every tile stores its empty owned cells as zeros.  Frames that cover only a part of the scan, or have a
+    hole in the middle (whole tiles without an event), must not show the previous frame's cells."""
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    with XMapsEngine(tb, n_slots=1) as eng:
+        for f in range(18):
+            evs = S.make_events(cfg, frame=f % 3, n=40_000 + 9_000 * (f % 4))
+            if f % 3 == 1:
+                evs = evs[: len(evs) // 3]
+            if f % 3 == 2:
+                t = evs["t"].astype(np.int64)
+                evs = evs[(t < t[0] + 4_000) | (t > t[0] + 9_000)]
+            assert _same(_run(eng, evs), _ref(tb, evs)), f
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 18
+
+
+def test_last_writer_across_columns_and_tile_boundaries():
+    """The same camera pixel fires again one to three time columns later: both events land on the same frame cell from different
+    X-map columns -- also when the two columns belong to different tiles (the later one is then a halo event of the owner)."""
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    rng = np.random.default_rng(3)
+    evs = S.make_events(cfg, frame=5, n=50_000)
+    n = len(evs)
+    per_col = n // cfg.proj_w
+    src = rng.choice(n - 4 * per_col, 6_000, replace=False)
+    dst = src + rng.integers(per_col // 2, 3 * per_col, len(src))
+    evs["x"][dst], evs["y"][dst] = evs["x"][src], evs["y"][src]
+    # ... and some with a different x (another disparity) in the same row, so that the winner's VALUE matters
+    src2 = rng.choice(n - 4 * per_col, 3_000, replace=False)
+    dst2 = src2 + rng.integers(1, 2 * per_col, len(src2))
+    evs["y"][dst2] = evs["y"][src2]
+    evs["x"][dst2] = np.clip(evs["x"][src2].astype(np.int64) - rng.integers(0, 3, len(src2)), 0, cfg.cam_w - 1)
+    with XMapsEngine(tb) as eng:
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 1
+
+
+def test_x_noise_negative_disparities_and_rows_outside():
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    rng = np.random.default_rng(9)
+    evs = S.make_events(cfg, frame=11, n=45_000)
+    noisy = rng.random(len(evs)) < 0.05
+    evs["x"][noisy] = rng.integers(0, cfg.cam_w, int(noisy.sum()))  # any disparity, many negative (xmd:29)
+    with XMapsEngine(tb) as eng:
+        got, ref = _run(eng, evs), _ref(tb, evs)
+        assert 0 < int(ref["mask"].sum()) < len(evs)
+        assert _same(got, ref)
+        assert eng.sorted_fallbacks() == 0
+
+
+@pytest.mark.parametrize("kind", ["swapped_blocks", "one_late_event", "reversed"])
+def test_unsorted_streams_fail_the_tiles_and_are_redone_exactly(kind):
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    evs = S.make_events(cfg, frame=6, n=48_000)
+    if kind == "swapped_blocks":
+        a, b = evs[8_000:9_000].copy(), evs[30_000:31_000].copy()
+        evs[8_000:9_000], evs[30_000:31_000] = b, a
+    elif kind == "one_late_event":
+        e = evs[5_000].copy()
+        evs[5_000:20_000] = evs[5_001:20_001]
+        evs[20_000] = e
+    else:
+        evs = evs[::-1].copy()
+    with XMapsEngine(tb) as eng:
+        assert _same(_run(eng, evs), _ref(tb, evs))
+        assert eng.sorted_fallbacks() == 1
+
+
+def test_groups_and_aos():
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    frames = [S.make_events(cfg, frame=40 + f, n=30_000 + 5_000 * f) for f in range(5)]
+    frames[3] = frames[3][::-1].copy()  # one frame of the group is not sorted: redone
+    with XMapsEngine(tb, n_slots=5) as eng:
+        out = eng.process_event_frames(frames)
+        for f, (d, b) in enumerate(out):
+            r = _ref(tb, frames[f])
+            assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), f
+        assert eng.path_counts()["cols"] == 5 and eng.sorted_fallbacks() == 1
+        d, b, st = eng.process_events(frames[1])  # one AoS frame
+        r = _ref(tb, frames[1])
+        assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]) and st.n_inliers == int(r["mask"].sum())
+
+
+def test_unaligned_soa_input_takes_the_scalar_loader():
+    torch = pytest.importorskip("torch")
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    evs = S.make_events(cfg, frame=2, n=33_333)
+    x, y, t, _ = S.to_soa(evs)
+    dev = torch.device("cuda", 0)
+    pad = 3
+    X = torch.zeros(len(x) + pad, dtype=torch.int16, device=dev)
+    Y = torch.zeros(len(x) + pad, dtype=torch.int16, device=dev)
+    T = torch.zeros(len(x) + pad, dtype=torch.int64, device=dev)
+    X[pad:] = torch.from_numpy(x.view(np.int16)).to(dev)
+    Y[pad:] = torch.from_numpy(y.view(np.int16)).to(dev)
+    T[pad:] = torch.from_numpy(t).to(dev)
+    depth = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb) as eng:
+        eng.process_frame_device(X.data_ptr() + 2 * pad, Y.data_ptr() + 2 * pad, T.data_ptr() + 8 * pad, None, len(x), depth.data_ptr())
+        eng.sync()
+        assert eng.path_counts()["cols"] == 1
+    assert np.array_equal(depth.cpu().numpy(), _ref(tb, evs)["depth"])
+
+
+def test_esl_like_rig_real_calibration_geometry():
+    """BASELINE configs 1 / 3 stand-in: the reference's calibration (data/ESL_calib_hhi.yaml numbers), 1080 time columns on ~300
+    frame columns, ~150 k events per frame."""
+    from x_maps_amd import rig
+    cp, tb, evs0, _ = rig.make_esl_like(row_stride=13)
+    frames = [evs0] + [rig.render_events(cp, tb, row_stride=13, seed=s, t0_us=7_000_000 + 16_600 * s)[0] for s in (1, 2, 3)]
+    with XMapsEngine(tb, n_slots=4) as eng:
+        info = eng.cols_info()
+        assert info["mode"] == "own" and info["halo"] == 4 and info["nxs_max"] <= 8 and info["extras"] > 0, info
+        for f, evs in enumerate(frames[:2]):  # frame by frame
+            d, b, st = eng.process_events(evs)
+            r = _ref(tb, evs)
+            assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]) and st.n_inliers == int(r["mask"].sum()), f
+        out = eng.process_event_frames(frames)  # as a group
+        for f, (d, b) in enumerate(out):
+            r = _ref(tb, frames[f])
+            assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), f
+        assert eng.path_counts()["cols"] == 6 and eng.sorted_fallbacks() == 0

@@ -1,0 +1,60 @@
+"""The owner-tile analysis of xm_create (csrc/xmaps_hip.hip: own_plan) is host code: xm_own_plan_info runs it without a device.
+Which rigs qualify, and with what geometry -- including the ESL-like rig built from the reference's calibration numbers
+(its X-map comes from the oracle's CPU builder here; on the GPU box the product's own kernel builds it)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import xmaps_oracle as O
+from x_maps_amd import _native as N
+from x_maps_amd import rig
+from x_maps_amd import synthetic as S
+
+
+def _plan(tb):
+    lib = N.load_library()
+    mapx = np.ascontiguousarray(tb["cam_mapx_i16"], np.int16)
+    mapy = np.ascontiguousarray(tb["cam_mapy_i16"], np.int16)
+    xmap = np.ascontiguousarray(tb["proj_x_map"], np.int16)
+    cfg = N.xm_config()
+    cfg.struct_size = C.sizeof(N.xm_config)
+    cfg.cam_height, cfg.cam_width = mapx.shape
+    cfg.rect_width, cfg.rect_height = int(tb["rect_w"]), int(tb["rect_h"])
+    cfg.xmap_height, cfg.xmap_width = xmap.shape
+    cfg.x_offset = int(tb.get("x_offset", 4242))
+    cfg.cam_mapx_i16, cfg.cam_mapy_i16, cfg.proj_x_map = mapx.ctypes.data, mapy.ctypes.data, xmap.ctypes.data
+    a = (C.c_int32 * 12)()
+    N.check(lib.xm_own_plan_info(C.byref(cfg), a))
+    keys = ("mode", "w", "halo", "nxs_max", "shear_m", "shear_extra", "r_lo", "rows", "extras", "extras_max_per_tile", "delta_max",
+            "lds_bytes")
+    return dict(zip(keys, a))
+
+
+@pytest.mark.parametrize("cpc,slant,halo", [(3.3, -0.4, 4), (2.0, 0.35, 4), (4.6, -0.7, 4), (1.4, 0.0, 4), (7.5, -0.2, 8)])
+def test_shared_cell_rigs_qualify(cpc, slant, halo):
+    p = _plan(S.make_tables_shared_cells(S.C_SHARED, cols_per_cell=cpc, slant=slant))
+    assert p["mode"] == 2 and p["halo"] == halo and p["w"] == 8 and 1 <= p["nxs_max"] <= 16, p
+    assert p["delta_max"] == int(np.ceil(cpc)) - 1 or p["delta_max"] == int(np.ceil(cpc)), p
+    assert (p["shear_m"] == 0) == (slant == 0.0), p
+    # the frame's shear undoes the slant: (rows / 8) groups x m / 4096 columns
+    assert abs(p["shear_extra"] - abs(slant) * S.C_SHARED.rect_h) <= 3, p
+    assert p["lds_bytes"] < 16 * 1024
+
+
+def test_too_many_columns_per_cell_or_too_wide_tiles_do_not_qualify():
+    assert _plan(S.make_tables_shared_cells(S.C_SHARED, cols_per_cell=9.5))["mode"] == 0  # delta > 7
+    # 2.1 cells per time column over 1320 rows: thousands of a tile's cells lie outside any 16-column band (such rigs are
+    # injective and take the plain column tiles anyway)
+    assert _plan(S.make_tables(S.C_1M))["mode"] == 0
+
+
+def test_esl_like_rig_qualifies():
+    """1080 time columns on ~300 frame columns, slant -0.40 columns per row: owner tiles of 8 + 4 columns, a 6-column band, a few
+    hundred extras in the first and the last tile (where the rectified time map replicates its border)."""
+    cp, tb, evs, _ = rig.make_esl_like(row_stride=13, x_map_fn=lambda tm, *a: O.compute_x_map_from_time_map(np.asarray(tm, np.float32), *a))
+    p = _plan(tb)
+    assert p["mode"] == 2 and p["w"] == 8 and p["halo"] == 4 and p["delta_max"] == 3, p
+    assert p["nxs_max"] <= 8 and p["extras"] < 2000 and p["extras_max_per_tile"] <= 1024, p
+    assert p["lds_bytes"] <= 32 * 1024, p  # five tiles per CU
+    assert p["r_lo"] % 8 == 0 and p["r_lo"] <= tb["cam_mapy_i16"].min() and p["r_lo"] + p["rows"] - 1 == tb["cam_mapy_i16"].max()

@@ -14,9 +14,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libxmaps_hip.so")
 SOURCES = [os.path.join(PKG_DIR, "csrc", "xmaps_hip.hip")]
-DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", "xmaps_kernels.hpp"),
-                     os.path.join(PKG_DIR, "csrc", "turbo_lut.inc"),
-                     os.path.join(ROOT, "include", "xmaps.h")]
+DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", f) for f in ("xmaps_kernels.hpp", "xmaps_k1cols.hpp", "xmaps_k1own.hpp",
+                                                                  "xmaps_ingest.hpp", "turbo_lut.inc")] + [
+    os.path.join(ROOT, "include", "xmaps.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY, XM_ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6
@@ -123,6 +123,8 @@ SYMBOLS = {
     "xm_sync": (C.c_int, [_P]),
     "xm_sorted_fallbacks": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_path_counts": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "xm_cols_info": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "xm_own_plan_info": (C.c_int, [C.POINTER(xm_config), C.POINTER(C.c_int32)]),
     "xm_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_process_frame_aos": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_last_frame_stats": (C.c_int, [_P, C.POINTER(xm_frame_stats)]),

@@ -291,7 +291,7 @@ def build_eval_tables(cp: CamProjCalibrationParams, **kw) -> dict:
 
 def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwards=True, device: int = 0,
                  x_map_on_gpu: bool = True, projector_time_map_rectified: Optional[np.ndarray] = None,
-                 zero_undistort_proj_map: bool = False, time_map_border: str = "replicate") -> dict:
+                 zero_undistort_proj_map: bool = False, time_map_border: str = "replicate", x_map_fn=None) -> dict:
     """Everything DepthReprojectionPipe.__post_init__ builds (python/depth_reprojection_pipe.py:69-99), as the
     tables dict XMapsEngine / RuntimeParams.tables take.  Projector = camera 1 of the stereo pair (calib:194-217)."""
     size = (cp.rect_image_width, cp.rect_image_height)
@@ -310,7 +310,9 @@ def build_tables(cp: CamProjCalibrationParams, z_near=0.1, z_far=1.2, scan_upwar
         time_map = generate_linear_projector_time_map(cp.projector_width, cp.projector_height, scan_upwards)
         time_map_rect = remap_nearest(time_map, pmx, pmy, time_map_border)  # BORDER_REPLICATE live, BORDER_CONSTANT in eval
     x_off, xw = 4242, cp.projector_width
-    if x_map_on_gpu:
+    if x_map_fn is not None:  # a caller-supplied builder with the reference's signature (the CPU tests pass the oracle's)
+        x_map, _ = x_map_fn(time_map_rect, xw, xw - 1, x_off, cp.projector_width)
+    elif x_map_on_gpu:
         from .x_map import compute_x_map_from_time_map
         x_map, _ = compute_x_map_from_time_map(time_map_rect, xw, xw - 1, x_off, cp.projector_width, device=device)
     else:

@@ -4,6 +4,7 @@
 // -ffp-contract=off keeps the time normalisation (divide, multiply, rint) unfused = bit-exact with NumPy.
 #include "xmaps_kernels.hpp"
 #include "xmaps_k1cols.hpp"
+#include "xmaps_k1own.hpp"
 #include "xmaps_ingest.hpp"
 
 #include <hip/hip_ext.h>
@@ -194,6 +195,17 @@ struct xm_handle {
                              // launch, the boundary pass, costs the pipelined one-frame-per-call path more than the tiles save)
   int cols_xr_min = 0, cols_w_max = 0, cols_target = 3700;
   int cols_flags = 0;  // COLS_F_ALL_IN_FRAME when no live (row, column) pair of the rig maps outside the frame
+  // owner tiles (xmaps_k1own.hpp): the rig's (row, column) -> cell map is not injective (the reference's own calibration), but
+  // every cell's columns lie within own_halo columns of its first one: cols_ok with own_mode set; fixed tile width own_w
+  bool own_mode = false;
+  int own_w = 0, own_halo = 0;
+  uint16_t* d_xmap_own = nullptr;
+  uint16_t* d_xmap_extra = nullptr;
+  int4* d_own_tiles = nullptr;
+  int16_t* d_own_base = nullptr;
+  uint16_t* d_own_masks = nullptr;
+  u32* d_own_extra_cells = nullptr;
+  int own_extras = 0;  // owner cells outside their tile's band, over all tiles
   std::atomic<uint64_t> path_counts[4] = {};  // frames enqueued per K1 variant (xm_path_counts)
   // (atomics: with XM_FLAG_LAUNCH_WORKERS the launch threads and the API thread all pass through enqueue_frame)
   std::atomic<int> key32_score{0};  // raised by frames that failed the compact path, decays with every frame that took it
@@ -458,14 +470,16 @@ size_t k2_lds_bytes(const xm_handle* h, int ppt) {
 
 template <int FMT>
 void launch_k2(xm_handle* h, hipStream_t stream, const u64* key_frame, SlotState* st, u32 tag_override, const unsigned char* dirty,
-               float* depth, uint8_t* bgr) {
+               float* depth, uint8_t* bgr, bool unsheared = false) {
   const int ppt = k2_ppt(h, 1);
   const dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY));
+  DevTables tb = h->tb;
+  if (unsheared) tb.shear_m = tb.shear_bias = tb.shear_extra = 0;  // a plain [rect_w][rect_h] u16 frame (shards), not a slot's frame16
   if (ppt == 1)
-    XM_LAUNCH((k_frame_proj_tiled<FMT, 1>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 1), stream, key_frame, h->tb, st, tag_override,
+    XM_LAUNCH((k_frame_proj_tiled<FMT, 1>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 1), stream, key_frame, tb, st, tag_override,
               dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[0]);
   else
-    XM_LAUNCH((k_frame_proj_tiled<FMT, 2>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 2), stream, key_frame, h->tb, st, tag_override,
+    XM_LAUNCH((k_frame_proj_tiled<FMT, 2>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 2), stream, key_frame, tb, st, tag_override,
               dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[1]);
 }
 
@@ -488,8 +502,231 @@ size_t cols_lds_bytes(const xm_handle* h, int W) {  // mirrors the carve-up at t
   return 16 * (lut_q + xm_q + slot_q);
 }
 
+size_t own_plan_lds_bytes(int nxs_max, int hrp, int extra_max) {  // mirrors the carve-up at the top of scatter_own_body
+  return (size_t)4 * nxs_max * hrp + (size_t)4 * extra_max + (size_t)8 * (hrp / 8) + (size_t)2 * hrp;
+}
+size_t own_lds_bytes(const xm_handle* h) { return own_plan_lds_bytes(h->tb.own_nxs_max, h->tb.own_hrp, h->tb.own_extra_max); }
+
+// ---- owner tiles (xmaps_k1own.hpp): the rig's ownership tables, worked out once on the host -------------------------------------
+struct OwnPlan {  // what own_plan() works out (host memory) and own_setup() uploads
+  bool ok = false, all_in = true;
+  int W = 0, halo = 0, r_lo = 0, hr = 0, hrp = 0, nxs_max = 0, extra_max = 0, m = 0, bias = 0, extra_cols = 0, delta_max = 0;
+  std::vector<uint16_t> packed, xextra, masks;
+  std::vector<int4> tiles;
+  std::vector<int16_t> bases;
+  std::vector<u32> extra_flat;
+};
+
+// Pure host code (no device needed: xm_own_plan_info runs it for the CPU tests).  pl.ok says whether the rig qualifies.
+void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
+  const int xmap_w = cfg->xmap_width, rect_w = cfg->rect_width, rect_h = cfg->rect_height, x_off = cfg->x_offset;
+  const int rows = std::min(xmap_h - 1, rect_h);
+  if (rows <= 0 || rect_h < xmap_h - 1 || xr_min <= -x_off) return;  // (an undefined X-map cell, 0, must read as dead)
+  int yr_min = 32767, yr_max = -32768;
+  const size_t cam_px = (size_t)cfg->cam_width * cfg->cam_height;
+  for (size_t i = 0; i < cam_px; ++i) {
+    yr_min = std::min<int>(yr_min, cfg->cam_mapy_i16[i]);
+    yr_max = std::max<int>(yr_max, cfg->cam_mapy_i16[i]);
+  }
+  const int r_lo = std::max(0, yr_min) & ~7, r_hi = std::min(yr_max, rows - 1);
+  if (r_hi < r_lo) return;
+  const int hr = r_hi - r_lo + 1, hrp = (hr + 7) & ~7;
+  int W = 8;
+  if (const char* e = getenv("XM_OWN_W")) W = atoi(e);
+  W = std::max(OWN_BW, std::min(W, 64)) / OWN_BW * OWN_BW;
+  // 1. owner column of every cell, row by row: delta = column - first column of the row that maps to the same cell
+  std::vector<uint16_t>& packed = pl.packed;  // [c][row], as tb.xmap
+  packed.assign((size_t)xmap_w * xmap_h, 0);
+  std::vector<int> first(rect_w, -1), fcs((size_t)xmap_w);
+  int delta_max = 0;
+  bool all_in = true;
+  for (int r = r_lo; r <= r_hi; ++r) {
+    const int16_t* X = cfg->proj_x_map + (size_t)r * xmap_w;
+    for (int c = 0; c < xmap_w; ++c) {
+      fcs[c] = -1;
+      const int xp = X[c], fu = xp - x_off;
+      if (fu < xr_min) continue;  // dead: no LUT entry gives disp >= 0
+      if (xp < 0 || xp >= (1 << OWN_XP_BITS)) return;
+      int fc = (int)(short)fu;
+      if (fc < 0) fc += rect_w;  // NumPy's negative wrap
+      const bool in = fc >= 0 && fc < rect_w;
+      if (!in || fu < 0) all_in = false;  // the kernel's lean path takes fu as the column
+      int delta = 0;
+      if (in) {
+        if (first[fc] < 0) first[fc] = c;
+        delta = c - first[fc];
+        fcs[c] = fc;
+      }
+      if (delta > OWN_MAX_DELTA) return;
+      delta_max = std::max(delta_max, delta);
+      packed[(size_t)c * xmap_h + r] = (uint16_t)(xp | (delta << OWN_XP_BITS));
+    }
+    for (int c = 0; c < xmap_w; ++c)
+      if (fcs[c] >= 0) first[fcs[c]] = -1;
+  }
+  const int halo = (delta_max + OWN_BW - 1) / OWN_BW * OWN_BW;
+  // 2. the shear: slope of the cell column against the row along the middle time columns (least squares over the live entries)
+  double slope = 0.0;
+  {
+    double sn = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
+    for (int c = xmap_w / 4; c < xmap_w; c += std::max(1, xmap_w / 4)) {
+      sn = sx = sy = sxx = sxy = 0;
+      for (int r = r_lo; r <= r_hi; ++r) {
+        const int fu = cfg->proj_x_map[(size_t)r * xmap_w + c] - x_off;
+        if (fu < xr_min || fu < 0 || fu >= rect_w) continue;
+        sn += 1; sx += r; sy += fu; sxx += (double)r * r; sxy += (double)r * fu;
+      }
+      if (sn >= 16 && sn * sxx - sx * sx > 0) {
+        slope = (sn * sxy - sx * sy) / (sn * sxx - sx * sx);
+        if (c >= xmap_w / 2) break;  // prefer the middle column
+      }
+    }
+  }
+  int m = 0;
+  if (std::fabs(slope) * hr >= 24.0) m = (int)std::lround(-slope * 8.0 * 4096.0);
+  if (const char* e = getenv("XM_OWN_SHEAR")) m = atoi(e);  // experiments
+  int sh_min = 0, sh_max = 0;
+  for (int g = 0; g <= (rect_h - 1) >> 3; ++g) {
+    const int sh = (g * m) >> 12;
+    sh_min = std::min(sh_min, sh);
+    sh_max = std::max(sh_max, sh);
+  }
+  const int bias = -sh_min, extra = sh_max - sh_min;
+  if (rect_w + extra > 32767) return;
+  // 3. per (tile, 8-row group): where its cells lie in the sheared frame.  The band of a group = the window of NX frame
+  //    columns that holds most of its owner cells (away from the middle time column the X-map's slant differs a little from
+  //    the frame's shear: the window moves slowly from group to group); owner cells outside it are "extras" (where the rectified
+  //    time map replicates its border the X-map jumps by hundreds of columns: first / last tile of the ESL rig).  NX = the
+  //    narrowest band that leaves (almost) no more extras than the widest one.
+  const int nt = (xmap_w + W - 1) / W, ng = hrp / 8;
+  const auto owner_col = [&](int r, int c, int& xs) {  // owner pairs only: the cell's column in the sheared frame
+    const uint16_t pk = packed[(size_t)c * xmap_h + r];
+    if (!pk || (pk >> OWN_XP_BITS) != 0) return false;
+    int fc = (int)(short)((int)(pk & ((1 << OWN_XP_BITS) - 1)) - x_off);
+    if (fc < 0) fc += rect_w;
+    if (fc < 0 || fc >= rect_w) return false;
+    xs = fc + bias + (((r >> 3) * m) >> 12);
+    return true;
+  };
+  std::vector<std::vector<int>> cells((size_t)nt * ng);  // sorted sheared columns of every (tile, group)'s owner cells
+  for (int r = r_lo; r <= r_hi; ++r)
+    for (int c = 0; c < xmap_w; ++c) {
+      int xs;
+      if (owner_col(r, c, xs)) cells[(size_t)(c / W) * ng + ((r - r_lo) >> 3)].push_back(xs);
+    }
+  for (auto& v : cells) std::sort(v.begin(), v.end());
+  const auto best_window = [](const std::vector<int>& v, int nx, int& start) {  // most cells inside [start, start + nx)
+    size_t best = 0, j = 0;
+    start = v.empty() ? 0 : v[0];
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (i && v[i] == v[i - 1]) continue;
+      while (j < v.size() && v[j] < v[i] + nx) ++j;
+      if (j - i > best) {
+        best = j - i;
+        start = v[i];
+      }
+    }
+    return best;
+  };
+  size_t extras_at[OWN_MAX_NXS + 1] = {};
+  for (int nx = 1; nx <= OWN_MAX_NXS; ++nx)
+    for (const auto& v : cells) {
+      int st;
+      extras_at[nx] += v.size() - best_window(v, nx, st);
+    }
+  int NX = OWN_MAX_NXS;
+  while (NX > 1 && extras_at[NX - 1] <= extras_at[OWN_MAX_NXS] + extras_at[OWN_MAX_NXS] / 8 + 64) NX -= 1;
+  if (const char* e = getenv("XM_OWN_NX")) NX = std::max(1, std::min(atoi(e), (int)OWN_MAX_NXS));  // experiments
+  std::vector<int4>& tiles = pl.tiles;
+  std::vector<int16_t>& bases = pl.bases;
+  tiles.assign(nt, make_int4(0, 0, 0, 0));
+  bases.assign((size_t)nt * ng, 0);
+  for (int t = 0; t < nt; ++t)
+    for (int g = 0; g < ng; ++g) {
+      int st;
+      best_window(cells[(size_t)t * ng + g], NX, st);
+      bases[(size_t)t * ng + g] = (int16_t)st;
+    }
+  std::vector<uint16_t>&masks = pl.masks, &xextra = pl.xextra;
+  masks.assign((size_t)nt * hrp, 0);
+  xextra.assign((size_t)xmap_w * xmap_h, 0);
+  std::vector<std::vector<u32>> extra_cells(nt);
+  for (int r = r_lo; r <= r_hi; ++r)
+    for (int c = 0; c < xmap_w; ++c) {
+      int xs;
+      if (!owner_col(r, c, xs)) continue;
+      const int t = c / W, k = xs - bases[(size_t)t * ng + ((r - r_lo) >> 3)];
+      if (k >= 0 && k < NX) {
+        masks[(size_t)t * hrp + (r - r_lo)] |= (uint16_t)(1u << k);
+        tiles[t].x = std::max(tiles[t].x, k + 1);
+      } else {
+        extra_cells[t].push_back((u32)xs * (u32)rect_h + (u32)r);
+        if (extra_cells[t].size() > 4096) return;  // (a wild X-map: the packed keys stay)
+        xextra[(size_t)c * xmap_h + r] = (uint16_t)extra_cells[t].size();
+      }
+    }
+  int nxs_max = 1, extra_max = 0;
+  std::vector<u32>& extra_flat = pl.extra_flat;
+  extra_flat.clear();
+  for (int t = 0; t < nt; ++t) {
+    tiles[t].y = (int)extra_flat.size();
+    tiles[t].z = (int)extra_cells[t].size();
+    extra_flat.insert(extra_flat.end(), extra_cells[t].begin(), extra_cells[t].end());
+    nxs_max = std::max(nxs_max, tiles[t].x);
+    extra_max = std::max(extra_max, tiles[t].z);
+  }
+  extra_max = (extra_max + 3) & ~3;
+  if (own_plan_lds_bytes(nxs_max, hrp, extra_max) > 60 * 1024) return;  // LDS per block
+  extra_flat.push_back(0);
+  pl.W = W; pl.halo = halo; pl.r_lo = r_lo; pl.hr = hr; pl.hrp = hrp; pl.nxs_max = nxs_max; pl.extra_max = extra_max;
+  pl.m = m; pl.bias = bias; pl.extra_cols = extra; pl.delta_max = delta_max; pl.all_in = all_in;
+  pl.ok = true;
+}
+
+// Returns XM_OK whether or not the rig qualifies (h->own_mode says); an error only for HIP failures.
+int own_setup(xm_handle* h, const xm_config* cfg, int xr_min) {
+  OwnPlan pl;
+  own_plan(cfg, h->tb.xmap_h, xr_min, pl);
+  if (!pl.ok) return XM_OK;
+  const auto up = [](auto** dst, const auto& v) -> hipError_t {
+    typedef typename std::remove_reference<decltype(v)>::type::value_type E;
+    hipError_t e = hipMalloc((void**)dst, v.size() * sizeof(E) + 64);
+    return e != hipSuccess ? e : hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice);
+  };
+  HIP_TRY(up(&h->d_xmap_own, pl.packed));
+  HIP_TRY(up(&h->d_xmap_extra, pl.xextra));
+  HIP_TRY(up(&h->d_own_tiles, pl.tiles));
+  HIP_TRY(up(&h->d_own_base, pl.bases));
+  HIP_TRY(up(&h->d_own_masks, pl.masks));
+  HIP_TRY(up(&h->d_own_extra_cells, pl.extra_flat));
+  h->own_extras = (int)pl.extra_flat.size() - 1;
+  h->tb.xmap_own = h->d_xmap_own;
+  h->tb.xmap_extra = h->d_xmap_extra;
+  h->tb.own_tiles = h->d_own_tiles;
+  h->tb.own_base = h->d_own_base;
+  h->tb.own_masks = h->d_own_masks;
+  h->tb.own_extra_cells = h->d_own_extra_cells;
+  h->tb.own_r_lo = pl.r_lo;
+  h->tb.own_hr = pl.hr;
+  h->tb.own_hrp = pl.hrp;
+  h->tb.own_nxs_max = pl.nxs_max;
+  h->tb.own_extra_max = pl.extra_max;
+  h->tb.shear_m = pl.m;
+  h->tb.shear_bias = pl.bias;
+  h->tb.shear_extra = pl.extra_cols;
+  h->own_mode = true;
+  h->own_w = pl.W;
+  h->own_halo = pl.halo;
+  if (pl.all_in) h->cols_flags |= COLS_F_ALL_IN_FRAME;
+  return XM_OK;
+}
+
 // time columns per tile for frames of n events: about cols_target events per tile, within the LDS budget; 0 = not this path
 int cols_width(const xm_handle* h, u64 n) {
+  if (h->cols_ok && h->own_mode) {  // owner tiles: one fixed width (the ownership tables are built for it); not for nearly empty frames
+    const u64 tiles = grid_for(h->tb.xmap_w, h->own_w);
+    return n >= tiles * 128 && n < (1ull << 28) ? h->own_w : 0;
+  }
   if (!h->cols_ok || h->cols_w_max < 1 || h->tb.xmap_w < 1 || n == 0 || n >= (1ull << 28)) return 0;
   const double per_col = (double)n / (double)h->tb.xmap_w;
   int W = (int)((double)h->cols_target / per_col);
@@ -501,6 +738,11 @@ int cols_width(const xm_handle* h, u64 n) {
 unsigned cols_threads(const xm_handle* h, u64 n, int W) {
   static const int force = getenv("XM_COLS_THREADS") ? atoi(getenv("XM_COLS_THREADS")) : 0;  // experiments
   if (force >= 64 && force <= COLS_MAX_THREADS && force % 64 == 0) return (unsigned)force;
+  if (h->own_mode) {  // own + halo columns in one pass where 512 threads hold them
+    const double per = (double)n / (double)h->tb.xmap_w * (W + h->own_halo);
+    const unsigned t = ((unsigned)(per * 1.12 / COLS_EPT) + 63u) / 64u * 64u;
+    return std::max(128u, std::min(t, (unsigned)COLS_MAX_THREADS));
+  }
   const double per_tile = (double)n / (double)h->tb.xmap_w * W;
   // one pass for a tile 12 % above the mean (Poisson spread of an evenly filled scan); fuller tiles take a second pass.
   // Tiles of more than 2048 events get the full 512 threads even when 448 would hold them: three blocks per CU are then
@@ -513,6 +755,7 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W) {
 
 // K0b: the tile boundaries + column thresholds of the frame (half a wave per boundary), left behind the slot's u16 frame
 void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
+  if (h->own_mode) W = OWN_BW;  // owner tiles: boundaries every OWN_BW columns (tile = own_w columns + a halo behind them)
   const unsigned nb = grid_for(h->tb.xmap_w, W);
   if (ev.aos)
     XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
@@ -524,6 +767,17 @@ void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, i
 
 int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint16_t* frame16, int W, hipStream_t stream) {
   const bool vec16 = !ev.aos && aligned(ev.x, 16) && aligned(ev.y, 16) && aligned(ev.t, 16);
+  if (h->own_mode) {
+    auto kern = k_scatter_own<false, false>;
+    if (ev.aos) kern = k_scatter_own<true, false>;
+    else if (vec16) kern = k_scatter_own<false, true>;
+    const size_t lds = own_lds_bytes(h);
+    int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
+    if (rc) return rc;
+    XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, W)), dim3(cols_threads(h, ev.n, W)), lds, stream, ev.x, ev.y, (const long long*)ev.t,
+              (const uint4*)ev.aos, (u32)ev.n, h->tb, st, frame16, W, h->own_halo, h->cols_flags);
+    return XM_OK;
+  }
   auto kern = k_scatter_cols<false, false>;
   if (ev.aos) kern = k_scatter_cols<true, false>;
   else if (vec16) kern = k_scatter_cols<false, true>;
@@ -705,12 +959,28 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   const auto prof_slot = [&](int i) { if (prof) g_prof = ProfCtx{prof[2 * i], prof[2 * i + 1]}; };
   if constexpr (std::is_same<T, long long>::value && !HAS_P) {
     if (cols_w) {  // column tiles: K1 grid = (tiles, frames), K2 on the plain u16 frames
+      int rc;
+      if (h->own_mode) {  // owner tiles (the rig's X-map is not injective): boundaries every OWN_BW columns, tiles of own_w + halo
+        auto kern = k_scatter_own_batch<AOS, false>;
+        if constexpr (!AOS) {
+          if (vec16) kern = k_scatter_own_batch<false, true>;
+        }
+        const size_t lds = own_lds_bytes(h);
+        rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc) return rc;
+        prof_slot(0);
+        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, OWN_BW) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
+                  dim3(256), 0, stream, d_descs, h->tb, OWN_BW);
+        prof_slot(1);
+        XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
+                  cols_w, h->own_halo, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
+      } else {
       auto kern = k_scatter_cols_batch<AOS, false>;
       if constexpr (!AOS) {
         if (vec16) kern = k_scatter_cols_batch<false, true>;
       }
       const size_t lds = cols_lds_bytes(h, cols_w);
-      int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
+      rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
       if (rc) return rc;
       prof_slot(0);
       XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
@@ -718,6 +988,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
+      }
       prof_slot(2);
       if (!d_descs_redo) {
         launch_k2_batch<2>(h, stream, d_descs, n_frames);
@@ -1459,6 +1730,19 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     }
     h->cols_ok = injective && h->d_pmap && !(ec && ec[0] == '0');
     h->cols_single = ec && ec[0] == '2';
+    if (!injective && cfg->view == XM_VIEW_PROJECTOR && no_wrap && h->d_pmap && !(ec && ec[0] == '0')) {
+      // the reference's own calibration: several time columns per frame cell -> owner tiles (xmaps_k1own.hpp)
+      h->cols_flags = 0;
+      const int rc_own = own_setup(h, cfg, xr_min);
+      if (rc_own) {
+        xm_destroy(h);
+        return rc_own;
+      }
+      h->cols_ok = h->own_mode;
+      // single-frame calls take the owner tiles too unless XM_COLS=1 says groups only (measured on ESL-like frames, four frames in
+      // flight: 12.05 us per frame against 13.6 with the one-thread-per-event kernel and its 150 k divergent atomics)
+      if (h->own_mode && !(ec && ec[0] == '1')) h->cols_single = true;
+    }
     // the compact key frame orders the writers of a cell by TILE only: two time columns of one tile that share a cell would be
     // ordered by their disparity bits -- it needs the same property (the 64-bit keys carry the full event index and do not)
     if (cfg->view == XM_VIEW_PROJECTOR) h->key32_ok = h->key32_ok && injective;
@@ -1518,7 +1802,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       while (wm < 16 && cols_lds_bytes(h, wm + 1) <= budget) wm += 1;
       h->cols_w_max = wm;
     }
-    if (h->cols_w_max < 1) h->cols_ok = false;
+    if (h->cols_w_max < 1 && !h->own_mode) h->cols_ok = false;
   }
 #ifdef XM_ABLATE
   if (const char* e = getenv("XM_ABLATE")) {
@@ -1557,7 +1841,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       XM_TRY_CREATE(hipMemset(s.key32, 0, h->key_cells * sizeof(u32)));
     }
     if (h->cols_ok) {  // cells no (row, column) pair maps to are never written: they stay 0 from here on
-      const size_t bytes = cols_frame_bytes(h->key_cells, cfg->xmap_width);  // frame + K0b's bounds and thresholds
+      const size_t bytes = cols_frame_bytes(frame16_cells(h->tb), cfg->xmap_width);  // frame + K0b's bounds and thresholds
       XM_TRY_CREATE(hipMalloc((void**)&s.frame16, bytes));
       XM_TRY_CREATE(hipMemset(s.frame16, 0, bytes));
     }
@@ -1669,6 +1953,12 @@ void xm_destroy(xm_handle* h) {
   if (h->d_states) (void)hipFree(h->d_states);
   if (h->d_lut) (void)hipFree(h->d_lut);
   if (h->d_xmap) (void)hipFree(h->d_xmap);
+  if (h->d_xmap_own) (void)hipFree(h->d_xmap_own);
+  if (h->d_own_tiles) (void)hipFree(h->d_own_tiles);
+  if (h->d_xmap_extra) (void)hipFree(h->d_xmap_extra);
+  if (h->d_own_base) (void)hipFree(h->d_own_base);
+  if (h->d_own_extra_cells) (void)hipFree(h->d_own_extra_cells);
+  if (h->d_own_masks) (void)hipFree(h->d_own_masks);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
   for (int g = 0; g < 2; ++g) {
@@ -1682,6 +1972,43 @@ void xm_destroy(xm_handle* h) {
 int xm_path_counts(xm_handle* h, uint64_t counts[4]) {
   if (!h || !counts) return fail(XM_ERR_INVALID, "NULL argument");
   for (int i = 0; i < 4; ++i) counts[i] = h->path_counts[i].load(std::memory_order_relaxed);
+  return XM_OK;
+}
+
+int xm_cols_info(xm_handle* h, int32_t info[12]) {
+  if (!h || !info) return fail(XM_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < 12; ++i) info[i] = 0;
+  info[0] = !h->cols_ok ? 0 : h->own_mode ? 2 : 1;
+  if (h->cols_ok && h->own_mode) {
+    info[1] = h->own_w;
+    info[2] = h->own_halo;
+    info[3] = h->tb.own_nxs_max;
+    info[4] = h->tb.shear_m;
+    info[5] = h->tb.shear_extra;
+    info[6] = h->tb.own_r_lo;
+    info[7] = h->tb.own_hr;
+    info[8] = h->own_extras;
+    info[9] = h->tb.own_extra_max;
+  }
+  return XM_OK;
+}
+
+int xm_own_plan_info(const xm_config* cfg, int32_t info[12]) {
+  if (!cfg || !info) return fail(XM_ERR_INVALID, "NULL argument");
+  if (cfg->struct_size != sizeof(xm_config)) return fail(XM_ERR_INVALID, "xm_config.struct_size");
+  if (!cfg->cam_mapx_i16 || !cfg->cam_mapy_i16 || !cfg->proj_x_map || cfg->cam_width <= 0 || cfg->cam_height <= 0 ||
+      cfg->xmap_width <= 1 || cfg->rect_width <= 0 || cfg->rect_height <= 0)
+    return fail(XM_ERR_INVALID, "bad tables");
+  for (int i = 0; i < 12; ++i) info[i] = 0;
+  const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
+  int xr_min = 32767;
+  for (size_t i = 0; i < (size_t)cfg->cam_width * cfg->cam_height; ++i) xr_min = std::min<int>(xr_min, cfg->cam_mapx_i16[i]);
+  OwnPlan pl;
+  own_plan(cfg, xmap_h, xr_min, pl);
+  if (!pl.ok) return XM_OK;
+  info[0] = 2; info[1] = pl.W; info[2] = pl.halo; info[3] = pl.nxs_max; info[4] = pl.m; info[5] = pl.extra_cols; info[6] = pl.r_lo;
+  info[7] = pl.hr; info[8] = (int)pl.extra_flat.size() - 1; info[9] = pl.extra_max; info[10] = pl.delta_max;
+  info[11] = (int)own_plan_lds_bytes(pl.nxs_max, pl.hrp, pl.extra_max);
   return XM_OK;
 }
 
@@ -2569,7 +2896,7 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
   hipStream_t stream = h->slots[0].stream;
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (h->k2_direct) return fail(XM_ERR_INVALID, "xm_shard_finish_u16 needs the tiled frame kernel (XM_K2_DIRECT is set)");
-    launch_k2<2>(h, stream, reinterpret_cast<const u64*>(disp_frame), h->aux_st, 1u, nullptr, depth_out, bgr_out);
+    launch_k2<2>(h, stream, reinterpret_cast<const u64*>(disp_frame), h->aux_st, 1u, nullptr, depth_out, bgr_out, true);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     hipLaunchKernelGGL(k_frame_direct_u16, dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, disp_frame, px, h->tb.dlut, depth_out, bgr_out);

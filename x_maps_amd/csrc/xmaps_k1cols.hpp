@@ -215,7 +215,7 @@ template <bool AOS>
 __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos, const int n, const DevTables& tb, const int W,
                                                  XM_GLOBAL unsigned char* frame_base, const u32 blk) {
   typedef long long T;
-  const size_t key_cells = (size_t)tb.rect_w * (size_t)tb.rect_h;
+  const size_t key_cells = frame16_cells(tb);
   XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
   XM_GLOBAL u32* thr = (XM_GLOBAL u32*)(frame_base + cols_thr_offset(key_cells, tb.xmap_w));
   constexpr int G = COLS_BOUNDS_LANES, FIN = COLS_BOUNDS_FIN;
@@ -357,7 +357,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63;
   const int n = (int)n_ev;
   const int cap = nthreads * EPT;  // events per pass
-  const size_t key_cells = (size_t)tb.rect_w * (size_t)tb.rect_h;
+  const size_t key_cells = frame16_cells(tb);
   gp_i4 bounds = (gp_i4)((const XM_GLOBAL unsigned char*)frame16 + cols_bounds_offset(key_cells));
   const XM_GLOBAL u32* thr = (const XM_GLOBAL u32*)((const XM_GLOBAL unsigned char*)frame16 + cols_thr_offset(key_cells, tb.xmap_w));
   // LDS carve-up (uint4 units; each band keeps 1 quad of alignment slack in front and a wave of slack behind it for the

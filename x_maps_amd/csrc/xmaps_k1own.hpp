@@ -1,0 +1,336 @@
+// xmaps_k1own.hpp -- K1 "owner tiles": the column tiles of xmaps_k1cols.hpp for rigs whose (row, time column) -> frame cell
+// map is NOT injective -- the reference's own calibration: X_MAP_WIDTH = projector_width = 1080 time columns
+// (x_maps_disparity.py:58-59) land on ~300 columns of the rectified frame (cam_proj_calibration.py:299-303), so up to four
+// consecutive time columns of a row share one cell and the plain column tiles (one slot per (row, column) pair, one owner
+// per cell by injectivity) do not apply.  (gfx950 / MI355X; included by xmaps_hip.hip after xmaps_k1cols.hpp)
+//
+//   * OWNER of a cell = the FIRST time column of its row that maps to it; delta(row, c) = c - owner column (0..7, found once
+//     in xm_create and packed into the top 3 bits of a second copy of the X-map: xp | delta << 13).  Tile T = W time columns
+//     [c0, c0 + W) owns the cells whose owner column is one of its own.  It reads the events of its columns AND of a halo of
+//     `halo` >= max delta columns behind them: an event of column c belongs to the tile iff c0 <= c - delta < c0 + W.  Halo
+//     events are read twice (by their own tile, which drops those whose cell the previous tile owns, and by that one).
+//     Every cell has exactly one owner tile: last-writer-wins is resolved in the tile's LDS slots (ds_max on
+//     (local index + 1) << 16 | disparity), the flush is a PLAIN 2-byte store, winners and empties alike -- the frame is
+//     rewritten completely by every frame: no tag, no clear, no atomics.
+//   * slots are indexed by the CELL, not by (row, column): on such rigs the X-map is strongly slanted (ESL: a time column's
+//     cell moves 0.37 .. 0.43 columns per row), so a tile's cells form a thin diagonal band.  The u16 disparity frame is
+//     SHEARED by whole columns per 8-row group -- cell (x, row) lives at column x + bias + ((row >> 3) * m >> 12), m fitted to
+//     the rig's middle time column in xm_create -- and every (tile, 8-row group) has its own first column `base` (what is left
+//     of the slant away from the middle): the slot array is [nxs sheared columns][rows the LUT can reach] with nxs = 6 on the
+//     ESL rig, the flush walks it in memory order (lanes = consecutive rows of one frame column), a precomputed bit mask per
+//     (tile, row) says which of the band's cells the tile owns.  K2 reads the same layout (its 16-byte loads take 8 aligned
+//     rows of one column: the shear is constant there).
+//   * cells outside the band ("extras": where the rectified time map replicates its border the X-map's arg-min jumps by hundreds
+//     of columns -- first and last tile of the ESL rig, ~470 cells) get a slot of their own behind the band (index from a second
+//     table, read by those events only) and are flushed one by one.
+//   * sparse frames (ESL: 140 events per time column, 1320 rows): staging the LUT / X-map bands through LDS costs more than
+//     it saves, both gathers go to L2 (tables of 1.2 + 2.9 MB, tiles in XCD-contiguous order), eight in flight per lane.
+//   * exactness for any input, as for the column tiles: every event a tile loads is verified against the tile's thresholds;
+//     a tile that objects fails the frame through the flag of the sorted-order verification -> automatic redo on the
+//     64-bit general path.
+// Algorithmic bytes are K1's: 24 B/event.
+#pragma once
+#include "xmaps_k1cols.hpp"
+
+namespace xm {
+
+constexpr int OWN_BW = 4;         // K0b's boundary spacing for this path (tile widths and halos are multiples of it)
+constexpr int OWN_MAX_DELTA = 7;  // 3 bits in the packed X-map
+constexpr int OWN_XP_BITS = 13;   // xp < 8192
+constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile (the ownership masks are u16)
+constexpr int OWN_MAX_COLS = 72;  // own + halo columns of a tile (W <= 64, halo <= 8)
+
+template <bool AOS, bool VEC>
+__device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts, gp_u4 aos, const u32 n_ev, const DevTables& tb,
+                                                 gp_state st, XM_GLOBAL uint16_t* frame16, const int W, const int halo,
+                                                 const u32 blk, const u32 nblk, const int flags) {
+  const bool device_redo = flags & COLS_F_DEVICE_REDO, all_in = flags & COLS_F_ALL_IN_FRAME;
+  typedef long long T;
+  static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
+  constexpr int EPT = COLS_EPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ u32 s_in, s_oob;
+  // the interior thresholds of the tile's columns, thr[c0 + j] at s_thr[3 + j] (j = 1, 5, 9, ... start a 16-byte quad), padded
+  // with ~0 ("no event reaches it"): the column of an event = #{j >= 1 : thr[c0 + j] <= a}, four compares per broadcast read
+  __shared__ __attribute__((aligned(16))) u32 s_thr[OWN_MAX_COLS + 8];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63;
+  const int n = (int)n_ev;
+  const int cap = nthreads * EPT;
+  const size_t cells16 = frame16_cells(tb);
+  gp_i4 bounds = (gp_i4)((const XM_GLOBAL unsigned char*)frame16 + cols_bounds_offset(cells16));
+  const XM_GLOBAL u32* thr = (const XM_GLOBAL u32*)((const XM_GLOBAL unsigned char*)frame16 + cols_thr_offset(cells16, tb.xmap_w));
+  const int HRp = tb.own_hrp, r_lo = tb.own_r_lo, NG = HRp >> 3;
+  // LDS carve-up (mirrored by own_lds_bytes() on the host): band slots [nxs_max][HRp] | extra slots [extra_max] | per 8-row
+  // group: first frame column of the band, and the same minus the frame's shear (what a cell's x is compared with) | masks [HRp]
+  u32* slots = reinterpret_cast<u32*>(smem);
+  const int n_band_max = tb.own_nxs_max * HRp;
+  u32* slots_x = slots + n_band_max;
+  int* s_base = reinterpret_cast<int*>(slots_x + tb.own_extra_max);
+  int* s_off = s_base + NG;
+  uint16_t* s_mask = reinterpret_cast<uint16_t*>(s_off + NG);
+
+  const u32 tile = xcd_contiguous(blk, nblk);
+  const int c0 = (int)tile * W;
+  const int Wc = min(W, tb.xmap_w - c0);
+  const int c_end = min(c0 + W + halo, tb.xmap_w);
+  const int ncols = c_end - c0;  // own + halo columns
+  // ---- 1. what locates the tile, in one round trip of uniform loads
+  const int4 b_lo = bounds[c0 / OWN_BW], b_hi = bounds[(c_end + OWN_BW - 1) / OWN_BW];
+  const u32 A_lo = thr[c0], A_hi = thr[c_end];
+  const int4 trec = ((const XM_GLOBAL int4*)tb.own_tiles)[tile];  // {band columns, first extra, extras, -}
+  T t_first, t_last;
+  if constexpr (AOS) {
+    const uint4 a = aos[0], b = aos[n - 1];
+    t_first = (T)(((u64)a.w << 32) | a.z);
+    t_last = (T)(((u64)b.w << 32) | b.z);
+  } else {
+    t_first = ts[0];
+    t_last = ts[n - 1];
+  }
+  const u32 tag = st->tag_b + 1;
+  const int nxs = trec.x, x_first = trec.y, n_extra = trec.z;
+  const int nslots = nxs * HRp;
+  {  // winner slots; the tile's ownership masks (one u16 per row) and band positions (one per 8-row group)
+    uint4* l_slots = reinterpret_cast<uint4*>(slots);
+    for (int i = tid; i < (nslots >> 2); i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);  // (HRp % 8 == 0)
+    for (int i = tid; i < n_extra; i += nthreads) slots_x[i] = 0;
+    const XM_GLOBAL uint16_t* gm = (const XM_GLOBAL uint16_t*)tb.own_masks + (size_t)tile * (size_t)HRp;
+    for (int i = tid; i < HRp; i += nthreads) s_mask[i] = gm[i];
+    const XM_GLOBAL int16_t* gb = (const XM_GLOBAL int16_t*)tb.own_base + (size_t)tile * (size_t)NG;
+    for (int i = tid; i < NG; i += nthreads) {
+      const int b = (int)gb[i];
+      s_base[i] = b;
+      s_off[i] = b - tb.shear_bias - ((((r_lo >> 3) + i) * tb.shear_m) >> 12);  // (r_lo % 8 == 0)
+    }
+  }
+  if (tid == 0) {
+    s_in = 0;
+    s_oob = 0;
+  }
+  if (tid < OWN_MAX_COLS + 5) s_thr[3 + tid] = tid < ncols ? thr[c0 + tid] : ~0u;
+  int lb_s = b_lo.x, lb_e = b_hi.x;
+  bool bad = false;
+  if (lb_s < 0 || lb_e > n || lb_e < lb_s || (u32)(lb_e - lb_s) > COLS_MAX_TILE_EVENTS) {
+    bad = true;
+    lb_s = lb_e = 0;
+  }
+  const int a0 = VEC ? (lb_s & ~(EPT - 1)) : lb_s;
+  int n_pass = 0;
+  for (int left = lb_e > lb_s ? lb_e - a0 : 0; left > 0; left -= cap) n_pass += 1;
+  u32 xw[EPT / 2], yw[EPT / 2];
+  T tt[EPT];
+  const auto load_events = [&](const int pass) {
+    if constexpr (VEC) {
+      const int base_true = a0 + pass * cap + tid * EPT;
+      const int last_grp = (n - 1) & ~(EPT - 1);
+      const int base = min(base_true, last_grp);
+      const uint4 xv = *(gp_u4)(xs + base);
+      const uint4 yv = *(gp_u4)(ys + base);
+      xw[0] = xv.x; xw[1] = xv.y; xw[2] = xv.z; xw[3] = xv.w;
+      yw[0] = yv.x; yw[1] = yv.y; yw[2] = yv.z; yw[3] = yv.w;
+#pragma unroll
+      for (int q = 0; q < EPT / 2; ++q) {
+        const longlong2 a = *(const XM_GLOBAL longlong2*)(ts + (base + 2 * q < n ? base + 2 * q : base));
+        tt[2 * q] = a.x;
+        tt[2 * q + 1] = a.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT / 2; ++q) xw[q] = yw[q] = 0;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int i = lb_s + pass * cap + k * nthreads + tid;
+        const int ic = i < lb_e ? i : lb_s;
+        if constexpr (AOS) {
+          const uint4 r = aos[ic];
+          xw[k >> 1] |= (r.x & 0xffff) << ((k & 1) * 16);
+          yw[k >> 1] |= (r.x >> 16) << ((k & 1) * 16);
+          tt[k] = (T)(((u64)r.w << 32) | r.z);
+        } else {
+          xw[k >> 1] |= (u32)xs[ic] << ((k & 1) * 16);
+          yw[k >> 1] |= (u32)ys[ic] << ((k & 1) * 16);
+          tt[k] = ts[ic];
+        }
+      }
+    }
+  };
+  const auto wave_on = [&](const int pass) {  // wave-uniform: does this wave hold any event of the pass?
+    const int w0 = VEC ? a0 + pass * cap + (tid & ~63) * EPT : lb_s + pass * cap + (tid & ~63);
+    return w0 < lb_e;
+  };
+  if (n_pass > 0 && wave_on(0)) load_events(0);
+
+  // frame extrema = (t[0], t[n-1]), verified per event below; slot bookkeeping by block 0 (as k_scatter_cols)
+  const u32 parity = tag & 1;
+  if (t_last < t_first) t_last = t_first;
+  if (blk == 0) {
+    if (tid == 0) {
+      st->tag_a = tag;
+      st->mm[parity][0][0] = TimeCodec<T>::enc(t_first);
+      st->mm[parity][0][1] = TimeCodec<T>::enc(t_last);
+    }
+    for (int i = tid; i < MM_SLOTS; i += nthreads) {
+      st->mm[parity ^ 1][i][0] = MM_INIT_MIN;
+      st->mm[parity ^ 1][i][1] = MM_INIT_MAX;
+    }
+  }
+  __syncthreads();  // slots cleared, masks in place
+
+  const u32* lut = tb.lut;
+  const uint16_t* xmo = tb.xmap_own;
+  u32 n_in = 0, n_oob = 0;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const bool on = wave_on(pass);
+    if (!on) continue;
+    if (pass > 0) load_events(pass);
+    int e0;
+    if constexpr (VEC) e0 = pass * cap + tid * EPT;
+    else e0 = pass * cap + tid;
+    const u32 used_n = (u32)(lb_e - lb_s), A_span = A_hi - A_lo;
+    const int u0 = VEC ? a0 + e0 - lb_s : e0;
+    int tl[EPT];
+    u32 av[EPT];
+    bool live[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u64 a64 = (u64)(tt[k] - t_first);
+      av[k] = (u32)a64;
+      const bool used = (u32)(u0 + (VEC ? k : k * nthreads)) < used_n;
+      const bool in_tile = (u32)(a64 >> 32) == 0u && av[k] - A_lo < A_span;
+      bad = bad || (used && !in_tile);
+      live[k] = used && in_tile;
+      tl[k] = 0;
+    }
+    for (int j0 = 1; j0 < ncols; j0 += 4) {
+      const uint4 A4 = *reinterpret_cast<const uint4*>(&s_thr[3 + j0]);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k)
+        tl[k] += (av[k] >= A4.x ? 1 : 0) + (av[k] >= A4.y ? 1 : 0) + (av[k] >= A4.z ? 1 : 0) + (av[k] >= A4.w ? 1 : 0);
+    }
+    // A1: the rectify LUT from L2, eight gathers in flight.  x / y outside the camera = map[y, x] IndexError in the reference
+    // (calib:279-280): dropped and counted (once: by the tile whose own columns hold the event)
+    u32 l[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u32 xk = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff, yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+      const bool inside = xk < (u32)tb.cam_w && yk < (u32)tb.cam_h;
+      n_oob += live[k] && !inside && tl[k] < Wc ? 1u : 0u;
+      live[k] = live[k] && inside;
+      l[k] = lut[live[k] ? __umul24(xk, (u32)tb.cam_h) + yk : 0u];
+    }
+    // A2: the packed X-map (xp | delta << 13) from L2
+    u32 xm[EPT];
+    int rr[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int yr = (int)(short)(l[k] >> 16);
+      rr[k] = yr - r_lo;
+      live[k] = live[k] && (u32)rr[k] < (u32)tb.own_hr;  // 0 <= yr < H - 1 (xmd:23): own_hr rows from r_lo on, all of them valid
+      xm[k] = xmo[live[k] ? __umul24((u32)(c0 + tl[k]), (u32)tb.xmap_h) + (u32)yr : 0u];
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int xr = (int)(short)(l[k] & 0xffff);
+      const int delta = (int)(xm[k] >> OWN_XP_BITS), fu = (int)(xm[k] & ((1u << OWN_XP_BITS) - 1u)) - tb.x_offset;
+      const int disp = fu - xr;          // (xm_create has checked the range: xmd:27's wrap never triggers)
+      bool write = live[k] && disp >= 0;  // xmd:29; an undefined X-map cell is packed as 0: fu = -x_offset < xr_min <= xr
+      int fc = fu;
+      if (!all_in) {
+        if (fc < 0) fc += tb.rect_w;  // NumPy's negative wrap
+        const bool in_frame = (u32)fc < (u32)tb.rect_w && rr[k] + r_lo < tb.rect_h;
+        n_oob += write && !in_frame && tl[k] < Wc ? 1u : 0u;
+        write = write && in_frame;
+      }
+      n_in += write && tl[k] < Wc ? 1u : 0u;  // counted by the tile whose own columns hold the event
+      const int jo = tl[k] - delta;            // the cell's owner column, relative to c0
+      write = write && (u32)jo < (u32)W;
+      const int sx = fc - s_off[(write ? rr[k] : 0) >> 3];  // the cell's column inside the band of its 8-row group
+      int idx = __mul24(sx, HRp) + rr[k];
+      if (write && (u32)sx >= (u32)nxs) {  // an extra: its slot index comes from the second table, at the cell's OWNER pair
+        const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)(c0 + jo), (u32)tb.xmap_h) + (u32)(rr[k] + r_lo)];
+        write = e != 0u;  // (always: xm_create lists every owner cell outside its band)
+        idx = n_band_max + (int)e - 1;
+      }
+      if (write) atomicMax(&slots[idx], ((u32)(e0 + (VEC ? k : k * nthreads) + 1) << 16) | (u32)disp);
+    }
+  }
+  if (__ballot(bad) && lane == 0) {
+    if (device_redo) {
+      st->pad[1] = tag;
+    } else {
+      __hip_atomic_fetch_add(&st->cnt[parity][blk % CNT_SLOTS][CNT_UNSORTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&st->unsorted_sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u32* hf = st->host_flags) host_flag_store(hf, tag);
+    }
+  }
+  {
+    u32 cnt2 = n_in | (n_oob << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt2 += __shfl_xor(cnt2, o, 64);
+    if (lane == 0) {
+      if (cnt2 & 0xffffu) atomicAdd(&s_in, cnt2 & 0xffffu);
+      if (cnt2 >> 16) atomicAdd(&s_oob, cnt2 >> 16);
+    }
+  }
+  __syncthreads();
+
+  // ---- flush: the tile's cell band in memory order; lanes walk consecutive rows of one (sheared) frame column
+  {
+    int k = 0, r_i = tid;
+    while (r_i >= HRp) {
+      r_i -= HRp;
+      k += 1;
+    }
+    int dk = 0, dr = nthreads;
+    while (dr >= HRp) {
+      dr -= HRp;
+      dk += 1;
+    }
+    XM_GLOBAL uint16_t* base = frame16 + (size_t)r_lo;
+    for (int i = tid; i < nslots; i += nthreads) {
+      const u32 v = slots[i];
+      const u32 m = s_mask[r_i];
+      if ((m >> k) & 1u) base[__umul24((u32)(s_base[r_i >> 3] + k), (u32)tb.rect_h) + (u32)r_i] = (uint16_t)(v & 0xffffu);
+      r_i += dr;
+      k += dk;
+      if (r_i >= HRp) {
+        r_i -= HRp;
+        k += 1;
+      }
+    }
+  }
+  {  // the extras, one by one
+    const XM_GLOBAL u32* xc = (const XM_GLOBAL u32*)tb.own_extra_cells + x_first;
+    for (int i = tid; i < n_extra; i += nthreads) frame16[xc[i]] = (uint16_t)(slots_x[i] & 0xffffu);
+  }
+  if (tid == 0) {
+    XM_GLOBAL u32* c = st->cnt[parity][blk % CNT_SLOTS];
+    if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool AOS, bool VEC>
+__global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own(
+    const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts, const uint4* __restrict__ aos,
+    u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int halo, int flags) {
+  {  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
+    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)aos | (u64)tb.lut | (u64)tb.xmap_own | (u64)tb.own_tiles | (u64)tb.own_masks | (u64)tb.own_base | (u64)tb.xmap_extra | (u64)tb.own_extra_cells |
+                   (u64)st | (u64)frame16;
+    const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.x_offset | tb.rect_w | tb.rect_h | W | halo | tb.own_hrp | tb.own_r_lo;
+    if ((long long)(pp | (u64)(long long)pi) < 0) return;
+  }
+  scatter_own_body<AOS, VEC>((gp_u16)xs, (gp_u16)ys, (gp_i64)ts, (gp_u4)aos, n, tb, (gp_state)st, (XM_GLOBAL uint16_t*)frame16, W,
+                             halo, blockIdx.x, gridDim.x, flags);
+}
+
+template <bool AOS, bool VEC>
+__global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W,
+                                                                        int halo, int flags) {
+  const FrameDesc d = descs[blockIdx.y];
+  if (!d.valid || d.n == 0) return;
+  scatter_own_body<AOS, VEC>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
+                             (XM_GLOBAL uint16_t*)d.key_frame, W, halo, blockIdx.x, gridDim.x, flags);
+}
+
+}  // namespace xm

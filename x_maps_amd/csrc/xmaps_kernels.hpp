@@ -58,7 +58,27 @@ struct DevTables {
   int x_offset, t_px_scale;
   double p03;
   float z_near, z_far;
+  // owner tiles (xmaps_k1own.hpp; rigs whose (row, time column) -> cell map is not injective): the X-map once more with the
+  // distance to the cell's owner column in the top bits; per tile {columns of its cell band, first extra, extras}; per (tile,
+  // 8-row group) the band's first frame column; per (tile, row) the mask of the band cells the tile owns; cells outside the
+  // band ("extras") have a slot index in xmap_extra (at their owner pair) and their frame cell in own_extra_cells.  The rows
+  // the rectify LUT can reach: own_hr rows from own_r_lo (a multiple of 8) on, padded to own_hrp (a multiple of 8)
+  const uint16_t* xmap_own;     // [xmap_w][xmap_h]  xp | delta << 13, 0 = undefined
+  const uint16_t* xmap_extra;   // [xmap_w][xmap_h]  extra slot + 1 at the owner pair of a cell outside its tile's band, else 0
+  const int4* own_tiles;        // [tiles] {band columns, first extra, extras, 0}
+  const int16_t* own_base;      // [tiles][own_hrp / 8]
+  const uint16_t* own_masks;    // [tiles][own_hrp]
+  const u32* own_extra_cells;   // [extras] cell index in the (sheared) u16 frame
+  int own_r_lo, own_hr, own_hrp, own_nxs_max, own_extra_max;
+  // the plain u16 disparity frame of the column / owner tiles is sheared by whole columns per 8-row group: cell (x, row) lives
+  // in frame column x + shear_bias + ((row >> 3) * shear_m >> 12); the frame has rect_w + shear_extra columns.  All 0 unless
+  // the rig's X-map is slanted (xm_create fits shear_m)
+  int shear_m, shear_bias, shear_extra;
 };
+
+__host__ __device__ inline size_t frame16_cells(const DevTables& tb) { return (size_t)(tb.rect_w + tb.shear_extra) * (size_t)tb.rect_h; }
+// column of cell (x, row) in the u16 frame
+__host__ __device__ inline int frame16_col(const DevTables& tb, int x, int row) { return x + tb.shear_bias + (((row >> 3) * tb.shear_m) >> 12); }
 
 // Per-slot device state.  tag_a is written by K0 (block 0) and read by K1/K2; tag_b is written by K1
 // (block 0) and read by K0 -- so no kernel reads a word that one of its own blocks is writing.
@@ -1815,6 +1835,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
       if constexpr (U16) {  // plain disparities: 8-byte loads of 4 rows copied straight into the LDS patch
         const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
         const bool interior = bx >= 0 && by >= 0 && bx + cols <= tb.rect_w && by + rows_p <= tb.rect_h && (tb.rect_h & 3) == 0;
+        const int g0 = by >> 3, sh0 = tb.shear_bias + ((g0 * tb.shear_m) >> 12);  // the patch's first 8-row group and its shear
         if (interior && (tb.rect_h & 7) == 0) {
           // 16-byte loads of 8 rows (the patch starts on a multiple of 8 rows and rows_p is one), copied as they are: LDS quad
           // index == patch (column, row octet) index.  A 50 x 56 patch is 350 quads: two loads per thread.
@@ -1830,8 +1851,10 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
               for (int j = 0; j < 2; ++j) {
                 const int sj = s0 + j * NT, c = sj >> 3, ro = sj & 7;
                 has[j] = sj < nslot && ro < oct;
-                k[j] = *reinterpret_cast<const uint4*>(d16 + (has[j] ? __umul24((u32)(bx + c), (u32)tb.rect_h) + (u32)(by + 8 * ro)
-                                                                     : __umul24((u32)bx, (u32)tb.rect_h) + (u32)by));
+                // (the frame is sheared by whole columns per 8-row group -- frame16_col; sh0 / shear_m are 0 on rigs that are not slanted)
+                const int cs = bx + c + (((g0 + ro) * tb.shear_m) >> 12);
+                k[j] = *reinterpret_cast<const uint4*>(d16 + (has[j] ? __umul24((u32)(cs + tb.shear_bias), (u32)tb.rect_h) + (u32)(by + 8 * ro)
+                                                                     : __umul24((u32)(bx + sh0), (u32)tb.rect_h) + (u32)by));
               }
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
@@ -1849,7 +1872,8 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
               int c = (int)((float)i * inv_o), ro = i - __mul24(c, oct);
               if (ro < 0) { c -= 1; ro += oct; }
               if (ro >= oct) { c += 1; ro -= oct; }
-              k[j] = *reinterpret_cast<const uint4*>(d16 + __umul24((u32)(bx + c), (u32)tb.rect_h) + (u32)(by + 8 * ro));
+              k[j] = *reinterpret_cast<const uint4*>(d16 + __umul24((u32)(bx + c + tb.shear_bias + (((g0 + ro) * tb.shear_m) >> 12)), (u32)tb.rect_h) +
+                                                     (u32)(by + 8 * ro));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -1867,7 +1891,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
               int c = (int)((float)i * inv_q), rq = i - __mul24(c, quarter);
               if (rq < 0) { c -= 1; rq += quarter; }
               if (rq >= quarter) { c += 1; rq -= quarter; }
-              k[j] = *reinterpret_cast<const uint2*>(d16 + __umul24((u32)(bx + c), (u32)tb.rect_h) + (u32)(by + 4 * rq));
+              k[j] = *reinterpret_cast<const uint2*>(d16 + __umul24((u32)frame16_col(tb, bx + c, by + 4 * rq), (u32)tb.rect_h) + (u32)(by + 4 * rq));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1882,7 +1906,8 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
             if (r >= rows_p) { c += 1; r -= rows_p; }
             const int gx = bx + c, gy = by + r;
             const bool inside = gx >= 0 && gx < tb.rect_w && gy >= 0 && gy < tb.rect_h;
-            const uint16_t v = d16[(u32)min(max(gx, 0), tb.rect_w - 1) * (u32)tb.rect_h + (u32)min(max(gy, 0), tb.rect_h - 1)];
+            const int cx = min(max(gx, 0), tb.rect_w - 1), cy = min(max(gy, 0), tb.rect_h - 1);
+            const uint16_t v = d16[(u32)frame16_col(tb, cx, cy) * (u32)tb.rect_h + (u32)cy];
             tile[i] = inside ? v : (uint16_t)0;
           }
         }
@@ -2089,7 +2114,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         if constexpr (U16) {
           const uint16_t* d16 = reinterpret_cast<const uint16_t*>(keys);
           for (int xx = xa; xx <= xb; ++xx)
-            for (int yy = ya; yy <= yb; ++yy) dq = fmaxf(dq, (float)d16[(u32)xx * (u32)tb.rect_h + (u32)yy]);
+            for (int yy = ya; yy <= yb; ++yy) dq = fmaxf(dq, (float)d16[(u32)frame16_col(tb, xx, yy) * (u32)tb.rect_h + (u32)yy]);
         } else if constexpr (KEY32) {
           const u32* keys32 = reinterpret_cast<const u32*>(keys);
           const u32 tag4 = key32_tag(tag);

@@ -158,6 +158,14 @@ class XMapsEngine:
         N.check(self._lib.xm_path_counts(self._h, v))
         return {"general": int(v[0]), "sorted_key64": int(v[1]), "key32": int(v[2]), "cols": int(v[3])}
 
+    def cols_info(self) -> dict:
+        """Which no-atomics K1 the rig qualified for (xm_cols_info): mode 'none' / 'cols' (injective X-map) / 'own' (several
+        time columns per frame cell: the reference's own calibration) and the owner tiles' geometry."""
+        a = (C.c_int32 * 12)()
+        N.check(self._lib.xm_cols_info(self._h, a))
+        return {"mode": ("none", "cols", "own")[a[0]], "w": a[1], "halo": a[2], "nxs_max": a[3], "shear_m": a[4],
+                "shear_extra": a[5], "r_lo": a[6], "rows": a[7], "extras": a[8], "extras_max_per_tile": a[9]}
+
     def stream(self, slot: int = 0) -> int:
         return int(self._lib.xm_stream(self._h, slot) or 0)
 

@@ -67,11 +67,11 @@ def render_events(cp: C.CamProjCalibrationParams, tables: dict, row_stride=13, t
     return evs, {"proj_u": cc[ok][order], "proj_v": rr[ok][order], "z_rect": z_rect}
 
 
-def make_esl_like(calib_npz: str | None = None, device: int = 0, **kw):
+def make_esl_like(calib_npz: str | None = None, device: int = 0, x_map_fn=None, **kw):
     if calib_npz is None:
         calib_npz = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g6_esl_calib.npz")
     cp = esl_like_params(calib_npz)
-    tables = C.build_tables(cp, device=device)
+    tables = C.build_tables(cp, device=device, x_map_fn=x_map_fn)
     evs, gt = render_events(cp, tables, **kw)
     return cp, tables, evs, gt
 

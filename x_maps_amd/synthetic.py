@@ -88,6 +88,38 @@ def make_tables(cfg: RigConfig, z_near: float = 0.1, z_far: float = 1.2) -> dict
     }
 
 
+C_SHARED = RigConfig("C-shared", 160, 120, 270, 120, 40_000)
+
+
+def make_tables_shared_cells(cfg: RigConfig = C_SHARED, cols_per_cell: float = 3.3, slant: float = -0.4, z_near: float = 0.1,
+                             z_far: float = 1.2) -> dict:
+    """A rig shaped like the reference's own calibration (data/ESL_calib_hhi.yaml through cam_proj_calibration.py:299-303):
+    `cols_per_cell` consecutive X-map time columns of a row land on ONE cell of the rectified frame (X_MAP_WIDTH =
+    projector_width is finer than the projector's image in the rectified frame), and a time column's cell moves `slant`
+    columns per row.  The (row, time column) -> cell map is not injective: such rigs take the owner tiles
+    (csrc/xmaps_k1own.hpp).  The camera LUT is made consistent with it: an event at camera x ~ t / scan * cam_w has a
+    disparity around 30."""
+    tb = make_tables(cfg, z_near, z_far)
+    cw, ch, pw = cfg.cam_w, cfg.cam_h, cfg.proj_w
+    rw, rh = cfg.rect_w, cfg.rect_h
+    ys, xs = np.mgrid[0:ch, 0:cw].astype(np.float64)
+    cam_mapy = tb["cam_mapy_i16"].astype(np.float64)
+    k = 1.0 / cols_per_cell
+    x0 = 18.0 + max(0.0, -slant) * rh
+    yr, tc = np.mgrid[0:rh, 0:pw].astype(np.float64)
+    xmap = np.rint(X_OFFSET + x0 + k * tc + slant * yr).astype(np.int16)
+    xmap[:, 0] = 0
+    xmap[:6, :] = 0
+    xmap[rh - 5:, :] = 0
+    xmap[(yr.astype(np.int64) * 131 + tc.astype(np.int64) * 71) % 257 == 0] = 0
+    assert xmap.max() - X_OFFSET < rw
+    cam_mapx = np.rint(x0 - 30.0 + k * pw * (xs / cw) + slant * cam_mapy).astype(np.int16)
+    tb["proj_x_map"] = np.ascontiguousarray(xmap)
+    tb["cam_mapx_i16"] = np.ascontiguousarray(cam_mapx)
+    tb["p03"] = 60.0
+    return tb
+
+
 def make_events(cfg: RigConfig, frame: int = 0, n: int | None = None, *, shuffled: bool = False,
                 p_zero_fraction: float = 0.0, t0: int = 5_000_000, scan_us: int = 13_000) -> np.ndarray:
     """One frame of EventCD records (structured AoS array, like Metavision hands them over).
