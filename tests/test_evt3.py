@@ -1,6 +1,7 @@
 """CPU: the EVT 3.0 decoder (x_maps_amd/evt3.py) on hand-built word sequences, a round trip through the encoder, chunked
 decoding (state carried across chunks) and a 24-bit time wrap."""
 import numpy as np
+import pytest
 
 from x_maps_amd import evt3
 from x_maps_amd import synthetic as S
@@ -66,3 +67,32 @@ def test_time_wraps_after_24_bits():
     dec = evt3.decode_evt3(words)
     assert list(dec["t"] - dec["t"][0]) == [0, 2, 5, 5003]
     assert dec["t"][2] > dec["t"][1]  # monotone across the wrap
+
+
+def test_time_high_change_restarts_the_low_field():
+    """A TIME_HIGH word that changes the high field is followed by its TIME_LOW word only later: events in between carry low = 0,
+    not the stale low of the previous period (stamps would jump up to 4095 us ahead and then run backwards)."""
+    from x_maps_amd import evt3 as E
+    TH, TL, Y, X = E.T_TIME_HIGH << 12, E.T_TIME_LOW << 12, E.T_ADDR_Y << 12, E.T_ADDR_X << 12
+    words = np.array([TH | 5, TL | 4000, Y | 7, X | (1 << 11) | 10,   # t = 5 << 12 | 4000
+                      TH | 5, X | (1 << 11) | 11,                      # redundant TIME_HIGH: nothing changes
+                      TH | 6, X | (1 << 11) | 12,                      # high changed, no TIME_LOW yet: low = 0
+                      TL | 3, X | (1 << 11) | 13], dtype="<u2")
+    ev = E.decode_evt3(words)
+    assert list(ev["x"]) == [10, 11, 12, 13]
+    assert list(ev["t"]) == [(5 << 12) | 4000, (5 << 12) | 4000, 6 << 12, (6 << 12) | 3]
+    assert np.all(np.diff(ev["t"]) >= 0)
+    # the same stream split between the TIME_HIGH change and the event behind it
+    dec = E.Evt3Decoder()
+    a, b = dec.decode(words[:7]), dec.decode(words[7:])
+    assert list(np.concatenate((a["t"], b["t"]))) == list(ev["t"])
+
+
+def test_read_raw_checks_the_format_token(tmp_path):
+    from x_maps_amd import evt3 as E
+    p = tmp_path / "x.raw"
+    p.write_bytes(b"% format EVT2;height=320;width=320\n% end\n" + b"\x00" * 8)
+    with pytest.raises(ValueError):
+        list(E.read_raw(str(p)))
+    p.write_bytes(b"% format EVT3;height=320;width=320\n% end\n")
+    assert list(E.read_raw(str(p))) == []

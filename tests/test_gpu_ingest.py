@@ -175,3 +175,34 @@ def test_pipe_with_device_ingest_calls_back_with_the_same_frames():
     assert len(a) == len(b) >= 3
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_the_slot_is_cleared_before_its_frame_tag_can_wrap(monkeypatch):
+    """The ingest slot's tag advances on the device (one per cut frame) and is 19 bits wide in the packed keys: the host clears
+    the slot every KEY_MAX_TAG - 16 pushes at the latest.  XM_INGEST_CLEAR_EVERY=3 makes that happen every third push here: the
+    frames must come out exactly as without it (every clear lands between two frames of the stream)."""
+    monkeypatch.setenv("XM_INGEST_CLEAR_EVERY", "3")
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(14, seed=31)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    tf = IO.TriggerFinderOracle(60)
+    for p in pk:
+        tf.process_events(IO.polarity_filter(p))
+    assert len(tf.frames) >= 4
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 11) as ing:
+        got = []
+        for p in pk:
+            ing.push(p)
+            got += ing.poll()
+        ing.flush()
+        got += ing.poll()
+    _check_frames(tb, got, tf.frames)
+
+
+def test_min_events_per_frame_below_four_is_rejected():
+    """The frame is evs[prev + 2 : next - 2] (trigger_finder.py:172): fewer than 4 events between two pauses cannot be a frame."""
+    from x_maps_amd._native import XMapsNativeError
+    tb = S.make_tables(S.C_TINY)
+    with XMapsEngine(tb) as eng:
+        with pytest.raises((XMapsNativeError, ValueError)):
+            DeviceIngest(eng, 60, min_events_per_frame=2)

@@ -3034,6 +3034,10 @@ struct xm_ingest {
   uint64_t next_seq = 0;     // frames delivered through xm_ingest_poll so far
   uint64_t pushed = 0;       // events handed in
   uint64_t pushes = 0;
+  // The slot's frame tag advances on the device by one per cut frame (<= one per push) and the host never reads it: the slot is
+  // cleared (k_reset_slot: tags back to 0, key frame emptied) before the pushes since the last clear can have brought the tag to
+  // KEY_MAX_TAG -- the tag field of the packed keys is 19 bits wide, and at 2^20 the shifted tag would leave the 64-bit key
+  uint64_t pushes_since_clear = 0, clear_every = KEY_MAX_TAG - 16;
   // Upper bound of the live part of the device buffer (its real size is known to the device only): grows with every push,
   // shrinks when a delivered frame reports how much was left after its cut.  Sizes the grids of the segmentation / frame kernels.
   uint64_t ub_live = 0;
@@ -3113,6 +3117,11 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   g->act_thresh = cfg->activity_thresh_us > 0 ? cfg->activity_thresh_us : (long long)(1e6 / cfg->projector_fps);  // pipe:65-68
   if (g->cfg.pause_thresh_us <= 0) g->cfg.pause_thresh_us = 40;       // trigger_finder.py:98
   if (g->cfg.min_events_per_frame <= 0) g->cfg.min_events_per_frame = 1000;  // trigger_finder.py:8
+  if (g->cfg.min_events_per_frame < 4) {  // the cut is evs[prev + 2 : next - 2] (trigger_finder.py:172): fewer than 4 events between
+    delete g;                             // two pauses would be an empty frame, on which the reference's t.min() raises
+    return fail(XM_ERR_INVALID, "min_events_per_frame must be >= 4 (the frame is evs[prev + 2 : next - 2])");
+  }
+  if (const char* e = getenv("XM_INGEST_CLEAR_EVERY")) g->clear_every = (uint64_t)std::max(1, atoi(e));  // tests: exercise the tag clear
   g->ring = cfg->result_ring > 0 ? cfg->result_ring : 8;
   const size_t cam_px = (size_t)h->tb.cam_w * h->tb.cam_h;
   const size_t px = (size_t)h->out_w * h->out_h;
@@ -3246,6 +3255,12 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
       HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, s));
     }
   }
+  if (g->pushes_since_clear >= g->clear_every) {  // (stream-ordered behind every frame cut so far)
+    hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s, g->slot, g->key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
+    HIP_TRY(hipGetLastError());
+    g->pushes_since_clear = 0;
+  }
+  g->pushes_since_clear += 1;
   // room for this packet behind the write cursor (device-side decision; the live part moves to the other buffer)
   hipLaunchKernelGGL(k_ing_compact, dim3(256), dim3(BLOCK), 0, s, g->st, g->buf[0], g->buf[1], g->capacity, (u64)g->max_packet);
   hipLaunchKernelGGL(k_ing_compact_commit, dim3(1), dim3(1), 0, s, g->st, g->capacity, (u64)g->max_packet);
@@ -3290,7 +3305,12 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   g->pushes += 1;
   g->ub_live = std::min<u64>(g->capacity, g->ub_live + n);
   g->recent.emplace_back(g->pushes, (uint64_t)n);
-  if (g->recent.size() > 4096) g->recent.erase(g->recent.begin(), g->recent.begin() + 2048);
+  if (g->recent.size() > 4096) {  // many pushes without a poll: fold the older half into one entry under its LAST push number (a
+    uint64_t sum = 0;              // frame that reports an earlier push then counts all of it: the bound stays an upper bound)
+    for (size_t i = 0; i < 2048; ++i) sum += g->recent[i].second;
+    g->recent[2047] = std::make_pair(g->recent[2047].first, sum);
+    g->recent.erase(g->recent.begin(), g->recent.begin() + 2047);
+  }
   // segmentation over the live part (its size is known to the device only: the grids cover the host's upper bound)
   const u64 bound64 = g->ub_live;
   const u32 n_bound = (u32)bound64;
@@ -3320,33 +3340,46 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   if (!g || !out) return fail(XM_ERR_INVALID, "NULL argument");
   const int slot = (int)(g->next_seq % (uint64_t)g->ring);
   const IngestStatus* st = g->h_status + slot;
+  const uint64_t want = g->next_seq + 1;  // the entry's seq once frame next_seq has been published
   const uint64_t seq = __atomic_load_n(&st->seq, __ATOMIC_ACQUIRE);
-  if (seq < g->next_seq + 1) return 0;  // not there yet
+  if (seq < want) return 0;  // not there yet
+  IngestStatus v;
+  memcpy(&v, st, sizeof v);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const uint64_t seq2 = __atomic_load_n(&st->seq, __ATOMIC_ACQUIRE);  // did the producer rewrite the entry while it was read?
+  const bool lapped = seq > want || seq2 != seq;  // the ring holds a later frame here (or is being rewritten): this one is lost
   memset(out, 0, sizeof *out);
   out->seq = g->next_seq;
-  out->lost = seq > g->next_seq + 1 ? 1 : 0;  // the producer lapped the ring: this entry already holds a later frame
-  out->n_events = st->n_events;
-  out->t_first = st->t_first;
-  out->t_last = st->t_last;
-  out->n_inliers = st->n_inliers;
-  out->n_index_errors = st->n_index_errors;
-  out->live_after = st->live_after;
-  out->overflow = st->overflow;
+  out->lost = lapped ? 1 : 0;
+  if (lapped) {
+    // Nothing of the entry can be trusted for frame next_seq (no statistics, no images: depth / bgr stay NULL).  The host's bound of
+    // the live part is left as it is (an upper bound stays one).  Resume with the oldest frame the ring may still hold intact.
+    const uint64_t newest = std::max(seq, seq2);  // >= want + ring - 1
+    g->next_seq = std::max<uint64_t>(g->next_seq + 1, newest >= (uint64_t)g->ring ? newest - (uint64_t)g->ring : 0);
+    return 1;
+  }
+  out->n_events = v.n_events;
+  out->t_first = v.t_first;
+  out->t_last = v.t_last;
+  out->n_inliers = v.n_inliers;
+  out->n_index_errors = v.n_index_errors;
+  out->live_after = v.live_after;
+  out->overflow = v.overflow;
   out->depth = g->h_depth[slot];
   out->bgr = g->h_bgr[slot];
-  g->est_frame_events = st->n_events;  // the next frames' K1 variant / block size follow the stream's density
+  g->est_frame_events = v.n_events;  // the next frames' K1 variant / block size follow the stream's density
   {  // after that frame's cut `live_after` events were left; everything pushed since may have been appended
     uint64_t later = 0;
     size_t keep_from = g->recent.size();
     for (size_t i = g->recent.size(); i-- > 0;) {
-      if (g->recent[i].first <= st->push_seq) break;
+      if (g->recent[i].first <= v.push_seq) break;
       later += g->recent[i].second;
       keep_from = i;
     }
     g->recent.erase(g->recent.begin(), g->recent.begin() + keep_from);
-    g->ub_live = std::min<uint64_t>(g->capacity, st->live_after + later);
+    g->ub_live = std::min<uint64_t>(g->capacity, v.live_after + later);
   }
-  g->next_seq = out->lost ? seq : g->next_seq + 1;
+  g->next_seq += 1;
   return 1;
 }
 

@@ -87,6 +87,9 @@ class DepthReprojectionPipe:
     # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------
     def _deliver_ingest_frames(self):
         for fr in self.ingest.poll():
+            if fr.lost:  # the result ring was lapped before the host polled: the frame's images are gone (never shown)
+                self.stats_printer.count("frame lost")
+                continue
             self.stats_printer.count("trig ✅")
             self.stats_printer.add_metric("frame len [ms]", (fr.t_last - fr.t_first) / 1000)
             self.last_ingest_frame = fr

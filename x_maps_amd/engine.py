@@ -210,10 +210,16 @@ class XMapsEngine:
     # ---- fused hot path, device pointers (async) -------------------------------------------------
     def process_frame_device(self, x_ptr, y_ptr, t_ptr, p_ptr, n, depth_ptr=None, bgr_ptr=None,
                              t_dtype=N.XM_T_INT64):
+        """Asynchronous: returns once the frame's kernels are enqueued on one of the handle's n_slots streams.  CONTRACT of the
+        default (verified-shortcut) mode: the frame's inputs AND outputs must stay untouched until `sync()` has returned or
+        `n_slots` further frames have been submitted -- a frame whose (t[0], t[n-1]) / tile verification failed is redone from its
+        inputs into its outputs at that point, so a caller that only synchronises `stream()` can read a not-yet-redone frame.
+        (force_general=True or assume_time_sorted=True never redo: there the stream alone orders the outputs.)"""
         N.check(self._lib.xm_process_frame(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), _ptr(p_ptr), n, t_dtype,
                                            N.XM_MEM_DEVICE, _ptr(depth_ptr), _ptr(bgr_ptr), None))
 
     def process_events_device(self, aos_ptr, n, use_polarity=False, depth_ptr=None, bgr_ptr=None):
+        """EventCD records (16-byte AoS) resident on the device; asynchronous, same contract as process_frame_device."""
         N.check(self._lib.xm_process_frame_aos(self._h, _ptr(aos_ptr), n, int(use_polarity), N.XM_MEM_DEVICE,
                                                _ptr(depth_ptr), _ptr(bgr_ptr), None))
 

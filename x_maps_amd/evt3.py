@@ -79,6 +79,13 @@ class Evt3Decoder:
             loops_at = np.where(ih >= 0, self.t_loops + wraps[np.searchsorted(hi_words, np.maximum(ih, 0))], self.t_loops)
         t_high = np.where(ih >= 0, w[np.maximum(ih, 0)] & 0xfff, self.t_high)
         t_low = np.where(il >= 0, w[np.maximum(il, 0)] & 0xfff, self.t_low)
+        if len(hi_words):
+            # a TIME_HIGH word that CHANGES the high field restarts the low field at 0 until the next TIME_LOW word (the stale
+            # low would put the stamp up to 4095 us too late, and stamps must not run backwards when the TIME_LOW arrives);
+            # the redundant TIME_HIGH words that repeat the current value change nothing
+            changed = np.concatenate(([th_seq[0] != self.t_high], th_seq[1:] != th_seq[:-1]))
+            last_change = _ffill_index(np.isin(pos, hi_words[changed]))
+            t_low = np.where(last_change > il, 0, t_low)
         t = (loops_at << 24) | (t_high << 12) | t_low
         # ---- row: last ADDR_Y ----
         iy = _ffill_index(typ == T_ADDR_Y)
@@ -128,7 +135,8 @@ def read_raw(path: str, chunk_words: int = 1 << 22):
         blob = f.read()
     fields, off = split_raw_header(blob)
     fmt = fields.get("evt", fields.get("format", "3.0"))
-    if "3" not in fmt:
+    # "% evt 3.0" (older headers) or "% format EVT3;height=720;width=1280" (newer ones): the first token decides
+    if fmt.split(";")[0].strip().upper() not in ("3.0", "3", "EVT3", "EVT3.0"):
         raise ValueError(f"{path}: only EVT 3.0 is supported (header says {fmt!r})")
     words = np.frombuffer(blob, dtype="<u2", offset=off, count=(len(blob) - off) // 2)
     dec = Evt3Decoder()

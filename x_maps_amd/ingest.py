@@ -40,7 +40,7 @@ class IngestFrame:
 class DeviceIngest:
     def __init__(self, engine, projector_fps: int, use_polarity: bool = True, activity_filter: bool = False,
                  activity_thresh_us: int = 0, capacity_events: int = 0, max_packet_events: int = 0, result_ring: int = 8,
-                 expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True):
+                 expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True, min_events_per_frame: int = 0):
         self._e = engine
         self._lib = engine._lib
         cfg = N.xm_ingest_config()
@@ -50,7 +50,7 @@ class DeviceIngest:
         cfg.activity_filter = int(activity_filter)
         cfg.activity_thresh_us = int(activity_thresh_us)
         cfg.pause_thresh_us = 0
-        cfg.min_events_per_frame = 0
+        cfg.min_events_per_frame = int(min_events_per_frame)  # 0 = the reference's 1000 (trigger_finder.py:8)
         cfg.result_ring = int(result_ring)
         cfg.capacity_events = int(capacity_events)
         cfg.max_packet_events = int(max_packet_events)
