@@ -193,7 +193,90 @@ def cpu_baseline_leg(args, O, tables, host_frame, n_ev, camera, want_bgr):
     return cpu
 
 
-def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=None):
+def roofline_dict(k_ms, prof, n_ev, B, tables, camera, bgr_b, wl, timing, cell_bytes=2):
+    """The `roofline` object from per-launch kernel durations (ms): k_ms = (helper pass, K1, K2, whole step).
+    n_ev = events per frame, B = frames per launch.  Three yardsticks side by side for the dominant kernel (never the helper
+    pass): SURVEY 8(d)'s algorithmic bytes (`frac`), the HBM bytes the PMC counters saw (`frac_counter_bytes`, from the committed
+    rocprofv3 passes of this workload: profiles/pmc_traffic.json[wl]), and -- filled in by pipeline_fractions() once the
+    pipelined rate is known -- the event stream's 14 B/event against the HBM read peak."""
+    rw, rh, pw, ph, cw, ch = (tables[k] for k in ("rect_w", "rect_h", "proj_w", "proj_h", "cam_w", "cam_h"))
+    # algorithmic bytes per launch (SURVEY.md section 8(d)); the helper pass is charged nothing (it is an extra pass)
+    frame_bytes = (12 + bgr_b) * cw * ch if camera else 8 * rw * rh + (8 + bgr_b) * pw * ph
+    alg = {"k_minmax": 0.0, "k_scatter": 24.0 * n_ev * B, "k_frame": float(frame_bytes) * B}
+    # what the frame kernel cannot avoid moving with the cell format it reads today (u16 / u32 / u64 cells, never cleared): one
+    # read of the disparity frame + its per-pixel patch offsets (u32) + the outputs
+    k2_min = ((cell_bytes + 4 + bgr_b) * cw * ch if camera else cell_bytes * rw * rh + (4 + 4 + bgr_b) * pw * ph) * B
+    names = ["k_minmax", "k_scatter", "k_frame"]
+    dom = 1 if k_ms[1] >= k_ms[2] else 2
+    pt = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+    except Exception:
+        pt = None
+
+    def traffic_of(name):
+        try:
+            e = pt[wl][name]
+            return int(e["hbm_bytes_per_frame"] * B) if "hbm_bytes_per_frame" in e else int(e["hbm_bytes_per_launch"])
+        except Exception:
+            return None
+
+    kernels = {}
+    for i, nme in enumerate(names):
+        if k_ms[i] <= 0:
+            continue
+        t_s = k_ms[i] * 1e-3
+        tr = traffic_of(nme)
+        kernels[nme] = {"avg_launch_us": round(float(k_ms[i]) * 1e3, 2), "us_per_frame": round(float(k_ms[i]) * 1e3 / B, 3),
+                        "algorithmic_bytes_per_launch": alg[nme],
+                        "frac_algorithmic": round(alg[nme] / t_s / 1e9 / HBM_PEAK_GBS, 5),
+                        "hbm_bytes_per_launch_counters": tr,
+                        "frac_counter_bytes": None if tr is None else round(tr / t_s / 1e9 / HBM_PEAK_GBS, 5)}
+        if nme == "k_scatter":
+            kernels[nme]["frac_event_stream_read"] = round(14.0 * n_ev * B / t_s / 1e9 / HBM_PEAK_GBS, 5)
+        if nme == "k_frame":
+            kernels[nme]["own_minimal_bytes_per_launch"] = float(k2_min)
+            kernels[nme]["frac_own_minimal_bytes"] = round(k2_min / t_s / 1e9 / HBM_PEAK_GBS, 5)
+    ach = alg[names[dom]] / max(k_ms[dom] * 1e-3, 1e-12) / 1e9
+    traffic = traffic_of(names[dom])
+    out = {
+        "bound": "hbm", "kernel": names[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "frac_counter_bytes": None if traffic is None else round(traffic / (k_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "traffic_source": (f"profiles/pmc_traffic.json[{wl}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                           "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE calibration, MI355X_MICROARCH.md)") if traffic else None,
+        "algorithmic_bytes_per_launch": alg[names[dom]], "frames_per_launch": B,
+        "fractions_note": "frac = SURVEY 8(d) algorithmic bytes of the dominant kernel / its launch time / 8 TB/s; frac_counter_bytes = "
+                          "the HBM bytes the counters saw instead; event_stream_read_roofline_frac = 14 B/event at the pipelined rate "
+                          "against the HBM read peak (the north star's yardstick: 571 Gev/s = 1.0)",
+        "kernels": kernels,
+        "avg_launch_us": {n: round(float(k_ms[i]) * 1e3, 2) for i, n in enumerate(names)},
+        "timing": timing,
+    }
+    if prof is not None:
+        out["launch_us_p10_p90"] = {n: [round(float(np.percentile(prof[:, i], q)) * 1e3, 2) for q in (10, 90)] for i, n in enumerate(names)}
+    return out, alg, pt
+
+
+def pipeline_fractions(roofline, alg, pt, wl, value, world, s_frame, frames_per_launch, helper_runs=True):
+    """Whole-pipeline figures at the measured (pipelined) seconds per frame."""
+    frame_alg = (alg["k_scatter"] + alg["k_frame"]) / frames_per_launch
+    roofline["whole_frame"] = {"algorithmic_bytes": frame_alg,
+                               "achieved_GBps_pipelined": round(frame_alg / s_frame / 1e9, 2),
+                               "frac_of_peak_pipelined": round(frame_alg / s_frame / 1e9 / HBM_PEAK_GBS, 5)}
+    roofline["event_stream_read_roofline_frac"] = round(value * 1e6 / world * 14 / 1e9 / HBM_PEAK_GBS, 5)
+    try:
+        names = ["k_scatter", "k_frame"] + (["k_minmax"] if helper_runs else [])
+        tot = sum(pt[wl][k].get("hbm_bytes_per_frame", pt[wl][k].get("hbm_bytes_per_launch")) for k in names)
+        roofline["pipeline_hbm_traffic"] = {"hbm_bytes_per_frame_all_kernels": tot, "kernels": names,
+                                            "GBps_at_measured_step_time": round(tot / s_frame / 1e9, 1),
+                                            "frac_of_peak": round(tot / s_frame / 1e9 / HBM_PEAK_GBS, 4)}
+    except Exception:
+        pass
+
+
+def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=None, wl_suffix="", cell_bytes=None):
     """Per-kernel launch durations from HIP events attached to each dispatch.  One frame per launch: 300 serial frames, median
     of the last 200.  group = (B, call): 60 serial groups of B frames (multi-frame launches), median of the last 40."""
     B = group[0] if group else 1
@@ -207,42 +290,20 @@ def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=Non
             st = eng.profile_frame_device(fx.data_ptr(), fy.data_ptr(), ft.data_ptr(), None, n_ev, outs[0], outs[1])
             prof[i] = st.gpu_ms
     k_ms = np.median(prof[skip:], axis=0)
-    rw, rh, pw, ph, cw, ch = (tables[k] for k in ("rect_w", "rect_h", "proj_w", "proj_h", "cam_w", "cam_h"))
-    # algorithmic bytes per launch; K0 is charged nothing (it is an extra pass)
-    frame_bytes = (12 + bgr_b) * cw * ch if camera else 8 * rw * rh + (8 + bgr_b) * pw * ph
-    # per LAUNCH: the per-frame figures x the frames one launch processes
-    alg = {"k_minmax": 0.0, "k_scatter": 24.0 * n_ev * B, "k_frame": float(frame_bytes) * B}
-    names = ["k_minmax", "k_scatter", "k_frame"]
-    dom = 1 if k_ms[1] >= k_ms[2] else 2  # never the helper pass
-    ach = alg[names[dom]] / (k_ms[dom] * 1e-3) / 1e9
-    traffic = pt = None
-    wl = ("camera" if camera else "projector") + ("_groups" if group else "")
-    try:  # HBM bytes from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f)
-        e = pt[wl][names[dom]]
-        traffic = int(e["hbm_bytes_per_frame"] * B) if "hbm_bytes_per_frame" in e else e["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    return {
-        "bound": "hbm", "kernel": names[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                           "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE calibration, MI355X_MICROARCH.md)") if traffic else None,
-        "algorithmic_bytes_per_launch": alg[names[dom]], "frames_per_launch": B,
-        "avg_launch_us": {n: round(float(k_ms[i]) * 1e3, 2) for i, n in enumerate(names)},
-        "launch_us_p10_p90": {n: [round(float(np.percentile(prof[skip:, i], q)) * 1e3, 2) for q in (10, 90)]
-                              for i, n in enumerate(names)},
-        "timing": ("HIP start/stop events attached to each dispatch (hipExtLaunchKernelGGL) on the stream it runs on; "
-                   + (f"{n_prof} serial groups of {B} frames (multi-frame launches, grid = frames x tiles) after the pre-warm and "
-                      f"BEFORE the timed blocks, median of the last {n_prof - skip}; k_minmax = the helper pass in front of K1: the "
-                      "boundary pass k_cols_bounds of the column-tile path (or the extrema pass K0 on the general path)"
-                      if group else
-                      "300 serial frames after the pre-warm and BEFORE the timed blocks, median of the last 200; k_minmax = 0: "
-                      "not launched (verified (t[0], t[n-1]) shortcut)")),
-        "empty_event_pair_us": round(eng.profile_event_overhead_ms(15) * 1e3, 2),
-        ("group_us_serial" if group else "frame_us_serial"): round(float(k_ms[3]) * 1e3, 2),
-    }, alg, pt, wl
+    wl = ("camera" if camera else "projector") + ("_groups" if group else "") + wl_suffix
+    timing = ("HIP start/stop events attached to each dispatch (hipExtLaunchKernelGGL) on the stream it runs on; "
+              + (f"{n_prof} serial groups of {B} frames (multi-frame launches, grid = frames x tiles) after the pre-warm and "
+                 f"BEFORE the timed blocks, median of the last {n_prof - skip}; k_minmax = the helper pass in front of K1: the "
+                 "boundary pass k_cols_bounds of the column-tile / owner-tile path (or the extrema pass K0 on the general path)"
+                 if group else
+                 "300 serial frames after the pre-warm and BEFORE the timed blocks, median of the last 200; k_minmax = 0: "
+                 "not launched (verified (t[0], t[n-1]) shortcut)"))
+    if cell_bytes is None:
+        cell_bytes = 2 if group else 4
+    r, alg, pt = roofline_dict(k_ms, prof[skip:], n_ev, B, tables, camera, bgr_b, wl, timing, cell_bytes)
+    r["empty_event_pair_us"] = round(eng.profile_event_overhead_ms(15) * 1e3, 2)
+    r["group_us_serial" if group else "frame_us_serial"] = round(float(k_ms[3]) * 1e3, 2)
+    return r, alg, pt, wl
 
 
 def main():
@@ -432,19 +493,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         return None
 
     s_frame = elapsed / (args.steps * fps)  # seconds per frame, pipelined
-    frame_alg = (alg["k_scatter"] + alg["k_frame"]) / fps
-    roofline["whole_frame"] = {"algorithmic_bytes": frame_alg,
-                               "achieved_GBps_pipelined": round(frame_alg / s_frame / 1e9, 2),
-                               "frac_of_peak_pipelined": round(frame_alg / s_frame / 1e9 / HBM_PEAK_GBS, 5)}
-    roofline["event_stream_read_roofline_frac"] = round(value * 1e6 / world * 14 / 1e9 / HBM_PEAK_GBS, 5)
-    try:
-        names = ["k_scatter", "k_frame"] + (["k_minmax"] if (paths["general"] or paths["cols"] or args.general) else [])
-        tot = sum(pt[wl][k].get("hbm_bytes_per_frame", pt[wl][k].get("hbm_bytes_per_launch")) for k in names)
-        roofline["pipeline_hbm_traffic"] = {"hbm_bytes_per_frame_all_kernels": tot, "kernels": names,
-                                            "GBps_at_measured_step_time": round(tot / s_frame / 1e9, 1),
-                                            "frac_of_peak": round(tot / s_frame / 1e9 / HBM_PEAK_GBS, 4)}
-    except Exception:
-        pass
+    pipeline_fractions(roofline, alg, pt, wl, value, world, s_frame, fps,
+                       helper_runs=bool(paths["general"] or paths["cols"] or args.general))
     frames_redone = eng.sorted_fallbacks()
 
     # ---- CPU baseline (rank 0 at N = 1 only) ---------------------------------------------------------------------------
@@ -735,6 +785,18 @@ def bench_graph(args, torch, dist, dev, rank, local_rank, world):
     if rank != 0:
         graph.close(), one.close(), eng.close()
         return None
+    # roofline: the graph's kernel nodes cannot carry events of their own, so the same three multi-frame kernels (boundary pass,
+    # K1, K2: the same grids over the same 60 frames and slots) are launched eagerly with HIP events attached to each dispatch
+    roofline = None
+    if slots >= F:
+        def prof_group(i):
+            return eng.profile_batch_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, offs, depth.data_ptr(),
+                                            None if bgr is None else bgr.data_ptr())
+        roofline, alg, pt, wl = roofline_of(eng, None, n_ev, (None, None), tables, camera, 0 if bgr is None else 3, world,
+                                            (F, prof_group), cell_bytes=2 if paths["cols"] else (4 if paths["key32"] else 8))
+        roofline["timing"] += ("; --graph: these are the graph's first three kernel nodes launched eagerly (the captured batch adds "
+                               "the four redo nodes, which return at once for frames whose tiles held)")
+        pipeline_fractions(roofline, alg, pt, wl, value, world, elapsed / steps, F, helper_runs=True)
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline_leg(args, O, tables, host[0], n_ev, camera, bgr is not None)
@@ -762,7 +824,7 @@ def bench_graph(args, torch, dist, dev, rank, local_rank, world):
                                      "resident in HBM), one replay at a time; 200 replays of the 60-frame graph, 1000 of a 1-frame graph"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
                    "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6)},
-        "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
     graph.close(), one.close(), eng.close()
     return out
@@ -779,31 +841,127 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
 
     camera = args.camera_perspective
     cp, tables, _, _ = rig.make_esl_like(row_stride=13, device=local_rank)
-    nf = 8
+    B = args.batch  # frames per call (0: one frame per call, what DepthReprojectionPipe.process_ev_frame supplies)
+    G = args.groups_in_flight if B else 1
+    nf = max(8, B * G)
     host = [rig.render_events(cp, tables, row_stride=13, seed=rank * nf + f)[0] for f in range(nf)]
-    n_mean = float(np.mean([len(e) for e in host]))
-    slots = args.slots or 4
+    lens = [len(e) for e in host]
+    n_mean = float(np.mean(lens))
+    slots = args.slots or (max(4, B * G) if B else 4)
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots)
+    info = eng.cols_info()
     H, W = eng.out_h, eng.out_w
+    bgr_b = 0 if args.no_bgr else 3
     dev_frames = [torch.from_numpy(e.view(np.uint8).reshape(-1, 16).copy()).to(dev) for e in host]
-    depth_out = torch.empty((slots, H, W), dtype=torch.float32, device=dev)
-    bgr_out = None if args.no_bgr else torch.empty((slots, H, W, 3), dtype=torch.uint8, device=dev)
+    n_out = max(slots, 1)
+    depth_out = torch.empty((n_out, H, W), dtype=torch.float32, device=dev)
+    bgr_out = None if args.no_bgr else torch.empty((n_out, H, W, 3), dtype=torch.uint8, device=dev)
+    groups = []
+    if B:
+        for g in range(G):
+            fr = host[g * B:(g + 1) * B]
+            offs = np.zeros(B + 1, np.uint64)
+            offs[1:] = np.cumsum([len(e) for e in fr])
+            rec = np.empty(int(offs[-1]), S.EVENT_CD_DTYPE)
+            for i, e in enumerate(fr):
+                rec[int(offs[i]):int(offs[i + 1])] = e
+            aos = torch.from_numpy(rec.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+            soa = tuple(torch.from_numpy(np.ascontiguousarray(rec[k]).view(np.int16) if k != "t" else np.ascontiguousarray(rec[k])).to(dev)
+                        for k in ("x", "y", "t"))
+            groups.append((aos, offs, soa))
     torch.cuda.synchronize()
     parity, O = None, None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import xmaps_oracle as O
+
+        def ref_of(e):
+            return O.process_ev_frame(tables, e["x"].astype(np.int64), e["y"].astype(np.int64), np.ascontiguousarray(e["t"]),
+                                      camera_perspective=camera, want_bgr=bgr_out is not None)
         d, b, st = eng.process_events(host[0], want_bgr=bgr_out is not None)
-        ref = O.process_ev_frame(tables, host[0]["x"].astype(np.int64), host[0]["y"].astype(np.int64),
-                                 np.ascontiguousarray(host[0]["t"]), camera_perspective=camera, want_bgr=bgr_out is not None)
+        ref = ref_of(host[0])
         parity = depth_parity(d, ref["depth"])
         if b is not None:
             parity["bgr_equal"] = bool(np.array_equal(b, ref["bgr"]))
         parity["n_inliers_equal"] = bool(st.n_inliers == int(ref["mask"].sum()))
-        if not (parity["depth_max_rel_err"] <= 1e-4 and parity["empty_mask_equal"] and parity.get("bgr_equal", True)) and not args.no_parity:
+        ok = parity["depth_max_rel_err"] <= 1e-4 and parity["empty_mask_equal"] and parity.get("bgr_equal", True)
+        if B:  # the group path: first and last frame of group 0
+            aos, offs, _ = groups[0]
+            eng.process_events_batch_device(aos.data_ptr(), offs, depth_out[0].data_ptr(), None if bgr_out is None else bgr_out[0].data_ptr())
+            eng.sync()
+            parity["group_first_frame_depth_bit_exact"] = bool(np.array_equal(depth_out[0].cpu().numpy(), ref["depth"]))
+            parity["group_last_frame_depth_bit_exact"] = bool(np.array_equal(depth_out[B - 1].cpu().numpy(), ref_of(host[B - 1])["depth"]))
+            ok = ok and parity["group_first_frame_depth_bit_exact"] and parity["group_last_frame_depth_bit_exact"]
+        if not ok and not args.no_parity:
             print(json.dumps({"error": "parity check failed", "parity": parity}))
             sys.exit(1)
-    # (A) what the pipe does per projector frame: one synchronous host call, EventCD records in, BGR frame out
+
+    def step_single(i):
+        f = dev_frames[i % nf]
+        o = i % min(slots, 4)
+        eng.process_events_device(f.data_ptr(), lens[i % nf], False, depth_out[o].data_ptr(),
+                                  None if bgr_out is None else bgr_out[o].data_ptr())
+
+    def step_group(i):
+        aos, offs, _ = groups[i % G]
+        o = (i % (slots // B)) * B
+        eng.process_events_batch_device(aos.data_ptr(), offs, depth_out[o].data_ptr(), None if bgr_out is None else bgr_out[o].data_ptr())
+
+    step = step_group if B else step_single
+    fps = B or 1
+    tm = Timer(torch, dist, dev, eng.sync)
+    for i in range(args.warmup):
+        step(i)
+    tm.prewarm(step, PREWARM_S)
+    roofline = alg = pt = wl = None
+    if rank == 0:
+        if B:
+            def prof_group(i):
+                _, offs, (sx, sy, st_) = groups[i % G]
+                return eng.profile_batch_device(sx.data_ptr(), sy.data_ptr(), st_.data_ptr(), None, offs, depth_out[0].data_ptr(),
+                                                None if bgr_out is None else bgr_out[0].data_ptr())
+            group = (B, prof_group)
+            frames_soa = None
+        else:
+            group = None
+            frames_soa = []
+            for e in host[:8]:  # (profile_frame_device takes one n: frames of their own length, one by one)
+                frames_soa.append((torch.from_numpy(np.ascontiguousarray(e["x"]).view(np.int16)).to(dev),
+                                   torch.from_numpy(np.ascontiguousarray(e["y"]).view(np.int16)).to(dev),
+                                   torch.from_numpy(np.ascontiguousarray(e["t"])).to(dev)))
+        if B:
+            roofline, alg, pt, wl = roofline_of(eng, None, n_mean, (None, None), tables, camera, bgr_b, world, group, wl_suffix="_esl",
+                                                cell_bytes=2 if info["mode"] != "none" else 8)
+        else:
+            n0 = lens[0]
+            roofline, alg, pt, wl = roofline_of(eng, frames_soa[:1], n0, (depth_out[0].data_ptr(), None if bgr_out is None else bgr_out[0].data_ptr()),
+                                                tables, camera, bgr_b, world, None, wl_suffix="_esl",
+                                                cell_bytes=2 if info["mode"] != "none" else 8)
+    est = tm.agree(tm.prewarm(step, 0.1))
+    steps = args.steps
+    R = 1 if args.single_block else int(min(200, max(3, round(TARGET_TIMED_S / max(steps * est, 1e-6)))))
+    el, enq = tm.blocks(lambda: [step(i) for i in range(steps)], R)
+    elapsed = float(np.median(el))
+    ev_per_step = float(np.mean([sum(lens[(i % G) * B:(i % G) * B + B]) if B else lens[i % nf] for i in range(steps)]))
+    value = ev_per_step * steps * world / elapsed / 1e6
+    paths = eng.path_counts()
+    if rank != 0:
+        eng.close()
+        return None
+    s_frame = elapsed / (steps * fps)
+    pipeline_fractions(roofline, alg, pt, wl, value, world, s_frame, fps, helper_runs=paths["cols"] > 0 or paths["general"] > 0)
+    # ---- other ways in (never `value`) -------------------------------------------------------------------------------
+    other = {}
+    if B and not args.no_other_modes:
+        tm1 = Timer(torch, None, dev, eng.sync)
+        e1 = tm1.prewarm(step_single, PREWARM_S)
+        k1 = max(1, steps * fps)
+        el1, _ = tm1.blocks(lambda: [step_single(i) for i in range(k1)], int(min(200, max(3, round(0.2 / max(k1 * e1, 1e-6))))))
+        dt1 = float(np.median(el1))
+        other["one_frame_per_call"] = {"value": round(float(np.mean(lens)) * k1 / dt1 / 1e6, 2), "unit": "Mevents/s",
+                                       "us_per_frame": round(dt1 / k1 * 1e6, 2), "frames_in_flight": min(slots, 4),
+                                       "note": "xm_process_frame_aos per frame, asynchronous (device-resident records)"}
+    # what the pipe does per projector frame: one synchronous host call, EventCD records in, BGR frame out
     for i in range(20):
         eng.process_events(host[i % nf], want_depth=False, want_bgr=True)
     lat = []
@@ -812,24 +970,7 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         eng.process_events(host[i % nf], want_depth=False, want_bgr=True)
         lat.append(time.perf_counter() - c0)
     lat = np.array(lat) * 1e3
-    # (B) device-resident EventCD frames, asynchronous, `slots` in flight
-    def step(i):
-        f = dev_frames[i % nf]
-        o = i % slots
-        eng.process_events_device(f.data_ptr(), len(host[i % nf]), False, depth_out[o].data_ptr(),
-                                  None if bgr_out is None else bgr_out[o].data_ptr())
-    tm = Timer(torch, dist, dev, eng.sync)
-    est = tm.agree(tm.prewarm(step, PREWARM_S))
-    steps = args.steps
-    R = 1 if args.single_block else int(min(200, max(3, round(TARGET_TIMED_S / max(steps * est, 1e-6)))))
-    el, enq = tm.blocks(lambda: [step(i) for i in range(steps)], R)
-    elapsed = float(np.median(el))
-    ev_per_step = float(np.mean([len(host[i % nf]) for i in range(steps)]))
-    value = ev_per_step * steps * world / elapsed / 1e6
-    if rank != 0:
-        eng.close()
-        return None
-    # (C) a camera-like stream through the device-side ingest, end to end
+    # a camera-like stream through the device-side ingest, end to end
     ingest = None
     if not args.no_host_path and world == 1:
         stream, _ = rig.render_stream(cp, tables, n_frames=16, row_stride=13, seed=9)
@@ -864,8 +1005,15 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         "config": {"workload": "C-ESL stand-in: frames rendered from a 3-D scene with the reference's real calibration geometry "
                                "(data/ESL_calib_hhi.yaml), rect 1760x1320, X-map 1320x1080, projector view 1080x1920; the ESL recording "
                                "itself is not available offline",
-                   "events_per_frame_mean": round(n_mean), "frames_in_flight": slots, "inputs": "EventCD AoS resident in HBM",
-                   "frames_per_s": round(steps * world / elapsed, 1)},
+                   "events_per_frame_mean": round(n_mean), "frames_per_step": fps, "frames_in_flight": slots,
+                   "inputs": "EventCD AoS resident in HBM", "frames_per_s": round(steps * fps * world / elapsed, 1),
+                   "us_per_frame": round(s_frame * 1e6, 3),
+                   "launch": (f"a step = one group of {B} frames through ONE call (xm_process_batch_aos), {G} groups in flight" if B else
+                              "one frame per call (xm_process_frame_aos), asynchronous"),
+                   "k1": {"none": "one thread per event, 64-bit atomic keys (the X-map is not injective and the rig did not "
+                                  "qualify for the owner tiles)",
+                          "cols": "column tiles", "own": "owner tiles (csrc/xmaps_k1own.hpp): no atomics, plain u16 frame"}[info["mode"]],
+                   "k1_geometry": info, "k1_paths_frames": paths, "frames_redone_on_general_path": eng.sorted_fallbacks()},
         "per_frame_host_call_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
                                    "definition": "DepthReprojectionPipe.process_ev_frame's work: one synchronous call, EventCD records in "
                                                  "pageable host memory -> BGR frame in host memory (H2D + kernels + D2H)",
@@ -873,7 +1021,7 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
                                                                       "(BASELINE.md section 1; other hardware, real data: context only)"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
                    "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6)},
-        "ingest_path": ingest, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "other_modes": other or None, "ingest_path": ingest, "cpu_baseline": cpu, "parity": parity,
     }
     eng.close()
     return out
@@ -953,11 +1101,31 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     # collective time, measured in a separate short pass (event records between the enqueues cost host time)
     for k, f in orig.items():
         setattr(proc, k, timed(f))
+    # ... and the shard's three kernels the same way (K0 extrema of the shard, K1 scatter with global event indices, K2 on the
+    # merged key frame): torch events on the engine's stream, which is torch's current stream inside process_shard
+    k_pairs = {"minmax_into": [], "scatter": [], "finish": [], "finish_u16": []}
+    p_orig = {k: getattr(prov, k) for k in k_pairs}
+
+    def timed_k(name, fn):
+        def wrapped(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            k_pairs[name].append((e0, e1))
+            return r
+        return wrapped
+    for k, f in p_orig.items():
+        setattr(prov, k, timed_k(k, f))
     for i in range(20):
         step(i)
     sync()
     for k, f in orig.items():
         setattr(proc, k, f)
+    for k, f in p_orig.items():
+        setattr(prov, k, f)
+    k_ms = [float(np.median([e0.elapsed_time(e1) for e0, e1 in k_pairs[k]])) if k_pairs[k] else 0.0
+            for k in ("minmax_into", "scatter", "finish" if args.merge == "all_reduce" else "finish_u16")]
     per_frame = 2 if args.merge == "all_reduce" else 3  # extrema + key frame | extrema + reduce-scatter + all-gather
     coll = np.array([e0.elapsed_time(e1) for e0, e1 in ev_pairs]).reshape(-1, per_frame)
     coll_ms = torch.tensor([float(np.median(coll[:, 0])), float(np.median(coll[:, 1:].sum(axis=1)))], dtype=torch.float64, device=dev)
@@ -967,6 +1135,14 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         eng.close()
         return None
     kshape = eng.key_shape
+    roofline, alg, pt = roofline_dict(np.array(k_ms + [elapsed / steps * 1e3]), None, b - a, 1, tables, camera, 0 if args.no_bgr else 3,
+                                      ("camera" if camera else "projector") + "_sharded",
+                                      "torch.cuda.Event pairs recorded on the engine's stream (torch's current stream inside "
+                                      "process_shard) around the shard's three kernel launches, 20 frames, median; k_minmax = the "
+                                      "shard's extrema pass K0; k_scatter processes THIS rank's events (events_per_rank); k_frame "
+                                      "runs on the merged key frame on every rank", cell_bytes=8 if args.merge == "all_reduce" else 2)
+    pipeline_fractions(roofline, alg, pt, ("camera" if camera else "projector") + "_sharded", value, 1, elapsed / steps, 1)
+    roofline["event_stream_read_roofline_frac_note"] = "whole frame (all ranks' events) per step time against ONE GPU's HBM read peak"
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         try:
@@ -999,7 +1175,7 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                                   "with one rank RCCL still runs its kernels (always_reduce) but nothing crosses xGMI"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
                    "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6)},
-        "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
     eng.close()
     return out

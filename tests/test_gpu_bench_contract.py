@@ -59,3 +59,33 @@ def test_other_configurations_print_one_json_line(flags, workload):
         assert all(v["depth_bit_exact"] for v in d["parity"].values())
     if "--sharded" in flags:
         assert d["scaling"] == "strong" and d["config"]["host_synchronisations_per_frame"] == 0 and d["parity"]["depth_bit_exact"]
+    if "--esl" in flags:
+        assert d["config"]["k1_geometry"]["mode"] == "own" and d["config"]["k1_paths_frames"]["cols"] > 0  # the owner-tile K1
+        assert d["parity"]["group_last_frame_depth_bit_exact"] and d["other_modes"]["one_frame_per_call"]["value"] > 100
+    _check_roofline(d["roofline"])
+
+
+def _check_roofline(r):
+    """Every mode's line carries the roofline object: the dominant kernel with the three fractions side by side (SURVEY 8(d)
+    algorithmic bytes, counter bytes when a PMC summary of the workload is committed, the event stream's 14 B/event), and K1 / K2
+    each with their own figures."""
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_counter_bytes", "event_stream_read_roofline_frac",
+              "kernels", "avg_launch_us", "whole_frame", "timing"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["kernel"] in ("k_scatter", "k_frame")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.0 < r["frac"] < 1.5
+    assert 0.0 < r["event_stream_read_roofline_frac"] < 1.0
+    ks, kf = r["kernels"]["k_scatter"], r["kernels"]["k_frame"]
+    for k in ("avg_launch_us", "us_per_frame", "algorithmic_bytes_per_launch", "frac_algorithmic", "hbm_bytes_per_launch_counters",
+              "frac_counter_bytes"):
+        assert k in ks and k in kf, k
+    assert ks["frac_event_stream_read"] > 0 and kf["frac_own_minimal_bytes"] > 0
+    assert ks["avg_launch_us"] > 0.5 and kf["avg_launch_us"] > 0.5
+    if r["traffic"] is not None:
+        assert r["frac_counter_bytes"] > 0
+
+
+def test_default_and_single_frame_lines_carry_the_three_fractions():
+    for flags in (("--steps", "20", "--warmup", "5"), ("--batch", "0", "--steps", "40", "--warmup", "5")):
+        d = _run(*flags, "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
+        _check_roofline(d["roofline"])

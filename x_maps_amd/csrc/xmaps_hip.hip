@@ -2226,7 +2226,7 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
   if (h->desc_used[k]) HIP_TRY(hipEventSynchronize(h->desc_ev[k]));  // the ring entry's previous batch has long finished
   FrameDesc* hd = h->h_descs + (size_t)k * ns;
   FrameDesc* dd = h->d_descs + (size_t)k * ns;
-  int kinds[2] = {0, 0};
+  int kinds[2] = {-1, -1};  // (stay -1 when the group fell back to frame-by-frame launches: nothing was attached then)
   int rc = enqueue_batch(h, idx.data(), evs.data(), dep.data(), bg.data(), n_frames, stream, hd, dd, true, true,
                          gpu_ms ? h->prof_ev : nullptr, kinds);
   if (rc) return rc;
@@ -2253,10 +2253,8 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
   if (gpu_ms) {  // profile mode: durations of the group's dispatches (the events were attached to the dispatch packets)
     HIP_TRY(hipStreamSynchronize(stream));
     gpu_ms[0] = gpu_ms[1] = gpu_ms[2] = gpu_ms[3] = 0.0f;
-    const int first = kinds[0] ? 0 : 1;  // no K0 / K0b launch on the verified-sorted keyed paths
-    u64 n_sum = 0;
-    for (int f = 0; f < n_frames; ++f) n_sum += evs[f].n;
-    if (batch_path(h, n_sum / (u64)n_frames)) {  // (frame-by-frame fallback for sparse frames: nothing was attached)
+    const int first = kinds[0] > 0 ? 0 : 1;  // no K0 / K0b launch on the verified-sorted keyed paths
+    if (kinds[1] >= 0) {
       for (int i = first; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&gpu_ms[i], h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
       HIP_TRY(hipEventElapsedTime(&gpu_ms[3], h->prof_ev[2 * first], h->prof_ev[5]));
     }
