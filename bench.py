@@ -488,6 +488,15 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     value = total_events / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     paths = eng.path_counts()
+    # N > 1: the frame-level replicas above need no collective.  The path's real exchange step -- one 10 M-event frame sharded by
+    # event index over the ranks, extrema MIN-reduce + packed-key MAX-merge over RCCL / xGMI (BASELINE configs[3]) -- is measured
+    # beside it on the same ranks (never `value`): every rank takes part, rank 0 keeps the figures
+    sharded_leg = None
+    if (world > 1 or os.environ.get("XM_BENCH_FORCE_SHARDED_LEG") == "1") and dist is not None and not args.no_other_modes:
+        import copy  # (XM_BENCH_FORCE_SHARDED_LEG + XM_BENCH_FORCE_DIST: the tests exercise this leg on a one-GPU box)
+        a2 = copy.copy(args)
+        a2.steps, a2.no_cpu_baseline, a2.single_block = 40, True, False
+        sharded_leg = bench_sharded(a2, torch, dist, dev, rank, local_rank, world)
     if rank != 0:
         eng.close()
         return None
@@ -636,6 +645,16 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "host_enqueue_us_per_step": round(float(np.median(enq)) / args.steps * 1e6, 2),
     }
+    if sharded_leg:
+        other_modes = other_modes or {}
+        other_modes["one_frame_sharded_over_the_ranks"] = {
+            "value": sharded_leg["value"], "unit": sharded_leg["unit"], "ms_per_frame": sharded_leg["ms_per_step"], "scaling": "strong",
+            "workload": sharded_leg["config"]["workload"], "events_per_rank": sharded_leg["config"]["events_per_rank"],
+            "collective_ms": sharded_leg["collective_ms"], "kernels_us": sharded_leg["roofline"]["avg_launch_us"],
+            "parity": sharded_leg["parity"],
+            "note": "bench.py --sharded on the same ranks: C-10M, the event buffer split by index, MIN all-reduce of the extrema + MAX "
+                    "all-reduce of the packed-key frame (collective time listed separately); the headline `value` is frame-level "
+                    "weak scaling without any collective"}
     if other_modes:
         out["other_modes"] = other_modes
     if host_path:

@@ -1,5 +1,6 @@
-"""CPU: the cv2-free table builder (x_maps_amd/calibration.py, row N4).  Rotations are pinned against the R1 / R2 that
-OpenCV's stereoRectify wrote into the reference's calibration file; the rest is checked for geometric consistency."""
+"""CPU: the cv2-free table builder (x_maps_amd/calibration.py, row N4).  stereo_rectify is pinned against everything OpenCV's
+stereoRectify wrote into the reference's calibration file (R1, R2, P1, P2, Q, both ROIs: bit for bit); the maps are checked for
+geometric consistency."""
 import os
 
 import numpy as np
@@ -11,14 +12,27 @@ def _g(golden_dir):
     return np.load(os.path.join(golden_dir, "g6_esl_calib.npz"))
 
 
-def test_rectifying_rotations_match_opencv_stored_in_reference_yaml(golden_dir):
+def test_stereo_rectify_reproduces_the_opencv_outputs_stored_in_the_reference_yaml(golden_dir):
+    """data/ESL_calib_hhi.yaml:62-134 holds what a real cv::stereoRectify returned for this rig: R1, R2, P1, P2, Q and both
+    validPixROIs, computed with alpha = 0.5 (:138).  The call that produced them -- camera first, imageSize = (480, 640) (the
+    file's img_shape, rows first), newImageSize = (1920, 1080) (proj_shape), T in centimetres, CALIB_ZERO_DISPARITY -- is
+    reproduced here to the last digit: the rotations, the common focal length (mean of the two, x newImageSize / imageSize),
+    the principal points (float32 corner images), the inner / outer rectangles behind the alpha scaling and the ROIs.  The
+    alpha = -1 path the reference takes (python/cam_proj_calibration.py:203-217) shares all of it but the scaling."""
     g = _g(golden_dir)
-    R1, R2, P1, P2, Q = C.stereo_rectify(g["camera_K"], g["camera_D"], g["projector_K"], g["projector_D"], (1920, 1080),
-                                         g["R"], g["T"])
+    R1, R2, P1, P2, Q, roi1, roi2 = C.stereo_rectify(g["camera_K"], g["camera_D"], g["projector_K"], g["projector_D"], (480, 640),
+                                                     g["R"], g["T"].reshape(3) * 100.0, alpha=0.5, new_image_size=(1920, 1080),
+                                                     return_rois=True)
     assert np.abs(R1 - g["R1"]).max() < 1e-12 and np.abs(R2 - g["R2"]).max() < 1e-12
+    for got, want in ((P1, g["P1"]), (P2, g["P2"]), (Q, g["Q"])):
+        assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (got, want)
+    assert roi1 == (0, 0, 1920, 1080) and roi2 == (0, 0, 0, 0)  # validPixROI1 / validPixROI2 of the file (:118-133)
     assert np.allclose(R1 @ R1.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R1) - 1) < 1e-12
-    assert P1[0, 0] == P1[1, 1] == P2[0, 0] and P1[0, 3] == 0 and P2[0, 3] != 0 and P2[1, 3] == 0
-    assert np.array_equal(P1[:, :3], P2[:, :3])  # CALIB_ZERO_DISPARITY: same intrinsics in both rectified views
+    # the alpha = -1 call of the reference: same rotations, no scaling, CALIB_ZERO_DISPARITY
+    r1, r2, p1, p2, q = C.stereo_rectify(g["camera_K"], g["camera_D"], g["projector_K"], g["projector_D"], (1920, 1080), g["R"], g["T"])
+    assert np.abs(r1 - g["R1"]).max() < 1e-12 and np.abs(r2 - g["R2"]).max() < 1e-12
+    assert p1[0, 0] == p1[1, 1] == p2[0, 0] == (g["camera_K"][1, 1] + g["projector_K"][1, 1]) / 2
+    assert p1[0, 3] == 0 and p2[0, 3] != 0 and p2[1, 3] == 0 and np.array_equal(p1[:, :3], p2[:, :3])
 
 
 def test_rodrigues_round_trip():

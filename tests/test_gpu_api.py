@@ -368,12 +368,15 @@ def test_esl_like_rig_parity_and_accuracy():
     assert np.array_equal(xm, tb["proj_x_map"])
     with XMapsEngine(tb) as eng:
         depth, bgr, st = eng.process_events(evs)
-    assert st.n_inliers == int(ref["mask"].sum()) > 0.9 * len(evs)
+    # (with the rectification pinned to OpenCV's -- tests/test_calibration_cpu.py -- a fifth of this rig's camera image is
+    #  rectified to rows outside the 1760 x 1320 frame the reference's launch configuration allots: those events fail xmd:23)
+    assert st.n_inliers == int(ref["mask"].sum()) > 0.75 * len(evs)
     assert np.array_equal(depth, ref["depth"]) and np.array_equal(bgr, ref["bgr"])
-    est = depth[gt["proj_v"], gt["proj_u"]]
+    m = ref["mask"]
+    est = depth[gt["proj_v"][m], gt["proj_u"][m]]
     ok = est > 0
-    rel = np.abs(est[ok] - gt["z_rect"][ok]) / gt["z_rect"][ok]
-    assert ok.mean() > 0.97 and np.median(rel) < 0.015 and np.percentile(rel, 95) < 0.03
+    rel = np.abs(est[ok] - gt["z_rect"][m][ok]) / gt["z_rect"][m][ok]
+    assert ok.mean() > 0.99 and np.median(rel) < 0.01 and np.percentile(rel, 95) < 0.02
     # a denser frame of the same scene goes through the tiled kernel (LDS windows on rotated, distorted geometry)
     evs2, gt2 = rig.render_events(cp, tb, row_stride=3, seed=1)
     ref2 = _ref(tb, evs2)

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
-    env = dict(os.environ, XM_BENCH_PREWARM_S="0.05")
+def _run(*flags, **extra_env):
+    env = dict(os.environ, XM_BENCH_PREWARM_S="0.05", **extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600, env=env,
                        cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -89,3 +89,15 @@ def test_default_and_single_frame_lines_carry_the_three_fractions():
     for flags in (("--steps", "20", "--warmup", "5"), ("--batch", "0", "--steps", "40", "--warmup", "5")):
         d = _run(*flags, "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
         _check_roofline(d["roofline"])
+
+
+
+def test_multi_gpu_line_carries_the_sharded_frame_beside_the_replicas():
+    """With N > 1 ranks the default line reports frame-level replicas (no collective) and, beside it, one C-10M frame sharded by
+    event index over the same ranks with the collective time listed separately.  One GPU here: the leg is forced through a
+    one-rank process group (RCCL kernels run, nothing crosses xGMI)."""
+    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path",
+             XM_BENCH_FORCE_DIST="1", XM_BENCH_FORCE_SHARDED_LEG="1")
+    sh = d["other_modes"]["one_frame_sharded_over_the_ranks"]
+    assert sh["scaling"] == "strong" and sh["value"] > 1000 and sh["parity"]["depth_bit_exact"]
+    assert sh["collective_ms"]["key_frame_merge"] > 0 and sh["kernels_us"]["k_scatter"] > 0

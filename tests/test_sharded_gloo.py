@@ -82,7 +82,17 @@ class OracleShardProvider:
         return a
 
 
-def _worker(rank, world, port, camera, out_dir, merge):
+def _cuts(n, world, uneven):
+    """shard boundaries: the library's even split, or a lopsided one (10 % | nothing | 55 % | 35 %) for world_size 4"""
+    if not uneven:
+        from x_maps_amd.sharded import shard_bounds
+        return [shard_bounds(n, r, world) for r in range(world)]
+    assert world == 4
+    e = [0, n // 10, n // 10, n // 10 + (n * 55) // 100, n]
+    return [(e[r], e[r + 1]) for r in range(4)]
+
+
+def _worker(rank, world, port, camera, out_dir, merge, uneven=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -95,7 +105,7 @@ def _worker(rank, world, port, camera, out_dir, merge):
     for frame, n in ((0, 4000), (1, 2501), (2, 1)):  # incl. an odd split and a frame with an EMPTY shard
         evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(frame == 1))
         x, y, t, _ = S.to_soa(evs)
-        a, b = shard_bounds(n, rank, world)
+        a, b = _cuts(n, world, uneven)[rank]
         depth, bgr = proc.process_shard((x[a:b], y[a:b], t[a:b], None), a)
         np.savez(os.path.join(out_dir, f"r{rank}_f{frame}.npz"), depth=depth, bgr=bgr)
     dist.destroy_process_group()
@@ -120,3 +130,24 @@ def test_two_rank_shards_equal_single_process(tmp_path, camera, merge):
             got = np.load(os.path.join(str(tmp_path), f"r{r}_f{frame}.npz"))
             assert np.array_equal(got["depth"], ref["depth"]), (frame, r)
             assert np.array_equal(got["bgr"], ref["bgr"]), (frame, r)
+
+
+@pytest.mark.parametrize("merge", ["all_reduce", "reduce_scatter"])
+def test_four_ranks_with_uneven_shards_equal_single_process(tmp_path, merge):
+    """world_size 4, shards of 10 % / nothing / 55 % / 35 % of the frame (whoever cuts the stream need not cut it evenly; a rank
+    may get no events at all): the extrema MIN-reduce and the packed-key MAX-merge reproduce the single-process frame on every rank."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(4, port, False, str(tmp_path), merge, True), nprocs=4, join=True)
+    import xmaps_oracle as O
+    from x_maps_amd import synthetic as S
+    tb = S.make_tables(S.C_TINY)
+    for frame, n in ((0, 4000), (1, 2501), (2, 1)):
+        evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(frame == 1))
+        x, y, t, _ = S.to_soa(evs)
+        ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t)
+        for r in range(4):
+            got = np.load(os.path.join(str(tmp_path), f"r{r}_f{frame}.npz"))
+            assert np.array_equal(got["depth"], ref["depth"]) and np.array_equal(got["bgr"], ref["bgr"]), (frame, r)

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libxmaps_hip.so")
 SOURCES = [os.path.join(PKG_DIR, "csrc", "xmaps_hip.hip")]
-DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", f) for f in ("xmaps_kernels.hpp", "xmaps_k1cols.hpp", "xmaps_k1own.hpp",
+DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", f) for f in ("xmaps_kernels.hpp", "xmaps_k1cols.hpp", "xmaps_k1own.hpp", "xmaps_k2pipe.hpp",
                                                                   "xmaps_ingest.hpp", "turbo_lut.inc")] + [
     os.path.join(ROOT, "include", "xmaps.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

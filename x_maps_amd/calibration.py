@@ -148,13 +148,42 @@ def project_points(xyz, K, D=None):
     return np.stack((K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]), -1)
 
 
-# ---- cv::stereoRectify (Bouguet), CALIB_ZERO_DISPARITY, alpha < 0 -------------------------------------------
-def stereo_rectify(K1, D1, K2, D2, image_size, R, T):
-    """Returns R1, R2, P1, P2, Q.  image_size = (width, height) of the RECTIFIED frame, as the reference passes it
-    (python/cam_proj_calibration.py:211-217, alpha=-1)."""
+# ---- cv::stereoRectify (Bouguet) -----------------------------------------------------------------------------------
+def _f32(a):
+    """round to float32 and back: OpenCV keeps these intermediate points as CV_32F"""
+    return np.asarray(a, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+
+def _inner_outer_rectangles(K, D, R, P, image_size):
+    """icvGetRectangles: a 9 x 9 grid over the source image, undistorted + rectified (float32 points); the largest rectangle
+    inscribed in / the bounding box of its image.  Returns ((x, y, w, h) inner, (x, y, w, h) outer), float32 arithmetic."""
+    nx, ny = image_size
+    N = 9
+    f = np.float32
+    pts = np.array([[f(x) * f(nx) / f(N - 1), f(y) * f(ny) / f(N - 1)] for y in range(N) for x in range(N)], dtype=np.float64)
+    p = _f32(undistort_points(pts, K, D, R, P)).reshape(N, N, 2)
+    ix0, ix1, iy0, iy1 = p[:, 0, 0].max(), p[:, N - 1, 0].min(), p[0, :, 1].max(), p[N - 1, :, 1].min()
+    ox0, ox1, oy0, oy1 = p[..., 0].min(), p[..., 0].max(), p[..., 1].min(), p[..., 1].max()
+    sub = lambda a, b: float(f(a) - f(b))
+    return (float(ix0), float(iy0), sub(ix1, ix0), sub(iy1, iy0)), (float(ox0), float(oy0), sub(ox1, ox0), sub(oy1, oy0))
+
+
+def stereo_rectify(K1, D1, K2, D2, image_size, R, T, alpha: float = -1.0, new_image_size=None, zero_disparity: bool = True,
+                   return_rois: bool = False):
+    """cv::stereoRectify as OpenCV >= 3.4.7 / 4.1.1 computes it.  Returns R1, R2, P1, P2, Q (+ validPixROI1, validPixROI2 as
+    (x, y, w, h) with return_rois).  image_size = (width, height) as the reference passes it -- the RECTIFIED frame's size,
+    alpha = -1, CALIB_ZERO_DISPARITY by default (python/cam_proj_calibration.py:203-217).
+
+    PINNED against real OpenCV output: called the way the calibration tool behind the reference's data/ESL_calib_hhi.yaml called
+    it (camera first, imageSize = (480, 640), newImageSize = (1920, 1080), alpha = 0.5, T in cm) this reproduces the P1, P2, Q,
+    validPixROI1 / 2 stored in that file (:90-134) to the last digit (tests/test_calibration_cpu.py).  That includes what the
+    alpha = -1 path shares: the common focal length = mean of the two focal lengths x newImageSize / imageSize (older OpenCV took
+    the smaller one, shrunk for barrel distortion: the file rules that out), the principal points from the float32 images of the
+    four frame corners, five fixed-point rounds in undistortPoints."""
     K1, K2 = np.asarray(K1, np.float64), np.asarray(K2, np.float64)
     R, T = np.asarray(R, np.float64), np.asarray(T, np.float64).reshape(3)
     nx, ny = image_size
+    nnx, nny = new_image_size if new_image_size is not None and new_image_size[0] * new_image_size[1] != 0 else image_size
     om = rodrigues(R)
     r_r = rodrigues(-0.5 * om)           # each camera takes half of the relative rotation
     t = r_r @ T
@@ -171,28 +200,52 @@ def stereo_rectify(K1, D1, K2, D2, image_size, R, T):
     R2 = wR @ r_r
     t = R2 @ T
 
-    # common focal length: the smaller one, shrunk a little for barrel distortion (k1 < 0)
-    fc_new = np.inf
-    for K, D in ((K1, D1), (K2, D2)):
-        fc = K[idx ^ 1, idx ^ 1]
-        dk1 = _dist5(D)[0]
-        if dk1 < 0:
-            fc *= 1 + dk1 * (nx * nx + ny * ny) / (4 * fc * fc)
-        fc_new = min(fc_new, fc)
-    # principal points: centre the (rectified) images of the four frame corners
+    # common focal length: the mean of the two, scaled to the new image size
+    ratio = (nnx / nx / 2) if idx == 1 else (nny / ny / 2)
+    fc_new = (K1[idx ^ 1, idx ^ 1] + K2[idx ^ 1, idx ^ 1]) * ratio
+    # principal points: centre the (rectified) images of the four frame corners; the points are float32 in OpenCV
     corners = np.array([[0, 0], [nx - 1, 0], [0, ny - 1], [nx - 1, ny - 1]], dtype=np.float64)
     cc = []
     for K, D, Rk in ((K1, D1, R1), (K2, D2, R2)):
-        n = undistort_points(corners, K, D)
+        n = _f32(undistort_points(corners, K, D))
         xyz = Rk @ np.stack((n[:, 0], n[:, 1], np.ones(4)), 0)
-        px, py = fc_new * xyz[0] / xyz[2], fc_new * xyz[1] / xyz[2]
+        px, py = _f32(fc_new * xyz[0] / xyz[2]), _f32(fc_new * xyz[1] / xyz[2])
         cc.append(np.array([(nx - 1) / 2 - px.mean(), (ny - 1) / 2 - py.mean()]))
-    cc0 = cc1 = (cc[0] + cc[1]) * 0.5    # CALIB_ZERO_DISPARITY: same principal point in both views
-    P1 = np.array([[fc_new, 0, cc0[0], 0], [0, fc_new, cc0[1], 0], [0, 0, 1, 0]], dtype=np.float64)
-    P2 = np.array([[fc_new, 0, cc1[0], 0], [0, fc_new, cc1[1], 0], [0, 0, 1, 0]], dtype=np.float64)
+    if zero_disparity:                   # CALIB_ZERO_DISPARITY: the same principal point in both views
+        cc[0] = cc[1] = (cc[0] + cc[1]) * 0.5
+    else:                                # only along the axis perpendicular to the baseline
+        m = (cc[0][idx ^ 1] + cc[1][idx ^ 1]) * 0.5
+        cc[0][idx ^ 1] = cc[1][idx ^ 1] = m
+    P1 = np.array([[fc_new, 0, cc[0][0], 0], [0, fc_new, cc[0][1], 0], [0, 0, 1, 0]], dtype=np.float64)
+    P2 = np.array([[fc_new, 0, cc[1][0], 0], [0, fc_new, cc[1][1], 0], [0, 0, 1, 0]], dtype=np.float64)
     P2[idx, 3] = t[idx] * fc_new
-    Q = np.array([[1, 0, 0, -cc0[0]], [0, 1, 0, -cc0[1]], [0, 0, 0, fc_new], [0, 0, -1.0 / t[idx], 0]], dtype=np.float64)
-    return R1, R2, P1, P2, Q
+    in1, out1 = _inner_outer_rectangles(K1, D1, R1, P1[:, :3], image_size)
+    in2, out2 = _inner_outer_rectangles(K2, D2, R2, P2[:, :3], image_size)
+    (cx1_0, cy1_0), (cx2_0, cy2_0) = cc[0], cc[1]
+    cx1, cy1, cx2, cy2 = nnx * cx1_0 / nx, nny * cy1_0 / ny, nnx * cx2_0 / nx, nny * cy2_0 / ny
+    s = 1.0
+    if alpha >= 0:  # 0: only valid pixels stay (inner rectangles), 1: every source pixel stays (outer rectangles)
+        def scale(r, cx, cy, cx0, cy0, pick):
+            return pick(pick(pick(cx / (cx0 - r[0]), cy / (cy0 - r[1])), (nnx - cx) / (r[0] + r[2] - cx0)), (nny - cy) / (r[1] + r[3] - cy0))
+        s0 = max(scale(in1, cx1, cy1, cx1_0, cy1_0, max), scale(in2, cx2, cy2, cx2_0, cy2_0, max))
+        s1 = min(scale(out1, cx1, cy1, cx1_0, cy1_0, min), scale(out2, cx2, cy2, cx2_0, cy2_0, min))
+        s = s0 * (1 - alpha) + s1 * alpha
+    fc_new *= s
+    P1[0, 0] = P1[1, 1] = P2[0, 0] = P2[1, 1] = fc_new
+    P1[0, 2], P1[1, 2], P2[0, 2], P2[1, 2] = cx1, cy1, cx2, cy2
+    P2[idx, 3] *= s
+    # (cv::stereoRectify builds Q from the principal points: -cx1, -cy1, f, -1/Tx, (cx1 - cx2)/Tx)
+    Q = np.array([[1, 0, 0, -cx1], [0, 1, 0, -cy1], [0, 0, 0, fc_new], [0, 0, -1.0 / t[idx], (cx1 - cx2) / t[idx] if idx == 0 else (cy1 - cy2) / t[idx]]],
+                 dtype=np.float64)
+    if not return_rois:
+        return R1, R2, P1, P2, Q
+
+    def roi(r, cx0, cy0, cx, cy):
+        x, y = int(np.ceil((r[0] - cx0) * s + cx)), int(np.ceil((r[1] - cy0) * s + cy))
+        w, h = int(np.floor(r[2] * s)), int(np.floor(r[3] * s))
+        x0, y0, x1, y1 = max(x, 0), max(y, 0), min(x + w, nnx), min(y + h, nny)  # & Rect(0, 0, newImageSize)
+        return (x0, y0, x1 - x0, y1 - y0) if x1 > x0 and y1 > y0 else (0, 0, 0, 0)
+    return R1, R2, P1, P2, Q, roi(in1, cx1_0, cy1_0, cx1, cy1), roi(in2, cx2_0, cy2_0, cx2, cy2)
 
 
 def init_undistort_rectify_map(K, D, R, P, size):

@@ -5,6 +5,7 @@
 #include "xmaps_kernels.hpp"
 #include "xmaps_k1cols.hpp"
 #include "xmaps_k1own.hpp"
+#include "xmaps_k2pipe.hpp"
 #include "xmaps_ingest.hpp"
 
 #include <hip/hip_ext.h>
@@ -163,10 +164,15 @@ struct xm_handle {
   u32* d_pmap = nullptr;
   uint2* d_dlut = nullptr;
   // K2's static per-tile / per-pixel tables for its two geometries: [0] one pixel per thread (16 x 16 tiles), [1] two (32 x 16)
-  int4* d_k2_tiles[2] = {nullptr, nullptr};
-  u32* d_k2_pix[2] = {nullptr, nullptr};
-  int k2_tile_cap[2] = {K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
+  // ([2]: four pixels per thread, 64 x 16 tiles -- the pipelined kernel on rigs whose patches are small against the tile)
+  int4* d_k2_tiles[3] = {nullptr, nullptr, nullptr};
+  u32* d_k2_pix[3] = {nullptr, nullptr, nullptr};
+  int k2_tile_cap[3] = {K2_TILE_MAX, K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
+  bool k2_pipe4 = false;  // the pipelined kernel takes the 64 x 16 geometry
   int k2_force_ppt = 0;                             // XM_K2_PPT=1/2: experiments
+  // pipelined K2 of the group launches (xmaps_k2pipe.hpp): table entries kept in LDS, CUs of the device, switch (XM_K2_PIPE=0: off)
+  int k2_pipe_nlds = 0, n_cus = 256;
+  bool k2_pipe = true, k2_pipe_rig_ok = false;  // (rig_ok: every tile's patch fits the pipelined loader, rect_h % 8 == 0)
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
   SlotState* aux_st = nullptr;
@@ -483,8 +489,40 @@ void launch_k2(xm_handle* h, hipStream_t stream, const u64* key_frame, SlotState
               dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[1]);
 }
 
+// the software-pipelined K2 (persistent blocks walking (frame, tile) items): groups on the plain u16 frame, two pixels per thread
+size_t k2_pipe_lds_bytes(const xm_handle* h, int g) {
+  return (size_t)((h->k2_tile_cap[g] + 32 + 7) & ~7) * sizeof(uint16_t) + (size_t)h->k2_pipe_nlds * sizeof(uint2);
+}
+
+bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
+  if (!h->k2_pipe || !h->k2_pipe_rig_ok || h->k2_pipe_nlds < 1 || k2_ppt(h, n_frames) != 2) return false;
+  const int g = h->k2_pipe4 ? 2 : 1, ppt = 1 << g;
+  const u32 gx = grid_for(h->tb.proj_w, K2_TX * ppt), gy = grid_for(h->tb.proj_h, K2_TY);
+  const u64 total = (u64)gx * gy * (u64)n_frames;
+  const size_t lds = k2_pipe_lds_bytes(h, g);
+  static const int bpc_env = getenv("XM_K2_PIPE_BPC") ? atoi(getenv("XM_K2_PIPE_BPC")) : 0;  // experiments: blocks per CU
+  const unsigned per_cu = bpc_env > 0 ? (unsigned)bpc_env : (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 2048)));
+  unsigned blocks = (unsigned)h->n_cus * per_cu / 8 * 8;
+  if (total < 3ull * blocks) return false;  // too few items per block for the pipeline to matter: one block per tile
+  const void* fn = g == 2 ? reinterpret_cast<const void*>(k_frame_proj_pipe<4>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2>);
+  if (h->ensure_lds(fn, lds) != XM_OK) return false;
+  K2PipeArgs pa;
+  pa.proj_w = h->tb.proj_w; pa.proj_h = h->tb.proj_h; pa.rect_w = h->tb.rect_w; pa.rect_h = h->tb.rect_h;
+  pa.shear_m = h->tb.shear_m; pa.shear_bias = h->tb.shear_bias;
+  if (g == 2)
+    XM_LAUNCH((k_frame_proj_pipe<4>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[2],
+              (const u32*)h->d_k2_pix[2], h->tb.dlut, pa, h->k2_tile_cap[2], (u32)n_frames, gx, gy, h->k2_pipe_nlds);
+  else
+    XM_LAUNCH((k_frame_proj_pipe<2>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, h->tb.k2_tiles, h->tb.k2_pix, h->tb.dlut, pa,
+              h->k2_tile_cap[1], (u32)n_frames, gx, gy, h->k2_pipe_nlds);
+  return true;
+}
+
 template <int FMT, int COND = 0>
 void launch_k2_batch(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
+  if constexpr (FMT == 2 && COND == 0) {
+    if (launch_k2_pipe(h, stream, d_descs, n_frames)) return;
+  }
   const int ppt = k2_ppt(h, n_frames);
   dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY), n_frames);
   if (COND == 1) grid = dim3(std::min(grid.x * grid.y, 32u), 1, n_frames);  // redo node: a few blocks per frame walk its tiles
@@ -503,7 +541,7 @@ size_t cols_lds_bytes(const xm_handle* h, int W) {  // mirrors the carve-up at t
 }
 
 size_t own_plan_lds_bytes(int nxs_max, int hrp, int extra_max) {  // mirrors the carve-up at the top of scatter_own_body
-  return (size_t)4 * nxs_max * hrp + (size_t)4 * extra_max + (size_t)8 * (hrp / 8) + (size_t)2 * hrp;
+  return (size_t)4 * nxs_max * hrp + (size_t)4 * extra_max + (size_t)4 * hrp;
 }
 size_t own_lds_bytes(const xm_handle* h) { return own_plan_lds_bytes(h->tb.own_nxs_max, h->tb.own_hrp, h->tb.own_extra_max); }
 
@@ -593,12 +631,12 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   }
   const int bias = -sh_min, extra = sh_max - sh_min;
   if (rect_w + extra > 32767) return;
-  // 3. per (tile, 8-row group): where its cells lie in the sheared frame.  The band of a group = the window of NX frame
-  //    columns that holds most of its owner cells (away from the middle time column the X-map's slant differs a little from
-  //    the frame's shear: the window moves slowly from group to group); owner cells outside it are "extras" (where the rectified
+  // 3. per (tile, row): where its cells lie in the sheared frame.  The band of a row = the window of NX frame columns that
+  //    holds most of the row's owner cells (a tile's cells of one row are a short run; the run moves with the row by what the
+  //    frame's shear leaves of the X-map's slant); owner cells outside it are "extras" (where the rectified
   //    time map replicates its border the X-map jumps by hundreds of columns: first / last tile of the ESL rig).  NX = the
   //    narrowest band that leaves (almost) no more extras than the widest one.
-  const int nt = (xmap_w + W - 1) / W, ng = hrp / 8;
+  const int nt = (xmap_w + W - 1) / W, ng = hrp;  // (one band position per row)
   const auto owner_col = [&](int r, int c, int& xs) {  // owner pairs only: the cell's column in the sheared frame
     const uint16_t pk = packed[(size_t)c * xmap_h + r];
     if (!pk || (pk >> OWN_XP_BITS) != 0) return false;
@@ -608,11 +646,11 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
     xs = fc + bias + (((r >> 3) * m) >> 12);
     return true;
   };
-  std::vector<std::vector<int>> cells((size_t)nt * ng);  // sorted sheared columns of every (tile, group)'s owner cells
+  std::vector<std::vector<int>> cells((size_t)nt * ng);  // sorted sheared columns of every (tile, row)'s owner cells
   for (int r = r_lo; r <= r_hi; ++r)
     for (int c = 0; c < xmap_w; ++c) {
       int xs;
-      if (owner_col(r, c, xs)) cells[(size_t)(c / W) * ng + ((r - r_lo) >> 3)].push_back(xs);
+      if (owner_col(r, c, xs)) cells[(size_t)(c / W) * ng + (r - r_lo)].push_back(xs);
     }
   for (auto& v : cells) std::sort(v.begin(), v.end());
   const auto best_window = [](const std::vector<int>& v, int nx, int& start) {  // most cells inside [start, start + nx)
@@ -655,7 +693,7 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
     for (int c = 0; c < xmap_w; ++c) {
       int xs;
       if (!owner_col(r, c, xs)) continue;
-      const int t = c / W, k = xs - bases[(size_t)t * ng + ((r - r_lo) >> 3)];
+      const int t = c / W, k = xs - bases[(size_t)t * ng + (r - r_lo)];
       if (k >= 0 && k < NX) {
         masks[(size_t)t * hrp + (r - r_lo)] |= (uint16_t)(1u << k);
         tiles[t].x = std::max(tiles[t].x, k + 1);
@@ -1666,20 +1704,39 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->tb.z_far = cfg->z_far;
   if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets, for both of its geometries
     if (const char* e = getenv("XM_K2_PPT")) h->k2_force_ppt = atoi(e);
-    for (int g = 0; g < 2; ++g) {
-      const unsigned tiles_x = grid_for(cfg->proj_width, K2_TX * (g + 1)), tiles_y = grid_for(cfg->proj_height, K2_TY);
+    double mean_cells2 = 0.0;
+    for (int g = 0; g < 3; ++g) {
+      const int ppt = 1 << g;
+      const unsigned tiles_x = grid_for(cfg->proj_width, K2_TX * ppt), tiles_y = grid_for(cfg->proj_height, K2_TY);
       XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_tiles[g], (size_t)tiles_x * tiles_y * sizeof(int4)));
       XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix[g], (size_t)cfg->proj_width * cfg->proj_height * sizeof(u32)));
       if (g == 0) hipLaunchKernelGGL(k_build_k2_tables<1>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
-      else hipLaunchKernelGGL(k_build_k2_tables<2>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
+      else if (g == 1) hipLaunchKernelGGL(k_build_k2_tables<2>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
+      else hipLaunchKernelGGL(k_build_k2_tables<4>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
       XM_TRY_CREATE(hipGetLastError());
       XM_TRY_CREATE(hipDeviceSynchronize());
       // largest LDS patch any tile of this rig needs -> K2's dynamic LDS
       std::vector<int4> tiles((size_t)tiles_x * tiles_y);
       XM_TRY_CREATE(hipMemcpy(tiles.data(), h->d_k2_tiles[g], tiles.size() * sizeof(int4), hipMemcpyDeviceToHost));
       int cap = 8;
-      for (const int4& r : tiles)
+      bool pipe_ok = (cfg->rect_height & 7) == 0;
+      double cells = 0.0;
+      for (const int4& r : tiles) {
         if (r.z > 0) cap = std::max(cap, r.z * r.w);
+        if (r.z > 0) cells += (double)r.z * r.w;
+        pipe_ok = pipe_ok && k2_pipe_tile_ok(r);
+      }
+      if (g == 1) {
+        h->k2_pipe_rig_ok = pipe_ok;
+        mean_cells2 = cells / (double)std::max<size_t>(tiles.size(), 1);
+      }
+      // Four pixels per thread when the 32 x 16-pixel tiles' patches are small against the tile (a projector image finer than
+      // the rectified frame: < 2 patch cells per pixel): an item's fixed costs -- five barriers, the descriptor reads, the tile
+      // arithmetic -- then weigh more than its patch, and half as many items carry the same pixels
+      if (g == 2) {
+        const char* e4 = getenv("XM_K2_PIPE_PPT");  // experiments: 2 / 4
+        h->k2_pipe4 = pipe_ok && h->k2_pipe_rig_ok && (e4 ? atoi(e4) == 4 : mean_cells2 < 2.0 * (2 * K2_TX * K2_TY));
+      }
       h->k2_tile_cap[g] = std::min((cap + 7) & ~7, (int)K2_TILE_MAX);
     }
     h->tb.k2_tiles1 = h->d_k2_tiles[0];
@@ -1696,6 +1753,11 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     // (camera view: (event index + 1) << 12 | disparity on the camera frame -- only the disparity range matters)
     h->key32_ok = (cfg->view != XM_VIEW_PROJECTOR || (cfg->rect_height & 3) == 0) && max_disp < (1l << KEY32_DISP_BITS) &&
                   !(e32 && e32[0] == '0');
+    // the pipelined K2 keeps the per-disparity table in LDS: every disparity an event of this rig can have (<= 4096 entries, 32 KB)
+    h->k2_pipe_nlds = max_disp + 1 <= 4096 ? (int)std::max<long>(1, max_disp + 1) : 0;
+    if (const char* e = getenv("XM_K2_PIPE")) h->k2_pipe = e[0] != '0';
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
   }
   {  // does the rig qualify for the column-tile K1?  (xmaps_k1cols.hpp)
     int xr_min = 32767, xr_max = -32768, xp_min = 32767, xp_max = -32768;
@@ -1961,7 +2023,7 @@ void xm_destroy(xm_handle* h) {
   if (h->d_own_masks) (void)hipFree(h->d_own_masks);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < 3; ++g) {
     if (h->d_k2_tiles[g]) (void)hipFree(h->d_k2_tiles[g]);
     if (h->d_k2_pix[g]) (void)hipFree(h->d_k2_pix[g]);
   }

@@ -15,10 +15,10 @@
 //   * slots are indexed by the CELL, not by (row, column): on such rigs the X-map is strongly slanted (ESL: a time column's
 //     cell moves 0.37 .. 0.43 columns per row), so a tile's cells form a thin diagonal band.  The u16 disparity frame is
 //     SHEARED by whole columns per 8-row group -- cell (x, row) lives at column x + bias + ((row >> 3) * m >> 12), m fitted to
-//     the rig's middle time column in xm_create -- and every (tile, 8-row group) has its own first column `base` (what is left
-//     of the slant away from the middle): the slot array is [nxs sheared columns][rows the LUT can reach] with nxs = 6 on the
-//     ESL rig, the flush walks it in memory order (lanes = consecutive rows of one frame column), a precomputed bit mask per
-//     (tile, row) says which of the band's cells the tile owns.  K2 reads the same layout (its 16-byte loads take 8 aligned
+//     the rig's middle time column in xm_create -- which keeps the stores of 64 consecutive rows within a few frame columns; in
+//     LDS every (tile, row) has its own first column `base`: the slot array is [nxs columns][rows the LUT can reach] with
+//     nxs = the cells a row has in a tile (+ 1), the flush walks it in memory order (lanes = consecutive rows), a precomputed
+//     bit mask per (tile, row) says which of the band's cells the tile owns.  K2 reads the same layout (its 16-byte loads take 8 aligned
 //     rows of one column: the shear is constant there).
 //   * cells outside the band ("extras": where the rectified time map replicates its border the X-map's arg-min jumps by hundreds
 //     of columns -- first and last tile of the ESL rig, ~470 cells) get a slot of their own behind the band (index from a second
@@ -34,7 +34,7 @@
 
 namespace xm {
 
-constexpr int OWN_BW = 4;         // K0b's boundary spacing for this path (tile widths and halos are multiples of it)
+constexpr int OWN_BW = 2;         // K0b's boundary spacing for this path (tile widths and halos are multiples of it)
 constexpr int OWN_MAX_DELTA = 7;  // 3 bits in the packed X-map
 constexpr int OWN_XP_BITS = 13;   // xp < 8192
 constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile (the ownership masks are u16)
@@ -59,15 +59,14 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const size_t cells16 = frame16_cells(tb);
   gp_i4 bounds = (gp_i4)((const XM_GLOBAL unsigned char*)frame16 + cols_bounds_offset(cells16));
   const XM_GLOBAL u32* thr = (const XM_GLOBAL u32*)((const XM_GLOBAL unsigned char*)frame16 + cols_thr_offset(cells16, tb.xmap_w));
-  const int HRp = tb.own_hrp, r_lo = tb.own_r_lo, NG = HRp >> 3;
-  // LDS carve-up (mirrored by own_lds_bytes() on the host): band slots [nxs_max][HRp] | extra slots [extra_max] | per 8-row
-  // group: first frame column of the band, and the same minus the frame's shear (what a cell's x is compared with) | masks [HRp]
+  const int HRp = tb.own_hrp, r_lo = tb.own_r_lo;
+  // LDS carve-up (mirrored by own_lds_bytes() on the host): band slots [nxs_max][HRp] | extra slots [extra_max] | per row: first
+  // frame column of the band, ownership mask
   u32* slots = reinterpret_cast<u32*>(smem);
   const int n_band_max = tb.own_nxs_max * HRp;
   u32* slots_x = slots + n_band_max;
-  int* s_base = reinterpret_cast<int*>(slots_x + tb.own_extra_max);
-  int* s_off = s_base + NG;
-  uint16_t* s_mask = reinterpret_cast<uint16_t*>(s_off + NG);
+  int16_t* s_base = reinterpret_cast<int16_t*>(slots_x + tb.own_extra_max);
+  uint16_t* s_mask = reinterpret_cast<uint16_t*>(s_base + HRp);
 
   const u32 tile = xcd_contiguous(blk, nblk);
   const int c0 = (int)tile * W;
@@ -95,12 +94,10 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     for (int i = tid; i < (nslots >> 2); i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);  // (HRp % 8 == 0)
     for (int i = tid; i < n_extra; i += nthreads) slots_x[i] = 0;
     const XM_GLOBAL uint16_t* gm = (const XM_GLOBAL uint16_t*)tb.own_masks + (size_t)tile * (size_t)HRp;
-    for (int i = tid; i < HRp; i += nthreads) s_mask[i] = gm[i];
-    const XM_GLOBAL int16_t* gb = (const XM_GLOBAL int16_t*)tb.own_base + (size_t)tile * (size_t)NG;
-    for (int i = tid; i < NG; i += nthreads) {
-      const int b = (int)gb[i];
-      s_base[i] = b;
-      s_off[i] = b - tb.shear_bias - ((((r_lo >> 3) + i) * tb.shear_m) >> 12);  // (r_lo % 8 == 0)
+    const XM_GLOBAL int16_t* gb = (const XM_GLOBAL int16_t*)tb.own_base + (size_t)tile * (size_t)HRp;
+    for (int i = tid; i < HRp; i += nthreads) {
+      s_mask[i] = gm[i];
+      s_base[i] = gb[i];
     }
   }
   if (tid == 0) {
@@ -244,7 +241,8 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       n_in += write && tl[k] < Wc ? 1u : 0u;  // counted by the tile whose own columns hold the event
       const int jo = tl[k] - delta;            // the cell's owner column, relative to c0
       write = write && (u32)jo < (u32)W;
-      const int sx = fc - s_off[(write ? rr[k] : 0) >> 3];  // the cell's column inside the band of its 8-row group
+      // the cell's column inside its row's band: its frame column (frame16_col) - the band's first
+      const int sx = fc + tb.shear_bias + ((((rr[k] + r_lo) >> 3) * tb.shear_m) >> 12) - (int)s_base[write ? rr[k] : 0];
       int idx = __mul24(sx, HRp) + rr[k];
       if (write && (u32)sx >= (u32)nxs) {  // an extra: its slot index comes from the second table, at the cell's OWNER pair
         const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)(c0 + jo), (u32)tb.xmap_h) + (u32)(rr[k] + r_lo)];
@@ -290,7 +288,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     for (int i = tid; i < nslots; i += nthreads) {
       const u32 v = slots[i];
       const u32 m = s_mask[r_i];
-      if ((m >> k) & 1u) base[__umul24((u32)(s_base[r_i >> 3] + k), (u32)tb.rect_h) + (u32)r_i] = (uint16_t)(v & 0xffffu);
+      if ((m >> k) & 1u) base[__umul24((u32)((int)s_base[r_i] + k), (u32)tb.rect_h) + (u32)r_i] = (uint16_t)(v & 0xffffu);
       r_i += dr;
       k += dk;
       if (r_i >= HRp) {

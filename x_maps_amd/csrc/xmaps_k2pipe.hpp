@@ -1,0 +1,257 @@
+// xmaps_k2pipe.hpp -- K2 (dilate o remap -> depth -> u8 -> Turbo BGR, disp_to_depth.py:7-97) for GROUPS of frames on the plain
+// u16 disparity frame of the column / owner tiles, as persistent, software-pipelined blocks.  (gfx950 / MI355X; included by
+// xmaps_hip.hip after xmaps_kernels.hpp)
+//
+// k_frame_proj_tiled_batch is one block per (tile, frame): a chain of dependent round trips -- frame descriptor + tile record ->
+// the tile's patch of the disparity frame -> (LDS work) -> the per-disparity table -> stores -- with 55 % of the block's lifetime
+// spent before the patch has arrived (tools/k2_timeline.py), at the CU's full complement of 32 waves: more waves cannot hide it.
+// Here a block walks a strided sequence of (frame, tile) items and keeps the NEXT item's patch in flight in registers while it
+// works on the current one:
+//   * the loads of item i + 1 (its 16-byte patch quads and the pixels' patch offsets) are issued right after item i's patch has
+//     been written to LDS, and nothing else of the iteration is a vector memory load: the per-disparity table {depth, BGR}
+//     (k_build_dlut) is copied into LDS once per block (its first n_lds entries; larger disparities -- rare -- read the global
+//     table), so no wait of the iteration has to drain the prefetch;
+//   * the tile's patch is written to LDS, reduced (7-tap maxima along the rows, in place) and sampled exactly as before
+//     (frame_proj_tiled_body, FMT = 2): same tables (k2_tiles / k2_pix), same arithmetic, same outputs;
+//   * patches that stick out of the frame load zeros for the octets outside (patch rows start on a multiple of 8 and so does
+//     the frame's height: an octet is inside or outside as a whole); a rig with a patch of more than 64 rows or 128 columns
+//     keeps the one-block-per-tile kernel (k2_pipe_tile_ok, checked once in xm_create).
+#pragma once
+#include "xmaps_kernels.hpp"
+
+namespace xm {
+
+constexpr int K2P_UN = 4;  // 16-byte patch loads per thread kept in registers (patches of <= 128 columns x <= 64 rows)
+
+// Can every tile of the rig take the pipelined kernel?  (decided once in xm_create from the tile table: patches of at most 64
+// rows and 128 columns, rows a multiple of 8 -- then every 8-row octet of a patch lies entirely inside or outside the frame)
+__host__ __device__ inline bool k2_pipe_tile_ok(const int4& rec) { return rec.z >= 0 && rec.w >= 0 && rec.w <= 64 && (rec.z << 3) <= K2P_UN * K2_TX * K2_TY; }
+
+// Barrier for LDS hand-offs only: __syncthreads() carries a workgroup-scope fence, for which the compiler drains EVERY outstanding
+// memory operation (s_waitcnt vmcnt(0)) -- including the next item's patch loads that are meant to stay in flight across it.
+// This one waits for the wave's LDS operations and joins the barrier; the prefetched registers are waited for where they are used.
+__device__ __forceinline__ void k2p_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct K2PipeArgs {  // (only what the loop needs: the whole DevTables would sit in scalar registers across it)
+  int proj_w, proj_h, rect_w, rect_h, shear_m, shear_bias;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XM_K2P_GLOBAL __attribute__((address_space(1)))
+#else
+#define XM_K2P_GLOBAL
+#endif
+
+template <int PPT>
+__global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDesc* __restrict__ descs, const int4* __restrict__ k2_tiles,
+                                                                const u32* __restrict__ k2_pix, const uint2* __restrict__ dlut,
+                                                                K2PipeArgs a, int tile_cap, u32 n_frames, u32 grid_x, u32 grid_y,
+                                                                int n_lds) {
+  // (the tables are kernel parameters of their own, __restrict__: block-uniform reads of them become scalar loads -- as members
+  //  of a struct they were vector loads, each with a full wait in front of the prefetch.  Pointers read from a frame descriptor
+  //  are cast to the global address space: generic ones make FLAT loads / stores, which count against the LDS counter too, and
+  //  every LDS wait would drain the prefetch.)
+  constexpr int NT = K2_TX * K2_TY, K2_TW = K2_TX * PPT;
+  extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
+  uint16_t* tile = k2_lds;                                                         // [tile_cap + 32]
+  uint2* s_dlut = reinterpret_cast<uint2*>(k2_lds + ((tile_cap + 32 + 7) & ~7));  // [n_lds] {f32 depth bits, BGR word}
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[K2_TY][K2_TW * 3];
+  const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
+  const u32 tpf = grid_x * grid_y;
+  for (int i = tid; i < n_lds; i += NT) s_dlut[i] = dlut[i];  // (n_lds covers every disparity of the rig; visible after the first barrier)
+
+  // ---- item = (frame, block-linear tile index); a block strides through them.  Per iteration: reduce + sample item 0's patch
+  //      (LDS), then move item 1's loads (in flight since the end of the previous iteration) from registers to LDS, then write
+  //      item 0's outputs, then issue item 2's loads.  The memory counter is in order and the compiler waits for "everything"
+  //      where item 1's registers are consumed: at that point the youngest outstanding operations are the previous iteration's
+  //      last loads and stores, one reduce + sample phase old -- nothing that was issued just now.
+  struct Meta {
+    int4 rec;
+    u32 f, lin;
+    bool run;
+  };
+  const auto meta_at = [&](u32 f, u32 b) {
+    Meta m;
+    m.f = f;
+    m.run = f < n_frames;
+    m.lin = xcd_contiguous(b, tpf);
+    m.rec = make_int4(0, 0, 0, 0);
+    if (m.run) {
+      m.rec = k2_tiles[m.lin];
+      m.run = descs[f].valid != 0;
+    }
+    return m;
+  };
+  const auto advance = [&](u32& f, u32& b) {
+    b += gridDim.x;
+    while (b >= tpf) {
+      b -= tpf;
+      f += 1;
+    }
+  };
+  uint4 K[K2P_UN];
+  // the item's vector loads: patch quads (thread slot s -> column s >> 3, row octet s & 7; an octet outside the frame is not
+  // loaded: it reads as zeros) and the pixels' offsets into the patch
+  const auto issue = [&](const Meta& m, u32 (&poff)[PPT]) {
+    const u32 tile_y = m.lin / grid_x, tile_x = m.lin - tile_y * grid_x;
+    const int v = tile_y * K2_TY + ty;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int u = tile_x * K2_TW + tx + j * K2_TX;
+      const bool in_img = u < a.proj_w && v < a.proj_h;
+      poff[j] = in_img ? k2_pix[__umul24((u32)v, (u32)a.proj_w) + (u32)u] : ~0u;
+    }
+    const XM_K2P_GLOBAL uint16_t* d16 = (const XM_K2P_GLOBAL uint16_t*)descs[m.f].key_frame;
+    const int bx = m.rec.x, by = m.rec.y, oct = m.rec.w >> 3, nslot = m.rec.z << 3;
+    const int g0 = by >> 3;
+#pragma unroll
+    for (int j = 0; j < K2P_UN; ++j) {
+      const int sj = tid + j * NT, c = sj >> 3, ro = sj & 7;
+      const int gx = bx + c, gy = by + 8 * ro;
+      const bool has = sj < nslot && ro < oct && (u32)gx < (u32)a.rect_w && (u32)gy < (u32)a.rect_h;  // (rect_h % 8 == 0)
+      K[j] = make_uint4(0, 0, 0, 0);
+      if (has)
+        K[j] = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(d16 + __umul24((u32)(gx + a.shear_bias + (((g0 + ro) * a.shear_m) >> 12)), (u32)a.rect_h) + (u32)gy);
+    }
+  };
+  const auto to_lds = [&](const Meta& m) {
+    const int oct = m.rec.w >> 3, nslot = m.rec.z << 3;
+#pragma unroll
+    for (int j = 0; j < K2P_UN; ++j) {
+      const int sj = tid + j * NT;
+      if (sj < nslot && (sj & 7) < oct) reinterpret_cast<uint4*>(tile)[__mul24(sj >> 3, oct) + (sj & 7)] = K[j];
+    }
+  };
+
+  u32 f = 0, b = blockIdx.x;
+  while (b >= tpf && f < n_frames) {
+    b -= tpf;
+    f += 1;
+  }
+  if (f >= n_frames) return;
+  u32 p0[PPT], p1[PPT];
+  Meta m0 = meta_at(f, b), m1;
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) p0[q] = p1[q] = ~0u;
+  if (m0.run) {
+    issue(m0, p1);
+    to_lds(m0);
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) p0[q] = p1[q];
+  advance(f, b);
+  m1 = meta_at(f, b);
+  if (m1.run) issue(m1, p1);
+  k2p_lds_barrier();
+  for (;;) {
+    uint2 e[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) e[q] = make_uint2(0u, 0u);
+    if (m0.run) {
+      const int cols = m0.rec.z, rows_p = m0.rec.w;
+      {  // 7-tap max along the rows of every patch column, in place (see frame_proj_tiled_body)
+        const int nseg = rows_p >> 3, tasks = cols * nseg;
+        constexpr int CH = 4;
+        for (int t0 = 0; t0 < tasks; t0 += CH * NT) {
+          uint4 w[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int t = t0 + j * NT + tid;
+            if (t < tasks)
+              w[j] = k2_rowmax8(*reinterpret_cast<const uint4*>(tile + t * 8), *reinterpret_cast<const uint4*>(tile + t * 8 + 8));
+          }
+          k2p_lds_barrier();
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int t = t0 + j * NT + tid;
+            if (t < tasks) *reinterpret_cast<uint4*>(tile + t * 8) = w[j];
+          }
+        }
+      }
+      k2p_lds_barrier();
+#pragma unroll
+      for (int q = 0; q < PPT; ++q) {
+        u32 best = 0;
+        if (p0[q] != ~0u) {
+          const uint16_t* p = tile + p0[q];
+#pragma unroll
+          for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
+        }
+        e[q] = s_dlut[min(best, (u32)(n_lds - 1))];
+      }
+    }
+    k2p_lds_barrier();  // every pixel has sampled the patch: the next one may take its place
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {  // (pinned HERE: sunk behind the stores below, the copy would wait for them -- the counter is in order)
+      p0[q] = p1[q];
+      asm volatile("" : "+v"(p0[q]));
+    }
+    if (m1.run) to_lds(m1);
+    if (m0.run) {  // item 0's outputs
+      const FrameDesc& d = descs[m0.f];
+      XM_K2P_GLOBAL float* depth = (XM_K2P_GLOBAL float*)d.depth;
+      XM_K2P_GLOBAL uint8_t* bgr = (XM_K2P_GLOBAL uint8_t*)d.bgr;
+      const u32 tile_y = m0.lin / grid_x, tile_x = m0.lin - tile_y * grid_x;
+      const int v = tile_y * K2_TY + ty;
+      if (m0.lin == 0 && tid < CNT_SLOTS) {  // re-arm the frame's next counters (as frame_proj_tiled_body)
+        XM_K2P_GLOBAL SlotState* st = (XM_K2P_GLOBAL SlotState*)d.st;
+        const u32 tag = st->tag_a;
+        XM_K2P_GLOBAL u32* c = st->cnt[(tag & 1) ^ 1][tid];
+        c[0] = c[1] = c[2] = c[3] = 0;
+        if (tid == 0) {
+          st->tag_b = tag;
+          if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
+        }
+      }
+      if (depth) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+          const int u = tile_x * K2_TW + tx + q * K2_TX;
+          if (u < a.proj_w && v < a.proj_h) depth[__umul24((u32)v, (u32)a.proj_w) + (u32)u] = __uint_as_float(e[q].x);
+        }
+      }
+      if (bgr) {
+        const bool full_rows = (a.proj_w & 3) == 0 && (tile_x + 1) * K2_TW <= (u32)a.proj_w;
+        if (full_rows) {
+#pragma unroll
+          for (int q = 0; q < PPT; ++q) {
+            s_out[ty][(tx + q * K2_TX) * 3 + 0] = (uint8_t)(e[q].y & 0xff);
+            s_out[ty][(tx + q * K2_TX) * 3 + 1] = (uint8_t)((e[q].y >> 8) & 0xff);
+            s_out[ty][(tx + q * K2_TX) * 3 + 2] = (uint8_t)((e[q].y >> 16) & 0xff);
+          }
+          k2p_lds_barrier();
+          constexpr int DW = K2_TW * 3 / 4;
+#pragma unroll
+          for (int i0 = 0; i0 < K2_TY * DW; i0 += NT) {
+            const int i = i0 + tid;
+            if (i < K2_TY * DW) {
+              const int r = i / DW, qq = i - r * DW, vv = tile_y * K2_TY + r;
+              if (vv < a.proj_h)
+                reinterpret_cast<XM_K2P_GLOBAL u32*>(bgr + (size_t)((__umul24((u32)vv, (u32)a.proj_w) + tile_x * K2_TW) * 3u))[qq] =
+                    reinterpret_cast<const u32*>(&s_out[r][0])[qq];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < PPT; ++q) {
+            const int u = tile_x * K2_TW + tx + q * K2_TX;
+            if (u < a.proj_w && v < a.proj_h) {
+              XM_K2P_GLOBAL uint8_t* bp = bgr + (u64)(__umul24((u32)v, (u32)a.proj_w) + (u32)u) * 3;
+              bp[0] = (uint8_t)(e[q].y & 0xff);
+              bp[1] = (uint8_t)((e[q].y >> 8) & 0xff);
+              bp[2] = (uint8_t)((e[q].y >> 16) & 0xff);
+            }
+          }
+        }
+      }
+    }
+    if (m1.f >= n_frames) break;  // (items are visited in order: nothing behind an item past the end)
+    m0 = m1;
+    advance(f, b);
+    m1 = meta_at(f, b);
+    if (m1.run) issue(m1, p1);  // in flight during the next item's reduce + sample phase
+    k2p_lds_barrier();          // the next patch is in LDS, the staging rows are free again
+  }
+}
+
+}  // namespace xm

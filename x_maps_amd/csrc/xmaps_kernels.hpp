@@ -60,13 +60,13 @@ struct DevTables {
   float z_near, z_far;
   // owner tiles (xmaps_k1own.hpp; rigs whose (row, time column) -> cell map is not injective): the X-map once more with the
   // distance to the cell's owner column in the top bits; per tile {columns of its cell band, first extra, extras}; per (tile,
-  // 8-row group) the band's first frame column; per (tile, row) the mask of the band cells the tile owns; cells outside the
+  // row) the band's first frame column and the mask of the band cells the tile owns; cells outside the
   // band ("extras") have a slot index in xmap_extra (at their owner pair) and their frame cell in own_extra_cells.  The rows
   // the rectify LUT can reach: own_hr rows from own_r_lo (a multiple of 8) on, padded to own_hrp (a multiple of 8)
   const uint16_t* xmap_own;     // [xmap_w][xmap_h]  xp | delta << 13, 0 = undefined
   const uint16_t* xmap_extra;   // [xmap_w][xmap_h]  extra slot + 1 at the owner pair of a cell outside its tile's band, else 0
   const int4* own_tiles;        // [tiles] {band columns, first extra, extras, 0}
-  const int16_t* own_base;      // [tiles][own_hrp / 8]
+  const int16_t* own_base;      // [tiles][own_hrp]  first frame column of the row's band
   const uint16_t* own_masks;    // [tiles][own_hrp]
   const u32* own_extra_cells;   // [extras] cell index in the (sheared) u16 frame
   int own_r_lo, own_hr, own_hrp, own_nxs_max, own_extra_max;
