@@ -82,6 +82,8 @@ def parse_args():
     ap.add_argument("--general", action="store_true", help="XM_FLAG_GENERAL: extrema pass K0 on every frame")
     ap.add_argument("--assume-sorted", action="store_true",
                     help="XM_FLAG_TIME_SORTED: extrema = t[0], t[n-1], verified on the device, violations reported")
+    ap.add_argument("--no-adaptive", action="store_true",
+                    help="one frame per call WITHOUT XM_FLAG_ADAPTIVE_BATCH (every frame its own three launches, 4 in flight)")
     ap.add_argument("--no-launch-workers", action="store_true",
                     help="launch from the calling thread (default: XM_FLAG_LAUNCH_WORKERS, one launch thread per slot stream -- the "
                          "two kernel launches of a frame cost a Python caller ~10 us, about what the GPU needs for the frame)")
@@ -367,11 +369,13 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     tables = S.make_tables(cfg)
     camera = args.camera_perspective
     B = args.batch
-    slots = args.slots or (max(4, args.groups_in_flight * B) if B else 4)
+    adaptive = not B and not args.no_adaptive  # one frame per call: frames that arrive while the GPU is busy go out as groups
+    slots = args.slots or (max(4, args.groups_in_flight * B) if B else (64 if adaptive else 4))
     mode_kw = {"force_general": args.general, "assume_time_sorted": args.assume_sorted}
-    # groups are launched by the calling thread (three launches per GROUP); the one-frame-per-call mode uses the launch workers
-    eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots,
-                      launch_workers=(not args.no_launch_workers) and not B, **mode_kw)
+    # groups are launched by the calling thread (three launches per GROUP); one frame per call without adaptive batching uses the
+    # launch workers
+    eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots, adaptive_batch=adaptive,
+                      launch_workers=(not args.no_launch_workers) and not B and not adaptive, **mode_kw)
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 
@@ -518,7 +522,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         other_modes = {}
         modes = []  # (name, engine flags, camera view, frames per call, launch workers)
         if B:
-            modes.append(("one_frame_per_call", dict(mode_kw), camera, 0, not args.no_launch_workers))
+            modes.append(("one_frame_per_call", dict(mode_kw, adaptive_batch=True), camera, 0, False))
+            modes.append(("one_frame_per_call_eager", dict(mode_kw), camera, 0, not args.no_launch_workers))
         else:
             modes.append(("groups_of_32_frames_per_call", dict(mode_kw), camera, 32, False))
             if not args.no_launch_workers:
@@ -529,7 +534,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         if not camera:
             modes.append(("camera_view", dict(mode_kw), True, B, (not args.no_launch_workers) and not B))
         for name, kw, cam, Bm, workers in modes:
-            nsl = max(4, args.groups_in_flight * Bm) if Bm else 4
+            nsl = max(4, args.groups_in_flight * Bm) if Bm else (64 if kw.get("adaptive_batch") else 4)
             e2 = XMapsEngine(tables, camera_perspective=cam, device=local_rank, n_slots=nsl, launch_workers=workers, **kw)
             H2, W2 = e2.out_h, e2.out_w
             d2 = torch.empty((nsl, H2, W2), dtype=torch.float32, device=dev)
@@ -556,7 +561,10 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             if same is not None:
                 other_modes[name]["depth_equals_oracle"] = same
             e2.close()
-        other_modes["note"] = ("one_frame_per_call = every frame through its own asynchronous call (xm_process_frame, 4 frames in "
+        other_modes["note"] = ("one_frame_per_call = every frame through its own asynchronous call (xm_process_frame) with "
+                               "XM_FLAG_ADAPTIVE_BATCH: a frame that arrives while two groups are in flight is held back and goes out "
+                               "with the frames behind it as one set of multi-frame launches (64 slots: groups of up to 16; an idle GPU launches at once); "
+                               "one_frame_per_call_eager = the same calls without the flag (three launches per frame, 4 frames in "
                                "flight, a launch thread per slot stream): round 2's headline mode; forced_general = "
                                "XM_FLAG_GENERAL (extrema pass K0 + 64-bit packed keys on every frame, one frame per call: round 1's "
                                "headline mode); camera_view = --camera-perspective; `value` above = library defaults, groups of "
@@ -626,8 +634,9 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
                    "outputs": "depth f32" + ("" if bgr_out is None else " + BGR u8"),
                    "launch": (f"eager; a step = one group of {B} frames through ONE call (xm_process_batch: one set of multi-frame "
                               f"launches, grid = frames x tiles), {slots // B} groups in flight, launches from the calling thread"
-                              if B else "eager, one frame per call"
-                              + ("" if args.no_launch_workers else "; XM_FLAG_LAUNCH_WORKERS (a launch thread per slot stream)")),
+                              if B else ("one frame per call, XM_FLAG_ADAPTIVE_BATCH (frames arriving while the GPU is busy are submitted as groups)"
+                                         if adaptive else "eager, one frame per call"
+                                         + ("" if args.no_launch_workers else "; XM_FLAG_LAUNCH_WORKERS (a launch thread per slot stream)"))),
                    "inputs": "SoA x:u16 y:u16 t:i64 resident in HBM",
                    "distinct_frames_resident": nf, "resident_set_MB": round(resident_mb, 1),
                    "resident_set_vs_infinity_cache": "exceeds the 256 MiB MALL" if resident_mb > 268.4 else "fits the 256 MiB MALL",

@@ -1,0 +1,79 @@
+"""-m gpu: XM_FLAG_ADAPTIVE_BATCH -- asynchronous one-frame-per-call submissions (xm_process_frame on device pointers, what an
+offline replay issues back to back) are grouped into multi-frame launches whenever the GPU is still busy with earlier frames, and
+launched at once when it is not.  Whatever the grouping turns out to be, every frame's outputs must equal the oracle's after
+xm_sync(); frames that fail the sorted-order verification are redone; synchronous calls in between flush what is held back."""
+import numpy as np
+import pytest
+
+import xmaps_oracle as O
+from x_maps_amd import XMapsEngine
+from x_maps_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _ref(tb, evs, **kw):
+    x, y, t, _ = S.to_soa(evs)
+    return O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, **kw)
+
+
+def _upload(evs, dev):
+    x, y, t, _ = S.to_soa(evs)
+    return (torch.from_numpy(x.view(np.int16)).to(dev), torch.from_numpy(y.view(np.int16)).to(dev), torch.from_numpy(t).to(dev))
+
+
+@pytest.mark.parametrize("camera", [False, True])
+def test_frames_submitted_back_to_back_equal_the_oracle(camera):
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    F = 40
+    host = [S.make_events(cfg, frame=f % 5, n=300_000 + 50_000 * (f % 3)) for f in range(F)]
+    host[7] = host[7][::-1].copy()  # one frame is not sorted: its tiles object, it is redone on the general path
+    refs = {f: _ref(tb, host[f], camera_perspective=camera) for f in (0, 1, 7, 8, 23, F - 1)}
+    up = [_upload(e, dev) for e in host]
+    H, W = (cfg.cam_h, cfg.cam_w) if camera else (cfg.proj_h, cfg.proj_w)
+    depth = torch.zeros((F, H, W), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((F, H, W, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb, camera_perspective=camera, n_slots=F, adaptive_batch=True) as eng:
+        for rep in range(2):
+            for f in range(F):
+                x, y, t = up[f]
+                eng.process_frame_device(x.data_ptr(), y.data_ptr(), t.data_ptr(), None, len(host[f]), depth[f].data_ptr(), bgr[f].data_ptr())
+            eng.sync()
+            for f, r in refs.items():
+                assert np.array_equal(depth[f].cpu().numpy(), r["depth"]), (rep, f)
+                assert np.array_equal(bgr[f].cpu().numpy(), r["bgr"]), (rep, f)
+            depth.zero_()
+            bgr.zero_()
+            torch.cuda.synchronize()
+        assert eng.sorted_fallbacks() == 2  # frame 7, once per repetition
+        pc = eng.path_counts()
+        assert sum(pc.values()) >= 2 * F  # every frame went through some K1 (redone frames count twice)
+
+
+def test_a_synchronous_call_flushes_what_is_held_back_and_few_slots_switch_it_off():
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    frames = [S.make_events(cfg, frame=f, n=20_000) for f in range(12)]
+    up = [_upload(e, dev) for e in frames]
+    depth = torch.zeros((12, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    for slots in (8, 4):  # (4 slots: the flag is ignored, every frame is launched at once)
+        with XMapsEngine(tb, n_slots=slots, adaptive_batch=True) as eng:
+            for f in range(12):
+                x, y, t = up[f]
+                eng.process_frame_device(x.data_ptr(), y.data_ptr(), t.data_ptr(), None, len(frames[f]), depth[f].data_ptr(), None)
+                if f == 5:  # a synchronous host-memory frame in the middle: everything before it has been submitted when it returns
+                    d, b, st = eng.process_events(frames[0])
+                    assert np.array_equal(d, _ref(tb, frames[0])["depth"])
+            st = eng.last_frame_stats()  # (flushes, waits for the last frame)
+            assert st.n_inliers == int(_ref(tb, frames[11])["mask"].sum())
+            eng.sync()
+            for f in (0, 4, 5, 6, 11):
+                assert np.array_equal(depth[f].cpu().numpy(), _ref(tb, frames[f])["depth"]), (slots, f)
+        depth.zero_()
+        torch.cuda.synchronize()

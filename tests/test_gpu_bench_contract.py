@@ -44,9 +44,14 @@ def test_default_line_as_the_driver_calls_it():
 
 
 def test_one_frame_per_call_mode_still_prints_the_line():
-    d = _run("--batch", "0", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
+    # without adaptive batching every frame is three launches of its own (compact key frame for lone C-1M frames)
+    d = _run("--batch", "0", "--no-adaptive", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
     assert d["config"]["frames_per_step"] == 1 and d["roofline"]["frames_per_launch"] == 1 and d["value"] > 1000
     assert d["parity"]["depth_bit_exact"] and d["config"]["k1_paths_frames"]["key32"] > 0
+    # with it (the default of --batch 0) frames that arrive while the GPU is busy go out as groups: the column tiles
+    d = _run("--batch", "0", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
+    assert d["config"]["frames_per_step"] == 1 and d["value"] > 1000 and "ADAPTIVE" in d["config"]["launch"]
+    assert d["parity"]["depth_bit_exact"] and d["config"]["k1_paths_frames"]["cols"] > 0
 
 
 @pytest.mark.parametrize("flags,workload", [(("--graph", "--steps", "60"), "C-60x1M"), (("--sharded", "--steps", "10"), "C-10M"),
@@ -86,7 +91,7 @@ def _check_roofline(r):
 
 
 def test_default_and_single_frame_lines_carry_the_three_fractions():
-    for flags in (("--steps", "20", "--warmup", "5"), ("--batch", "0", "--steps", "40", "--warmup", "5")):
+    for flags in (("--steps", "20", "--warmup", "5"), ("--batch", "0", "--no-adaptive", "--steps", "40", "--warmup", "5")):
         d = _run(*flags, "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
         _check_roofline(d["roofline"])
 

@@ -25,6 +25,7 @@ XM_FLAG_TRY_SORTED = 2
 XM_FLAG_DEFAULT_STREAMS = 4
 XM_FLAG_LAUNCH_WORKERS = 8
 XM_FLAG_GENERAL = 16
+XM_FLAG_ADAPTIVE_BATCH = 32
 XM_VIEW_PROJECTOR, XM_VIEW_CAMERA = 0, 1
 XM_MEM_HOST, XM_MEM_DEVICE, XM_MEM_HOST_PINNED = 0, 1, 2
 XM_T_INT64, XM_T_FLOAT32, XM_T_FLOAT64 = 0, 1, 2

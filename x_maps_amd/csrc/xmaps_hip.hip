@@ -212,6 +212,19 @@ struct xm_handle {
   uint16_t* d_own_masks = nullptr;
   u32* d_own_extra_cells = nullptr;
   int own_extras = 0;  // owner cells outside their tile's band, over all tiles
+  // XM_FLAG_ADAPTIVE_BATCH: asynchronous device-pointer frames are submitted as GROUPS (multi-frame launches) whenever the GPU
+  // is still busy with earlier ones: a frame is launched at once while fewer than three groups are in flight (an idle GPU -- the
+  // 60 Hz live case -- never waits), otherwise it joins the pending list, which goes out as one group when a group in flight
+  // has finished, when it holds ab_max = n_slots / 4 frames, or at the next synchronising call
+  struct Deferred {
+    EventsView ev;
+    float* depth;
+    uint8_t* bgr;
+  };
+  std::vector<Deferred> pending;
+  int ab_max = 0;                                  // 0: off
+  hipEvent_t ab_inflight[4] = {nullptr, nullptr, nullptr, nullptr};  // end-of-group events of the last four groups submitted this way
+  uint64_t ab_groups = 0, ab_frames = 0;
   std::atomic<uint64_t> path_counts[4] = {};  // frames enqueued per K1 variant (xm_path_counts)
   // (atomics: with XM_FLAG_LAUNCH_WORKERS the launch threads and the API thread all pass through enqueue_frame)
   std::atomic<int> key32_score{0};  // raised by frames that failed the compact path, decays with every frame that took it
@@ -252,6 +265,8 @@ struct xm_graph {
   std::vector<FrameDesc> h_descs;  // batched capture: the frames' descriptors (static for the graph's lifetime)
   FrameDesc* d_descs = nullptr;
 };
+
+int flush_pending(xm_handle* h);  // XM_FLAG_ADAPTIVE_BATCH: submit the frames held back (defined beside xm_process_batch)
 
 int xm_handle::ensure_lds(const void* fn, size_t bytes) {
   std::lock_guard<std::mutex> lk(lds_mu);
@@ -1375,8 +1390,9 @@ int drain_workers(xm_handle* h, int only = -1) {
 #define XM_ENTER(h)                          \
   do {                                       \
     HIP_TRY(hipSetDevice((h)->cfg.device));  \
-    const int rc_enter_ = drain_workers(h);  \
+    int rc_enter_ = drain_workers(h);        \
     if (rc_enter_) return rc_enter_;         \
+    if (!(h)->pending.empty() && (rc_enter_ = flush_pending(h))) return rc_enter_;  \
   } while (0)
 
 #ifndef XM_POLL_FIRST_US
@@ -1445,6 +1461,16 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
   int rc = check_events(ev);
   if (rc) return rc;
   const size_t px = (size_t)h->out_w * h->out_h;
+  if (h->ab_max >= 2 && mem == XM_MEM_DEVICE && !profile && !h->capturing && !stats) {  // adaptive batching (see xm_handle::pending)
+    h->pending.push_back(xm_handle::Deferred{ev, depth_out, bgr_out});
+    int in_flight = 0;
+    for (hipEvent_t e : h->ab_inflight)
+      if (e && hipEventQuery(e) == hipErrorNotReady) in_flight += 1;
+    (void)hipGetLastError();
+    if ((int)h->pending.size() >= h->ab_max || in_flight < 3) return flush_pending(h);
+    return XM_OK;
+  }
+  if (!h->pending.empty() && (rc = flush_pending(h))) return rc;  // (a synchronous / host-memory call behind deferred frames)
   Slot& s = profile ? h->slots[0] : pick_slot(h);
   if (profile) h->last_slot = 0;
   if ((rc = resolve_prev(h, s))) return rc;
@@ -1638,6 +1664,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->try_sorted = !h->time_sorted && !(cfg->flags & XM_FLAG_GENERAL) && !(eg && eg[0] == '1');
   if (const char* e = getenv("XM_GATE_SLOTS")) h->gate_slots = e[0] != '0';
   h->cfg.xmap_height = xmap_h;
+  if ((cfg->flags & XM_FLAG_ADAPTIVE_BATCH) && n_slots >= 8) h->ab_max = std::min(n_slots / 4, 32);  // (four groups' worth of slots)
 
 #define XM_TRY_CREATE(expr)                   \
   do {                                        \
@@ -2242,6 +2269,9 @@ int xm_profile_event_overhead(xm_handle* h, int reps, float* ms_out) {
 }
 
 // ---- a group of frames in one set of multi-frame launches ---------------------------------------------------
+static int submit_group(xm_handle* h, const std::vector<EventsView>& evs, const std::vector<float*>& dep, const std::vector<uint8_t*>& bg,
+                        float* gpu_ms, hipEvent_t* done_out = nullptr);
+
 static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
                               const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out, float* gpu_ms,
                               const void* aos = nullptr) {
@@ -2251,7 +2281,6 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
   XM_ENTER(h);
   const size_t px = (size_t)h->out_w * h->out_h;
   const size_t tsz = t_size(t_dtype);
-  std::vector<int> idx(n_frames);
   std::vector<EventsView> evs(n_frames);
   std::vector<float*> dep(n_frames);
   std::vector<uint8_t*> bg(n_frames);
@@ -2272,6 +2301,14 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
     dep[f] = depth_out ? depth_out + f * px : nullptr;
     bg[f] = bgr_out ? bgr_out + f * px * 3 : nullptr;
   }
+  return submit_group(h, evs, dep, bg, gpu_ms);
+}
+
+// frames evs[f] -> outputs dep[f] / bg[f] (device pointers) as ONE group on the next n slots: one set of multi-frame launches
+static int submit_group(xm_handle* h, const std::vector<EventsView>& evs, const std::vector<float*>& dep, const std::vector<uint8_t*>& bg,
+                        float* gpu_ms, hipEvent_t* done_out) {
+  const int n_frames = (int)evs.size(), ns = (int)h->slots.size();
+  std::vector<int> idx(n_frames);
   for (int f = 0; f < n_frames; ++f) {
     idx[f] = (h->next_slot + f) % ns;
     int rc = resolve_prev(h, h->slots[idx[f]]);  // try-sorted verdict of the slot's previous frame (may redo it)
@@ -2296,6 +2333,7 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
   h->desc_used[k] = true;
   hipEvent_t done = h->batch_ev[si][h->batch_ev_next[si]++ % 8];
   HIP_TRY(hipEventRecord(done, stream));
+  if (done_out) *done_out = done;
   for (int f = 0; f < n_frames; ++f) {
     Slot& s = h->slots[idx[f]];
     s.pending_batch_ev = done;
@@ -2323,6 +2361,32 @@ static int process_batch_impl(xm_handle* h, const uint16_t* x, const uint16_t* y
   }
   return XM_OK;
 }
+
+}  // extern "C"
+
+// XM_FLAG_ADAPTIVE_BATCH: everything on the pending list goes out as one group (at most ab_max = n_slots / 4 frames)
+int flush_pending(xm_handle* h) {
+  if (h->pending.empty()) return XM_OK;
+  const size_t n = h->pending.size();
+  std::vector<EventsView> evs(n);
+  std::vector<float*> dep(n);
+  std::vector<uint8_t*> bg(n);
+  for (size_t i = 0; i < n; ++i) {
+    evs[i] = h->pending[i].ev;
+    dep[i] = h->pending[i].depth;
+    bg[i] = h->pending[i].bgr;
+  }
+  h->pending.clear();  // (first: submit_group's callees pass through XM_ENTER-free paths only, but keep re-entry harmless)
+  hipEvent_t done = nullptr;
+  int rc = submit_group(h, evs, dep, bg, nullptr, &done);
+  if (rc) return rc;
+  h->ab_inflight[h->ab_groups & 3] = done;
+  h->ab_groups += 1;
+  h->ab_frames += n;
+  return XM_OK;
+}
+
+extern "C" {
 
 int xm_process_batch(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, int t_dtype,
                      const uint64_t* offsets_host, int n_frames, float* depth_out, uint8_t* bgr_out) {

@@ -72,7 +72,7 @@ class XMapsEngine:
 
     def __init__(self, tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1,
                  assume_time_sorted: bool = False, try_sorted: bool = True, default_priority_streams: bool = False,
-                 launch_workers: bool = False, force_general: bool = False):
+                 launch_workers: bool = False, force_general: bool = False, adaptive_batch: bool = False):
         """Extrema of t: by default the verified (t[0], t[n-1]) shortcut with automatic redo (exact for any order, the
         library's default); force_general=True (or try_sorted=False) runs the extrema pass K0 on every frame;
         assume_time_sorted=True declares the frames sorted (verified, reported instead of redone for asynchronous calls)."""
@@ -101,7 +101,8 @@ class XMapsEngine:
         cfg.flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0)
                      | (N.XM_FLAG_GENERAL if (force_general or not try_sorted) else 0)
                      | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0)
-                     | (N.XM_FLAG_LAUNCH_WORKERS if launch_workers else 0))
+                     | (N.XM_FLAG_LAUNCH_WORKERS if launch_workers else 0)
+                     | (N.XM_FLAG_ADAPTIVE_BATCH if adaptive_batch else 0))
         cfg.p03 = float(tables["p03"])
         self.p03 = cfg.p03
         cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
