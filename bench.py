@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--sharded", action="store_true", help="config 4: C-10M sharded by event index over the ranks (RCCL)")
     ap.add_argument("--esl", action="store_true",
                     help="configs 1/3 stand-in: ESL-like frames (real calibration geometry, ~150 k events, projector 1080x1920)")
-    ap.add_argument("--merge", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
+    ap.add_argument("--merge", choices=("all_reduce", "reduce_scatter", "bands"), default="all_reduce",
                     help="--sharded: how the shards' key frames are merged (x_maps_amd/sharded.py)")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
@@ -1131,7 +1131,7 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         setattr(proc, k, timed(f))
     # ... and the shard's three kernels the same way (K0 extrema of the shard, K1 scatter with global event indices, K2 on the
     # merged key frame): torch events on the engine's stream, which is torch's current stream inside process_shard
-    k_pairs = {"minmax_into": [], "scatter": [], "finish": [], "finish_u16": []}
+    k_pairs = {"minmax_into": [], "scatter": [], "finish": [], "finish_u16": [], "finish_u16_band": []}
     p_orig = {k: getattr(prov, k) for k in k_pairs}
 
     def timed_k(name, fn):
@@ -1153,8 +1153,10 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     for k, f in p_orig.items():
         setattr(prov, k, f)
     k_ms = [float(np.median([e0.elapsed_time(e1) for e0, e1 in k_pairs[k]])) if k_pairs[k] else 0.0
-            for k in ("minmax_into", "scatter", "finish" if args.merge == "all_reduce" else "finish_u16")]
-    per_frame = 2 if args.merge == "all_reduce" else 3  # extrema + key frame | extrema + reduce-scatter + all-gather
+            for k in ("minmax_into", "scatter", {"all_reduce": "finish", "reduce_scatter": "finish_u16", "bands": "finish_u16_band"}[args.merge])]
+    # extrema + key frame | extrema + reduce-scatter + all-gather | extrema + reduce-scatter + depth + BGR (the halo exchange is
+    # point to point and not timed here)
+    per_frame = {"all_reduce": 2, "reduce_scatter": 3, "bands": 3 if args.no_bgr else 4}[args.merge]
     coll = np.array([e0.elapsed_time(e1) for e0, e1 in ev_pairs]).reshape(-1, per_frame)
     coll_ms = torch.tensor([float(np.median(coll[:, 0])), float(np.median(coll[:, 1:].sum(axis=1)))], dtype=torch.float64, device=dev)
     if world > 1:
@@ -1197,7 +1199,10 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                    "merge": args.merge,
                    "collectives_per_frame": ["all_reduce MIN int64[2] (frame extrema)"] +
                                             (["all_reduce MAX int64[key frame]"] if args.merge == "all_reduce" else
-                                             ["reduce_scatter MAX int64[key frame]", "all_gather u16[key frame] (decoded disparities)"])},
+                                             ["reduce_scatter MAX int64[key frame]", "all_gather u16[key frame] (decoded disparities)"]
+                                             if args.merge == "reduce_scatter" else
+                                             ["reduce_scatter MAX int64[key frame]", "send / recv of the band's halos (neighbours)",
+                                              "all_reduce MAX of the partial projector frames (depth as int32, BGR u8)"])},
         "collective_ms": {"extrema_min_all_reduce": round(float(coll_ms[0]), 4), "key_frame_merge": round(float(coll_ms[1]), 4),
                           "note": "median over 20 frames, torch events on the engine's stream around each all-reduce, max over ranks; "
                                   "with one rank RCCL still runs its kernels (always_reduce) but nothing crosses xGMI"},

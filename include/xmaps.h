@@ -321,6 +321,14 @@ int xm_shard_finish(xm_handle* h, const uint64_t* key_frame, uint32_t tag, float
  * instead of (W-1)/W * 16.  All asynchronous on slot 0's stream. */
 int xm_shard_decode_u16(xm_handle* h, const uint64_t* key_cells, size_t n_cells, uint32_t tag, uint16_t* disp_out);
 int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_out, uint8_t* bgr_out);
+/* Band-sharded finish ("reduce-scatter by bands + halo, K2 band-sharded, gather the projector frame"): after the
+ * reduce-scatter a rank holds the merged disparities of a band of frame columns; with a halo of xm_k2_patch_cols_max() columns
+ * from either neighbour it can finish every projector tile whose patch is centred on one of its columns [col_lo, col_hi).
+ * disp_frame is a full-size u16 frame ([rect_w][rect_h], column-major) of which only the band and its halos need to be valid;
+ * depth_out / bgr_out are full-size projector frames: pixels of other ranks' tiles are left as they were (zero them first; a MAX
+ * all-reduce over the ranks -- depth >= 0, an owner's BGR >= the zeros of the others -- assembles the frame).  Projector view. */
+int xm_shard_finish_u16_band(xm_handle* h, const uint16_t* disp_frame, int col_lo, int col_hi, float* depth_out, uint8_t* bgr_out);
+int xm_k2_patch_cols_max(xm_handle* h, int* cols_out);
 /* the stream the shard calls run on (hipStream_t as void*), so the caller can order its collective */
 void* xm_stream(xm_handle* h, int slot);
 

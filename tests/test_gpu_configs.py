@@ -304,6 +304,59 @@ def test_config4_reduce_scatter_merge_on_one_gpu(c10m, world):
         assert np.array_equal(depth.cpu().numpy(), ref["depth"]) and np.array_equal(bgr.cpu().numpy(), ref["bgr"])
 
 
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_config4_band_sharded_finish_on_one_gpu(c10m, world):
+    """merge = "bands" with every rank played by one GPU: rank r holds the merged u16 disparities of its chunk of frame columns
+    plus a halo of k2_patch_cols_max + 1 columns from either neighbour (everything else of its frame buffer is POISONED here),
+    finishes the projector tiles centred on its band into a zeroed output, and the element-wise maximum of the ranks' partial
+    frames must be the oracle's frame: every tile has exactly one owner, and an owner sees every cell its tiles read."""
+    import torch
+    cfg, tb, (x, y, t), ref = c10m
+    dev = torch.device("cuda", 0)
+    X, Y, T = (torch.from_numpy(a).to(dev) for a in (x.view(np.int16), y.view(np.int16), t))
+    n = len(t)
+    with XMapsEngine(tb) as eng:
+        stream = torch.cuda.ExternalStream(eng.stream(0), device=dev)
+        rect_w, rect_h = eng.key_shape
+        cells = rect_w * rect_h
+        padded = (cells + world - 1) // world * world
+        C = padded // world
+        halo = eng.k2_patch_cols_max() + 1
+        assert 0 < halo and halo * rect_h <= C
+        Hc = halo * rect_h
+        kf = torch.zeros(padded, dtype=torch.int64, device=dev)
+        mm = torch.zeros(2, dtype=torch.int64, device=dev)
+        u16 = torch.zeros(padded, dtype=torch.int16, device=dev)
+        acc_d = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.int32, device=dev)
+        acc_b = torch.zeros((cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        tag = 3
+        with torch.cuda.stream(stream):
+            eng.shard_minmax_device(T.data_ptr(), None, n, mm.data_ptr())
+            eng.shard_scatter_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, n, 0, mm.data_ptr(), tag, kf.data_ptr())
+            eng.shard_decode_u16(kf.data_ptr(), padded, tag, u16.data_ptr())  # the merged frame (what the reduce-scatter leaves, chunk by chunk)
+        eng.sync()
+        torch.cuda.synchronize()
+        for r in range(world):
+            full = torch.full((padded,), 0x7777, dtype=torch.int16, device=dev)  # poison: a cell the rank was not given must not be read
+            a, b = max(r * C - Hc, 0), min((r + 1) * C + Hc, padded)
+            full[a:b] = u16[a:b]
+            lo = -(-(r * C) // rect_h)
+            hi = min(-(-((r + 1) * C) // rect_h), rect_w) if r < world - 1 else rect_w
+            d = torch.zeros((cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+            bg = torch.zeros((cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                eng.shard_finish_u16_band(full.data_ptr(), lo, hi, d.data_ptr(), bg.data_ptr())
+            eng.sync()
+            torch.cuda.synchronize()
+            # every pixel is written by exactly one rank: no overlap with what earlier ranks produced
+            assert not bool(((acc_b.amax(dim=-1) > 0) & (bg.amax(dim=-1) > 0)).any()), r
+            torch.maximum(acc_d, d.view(torch.int32), out=acc_d)
+            torch.maximum(acc_b, bg, out=acc_b)
+        assert np.array_equal(acc_d.view(torch.float32).cpu().numpy(), ref["depth"]) and np.array_equal(acc_b.cpu().numpy(), ref["bgr"])
+
+
 @pytest.mark.parametrize("camera", [False, True])
 def test_reduce_scatter_merge_through_the_processor_over_rccl(camera, tmp_path):
     """ShardedFrameProcessor(merge="reduce_scatter") over a real RCCL group (one rank here, the collectives are issued all the
@@ -321,8 +374,11 @@ def test_reduce_scatter_merge_through_the_processor_over_rccl(camera, tmp_path):
         created = True
     try:
         with XMapsEngine(tb, camera_perspective=camera) as eng:
-            proc = ShardedFrameProcessor(GpuShardProvider(eng, dev), dist, always_reduce=True, merge="reduce_scatter")
-            for f in range(3):
+            procs = [ShardedFrameProcessor(GpuShardProvider(eng, dev), dist, always_reduce=True, merge="reduce_scatter")]
+            if not camera:  # ... and the band-sharded finish (one rank: one band, no halo exchange; the outputs are MAX-reduced all the same)
+                procs.append(ShardedFrameProcessor(GpuShardProvider(eng, dev), dist, always_reduce=True, merge="bands"))
+            for proc in procs:
+              for f in range(3):
                 evs = S.make_events(cfg, frame=60 + f, n=2500 + 400 * f, shuffled=(f == 1))
                 sh = _soa_dev(torch, evs, dev) + (None,)
                 torch.cuda.synchronize()
@@ -331,8 +387,8 @@ def test_reduce_scatter_merge_through_the_processor_over_rccl(camera, tmp_path):
                 torch.cuda.synchronize()
                 x, y, t, _ = S.to_soa(evs)
                 r = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
-                assert np.array_equal(depth.cpu().numpy(), r["depth"]) and np.array_equal(bgr.cpu().numpy(), r["bgr"]), f
-            assert proc.collectives_issued == 3 * 3
+                assert np.array_equal(depth.cpu().numpy(), r["depth"]) and np.array_equal(bgr.cpu().numpy(), r["bgr"]), (proc.merge, f)
+              assert proc.collectives_issued == 3 * (4 if proc.merge == "bands" else 3), proc.merge  # bands: extrema, reduce-scatter, depth, BGR
     finally:
         if created:
             dist.destroy_process_group()

@@ -45,6 +45,26 @@ class OracleShardProvider:
         bgr = O.generate_color_map(O.clip_normalize_uint8_depth_frame(depth, self.tb["z_near"], self.tb["z_far"]))
         return depth, bgr
 
+    # ---- merge = "bands": this stand-in's frame is row-major, so its bands are bands of frame ROWS; a pixel belongs to the band
+    #      that holds its map target's row (pixels mapped outside the frame go with row 0), and needs 3 rows of halo (7 x 7 dilate)
+    def frame_lines(self):
+        return self.shape
+
+    def halo_lines(self):
+        return -1 if self.camera else 4
+
+    def finish_u16_band(self, disp_frame, lo, hi, want_bgr=True):
+        O = self.O
+        depth, bgr = self.finish_u16(disp_frame, want_bgr)
+        m = self.tb["disp_proj_mapxy_i16"]
+        my, mx = m[..., 1].astype(np.int64), m[..., 0].astype(np.int64)
+        inside = (mx >= 0) & (mx < self.tb["rect_w"]) & (my >= 0) & (my < self.tb["rect_h"])
+        line = np.where(inside, my, 0)
+        own = (line >= lo) & (line < hi)
+        depth = torch.from_numpy(np.where(own, depth, np.float32(0.0)).astype(np.float32))
+        bgr = torch.from_numpy(np.where(own[..., None], bgr, np.uint8(0)).astype(np.uint8))
+        return depth, bgr
+
     def clear_key_frame(self, kf):
         kf.zero_()
 
@@ -102,16 +122,17 @@ def _worker(rank, world, port, camera, out_dir, merge, uneven=False):
     from x_maps_amd.sharded import ShardedFrameProcessor, shard_bounds
     tb = S.make_tables(S.C_TINY)
     proc = ShardedFrameProcessor(OracleShardProvider(tb, camera), dist, merge=merge)
+    assert merge != "bands" or camera or proc._bands_ok()  # (the camera view has no band finish: it falls back to the all-gather)
     for frame, n in ((0, 4000), (1, 2501), (2, 1)):  # incl. an odd split and a frame with an EMPTY shard
         evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(frame == 1))
         x, y, t, _ = S.to_soa(evs)
         a, b = _cuts(n, world, uneven)[rank]
         depth, bgr = proc.process_shard((x[a:b], y[a:b], t[a:b], None), a)
-        np.savez(os.path.join(out_dir, f"r{rank}_f{frame}.npz"), depth=depth, bgr=bgr)
+        np.savez(os.path.join(out_dir, f"r{rank}_f{frame}.npz"), depth=np.asarray(depth), bgr=np.asarray(bgr))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("merge", ["all_reduce", "reduce_scatter"])
+@pytest.mark.parametrize("merge", ["all_reduce", "reduce_scatter", "bands"])
 @pytest.mark.parametrize("camera", [False, True])
 def test_two_rank_shards_equal_single_process(tmp_path, camera, merge):
     s = socket.socket()
@@ -132,7 +153,7 @@ def test_two_rank_shards_equal_single_process(tmp_path, camera, merge):
             assert np.array_equal(got["bgr"], ref["bgr"]), (frame, r)
 
 
-@pytest.mark.parametrize("merge", ["all_reduce", "reduce_scatter"])
+@pytest.mark.parametrize("merge", ["all_reduce", "reduce_scatter", "bands"])
 def test_four_ranks_with_uneven_shards_equal_single_process(tmp_path, merge):
     """world_size 4, shards of 10 % / nothing / 55 % / 35 % of the frame (whoever cuts the stream need not cut it evenly; a rank
     may get no events at all): the extrema MIN-reduce and the packed-key MAX-merge reproduce the single-process frame on every rank."""

@@ -156,6 +156,8 @@ SYMBOLS = {
     "xm_shard_finish": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
     "xm_shard_decode_u16": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P]),
     "xm_shard_finish_u16": (C.c_int, [_P, _P, _P, _P]),
+    "xm_shard_finish_u16_band": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "xm_k2_patch_cols_max": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "xm_frame_event_filter": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_size_t)]),
     "xm_find_pauses": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "xm_ingest_create": (C.c_int, [_P, C.POINTER(xm_ingest_config), C.POINTER(_P)]),

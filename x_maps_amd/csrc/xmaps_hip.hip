@@ -169,6 +169,7 @@ struct xm_handle {
   u32* d_k2_pix[3] = {nullptr, nullptr, nullptr};
   int k2_tile_cap[3] = {K2_TILE_MAX, K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
   bool k2_pipe4 = false;  // the pipelined kernel takes the 64 x 16 geometry
+  int k2_patch_cols_max = 0;  // widest patch of the 16 x 16 / 32 x 16 tiles (-1: some patch does not fit LDS)
   int k2_force_ppt = 0;                             // XM_K2_PPT=1/2: experiments
   // pipelined K2 of the group launches (xmaps_k2pipe.hpp): table entries kept in LDS, CUs of the device, switch (XM_K2_PIPE=0: off)
   int k2_pipe_nlds = 0, n_cus = 256;
@@ -491,17 +492,17 @@ size_t k2_lds_bytes(const xm_handle* h, int ppt) {
 
 template <int FMT>
 void launch_k2(xm_handle* h, hipStream_t stream, const u64* key_frame, SlotState* st, u32 tag_override, const unsigned char* dirty,
-               float* depth, uint8_t* bgr, bool unsheared = false) {
+               float* depth, uint8_t* bgr, bool unsheared = false, int col_lo = 0, int col_hi = 0) {
   const int ppt = k2_ppt(h, 1);
   const dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY));
   DevTables tb = h->tb;
   if (unsheared) tb.shear_m = tb.shear_bias = tb.shear_extra = 0;  // a plain [rect_w][rect_h] u16 frame (shards), not a slot's frame16
   if (ppt == 1)
     XM_LAUNCH((k_frame_proj_tiled<FMT, 1>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 1), stream, key_frame, tb, st, tag_override,
-              dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[0]);
+              dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[0], col_lo, col_hi);
   else
     XM_LAUNCH((k_frame_proj_tiled<FMT, 2>), grid, dim3(K2_TX * K2_TY), k2_lds_bytes(h, 2), stream, key_frame, tb, st, tag_override,
-              dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[1]);
+              dirty, (const ulonglong2*)h->d_zero16, depth, bgr, h->k2_tile_cap[1], col_lo, col_hi);
 }
 
 // the software-pipelined K2 (persistent blocks walking (frame, tile) items): groups on the plain u16 frame, two pixels per thread
@@ -1753,6 +1754,8 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
         if (r.z > 0) cells += (double)r.z * r.w;
         pipe_ok = pipe_ok && k2_pipe_tile_ok(r);
       }
+      if (g < 2)
+        for (const int4& r : tiles) h->k2_patch_cols_max = r.z < 0 || h->k2_patch_cols_max < 0 ? -1 : std::max(h->k2_patch_cols_max, r.z);
       if (g == 1) {
         h->k2_pipe_rig_ok = pipe_ok;
         mean_cells2 = cells / (double)std::max<size_t>(tiles.size(), 1);
@@ -3011,6 +3014,26 @@ int xm_shard_decode_u16(xm_handle* h, const uint64_t* key_cells, size_t n_cells,
   hipLaunchKernelGGL(k_decode_keys_u16, dim3(grid_for(n_cells, BLOCK)), dim3(BLOCK), 0, h->slots[0].stream, (const u64*)key_cells,
                      (u64)n_cells, tag, disp_out);
   HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// Band-sharded finish: the frame kernel for the projector tiles whose patch is centred on a frame column of [col_lo, col_hi)
+// only; the caller's depth / BGR buffers keep what they held everywhere else (zero them first, MAX-reduce them over the ranks).
+int xm_shard_finish_u16_band(xm_handle* h, const uint16_t* disp_frame, int col_lo, int col_hi, float* depth_out, uint8_t* bgr_out) {
+  if (!h || !disp_frame) return fail(XM_ERR_INVALID, "NULL argument");
+  if (h->cfg.view != XM_VIEW_PROJECTOR || h->k2_direct) return fail(XM_ERR_INVALID, "the band-sharded finish is the tiled projector-view frame kernel");
+  if (col_lo < 0 || col_hi <= col_lo) return fail(XM_ERR_INVALID, "empty column band");
+  XM_ENTER(h);
+  launch_k2<2>(h, h->slots[0].stream, reinterpret_cast<const u64*>(disp_frame), h->aux_st, 1u, nullptr, depth_out, bgr_out, true, col_lo, col_hi);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// Widest patch (frame columns) any projector tile reads, over both tile geometries; -1 when a tile's patch does not fit LDS (such
+// a tile reads the frame wherever its map points: no band can be cut for it).  The halo a band-sharded rank needs on either side.
+int xm_k2_patch_cols_max(xm_handle* h, int* cols_out) {
+  if (!h || !cols_out) return fail(XM_ERR_INVALID, "NULL argument");
+  *cols_out = h->k2_patch_cols_max;
   return XM_OK;
 }
 

@@ -2198,12 +2198,18 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_tiled(const u64* __
                                                                   const unsigned char* __restrict__ dirty,
                                                                   const ulonglong2* __restrict__ zero16,
                                                                   float* __restrict__ depth, uint8_t* __restrict__ bgr,
-                                                                  int tile_cap) {
+                                                                  int tile_cap, int col_lo = 0, int col_hi = 0) {
   // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
   if ((long long)((u64)keys | (u64)tb.k2_tiles | (u64)tb.k2_pix | (u64)tb.k2_tiles1 | (u64)tb.k2_pix1 | (u64)tb.dlut | (u64)tb.pmap | (u64)st | (u64)dirty |
                   (u64)zero16 | (u64)depth | (u64)bgr |
                   (u64)(long long)(tb.proj_w | tb.proj_h | tb.rect_w | tb.rect_h | (int)tag_override)) < 0)
     return;
+  if (col_hi > col_lo) {  // band-sharded finish (xm_shard_finish_u16_band): only the tiles whose patch is centred on a frame column
+                          // of [col_lo, col_hi) -- the rank's band of the merged frame; tiles without a patch go with column 0
+    const int4 rec = (PPT == 1 ? tb.k2_tiles1 : tb.k2_tiles)[xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y)];
+    const int c = rec.z > 0 ? rec.x + (rec.z >> 1) : 0;
+    if (c < col_lo || c >= col_hi) return;
+  }
   frame_proj_tiled_body<FMT, PPT>(keys, tb, st, tag_override, dirty, zero16, depth, bgr, tile_cap,
                                   blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
 }

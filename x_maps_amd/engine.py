@@ -485,6 +485,15 @@ class XMapsEngine:
     def shard_decode_u16(self, key_ptr, n_cells, tag, out_ptr):
         N.check(self._lib.xm_shard_decode_u16(self._h, _ptr(key_ptr), int(n_cells), int(tag), _ptr(out_ptr)))
 
+    def shard_finish_u16_band(self, disp_ptr, col_lo: int, col_hi: int, depth_ptr=None, bgr_ptr=None):
+        """The frame kernel for the projector tiles centred on frame columns [col_lo, col_hi) only (band-sharded finish)."""
+        N.check(self._lib.xm_shard_finish_u16_band(self._h, _ptr(disp_ptr), int(col_lo), int(col_hi), _ptr(depth_ptr), _ptr(bgr_ptr)))
+
+    def k2_patch_cols_max(self) -> int:
+        v = C.c_int(0)
+        N.check(self._lib.xm_k2_patch_cols_max(self._h, C.byref(v)))
+        return int(v.value)
+
     def shard_finish_u16(self, disp_ptr, depth_ptr=None, bgr_ptr=None):
         N.check(self._lib.xm_shard_finish_u16(self._h, _ptr(disp_ptr), _ptr(depth_ptr), _ptr(bgr_ptr)))
 

@@ -77,6 +77,23 @@ class GpuShardProvider:
         self.eng.shard_finish_u16(disp_frame.data_ptr(), depth.data_ptr(), None if bgr is None else bgr.data_ptr())
         return depth, bgr
 
+    def frame_lines(self):
+        """(lines, cells per line) of the key frame along its slow axis: the device frame is column-major, a line = a frame column"""
+        return self.eng.rect_w, self.eng.rect_h
+
+    def halo_lines(self):
+        """Frame columns a band-sharded rank needs from either neighbour: the widest tile patch + 1 (-1: no band can be cut)."""
+        c = self.eng.k2_patch_cols_max()
+        return -1 if c < 0 or self.eng.camera_perspective else c + 1
+
+    def finish_u16_band(self, disp_frame, col_lo, col_hi, want_bgr=True):
+        """Partial projector frame: the tiles centred on frame columns [col_lo, col_hi); zeros elsewhere."""
+        torch = self.torch
+        depth = self._zeros(self.eng.out_h * self.eng.out_w, torch.float32).view(self.eng.out_h, self.eng.out_w)
+        bgr = self._zeros(self.eng.out_h * self.eng.out_w * 3, torch.uint8).view(self.eng.out_h, self.eng.out_w, 3) if want_bgr else None
+        self.eng.shard_finish_u16_band(disp_frame.data_ptr(), col_lo, col_hi, depth.data_ptr(), None if bgr is None else bgr.data_ptr())
+        return depth, bgr
+
     def clear_key_frame(self, kf):
         self.eng.shard_clear(kf.data_ptr())
 
@@ -125,16 +142,21 @@ class ShardedFrameProcessor:
         """merge: "all_reduce" -- MAX all-reduce of the whole 8-byte key frame (2 (W-1)/W x 8 bytes per cell and rank);
         "reduce_scatter" -- MAX reduce-scatter of the key frame, the own chunk decoded to u16 disparities, all-gather of
         the u16 chunks, frame kernel on the plain disparity frame ((W-1)/W x (8 + 2) bytes per cell): 37 % less traffic,
-        and the frame kernel reads 2 instead of 8 bytes per cell."""
-        assert merge in ("all_reduce", "reduce_scatter")
+        and the frame kernel reads 2 instead of 8 bytes per cell;
+        "bands" -- the same reduce-scatter, but the u16 frame is never gathered: every rank keeps its band of frame columns, gets a
+        halo of a few columns from either neighbour (point to point), finishes the projector tiles centred on its band, and the
+        partial projector frames are MAX-all-reduced (K2 sharded as well; what crosses the links after the
+        reduce-scatter is 2 halos + the projector frame instead of the whole disparity frame).  Projector view; falls back to
+        "reduce_scatter" when a band is narrower than the halo."""
+        assert merge in ("all_reduce", "reduce_scatter", "bands")
         self.p = provider
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.merge = merge
-        self.key_frame = provider.new_key_frame(self.world) if merge == "reduce_scatter" else provider.new_key_frame()
-        if merge == "reduce_scatter":
+        self.key_frame = provider.new_key_frame(self.world) if merge != "all_reduce" else provider.new_key_frame()
+        if merge != "all_reduce":
             chunk = self.key_frame.numel() // self.world
             self.kf_chunk = self.key_frame.new_zeros(chunk)
             self.u16_chunk = provider.new_u16(chunk)
@@ -172,7 +194,11 @@ class ShardedFrameProcessor:
             self._all_reduce(self.mm, self.dist.ReduceOp.MIN)
             # 2. private scatter (reads the reduced extrema from device memory), 3. merge
             self.p.scatter(shard, idx_offset, self.mm, tag, self.key_frame)
-            if self.merge == "reduce_scatter":
+            if self.merge == "bands" and self._bands_ok():
+                self._reduce_scatter_max(self.key_frame, self.kf_chunk)
+                self.p.decode_u16(self.kf_chunk, tag, self.u16_chunk)
+                return self._finish_bands(want_bgr)
+            if self.merge != "all_reduce":
                 self._reduce_scatter_max(self.key_frame, self.kf_chunk)
                 self.p.decode_u16(self.kf_chunk, tag, self.u16_chunk)
                 self._all_gather(self.u16_full, self.u16_chunk)
@@ -184,6 +210,53 @@ class ShardedFrameProcessor:
             if finish_on_all_ranks or self.rank == 0:
                 return self.p.finish(self.key_frame, tag, want_bgr)
         return None, None
+
+    # ---- merge = "bands" ------------------------------------------------------------------------------------------------
+    def _frame_geometry(self):
+        n_lines, line_len = self.p.frame_lines()  # the key frame's slow axis (device: frame columns of rect_h cells)
+        return n_lines, line_len, self.kf_chunk.numel()
+
+    def _bands_ok(self):
+        hl = self.p.halo_lines() if hasattr(self.p, "halo_lines") else -1
+        if hl < 0:
+            return False
+        n_lines, line_len, chunk = self._frame_geometry()
+        return hl * line_len <= chunk  # a neighbour's band must hold the whole halo
+
+    def _finish_bands(self, want_bgr):
+        import torch
+        n_lines, line_len, C = self._frame_geometry()
+        r, W = self.rank, self.world
+        Hc = self.p.halo_lines() * line_len
+        full = self.u16_full  # [W * C] cells; only [r C - Hc, (r + 1) C + Hc) will be valid
+        full[r * C:(r + 1) * C].copy_(self.u16_chunk)
+        ops, keep = [], []
+        as_u8 = lambda a: self.p.as_tensor(a).view(torch.uint8)  # (bytes on the wire: gloo has no int16)
+        if W > 1:
+            if r > 0:       # my first cells are the left neighbour's right halo; its last cells are my left halo
+                send_l = self.u16_chunk[:Hc].contiguous()
+                keep.append(send_l)
+                ops.append(self.dist.P2POp(self.dist.isend, as_u8(send_l), self._peer(r - 1), group=self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, as_u8(full[r * C - Hc:r * C]), self._peer(r - 1), group=self.group))
+            if r < W - 1:
+                send_r = self.u16_chunk[C - Hc:].contiguous()
+                keep.append(send_r)
+                ops.append(self.dist.P2POp(self.dist.isend, as_u8(send_r), self._peer(r + 1), group=self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, as_u8(full[(r + 1) * C:(r + 1) * C + Hc]), self._peer(r + 1), group=self.group))
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+            self.collectives_issued += 1
+        lo = -(-(r * C) // line_len)  # the lines that START inside this rank's chunk
+        hi = min(-(-((r + 1) * C) // line_len), n_lines) if r < W - 1 else n_lines
+        depth, bgr = self.p.finish_u16_band(full, lo, max(hi, lo + 1), want_bgr)
+        # non-owners hold zeros: MAX assembles the frame (depth >= 0 orders like its int32 bits)
+        self._all_reduce(self.p.as_tensor(depth).view(torch.int32), self.dist.ReduceOp.MAX)
+        if bgr is not None:
+            self._all_reduce(bgr, self.dist.ReduceOp.MAX)
+        return depth, bgr
+
+    def _peer(self, group_rank):
+        return self.dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
     def _reduce_scatter_max(self, full, chunk):
         """chunk <- MAX over ranks of full[rank * len(chunk) : (rank + 1) * len(chunk)]."""
