@@ -14,9 +14,15 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libxmaps_hip.so")
 SOURCES = [os.path.join(PKG_DIR, "csrc", "xmaps_hip.hip")]
-DEPENDS = SOURCES + [os.path.join(PKG_DIR, "csrc", f) for f in ("xmaps_kernels.hpp", "xmaps_k1cols.hpp", "xmaps_k1own.hpp", "xmaps_k2pipe.hpp",
-                                                                  "xmaps_ingest.hpp", "turbo_lut.inc")] + [
-    os.path.join(ROOT, "include", "xmaps.h")]
+def _depends():
+    """every file the one translation unit is made of: csrc/*.hpp, csrc/*.inc, csrc/host/*.hpp, include/xmaps.h"""
+    import glob
+    csrc = os.path.join(PKG_DIR, "csrc")
+    return SOURCES + sorted(glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.inc")) +
+                            glob.glob(os.path.join(csrc, "host", "*.hpp"))) + [os.path.join(ROOT, "include", "xmaps.h")]
+
+
+DEPENDS = _depends()
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 XM_OK, XM_ERR_INVALID, XM_ERR_HIP, XM_ERR_NOMEM, XM_ERR_INDEX, XM_ERR_TOO_MANY, XM_ERR_UNSORTED = 0, -1, -2, -3, -4, -5, -6

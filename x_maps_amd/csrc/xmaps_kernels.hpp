@@ -843,12 +843,8 @@ __device__ __forceinline__ void scatter_tiled_body(
   // the pipelined frame rate: tools/block_timeline.py).
   const int win_words = VIEW == 0 ? w_ts * tb.xmap_h : w_x * tb.cam_h;
   const int win_q = (win_words + 3) >> 2;  // uint4 count
-#ifndef XM_NO_LDS_DMA
   // LDS-direct band loads write whole waves (64 x 16 B): each band keeps one wave of slack behind it (k1_lds_bytes())
   const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1 + 64;
-#else
-  const int lut_q = ((w_x * tb.cam_h + 3) >> 2) + 1;
-#endif
   u32* win = reinterpret_cast<u32*>(smem);
   u32* lut_base = win;
   int16_t* xm_base = reinterpret_cast<int16_t*>(win + 4 * max(win_q, lut_q));
@@ -1086,7 +1082,6 @@ __device__ __forceinline__ void scatter_tiled_body(
   const int nq_all = nq_lut + nq_xm;
   uint4* l_lut = reinterpret_cast<uint4*>(lut_base);
   uint4* l_xm = reinterpret_cast<uint4*>(xm_base);
-#ifndef XM_NO_LDS_DMA
   // LDS-DIRECT loads (global_load_lds_dwordx4, gfx950): the bands go L2 -> LDS without passing through VGPRs -- no 24
   // registers of band data held across the event arithmetic, no ds_write_b128, nothing to wait for until the gathers.
   // Lane l of a wave writes 16 B at M0 + 16 l, so a wave's 64 quads land contiguously: LDS quad index == band quad index,
@@ -1099,12 +1094,10 @@ __device__ __forceinline__ void scatter_tiled_body(
   // it does not count past them), i.e. the time-column arithmetic below would wait for the bands too.  Touch the event
   // registers here instead: the wait lands in front of the band loads, where only the events are outstanding (they were
   // issued ~1 us ago and the samples behind them have already arrived), and the bands then fly during the arithmetic.
-#ifndef XM_NO_EVENT_PIN
 #pragma unroll
   for (int q = 0; q < TILE_EPT / 2; ++q) asm volatile("" : "+v"(xw[q]), "+v"(yw[q]), "+v"(pw[q]));
 #pragma unroll
   for (int k = 0; k < TILE_EPT; ++k) asm volatile("" : "+v"(tt[k]));
-#endif
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   constexpr int UL_L = TILE_THREADS >= 1024 ? 2 : 4, UL_X = TILE_THREADS >= 1024 ? 1 : 2;
@@ -1126,19 +1119,6 @@ __device__ __forceinline__ void scatter_tiled_body(
     }
     (void)nq_all;
   }
-#else
-  uint4* l_dummy = l_xm + (((w_ts * tb.xmap_h + 7) >> 3) + 1);
-  constexpr int UNB = TILE_THREADS >= 1024 ? 3 : 6;  // 43 KB of bands = 2745 quads: one pass for the largest block
-  const auto band_src = [&](int i) -> const uint4* { return i < nq_lut ? g_lut + i : g_xm + min(i - nq_lut, nq_xm - 1); };
-  const auto band_dst = [&](int i) -> uint4* { return i < nq_lut ? l_lut + i : (i < nq_all ? l_xm + (i - nq_lut) : l_dummy); };
-  const uint4 bv0 = *band_src(tid), bv1 = *band_src(tid + nthreads), bv2 = *band_src(tid + 2 * nthreads);
-  uint4 bv3 = make_uint4(0, 0, 0, 0), bv4 = bv3, bv5 = bv3;
-  if constexpr (UNB == 6) {
-    bv3 = *band_src(tid + 3 * nthreads);
-    bv4 = *band_src(tid + 4 * nthreads);
-    bv5 = *band_src(tid + 5 * nthreads);
-  }
-#endif
   XM_STAMP(4);
 
   // ---- 4. with the bands in flight: unpack the events, their time columns (bit-exact with NumPy, see TimeNorm) ---------
@@ -1261,31 +1241,12 @@ __device__ __forceinline__ void scatter_tiled_body(
     n_oob += __popcll(__ballot(oob));
   }
   XM_STAMP(5);
-#ifndef XM_NO_LDS_DMA
   for (int q0 = dma_q0 + UL_L * nthreads; q0 < nq_lut; q0 += nthreads)  // taller tables / smaller blocks: the rest
     __builtin_amdgcn_global_load_lds((glb_void*)(g_lut + min(q0 + dma_lane, nq_lut - 1)), (lds_void*)(l_lut + q0), 16, 0, 0);
   for (int q0 = dma_q0 + UL_X * nthreads; q0 < nq_xm; q0 += nthreads)
     __builtin_amdgcn_global_load_lds((glb_void*)(g_xm + min(q0 + dma_lane, nq_xm - 1)), (lds_void*)(l_xm + q0), 16, 0, 0);
   // the LDS-direct loads are tracked by vmcnt like any vector load: all of them landed before the barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-  {
-    *band_dst(tid) = bv0;
-    *band_dst(tid + nthreads) = bv1;
-    *band_dst(tid + 2 * nthreads) = bv2;
-    if constexpr (UNB == 6) {
-      *band_dst(tid + 3 * nthreads) = bv3;
-      *band_dst(tid + 4 * nthreads) = bv4;
-      *band_dst(tid + 5 * nthreads) = bv5;
-    }
-    for (int i0 = tid + UNB * nthreads; i0 < nq_all; i0 += 3 * nthreads) {  // smaller blocks / taller tables
-      const uint4 v0 = *band_src(i0), v1 = *band_src(i0 + nthreads), v2 = *band_src(i0 + 2 * nthreads);
-      *band_dst(i0) = v0;
-      *band_dst(i0 + nthreads) = v1;
-      *band_dst(i0 + 2 * nthreads) = v2;
-    }
-  }
-#endif
   XM_STAMP(11);
   XM_STAMP(12);
   __syncthreads();  // bands visible
@@ -1431,7 +1392,6 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
     const int16_t* __restrict__ ps, const uint4* __restrict__ aos, u64 n, u64 idx_offset, DevTables tb, SlotState* st,
     u32 tag_override, u64 mm_lo, u64 mm_hi, const void* __restrict__ mm_ext, u64* __restrict__ frame,
     unsigned char* __restrict__ dirty, int w_ts, int w_x, int sorted_mode) {
-#ifndef XM_NO_KERNARG_BATCH
   // All kernel arguments into SGPRs in ONE scalar-load round trip: a test that needs every one of them, placed first.
   // Left alone the compiler fetches them lazily, block by block -- eight dependent s_load -> s_waitcnt pairs along the
   // critical chain of every block (seen in the ISA).  (Inline asm would do it too, but makes every later uniform load a
@@ -1443,7 +1403,6 @@ __global__ XM_K1_BOUNDS void k_scatter_tiled(
                    (int)tag_override | w_ts | w_x | sorted_mode;
     if ((long long)(pp | (u64)(long long)pi) < 0) return;
   }
-#endif
   scatter_tiled_body<T, AOS, HAS_P, VIEW, VEC, KEY32>(xs, ys, ts, ps, aos, n, idx_offset, tb, st, tag_override, mm_lo, mm_hi, mm_ext,
                                                       frame, dirty, w_ts, w_x, sorted_mode, blockIdx.x, gridDim.x);
 }
@@ -1765,11 +1724,7 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   constexpr int K2_PPT = PPT, K2_TW = K2_TX * PPT;
   extern __shared__ __attribute__((aligned(16))) uint16_t k2_lds[];
   uint16_t* tile = k2_lds;  // [tile_cap + 16]  (+16: the last 16-byte read may overrun)
-#ifdef XM_K2_TWO_BUFFERS
-  uint16_t* vmax = k2_lds + tile_cap + 16;  // [tile_cap]
-#else
   uint16_t* vmax = tile;  // the row maxima replace the patch IN PLACE: half the LDS per block = more blocks per CU
-#endif
   constexpr int NT = K2_TX * K2_TY, NW = NT / 64;
   __shared__ __attribute__((aligned(16))) uint8_t s_bgr[K2_TY][K2_TW * 3];
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
@@ -2068,11 +2023,6 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
         // consecutive tasks is computed into registers, a barrier, then stored over its own inputs; the next chunk's inputs
         // lie behind everything this one wrote.
         const int nseg = rows_p >> 3, tasks = cols * nseg;
-#ifdef XM_K2_TWO_BUFFERS
-        for (int t = tid; t < tasks; t += NT)
-          *reinterpret_cast<uint4*>(vmax + t * 8) = k2_rowmax8(*reinterpret_cast<const uint4*>(tile + t * 8),
-                                                                *reinterpret_cast<const uint4*>(tile + t * 8 + 8));
-#else
         constexpr int CH = 4;
         for (int t0 = 0; t0 < tasks; t0 += CH * NT) {  // (block-uniform trip count)
           uint4 w[CH];
@@ -2089,7 +2039,6 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
             if (t < tasks) *reinterpret_cast<uint4*>(vmax + t * 8) = w[j];
           }
         }
-#endif
       }
       XM_K2STAMP(3);
       __syncthreads();
@@ -2133,15 +2082,11 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   PixelOut o[K2_PPT];
 #pragma unroll
   for (int q = 0; q < K2_PPT; ++q) {
-#ifndef XM_K2_NO_DLUT
     if (rec.z <= 0) di[q] = (u32)d[q];  // d is an integer disparity here (max of u16 key fields)
     // (byte offset off the table's base: a scalar-base + 32-bit-offset load instead of a 64-bit multiply-add per pixel)
     const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(tb.dlut) + ((di[q] & 0xffffu) << 3));
     o[q].depth = __uint_as_float(e.x);
     o[q].bgr = e.y;
-#else
-    o[q] = disparity_pixel(rec.z > 0 ? (float)di[q] : d[q], tb.p03, tb.z_near, tb.z_far);
-#endif
   }
   if (!tag_override && lin_tile == 0 && tid < CNT_SLOTS) {  // re-arm the next frame's counters
     u32* c = st->cnt[(tag & 1) ^ 1][tid];
