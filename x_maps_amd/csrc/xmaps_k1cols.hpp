@@ -51,7 +51,9 @@ typedef XM_GLOBAL SlotState* gp_state;
 #define XM_CSTAMP_FRAME 30
 #endif
 #define XM_CSTAMP(ph) do { if (threadIdx.x == 0 && blockIdx.y == XM_CSTAMP_FRAME && blockIdx.x < 64) g_timeline[blockIdx.x][ph] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XM_CABL(bit) (g_ablate & (1 << (bit)))  /* bit 4: no flush stores, 5: no band loads, 6: no event loads, 7: no per-event work */
 #else
+#define XM_CABL(bit) false
 #define XM_CSTAMP(ph) do { } while (0)
 #endif
 
@@ -405,6 +407,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   const int16_t* xm_t = xm_base + xm_shift;
   const uint4* g_xm = reinterpret_cast<const uint4*>(tb.xmap + (xm_start - xm_shift));
   const int nq_xm = (int)((xm_shift + (u32)nslots + 7u) >> 3);
+  if (!XM_CABL(5))
   for (int q0 = dma_q0; q0 < nq_xm; q0 += nthreads)
     __builtin_amdgcn_global_load_lds((glb_void*)(g_xm + min(q0 + lane, nq_xm - 1)), (lds_void*)(l_xm + q0), 16, 0, 0);
   {  // winner slots
@@ -477,7 +480,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
     const int w0 = VEC ? a0 + pass * cap + (tid & ~63) * EPT : lb_s + pass * cap + (tid & ~63);
     return w0 < lb_e;
   };
-  if (n_pass > 0 && wave_on(0)) {
+  if (n_pass > 0 && wave_on(0) && !XM_CABL(6)) {
     load_events(0);
     // the compiler waits with vmcnt(0) before the first use of a register loaded BEFORE an LDS-direct load: touch the event
     // registers here, so that the wait sits in front of the LUT band's loads and the band flies during the event arithmetic
@@ -493,7 +496,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
   const u32* lut_t = lut_base + lut_shift;
   const uint4* g_lut = reinterpret_cast<const uint4*>(tb.lut + (lut_start - lut_shift));
   const int nq_lut = (int)((lut_shift + (u32)wx_eff * (u32)tb.cam_h + 3u) >> 2);
-  if (n_pass > 0)
+  if (n_pass > 0 && !XM_CABL(5))
     for (int q0 = dma_q0; q0 < nq_lut; q0 += nthreads)
       __builtin_amdgcn_global_load_lds((glb_void*)(g_lut + min(q0 + lane, nq_lut - 1)), (lds_void*)(l_lut + q0), 16, 0, 0);
 
@@ -515,7 +518,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 
   u32 n_in = 0, n_oob = 0;  // per-lane counters (summed over the wave at the end: no ballot + popcount per event)
   for (int pass = 0; pass < n_pass; ++pass) {
-    const bool on = wave_on(pass);
+    const bool on = wave_on(pass) && !XM_CABL(7);
     if (pass > 0 && on) load_events(pass);
     int e0;  // order of the thread's event 0 inside the tile (event index - a0); event k: + k (VEC) / + k * nthreads
     if constexpr (VEC) e0 = pass * cap + tid * EPT;
@@ -696,7 +699,7 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 #pragma unroll
         for (int j = 0; j < FL; ++j) {
           const int fu = xv[j] - tb.x_offset;
-          if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && fu >= xr_min && fu < tb.rect_w)
+          if (i0 + j * nthreads < nslots && rs[j] < tb.xmap_h - 1 && fu >= xr_min && fu < tb.rect_w && !XM_CABL(4))
             frame16[__umul24((u32)fu, (u32)tb.rect_h) + (u32)rs[j]] = (uint16_t)(v[j] & 0xffffu);
         }
       } else {
