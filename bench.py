@@ -986,9 +986,30 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         k1 = max(1, steps * fps)
         el1, _ = tm1.blocks(lambda: [step_single(i) for i in range(k1)], int(min(200, max(3, round(0.2 / max(k1 * e1, 1e-6))))))
         dt1 = float(np.median(el1))
-        other["one_frame_per_call"] = {"value": round(float(np.mean(lens)) * k1 / dt1 / 1e6, 2), "unit": "Mevents/s",
-                                       "us_per_frame": round(dt1 / k1 * 1e6, 2), "frames_in_flight": min(slots, 4),
-                                       "note": "xm_process_frame_aos per frame, asynchronous (device-resident records)"}
+        other["one_frame_per_call_eager"] = {"value": round(float(np.mean(lens)) * k1 / dt1 / 1e6, 2), "unit": "Mevents/s",
+                                             "us_per_frame": round(dt1 / k1 * 1e6, 2), "frames_in_flight": min(slots, 4),
+                                             "note": "xm_process_frame_aos per frame, asynchronous (device-resident records), three launches per frame"}
+        # the same calls on a handle with XM_FLAG_ADAPTIVE_BATCH: frames that arrive while the GPU is busy leave as one group
+        eng.sync()
+        with XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots, adaptive_batch=True) as eng_a:
+            def step_adaptive(i):
+                o = i % slots
+                eng_a.process_events_device(dev_frames[i % nf].data_ptr(), lens[i % nf], False, depth_out[o].data_ptr(),
+                                            None if bgr_out is None else bgr_out[o].data_ptr())
+            tm2 = Timer(torch, None, dev, eng_a.sync)
+            e2 = tm2.prewarm(step_adaptive, PREWARM_S)
+            el2, _ = tm2.blocks(lambda: [step_adaptive(i) for i in range(k1)], int(min(200, max(3, round(0.2 / max(k1 * e2, 1e-6))))))
+            dt2 = float(np.median(el2))
+            pa = eng_a.path_counts()
+            ok_a = True
+            if O is not None:  # parity of the last frame the adaptive handle wrote
+                j = (k1 - 1) % nf
+                ok_a = bool(np.array_equal(depth_out[(k1 - 1) % slots].cpu().numpy(), ref_of(host[j])["depth"]))
+        other["one_frame_per_call"] = {"value": round(float(np.mean(lens)) * k1 / dt2 / 1e6, 2), "unit": "Mevents/s",
+                                       "us_per_frame": round(dt2 / k1 * 1e6, 2), "slots": slots, "k1_paths": pa,
+                                       "last_frame_depth_bit_exact": ok_a,
+                                       "note": "xm_process_frame_aos per frame on a handle with XM_FLAG_ADAPTIVE_BATCH (asynchronous, "
+                                               "device-resident records)"}
     # what the pipe does per projector frame: one synchronous host call, EventCD records in, BGR frame out
     for i in range(20):
         eng.process_events(host[i % nf], want_depth=False, want_bgr=True)
