@@ -500,7 +500,11 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         import copy  # (XM_BENCH_FORCE_SHARDED_LEG + XM_BENCH_FORCE_DIST: the tests exercise this leg on a one-GPU box)
         a2 = copy.copy(args)
         a2.steps, a2.no_cpu_baseline, a2.single_block = 40, True, False
-        sharded_leg = bench_sharded(a2, torch, dist, dev, rank, local_rank, world)
+        try:
+            sharded_leg = bench_sharded(a2, torch, dist, dev, rank, local_rank, world)
+        except Exception as e:  # never lose the replicas' line to the extra leg
+            sharded_leg = None
+            sys.stderr.write("bench.py: sharded leg failed on rank %d: %r\n" % (rank, e))
     if rank != 0:
         eng.close()
         return None

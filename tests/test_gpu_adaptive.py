@@ -77,3 +77,30 @@ def test_a_synchronous_call_flushes_what_is_held_back_and_few_slots_switch_it_of
                 assert np.array_equal(depth[f].cpu().numpy(), _ref(tb, frames[f])["depth"]), (slots, f)
         depth.zero_()
         torch.cuda.synchronize()
+
+
+def test_eventcd_records_on_an_owner_tile_rig():
+    """xm_process_frame_aos on a handle with the flag, on a rig whose X-map is not injective (owner tiles): frames of different
+    lengths, one of them unsorted, submitted back to back; every frame == the oracle (what `bench.py --esl` times as
+    other_modes.one_frame_per_call)."""
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    dev = torch.device("cuda", 0)
+    F = 24
+    host = [S.make_events(cfg, frame=f % 6, n=40_000 + 7_000 * (f % 4)) for f in range(F)]
+    host[5] = host[5][::-1].copy()
+    up = [torch.from_numpy(e.view(np.uint8).reshape(-1, 16).copy()).to(dev) for e in host]
+    depth = torch.zeros((F, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    bgr = torch.zeros((F, cfg.proj_h, cfg.proj_w, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb, n_slots=F, adaptive_batch=True) as eng:
+        assert eng.cols_info()["mode"] == "own"
+        for f in range(F):
+            eng.process_events_device(up[f].data_ptr(), len(host[f]), False, depth[f].data_ptr(), bgr[f].data_ptr())
+        eng.sync()
+        for f in (0, 4, 5, 6, 13, F - 1):
+            r = _ref(tb, host[f])
+            assert np.array_equal(depth[f].cpu().numpy(), r["depth"]), f
+            assert np.array_equal(bgr[f].cpu().numpy(), r["bgr"]), f
+        assert eng.sorted_fallbacks() == 1
+        assert eng.path_counts()["cols"] >= F - 1
