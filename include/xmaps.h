@@ -255,6 +255,9 @@ void xm_graph_destroy(xm_graph* g);
  * t_first / t_last: thr[c] = the smallest a in [0, t_last - t_first + 1] with column(t_first + a) >= c, column() being
  * `rint(((t - tmin) / (tmax - tmin)) * (xmap_width - 1))` in float64 exactly as python/x_maps_disparity.py:16-19 computes it. */
 int xm_debug_cols_thresholds(xm_handle* h, long long t_first, long long t_last, uint32_t* out_host);
+/* tests: A3's output of the handle's last frame when it took the column / owner tiles (xm_path_counts; not after a redo): the
+ * u16 disparity frame as [rect_height][rect_width] row-major (python/cam_proj_calibration.py:299-303's disp_map, 0 = empty). */
+int xm_debug_last_disp_frame(xm_handle* h, uint16_t* out_host);
 int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
                            size_t n, int t_dtype, int mem, int16_t* xr, int16_t* yr, int16_t* ts, int16_t* disp,
                            uint8_t* mask);

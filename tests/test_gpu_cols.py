@@ -490,6 +490,8 @@ def test_random_rigs_and_streams_on_the_tiles(seed):
             d, b, st = eng.process_events(evs) if aos else eng.process_frame(x, y, t)
             assert st.n_inliers == int(ref["mask"].sum()), aos
             assert np.array_equal(d, ref["depth"]) and np.array_equal(b, ref["bgr"]), aos
+            if eng.path_counts()["cols"] == 1 + aos and eng.sorted_fallbacks() == 0:  # A3's output itself, before the 7x7 maximum
+                assert np.array_equal(eng.debug_last_disp_frame(), np.asarray(ref["disp_map"]).astype(np.uint16)), aos
         pc = eng.path_counts()
         # sorted streams on these rigs take the tiles; a failing frame is redone on the general path (still exact)
         assert pc["cols"] + pc["key32"] + pc["sorted_key64"] + pc["general"] == 2 + eng.sorted_fallbacks()

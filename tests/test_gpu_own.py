@@ -231,3 +231,57 @@ def test_esl_like_rig_real_calibration_geometry():
             r = _ref(tb, frames[f])
             assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), f
         assert eng.path_counts()["cols"] == 6 and eng.sorted_fallbacks() == 0
+
+
+def _random_shared_rig(seed):
+    """a shared-cell rig with a random shape, a locally perturbed X-map (cells jump, rows swap owners, undefined cells, a
+    replicated border) and a random event stream: duplicates, x noise, bursts, events outside the LUT's rows"""
+    rng = np.random.default_rng(9000 + seed)
+    cfg = S.C_SHARED
+    cpc = float(rng.choice([1.2, 1.4, 2.0, 3.3, 4.6, 6.5]))
+    slant = float(rng.choice([-0.7, -0.4, -0.2, 0.0, 0.35]))
+    if 18.0 + max(0.0, -slant) * cfg.rect_h + cfg.proj_w / cpc + max(0.0, slant) * cfg.rect_h >= cfg.rect_w:
+        cpc = 3.3  # (the finest X-map with the steepest slant does not fit the frame)
+    tb = S.make_tables_shared_cells(cfg, cols_per_cell=cpc, slant=slant)
+    xm = tb["proj_x_map"].copy()
+    H, W = xm.shape
+    for _ in range(int(rng.integers(0, 40))):  # local jumps of a few cells (what rounding of a real time map does)
+        r, c = int(rng.integers(0, H)), int(rng.integers(1, W))
+        xm[r, c:c + int(rng.integers(1, 6))] += np.int16(rng.integers(-3, 4))
+    if rng.random() < 0.5:  # a replicated border: the last columns all map to one far-away cell
+        xm[:, W - int(rng.integers(1, 12)):] = xm[:, :1] + np.int16(rng.integers(0, 40))
+    xm[rng.random(xm.shape) < 0.002] = 0  # undefined cells
+    xm = np.clip(xm, 0, S.X_OFFSET + cfg.rect_w - 1).astype(np.int16)
+    tb["proj_x_map"] = np.ascontiguousarray(xm)
+    n = int(rng.integers(25_000, 120_000))
+    evs = S.make_events(cfg, frame=int(rng.integers(0, 1000)), n=n)
+    k = int(rng.integers(0, n // 50))
+    if k:  # duplicates of earlier events a little later in the stream (same pixel, later stamp): last writer must win
+        src = rng.integers(0, n - 1, k)
+        dst = np.minimum(src + rng.integers(1, 400, k), n - 1)
+        evs["x"][dst] = evs["x"][src]
+        evs["y"][dst] = evs["y"][src]
+    if rng.random() < 0.3:  # a burst: a tenth of the frame's events inside 1 % of its time
+        i0 = int(rng.integers(0, n - n // 10))
+        evs["t"][i0:i0 + n // 10] = np.sort(evs["t"][i0] + rng.integers(0, 130, n // 10))
+        evs["t"] = np.maximum.accumulate(evs["t"])
+    m = rng.random(n) < 0.01  # x noise far outside the window / the camera
+    evs["x"][m] = rng.integers(0, cfg.cam_w, int(m.sum())).astype(np.uint16)
+    return tb, evs
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shared_cell_rigs_and_streams(seed):
+    """whatever the rig and the stream: frame == oracle, through the owner tiles when the rig qualifies (single frames and a group
+    of three), on the packed keys otherwise"""
+    tb, evs = _random_shared_rig(seed)
+    ref = _ref(tb, evs)
+    with XMapsEngine(tb, n_slots=4) as eng:
+        assert _same(_run(eng, evs), ref), (seed, eng.cols_info())
+        if eng.path_counts()["cols"] == 1 and eng.sorted_fallbacks() == 0:  # A3's output itself, before the 7x7 maximum can hide a cell
+            assert np.array_equal(eng.debug_last_disp_frame(), np.asarray(ref["disp_map"]).astype(np.uint16)), seed
+        frames = [evs, evs[: len(evs) // 2].copy(), evs]
+        out = eng.process_event_frames(frames)
+        for e, (d, b) in zip(frames, out):
+            r = _ref(tb, e)
+            assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), (seed, len(e))

@@ -579,6 +579,28 @@ int xm_debug_cols_thresholds(xm_handle* h, long long t_first, long long t_last, 
   return XM_OK;
 }
 
+// tests: the u16 disparity frame the column / owner tiles left in the slot of the handle's last frame (A3's output before K2),
+// un-sheared, as [rect_h][rect_w] row-major like the reference's disp_map.  Meaningful only if that frame took the tiles
+// (xm_path_counts) and was not redone.
+int xm_debug_last_disp_frame(xm_handle* h, uint16_t* out_host) {
+  if (!h || !out_host) return fail(XM_ERR_INVALID, "NULL argument");
+  XM_ENTER(h);
+  Slot& s = h->slots[h->last_slot];
+  if (!s.frame16) return fail(XM_ERR_INVALID, "this handle has no column-tile frames");
+  if (s.pending_batch_ev) {
+    HIP_TRY(hipEventSynchronize(s.pending_batch_ev));
+    s.pending_batch_ev = nullptr;
+  }
+  HIP_TRY(hipStreamSynchronize(s.stream));
+  const size_t cells = frame16_cells(h->tb);
+  std::vector<uint16_t> raw(cells);
+  HIP_TRY(hipMemcpy(raw.data(), s.frame16, cells * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  const int rw = h->tb.rect_w, rh = h->tb.rect_h;
+  for (int r = 0; r < rh; ++r)
+    for (int x = 0; x < rw; ++x) out_host[(size_t)r * rw + x] = raw[(size_t)frame16_col(h->tb, x, r) * rh + r];
+  return XM_OK;
+}
+
 void* xm_stream(xm_handle* h, int slot) {
   if (!h || slot < 0 || slot >= (int)h->slots.size()) return nullptr;
   return (void*)h->slots[slot].stream;

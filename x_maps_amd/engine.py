@@ -320,6 +320,12 @@ class XMapsEngine:
         return out
 
     # ---- debug: every per-event intermediate -------------------------------------------------------
+    def debug_last_disp_frame(self) -> np.ndarray:
+        """tests: A3's u16 disparity frame [rect_h][rect_w] of the last frame, when it took the column / owner tiles"""
+        out = np.zeros((self.rect_h, self.rect_w), np.uint16)
+        N.check(self._lib.xm_debug_last_disp_frame(self._h, out.ctypes.data_as(C.POINTER(C.c_uint16))))
+        return out
+
     def debug_event_outputs(self, x, y, t, p=None):
         x, y = _coords_u16(x, "x"), _coords_u16(y, "y")
         t, tdt = _time_col(t)
