@@ -258,6 +258,9 @@ int xm_debug_cols_thresholds(xm_handle* h, long long t_first, long long t_last, 
 /* tests: A3's output of the handle's last frame when it took the column / owner tiles (xm_path_counts; not after a redo): the
  * u16 disparity frame as [rect_height][rect_width] row-major (python/cam_proj_calibration.py:299-303's disp_map, 0 = empty). */
 int xm_debug_last_disp_frame(xm_handle* h, uint16_t* out_host);
+/* tests: frames finished by the software-pipelined K2 (groups on the u16 frame) since xm_create; XM_K2_PIPE=2 in the environment
+ * sends every group there, XM_K2_PIPE=0 none. */
+int xm_debug_k2_pipe_frames(xm_handle* h, uint64_t* count);
 int xm_debug_event_outputs(xm_handle* h, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p,
                            size_t n, int t_dtype, int mem, int16_t* xr, int16_t* yr, int16_t* ts, int16_t* disp,
                            uint8_t* mask);

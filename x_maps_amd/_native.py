@@ -143,6 +143,7 @@ SYMBOLS = {
     "xm_graph_create": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.c_int, _P, _P, C.POINTER(_P)]),
     "xm_graph_launch": (C.c_int, [_P]),
     "xm_graph_destroy": (None, [_P]),
+    "xm_debug_k2_pipe_frames": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_debug_last_disp_frame": (C.c_int, [_P, C.POINTER(C.c_uint16)]),
     "xm_debug_cols_thresholds": (C.c_int, [_P, C.c_longlong, C.c_longlong, C.POINTER(C.c_uint32)]),
     "xm_debug_event_outputs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

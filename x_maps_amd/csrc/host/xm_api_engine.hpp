@@ -119,6 +119,14 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       else if (g == 1) hipLaunchKernelGGL(k_build_k2_tables<2>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
       else hipLaunchKernelGGL(k_build_k2_tables<4>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
       XM_TRY_CREATE(hipGetLastError());
+      if (g > 0) {  // the pipelined kernel's u16 copy
+        h->k2_pix_stride = (cfg->proj_width + 3) & ~3;
+        const size_t n16 = (size_t)h->k2_pix_stride * cfg->proj_height;
+        XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix16[g], n16 * sizeof(uint16_t) + 16));
+        hipLaunchKernelGGL(k_k2_pix_to_u16, dim3(grid_for(n16, BLOCK)), dim3(BLOCK), 0, 0, h->d_k2_pix[g], h->d_k2_pix16[g], cfg->proj_width,
+                           cfg->proj_height, h->k2_pix_stride);
+        XM_TRY_CREATE(hipGetLastError());
+      }
       XM_TRY_CREATE(hipDeviceSynchronize());
       // largest LDS patch any tile of this rig needs -> K2's dynamic LDS
       std::vector<int4> tiles((size_t)tiles_x * tiles_y);
@@ -161,8 +169,17 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     h->key32_ok = (cfg->view != XM_VIEW_PROJECTOR || (cfg->rect_height & 3) == 0) && max_disp < (1l << KEY32_DISP_BITS) &&
                   !(e32 && e32[0] == '0');
     // the pipelined K2 keeps the per-disparity table in LDS: every disparity an event of this rig can have (<= 4096 entries, 32 KB)
-    h->k2_pipe_nlds = max_disp + 1 <= 4096 ? (int)std::max<long>(1, max_disp + 1) : 0;
-    if (const char* e = getenv("XM_K2_PIPE")) h->k2_pipe = e[0] != '0';
+    // (at most 2048 entries = 16 KB: with the patch and the staging rows a block then stays under 27 KB of LDS, six blocks per CU;
+    //  a larger disparity -- the reference's ESL calibration allows 3808 through LUT entries far outside the frame, no rendered
+    //  frame comes near -- reads the global table)
+    int nlds_max = 2048;
+    if (const char* e = getenv("XM_K2_NLDS_MAX")) nlds_max = std::max(1, std::min(4096, atoi(e)));  // experiments
+    h->k2_pipe_nlds = (int)std::max<long>(1, std::min<long>(std::min<long>(max_disp + 1, 65536), nlds_max));
+    if (const char* e = getenv("XM_K2_PIPE")) {
+      h->k2_pipe = e[0] != '0';
+      h->k2_pipe_force = e[0] == '2';
+    }
+    if (const char* e = getenv("XM_K2_CONSEC")) h->k2_consec = e[0] != '0' ? 1 : 0;  // experiments / tests: the strided pixel assignment
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
   }
@@ -424,6 +441,7 @@ void xm_destroy(xm_handle* h) {
   for (int g = 0; g < 3; ++g) {
     if (h->d_k2_tiles[g]) (void)hipFree(h->d_k2_tiles[g]);
     if (h->d_k2_pix[g]) (void)hipFree(h->d_k2_pix[g]);
+    if (h->d_k2_pix16[g]) (void)hipFree(h->d_k2_pix16[g]);
   }
   if (h->d_zero16) (void)hipFree(h->d_zero16);
   delete h;
@@ -598,6 +616,14 @@ int xm_debug_last_disp_frame(xm_handle* h, uint16_t* out_host) {
   const int rw = h->tb.rect_w, rh = h->tb.rect_h;
   for (int r = 0; r < rh; ++r)
     for (int x = 0; x < rw; ++x) out_host[(size_t)r * rw + x] = raw[(size_t)frame16_col(h->tb, x, r) * rh + r];
+  return XM_OK;
+}
+
+// tests: frames finished by the software-pipelined K2 (k_frame_proj_pipe) since xm_create
+int xm_debug_k2_pipe_frames(xm_handle* h, uint64_t* count) {
+  if (!h || !count) return fail(XM_ERR_INVALID, "NULL argument");
+  XM_ENTER(h);
+  *count = h->k2_pipe_frames;
   return XM_OK;
 }
 

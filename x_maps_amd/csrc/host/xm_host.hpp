@@ -137,12 +137,17 @@ struct xm_handle {
   // ([2]: four pixels per thread, 64 x 16 tiles -- the pipelined kernel on rigs whose patches are small against the tile)
   int4* d_k2_tiles[3] = {nullptr, nullptr, nullptr};
   u32* d_k2_pix[3] = {nullptr, nullptr, nullptr};
+  uint16_t* d_k2_pix16[3] = {nullptr, nullptr, nullptr};  // the pipelined K2's copy: u16, rows padded to k2_pix_stride
+  int k2_pix_stride = 0;
+  int k2_consec = -1;  // k_frame_proj_pipe<PPT, true>: PPT consecutive pixels per thread; -1 = where it measured faster (PPT = 4), XM_K2_CONSEC=0|1 forces
   int k2_tile_cap[3] = {K2_TILE_MAX, K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
   bool k2_pipe4 = false;  // the pipelined kernel takes the 64 x 16 geometry
   int k2_patch_cols_max = 0;  // widest patch of the 16 x 16 / 32 x 16 tiles (-1: some patch does not fit LDS)
   int k2_force_ppt = 0;                             // XM_K2_PPT=1/2: experiments
   // pipelined K2 of the group launches (xmaps_k2pipe.hpp): table entries kept in LDS, CUs of the device, switch (XM_K2_PIPE=0: off)
   int k2_pipe_nlds = 0, n_cus = 256;
+  uint64_t k2_pipe_frames = 0;  // frames finished by the pipelined K2 since xm_create (xm_debug_k2_pipe_frames)
+  bool k2_pipe_force = false;   // XM_K2_PIPE=2 (tests): also for groups too small for the pipeline to matter
   bool k2_pipe = true, k2_pipe_rig_ok = false;  // (rig_ok: every tile's patch fits the pipelined loader, rect_h % 8 == 0)
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)

@@ -183,25 +183,35 @@ size_t k2_pipe_lds_bytes(const xm_handle* h, int g) {
 }
 
 bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
-  if (!h->k2_pipe || !h->k2_pipe_rig_ok || h->k2_pipe_nlds < 1 || k2_ppt(h, n_frames) != 2) return false;
+  if (!h->k2_pipe || !h->k2_pipe_rig_ok || h->k2_pipe_nlds < 1 || (k2_ppt(h, n_frames) != 2 && !h->k2_pipe_force)) return false;
   const int g = h->k2_pipe4 ? 2 : 1, ppt = 1 << g;
   const u32 gx = grid_for(h->tb.proj_w, K2_TX * ppt), gy = grid_for(h->tb.proj_h, K2_TY);
   const u64 total = (u64)gx * gy * (u64)n_frames;
   const size_t lds = k2_pipe_lds_bytes(h, g);
   const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 2048)));
   unsigned blocks = (unsigned)h->n_cus * per_cu / 8 * 8;
-  if (total < 3ull * blocks) return false;  // too few items per block for the pipeline to matter: one block per tile
-  const void* fn = g == 2 ? reinterpret_cast<const void*>(k_frame_proj_pipe<4>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2>);
+  if (total < 3ull * blocks && !h->k2_pipe_force) return false;  // too few items per block for the pipeline to matter: one block per tile
+  blocks = (unsigned)std::min<u64>(blocks, std::max<u64>(total, 1));
+  const bool cs = (h->k2_consec < 0 ? g == 2 : h->k2_consec != 0) && h->d_k2_pix16[g];  // default: consecutive pixels on the 64 x 16 tiles
+  const void* fn = g == 2 ? (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<4, true>) : reinterpret_cast<const void*>(k_frame_proj_pipe<4, false>))
+                          : (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<2, true>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2, false>));
   if (h->ensure_lds(fn, lds) != XM_OK) return false;
   K2PipeArgs pa;
   pa.proj_w = h->tb.proj_w; pa.proj_h = h->tb.proj_h; pa.rect_w = h->tb.rect_w; pa.rect_h = h->tb.rect_h;
   pa.shear_m = h->tb.shear_m; pa.shear_bias = h->tb.shear_bias;
-  if (g == 2)
-    XM_LAUNCH((k_frame_proj_pipe<4>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[2],
-              (const u32*)h->d_k2_pix[2], h->tb.dlut, pa, h->k2_tile_cap[2], (u32)n_frames, gx, gy, h->k2_pipe_nlds);
-  else
-    XM_LAUNCH((k_frame_proj_pipe<2>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, h->tb.k2_tiles, h->tb.k2_pix, h->tb.dlut, pa,
-              h->k2_tile_cap[1], (u32)n_frames, gx, gy, h->k2_pipe_nlds);
+#define XM_K2P_LAUNCH(P, C)                                                                                                          \
+  XM_LAUNCH((k_frame_proj_pipe<P, C>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[g],      \
+            (const u32*)h->d_k2_pix[g], (const uint16_t*)h->d_k2_pix16[g], h->k2_pix_stride, h->tb.dlut, pa, h->k2_tile_cap[g],      \
+            (u32)n_frames, gx, gy, h->k2_pipe_nlds)
+  if (g == 2) {
+    if (cs) XM_K2P_LAUNCH(4, true);
+    else XM_K2P_LAUNCH(4, false);
+  } else {
+    if (cs) XM_K2P_LAUNCH(2, true);
+    else XM_K2P_LAUNCH(2, false);
+  }
+#undef XM_K2P_LAUNCH
+  h->k2_pipe_frames += (uint64_t)n_frames;
   return true;
 }
 

@@ -10,7 +10,7 @@
 //   * the loads of item i + 1 (its 16-byte patch quads and the pixels' patch offsets) are issued right after item i's patch has
 //     been written to LDS, and nothing else of the iteration is a vector memory load: the per-disparity table {depth, BGR}
 //     (k_build_dlut) is copied into LDS once per block (its first n_lds entries; larger disparities -- rare -- read the global
-//     table), so no wait of the iteration has to drain the prefetch;
+//     table, behind a branch), so no wait of the iteration has to drain the prefetch;
 //   * the tile's patch is written to LDS, reduced (7-tap maxima along the rows, in place) and sampled exactly as before
 //     (frame_proj_tiled_body, FMT = 2): same tables (k2_tiles / k2_pix), same arithmetic, same outputs;
 //   * patches that stick out of the frame load zeros for the octets outside (patch rows start on a multiple of 8 and so does
@@ -42,9 +42,28 @@ struct K2PipeArgs {  // (only what the loop needs: the whole DevTables would sit
 #define XM_K2P_GLOBAL
 #endif
 
-template <int PPT>
+// One-off (xm_create): the pixel table as u16 (patch offsets are < K2_TILE_MAX; ~0 -> 0xffff), rows padded to `stride` entries
+__global__ __launch_bounds__(BLOCK) void k_k2_pix_to_u16(const u32* __restrict__ pix, uint16_t* __restrict__ out, int proj_w, int proj_h, int stride) {
+  const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= (u32)stride * (u32)proj_h) return;
+  const u32 v = i / (u32)stride, u = i - v * (u32)stride;
+  u32 o = 0xffffu;
+  if (u < (u32)proj_w) {
+    const u32 p = pix[v * (u32)proj_w + u];
+    if (p < 0xffffu) o = p;
+  }
+  out[i] = (uint16_t)o;
+}
+
+// CONSEC: thread (tx, ty) takes the PPT CONSECUTIVE pixels tx * PPT .. tx * PPT + PPT - 1 of its row (instead of tx + j * K2_TX): the
+// pixels' patch offsets come as ONE load from a u16 copy of the pixel table (k2_pix16, row stride pix_stride, 0xffff = no
+// target), the depths leave as ONE 8 / 16-byte store, the BGR bytes are packed into dwords before they are staged, and the
+// staged rows leave as 8 / 16-byte stores where the output's alignment allows: per item and wave 4 + 7 vector memory
+// instructions (PPT = 4) become 1 + 2.
+template <int PPT, bool CONSEC = false>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDesc* __restrict__ descs, const int4* __restrict__ k2_tiles,
-                                                                const u32* __restrict__ k2_pix, const uint2* __restrict__ dlut,
+                                                                const u32* __restrict__ k2_pix, const uint16_t* __restrict__ k2_pix16,
+                                                                int pix_stride, const uint2* __restrict__ dlut,
                                                                 K2PipeArgs a, int tile_cap, u32 n_frames, u32 grid_x, u32 grid_y,
                                                                 int n_lds) {
   // (the tables are kernel parameters of their own, __restrict__: block-uniform reads of them become scalar loads -- as members
@@ -92,14 +111,32 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
   uint4 K[K2P_UN];
   // the item's vector loads: patch quads (thread slot s -> column s >> 3, row octet s & 7; an octet outside the frame is not
   // loaded: it reads as zeros) and the pixels' offsets into the patch
-  const auto issue = [&](const Meta& m, u32 (&poff)[PPT]) {
+  constexpr int NP = CONSEC ? PPT / 2 : PPT;  // registers that hold a thread's patch offsets (CONSEC: u16 pairs)
+  const auto issue = [&](const Meta& m, u32 (&poff)[NP]) {
     const u32 tile_y = m.lin / grid_x, tile_x = m.lin - tile_y * grid_x;
     const int v = tile_y * K2_TY + ty;
+    if constexpr (CONSEC) {  // (poff[] holds the PPT u16 offsets packed in pairs; the rest of it stays ~0)
+      const int u0 = tile_x * K2_TW + tx * PPT;
+      const bool in_tab = u0 < pix_stride && v < a.proj_h;  // (pix_stride % 4 == 0: the thread's run lies inside the row or outside)
+      const XM_K2P_GLOBAL uint16_t* src = (const XM_K2P_GLOBAL uint16_t*)k2_pix16 + (__umul24((u32)v, (u32)pix_stride) + (u32)u0);
+      if constexpr (PPT == 4) {
+        uint2 w = make_uint2(~0u, ~0u);
+        if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint2*>(src);
+        poff[0] = w.x;
+        poff[1] = w.y;
+      } else {
+        static_assert(PPT == 2, "two or four pixels per thread");
+        u32 w = ~0u;
+        if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL u32*>(src);
+        poff[0] = w;
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int u = tile_x * K2_TW + tx + j * K2_TX;
-      const bool in_img = u < a.proj_w && v < a.proj_h;
-      poff[j] = in_img ? k2_pix[__umul24((u32)v, (u32)a.proj_w) + (u32)u] : ~0u;
+      for (int j = 0; j < PPT; ++j) {
+        const int u = tile_x * K2_TW + tx + j * K2_TX;
+        const bool in_img = u < a.proj_w && v < a.proj_h;
+        poff[j] = in_img ? k2_pix[__umul24((u32)v, (u32)a.proj_w) + (u32)u] : ~0u;
+      }
     }
     const XM_K2P_GLOBAL uint16_t* d16 = (const XM_K2P_GLOBAL uint16_t*)descs[m.f].key_frame;
     const int bx = m.rec.x, by = m.rec.y, oct = m.rec.w >> 3, nslot = m.rec.z << 3;
@@ -129,16 +166,16 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
     f += 1;
   }
   if (f >= n_frames) return;
-  u32 p0[PPT], p1[PPT];
+  u32 p0[NP], p1[NP];
   Meta m0 = meta_at(f, b), m1;
 #pragma unroll
-  for (int q = 0; q < PPT; ++q) p0[q] = p1[q] = ~0u;
+  for (int q = 0; q < NP; ++q) p0[q] = p1[q] = ~0u;
   if (m0.run) {
     issue(m0, p1);
     to_lds(m0);
   }
 #pragma unroll
-  for (int q = 0; q < PPT; ++q) p0[q] = p1[q];
+  for (int q = 0; q < NP; ++q) p0[q] = p1[q];
   advance(f, b);
   m1 = meta_at(f, b);
   if (m1.run) issue(m1, p1);
@@ -172,17 +209,19 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
 #pragma unroll
       for (int q = 0; q < PPT; ++q) {
         u32 best = 0;
-        if (p0[q] != ~0u) {
-          const uint16_t* p = tile + p0[q];
+        const u32 off_q = CONSEC ? (p0[q >> 1] >> ((q & 1) * 16)) & 0xffffu : p0[q];
+        if (off_q != (CONSEC ? 0xffffu : ~0u)) {
+          const uint16_t* p = tile + off_q;
 #pragma unroll
           for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
         }
-        e[q] = s_dlut[min(best, (u32)(n_lds - 1))];
+        if (best < (u32)n_lds) e[q] = s_dlut[best];
+        else e[q] = ((const XM_K2P_GLOBAL uint2*)dlut)[min(best, 65535u)];  // (a disparity beyond the LDS copy: x noise far off the scan; the wait drains the prefetch, rarely)
       }
     }
     k2p_lds_barrier();  // every pixel has sampled the patch: the next one may take its place
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {  // (pinned HERE: sunk behind the stores below, the copy would wait for them -- the counter is in order)
+    for (int q = 0; q < NP; ++q) {  // (pinned HERE: sunk behind the stores below, the copy would wait for them -- the counter is in order)
       p0[q] = p1[q];
       asm volatile("" : "+v"(p0[q]));
     }
@@ -203,43 +242,111 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
           if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
         }
       }
-      if (depth) {
+      if constexpr (CONSEC) {
+        const int u0 = tile_x * K2_TW + tx * PPT;
+        const bool vec_ok = (a.proj_w & (PPT - 1)) == 0;  // then the thread's run lies inside the row or outside, and is aligned
+        if (depth && v < a.proj_h) {
+          XM_K2P_GLOBAL float* dp = depth + (__umul24((u32)v, (u32)a.proj_w) + (u32)u0);
+          if (vec_ok) {
+            if (u0 < a.proj_w) {
+              if constexpr (PPT == 4) *reinterpret_cast<XM_K2P_GLOBAL uint4*>(dp) = make_uint4(e[0].x, e[1].x, e[2].x, e[3].x);
+              else *reinterpret_cast<XM_K2P_GLOBAL uint2*>(dp) = make_uint2(e[0].x, e[1].x);
+            }
+          } else {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-          const int u = tile_x * K2_TW + tx + q * K2_TX;
-          if (u < a.proj_w && v < a.proj_h) depth[__umul24((u32)v, (u32)a.proj_w) + (u32)u] = __uint_as_float(e[q].x);
-        }
-      }
-      if (bgr) {
-        const bool full_rows = (a.proj_w & 3) == 0 && (tile_x + 1) * K2_TW <= (u32)a.proj_w;
-        if (full_rows) {
-#pragma unroll
-          for (int q = 0; q < PPT; ++q) {
-            s_out[ty][(tx + q * K2_TX) * 3 + 0] = (uint8_t)(e[q].y & 0xff);
-            s_out[ty][(tx + q * K2_TX) * 3 + 1] = (uint8_t)((e[q].y >> 8) & 0xff);
-            s_out[ty][(tx + q * K2_TX) * 3 + 2] = (uint8_t)((e[q].y >> 16) & 0xff);
+            for (int q = 0; q < PPT; ++q)
+              if (u0 + q < a.proj_w) dp[q] = __uint_as_float(e[q].x);
           }
-          k2p_lds_barrier();
-          constexpr int DW = K2_TW * 3 / 4;
-#pragma unroll
-          for (int i0 = 0; i0 < K2_TY * DW; i0 += NT) {
-            const int i = i0 + tid;
-            if (i < K2_TY * DW) {
-              const int r = i / DW, qq = i - r * DW, vv = tile_y * K2_TY + r;
-              if (vv < a.proj_h)
-                reinterpret_cast<XM_K2P_GLOBAL u32*>(bgr + (size_t)((__umul24((u32)vv, (u32)a.proj_w) + tile_x * K2_TW) * 3u))[qq] =
-                    reinterpret_cast<const u32*>(&s_out[r][0])[qq];
+        }
+        if (bgr) {
+          // the row's bytes of this tile: valid_b of them inside the image.  Vector stores of VB bytes when the frame's rows, the
+          // tile's first byte and the valid run are all multiples of VB (VB = 16, 8 or 4)
+          const int px_in = min((int)K2_TW, a.proj_w - (int)(tile_x * K2_TW));
+          const u32 valid_b = (u32)px_in * 3u, row_b = (u32)a.proj_w * 3u;
+          const u32 algn = (u32)(size_t)bgr | row_b | valid_b;
+          {  // 3 bytes per pixel, packed: PPT = 4: 12 bytes = 3 dwords, PPT = 2: 6 bytes
+            u32* so = reinterpret_cast<u32*>(&s_out[ty][tx * PPT * 3]);
+            if constexpr (PPT == 4) {
+              so[0] = (e[0].y & 0xffffffu) | (e[1].y << 24);
+              so[1] = ((e[1].y >> 8) & 0xffffu) | (e[2].y << 16);
+              so[2] = ((e[2].y >> 16) & 0xffu) | (e[3].y << 8);
+            } else {
+              uint16_t* sh = reinterpret_cast<uint16_t*>(&s_out[ty][tx * 6]);
+              const u32 w0 = (e[0].y & 0xffffffu) | (e[1].y << 24);
+              sh[0] = (uint16_t)w0;
+              sh[1] = (uint16_t)(w0 >> 16);
+              sh[2] = (uint16_t)((e[1].y >> 8) & 0xffffu);
             }
           }
-        } else {
+          k2p_lds_barrier();
+          const u32 row0 = (__umul24((u32)(tile_y * K2_TY), (u32)a.proj_w) + tile_x * K2_TW) * 3u;  // byte offset of the tile's first row
+          if ((algn & 15u) == 0) {
+            constexpr int PER = K2_TW * 3 / 16;  // 16-byte words per staged row
+            for (int i = tid; i < K2_TY * PER; i += NT) {
+              const int r = i / PER, qq = i - r * PER;
+              if ((int)(tile_y * K2_TY) + r < a.proj_h && (u32)qq * 16u < valid_b)
+                *reinterpret_cast<XM_K2P_GLOBAL uint4*>(bgr + (size_t)(row0 + (u32)r * row_b + (u32)qq * 16u)) = reinterpret_cast<const uint4*>(&s_out[r][0])[qq];
+            }
+          } else if ((algn & 7u) == 0) {
+            constexpr int PER = K2_TW * 3 / 8;
+            for (int i = tid; i < K2_TY * PER; i += NT) {
+              const int r = i / PER, qq = i - r * PER;
+              if ((int)(tile_y * K2_TY) + r < a.proj_h && (u32)qq * 8u < valid_b)
+                *reinterpret_cast<XM_K2P_GLOBAL uint2*>(bgr + (size_t)(row0 + (u32)r * row_b + (u32)qq * 8u)) = reinterpret_cast<const uint2*>(&s_out[r][0])[qq];
+            }
+          } else if ((algn & 3u) == 0) {
+            constexpr int PER = K2_TW * 3 / 4;
+            for (int i = tid; i < K2_TY * PER; i += NT) {
+              const int r = i / PER, qq = i - r * PER;
+              if ((int)(tile_y * K2_TY) + r < a.proj_h && (u32)qq * 4u < valid_b)
+                *reinterpret_cast<XM_K2P_GLOBAL u32*>(bgr + (size_t)(row0 + (u32)r * row_b + (u32)qq * 4u)) = reinterpret_cast<const u32*>(&s_out[r][0])[qq];
+            }
+          } else {
+            for (int i = tid; i < K2_TY * (int)(K2_TW * 3); i += NT) {
+              const int r = i / (int)(K2_TW * 3), qq = i - r * (int)(K2_TW * 3);
+              if ((int)(tile_y * K2_TY) + r < a.proj_h && (u32)qq < valid_b) bgr[(size_t)(row0 + (u32)r * row_b + (u32)qq)] = s_out[r][qq];
+            }
+          }
+        }
+      } else {
+        if (depth) {
 #pragma unroll
           for (int q = 0; q < PPT; ++q) {
             const int u = tile_x * K2_TW + tx + q * K2_TX;
-            if (u < a.proj_w && v < a.proj_h) {
-              XM_K2P_GLOBAL uint8_t* bp = bgr + (u64)(__umul24((u32)v, (u32)a.proj_w) + (u32)u) * 3;
-              bp[0] = (uint8_t)(e[q].y & 0xff);
-              bp[1] = (uint8_t)((e[q].y >> 8) & 0xff);
-              bp[2] = (uint8_t)((e[q].y >> 16) & 0xff);
+            if (u < a.proj_w && v < a.proj_h) depth[__umul24((u32)v, (u32)a.proj_w) + (u32)u] = __uint_as_float(e[q].x);
+          }
+        }
+        if (bgr) {
+          const bool full_rows = (a.proj_w & 3) == 0 && (tile_x + 1) * K2_TW <= (u32)a.proj_w;
+          if (full_rows) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+              s_out[ty][(tx + q * K2_TX) * 3 + 0] = (uint8_t)(e[q].y & 0xff);
+              s_out[ty][(tx + q * K2_TX) * 3 + 1] = (uint8_t)((e[q].y >> 8) & 0xff);
+              s_out[ty][(tx + q * K2_TX) * 3 + 2] = (uint8_t)((e[q].y >> 16) & 0xff);
+            }
+            k2p_lds_barrier();
+            constexpr int DW = K2_TW * 3 / 4;
+#pragma unroll
+            for (int i0 = 0; i0 < K2_TY * DW; i0 += NT) {
+              const int i = i0 + tid;
+              if (i < K2_TY * DW) {
+                const int r = i / DW, qq = i - r * DW, vv = tile_y * K2_TY + r;
+                if (vv < a.proj_h)
+                  reinterpret_cast<XM_K2P_GLOBAL u32*>(bgr + (size_t)((__umul24((u32)vv, (u32)a.proj_w) + tile_x * K2_TW) * 3u))[qq] =
+                      reinterpret_cast<const u32*>(&s_out[r][0])[qq];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+              const int u = tile_x * K2_TW + tx + q * K2_TX;
+              if (u < a.proj_w && v < a.proj_h) {
+                XM_K2P_GLOBAL uint8_t* bp = bgr + (u64)(__umul24((u32)v, (u32)a.proj_w) + (u32)u) * 3;
+                bp[0] = (uint8_t)(e[q].y & 0xff);
+                bp[1] = (uint8_t)((e[q].y >> 8) & 0xff);
+                bp[2] = (uint8_t)((e[q].y >> 16) & 0xff);
+              }
             }
           }
         }

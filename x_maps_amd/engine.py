@@ -320,6 +320,12 @@ class XMapsEngine:
         return out
 
     # ---- debug: every per-event intermediate -------------------------------------------------------
+    def debug_k2_pipe_frames(self) -> int:
+        """tests: frames finished by the software-pipelined K2 since the engine was created"""
+        v = C.c_uint64(0)
+        N.check(self._lib.xm_debug_k2_pipe_frames(self._h, C.byref(v)))
+        return int(v.value)
+
     def debug_last_disp_frame(self) -> np.ndarray:
         """tests: A3's u16 disparity frame [rect_h][rect_w] of the last frame, when it took the column / owner tiles"""
         out = np.zeros((self.rect_h, self.rect_w), np.uint16)
