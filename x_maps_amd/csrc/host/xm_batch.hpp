@@ -148,7 +148,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       launch_k2_batch<0>(h, stream, d_descs, n_frames);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
-    if (key32) XM_LAUNCH(k_frame_cam32_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
+    if (key32) XM_LAUNCH(k_frame_cam32_batch, dim3(grid_for(h->tb.cam_w, CAM32_T), grid_for(h->tb.cam_h, CAM32_T), n_frames), dim3(BLOCK), 0, stream, d_descs, h->tb.cam_w, h->tb.cam_h, h->tb.dlut);
     else XM_LAUNCH(k_frame_direct_batch, dim3(grid_for(px, BLOCK), n_frames), dim3(BLOCK), 0, stream, d_descs, px, h->tb.dlut);
   }
   HIP_TRY(hipGetLastError());

@@ -85,9 +85,8 @@ void launch_frame_kernel(xm_handle* h, const u64* key_frame, SlotState* st, u32 
     XM_LAUNCH((k_frame_proj<KeyCells, 0>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, h->tb, st,
               tag_override, depth, bgr);
   } else if (key32) {  // camera view, compact frame: (event index + 1) << 12 | disparity, zeroed as it is read
-    const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
-    XM_LAUNCH(k_frame_cam32, dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, reinterpret_cast<u32*>(const_cast<u64*>(key_frame)), px, st,
-              h->tb.dlut, depth, bgr);
+    XM_LAUNCH(k_frame_cam32, dim3(grid_for(h->tb.cam_w, CAM32_T), grid_for(h->tb.cam_h, CAM32_T)), dim3(BLOCK), 0, stream,
+              reinterpret_cast<u32*>(const_cast<u64*>(key_frame)), h->tb.cam_w, h->tb.cam_h, st, h->tb.dlut, depth, bgr);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     XM_LAUNCH((k_frame_direct<KeyCells>), dim3(grid_for(px, BLOCK)), dim3(BLOCK), 0, stream, cells, px,

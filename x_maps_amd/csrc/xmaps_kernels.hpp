@@ -1227,6 +1227,7 @@ __device__ __forceinline__ void scatter_tiled_body(
       }
       if (write) {
         if constexpr (CAM32) {
+          cell = ex * (u32)tb.cam_h + ey;  // (the compact camera frame is column-major; event_cell has checked the pixel)
           __hip_atomic_fetch_max(reinterpret_cast<u32*>(frame) + cell,
                                  ((u32)(idx_offset + block_base + el + 1) << KEY32_DISP_BITS) | ((u32)r.disp & 0xfffu),
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1288,6 +1289,8 @@ __device__ __forceinline__ void scatter_tiled_body(
         n_oob += __popcll(__ballot(write && !in_frame));  // NumPy IndexError
         write = write && in_frame;
         slot[k] = tl[k] * tb.xmap_h + yr[k];
+      } else if constexpr (CAM32) {
+        slot[k] = xl[k] * tb.cam_h + (int)y[k];  // [window column][row], as the LUT band: the compact camera frame is column-major
       } else {
         slot[k] = (int)y[k] * w_x + xl[k];
       }
@@ -1323,7 +1326,7 @@ __device__ __forceinline__ void scatter_tiled_body(
     static_assert(KEY_IDX_SHIFT == 16, "slot value ((local idx + 1) << 16 | disp) is added to the key as is");
     // key = tag | (global idx << 16) | disp, and the slot holds ((local idx + 1) << 16) | disp: one 64-bit add
     const u64 key_base = key_hi + ((idx_offset + block_base - 1) << KEY_IDX_SHIFT);
-    const int per = VIEW == 0 ? tb.xmap_h : w_x;  // slots per window column (VIEW 0) / per camera row (VIEW 1)
+    const int per = VIEW == 0 ? tb.xmap_h : CAM32 ? tb.cam_h : w_x;  // slots per window column (VIEW 0, compact camera frame) / per camera row (VIEW 1)
     // (q, r) = divmod(slot, per), advanced incrementally: slot -> slot + nthreads is (q + dq, r + dr) with one carry
     const int dq = nthreads / per, dr = nthreads - dq * per;
     int q_i, r_i;
@@ -1358,6 +1361,8 @@ __device__ __forceinline__ void scatter_tiled_body(
             int fc = (int)(short)(xv[j] - tb.x_offset);
             if (fc < 0) fc += tb.rect_w;
             cell = (u32)fc * (u32)tb.rect_h + (u32)r;
+          } else if constexpr (CAM32) {  // q = window column, r = camera row: lanes walk consecutive rows of one column of the
+            cell = (u32)(x_lo + q) * (u32)tb.cam_h + (u32)r;  // column-major frame (64 lanes = 256 contiguous bytes)
           } else {  // q = camera row, r = x - x_lo
             cell = (u32)q * (u32)tb.cam_w + (u32)(x_lo + r);
           }
@@ -2246,40 +2251,80 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct_batch(const FrameDesc* _
 }
 
 // camera view on the compact key frame ((event index + 1) << 12 | disparity, 0 = no event): the pixel is zeroed once read, so
-// the next frame of the slot starts from an empty frame without a clear of its own
-__device__ __forceinline__ void frame_cam32_body(u32* __restrict__ frame32, u64 n_pixels, SlotState* st, const uint2* __restrict__ dlut,
-                                                 float* __restrict__ depth, uint8_t* __restrict__ bgr, const u32 blk) {
-  const u32 tag = st->tag_a;
-  if (blk == 0 && threadIdx.x < CNT_SLOTS) {
-    u32* c = st->cnt[(tag & 1) ^ 1][threadIdx.x];
+// the next frame of the slot starts from an empty frame without a clear of its own.  The frame is COLUMN-major
+// (u32[cam_w][cam_h]: K1's flush walks consecutive rows of one window column -- 64 lanes = 256 contiguous bytes per atomic
+// instruction instead of four 64-byte row pieces), the outputs are row-major: a block takes a 32 x 32-pixel tile, reads it
+// along the columns, hands the 12-bit disparities over through LDS and writes rows (128 bytes of depth, 96 of BGR per row).
+constexpr int CAM32_T = 32;
+__device__ __forceinline__ void frame_cam32_body(u32* __restrict__ frame32, const int cam_w, const int cam_h, SlotState* st,
+                                                 const uint2* __restrict__ dlut, float* __restrict__ depth, uint8_t* __restrict__ bgr,
+                                                 const u32 tile_x, const u32 tile_y) {
+  __shared__ uint16_t s_d[CAM32_T][CAM32_T + 2];
+  __shared__ __attribute__((aligned(16))) uint8_t s_b[CAM32_T][CAM32_T * 3];
+  const int tid = threadIdx.x, lo = tid & (CAM32_T - 1), hi = tid / CAM32_T;  // BLOCK / 32 = 8 columns (rows) per pass
+  if (tile_x == 0 && tile_y == 0 && tid < CNT_SLOTS) {
+    const u32 tag = st->tag_a;
+    u32* c = st->cnt[(tag & 1) ^ 1][tid];
     c[0] = c[1] = c[2] = c[3] = 0;
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       st->tag_b = tag;
       if (u32* hf = st->host_flags) host_flag_store(hf + 1, tag);
     }
   }
-  const u64 pixel = (u64)blk * BLOCK + threadIdx.x;
-  u32 k = 0;
-  if (pixel < n_pixels) {
-    k = frame32[pixel];
-    if (k) frame32[pixel] = 0u;
+  const int x0 = (int)tile_x * CAM32_T, y0 = (int)tile_y * CAM32_T;
+#pragma unroll
+  for (int i = 0; i < CAM32_T * CAM32_T / BLOCK; ++i) {  // lanes = consecutive rows of one frame column
+    const int c = hi + i * (BLOCK / CAM32_T), x = x0 + c, y = y0 + lo;
+    u32 k = 0;
+    if (x < cam_w && y < cam_h) {
+      u32* p = frame32 + (u32)x * (u32)cam_h + (u32)y;
+      k = *p;
+      if (k) *p = 0u;
+    }
+    s_d[c][lo] = (uint16_t)(k & 0xfffu);
   }
-  const uint2 e = dlut[k & 0xfffu];
-  if (depth && pixel < n_pixels) depth[pixel] = __uint_as_float(e.x);
-  if (bgr) store_bgr_block(bgr, (u64)blk * BLOCK, n_pixels, e.y);
+  __syncthreads();
+  const bool dw_rows = bgr && (cam_w & 3) == 0 && x0 + CAM32_T <= cam_w && ((size_t)bgr & 3) == 0;  // whole 96-byte rows, dword aligned
+#pragma unroll
+  for (int i = 0; i < CAM32_T * CAM32_T / BLOCK; ++i) {  // lanes = consecutive pixels of one output row
+    const int r = hi + i * (BLOCK / CAM32_T), x = x0 + lo, y = y0 + r;
+    const uint2 e = dlut[s_d[lo][r]];
+    if (x < cam_w && y < cam_h) {
+      const u32 pixel = (u32)y * (u32)cam_w + (u32)x;
+      if (depth) depth[pixel] = __uint_as_float(e.x);
+      if (bgr && !dw_rows) {
+        bgr[(size_t)pixel * 3 + 0] = (uint8_t)(e.y & 0xff);
+        bgr[(size_t)pixel * 3 + 1] = (uint8_t)((e.y >> 8) & 0xff);
+        bgr[(size_t)pixel * 3 + 2] = (uint8_t)((e.y >> 16) & 0xff);
+      }
+    }
+    if (dw_rows) {
+      s_b[r][lo * 3 + 0] = (uint8_t)(e.y & 0xff);
+      s_b[r][lo * 3 + 1] = (uint8_t)((e.y >> 8) & 0xff);
+      s_b[r][lo * 3 + 2] = (uint8_t)((e.y >> 16) & 0xff);
+    }
+  }
+  if (dw_rows) {
+    __syncthreads();
+    constexpr int DW = CAM32_T * 3 / 4;  // dwords per staged row
+    for (int i = tid; i < CAM32_T * DW; i += BLOCK) {
+      const int r = i / DW, q = i - r * DW, y = y0 + r;
+      if (y < cam_h) reinterpret_cast<u32*>(bgr + ((size_t)y * (size_t)cam_w + (size_t)x0) * 3)[q] = reinterpret_cast<const u32*>(&s_b[r][0])[q];
+    }
+  }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_frame_cam32(u32* __restrict__ frame32, u64 n_pixels, SlotState* st,
+__global__ __launch_bounds__(BLOCK) void k_frame_cam32(u32* __restrict__ frame32, int cam_w, int cam_h, SlotState* st,
                                                        const uint2* __restrict__ dlut, float* __restrict__ depth,
                                                        uint8_t* __restrict__ bgr) {
-  frame_cam32_body(frame32, n_pixels, st, dlut, depth, bgr, blockIdx.x);
+  frame_cam32_body(frame32, cam_w, cam_h, st, dlut, depth, bgr, blockIdx.x, blockIdx.y);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_frame_cam32_batch(const FrameDesc* __restrict__ descs, u64 n_pixels,
+__global__ __launch_bounds__(BLOCK) void k_frame_cam32_batch(const FrameDesc* __restrict__ descs, int cam_w, int cam_h,
                                                              const uint2* __restrict__ dlut) {
-  const FrameDesc d = descs[blockIdx.y];
+  const FrameDesc d = descs[blockIdx.z];
   if (!d.valid) return;
-  frame_cam32_body(reinterpret_cast<u32*>(d.key_frame), n_pixels, d.st, dlut, d.depth, d.bgr, blockIdx.x);
+  frame_cam32_body(reinterpret_cast<u32*>(d.key_frame), cam_w, cam_h, d.st, dlut, d.depth, d.bgr, blockIdx.x, blockIdx.y);
 }
 
 // Sharded frames: a chunk of the (reduced) packed-key frame -> u16 disparities (0 where the tag differs): 2 instead of 8
