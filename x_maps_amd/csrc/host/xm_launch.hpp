@@ -182,6 +182,7 @@ size_t k2_pipe_lds_bytes(const xm_handle* h, int g) {
   return (size_t)((h->k2_tile_cap[g] + 32 + 7) & ~7) * sizeof(uint16_t) + (size_t)h->k2_pipe_nlds * sizeof(uint2);
 }
 
+template <int COND = 0>
 bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
   if (!h->k2_pipe || !h->k2_pipe_rig_ok || h->k2_pipe_nlds < 1 || (k2_ppt(h, n_frames) != 2 && !h->k2_pipe_force)) return false;
   const int g = h->k2_pipe4 ? 2 : 1, ppt = 1 << g;
@@ -193,14 +194,14 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
   if (total < 3ull * blocks && !h->k2_pipe_force) return false;  // too few items per block for the pipeline to matter: one block per tile
   blocks = (unsigned)std::min<u64>(blocks, std::max<u64>(total, 1));
   const bool cs = (h->k2_consec < 0 ? g == 2 : h->k2_consec != 0) && h->d_k2_pix16[g];  // default: consecutive pixels on the 64 x 16 tiles
-  const void* fn = g == 2 ? (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<4, true>) : reinterpret_cast<const void*>(k_frame_proj_pipe<4, false>))
-                          : (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<2, true>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2, false>));
+  const void* fn = g == 2 ? (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<4, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<4, false, COND>))
+                          : (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<2, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2, false, COND>));
   if (h->ensure_lds(fn, lds) != XM_OK) return false;
   K2PipeArgs pa;
   pa.proj_w = h->tb.proj_w; pa.proj_h = h->tb.proj_h; pa.rect_w = h->tb.rect_w; pa.rect_h = h->tb.rect_h;
   pa.shear_m = h->tb.shear_m; pa.shear_bias = h->tb.shear_bias;
 #define XM_K2P_LAUNCH(P, C)                                                                                                          \
-  XM_LAUNCH((k_frame_proj_pipe<P, C>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[g],      \
+  XM_LAUNCH((k_frame_proj_pipe<P, C, COND>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[g],      \
             (const u32*)h->d_k2_pix[g], (const uint16_t*)h->d_k2_pix16[g], h->k2_pix_stride, h->tb.dlut, pa, h->k2_tile_cap[g],      \
             (u32)n_frames, gx, gy, h->k2_pipe_nlds)
   if (g == 2) {
@@ -217,8 +218,8 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
 
 template <int FMT, int COND = 0>
 void launch_k2_batch(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames) {
-  if constexpr (FMT == 2 && COND == 0) {
-    if (launch_k2_pipe(h, stream, d_descs, n_frames)) return;
+  if constexpr (FMT == 2 && (COND == 0 || COND == 2)) {  // (COND = 2: the attempt's K2 node of a captured batch)
+    if (launch_k2_pipe<COND>(h, stream, d_descs, n_frames)) return;
   }
   const int ppt = k2_ppt(h, n_frames);
   dim3 grid(grid_for(h->tb.proj_w, K2_TX * ppt), grid_for(h->tb.proj_h, K2_TY), n_frames);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void k_k2_pix_to_u16(const u32* __restrict__
 // target), the depths leave as ONE 8 / 16-byte store, the BGR bytes are packed into dwords before they are staged, and the
 // staged rows leave as 8 / 16-byte stores where the output's alignment allows: per item and wave 4 + 7 vector memory
 // instructions (PPT = 4) become 1 + 2.
-template <int PPT, bool CONSEC = false>
+template <int PPT, bool CONSEC = false, int COND = 0>
 __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDesc* __restrict__ descs, const int4* __restrict__ k2_tiles,
                                                                 const u32* __restrict__ k2_pix, const uint16_t* __restrict__ k2_pix16,
                                                                 int pix_stride, const uint2* __restrict__ dlut,
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
     m.rec = make_int4(0, 0, 0, 0);
     if (m.run) {
       m.rec = k2_tiles[m.lin];
-      m.run = descs[f].valid != 0;
+      m.run = descs[f].valid != 0 && !frame_skipped<COND>(descs[f].st);  // (COND = 2, captured batches: only frames whose attempt held)
     }
     return m;
   };
