@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 out = os.path.join(ROOT, "gpurun_out", tag + "_profiles")
 os.makedirs(out, exist_ok=True)
-SKIP = ("reset", "build_dlut", "k2_tables", "cols_check", "build_x_map", "rocclr", "at::native", "elementwise", "Rccl", "rccl", "ncclDev")
+SKIP = ("reset", "build_dlut", "k2_tables", "pix_to_u16", "cols_check", "build_x_map", "rocclr", "at::native", "elementwise", "Rccl", "rccl", "ncclDev")
 
 
 def short(n):
