@@ -65,7 +65,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
                                                                 const u32* __restrict__ k2_pix, const uint16_t* __restrict__ k2_pix16,
                                                                 int pix_stride, const uint2* __restrict__ dlut,
                                                                 K2PipeArgs a, int tile_cap, u32 n_frames, u32 grid_x, u32 grid_y,
-                                                                int n_lds) {
+                                                                int n_lds, u32 gx_magic) {
   // (the tables are kernel parameters of their own, __restrict__: block-uniform reads of them become scalar loads -- as members
   //  of a struct they were vector loads, each with a full wait in front of the prefetch.  Pointers read from a frame descriptor
   //  are cast to the global address space: generic ones make FLAT loads / stores, which count against the LDS counter too, and
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
   //      last loads and stores, one reduce + sample phase old -- nothing that was issued just now.
   struct Meta {
     int4 rec;
-    u32 f, lin;
+    u32 f, lin, tile_x, tile_y;
     bool run;
   };
   const auto meta_at = [&](u32 f, u32 b) {
@@ -94,6 +94,10 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
     m.f = f;
     m.run = f < n_frames;
     m.lin = xcd_contiguous(b, tpf);
+    // (tile_y, tile_x) = divmod(lin, grid_x) once per item, by a multiply: gx_magic = ceil(2^32 / grid_x) is exact for
+    // lin * grid_x < 2^32 (the host passes 0 otherwise)
+    m.tile_y = gx_magic ? __umulhi(m.lin, gx_magic) : m.lin / grid_x;
+    m.tile_x = m.lin - m.tile_y * grid_x;
     m.rec = make_int4(0, 0, 0, 0);
     if (m.run) {
       m.rec = k2_tiles[m.lin];
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
   // loaded: it reads as zeros) and the pixels' offsets into the patch
   constexpr int NP = CONSEC ? PPT / 2 : PPT;  // registers that hold a thread's patch offsets (CONSEC: u16 pairs)
   const auto issue = [&](const Meta& m, u32 (&poff)[NP]) {
-    const u32 tile_y = m.lin / grid_x, tile_x = m.lin - tile_y * grid_x;
+    const u32 tile_y = m.tile_y, tile_x = m.tile_x;
     const int v = tile_y * K2_TY + ty;
     if constexpr (CONSEC) {  // (poff[] holds the PPT u16 offsets packed in pairs; the rest of it stays ~0)
       const int u0 = tile_x * K2_TW + tx * PPT;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       const FrameDesc& d = descs[m0.f];
       XM_K2P_GLOBAL float* depth = (XM_K2P_GLOBAL float*)d.depth;
       XM_K2P_GLOBAL uint8_t* bgr = (XM_K2P_GLOBAL uint8_t*)d.bgr;
-      const u32 tile_y = m0.lin / grid_x, tile_x = m0.lin - tile_y * grid_x;
+      const u32 tile_y = m0.tile_y, tile_x = m0.tile_x;
       const int v = tile_y * K2_TY + ty;
       if (m0.lin == 0 && tid < CNT_SLOTS) {  // re-arm the frame's next counters (as frame_proj_tiled_body)
         XM_K2P_GLOBAL SlotState* st = (XM_K2P_GLOBAL SlotState*)d.st;
