@@ -38,9 +38,8 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->cfg.n_slots = n_slots;
   h->time_sorted = (cfg->flags & XM_FLAG_TIME_SORTED) != 0;
   // default: the verified (t[0], t[n-1]) shortcut with automatic redo (exact for any event order); XM_FLAG_GENERAL forces the
-  // extrema pass on every frame; XM_GENERAL=1 in the environment does the same (experiments)
-  const char* eg = getenv("XM_GENERAL");
-  h->try_sorted = !h->time_sorted && !(cfg->flags & XM_FLAG_GENERAL) && !(eg && eg[0] == '1');
+  // extrema pass on every frame
+  h->try_sorted = !h->time_sorted && !(cfg->flags & XM_FLAG_GENERAL);
   h->cfg.xmap_height = xmap_h;
   if ((cfg->flags & XM_FLAG_ADAPTIVE_BATCH) && n_slots >= 8) h->ab_max = std::min(n_slots / 4, 32);  // (four groups' worth of slots)
 
@@ -232,7 +231,6 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     // the compact key frame orders the writers of a cell by TILE only: two time columns of one tile that share a cell would be
     // ordered by their disparity bits -- it needs the same property (the 64-bit keys carry the full event index and do not)
     if (cfg->view == XM_VIEW_PROJECTOR) h->key32_ok = h->key32_ok && injective;
-    if (const char* e = getenv("XM_COLS_TARGET")) h->cols_target = std::max(256, atoi(e));
   }
   if (cfg->view == XM_VIEW_PROJECTOR) {
     h->key_cells = (size_t)cfg->rect_width * cfg->rect_height;

@@ -91,8 +91,6 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
   g->h = h;
   g->n_frames = n_frames;
   g->frames_on_slot.assign(ns, 0);
-  const size_t px = (size_t)h->out_w * h->out_h;
-  const size_t tsz = t_size(t_dtype);
   struct Saved {
     u32 host_tag, api_tag;
     bool any_frame, last_sorted;
@@ -116,54 +114,7 @@ int xm_graph_create(xm_handle* h, const uint16_t* x, const uint16_t* y, const vo
       }
     }
   }
-  static const bool per_frame = getenv("XM_GRAPH_PER_FRAME") && getenv("XM_GRAPH_PER_FRAME")[0] == '1';
-  int rc = XM_OK;
-  if (!per_frame) {
-    rc = graph_capture_batched(h, g, x, y, t, p, t_dtype, offsets_host, n_frames, depth_out, bgr_out);
-  } else {
-    for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);  // enqueue_frame launches on slot.stream
-    hipStream_t origin = h->slots[0].stream;
-    h->capturing = true;
-    hipError_t e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) {
-      h->capturing = false;
-      for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
-      delete g;
-      return fail(XM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
-    }
-    do {
-      if (ns > 1) {
-        if ((e = hipEventRecord(h->fork_ev, origin)) != hipSuccess) break;
-        for (int i = 1; i < ns; ++i)
-          if ((e = hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0)) != hipSuccess) break;
-        if (e != hipSuccess) break;
-      }
-      for (int f = 0; f < n_frames && rc == XM_OK; ++f) {
-        Slot& s = h->slots[f % ns];
-        EventsView ev;
-        const u64 a = offsets_host[f], b = offsets_host[f + 1];
-        ev.x = x + a; ev.y = y + a; ev.t = (const char*)t + a * tsz; ev.p = p ? p + a : nullptr;
-        ev.n = (size_t)(b - a); ev.t_dtype = t_dtype; ev.use_p = p != nullptr;
-        if ((rc = check_events(ev))) break;
-        // tags inside a graph advance on the device; keep the host mirror from triggering a reset mid-capture
-        s.host_tag = 0;
-        rc = enqueue_frame(h, s, ev, depth_out ? depth_out + f * px : nullptr, bgr_out ? bgr_out + f * px * 3 : nullptr,
-                           nullptr);
-        g->frames_on_slot[f % ns] += 1;
-      }
-      if (ns > 1) {
-        for (int i = 1; i < ns; ++i) {
-          if ((e = hipEventRecord(h->join_ev[i], h->slots[i].stream)) != hipSuccess) break;
-          if ((e = hipStreamWaitEvent(origin, h->join_ev[i], 0)) != hipSuccess) break;
-        }
-      }
-    } while (0);
-    hipError_t e2 = hipStreamEndCapture(origin, &g->graph);
-    h->capturing = false;
-    for (int i = 0; i < ns; ++i) std::swap(h->slots[i].stream, h->gstreams[i]);
-    if (rc == XM_OK && (e != hipSuccess || e2 != hipSuccess))
-      rc = fail(XM_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-  }
+  int rc = graph_capture_batched(h, g, x, y, t, p, t_dtype, offsets_host, n_frames, depth_out, bgr_out);
   for (int i = 0; i < ns; ++i) {  // capture only recorded launches: the slots are where they were
     Slot& s = h->slots[i];
     s.host_tag = saved[i].host_tag; s.api_tag = saved[i].api_tag; s.any_frame = saved[i].any_frame;
