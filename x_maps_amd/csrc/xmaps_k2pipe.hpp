@@ -123,13 +123,20 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       const int u0 = tile_x * K2_TW + tx * PPT;
       const bool in_tab = u0 < pix_stride && v < a.proj_h;  // (pix_stride % 4 == 0: the thread's run lies inside the row or outside)
       const XM_K2P_GLOBAL uint16_t* src = (const XM_K2P_GLOBAL uint16_t*)k2_pix16 + (__umul24((u32)v, (u32)pix_stride) + (u32)u0);
-      if constexpr (PPT == 4) {
+      if constexpr (PPT == 8) {
+        uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(src);
+        poff[0] = w.x;
+        poff[1] = w.y;
+        poff[2] = w.z;
+        poff[3] = w.w;
+      } else if constexpr (PPT == 4) {
         uint2 w = make_uint2(~0u, ~0u);
         if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint2*>(src);
         poff[0] = w.x;
         poff[1] = w.y;
       } else {
-        static_assert(PPT == 2, "two or four pixels per thread");
+        static_assert(PPT == 2, "two, four or eight pixels per thread");
         u32 w = ~0u;
         if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL u32*>(src);
         poff[0] = w;
@@ -253,8 +260,13 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
           XM_K2P_GLOBAL float* dp = depth + (__umul24((u32)v, (u32)a.proj_w) + (u32)u0);
           if (vec_ok) {
             if (u0 < a.proj_w) {
-              if constexpr (PPT == 4) *reinterpret_cast<XM_K2P_GLOBAL uint4*>(dp) = make_uint4(e[0].x, e[1].x, e[2].x, e[3].x);
-              else *reinterpret_cast<XM_K2P_GLOBAL uint2*>(dp) = make_uint2(e[0].x, e[1].x);
+              if constexpr (PPT >= 4) {
+#pragma unroll
+                for (int q = 0; q < PPT; q += 4)
+                  reinterpret_cast<XM_K2P_GLOBAL uint4*>(dp)[q >> 2] = make_uint4(e[q].x, e[q + 1].x, e[q + 2].x, e[q + 3].x);
+              } else {
+                *reinterpret_cast<XM_K2P_GLOBAL uint2*>(dp) = make_uint2(e[0].x, e[1].x);
+              }
             }
           } else {
 #pragma unroll
@@ -268,12 +280,19 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
           const int px_in = min((int)K2_TW, a.proj_w - (int)(tile_x * K2_TW));
           const u32 valid_b = (u32)px_in * 3u, row_b = (u32)a.proj_w * 3u;
           const u32 algn = (u32)(size_t)bgr | row_b | valid_b;
-          {  // 3 bytes per pixel, packed: PPT = 4: 12 bytes = 3 dwords, PPT = 2: 6 bytes
-            u32* so = reinterpret_cast<u32*>(&s_out[ty][tx * PPT * 3]);
-            if constexpr (PPT == 4) {
-              so[0] = (e[0].y & 0xffffffu) | (e[1].y << 24);
-              so[1] = ((e[1].y >> 8) & 0xffffu) | (e[2].y << 16);
-              so[2] = ((e[2].y >> 16) & 0xffu) | (e[3].y << 8);
+          {  // 3 bytes per pixel, packed: PPT = 8 / 4: 24 / 12 bytes = 6 / 3 dwords, PPT = 2: 6 bytes
+            if constexpr (PPT >= 4) {  // byte n of the thread's run = byte n % 3 of pixel n / 3: PPT * 3 / 4 whole dwords
+              u32* so = reinterpret_cast<u32*>(&s_out[ty][tx * PPT * 3]);
+#pragma unroll
+              for (int d = 0; d < PPT * 3 / 4; ++d) {
+                u32 w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                  const int n = 4 * d + b;
+                  w |= ((e[n / 3].y >> (8 * (n % 3))) & 0xffu) << (8 * b);
+                }
+                so[d] = w;
+              }
             } else {
               uint16_t* sh = reinterpret_cast<uint16_t*>(&s_out[ty][tx * 6]);
               const u32 w0 = (e[0].y & 0xffffffu) | (e[1].y << 24);
