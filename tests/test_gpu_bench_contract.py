@@ -43,6 +43,15 @@ def test_default_line_as_the_driver_calls_it():
     assert d["host_path"]["meets_north_star_1_Gevent_per_s_end_to_end"] and d["ingest_path"]["first_frame_depth_equals_oracle"]
 
 
+def test_the_default_line_carries_the_other_engine_settings():
+    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path")
+    om = d["other_modes"]
+    for k in ("eventcd_records", "one_frame_per_call", "one_frame_per_call_eager", "forced_general", "camera_view"):
+        assert om[k]["value"] > 1000 and om[k]["unit"] == "Mevents/s", k
+    # the reference's own input layout (Metavision's 16-byte EventCD records) through xm_process_batch_aos
+    assert om["eventcd_records"]["depth_equals_oracle"] and om["eventcd_records"]["k1_paths"]["cols"] > 0
+
+
 def test_one_frame_per_call_mode_still_prints_the_line():
     # without adaptive batching every frame is three launches of its own (compact key frame for lone C-1M frames)
     d = _run("--batch", "0", "--no-adaptive", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
