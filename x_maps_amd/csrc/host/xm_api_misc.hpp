@@ -27,15 +27,31 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
       rc = fail(XM_ERR_HIP, "xm_build_x_map: %s", hipGetErrorString(e));
       break;
     }
-    const size_t lds = (size_t)width * sizeof(double);
-    if (lds > 64 * 1024 &&
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_x_map), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds)) != hipSuccess) {
-      rc = fail(XM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      break;
+    int wp = 2;
+    while (wp < width) wp <<= 1;
+    const char* es = getenv("XM_XMAP_SCAN");  // tests: XM_XMAP_SCAN=1 takes the exhaustive scan (read at every call)
+    const bool brute = es && es[0] == '1';
+    if (wp <= 8192 && !brute) {  // rows of up to 8192 columns: the sorted-row kernel (96 KB of LDS at most)
+      const size_t lds = (size_t)wp * sizeof(u64) + (size_t)width * sizeof(float);
+      if (lds > 64 * 1024 &&
+          (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_x_map_sorted), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds)) != hipSuccess) {
+        rc = fail(XM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        break;
+      }
+      hipLaunchKernelGGL(k_build_x_map_sorted, dim3(height), dim3(BLOCK), lds, 0, d_in, height, width, wp, x_map_width, t_px_scale,
+                         x_offset, 2.0 / (double)num_scanlines, d_x, d_d);
+    } else {
+      const size_t lds = (size_t)width * sizeof(double);
+      if (lds > 64 * 1024 &&
+          (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_x_map), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds)) != hipSuccess) {
+        rc = fail(XM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        break;
+      }
+      hipLaunchKernelGGL(k_build_x_map, dim3(height), dim3(BLOCK), lds, 0, d_in, height, width, x_map_width, t_px_scale,
+                         x_offset, 2.0 / (double)num_scanlines, d_x, d_d);
     }
-    hipLaunchKernelGGL(k_build_x_map, dim3(height), dim3(BLOCK), lds, 0, d_in, height, width, x_map_width, t_px_scale,
-                       x_offset, 2.0 / (double)num_scanlines, d_x, d_d);
     if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
         (e = hipMemcpy(x_map_out, d_x, n_out * 2, hipMemcpyDeviceToHost)) != hipSuccess ||
         (t_diffs_out && (e = hipMemcpy(t_diffs_out, d_d, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess)) {

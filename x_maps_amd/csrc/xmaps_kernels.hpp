@@ -2553,6 +2553,131 @@ __global__ __launch_bounds__(BLOCK) void k_build_x_map(const float* __restrict__
   }
 }
 
+// The same result from a sorted row (round 3): argmin_x |t - m[x]| with the FIRST minimum winning only depends on the row's defined
+// values in sorted order, so the block sorts (value, x) pairs once (bitonic sort in LDS on 48-bit keys: the f32 value in an
+// order-preserving encoding, then x -- equal values keep their smallest x in front) and every time column takes a few binary
+// searches instead of a scan of the whole row: the nearest value at or above t and the nearest below it, each represented by
+// its first x; the distances are the very fabs(t - m) of the scan, in FP64.  Ties: equal distances from both sides -> the
+// smaller x, as the scan order would have it.  Two DIFFERENT values whose distances round to the same double (values many
+// orders of magnitude below t) could hide a smaller x further out: the neighbouring distinct value on either side is checked
+// and such a column is scanned like before (so is a row with a NaN).  H W log W + H W_t log W instead of H W_t W.
+__device__ __forceinline__ u32 xmap_f32_key(float m) {
+  const u32 b = __float_as_uint(m);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ double xmap_key_val(u64 key) {
+  const u32 k = (u32)(key >> 16);
+  const u32 b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return (double)__uint_as_float(b);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_build_x_map_sorted(const float* __restrict__ time_map, int height, int width, int wp,
+                                                              int x_map_width, int t_px_scale, int x_offset, double max_t_diff,
+                                                              int16_t* __restrict__ x_map, float* __restrict__ t_diffs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* keys = reinterpret_cast<u64*>(smem);              // [wp] (wp = power of two >= width)
+  float* row = reinterpret_cast<float*>(keys + wp);      // [width], in scan order (the fallback)
+  __shared__ int s_nan, s_ndef;
+  const int y = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_nan = s_ndef = 0;
+  __syncthreads();
+  int my_def = 0;
+  bool my_nan = false;
+  for (int x = tid; x < wp; x += BLOCK) {
+    u64 k = ~0ull;
+    if (x < width) {
+      const float m = time_map[(size_t)y * width + x];
+      row[x] = m;
+      my_nan = my_nan || m != m;
+      if (m != 0.0f && m == m) {
+        k = ((u64)xmap_f32_key(m) << 16) | (u64)(u32)x;
+        my_def += 1;
+      }
+    }
+    keys[x] = k;
+  }
+  if (my_def) atomicAdd(&s_ndef, my_def);
+  if (my_nan) s_nan = 1;
+  __syncthreads();
+  for (int size = 2; size <= wp; size <<= 1)  // bitonic sort, ascending
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (wp >> 1); i += BLOCK) {
+        const int lo = ((i / stride) * stride << 1) + (i % stride), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const u64 a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  const int n_def = s_ndef;
+  const bool scan_all = s_nan != 0;
+  const auto lower = [&](int lo, int hi, double v) {  // first index in [lo, hi) whose value is >= v
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (xmap_key_val(keys[mid]) >= v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  const auto upper = [&](int lo, int hi, double v) {  // first index in [lo, hi) whose value is > v
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (xmap_key_val(keys[mid]) > v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  for (int c = tid; c < x_map_width; c += BLOCK) {
+    int16_t out = 0;
+    float out_d = 0.0f;
+    const double t = (double)c / (double)t_px_scale;
+    if (t != 0.0 && (n_def > 0 || scan_all)) {
+      double best = __builtin_inf();
+      int best_x = -1;
+      bool scan = scan_all;
+      if (!scan) {
+        const int i = lower(0, n_def, t);
+        if (i < n_def) {
+          const double m_hi = xmap_key_val(keys[i]);
+          best = fabs(t - m_hi);
+          best_x = (int)(keys[i] & 0xffffull);
+          const int e = upper(i, n_def, m_hi);
+          if (e < n_def && fabs(t - xmap_key_val(keys[e])) == best) scan = true;
+        }
+        if (i > 0) {
+          const double m_lo = xmap_key_val(keys[i - 1]);
+          const int j = lower(0, i, m_lo);
+          const double d_lo = fabs(t - m_lo);
+          const int x_lo = (int)(keys[j] & 0xffffull);
+          if (j > 0 && fabs(t - xmap_key_val(keys[j - 1])) == d_lo) scan = true;
+          if (d_lo < best || (d_lo == best && x_lo < best_x)) {
+            best = d_lo;
+            best_x = x_lo;
+          }
+        }
+      }
+      if (scan) {  // the scan of k_build_x_map
+        best = __builtin_inf();
+        best_x = -1;
+        for (int x = 0; x < width; ++x) {
+          const double m = (double)row[x];
+          const double d = fabs(t - m);
+          const bool take = (m != 0.0) && (d < best);
+          best = take ? d : best;
+          best_x = take ? x : best_x;
+        }
+      }
+      if (best_x != -1 && best <= max_t_diff) {
+        out = (int16_t)(best_x + x_offset);
+        out_d = (float)best;
+      }
+    }
+    x_map[(size_t)y * x_map_width + c] = out;
+    if (t_diffs) t_diffs[(size_t)y * x_map_width + c] = out_d;
+  }
+}
+
 // =====================================================================================================
 // N3: per-frame de-duplication filters, reference python/frame_event_filter.py:19-128.
 //   LastEventPerXY / FirstEventPerXY / MeanFirstLastEventPerXY: one output event per camera pixel that fired, carrying
