@@ -2,7 +2,7 @@
 python/disp_to_depth.py:7-97) that groups of frames take on the u16 disparity frame of the column / owner tiles.  The suite's
 rigs are too small for it by default (fewer than three items per persistent block keep the one-block-per-tile kernel), so
 XM_K2_PIPE=2 sends every group there; xm_debug_k2_pipe_frames confirms it.  Checked against the CPU oracle, bit for bit, in
-every variant of the kernel: two / four / eight pixels per thread, strided / consecutive pixel assignment (u16 pixel table, 8 / 16-byte
+every variant of the kernel: two / four pixels per thread, strided / consecutive pixel assignment (u16 pixel table, 8 / 16-byte
 depth stores, packed BGR rows), projector widths that are / are not multiples of 4, 8, 16 and of the tile width (every BGR store
 width and the partial last tile), the per-disparity table in LDS cut short (larger disparities read the global table), depth only /
 BGR only, output rows at odd addresses."""
@@ -26,8 +26,11 @@ def _rig(kind, proj_w):
         cfg = S.RigConfig("k2p-own", 160, 128, proj_w, 120, 40_000)  # (rect_h = 352: the pipelined loader needs a multiple of 8)
         return cfg, S.make_tables_shared_cells(cfg, cols_per_cell=proj_w / 82.0)
     if kind == "fine":  # a projector finer than the rectified frame (0.7 cells per pixel, as the reference's ESL rig): small patches,
-        cfg = S.RigConfig("k2p-fine", 160, 128, proj_w, 256, 60_000)  # the rigs that take 64 / 128 x 16-pixel tiles by default
+        cfg = S.RigConfig("k2p-fine", 160, 128, proj_w, 256, 60_000)  # the rigs that take 64 x 16-pixel tiles by default
         return cfg, S.make_tables_shared_cells(cfg, cols_per_cell=2.0, slant=0.0)
+    if kind == "tall":  # a coarse projector: patches of 9 - 10 row octets (the loader takes the patch in memory order, <= 128 rows)
+        cfg = S.RigConfig("k2p-tall", 160, 128, proj_w, 96, 60_000)
+        return cfg, S.make_tables(cfg)
     cfg = S.RigConfig("k2p-cols", 160, 128, proj_w, 128, 60_000)  # 1.3 cells per time column: column tiles; patches of <= 64 rows
     return cfg, S.make_tables(cfg)
 
@@ -49,9 +52,9 @@ def _check_group(tb, cfg, n_frames=5, **kw):
 
 
 @pytest.mark.parametrize("consec", ["0", "1"])
-@pytest.mark.parametrize("ppt", ["2", "4", "8"])  # (8: 128 x 16 tiles where the patches fit -- the "fine" rigs -- else 4)
+@pytest.mark.parametrize("ppt", ["2", "4"])
 @pytest.mark.parametrize("kind,proj_w", [("cols", 256), ("cols", 264), ("cols", 260), ("cols", 250), ("own", 270), ("own", 320),
-                                         ("fine", 640), ("fine", 600), ("fine", 604), ("fine", 570)])
+                                         ("fine", 640), ("fine", 600), ("fine", 604), ("fine", 570), ("tall", 256)])
 def test_every_variant_against_the_oracle(monkeypatch, kind, proj_w, ppt, consec):
     monkeypatch.setenv("XM_K2_PIPE", "2")
     monkeypatch.setenv("XM_K2_PIPE_PPT", ppt)
@@ -60,7 +63,7 @@ def test_every_variant_against_the_oracle(monkeypatch, kind, proj_w, ppt, consec
     assert _check_group(tb, cfg) == 10
 
 
-def test_a_fine_projector_takes_the_widest_tiles_by_default(monkeypatch):
+def test_a_fine_projector_takes_the_wide_tiles_by_default(monkeypatch):
     monkeypatch.setenv("XM_K2_PIPE", "2")
     cfg, tb = _rig("fine", 640)
     assert _check_group(tb, cfg, n_frames=3) == 6

@@ -109,16 +109,15 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets, for both of its geometries
     if (const char* e = getenv("XM_K2_PPT")) h->k2_force_ppt = atoi(e);
     double mean_cells2 = 0.0;
-    bool pipe_ok_g[4] = {false, false, false, false};
-    for (int g = 0; g < 4; ++g) {
+    bool pipe_ok_g[3] = {false, false, false};
+    for (int g = 0; g < 3; ++g) {
       const int ppt = 1 << g;
       const unsigned tiles_x = grid_for(cfg->proj_width, K2_TX * ppt), tiles_y = grid_for(cfg->proj_height, K2_TY);
       XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_tiles[g], (size_t)tiles_x * tiles_y * sizeof(int4)));
       XM_TRY_CREATE(hipMalloc((void**)&h->d_k2_pix[g], (size_t)cfg->proj_width * cfg->proj_height * sizeof(u32)));
       if (g == 0) hipLaunchKernelGGL(k_build_k2_tables<1>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
       else if (g == 1) hipLaunchKernelGGL(k_build_k2_tables<2>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
-      else if (g == 2) hipLaunchKernelGGL(k_build_k2_tables<4>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
-      else hipLaunchKernelGGL(k_build_k2_tables<8>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
+      else hipLaunchKernelGGL(k_build_k2_tables<4>, dim3(tiles_x, tiles_y), dim3(K2_TX * K2_TY), 0, 0, h->tb, h->d_k2_tiles[g], h->d_k2_pix[g]);
       XM_TRY_CREATE(hipGetLastError());
       if (g > 0) {  // the pipelined kernel's u16 copy
         h->k2_pix_stride = (cfg->proj_width + 7) & ~7;
@@ -147,16 +146,16 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
         mean_cells2 = cells / (double)std::max<size_t>(tiles.size(), 1);
       }
       pipe_ok_g[g] = pipe_ok;
-      // Four / eight pixels per thread when the 32 x 16-pixel tiles' patches are small against the tile (a projector image finer
-      // than the rectified frame: < 2 patch cells per pixel): an item's fixed costs -- five barriers, the descriptor reads, the
-      // tile arithmetic -- then weigh more than its patch, and half / a quarter as many items carry the same pixels
-      if (g == 3) {
-        const char* e4 = getenv("XM_K2_PIPE_PPT");  // experiments / tests: 2 / 4 / 8
+      // Four pixels per thread when the 32 x 16-pixel tiles' patches are small against the tile (a projector image finer than
+      // the rectified frame: < 2 patch cells per pixel): an item's fixed costs -- five barriers, the descriptor reads, the tile
+      // arithmetic -- then weigh more than its patch, and half as many items carry the same pixels.  (Eight per thread --
+      // 128 x 16 tiles -- was built and measured on the ESL-like rig: 94 VGPRs, five blocks per CU, K2 7.3-7.9 against 5.9-6.7 us
+      // per frame; removed.)
+      if (g == 2) {
+        const char* e4 = getenv("XM_K2_PIPE_PPT");  // experiments / tests: 2 / 4
         const bool small = mean_cells2 < 2.0 * (2 * K2_TX * K2_TY);
-        const int want = e4 ? atoi(e4) : small ? 8 : 2;
-        h->k2_pipe_g = 1;
-        if (h->k2_pipe_rig_ok && want >= 4 && pipe_ok_g[2]) h->k2_pipe_g = 2;
-        if (h->k2_pipe_rig_ok && want >= 8 && pipe_ok_g[2] && pipe_ok_g[3]) h->k2_pipe_g = 3;
+        const int want = e4 ? atoi(e4) : small ? 4 : 2;
+        h->k2_pipe_g = h->k2_pipe_rig_ok && want >= 4 && pipe_ok_g[2] ? 2 : 1;
       }
       h->k2_tile_cap[g] = std::min((cap + 7) & ~7, (int)K2_TILE_MAX);
     }
@@ -443,7 +442,7 @@ void xm_destroy(xm_handle* h) {
   if (h->d_own_masks) (void)hipFree(h->d_own_masks);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < 3; ++g) {
     if (h->d_k2_tiles[g]) (void)hipFree(h->d_k2_tiles[g]);
     if (h->d_k2_pix[g]) (void)hipFree(h->d_k2_pix[g]);
     if (h->d_k2_pix16[g]) (void)hipFree(h->d_k2_pix16[g]);

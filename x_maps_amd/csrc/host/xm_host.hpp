@@ -135,13 +135,13 @@ struct xm_handle {
   uint2* d_dlut = nullptr;
   // K2's static per-tile / per-pixel tables for its two geometries: [0] one pixel per thread (16 x 16 tiles), [1] two (32 x 16)
   // ([2]: four pixels per thread, 64 x 16 tiles -- the pipelined kernel on rigs whose patches are small against the tile)
-  int4* d_k2_tiles[4] = {nullptr, nullptr, nullptr, nullptr};  // [g]: tiles of 16 << g pixels x 16 rows
-  u32* d_k2_pix[4] = {nullptr, nullptr, nullptr, nullptr};
-  uint16_t* d_k2_pix16[4] = {nullptr, nullptr, nullptr, nullptr};  // the pipelined K2's copy: u16, rows padded to k2_pix_stride
+  int4* d_k2_tiles[3] = {nullptr, nullptr, nullptr};  // [g]: tiles of 16 << g pixels x 16 rows
+  u32* d_k2_pix[3] = {nullptr, nullptr, nullptr};
+  uint16_t* d_k2_pix16[3] = {nullptr, nullptr, nullptr};  // the pipelined K2's copy: u16, rows padded to k2_pix_stride
   int k2_pix_stride = 0;
   int k2_consec = -1;  // k_frame_proj_pipe<PPT, true>: PPT consecutive pixels per thread; -1 = where it measured faster (PPT = 4), XM_K2_CONSEC=0|1 forces
-  int k2_tile_cap[4] = {K2_TILE_MAX, K2_TILE_MAX, K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
-  int k2_pipe_g = 1;  // the pipelined kernel's geometry: tiles of 16 << g pixels x 16 rows (2 / 4 / 8 pixels per thread)
+  int k2_tile_cap[3] = {K2_TILE_MAX, K2_TILE_MAX, K2_TILE_MAX};  // cells of the largest K2 patch (multiple of 8)
+  int k2_pipe_g = 1;  // the pipelined kernel's geometry: tiles of 16 << g pixels x 16 rows (2 / 4 pixels per thread)
   int k2_patch_cols_max = 0;  // widest patch of the 16 x 16 / 32 x 16 tiles (-1: some patch does not fit LDS)
   int k2_force_ppt = 0;                             // XM_K2_PPT=1/2: experiments
   // pipelined K2 of the group launches (xmaps_k2pipe.hpp): table entries kept in LDS, CUs of the device, switch (XM_K2_PIPE=0: off)

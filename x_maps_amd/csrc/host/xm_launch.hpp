@@ -195,10 +195,9 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
   blocks = (unsigned)std::min<u64>(blocks, std::max<u64>(total, 1));
   // divmod(tile, gx) by a multiply in the kernel: exact while tile * gx < 2^32
   const u32 gx_magic = gx > 1 && (u64)gx * gy * gx < (1ull << 32) ? (u32)(((1ull << 32) + gx - 1) / gx) : 0u;
-  const bool cs = (h->k2_consec < 0 ? g >= 2 : h->k2_consec != 0) && h->d_k2_pix16[g];  // default: consecutive pixels on the 64 / 128 x 16 tiles
-  const void* fn = g == 3 ? (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<8, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<8, false, COND>))
-                   : g == 2 ? (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<4, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<4, false, COND>))
-                            : (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<2, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2, false, COND>));
+  const bool cs = (h->k2_consec < 0 ? g >= 2 : h->k2_consec != 0) && h->d_k2_pix16[g];  // default: consecutive pixels on the 64 x 16 tiles
+  const void* fn = g == 2 ? (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<4, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<4, false, COND>))
+                          : (cs ? reinterpret_cast<const void*>(k_frame_proj_pipe<2, true, COND>) : reinterpret_cast<const void*>(k_frame_proj_pipe<2, false, COND>));
   if (h->ensure_lds(fn, lds) != XM_OK) return false;
   K2PipeArgs pa;
   pa.proj_w = h->tb.proj_w; pa.proj_h = h->tb.proj_h; pa.rect_w = h->tb.rect_w; pa.rect_h = h->tb.rect_h;
@@ -207,10 +206,7 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
   XM_LAUNCH((k_frame_proj_pipe<P, C, COND>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[g],      \
             (const u32*)h->d_k2_pix[g], (const uint16_t*)h->d_k2_pix16[g], h->k2_pix_stride, h->tb.dlut, pa, h->k2_tile_cap[g],      \
             (u32)n_frames, gx, gy, h->k2_pipe_nlds, gx_magic)
-  if (g == 3) {
-    if (cs) XM_K2P_LAUNCH(8, true);
-    else XM_K2P_LAUNCH(8, false);
-  } else if (g == 2) {
+  if (g == 2) {
     if (cs) XM_K2P_LAUNCH(4, true);
     else XM_K2P_LAUNCH(4, false);
   } else {

@@ -14,18 +14,22 @@
 //   * the tile's patch is written to LDS, reduced (7-tap maxima along the rows, in place) and sampled exactly as before
 //     (frame_proj_tiled_body, FMT = 2): same tables (k2_tiles / k2_pix), same arithmetic, same outputs;
 //   * patches that stick out of the frame load zeros for the octets outside (patch rows start on a multiple of 8 and so does
-//     the frame's height: an octet is inside or outside as a whole); a rig with a patch of more than 64 rows or 128 columns
-//     keeps the one-block-per-tile kernel (k2_pipe_tile_ok, checked once in xm_create).
+//     the frame's height: an octet is inside or outside as a whole); a rig with a patch of more than 128 rows or more quads than
+//     the loader's registers hold keeps the one-block-per-tile kernel (k2_pipe_tile_ok, checked once in xm_create).
 #pragma once
 #include "xmaps_kernels.hpp"
 
 namespace xm {
 
-constexpr int K2P_UN = 4;  // 16-byte patch loads per thread kept in registers (patches of <= 128 columns x <= 64 rows)
+// 16-byte patch loads per thread kept in registers: thread slot s = tid + j * 256 holds quad s of the patch in memory order
+// (column s / oct, row octet s % oct, oct = rows / 8), so a patch of q quads needs ceil(q / 256) of them: four cover 8192 cells
+constexpr int K2P_UN = 4;
 
-// Can every tile of the rig take the pipelined kernel?  (decided once in xm_create from the tile table: patches of at most 64
-// rows and 128 columns, rows a multiple of 8 -- then every 8-row octet of a patch lies entirely inside or outside the frame)
-__host__ __device__ inline bool k2_pipe_tile_ok(const int4& rec) { return rec.z >= 0 && rec.w >= 0 && rec.w <= 64 && (rec.z << 3) <= K2P_UN * K2_TX * K2_TY; }
+// Can every tile of the rig take the pipelined kernel?  (decided once in xm_create from the tile table; rows a multiple of 8 --
+// then every 8-row octet of a patch lies entirely inside or outside the frame -- and at most 128)
+__host__ __device__ inline bool k2_pipe_tile_ok(const int4& rec) {
+  return rec.z >= 0 && rec.w >= 0 && rec.w <= 128 && (rec.w & 7) == 0 && rec.z * (rec.w >> 3) <= K2P_UN * K2_TX * K2_TY;
+}
 
 // Barrier for LDS hand-offs only: __syncthreads() carries a workgroup-scope fence, for which the compiler drains EVERY outstanding
 // memory operation (s_waitcnt vmcnt(0)) -- including the next item's patch loads that are meant to stay in flight across it.
@@ -112,9 +116,10 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       f += 1;
     }
   };
-  uint4 K[K2P_UN];
-  // the item's vector loads: patch quads (thread slot s -> column s >> 3, row octet s & 7; an octet outside the frame is not
-  // loaded: it reads as zeros) and the pixels' offsets into the patch
+  constexpr int UN = K2P_UN;
+  uint4 K[UN];
+  // the item's vector loads: patch quads (thread slot s -> column s / oct, row octet s % oct: the patch in memory order; an octet
+  // outside the frame is not loaded: it reads as zeros) and the pixels' offsets into the patch
   constexpr int NP = CONSEC ? PPT / 2 : PPT;  // registers that hold a thread's patch offsets (CONSEC: u16 pairs)
   const auto issue = [&](const Meta& m, u32 (&poff)[NP]) {
     const u32 tile_y = m.tile_y, tile_x = m.tile_x;
@@ -123,20 +128,13 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       const int u0 = tile_x * K2_TW + tx * PPT;
       const bool in_tab = u0 < pix_stride && v < a.proj_h;  // (pix_stride % 4 == 0: the thread's run lies inside the row or outside)
       const XM_K2P_GLOBAL uint16_t* src = (const XM_K2P_GLOBAL uint16_t*)k2_pix16 + (__umul24((u32)v, (u32)pix_stride) + (u32)u0);
-      if constexpr (PPT == 8) {
-        uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(src);
-        poff[0] = w.x;
-        poff[1] = w.y;
-        poff[2] = w.z;
-        poff[3] = w.w;
-      } else if constexpr (PPT == 4) {
+      if constexpr (PPT == 4) {
         uint2 w = make_uint2(~0u, ~0u);
         if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint2*>(src);
         poff[0] = w.x;
         poff[1] = w.y;
       } else {
-        static_assert(PPT == 2, "two, four or eight pixels per thread");
+        static_assert(PPT == 2, "two or four pixels per thread");
         u32 w = ~0u;
         if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL u32*>(src);
         poff[0] = w;
@@ -150,24 +148,26 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       }
     }
     const XM_K2P_GLOBAL uint16_t* d16 = (const XM_K2P_GLOBAL uint16_t*)descs[m.f].key_frame;
-    const int bx = m.rec.x, by = m.rec.y, oct = m.rec.w >> 3, nslot = m.rec.z << 3;
+    const int bx = m.rec.x, by = m.rec.y, oct = m.rec.w >> 3, nslot = __mul24(m.rec.z, oct);
     const int g0 = by >> 3;
+    // s / oct in float: (s + 0.5) / oct is at least 1 / 32 away from an integer and s < 2^11, oct <= 16: the rounding cannot reach it
+    const float inv_oct = __frcp_rn((float)max(oct, 1));
 #pragma unroll
-    for (int j = 0; j < K2P_UN; ++j) {
-      const int sj = tid + j * NT, c = sj >> 3, ro = sj & 7;
+    for (int j = 0; j < UN; ++j) {
+      const int sj = tid + j * NT, c = (int)(((float)sj + 0.5f) * inv_oct), ro = sj - __mul24(c, oct);
       const int gx = bx + c, gy = by + 8 * ro;
-      const bool has = sj < nslot && ro < oct && (u32)gx < (u32)a.rect_w && (u32)gy < (u32)a.rect_h;  // (rect_h % 8 == 0)
+      const bool has = sj < nslot && (u32)gx < (u32)a.rect_w && (u32)gy < (u32)a.rect_h;  // (rect_h % 8 == 0)
       K[j] = make_uint4(0, 0, 0, 0);
       if (has)
         K[j] = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(d16 + __umul24((u32)(gx + a.shear_bias + (((g0 + ro) * a.shear_m) >> 12)), (u32)a.rect_h) + (u32)gy);
     }
   };
   const auto to_lds = [&](const Meta& m) {
-    const int oct = m.rec.w >> 3, nslot = m.rec.z << 3;
+    const int nslot = __mul24(m.rec.z, m.rec.w >> 3);
 #pragma unroll
-    for (int j = 0; j < K2P_UN; ++j) {
+    for (int j = 0; j < UN; ++j) {
       const int sj = tid + j * NT;
-      if (sj < nslot && (sj & 7) < oct) reinterpret_cast<uint4*>(tile)[__mul24(sj >> 3, oct) + (sj & 7)] = K[j];
+      if (sj < nslot) reinterpret_cast<uint4*>(tile)[sj] = K[j];
     }
   };
 
