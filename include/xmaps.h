@@ -429,6 +429,25 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
 int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */
 int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events */
 
+/* ---- EVT 3.0 words -> EventCD records on the device --------------------------------------------------------------
+ * The reader in front of the ingest for recordings (Prophesee RAW files, EVT 3.0: a public format; the reference reads them
+ * through Metavision's closed RawReaderBase, python/bias_events_iterator.py:53-96).  The 16-bit words cross PCIe as they are
+ * stored (about 2-4 bytes per event) and are decoded by three kernels (scans over the format's state machine:
+ * x_maps_amd/csrc/xmaps_evt3.hpp); the decoder keeps the state (row, time, vector base, 24-bit wrap count) from chunk to chunk.
+ * Same results as x_maps_amd/evt3.py's host decoder, word for word (unpinned against Metavision, like that one).
+ * max_words = the largest chunk (0 = 2^20), max_events = room for xm_evt3_decode's records (0 = 2 * max_words). */
+typedef struct xm_evt3 xm_evt3;
+int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out);
+void xm_evt3_destroy(xm_evt3* d);
+int xm_evt3_reset(xm_evt3* d); /* forget the state: the next chunk starts a stream */
+/* Synchronous.  *events_dev = the records in device memory (16-byte EventCD, valid until the next call), *n_events their number;
+ * XM_ERR_TOO_MANY if the chunk has more words than max_words or decodes to more events than max_events. */
+int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
+/* One chunk of words as ONE packet of the ingest: decoded straight into the packet's slot, then everything xm_ingest_push does
+ * behind the copy.  The chunk must decode to <= max_packet_events; not with the activity filter (it splits a packet by time
+ * stamps on the host).  *n_events (may be NULL) = the packet's events. */
+int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, size_t* n_events);
+
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out);
 int xm_host_free(xm_handle* h, void* p);

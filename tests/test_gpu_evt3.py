@@ -1,0 +1,140 @@
+"""-m gpu: the EVT 3.0 decoder on the device (x_maps_amd/csrc/xmaps_evt3.hpp: the format's state machine as three scan kernels)
+against the host decoder (x_maps_amd/evt3.py), word for word: the hand-built sequences of tests/test_evt3.py, random streams
+with single and vector events, redundant / changing TIME_HIGH words, 24-bit wrap-arounds, skipped word types, words in front of
+the first row / time word, any chunking (state carried on the device), and the decoder in front of the device ingest
+(xm_ingest_push_evt3): the same frames as pushing the host-decoded packets."""
+import numpy as np
+import pytest
+
+from x_maps_amd import XMapsEngine, evt3
+from x_maps_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def W(typ, payload):
+    return (typ << 12) | (payload & 0xfff)
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[k], b[k]) for k in ("x", "y", "p", "t"))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    with XMapsEngine(S.make_tables(S.C_TINY)) as e:
+        yield e
+
+
+def test_hand_built_sequences(eng):
+    seqs = [
+        [W(0x8, 0x001), W(0x6, 0x010), W(0x0, 37), W(0x2, (1 << 11) | 100), W(0x2, 101), W(0x6, 0x011),
+         W(0x3, (1 << 11) | 200), W(0x4, 0b100000000101), W(0x5, 0b10000001), W(0xE, 0x123), W(0xA, 0x001), W(0x0, 5), W(0x2, 7)],
+        # a TIME_HIGH that changes the field restarts the low field; a redundant one does not
+        [W(0x8, 5), W(0x6, 4000), W(0x0, 7), W(0x2, (1 << 11) | 10), W(0x8, 5), W(0x2, (1 << 11) | 11), W(0x8, 6),
+         W(0x2, (1 << 11) | 12), W(0x6, 3), W(0x2, (1 << 11) | 13)],
+        # events before any row / time / base word (the initial state), vectors without a base, empty vectors
+        [W(0x2, 3), W(0x4, 0xfff), W(0x5, 0), W(0x4, 0), W(0x3, 9), W(0x5, 0xff), W(0x5, 0x81)],
+        # wrap-around of the 24-bit time
+        [W(0x8, 0xffe), W(0x6, 0xfff), W(0x0, 1), W(0x2, 1), W(0x8, 0xfff), W(0x2, 2), W(0x8, 0x000), W(0x6, 2), W(0x2, 3),
+         W(0x8, 0x001), W(0x2, 4)],
+        [],
+    ]
+    for words in seqs:
+        w = np.array(words, dtype="<u2")
+        with evt3.DeviceEvt3Decoder(eng, max_words=64) as dec:
+            assert _same(dec.decode(w), evt3.decode_evt3(w)), words
+
+
+def _random_stream(seed, n_ev):
+    rng = np.random.default_rng(700 + seed)
+    cfg = S.RigConfig("evt3", 640, 480, 640, 480, n_ev)
+    evs = S.make_events(cfg, frame=seed, n=n_ev, p_zero_fraction=0.3, t0=int(rng.choice([5_000_000, (1 << 24) - 6_000, 3 * (1 << 24) - 2_000])))
+    # rows of simultaneous neighbours so that the encoder emits vectors
+    k = n_ev // 40
+    extra = np.zeros(6 * k, S.EVENT_CD_DTYPE)
+    extra["t"] = np.repeat(evs["t"][:: max(n_ev // k, 1)][:k], 6)[: 6 * k]
+    extra["y"] = np.repeat(rng.integers(0, 480, k), 6)
+    extra["x"] = np.repeat(rng.integers(0, 600, k), 6) + np.tile(np.array([0, 1, 3, 4, 8, 11]), k)
+    extra["p"] = np.repeat(rng.integers(0, 2, k), 6)
+    allv = np.zeros(len(evs) + len(extra), S.EVENT_CD_DTYPE)
+    allv[: len(evs)], allv[len(evs):] = evs, extra
+    allv = allv[np.argsort(allv["t"], kind="stable")]
+    words = evt3.encode_evt3(allv).astype(np.int64)
+    # what a camera adds: redundant TIME_HIGH words, OTHERS / EXT_TRIGGER / CONTINUED words, stray empty vectors
+    ins = np.sort(rng.integers(0, len(words), len(words) // 30))
+    hi_at = np.maximum.accumulate(np.where((words >> 12) == 0x8, np.arange(len(words)), -1))
+    filler = []
+    for i in ins:
+        r = rng.random()
+        if r < 0.5 and hi_at[i] >= 0:
+            filler.append(int(words[hi_at[i]]))  # the current TIME_HIGH once more
+        elif r < 0.8:
+            filler.append(int(W(int(rng.choice([0xE, 0xA, 0x7, 0xF])), int(rng.integers(0, 4096)))))
+        else:
+            filler.append(int(W(0x5, 0)))
+    words = np.insert(words, ins, filler)
+    return words.astype("<u2")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_streams_whole_and_chunked(eng, seed):
+    rng = np.random.default_rng(seed)
+    words = _random_stream(seed, 30_000)
+    ref = evt3.decode_evt3(words)
+    assert len(ref) > 30_000 and ((words >> 12) == 0x4).sum() > 100
+    with evt3.DeviceEvt3Decoder(eng, max_words=len(words) + 8, max_events=len(ref) + 64) as dec:
+        assert _same(dec.decode(words), ref)
+        # chunks of any length, the state carried on the device; the host decoder in ONE go is the reference (streaming decoders)
+        dec.reset()
+        cuts = np.unique(np.concatenate(([0, len(words)], rng.integers(0, len(words), 12), [1, 2, 2049, 4096, 4097])))
+        parts = [dec.decode(words[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        cat = np.zeros(sum(len(p) for p in parts), S.EVENT_CD_DTYPE)
+        o = 0
+        for p in parts:
+            cat[o:o + len(p)] = p
+            o += len(p)
+        assert _same(cat, ref)
+    with evt3.DeviceEvt3Decoder(eng, max_words=1000) as dec:  # decode() splits by max_words
+        assert _same(dec.decode(words), ref)
+
+
+def test_limits_are_reported(eng):
+    words = _random_stream(1, 4_000)
+    with evt3.DeviceEvt3Decoder(eng, max_words=len(words), max_events=100) as dec:
+        with pytest.raises(Exception):
+            dec.decode_device(words)
+    with evt3.DeviceEvt3Decoder(eng, max_words=100) as dec:
+        with pytest.raises(Exception):
+            dec.decode_device(words)
+
+
+def test_in_front_of_the_device_ingest():
+    """raw words -> xm_ingest_push_evt3 == host decoder -> xm_ingest_push, packet by packet: same frames, same depth"""
+    from x_maps_amd.ingest import DeviceIngest
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    fps = 60
+    import test_gpu_ingest as TI
+    stream = TI._tiny_stream(14, seed=7)  # frames without a 40 us pause inside, 3.6 ms between them
+    chunks = [evt3.encode_evt3(pk) for pk in TI._packets(stream, int(1e6 / fps / 4)) if len(pk)]  # a quarter of a period per chunk
+    host_dec = evt3.Evt3Decoder()
+    with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2:
+        ing1 = DeviceIngest(e1, fps, max_packet_events=8192, capacity_events=65536)
+        ing2 = DeviceIngest(e2, fps, max_packet_events=8192, capacity_events=65536)
+        out1, out2 = [], []
+        with evt3.DeviceEvt3Decoder(e1, max_words=max(len(c) for c in chunks)) as dec:
+            for words in chunks:
+                n_dev = dec.push(ing1, words)
+                pkt = host_dec.decode(words)
+                assert n_dev == len(pkt)
+                ing2.push(pkt)
+                out1 += ing1.poll()
+                out2 += ing2.poll()
+            ing1.flush(); ing2.flush()
+            out1 += ing1.poll(); out2 += ing2.poll()
+        assert len(out1) == len(out2) >= 4
+        for a, b in zip(out1, out2):
+            assert (a.n_events, a.t_first, a.t_last, a.n_inliers) == (b.n_events, b.t_first, b.t_last, b.n_inliers)
+            assert np.array_equal(a.depth, b.depth) and np.array_equal(a.bgr, b.bgr)
+        ing1.close(); ing2.close()

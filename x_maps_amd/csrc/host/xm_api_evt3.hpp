@@ -1,0 +1,130 @@
+// xm_api_evt3.hpp -- C-ABI: EVT 3.0 words -> EventCD records on the device (xmaps_evt3.hpp), alone or straight into the ingest
+// (part of libxmaps_hip.so's host side: included by ../xmaps_hip.hip, one translation unit; see that file for the order)
+#pragma once
+
+struct xm_evt3 {
+  xm_handle* h = nullptr;
+  hipStream_t stream = nullptr;
+  size_t max_words = 0, max_events = 0;
+  uint16_t* h_words = nullptr;   // pinned staging
+  uint16_t* d_words = nullptr;
+  Evt3Scan* d_agg = nullptr;
+  Evt3State* d_state = nullptr;  // [2]: in / out, swapped per chunk
+  Evt3State* h_state = nullptr;  // pinned: the chunk's event count comes back here
+  uint4* d_out = nullptr;        // records of the last xm_evt3_decode
+  int cur = 0;
+};
+
+namespace {
+
+// words (host) -> records at `out` (device, room for out_cap) on `stream`; *n_events once the count is back (synchronises the stream)
+int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
+  *n_events = 0;
+  if (!n_words) return XM_OK;
+  if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
+  HIP_TRY(hipStreamSynchronize(stream));  // (the staging buffer's previous chunk has been consumed: decoding is synchronous anyway)
+  memcpy(d->h_words, words_host, n_words * 2);
+  HIP_TRY(hipMemcpyAsync(d->d_words, d->h_words, n_words * 2, hipMemcpyHostToDevice, stream));
+  const u32 n = (u32)n_words, nb = (u32)grid_for(n_words, EVT3_PER_BLOCK);
+  Evt3State* st_in = d->d_state + d->cur;
+  Evt3State* st_out = d->d_state + (d->cur ^ 1);
+  hipLaunchKernelGGL(k_evt3_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, d->d_agg);
+  hipLaunchKernelGGL(k_evt3_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, nb, d->d_agg, (const Evt3State*)st_in, st_out);
+  hipLaunchKernelGGL(k_evt3_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, (const Evt3Scan*)d->d_agg,
+                     (const Evt3State*)st_in, out, (u32)std::min<size_t>(out_cap, 0xffffffffu));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(d->h_state, st_out, sizeof(Evt3State), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  d->cur ^= 1;
+  *n_events = (size_t)d->h_state->n_events;
+  if (*n_events > out_cap) return fail(XM_ERR_TOO_MANY, "the chunk decodes to %zu events, room for %zu", *n_events, out_cap);
+  return XM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out) {
+  if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  XM_ENTER(h);
+  xm_evt3* d = new (std::nothrow) xm_evt3();
+  if (!d) return fail(XM_ERR_NOMEM, "out of host memory");
+  d->h = h;
+  d->max_words = max_words ? max_words : (size_t)1 << 20;
+  d->max_events = max_events ? max_events : 2 * d->max_words;
+  if (d->max_words >= 0x7fffffffull || d->max_events >= 0x7fffffffull) {
+    delete d;
+    return fail(XM_ERR_INVALID, "max_words and max_events must be < 2^31");
+  }
+  const size_t nb = grid_for(d->max_words, EVT3_PER_BLOCK);
+#define EV_TRY(expr)                                                             \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      int rc_ = fail(XM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+      xm_evt3_destroy(d);                                                        \
+      return rc_;                                                                \
+    }                                                                            \
+  } while (0)
+  EV_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  EV_TRY(hipHostMalloc((void**)&d->h_words, d->max_words * 2, hipHostMallocDefault));
+  EV_TRY(hipHostMalloc((void**)&d->h_state, sizeof(Evt3State), hipHostMallocDefault));
+  EV_TRY(hipMalloc((void**)&d->d_words, d->max_words * 2 + 64));
+  EV_TRY(hipMalloc((void**)&d->d_agg, (nb + 1) * sizeof(Evt3Scan)));
+  EV_TRY(hipMalloc((void**)&d->d_state, 2 * sizeof(Evt3State)));
+  EV_TRY(hipMemset(d->d_state, 0, 2 * sizeof(Evt3State)));
+  EV_TRY(hipMalloc((void**)&d->d_out, d->max_events * 16));
+#undef EV_TRY
+  *out = d;
+  return XM_OK;
+}
+
+void xm_evt3_destroy(xm_evt3* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->h->cfg.device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->h_words) (void)hipHostFree(d->h_words);
+  if (d->h_state) (void)hipHostFree(d->h_state);
+  if (d->d_words) (void)hipFree(d->d_words);
+  if (d->d_agg) (void)hipFree(d->d_agg);
+  if (d->d_state) (void)hipFree(d->d_state);
+  if (d->d_out) (void)hipFree(d->d_out);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+int xm_evt3_reset(xm_evt3* d) {
+  if (!d) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(d->h->cfg.device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(hipMemset(d->d_state, 0, 2 * sizeof(Evt3State)));
+  d->cur = 0;
+  return XM_OK;
+}
+
+int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events) {
+  if (!d || (n_words && !words_host) || !n_events) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(d->h->cfg.device));
+  if (events_dev) *events_dev = d->d_out;
+  return evt3_run(d, words_host, n_words, d->d_out, d->max_events, d->stream, n_events);
+}
+
+int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, size_t* n_events) {
+  if (!g || !d || (n_words && !words_host)) return fail(XM_ERR_INVALID, "NULL argument");
+  if (g->h != d->h) return fail(XM_ERR_INVALID, "the decoder and the ingest belong to different handles");
+  if (g->cfg.activity_filter)
+    return fail(XM_ERR_INVALID, "the activity filter splits a packet by time stamps on the host: not for packets decoded on the device");
+  HIP_TRY(hipSetDevice(g->h->cfg.device));
+  const int k = g->pkt_next;
+  g->pkt_next = (k + 1) % xm_ingest::STAGE;
+  if (g->pkt_used[k]) HIP_TRY(hipEventSynchronize(g->pkt_ev[k]));  // the staging entry's previous packet has been consumed
+  size_t n = 0;
+  int rc = evt3_run(d, words_host, n_words, g->d_pkt[k], (size_t)g->max_packet, g->stream, &n);  // records straight into the packet's slot
+  if (n_events) *n_events = n;
+  if (rc) return rc;
+  return ingest_process(g, k, n, nullptr);
+}
+
+}  // extern "C"

@@ -241,6 +241,10 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
 int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n) { return ingest_push(g, eventcd16, n, false); }
 int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n) { return ingest_push(g, eventcd16_pinned, n, true); }
 
+// everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation, the frame kernels, publish.  hp = the packet
+// in host memory (the activity filter splits it into sub-packets by time stamps there); NULL for a packet decoded on the device
+static int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp);
+
 static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinned) {
   if (!g || (n && !eventcd16)) return fail(XM_ERR_INVALID, "NULL argument");
   xm_handle* h = g->h;
@@ -261,6 +265,12 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
       HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, s));
     }
   }
+  return ingest_process(g, k, n, hp);
+}
+
+static int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp) {
+  xm_handle* h = g->h;
+  hipStream_t s = g->stream;
   if (g->pushes_since_clear >= g->clear_every) {  // (stream-ordered behind every frame cut so far)
     hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s, g->slot, g->key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
     HIP_TRY(hipGetLastError());
@@ -276,7 +286,7 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   size_t a = 0;
   while (a < n) {
     size_t b = n;
-    if (act) {
+    if (act && hp) {
       long long lo = rec_t_host(hp[a]), hi = lo;
       b = a + 1;
       while (b < n) {

@@ -7,6 +7,7 @@
 #include "xmaps_k1own.hpp"
 #include "xmaps_k2pipe.hpp"
 #include "xmaps_ingest.hpp"
+#include "xmaps_evt3.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -45,4 +46,5 @@ using namespace xm;
 #include "host/xm_api_shard.hpp"    // shards (multi-GPU)
 #include "host/xm_api_filters.hpp"  // frame event filters, pause detection
 #include "host/xm_api_ingest.hpp"   // device-side ingest
+#include "host/xm_api_evt3.hpp"     // EVT 3.0 decoder on the device (alone / in front of the ingest)
 #include "host/xm_api_misc.hpp"     // X-map builder, evaluation metrics, memory helpers

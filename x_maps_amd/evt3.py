@@ -129,6 +129,79 @@ def decode_evt3(words: np.ndarray) -> np.ndarray:
     return Evt3Decoder().decode(words)
 
 
+class DeviceEvt3Decoder:
+    """The same decoder as three kernels (csrc/xmaps_evt3.hpp: the state machine as scans): the words cross PCIe as the
+    recording stores them, the records stay on the device.
+
+        dec = DeviceEvt3Decoder(engine)
+        ptr, n = dec.decode_device(words)       # 16-byte EventCD records in device memory, valid until the next call
+        evs = dec.decode(words)                 # ... copied back (tests)
+        n = dec.push(ingest, words)             # one chunk = one packet of a DeviceIngest (xm_ingest_push_evt3)
+
+    State (row, time, vector base, 24-bit wraps) carries over from chunk to chunk, as in Evt3Decoder."""
+
+    def __init__(self, engine, max_words: int = 1 << 20, max_events: int = 0):
+        import ctypes as C
+
+        from . import _native as N
+        self._C, self._N, self._e = C, N, engine
+        self._lib = engine._lib
+        self._d = C.c_void_p(None)
+        self.max_words = int(max_words)
+        N.check(self._lib.xm_evt3_create(engine._h, int(max_words), int(max_events), C.byref(self._d)))
+
+    def close(self):
+        if getattr(self, "_d", None) is not None and self._d.value:
+            self._lib.xm_evt3_destroy(self._d)
+            self._d = self._C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def reset(self):
+        self._N.check(self._lib.xm_evt3_reset(self._d))
+
+    def decode_device(self, words: np.ndarray):
+        C = self._C
+        w = np.ascontiguousarray(words, dtype="<u2")
+        ptr, n = C.c_void_p(None), C.c_size_t(0)
+        self._N.check(self._lib.xm_evt3_decode(self._d, C.c_void_p(w.ctypes.data), len(w), C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
+    def decode(self, words: np.ndarray) -> np.ndarray:
+        out = []
+        w = np.ascontiguousarray(words, dtype="<u2")
+        for a in range(0, max(len(w), 1), self.max_words):
+            ptr, n = self.decode_device(w[a:a + self.max_words])
+            ev = np.zeros(n, EVENT_CD_DTYPE)
+            if n:
+                self._e.dev_download(ev, ptr)
+            out.append(ev)
+        cat = np.zeros(sum(len(e) for e in out), EVENT_CD_DTYPE)  # (np.concatenate hands back the packed 14-byte layout under NumPy 2)
+        o = 0
+        for e in out:
+            cat[o:o + len(e)] = e
+            o += len(e)
+        return cat
+
+    def push(self, ingest, words: np.ndarray) -> int:
+        C = self._C
+        w = np.ascontiguousarray(words, dtype="<u2")
+        n = C.c_size_t(0)
+        self._N.check(self._lib.xm_ingest_push_evt3(ingest._g, self._d, C.c_void_p(w.ctypes.data), len(w), C.byref(n)))
+        return int(n.value)
+
+
 def read_raw(path: str, chunk_words: int = 1 << 22):
     """Yields EventCD packets of a .raw file (EVT 3.0)."""
     with open(path, "rb") as f:
