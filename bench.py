@@ -753,6 +753,58 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
         got = ing.poll()
         dt = time.perf_counter() - c0
     same_cut = [(f.t_first, f.n_events) for f in got] == cut_frames
+    # the same stream as the recording stores it: EVT 3.0 words (about 4 bytes per event here: every event its own row word),
+    # decoded on the device in front of the ingest (xm_ingest_push_evt3) -- a quarter of the bytes cross PCIe
+    evt3_leg = None
+    try:
+        from x_maps_amd import evt3
+        evt3_leg = {}
+        t_mask = (1 << 24) - 1  # (the format carries 24 bits of time; the stream starts below 2^24 and wraps are counted from 0)
+        for label, pk_us in (("quarter_period_chunks", packet), ("period_chunks", 4 * packet)):
+            edges3 = np.arange(stream["t"][0], stream["t"][-1] + pk_us, pk_us)
+            cuts3 = np.searchsorted(stream["t"], edges3)
+            chunks = []
+            for a, b in zip(cuts3[:-1], cuts3[1:]):
+                if b > a:
+                    w = evt3.encode_evt3_singles(stream[a:b])
+                    pw = eng.host_empty(w.shape, np.uint16)  # pinned, like the EventCD packets above
+                    pw[:] = w
+                    chunks.append(pw)
+            n_words = int(sum(len(c) for c in chunks))
+            with DeviceIngest(eng, 60, capacity_events=1 << 22, max_packet_events=1 << 20, expected_events_per_frame=n_ev,
+                              result_ring=max(8, n_frames)) as ing, \
+                    evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
+                for c in chunks[:4]:
+                    dec.push(ing, c, pinned=True)
+                ing.flush()
+                ing.reset()
+                ing.poll()
+                dec.reset()
+                c0 = time.perf_counter()
+                for c in chunks:
+                    dec.push(ing, c, pinned=True)
+                ing.flush()
+                got3 = ing.poll()
+                dt3 = time.perf_counter() - c0
+            leg = {"Mevents_per_s_end_to_end": round(total / dt3 / 1e6, 2), "chunks": len(chunks),
+                   "bytes_per_event_over_pcie": round(2.0 * n_words / total, 2), "pcie_GBps_in": round(2.0 * n_words / dt3 / 1e9, 2),
+                   "frames_cut": len(got3)}
+            if label == "quarter_period_chunks":  # the packets of the EventCD run above: the same frames must come out
+                leg["same_frames_as_from_eventcd_records"] = bool(
+                    [(f.t_first & t_mask, f.n_events) for f in got3] == [(f.t_first & t_mask, f.n_events) for f in got]) and \
+                    bool(all(np.array_equal(a.depth, b.depth) for a, b in zip(got3, got)))
+            else:  # other packets, other cuts (the trigger finder decides once per packet): every frame against the oracle's cut
+                tf3 = RobustTriggerFinder(60, lambda e, acc=leg.setdefault("_cut", []): acc.append((int(e["t"][0]) & t_mask, len(e))))
+                for a, b in zip(cuts3[:-1], cuts3[1:]):
+                    tf3.process_events(stream[a:b])
+                leg["same_frames_as_host_trigger_finder"] = bool([(f.t_first & t_mask, f.n_events) for f in got3] == leg.pop("_cut"))
+            evt3_leg[label] = leg
+        evt3_leg["note"] = ("the same stream as EVT 3.0 words in pinned host memory -> H2D -> decoded by three scan kernels straight into "
+                            "the ingest's packet slot (xm_ingest_push_evt3: one synchronisation of the decoder's stream per chunk for its "
+                            "event count) -> the same device pipeline; quarter_period_chunks = the packets of the EventCD run, "
+                            "period_chunks = one projector period per chunk (an offline replay chooses its chunks)")
+    except Exception as e:  # never lose the line to the extra leg
+        evt3_leg = {"error": repr(e)[:200]}
     ok = None
     if got and same_cut:
         f0 = got[0]
@@ -762,7 +814,7 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
         ok = bool(np.array_equal(f0.depth, ref["depth"]))
     return {"Mevents_per_s_end_to_end": round(total / dt / 1e6, 2), "frames_cut": len(got), "frames_in_stream": n_frames,
             "same_frames_as_host_trigger_finder": bool(same_cut), "first_frame_depth_equals_oracle": ok,
-            "pcie_GBps_in": round(total * 16 / dt / 1e9, 2),
+            "pcie_GBps_in": round(total * 16 / dt / 1e9, 2), "from_evt3_words": evt3_leg,
             "note": "raw 16-byte EventCD packets in pinned host memory -> H2D -> filter / segment / K0-K1-K2 on the device "
                     "(the event stream never returns to the host) -> depth + BGR in pinned host memory; pushed back to back, "
                     "i.e. faster than the 60 Hz it was stamped for; the reference's trigger finder cannot cut the first and "

@@ -443,10 +443,12 @@ int xm_evt3_reset(xm_evt3* d); /* forget the state: the next chunk starts a stre
 /* Synchronous.  *events_dev = the records in device memory (16-byte EventCD, valid until the next call), *n_events their number;
  * XM_ERR_TOO_MANY if the chunk has more words than max_words or decodes to more events than max_events. */
 int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
-/* One chunk of words as ONE packet of the ingest: decoded straight into the packet's slot, then everything xm_ingest_push does
- * behind the copy.  The chunk must decode to <= max_packet_events; not with the activity filter (it splits a packet by time
- * stamps on the host).  *n_events (may be NULL) = the packet's events. */
-int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, size_t* n_events);
+/* One chunk of words as ONE packet of the ingest: decoded straight into the packet's slot (on the decoder's own stream: only the
+ * decoding is waited for, its event count sizes the launches), then everything xm_ingest_push does behind the copy.  The chunk
+ * must decode to <= max_packet_events; not with the activity filter (it splits a packet by time stamps on the host).
+ * words_pinned != 0: the words lie in pinned host memory (xm_host_alloc) and are copied from there.  *n_events (may be NULL) =
+ * the packet's events. */
+int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events);
 
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out);

@@ -96,3 +96,13 @@ def test_read_raw_checks_the_format_token(tmp_path):
         list(E.read_raw(str(p)))
     p.write_bytes(b"% format EVT3;height=320;width=320\n% end\n")
     assert list(E.read_raw(str(p))) == []
+
+
+def test_vectorised_encoder_round_trips():
+    evs = S.make_events(S.C_TINY, frame=4, n=30_000, p_zero_fraction=0.4, t0=(1 << 24) - 5_000)  # across a 24-bit wrap
+    words = evt3.encode_evt3_singles(evs)
+    assert np.array_equal(words, evt3.encode_evt3(evs, use_vectors=False))  # the same words as the file writer's loop
+    dec = evt3.decode_evt3(words)
+    assert np.array_equal(dec["x"], evs["x"]) and np.array_equal(dec["y"], evs["y"]) and np.array_equal(dec["p"], evs["p"])
+    assert np.array_equal(dec["t"] - dec["t"][0], evs["t"] - evs["t"][0])  # (the format carries 24 bits of time)
+    assert len(evt3.encode_evt3_singles(evs[:0])) == 0

@@ -41,6 +41,9 @@ def test_default_line_as_the_driver_calls_it():
     assert d["config"]["k1_paths_frames"]["cols"] > 0  # the groups took the column-tile K1
     assert abs(d["value"] - 1e6 * fps * 20 / (d["ms_per_step"] * 20 * 1e-3) / 1e6) / d["value"] < 0.01  # value == events / time
     assert d["host_path"]["meets_north_star_1_Gevent_per_s_end_to_end"] and d["ingest_path"]["first_frame_depth_equals_oracle"]
+    e3 = d["ingest_path"]["from_evt3_words"]  # the same stream as EVT 3.0 words, decoded on the device in front of the ingest
+    assert e3["quarter_period_chunks"]["same_frames_as_from_eventcd_records"] and e3["period_chunks"]["same_frames_as_host_trigger_finder"]
+    assert e3["period_chunks"]["Mevents_per_s_end_to_end"] > 500 and e3["period_chunks"]["bytes_per_event_over_pcie"] < 8
 
 
 def test_the_default_line_carries_the_other_engine_settings():

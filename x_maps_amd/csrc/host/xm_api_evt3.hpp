@@ -18,13 +18,13 @@ struct xm_evt3 {
 namespace {
 
 // words (host) -> records at `out` (device, room for out_cap) on `stream`; *n_events once the count is back (synchronises the stream)
-int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
+int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
   *n_events = 0;
   if (!n_words) return XM_OK;
   if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
-  HIP_TRY(hipStreamSynchronize(stream));  // (the staging buffer's previous chunk has been consumed: decoding is synchronous anyway)
-  memcpy(d->h_words, words_host, n_words * 2);
-  HIP_TRY(hipMemcpyAsync(d->d_words, d->h_words, n_words * 2, hipMemcpyHostToDevice, stream));
+  // (the staging buffer's previous chunk has been consumed: every call ends with a synchronisation of this stream)
+  if (!pinned) memcpy(d->h_words, words_host, n_words * 2);  // pageable memory: through the pinned staging buffer
+  HIP_TRY(hipMemcpyAsync(d->d_words, pinned ? words_host : d->h_words, n_words * 2, hipMemcpyHostToDevice, stream));
   const u32 n = (u32)n_words, nb = (u32)grid_for(n_words, EVT3_PER_BLOCK);
   Evt3State* st_in = d->d_state + d->cur;
   Evt3State* st_out = d->d_state + (d->cur ^ 1);
@@ -108,10 +108,13 @@ int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const
   if (!d || (n_words && !words_host) || !n_events) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(d->h->cfg.device));
   if (events_dev) *events_dev = d->d_out;
-  return evt3_run(d, words_host, n_words, d->d_out, d->max_events, d->stream, n_events);
+  return evt3_run(d, words_host, n_words, false, d->d_out, d->max_events, d->stream, n_events);
 }
 
-int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, size_t* n_events) {
+// The chunk is decoded on the DECODER's stream into the packet slot (free: its previous packet has been consumed), and only that
+// stream is waited for (the chunk's event count sizes the ingest's launches): the frame kernels of the packets before it keep
+// running on the ingest's stream meanwhile.
+int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events) {
   if (!g || !d || (n_words && !words_host)) return fail(XM_ERR_INVALID, "NULL argument");
   if (g->h != d->h) return fail(XM_ERR_INVALID, "the decoder and the ingest belong to different handles");
   if (g->cfg.activity_filter)
@@ -121,7 +124,7 @@ int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, si
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
   if (g->pkt_used[k]) HIP_TRY(hipEventSynchronize(g->pkt_ev[k]));  // the staging entry's previous packet has been consumed
   size_t n = 0;
-  int rc = evt3_run(d, words_host, n_words, g->d_pkt[k], (size_t)g->max_packet, g->stream, &n);  // records straight into the packet's slot
+  int rc = evt3_run(d, words_host, n_words, words_pinned != 0, g->d_pkt[k], (size_t)g->max_packet, d->stream, &n);  // records straight into the packet's slot
   if (n_events) *n_events = n;
   if (rc) return rc;
   return ingest_process(g, k, n, nullptr);

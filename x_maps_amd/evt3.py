@@ -194,11 +194,12 @@ class DeviceEvt3Decoder:
             o += len(e)
         return cat
 
-    def push(self, ingest, words: np.ndarray) -> int:
+    def push(self, ingest, words: np.ndarray, pinned: bool = False) -> int:
+        """pinned=True: `words` lies in pinned host memory (XMapsEngine.host_empty): no staging copy"""
         C = self._C
         w = np.ascontiguousarray(words, dtype="<u2")
         n = C.c_size_t(0)
-        self._N.check(self._lib.xm_ingest_push_evt3(ingest._g, self._d, C.c_void_p(w.ctypes.data), len(w), C.byref(n)))
+        self._N.check(self._lib.xm_ingest_push_evt3(ingest._g, self._d, C.c_void_p(w.ctypes.data), len(w), int(bool(pinned)), C.byref(n)))
         return int(n.value)
 
 
@@ -252,6 +253,32 @@ def encode_evt3(evs: np.ndarray, use_vectors: bool = True) -> np.ndarray:
             j = i + 1
         i = j
     return np.array(words, dtype="<u2")
+
+
+def encode_evt3_singles(evs: np.ndarray) -> np.ndarray:
+    """EventCD (time-ordered) -> EVT 3.0 words without vector words, vectorised (the file writer above is a Python loop): per
+    event [TIME_HIGH if the high field changed] [TIME_LOW if the low field changed] [ADDR_Y if the row changed] ADDR_X."""
+    n = len(evs)
+    if n == 0:
+        return np.zeros(0, "<u2")
+    x, y, p, t = (evs[k].astype(np.int64) for k in ("x", "y", "p", "t"))
+    hi, lo = (t >> 12) & 0xfff, t & 0xfff
+    first = np.zeros(n, bool)
+    first[0] = True
+    c_hi = first | (np.concatenate(([0], hi[:-1])) != hi)
+    c_lo = first | (np.concatenate(([0], lo[:-1])) != lo)
+    c_y = first | (np.concatenate(([0], y[:-1])) != y)
+    per = c_hi.astype(np.int64) + c_lo + c_y + 1
+    end = np.cumsum(per)  # one past the event's ADDR_X word
+    words = np.zeros(int(end[-1]), np.int64)
+    words[end - 1] = (T_ADDR_X << 12) | ((p & 1) << 11) | (x & 0x7ff)
+    pos = end - 1 - c_y
+    words[pos[c_y]] = ((T_ADDR_Y << 12) | (y & 0x7ff))[c_y]
+    pos = pos - c_lo
+    words[pos[c_lo]] = ((T_TIME_LOW << 12) | lo)[c_lo]
+    pos = pos - c_hi
+    words[pos[c_hi]] = ((T_TIME_HIGH << 12) | hi)[c_hi]
+    return words.astype("<u2")
 
 
 def write_raw(path: str, evs: np.ndarray, width: int = 640, height: int = 480):
