@@ -138,3 +138,50 @@ def test_in_front_of_the_device_ingest():
             assert (a.n_events, a.t_first, a.t_last, a.n_inliers) == (b.n_events, b.t_first, b.t_last, b.n_inliers)
             assert np.array_equal(a.depth, b.depth) and np.array_equal(a.bgr, b.bgr)
         ing1.close(); ing2.close()
+
+
+def test_a_raw_file_through_the_processor(tmp_path):
+    """DepthReprojectionProcessor.process_evt3_words (device ingest: words decoded on the GPU; host ingest: on the host) shows the
+    same frames as process_events on the decoded packets"""
+    import test_gpu_ingest as TI
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor, RuntimeParams
+    cfg = S.C_TINY
+    tb = S.make_tables(cfg)
+    stream = TI._tiny_stream(14, seed=7)
+    chunks = [evt3.encode_evt3(pk) for pk in TI._packets(stream, int(1e6 / 60 / 4)) if len(pk)]  # a quarter of a period per chunk
+    path = tmp_path / "rec.raw"
+    with open(path, "wb") as f:
+        f.write(b"% evt 3.0\n% end\n")
+        for c in chunks:
+            f.write(c.tobytes())
+    assert np.array_equal(np.concatenate(list(evt3.read_raw_words(str(path), chunk_words=777))), np.concatenate(chunks))
+    host_dec = evt3.Evt3Decoder()
+    packets = [host_dec.decode(c) for c in chunks]
+    shown = {}
+    for mode in ("words_device", "words_host", "records_device", "records_host"):
+        frames = []
+
+        class Window:
+            def should_close(self):
+                return False
+
+            def show_async(self, img, acc=frames):
+                acc.append(np.array(img))
+
+        params = RuntimeParams(camera_width=cfg.cam_w, camera_height=cfg.cam_h, projector_width=cfg.proj_w,
+                               projector_height=cfg.proj_h, projector_fps=60, z_near=0.1, z_far=1.2, calib=None,
+                               projector_time_map=None, no_frame_dropping=True, camera_perspective=False, tables=tb,
+                               device_ingest=mode.endswith("device"))
+        with DepthReprojectionProcessor(params, window=Window()) as proc:
+            if mode.startswith("records"):
+                for ev in packets:
+                    proc.process_events(ev)
+            else:
+                for w in chunks:
+                    proc.process_evt3_words(w)
+            proc.flush()
+        shown[mode] = frames
+    assert len(shown["records_host"]) >= 4
+    for mode in ("words_device", "words_host", "records_device"):
+        assert len(shown[mode]) == len(shown["records_host"]), mode
+        assert all(np.array_equal(a, b) for a, b in zip(shown[mode], shown["records_host"])), mode

@@ -79,6 +79,7 @@ class DepthReprojectionPipe:
         # device-side ingest (row N2): raw packets go to the GPU, which filters, buffers, cuts frames and runs the hot path on
         # them without the event stream (or any index into it) coming back to the host
         self.ingest = None
+        self._evt3_dev = self._evt3_host = None  # EVT 3.0 decoders (process_evt3_words), created on first use
         if getattr(p, "device_ingest", False):
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
@@ -99,6 +100,25 @@ class DepthReprojectionPipe:
         if self.ingest is not None:
             self.ingest.flush()
             self._deliver_ingest_frames()
+
+    def process_evt3_words(self, words):
+        """A chunk of a recording's EVT 3.0 words (x_maps_amd.evt3.read_raw_words) instead of an EventCD packet: decoded on the
+        device in front of the ingest when `device_ingest` is on (the words cross PCIe as the file stores them), on the host
+        otherwise.  What Metavision's reader + process_events do together in the reference (bias_events_iterator.py:53-96)."""
+        from . import evt3
+        if self.ingest is not None and not getattr(self.params, "activity_filter", False):
+            if self._evt3_dev is None:
+                self._evt3_dev = evt3.DeviceEvt3Decoder(self.calib_maps.engine, max_words=1 << 20)
+            w = np.ascontiguousarray(words, dtype="<u2")
+            for a in range(0, len(w), self._evt3_dev.max_words):
+                self._evt3_dev.push(self.ingest, w[a:a + self._evt3_dev.max_words])
+                self._deliver_ingest_frames()
+            return
+        if self._evt3_host is None:
+            self._evt3_host = evt3.Evt3Decoder()
+        evs = self._evt3_host.decode(words)
+        if len(evs):
+            self.process_events(evs)
 
     def process_events(self, evs):
         if self.ingest is not None:

@@ -115,6 +115,13 @@ class DepthReprojectionProcessor:
         self._pipe.process_events(evs)
         self.stats_printer.print_stats_if_needed()
 
+    def process_evt3_words(self, words):
+        """A chunk of a recording's EVT 3.0 words (x_maps_amd.evt3.read_raw_words) instead of an EventCD packet; with
+        RuntimeParams(device_ingest=True) the words are decoded on the device in front of the ingest."""
+        self.stats_printer.print_stats_if_needed()
+        self._pipe.process_evt3_words(words)
+        self.stats_printer.print_stats_if_needed()
+
     def flush(self):
         """Device ingest: wait for the packets pushed so far and deliver the frames they produced."""
         self._pipe.flush()

@@ -220,6 +220,19 @@ def read_raw(path: str, chunk_words: int = 1 << 22):
             yield ev
 
 
+def read_raw_words(path: str, chunk_words: int = 1 << 20):
+    """Yields the EVT 3.0 words of a .raw file chunk by chunk, undecoded: for DeviceEvt3Decoder / process_evt3_words."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    fields, off = split_raw_header(blob)
+    fmt = fields.get("evt", fields.get("format", "3.0"))
+    if fmt.split(";")[0].strip().upper() not in ("3.0", "3", "EVT3", "EVT3.0"):
+        raise ValueError(f"{path}: only EVT 3.0 is supported (header says {fmt!r})")
+    words = np.frombuffer(blob, dtype="<u2", offset=off, count=(len(blob) - off) // 2)
+    for a in range(0, len(words), chunk_words):
+        yield words[a:a + chunk_words]
+
+
 def encode_evt3(evs: np.ndarray, use_vectors: bool = True) -> np.ndarray:
     """EventCD (time-ordered) -> EVT 3.0 words.  Test helper / file writer: runs of events that share (t, y, p) and have
     increasing columns within a 12-column window become VECT_BASE_X + VECT_12, everything else EVT_ADDR_X."""
