@@ -1132,6 +1132,33 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         ingest = {"Mevents_per_s_end_to_end": round(len(stream) / dt / 1e6, 2), "frames_cut": len(got), "frames_in_stream": 16,
                   "stream_seconds_at_60Hz": round(16 / 60, 3), "processed_in_seconds": round(dt, 4),
                   "note": "raw packets (10 % negative polarity, gap noise) in pinned host memory -> frames in pinned host memory"}
+        try:  # the same stream as the recording stores it (EVT 3.0 words), one projector period per chunk, decoded on the device
+            from x_maps_amd import evt3
+            cuts3 = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + 4 * packet, 4 * packet))
+            chunks = []
+            for a, b in zip(cuts3[:-1], cuts3[1:]):
+                if b > a:
+                    w = evt3.encode_evt3_singles(pin[a:b])
+                    pw = eng.host_empty(w.shape, np.uint16)
+                    pw[:] = w
+                    chunks.append(pw)
+            n_words = int(sum(len(c) for c in chunks))
+            with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=int(n_mean),
+                              result_ring=32) as ing, evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
+                for c in chunks[:3]:
+                    dec.push(ing, c, pinned=True)
+                ing.flush(), ing.reset(), ing.poll(), dec.reset()
+                c0 = time.perf_counter()
+                for c in chunks:
+                    dec.push(ing, c, pinned=True)
+                ing.flush()
+                got3 = ing.poll()
+                dt3 = time.perf_counter() - c0
+            ingest["from_evt3_words_period_chunks"] = {
+                "Mevents_per_s_end_to_end": round(len(stream) / dt3 / 1e6, 2), "frames_cut": len(got3), "chunks": len(chunks),
+                "bytes_per_event_over_pcie": round(2.0 * n_words / len(stream), 2), "processed_in_seconds": round(dt3, 4)}
+        except Exception as e:  # never lose the line to the extra leg
+            ingest["from_evt3_words_period_chunks"] = {"error": repr(e)[:200]}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         e0 = host[0]
