@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""What bounds the device ingest on ESL-like frames: the same stream with depth + BGR, BGR only, depth only, and neither."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from x_maps_amd import XMapsEngine, rig, synthetic as S
+from x_maps_amd.ingest import DeviceIngest
+cp, tables, evs0, _ = rig.make_esl_like(row_stride=13)
+stream, _ = rig.render_stream(cp, tables, n_frames=16, row_stride=13, seed=9)
+with XMapsEngine(tables) as eng:
+    pin = eng.host_empty((len(stream),), S.EVENT_CD_DTYPE)
+    pin[:] = stream
+    packet = int(1e6 / 60 / 4)
+    cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
+    for wd, wb in ((True, True), (False, True), (True, False), (False, False)):
+        with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=150_000, result_ring=32,
+                          want_depth=wd, want_bgr=wb) as ing:
+            for a, b in zip(cuts[:4], cuts[1:5]):
+                ing.push_pinned(pin[a:b])
+            ing.flush(), ing.reset(), ing.poll()
+            c0 = time.perf_counter()
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                ing.push_pinned(pin[a:b])
+            ing.flush()
+            got = ing.poll()
+            dt = time.perf_counter() - c0
+        print(f"depth={wd} bgr={wb}: {len(got)} frames in {dt * 1e3:.2f} ms = {dt / max(len(got), 1) * 1e3:.3f} ms per frame, {len(stream) / dt / 1e6:.1f} Mev/s, {len(cuts) - 1} pushes")
