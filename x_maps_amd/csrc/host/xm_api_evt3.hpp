@@ -4,6 +4,7 @@
 
 struct xm_evt3 {
   xm_handle* h = nullptr;
+  int device = 0;  // (kept here: the decoder may be destroyed after its handle)
   hipStream_t stream = nullptr;
   size_t max_words = 0, max_events = 0;
   uint16_t* h_words = nullptr;   // pinned staging
@@ -52,6 +53,7 @@ int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** 
   xm_evt3* d = new (std::nothrow) xm_evt3();
   if (!d) return fail(XM_ERR_NOMEM, "out of host memory");
   d->h = h;
+  d->device = h->cfg.device;
   d->max_words = max_words ? max_words : (size_t)1 << 20;
   d->max_events = max_events ? max_events : 2 * d->max_words;
   if (d->max_words >= 0x7fffffffull || d->max_events >= 0x7fffffffull) {
@@ -83,7 +85,7 @@ int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** 
 
 void xm_evt3_destroy(xm_evt3* d) {
   if (!d) return;
-  (void)hipSetDevice(d->h->cfg.device);
+  (void)hipSetDevice(d->device);
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->h_words) (void)hipHostFree(d->h_words);
   if (d->h_state) (void)hipHostFree(d->h_state);
@@ -97,7 +99,7 @@ void xm_evt3_destroy(xm_evt3* d) {
 
 int xm_evt3_reset(xm_evt3* d) {
   if (!d) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(d->h->cfg.device));
+  HIP_TRY(hipSetDevice(d->device));
   HIP_TRY(hipStreamSynchronize(d->stream));
   HIP_TRY(hipMemset(d->d_state, 0, 2 * sizeof(Evt3State)));
   d->cur = 0;
@@ -106,7 +108,7 @@ int xm_evt3_reset(xm_evt3* d) {
 
 int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events) {
   if (!d || (n_words && !words_host) || !n_events) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(d->h->cfg.device));
+  HIP_TRY(hipSetDevice(d->device));
   if (events_dev) *events_dev = d->d_out;
   return evt3_run(d, words_host, n_words, false, d->d_out, d->max_events, d->stream, n_events);
 }

@@ -208,6 +208,9 @@ class DepthReprojectionPipe:
         if getattr(self, "_replay_engine", None) is not None:
             self._replay_engine.close()
             self._replay_engine = None
+        if getattr(self, "_evt3_dev", None) is not None:  # (before the engine it belongs to)
+            self._evt3_dev.close()
+            self._evt3_dev = None
         if self.ingest is not None:
             self.ingest.close()
         self.calib_maps.engine.close()
