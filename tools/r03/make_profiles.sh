@@ -29,6 +29,8 @@ PMC_SETS=2 run_set sharded --sharded
 PMC_SETS=2 run_set single --batch 0 --slots 1
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_groups3 -- python bench.py $Q > $OUT/trace_groups3.log 2>&1
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_graph -- python bench.py --graph $Q > $OUT/trace_graph.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_evt3 -- python tools/evt3_probe.py 2000000 20 > $OUT/trace_evt3.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_ingest -- python bench.py --no-cpu-baseline --no-other-modes > $OUT/trace_ingest.log 2>&1
 unset XM_BENCH_PREWARM_S
 timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 200 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
