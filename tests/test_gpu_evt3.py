@@ -99,6 +99,26 @@ def test_random_streams_whole_and_chunked(eng, seed):
         assert _same(dec.decode(words), ref)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_arbitrary_words(eng, seed):
+    """any sequence of 16-bit words drives the state machine: uniformly random words (every type, vectors without bases, time
+    fields jumping both ways, rows with the camera-id bit) decode the same on both sides, whole and in chunks"""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(1, 60_000))
+    words = rng.integers(0, 65536, n).astype("<u2")
+    if seed % 2:  # more of the words that carry state, fewer events
+        sel = rng.random(n) < 0.5
+        words[sel] = ((rng.choice([0x0, 0x3, 0x6, 0x8], int(sel.sum())) << 12) | rng.integers(0, 4096, int(sel.sum()))).astype("<u2")
+    ref = evt3.decode_evt3(words)
+    with evt3.DeviceEvt3Decoder(eng, max_words=n + 8, max_events=len(ref) + 64) as dec:
+        assert _same(dec.decode(words), ref)
+        dec.reset()
+        host = evt3.Evt3Decoder()
+        cuts = np.unique(np.concatenate(([0, n], rng.integers(0, n, 9))))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            assert _same(dec.decode(words[a:b]), host.decode(words[a:b])), (a, b)
+
+
 def test_limits_are_reported(eng):
     words = _random_stream(1, 4_000)
     with evt3.DeviceEvt3Decoder(eng, max_words=len(words), max_events=100) as dec:
