@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""What bounds the device ingest on ESL-like frames: the same stream with depth + BGR, BGR only, depth only, and neither."""
+"""What bounds the device ingest on ESL-like frames: the same stream with depth + BGR handed out as fresh arrays / as views into
+the pinned ring, BGR only, and no images."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +14,7 @@ with XMapsEngine(tables) as eng:
     pin[:] = stream
     packet = int(1e6 / 60 / 4)
     cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
-    for wd, wb in ((True, True), (False, True), (True, False), (False, False)):
+    for wd, wb, COPY in ((True, True, True), (True, True, False), (False, True, True), (False, False, True)):
         with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=150_000, result_ring=32,
                           want_depth=wd, want_bgr=wb) as ing:
             for a, b in zip(cuts[:4], cuts[1:5]):
@@ -23,6 +24,9 @@ with XMapsEngine(tables) as eng:
             for a, b in zip(cuts[:-1], cuts[1:]):
                 ing.push_pinned(pin[a:b])
             ing.flush()
-            got = ing.poll()
-            dt = time.perf_counter() - c0
-        print(f"depth={wd} bgr={wb}: {len(got)} frames in {dt * 1e3:.2f} ms = {dt / max(len(got), 1) * 1e3:.3f} ms per frame, {len(stream) / dt / 1e6:.1f} Mev/s, {len(cuts) - 1} pushes")
+            c1 = time.perf_counter()
+            got = ing.poll(copy=COPY)
+            c2 = time.perf_counter()
+            dt = c2 - c0
+        print(f"depth={wd} bgr={wb} fresh arrays={COPY}: {len(got)} frames in {dt * 1e3:.2f} ms = {dt / max(len(got), 1) * 1e3:.3f} ms per frame "
+              f"(of which poll: {(c2 - c1) * 1e3:.2f} ms), {len(stream) / dt / 1e6:.1f} Mev/s, {len(cuts) - 1} pushes")
