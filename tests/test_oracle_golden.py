@@ -157,3 +157,22 @@ def test_eval_metrics_oracle_matches_reference(golden_dir):
         np.testing.assert_allclose(got, g[f"{k}_res"], rtol=1e-12, atol=0)
     r = O.evaluation_stats(np.zeros_like(g["a_gt"]), g["a_gt"])
     assert r["rmse"] == 0 and r["fillrate"] == g["empty_res"][0]
+
+
+def test_a4_dilation_equals_an_independent_maximum_filter():
+    """A4 is restated from OpenCV's documentation (no cv2 offline).  An independent implementation of the same definition --
+    SciPy's 7 x 7 maximum filter with a constant border that can never win (cv2.dilate's default border value is the type's
+    minimum, python/disp_to_depth.py:84-85 runs it on non-negative disparities) -- followed by the integer gather that
+    cv2.remap(INTER_NEAREST) with a CV_16SC2 map and BORDER_CONSTANT 0 performs (:88-96) must give the same frames."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(17)
+    for h, w in ((40, 56), (7, 9), (3, 3), (64, 1), (1, 64)):
+        rect = np.where(rng.random((h, w)) < 0.15, rng.integers(1, 300, (h, w)), 0).astype(np.float32)
+        assert np.array_equal(O.dilate7x7(rect), ndi.maximum_filter(rect, size=7, mode="constant", cval=0.0))
+        ph, pw = 23, 31
+        mxy = np.stack((rng.integers(-4, w + 4, (ph, pw)), rng.integers(-4, h + 4, (ph, pw))), axis=-1).astype(np.int16)
+        dil = ndi.maximum_filter(rect, size=7, mode="constant", cval=0.0)
+        mx, my = mxy[..., 0].astype(np.int64), mxy[..., 1].astype(np.int64)
+        inside = (mx >= 0) & (mx < w) & (my >= 0) & (my < h)
+        want = np.where(inside, dil[np.clip(my, 0, h - 1), np.clip(mx, 0, w - 1)], np.float32(0))
+        assert np.array_equal(O.remap_rectified_disp_map_to_proj(rect, mxy), want)
