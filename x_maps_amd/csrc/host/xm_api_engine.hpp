@@ -294,6 +294,9 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
 #endif
   XM_TRY_CREATE(hipMalloc((void**)&h->d_states, sizeof(SlotState) * (n_slots + 1)));
   XM_TRY_CREATE(hipMemset(h->d_states, 0, sizeof(SlotState) * (n_slots + 1)));  // host_flags = NULL
+  // (a memset of device memory may return before it has run, and the slots' non-blocking streams do not wait for the default one:
+  //  k_reset_slot below initialises the extrema slots in the same bytes -- the memset must have landed first)
+  XM_TRY_CREATE(hipDeviceSynchronize());
   h->aux_st = h->d_states + n_slots;
   h->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
@@ -371,6 +374,9 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     for (auto& e : h->desc_ev) XM_TRY_CREATE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : h->graph_ev) XM_TRY_CREATE(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  // (the memsets and table builders above ran on the default stream; the slots' streams are non-blocking: nothing of a first frame
+  //  may overtake them)
+  XM_TRY_CREATE(hipDeviceSynchronize());
   {  // launch workers: one per distinct slot stream (XM_FLAG_LAUNCH_WORKERS; off: launches stay in the calling thread)
     const char* we = getenv("XM_WORKERS");  // overrides the flag either way
     const bool want = we ? we[0] != '0' : (cfg->flags & XM_FLAG_LAUNCH_WORKERS) != 0;
@@ -554,6 +560,7 @@ int xm_sync(xm_handle* h) {
         HIP_TRY(hipMemset(&h->slots[i].st->unsorted_sticky, 0, sizeof(u32)));
       }
     }
+    if (bad) HIP_TRY(hipDeviceSynchronize());  // (a memset of device memory may return early; the slots' streams do not wait for the default one)
     if (bad) return fail(XM_ERR_UNSORTED, "XM_FLAG_TIME_SORTED: %u wavefront(s) saw events outside [t[0], t[n-1]] -- a frame "
                          "processed since the last xm_sync was not time-sorted, its output is invalid", bad);
   }

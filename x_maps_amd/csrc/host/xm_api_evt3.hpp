@@ -76,7 +76,8 @@ int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** 
   EV_TRY(hipMalloc((void**)&d->d_words, d->max_words * 2 + 64));
   EV_TRY(hipMalloc((void**)&d->d_agg, (nb + 1) * sizeof(Evt3Scan)));
   EV_TRY(hipMalloc((void**)&d->d_state, 2 * sizeof(Evt3State)));
-  EV_TRY(hipMemset(d->d_state, 0, 2 * sizeof(Evt3State)));
+  EV_TRY(hipMemsetAsync(d->d_state, 0, 2 * sizeof(Evt3State), d->stream));  // (on the decoder's stream: it does not wait for the default one)
+  EV_TRY(hipStreamSynchronize(d->stream));
   EV_TRY(hipMalloc((void**)&d->d_out, d->max_events * 16));
 #undef EV_TRY
   *out = d;
@@ -101,7 +102,8 @@ int xm_evt3_reset(xm_evt3* d) {
   if (!d) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(d->device));
   HIP_TRY(hipStreamSynchronize(d->stream));
-  HIP_TRY(hipMemset(d->d_state, 0, 2 * sizeof(Evt3State)));
+  HIP_TRY(hipMemsetAsync(d->d_state, 0, 2 * sizeof(Evt3State), d->stream));  // (a memset on the default stream could be overtaken by the next chunk's kernels)
+  HIP_TRY(hipStreamSynchronize(d->stream));
   d->cur = 0;
   return XM_OK;
 }

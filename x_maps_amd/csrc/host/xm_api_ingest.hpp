@@ -171,6 +171,9 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipMalloc((void**)&g->key_frame, h->key_cells * sizeof(u64)));
   ING_TRY(hipMalloc((void**)&g->slot, sizeof(SlotState)));
   ING_TRY(hipMemset(g->slot, 0, sizeof(SlotState)));
+  // (a memset of device memory may return before it has run and g->stream does not wait for the default stream: k_reset_slot
+  //  initialises the extrema slots inside these bytes -- seen once as a first frame with a wrong time normalisation)
+  ING_TRY(hipDeviceSynchronize());
   hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->stream, g->slot, g->key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
   ING_TRY(hipGetLastError());
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
@@ -198,7 +201,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipMalloc((void**)&g->d_bgr_ring, sizeof(uint8_t*) * g->ring));
   ING_TRY(hipMemcpy(g->d_depth_ring, dd.data(), sizeof(float*) * g->ring, hipMemcpyHostToDevice));
   ING_TRY(hipMemcpy(g->d_bgr_ring, db.data(), sizeof(uint8_t*) * g->ring, hipMemcpyHostToDevice));
-  ING_TRY(hipStreamSynchronize(g->stream));
+  ING_TRY(hipDeviceSynchronize());  // (the memsets above ran on the default stream, which the ingest's non-blocking streams do not wait for)
   g->est_frame_events = cfg->expected_events_per_frame;
 #undef ING_TRY
   *out = g;
@@ -415,6 +418,7 @@ int xm_ingest_reset(xm_ingest* g) {
   HIP_TRY(hipMemcpy(&z, g->st, sizeof z, hipMemcpyDeviceToHost));
   z.buf_start = z.write = 0;  // RobustTriggerFinder.reset(): the buffered events are discarded (trigger_finder.py:116-119)
   HIP_TRY(hipMemcpy(g->st, &z, sizeof z, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());  // (default-stream work: the ingest's non-blocking streams do not wait for it)
   g->ub_live = 0;
   g->recent.clear();
   return XM_OK;
