@@ -59,8 +59,8 @@ def parse_args():
                     help="frames in flight per GPU (key frame + state each); default 4 (one stream per hardware queue), "
                          "60 with --graph")
     ap.add_argument("--frames", type=int, default=0,
-                    help="distinct synthetic frames resident in HBM; default: one distinct group per group in flight (3 x 32 frames = "
-                         "1.15 GB of events: no group re-reads what another one has just pulled into the 256 MiB Infinity Cache), "
+                    help="distinct synthetic frames resident in HBM; default: one distinct group per group in flight (4 x 32 frames = "
+                         "1.5 GB of events: no group re-reads what another one has just pulled into the 256 MiB Infinity Cache), "
                          "32 with --batch 0")
     ap.add_argument("--camera-perspective", action="store_true")
     ap.add_argument("--no-bgr", action="store_true", help="depth frame only")
@@ -74,7 +74,9 @@ def parse_args():
                     help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
                          "launches, grid = frames x tiles); 0 = a step is one frame through one asynchronous call (round 2's "
                          "headline mode, reported under other_modes by default)")
-    ap.add_argument("--groups-in-flight", type=int, default=3, help="with --batch: slots = groups x B (default 3)")
+    ap.add_argument("--groups-in-flight", type=int, default=4,
+                    help="with --batch: slots = groups x B (default 4 = one group per stream / hardware queue of the handle: 149-151 -> "
+                         "162-166 Gev/s against 3 in alternating runs, 5 / 6 / 8 no different)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host->host figures")
