@@ -68,7 +68,7 @@ with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
             "Group modes: a bench step = one group of 32 frames through one xm_process_batch call = ONE launch each of the boundary pass\n"
             "(k_cols_bounds_batch), K1 (k_scatter_cols_batch: column tiles; k_scatter_own_batch: owner tiles) and K2 (k_frame_proj_pipe:\n"
             "persistent, software-pipelined blocks).  Per-frame cost = avg us / 32.\n\n")
-    for key, title, cmd, fpl, wl in SETS + (("groups3", "the default bench command (3 groups in flight: launches of different groups overlap)", "python bench.py", 32, None),
+    for key, title, cmd, fpl, wl in SETS + (("groups3", "the default bench command (4 groups in flight: launches of different groups overlap)", "python bench.py", 32, None),
                                             ("graph", "60 frames x 1 M events from one captured hipGraph (configs[4])", "python bench.py --graph", 60, None),
                                             ("evt3", "the EVT 3.0 decoder alone: 20 chunks of 2 M events = 4 M words each (tools/evt3_probe.py)", None, 1, None),
                                             ("ingest", "the default bench's host / ingest legs (records and EVT 3.0 words through the device ingest)", "python bench.py --no-cpu-baseline --no-other-modes", 1, None)):
