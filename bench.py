@@ -606,7 +606,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
                 other_modes["eventcd_records"] = {"error": repr(e)[:200]}
         other_modes["note"] = ("eventcd_records = the same groups as 16-byte EventCD records (xm_process_batch_aos), the layout Metavision "
                                "delivers; one_frame_per_call = every frame through its own asynchronous call (xm_process_frame) with "
-                               "XM_FLAG_ADAPTIVE_BATCH: a frame that arrives while two groups are in flight is held back and goes out "
+                               "XM_FLAG_ADAPTIVE_BATCH: a frame that arrives while the GPU is busy is held back and goes out "
                                "with the frames behind it as one set of multi-frame launches (64 slots: groups of up to 16; an idle GPU launches at once); "
                                "one_frame_per_call_eager = the same calls without the flag (three launches per frame, 4 frames in "
                                "flight, a launch thread per slot stream): round 2's headline mode; forced_general = "

@@ -79,10 +79,10 @@ extern "C" {
 
 #define XM_FLAG_ADAPTIVE_BATCH 32u /* Asynchronous device-pointer frames (XM_MEM_DEVICE, stats == NULL) are submitted as GROUPS -- one
                                     * set of multi-frame launches, the path xm_process_batch takes -- whenever the GPU is still busy:
-                                    * a frame is launched at once while fewer than three groups are in flight (an idle GPU, e.g. the
-                                    * 60 Hz live pipe, never waits); otherwise it is held back and goes out together with the frames
-                                    * that follow once a group has finished, when n_slots / 4 (at most 32) frames are held, or at
-                                    * the next synchronising call (xm_sync, any synchronous call).  Needs n_slots >= 8.  The
+                                    * a frame is launched at once when no group is in flight (an idle GPU, e.g. the 60 Hz live pipe,
+                                    * never waits); otherwise it is held back and goes out together with the frames that follow --
+                                    * with the first call that finds the GPU idle, when n_slots / 4 (at most 32) frames are held, or
+                                    * at the next synchronising call (xm_sync, any synchronous call).  Needs n_slots >= 8.  The
                                     * contract of asynchronous calls is unchanged: inputs and outputs of a frame stay untouched
                                     * until xm_sync() has returned or n_slots further frames have been submitted. */
 #define XM_FLAG_LAUNCH_WORKERS 8u /* One launch thread per slot stream: asynchronous device-pointer calls (XM_MEM_DEVICE) only post

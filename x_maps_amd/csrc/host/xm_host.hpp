@@ -189,9 +189,9 @@ struct xm_handle {
   u32* d_own_extra_cells = nullptr;
   int own_extras = 0;  // owner cells outside their tile's band, over all tiles
   // XM_FLAG_ADAPTIVE_BATCH: asynchronous device-pointer frames are submitted as GROUPS (multi-frame launches) whenever the GPU
-  // is still busy with earlier ones: a frame is launched at once while fewer than three groups are in flight (an idle GPU -- the
-  // 60 Hz live case -- never waits), otherwise it joins the pending list, which goes out as one group when a group in flight
-  // has finished, when it holds ab_max = n_slots / 4 frames, or at the next synchronising call
+  // is still busy with earlier ones: a frame is launched at once when no group is in flight (an idle GPU -- the 60 Hz live
+  // case -- never waits), otherwise it joins the pending list, which goes out as one group with the first call that finds the
+  // GPU idle, when it holds ab_max = n_slots / 4 frames, or at the next synchronising call
   struct Deferred {
     EventsView ev;
     float* depth;

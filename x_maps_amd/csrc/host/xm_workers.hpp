@@ -155,7 +155,11 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
     for (hipEvent_t e : h->ab_inflight)
       if (e && hipEventQuery(e) == hipErrorNotReady) in_flight += 1;
     (void)hipGetLastError();
-    if ((int)h->pending.size() >= h->ab_max || in_flight < 3) return flush_pending(h);
+    // Launch at once when the GPU is idle (the 60 Hz live pipe: latency), else hold the frame back until a full group is pending: a
+    // caller that produces frames faster than the GPU takes them gets groups of ab_max from the second launch on.  ("in_flight < 3"
+    // until the end of round 3: every group's submission costs the CALLING thread ~30 us, so a run that started with small groups
+    // could stay there -- the thread had no time left to get ahead of the GPU: 37 instead of 140 Gev/s on some boxes.)
+    if ((int)h->pending.size() >= h->ab_max || in_flight == 0) return flush_pending(h);
     return XM_OK;
   }
   if (!h->pending.empty() && (rc = flush_pending(h))) return rc;  // (a synchronous / host-memory call behind deferred frames)
