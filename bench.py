@@ -310,18 +310,71 @@ def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=Non
     return r, alg, pt, wl
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: this process becomes the launcher -- it re-executes the
+    script under torch.distributed.run with one rank per GPU (the command line the driver uses) and hands back its exit code;
+    rank 0 of that run prints the one JSON line.  Fewer than N GPUs visible: an error line and a non-zero exit, never a silent
+    N = 1 run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("XM_BENCH_DRY") != "1":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(json.dumps({"error": f"--gpus {n} but only {have} GPU(s) visible", "n_gpus_requested": n, "n_gpus_visible": have}), flush=True)
+            sys.exit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, XM_BENCH_SPAWNED="1")
+    sys.stderr.write("[bench] --gpus %d without a launcher: %s\n" % (n, " ".join(cmd)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """XM_BENCH_DRY=1 (CPU tests of the launch logic): the ranks meet over gloo, count each other with an all-reduce, rank 0
+    prints a line with the contract's keys and no measurement."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "int64+f64", "data": "synthetic", "config": {"workload": "dry"}, "ranks_seen": seen,
+                          "spawned_by_bench": os.environ.get("XM_BENCH_SPAWNED") == "1"}), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
+            print(json.dumps({"error": f"WORLD_SIZE={world} but --gpus {args.gpus}: the launcher's --nproc-per-node and --gpus must agree"}),
+                  flush=True)
+        sys.exit(2)
+    if os.environ.get("XM_BENCH_DRY") == "1":
+        return dry_run(args, rank, world)
 
     import torch
 
+    if torch.cuda.device_count() <= local_rank:
+        if rank == 0:
+            print(json.dumps({"error": f"rank {rank} has no GPU (visible: {torch.cuda.device_count()})", "n_gpus_requested": args.gpus}), flush=True)
+        sys.exit(2)
     dist = None
     if world > 1 or args.sharded or os.environ.get("XM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
@@ -336,6 +389,13 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
+    if dist is not None:  # the ranks count each other over RCCL before anything is measured
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            raise SystemExit(f"RCCL all-reduce saw {ranks_seen} ranks, WORLD_SIZE is {world}")
     out = None
     try:
         if args.sharded:
@@ -350,6 +410,8 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
     if rank == 0 and out is not None:
+        assert out["n_gpus"] == args.gpus == world, (out["n_gpus"], args.gpus, world)
+        out["rccl_ranks_seen"] = ranks_seen if dist is not None else None
         # RCCL prints its version banner through C stdio, which (redirected) is flushed at exit, i.e. AFTER Python's own
         # buffer: flush it now so that the JSON line is the LAST line on stdout
         try:

@@ -82,9 +82,14 @@ extern "C" {
                                     * a frame is launched at once when no group is in flight (an idle GPU, e.g. the 60 Hz live pipe,
                                     * never waits); otherwise it is held back and goes out together with the frames that follow --
                                     * with the first call that finds the GPU idle, when n_slots / 4 (at most 32) frames are held, or
-                                    * at the next synchronising call (xm_sync, any synchronous call).  Needs n_slots >= 8.  The
-                                    * contract of asynchronous calls is unchanged: inputs and outputs of a frame stay untouched
-                                    * until xm_sync() has returned or n_slots further frames have been submitted. */
+                                    * at the next synchronising call (xm_sync, any synchronous call, xm_destroy).  Needs n_slots >= 8.
+                                    * A group holds frames of ONE layout (AoS or SoA, one t_dtype, polarity column or not): a frame of
+                                    * another layout closes the pending group first.  Contract of asynchronous calls on such a handle:
+                                    * inputs and outputs of a frame stay untouched until xm_sync() has returned or n_slots + n_slots / 4
+                                    * further frames have been submitted (a slot's previous frame is resolved -- and, if its time-sorted
+                                    * shortcut failed, redone from its inputs -- when the GROUP that reuses the slot is launched, and up
+                                    * to n_slots / 4 - 1 frames can be held in front of it).  Held frames are not on any stream yet:
+                                    * synchronising xm_stream() alone does not launch them, xm_sync() does. */
 #define XM_FLAG_LAUNCH_WORKERS 8u /* One launch thread per slot stream: asynchronous device-pointer calls (XM_MEM_DEVICE) only post
                                     a job (~5 us per call instead of ~11.5 us for the three kernel launches); everything else
                                     waits for the workers to be idle first, so ordering and results are unchanged.  Does not
@@ -382,11 +387,14 @@ int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t
 /* ---- device-side ingest ("next" row N2): raw camera packets -> frames, the stream never leaves HBM ----------------------- */
 /* Replaces, per packet, what depth_reprojection_pipe.py:110-119 + trigger_finder.py:128-189 do on the host: polarity filter
  * (p == 1), activity-noise filter, buffering, pause detection (diff(t) >= 40 us), frame cut (> 1/2 period, <= 1 period,
- * > 1000 events, 2 events trimmed on both sides) -- all as kernels over a device-resident event buffer.  The cut frame is
- * described by a record in DEVICE memory that the frame kernels read (K0 -> K1 -> K2, grids sized for the host's upper
- * bound): no index and no event count ever travels to the host.  xm_ingest_push only copies the packet H2D (pinned staging
- * ring) and enqueues a fixed sequence of launches; finished frames appear in a ring of pinned host buffers and are picked
- * up with xm_ingest_poll.  One frame at most is cut per push, exactly like RobustTriggerFinder.process_events.
+ * > 1000 events, 2 events trimmed on both sides) -- as kernels over a device-resident event RING (capacity_events rounded up to
+ * a power of two; its first half is mirrored behind its end, so a frame of up to capacity / 2 events is contiguous wherever it
+ * starts and nothing is ever moved).  Per packet: three ingest launches (count, append, trigger finder -- pauses are found once,
+ * when an event is appended, and kept in a ring of stream indices), the frame kernels K0 -> K1 -> K2 on the frame the DEVICE
+ * described (a record in device memory, grids sized for the host's upper bound: no index and no event count ever travels to
+ * the host), and one launch that publishes the result.  xm_ingest_push only copies the packet H2D (pinned staging ring, its
+ * own stream) and enqueues those launches; finished frames appear in a ring of pinned host buffers and are picked up with
+ * xm_ingest_poll.  One frame at most is cut per push, exactly like RobustTriggerFinder.process_events.
  * Activity filter: Metavision's ActivityNoiseFilterAlgorithm is closed source; the rule implemented here (own definition,
  * same in oracle/ingest_oracle.py): an event is kept iff an EARLIER event of the stream at one of its 8 neighbouring
  * pixels has t - t' <= activity_thresh_us; every (positive) event then becomes its pixel's latest event. */
@@ -400,12 +408,18 @@ typedef struct xm_ingest_config {
   int64_t pause_thresh_us;         /* 0 => 40 (trigger_finder.py:98) */
   int32_t min_events_per_frame;    /* 0 => 1000 (trigger_finder.py:8) */
   int32_t result_ring;             /* finished frames kept in pinned host memory before they are overwritten; 0 => 8 */
-  uint64_t capacity_events;        /* resident stream buffer, events (two buffers of this size); 0 => 2^21 */
-  uint64_t max_packet_events;      /* largest packet xm_ingest_push accepts; 0 => 2^19 */
+  uint64_t capacity_events;        /* resident event ring, events (rounded up to a power of two; a frame may hold at most half of
+                                      it, a full ring drops the incoming events and counts them in `overflow`); 0 => 2^21 */
+  uint64_t max_packet_events;      /* largest packet xm_ingest_push accepts (<= capacity / 2, <= 2^21); 0 => 2^19 */
   uint64_t expected_events_per_frame; /* hint for the first frames' kernel choice (0: one thread per event until a frame
                                          has been delivered; afterwards the stream's own density decides) */
   int32_t want_depth, want_bgr;    /* which outputs the result ring holds */
+  uint32_t flags;                  /* XM_INGEST_* */
+  uint32_t reserved;               /* 0 */
 } xm_ingest_config;
+#define XM_INGEST_NO_LAUNCH_THREAD 1u /* By default xm_ingest_push* only stages the packet and posts it to a launch thread owned
+                                       * by the ingest, which issues the copy and the ~10 launches (the caller pays ~2 us per pinned
+                                       * packet instead of ~35).  With this flag the calling thread issues them itself. */
 typedef struct xm_ingest_frame {
   uint64_t seq;                    /* frame number, from 0 */
   uint64_t n_events;               /* events of the cut frame */
@@ -422,12 +436,15 @@ void xm_ingest_destroy(xm_ingest* g);
 /* one packet of raw EventCD records (host memory, any polarity, time-ordered as the camera delivers them); asynchronous */
 int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n);
 /* the same from PINNED host memory (xm_host_alloc / hipHostMalloc): no staging copy on the host; the packet must stay
- * untouched until 4 further packets have been pushed or xm_ingest_flush() has returned */
+ * untouched until 16 further packets have been pushed or xm_ingest_flush() has returned */
 int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n);
 /* next finished frame, if any: returns 1 and fills *out, 0 if none is ready (never blocks), < 0 on error */
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
 int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */
 int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events */
+/* what the calling thread has paid so far: number of xm_ingest_push* calls, seconds spent inside them, and how often a push had
+ * to wait for a staging entry (the GPU more than 16 packets behind).  Any pointer may be NULL. */
+int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits);
 
 /* ---- EVT 3.0 words -> EventCD records on the device --------------------------------------------------------------
  * The reader in front of the ingest for recordings (Prophesee RAW files, EVT 3.0: a public format; the reference reads them
@@ -443,11 +460,14 @@ int xm_evt3_reset(xm_evt3* d); /* forget the state: the next chunk starts a stre
 /* Synchronous.  *events_dev = the records in device memory (16-byte EventCD, valid until the next call), *n_events their number;
  * XM_ERR_TOO_MANY if the chunk has more words than max_words or decodes to more events than max_events. */
 int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
-/* One chunk of words as ONE packet of the ingest: decoded straight into the packet's slot (on the decoder's own stream: only the
- * decoding is waited for, its event count sizes the launches), then everything xm_ingest_push does behind the copy.  The chunk
- * must decode to <= max_packet_events; not with the activity filter (it splits a packet by time stamps on the host).
- * words_pinned != 0: the words lie in pinned host memory (xm_host_alloc) and are copied from there.  *n_events (may be NULL) =
- * the packet's events. */
+/* One chunk of words as ONE packet of the ingest: decoded straight into the packet's slot on the decoder's own stream, then
+ * everything xm_ingest_push does behind the copy.  Not with the activity filter (it splits a packet by time stamps on the host).
+ * words_pinned != 0: the words lie in pinned host memory (xm_host_alloc) and are copied from there (untouched until 16 further chunks have been
+ * pushed or xm_ingest_flush() has returned).
+ * n_events != NULL: the decoding is waited for and *n_events = the packet's events; a chunk that decodes to more than
+ * max_packet_events returns XM_ERR_TOO_MANY with decoder and ingest unchanged (push it again in halves).
+ * n_events == NULL: nothing is waited for -- the ingest's kernels read the chunk's event count from device memory; a chunk that
+ * decodes to more than max_packet_events is truncated to that and the excess counted in the frames' `overflow`. */
 int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events);
 
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */

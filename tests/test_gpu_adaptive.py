@@ -104,3 +104,53 @@ def test_eventcd_records_on_an_owner_tile_rig():
             assert np.array_equal(bgr[f].cpu().numpy(), r["bgr"]), f
         assert eng.sorted_fallbacks() == 1
         assert eng.path_counts()["cols"] >= F - 1
+
+
+def test_frames_of_different_layouts_never_share_a_group():
+    """SoA int64, AoS records, SoA float64 time stamps and SoA with a polarity column submitted in turn on one adaptive handle:
+    a group's kernels are instantiated for ONE layout (chosen from its first frame), so a frame of another layout must close the
+    pending group first -- every frame still equals the oracle"""
+    cfg = S.C_1M
+    tb = S.make_tables(cfg)
+    dev = torch.device("cuda", 0)
+    F = 24
+    host = [S.make_events(cfg, frame=f % 4, n=200_000 + 30_000 * (f % 3), p_zero_fraction=0.2 if f % 4 == 3 else 0.0) for f in range(F)]
+    keep = []
+    depth = torch.zeros((F, cfg.proj_h, cfg.proj_w), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    with XMapsEngine(tb, n_slots=32, adaptive_batch=True) as eng:
+        for rep in range(2):
+            for f in range(F):
+                e = host[f]
+                x, y, t, p = S.to_soa(e)
+                kind = f % 4
+                if kind == 0:  # SoA, int64 time stamps
+                    bufs = (torch.from_numpy(x.view(np.int16)).to(dev), torch.from_numpy(y.view(np.int16)).to(dev), torch.from_numpy(t).to(dev))
+                    eng.process_frame_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), None, len(e), depth[f].data_ptr(), None)
+                elif kind == 1:  # 16-byte EventCD records
+                    bufs = (torch.from_numpy(e.view(np.uint8).reshape(-1, 16).copy()).to(dev),)
+                    eng.process_events_device(bufs[0].data_ptr(), len(e), False, depth[f].data_ptr(), None)
+                elif kind == 2:  # SoA, float64 time stamps (the evaluation caller's dtype)
+                    bufs = (torch.from_numpy(x.view(np.int16)).to(dev), torch.from_numpy(y.view(np.int16)).to(dev),
+                            torch.from_numpy(t.astype(np.float64)).to(dev))
+                    from x_maps_amd import _native as N
+                    eng.process_frame_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), None, len(e), depth[f].data_ptr(), None,
+                                             t_dtype=N.XM_T_FLOAT64)
+                else:  # SoA with a polarity column (20 % of the events have p = 0)
+                    bufs = (torch.from_numpy(x.view(np.int16)).to(dev), torch.from_numpy(y.view(np.int16)).to(dev), torch.from_numpy(t).to(dev),
+                            torch.from_numpy(p).to(dev))
+                    eng.process_frame_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr(), len(e),
+                                             depth[f].data_ptr(), None)
+                keep.append(bufs)  # (inputs stay untouched until sync)
+            eng.sync()
+            for f in range(F):
+                e = host[f]
+                x, y, t, p = S.to_soa(e)
+                tt = t.astype(np.float64) if f % 4 == 2 else t
+                if f % 4 == 3:  # the polarity column: events[p == 1], as the pipe's PolarityFilterAlgorithm(1) leaves them
+                    x, y, tt = x[p == 1], y[p == 1], tt[p == 1]
+                ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), tt, want_bgr=False)
+                assert np.array_equal(depth[f].cpu().numpy(), ref["depth"]), (rep, f, f % 4)
+            depth.zero_()
+            torch.cuda.synchronize()
+            keep.clear()

@@ -1,11 +1,13 @@
 """-m gpu: the EVT 3.0 decoder on the device (x_maps_amd/csrc/xmaps_evt3.hpp: the format's state machine as three scan kernels)
-against the host decoder (x_maps_amd/evt3.py), word for word: the hand-built sequences of tests/test_evt3.py, random streams
+against the INDEPENDENT checker oracle/evt3_oracle.py (one word at a time, nothing shared with the product; itself pinned by the
+hand-derived sequences of tests/test_evt3_oracle.py), word for word: those hand-derived sequences, random streams
 with single and vector events, redundant / changing TIME_HIGH words, 24-bit wrap-arounds, skipped word types, words in front of
 the first row / time word, any chunking (state carried on the device), and the decoder in front of the device ingest
 (xm_ingest_push_evt3): the same frames as pushing the host-decoded packets."""
 import numpy as np
 import pytest
 
+import evt3_oracle as EO
 from x_maps_amd import XMapsEngine, evt3
 from x_maps_amd import synthetic as S
 
@@ -26,24 +28,16 @@ def eng():
         yield e
 
 
-def test_hand_built_sequences(eng):
-    seqs = [
-        [W(0x8, 0x001), W(0x6, 0x010), W(0x0, 37), W(0x2, (1 << 11) | 100), W(0x2, 101), W(0x6, 0x011),
-         W(0x3, (1 << 11) | 200), W(0x4, 0b100000000101), W(0x5, 0b10000001), W(0xE, 0x123), W(0xA, 0x001), W(0x0, 5), W(0x2, 7)],
-        # a TIME_HIGH that changes the field restarts the low field; a redundant one does not
-        [W(0x8, 5), W(0x6, 4000), W(0x0, 7), W(0x2, (1 << 11) | 10), W(0x8, 5), W(0x2, (1 << 11) | 11), W(0x8, 6),
-         W(0x2, (1 << 11) | 12), W(0x6, 3), W(0x2, (1 << 11) | 13)],
-        # events before any row / time / base word (the initial state), vectors without a base, empty vectors
-        [W(0x2, 3), W(0x4, 0xfff), W(0x5, 0), W(0x4, 0), W(0x3, 9), W(0x5, 0xff), W(0x5, 0x81)],
-        # wrap-around of the 24-bit time
-        [W(0x8, 0xffe), W(0x6, 0xfff), W(0x0, 1), W(0x2, 1), W(0x8, 0xfff), W(0x2, 2), W(0x8, 0x000), W(0x6, 2), W(0x2, 3),
-         W(0x8, 0x001), W(0x2, 4)],
-        [],
-    ]
-    for words in seqs:
+def test_hand_derived_sequences(eng):
+    """the word sequences whose events were worked out on paper (tests/test_evt3_oracle.py: HAND), whole and split anywhere"""
+    from test_evt3_oracle import HAND, _rows
+    for name, (words, want) in sorted(HAND.items()):
         w = np.array(words, dtype="<u2")
         with evt3.DeviceEvt3Decoder(eng, max_words=64) as dec:
-            assert _same(dec.decode(w), evt3.decode_evt3(w)), words
+            assert _rows(dec.decode(w)) == want, name
+            for cut in range(len(words) + 1):
+                dec.reset()
+                assert _rows(dec.decode(w[:cut])) + _rows(dec.decode(w[cut:])) == want, (name, cut)
 
 
 def _random_stream(seed, n_ev):
@@ -81,11 +75,11 @@ def _random_stream(seed, n_ev):
 def test_random_streams_whole_and_chunked(eng, seed):
     rng = np.random.default_rng(seed)
     words = _random_stream(seed, 30_000)
-    ref = evt3.decode_evt3(words)
+    ref = EO.decode(words)
     assert len(ref) > 30_000 and ((words >> 12) == 0x4).sum() > 100
     with evt3.DeviceEvt3Decoder(eng, max_words=len(words) + 8, max_events=len(ref) + 64) as dec:
         assert _same(dec.decode(words), ref)
-        # chunks of any length, the state carried on the device; the host decoder in ONE go is the reference (streaming decoders)
+        # chunks of any length, the state carried on the device; the checker in ONE go is the reference (streaming decoders)
         dec.reset()
         cuts = np.unique(np.concatenate(([0, len(words)], rng.integers(0, len(words), 12), [1, 2, 2049, 4096, 4097])))
         parts = [dec.decode(words[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
@@ -104,19 +98,19 @@ def test_arbitrary_words(eng, seed):
     """any sequence of 16-bit words drives the state machine: uniformly random words (every type, vectors without bases, time
     fields jumping both ways, rows with the camera-id bit) decode the same on both sides, whole and in chunks"""
     rng = np.random.default_rng(900 + seed)
-    n = int(rng.integers(1, 60_000))
+    n = int(rng.integers(1, 30_000))
     words = rng.integers(0, 65536, n).astype("<u2")
     if seed % 2:  # more of the words that carry state, fewer events
         sel = rng.random(n) < 0.5
         words[sel] = ((rng.choice([0x0, 0x3, 0x6, 0x8], int(sel.sum())) << 12) | rng.integers(0, 4096, int(sel.sum()))).astype("<u2")
-    ref = evt3.decode_evt3(words)
+    ref = EO.decode(words)
     with evt3.DeviceEvt3Decoder(eng, max_words=n + 8, max_events=len(ref) + 64) as dec:
         assert _same(dec.decode(words), ref)
         dec.reset()
-        host = evt3.Evt3Decoder()
+        sm = EO.Evt3StateMachine()
         cuts = np.unique(np.concatenate(([0, n], rng.integers(0, n, 9))))
         for a, b in zip(cuts[:-1], cuts[1:]):
-            assert _same(dec.decode(words[a:b]), host.decode(words[a:b])), (a, b)
+            assert _same(dec.decode(words[a:b]), sm.feed(words[a:b])), (a, b)
 
 
 def test_limits_are_reported(eng):
@@ -130,7 +124,8 @@ def test_limits_are_reported(eng):
 
 
 def test_in_front_of_the_device_ingest():
-    """raw words -> xm_ingest_push_evt3 == host decoder -> xm_ingest_push, packet by packet: same frames, same depth"""
+    """raw words -> xm_ingest_push_evt3 (count waited for / left on the device) == checker-decoded packets -> xm_ingest_push, packet
+    by packet: same frames, same depth"""
     from x_maps_amd.ingest import DeviceIngest
     cfg = S.C_TINY
     tb = S.make_tables(cfg)
@@ -138,26 +133,37 @@ def test_in_front_of_the_device_ingest():
     import test_gpu_ingest as TI
     stream = TI._tiny_stream(14, seed=7)  # frames without a 40 us pause inside, 3.6 ms between them
     chunks = [evt3.encode_evt3(pk) for pk in TI._packets(stream, int(1e6 / fps / 4)) if len(pk)]  # a quarter of a period per chunk
-    host_dec = evt3.Evt3Decoder()
-    with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2:
+    sm = EO.Evt3StateMachine()
+    with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2, XMapsEngine(tb) as e3:
         ing1 = DeviceIngest(e1, fps, max_packet_events=8192, capacity_events=65536)
         ing2 = DeviceIngest(e2, fps, max_packet_events=8192, capacity_events=65536)
-        out1, out2 = [], []
-        with evt3.DeviceEvt3Decoder(e1, max_words=max(len(c) for c in chunks)) as dec:
+        ing3 = DeviceIngest(e3, fps, max_packet_events=8192, capacity_events=65536)
+        out1, out2, out3 = [], [], []
+        pinned = []
+        with evt3.DeviceEvt3Decoder(e1, max_words=max(len(c) for c in chunks)) as dec, \
+                evt3.DeviceEvt3Decoder(e3, max_words=max(len(c) for c in chunks)) as dec3:
             for words in chunks:
                 n_dev = dec.push(ing1, words)
-                pkt = host_dec.decode(words)
+                pkt = sm.feed(words)
                 assert n_dev == len(pkt)
                 ing2.push(pkt)
+                # nothing waited for: the chunk's event count stays on the device (pinned words go through the launch thread)
+                pw = e3.host_empty(words.shape, np.uint16)
+                pw[:] = words
+                pinned.append(pw)
+                assert dec3.push(ing3, pw, pinned=True, count=False) is None
                 out1 += ing1.poll()
                 out2 += ing2.poll()
-            ing1.flush(); ing2.flush()
-            out1 += ing1.poll(); out2 += ing2.poll()
-        assert len(out1) == len(out2) >= 4
-        for a, b in zip(out1, out2):
+                out3 += ing3.poll()
+            ing1.flush(); ing2.flush(); ing3.flush()
+            out1 += ing1.poll(); out2 += ing2.poll(); out3 += ing3.poll()
+        assert len(out1) == len(out2) == len(out3) >= 4
+        for a, b, c in zip(out1, out2, out3):
             assert (a.n_events, a.t_first, a.t_last, a.n_inliers) == (b.n_events, b.t_first, b.t_last, b.n_inliers)
+            assert (c.n_events, c.t_first, c.t_last, c.n_inliers, c.overflow) == (b.n_events, b.t_first, b.t_last, b.n_inliers, 0)
             assert np.array_equal(a.depth, b.depth) and np.array_equal(a.bgr, b.bgr)
-        ing1.close(); ing2.close()
+            assert np.array_equal(c.depth, b.depth) and np.array_equal(c.bgr, b.bgr)
+        ing1.close(); ing2.close(); ing3.close()
 
 
 def test_a_raw_file_through_the_processor(tmp_path):

@@ -206,3 +206,108 @@ def test_min_events_per_frame_below_four_is_rejected():
     with XMapsEngine(tb) as eng:
         with pytest.raises((XMapsNativeError, ValueError)):
             DeviceIngest(eng, 60, min_events_per_frame=2)
+
+
+@pytest.mark.parametrize("launch_thread", [True, False])
+def test_the_ring_wraps_many_times(launch_thread):
+    """40 frames through a ring of 8192 events (~13 wrap-arounds; frames that straddle the ring's end are read through the
+    mirrored head), launches from the ingest's own thread and from the caller: the same frames as the CPU chain"""
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(40, seed=11)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    tf = IO.TriggerFinderOracle(60)
+    for p in pk:
+        tf.process_events(IO.polarity_filter(p))
+    assert len(tf.frames) >= 12
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 11, result_ring=4,
+                                              launch_thread=launch_thread) as ing:
+        got = []
+        for p in pk:
+            ing.push(p)
+            ing.flush()  # (a result ring of 4: pick every frame up before it can be lapped)
+            got += ing.poll()
+        hs = ing.host_stats()
+    assert hs["pushes"] == len(pk)
+    _check_frames(tb, got, tf.frames)
+
+
+def test_packets_of_any_size_and_empty_packets():
+    """the same stream in packets of 1 .. 7000 events (several blocks of 2048 per packet, blocks that keep nothing, pauses at
+    block and packet borders) with empty pushes in between: the trigger finder sees the same buffer at every decision only if
+    the packets are the same, so the CPU chain gets the very same packets"""
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(16, seed=19)
+    rng = np.random.default_rng(4)
+    cuts = [0]
+    while cuts[-1] < len(stream):
+        cuts.append(min(len(stream), cuts[-1] + int(rng.choice([1, 2, 63, 64, 65, 500, 2047, 2048, 2049, 4100, 7000]))))
+    pk = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        pk.append(stream[a:b])
+        if rng.random() < 0.2:
+            pk.append(stream[:0])
+    # a run of negative events as long as two blocks: blocks that keep nothing
+    run = stream[cuts[5]:cuts[5] + 1].repeat(4500)
+    run["p"] = 0
+    pk.insert(6, run)
+    tf = IO.TriggerFinderOracle(60)
+    for p in pk:
+        tf.process_events(IO.polarity_filter(p))
+    assert len(tf.frames) >= 4
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 14, max_packet_events=1 << 13) as ing:
+        got = []
+        for p in pk:
+            ing.push(p)
+            got += ing.poll()
+        ing.flush()
+        got += ing.poll()
+    _check_frames(tb, got, tf.frames)
+
+
+def test_a_ring_without_room_drops_its_live_part_and_says_so():
+    """a stream without any pause never yields a frame (the reference's buffer would grow without bound); once the live part
+    leaves no room for another full packet it is dropped and counted, and the stream behind it is cut as usual"""
+    tb = S.make_tables(S.C_TINY)
+    n = 20_000
+    ev = np.zeros(n, S.EVENT_CD_DTYPE)
+    ev["t"] = 1_000_000 + np.arange(n) // 4  # 4 events per us for 5 ms: no pause, less than a period
+    ev["x"], ev["y"], ev["p"] = 3, 3, 1
+    tail = _tiny_stream(8, seed=2)
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 12) as ing:
+        for a in range(0, n, 4000):
+            ing.push(ev[a:a + 4000])  # 4000 live: room; 8000 live: no room for 4096 more -> dropped; and again
+        for p in _packets(tail, int(1e6 / 60 / 4)):
+            ing.push(p)
+        ing.flush()
+        got = ing.poll()
+    assert len(got) >= 2 and all(f.overflow == 16_000 and not f.lost for f in got)
+    x, y, t, _ = S.to_soa(tail)
+    for f in got:  # every frame is a contiguous piece of the tail stream, processed like any other
+        a = int(np.searchsorted(t, f.t_first))
+        while not (t[a + f.n_events - 1] == f.t_last):
+            a += 1
+        ref = O.process_ev_frame(tb, x[a:a + f.n_events].astype(np.int64), y[a:a + f.n_events].astype(np.int64), t[a:a + f.n_events])
+        assert np.array_equal(f.depth, ref["depth"])
+
+
+def test_views_into_the_result_ring():
+    """poll(copy=False) hands out views into the pinned ring: same pixels as the copies, same buffers coming round again"""
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(14, seed=7)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2, DeviceIngest(e1, 60, capacity_events=1 << 14, max_packet_events=1 << 12,
+                                                                       result_ring=2) as a, \
+            DeviceIngest(e2, 60, capacity_events=1 << 14, max_packet_events=1 << 12) as b:
+        n = 0
+        addrs = set()
+        for p in pk:
+            a.push(p), b.push(p)
+            a.flush(), b.flush()
+            va, vb = a.poll(copy=False), b.poll()
+            assert len(va) == len(vb)
+            for x, y in zip(va, vb):
+                assert np.array_equal(x.depth, y.depth) and np.array_equal(x.bgr, y.bgr)
+                assert not x.bgr.flags.owndata and y.bgr.flags.owndata
+                addrs.add(x.bgr.ctypes.data)
+                n += 1
+        assert n >= 4 and len(addrs) == 2

@@ -97,13 +97,16 @@ class xm_frame_stats(C.Structure):
     ]
 
 
+XM_INGEST_NO_LAUNCH_THREAD = 1
+
+
 class xm_ingest_config(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("projector_fps", C.c_int32), ("use_polarity", C.c_int32), ("activity_filter", C.c_int32),
         ("activity_thresh_us", C.c_int64), ("pause_thresh_us", C.c_int64),
         ("min_events_per_frame", C.c_int32), ("result_ring", C.c_int32),
         ("capacity_events", C.c_uint64), ("max_packet_events", C.c_uint64), ("expected_events_per_frame", C.c_uint64),
-        ("want_depth", C.c_int32), ("want_bgr", C.c_int32),
+        ("want_depth", C.c_int32), ("want_bgr", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -175,6 +178,7 @@ SYMBOLS = {
     "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
     "xm_ingest_flush": (C.c_int, [_P]),
     "xm_ingest_reset": (C.c_int, [_P]),
+    "xm_ingest_host_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "xm_evt3_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xm_evt3_destroy": (None, [_P]),
     "xm_evt3_reset": (C.c_int, [_P]),

@@ -405,6 +405,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
 void xm_destroy(xm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
+  if (!h->pending.empty()) (void)flush_pending(h);  // XM_FLAG_ADAPTIVE_BATCH: frames still held back are submitted, not dropped
   for (auto& w : h->workers) {
     Job stop;
     stop.kind = Job::STOP;

@@ -18,13 +18,14 @@ struct xm_evt3 {
 
 namespace {
 
-// words (host) -> records at `out` (device, room for out_cap) on `stream`; *n_events once the count is back (synchronises the stream)
-int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
-  *n_events = 0;
-  if (!n_words) return XM_OK;
+// words (host) -> records at `out` (device, room for out_cap) enqueued on `stream`; the chunk's event count is left in
+// d->d_state[d->cur ^ 1].n_events (device memory) -- evt3_commit() flips `cur` once the caller has decided to keep the chunk
+int evt3_enqueue(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream) {
   if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
-  // (the staging buffer's previous chunk has been consumed: every call ends with a synchronisation of this stream)
-  if (!pinned) memcpy(d->h_words, words_host, n_words * 2);  // pageable memory: through the pinned staging buffer
+  if (!pinned) {  // pageable memory: through the pinned staging buffer, once its previous chunk has been copied out of it
+    HIP_TRY(hipStreamSynchronize(stream));
+    memcpy(d->h_words, words_host, n_words * 2);
+  }
   HIP_TRY(hipMemcpyAsync(d->d_words, pinned ? words_host : d->h_words, n_words * 2, hipMemcpyHostToDevice, stream));
   const u32 n = (u32)n_words, nb = (u32)grid_for(n_words, EVT3_PER_BLOCK);
   Evt3State* st_in = d->d_state + d->cur;
@@ -34,12 +35,38 @@ int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned
   hipLaunchKernelGGL(k_evt3_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, (const Evt3Scan*)d->d_agg,
                      (const Evt3State*)st_in, out, (u32)std::min<size_t>(out_cap, 0xffffffffu));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(d->h_state, st_out, sizeof(Evt3State), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  d->cur ^= 1;
-  *n_events = (size_t)d->h_state->n_events;
-  if (*n_events > out_cap) return fail(XM_ERR_TOO_MANY, "the chunk decodes to %zu events, room for %zu", *n_events, out_cap);
   return XM_OK;
+}
+
+// the synchronous form: *n_events once the count is back (synchronises the stream)
+int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
+  *n_events = 0;
+  if (!n_words) return XM_OK;
+  int rc = evt3_enqueue(d, words_host, n_words, pinned, out, out_cap, stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(d->h_state, d->d_state + (d->cur ^ 1), sizeof(Evt3State), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  *n_events = (size_t)d->h_state->n_events;
+  // Too many events for `out`: the decoder's state is NOT advanced (st_in is still current), so the caller can decode the same
+  // chunk again into a larger buffer or in halves; the records written so far are a truncated prefix and must not be used.
+  if (*n_events > out_cap) return fail(XM_ERR_TOO_MANY, "the chunk decodes to %zu events, room for %zu (decoder state unchanged: decode it again in smaller pieces)", *n_events, out_cap);
+  d->cur ^= 1;
+  return XM_OK;
+}
+
+// decode + everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned) {
+  if (n_words) {
+    int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g->copied_ev[k], d->stream));
+    HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
+  }
+  const Evt3State* st_out = d->d_state + (d->cur ^ 1);
+  if (n_words) d->cur ^= 1;
+  // (upper bound of the chunk's events for the host's bookkeeping: a vector word yields up to 12, everything else at most one)
+  const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * 12);
+  return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? reinterpret_cast<const u32*>(&st_out->n_events) : nullptr);
 }
 
 }  // namespace
@@ -115,23 +142,49 @@ int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const
   return evt3_run(d, words_host, n_words, false, d->d_out, d->max_events, d->stream, n_events);
 }
 
-// The chunk is decoded on the DECODER's stream into the packet slot (free: its previous packet has been consumed), and only that
-// stream is waited for (the chunk's event count sizes the ingest's launches): the frame kernels of the packets before it keep
-// running on the ingest's stream meanwhile.
+// The chunk is decoded on the DECODER's stream into the packet slot (free: its previous packet has been consumed) while the frame
+// kernels of the packets before it keep running on the ingest's stream.  n_events != NULL: the decoding is waited for and the
+// chunk's event count returned (and checked against max_packet_events: XM_ERR_TOO_MANY leaves decoder and ingest as they were).
+// n_events == NULL: nothing is waited for -- the ingest's kernels read the count from device memory (round 4); a chunk that
+// decodes to more than max_packet_events events is truncated to that many and the excess counted in the frames' `overflow`;
+// pinned words are handed to the ingest's launch thread like a pinned packet of records.
 int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events) {
   if (!g || !d || (n_words && !words_host)) return fail(XM_ERR_INVALID, "NULL argument");
   if (g->h != d->h) return fail(XM_ERR_INVALID, "the decoder and the ingest belong to different handles");
   if (g->cfg.activity_filter)
     return fail(XM_ERR_INVALID, "the activity filter splits a packet by time stamps on the host: not for packets decoded on the device");
+  if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
+  const double c0 = ingest_now();
   HIP_TRY(hipSetDevice(g->h->cfg.device));
   const int k = g->pkt_next;
-  g->pkt_next = (k + 1) % xm_ingest::STAGE;
-  if (g->pkt_used[k]) HIP_TRY(hipEventSynchronize(g->pkt_ev[k]));  // the staging entry's previous packet has been consumed
-  size_t n = 0;
-  int rc = evt3_run(d, words_host, n_words, words_pinned != 0, g->d_pkt[k], (size_t)g->max_packet, d->stream, &n);  // records straight into the packet's slot
-  if (n_events) *n_events = n;
+  int rc = ingest_wait_entry(g, k);  // the staging entry's previous packet has been consumed
   if (rc) return rc;
-  return ingest_process(g, k, n, nullptr);
+  const bool async_job = g->threaded && !n_events && words_pinned;
+  if (!async_job && (rc = ingest_drain(g))) return rc;  // this thread issues the launches itself: behind everything posted so far
+  if (n_events) {
+    size_t n = 0;
+    rc = evt3_run(d, words_host, n_words, words_pinned != 0, g->d_pkt[k], (size_t)g->max_packet, d->stream, &n);  // records straight into the packet's slot
+    *n_events = n;
+    if (rc) return rc;  // (XM_ERR_TOO_MANY: neither the decoder nor the ingest has advanced -- push the chunk again in halves)
+    g->pkt_next = (k + 1) % xm_ingest::STAGE;
+    g->posted += 1;
+    g->pkt_push[k] = g->posted;
+    rc = ingest_process(g, k, n, nullptr);
+  } else {
+    g->pkt_next = (k + 1) % xm_ingest::STAGE;
+    g->posted += 1;
+    g->pkt_push[k] = g->posted;
+    if (async_job) {
+      xm_ingest::Job j;
+      j.kind = 1; j.k = k; j.n = n_words; j.host = words_host; j.dec = d; j.push_no = g->posted;
+      ingest_post(g, j);
+    } else {
+      rc = ingest_issue_evt3(g, d, k, words_host, n_words, words_pinned != 0);
+    }
+  }
+  g->push_host_s += ingest_now() - c0;
+  g->push_calls += 1;
+  return rc;
 }
 
 }  // extern "C"

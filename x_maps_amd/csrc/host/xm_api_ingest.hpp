@@ -9,46 +9,65 @@ struct xm_ingest {
   xm_ingest_config cfg{};
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of packet k+1 runs beside the kernels of packet k
-  hipEvent_t copied_ev[4] = {};       // per staging entry: its H2D has finished (the compute stream waits for it)
-  u64 capacity = 0, max_packet = 0;
+  u64 capacity = 0, max_packet = 0;   // capacity: a power of two (the request rounded up)
   double period = 0.0;
   long long act_thresh = 0;
   // device
-  uint4* buf[2] = {nullptr, nullptr};
-  u32* first_idx = nullptr;
-  long long* last_ts = nullptr;
-  u32 *keep = nullptr, *pos = nullptr, *sums = nullptr, *total = nullptr;        // packet-sized scan scratch
-  u32 *flags = nullptr, *pos2 = nullptr, *pauses = nullptr, *sums2 = nullptr, *n_pauses = nullptr;  // buffer-sized
-  IngestState* st = nullptr;
-  FrameDesc* desc = nullptr;
-  u64* key_frame = nullptr;
-  SlotState* slot = nullptr;
+  IngestDev dev{};                    // what every ingest kernel gets by value (ring, pause ring, state, descriptor, result ring)
+  u32* first_idx = nullptr;           // activity filter: first event index of the sub-packet per pixel
+  u32* keep = nullptr;                // activity filter: keep flags of the (sub-)packet
   float** d_depth_ring = nullptr;
   uint8_t** d_bgr_ring = nullptr;
   // staging (pinned host -> device), a small ring so that the copy of packet k+1 does not wait for packet k's kernels
-  static constexpr int STAGE = 4;
+  static constexpr int STAGE = 16;
   uint4* h_pkt[STAGE] = {};
   uint4* d_pkt[STAGE] = {};
-  hipEvent_t pkt_ev[STAGE] = {};
-  bool pkt_used[STAGE] = {};
+  hipEvent_t copied_ev[STAGE] = {};   // per staging entry: its H2D has finished (the compute stream waits for it)
+  uint64_t pkt_push[STAGE] = {};      // number of the push that used the entry last (0: never): free once that push has run
   int pkt_next = 0;
   // results (pinned host, written by the kernels)
   int ring = 0;
   IngestStatus* h_status = nullptr;
+  u64* h_pushes_done = nullptr;       // pinned: number of the last push whose kernels have run (written by k_ing_publish)
   std::vector<float*> h_depth;
   std::vector<uint8_t*> h_bgr;
   uint64_t next_seq = 0;     // frames delivered through xm_ingest_poll so far
   uint64_t pushed = 0;       // events handed in
-  uint64_t pushes = 0;
+  std::atomic<uint64_t> pushes{0};  // packets whose launches have been issued (by the launch thread, if there is one)
   // The slot's frame tag advances on the device by one per cut frame (<= one per push) and the host never reads it: the slot is
   // cleared (k_reset_slot: tags back to 0, key frame emptied) before the pushes since the last clear can have brought the tag to
   // KEY_MAX_TAG -- the tag field of the packed keys is 19 bits wide, and at 2^20 the shifted tag would leave the 64-bit key
   uint64_t pushes_since_clear = 0, clear_every = KEY_MAX_TAG - 16;
   // Upper bound of the live part of the device buffer (its real size is known to the device only): grows with every push,
-  // shrinks when a delivered frame reports how much was left after its cut.  Sizes the grids of the segmentation / frame kernels.
+  // shrinks when a delivered frame reports how much was left after its cut.  Sizes the grids of the frame kernels.
   uint64_t ub_live = 0;
   std::vector<std::pair<uint64_t, uint64_t>> recent;  // (push number, events) of the pushes a frame may still report on
   uint64_t est_frame_events = 0;
+  // host time spent inside xm_ingest_push* (what the calling thread pays per packet), for xm_ingest_host_stats
+  double push_host_s = 0.0;
+  uint64_t push_calls = 0, stage_waits = 0;
+  // The launch thread (default; XM_INGEST_NO_LAUNCH_THREAD turns it off): xm_ingest_push* stages the packet and posts a job, the
+  // thread issues the copy and the launches (~10 API calls, 35 us per packet) -- the caller pays ~2 us for a pinned packet.
+  // `mu` guards what both sides touch: ub_live, recent, est_frame_events (xm_ingest_poll tightens them, the launches read them).
+  struct Job {
+    int kind = 0;                       // 0: records, 1: EVT 3.0 words (pinned), 2: stop
+    int k = 0;                          // staging entry
+    size_t n = 0;                       // events (records) / words
+    const void* host = nullptr;         // pinned source (the staging entry or the caller's pinned memory)
+    xm_evt3* dec = nullptr;
+    uint64_t push_no = 0;
+  };
+  static constexpr unsigned QCAP = 64;
+  Job queue[QCAP];
+  std::atomic<unsigned long long> q_head{0}, q_tail{0}, q_done{0};
+  std::atomic<int> q_error{0};
+  std::string q_error_text;
+  std::mutex q_mu, mu;
+  std::condition_variable q_cv;
+  std::atomic<bool> q_sleeping{false};
+  std::thread th;
+  bool threaded = false;
+  uint64_t posted = 0;                  // pushes accepted so far (the caller's count; `pushes` = issued, the launch side's)
 };
 
 namespace {
@@ -57,18 +76,19 @@ template <bool DIRECT>
 int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   xm_handle* h = g->h;
   hipStream_t s = g->stream;
+  const FrameDesc* desc = g->dev.desc;
   // K0 over the frame (general path: the cut frame is sorted whenever the camera stream is, but nothing here relies on it)
   {
     unsigned gx = grid_for(n_bound, BLOCK * 4);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL((k_minmax_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc);
+    hipLaunchKernelGGL((k_minmax_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, desc);
   }
   if constexpr (DIRECT) {
     const unsigned gx = grid_for(n_bound, BLOCK);
     if (h->cfg.view == XM_VIEW_PROJECTOR)
-      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 0>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, h->tb, 0);
+      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 0>), dim3(gx, 1), dim3(BLOCK), 0, s, desc, h->tb, 0);
     else
-      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, h->tb, 0);
+      hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, desc, h->tb, 0);
   } else {
     const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)est_n / (double)h->tb.xmap_w : 0.0;
     unsigned threads = TILE_THREADS;
@@ -79,7 +99,7 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
       auto kern = k_scatter_tiled_batch<long long, true, false, VIEW, false>;
       int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), h->k1_lds);
       if (rc) return rc;
-      hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(threads), h->k1_lds, s, (const FrameDesc*)g->desc, h->tb, h->w_ts, h->w_x, 0);
+      hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(threads), h->k1_lds, s, desc, h->tb, h->w_ts, h->w_x, 0);
       return XM_OK;
     };
     int rc = h->cfg.view == XM_VIEW_PROJECTOR ? launch(std::integral_constant<int, 0>{}) : launch(std::integral_constant<int, 1>{});
@@ -87,15 +107,111 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
   }
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (!h->k2_direct) {
-      launch_k2_batch<0>(h, s, (const FrameDesc*)g->desc, 1);
+      launch_k2_batch<0>(h, s, desc, 1);
     } else {
       return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");
     }
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
-    hipLaunchKernelGGL(k_frame_direct_batch, dim3(grid_for(px, BLOCK), 1), dim3(BLOCK), 0, s, (const FrameDesc*)g->desc, px, h->tb.dlut);
+    hipLaunchKernelGGL(k_frame_direct_batch, dim3(grid_for(px, BLOCK), 1), dim3(BLOCK), 0, s, desc, px, h->tb.dlut);
   }
   HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+inline double ingest_now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// the staging entry's previous packet has been consumed once the push that used it has run (k_ing_publish reports the number of
+// a finished push in pinned memory -- every fourth one and every one that cut a frame: no API call, no event)
+int ingest_wait_entry(xm_ingest* g, int k) {
+  const uint64_t need = g->pkt_push[k];
+  if (!need || __atomic_load_n(g->h_pushes_done, __ATOMIC_ACQUIRE) >= need) return XM_OK;
+  g->stage_waits += 1;
+  while (g->pushes.load(std::memory_order_acquire) < std::min<uint64_t>(g->posted, (need + 3) & ~3ull)) __builtin_ia32_pause();  // (still queued)
+  unsigned spins = 0;
+  while (__atomic_load_n(g->h_pushes_done, __ATOMIC_ACQUIRE) < need) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfff) == 0) {  // make sure the runtime has handed the launches to the GPU; stop once the stream is empty
+      hipError_t q = hipStreamQuery(g->stream);
+      if (q == hipSuccess && g->pushes.load(std::memory_order_acquire) >= g->posted) break;
+      if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(q);
+    }
+  }
+  return XM_OK;
+}
+
+int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr);
+
+// the launches of one packet of records: H2D on the copy stream (beside the previous packets' kernels), then everything else
+int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
+    HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
+  }
+  return ingest_process(g, k, n, hp);
+}
+
+int evt3_enqueue(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream);
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned);
+
+void ingest_thread_main(xm_ingest* g) {
+  (void)hipSetDevice(g->h->cfg.device);
+  for (;;) {
+    unsigned long long t = g->q_tail.load(std::memory_order_relaxed);
+    if (t == g->q_head.load(std::memory_order_acquire)) {  // empty: spin a little, then sleep
+      bool got = false;
+      for (int i = 0; i < 20000 && !got; ++i) {
+        __builtin_ia32_pause();
+        got = t != g->q_head.load(std::memory_order_acquire);
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(g->q_mu);
+        g->q_sleeping.store(true, std::memory_order_seq_cst);
+        g->q_cv.wait(lk, [&] { return t != g->q_head.load(std::memory_order_acquire); });
+        g->q_sleeping.store(false, std::memory_order_relaxed);
+      }
+    }
+    const xm_ingest::Job j = g->queue[t % xm_ingest::QCAP];
+    g->q_tail.store(t + 1, std::memory_order_release);
+    if (j.kind == 2) {
+      g->q_done.store(t + 1, std::memory_order_release);
+      return;
+    }
+    const int rc = j.kind == 0 ? ingest_issue_records(g, j.k, j.n, (const uint4*)j.host)
+                               : ingest_issue_evt3(g, j.dec, j.k, (const uint16_t*)j.host, j.n, true);
+    if (rc != XM_OK && g->q_error.load(std::memory_order_relaxed) == 0) {
+      g->q_error_text = g_err;  // thread-local text of this thread
+      g->q_error.store(rc, std::memory_order_release);
+    }
+    g->q_done.store(t + 1, std::memory_order_release);
+  }
+}
+
+void ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
+  const unsigned long long hd = g->q_head.load(std::memory_order_relaxed);
+  while (hd - g->q_tail.load(std::memory_order_acquire) >= xm_ingest::QCAP) __builtin_ia32_pause();  // queue full: back-pressure
+  g->queue[hd % xm_ingest::QCAP] = j;
+  g->q_head.store(hd + 1, std::memory_order_seq_cst);
+  if (g->q_sleeping.load(std::memory_order_seq_cst)) {
+    std::lock_guard<std::mutex> lk(g->q_mu);
+    g->q_cv.notify_one();
+  }
+}
+
+// wait until the launch thread has issued everything posted so far (the GPU may still be running it); reports a failed job
+int ingest_drain(xm_ingest* g) {
+  if (g->threaded) {
+    const unsigned long long hd = g->q_head.load(std::memory_order_acquire);
+    while (g->q_done.load(std::memory_order_acquire) < hd) __builtin_ia32_pause();
+  }
+  const int e = g->q_error.load(std::memory_order_acquire);
+  if (e) {
+    g->q_error.store(0, std::memory_order_release);
+    return fail(e, "%s (reported by the ingest's launch thread)", g->q_error_text.c_str());
+  }
   return XM_OK;
 }
 
@@ -113,11 +229,14 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   if (!g) return fail(XM_ERR_NOMEM, "out of host memory");
   g->h = h;
   g->cfg = *cfg;
-  g->capacity = cfg->capacity_events ? cfg->capacity_events : (1u << 21);
+  const u64 want_cap = cfg->capacity_events ? cfg->capacity_events : (1u << 21);
+  g->capacity = 1;
+  while (g->capacity < want_cap) g->capacity <<= 1;  // the ring is indexed by (absolute stream index) & (capacity - 1)
   g->max_packet = cfg->max_packet_events ? cfg->max_packet_events : (1u << 19);
-  if (g->capacity >= 0x7fffffffull || g->max_packet * 2 > g->capacity) {
+  if (g->capacity >= 0x7fffffffull || g->max_packet * 2 > g->capacity || g->max_packet > (u64)ING_MAX_BLOCKS * ING_EPB) {
     delete g;
-    return fail(XM_ERR_INVALID, "capacity must be < 2^31 events and at least twice max_packet_events");
+    return fail(XM_ERR_INVALID, "capacity must be < 2^31 events and at least twice max_packet_events (itself at most %llu)",
+                (unsigned long long)ING_MAX_BLOCKS * ING_EPB);
   }
   g->period = 1e6 / (double)cfg->projector_fps;                       // trigger_finder.py: 1e6 / self.projector_fps (float)
   g->act_thresh = cfg->activity_thresh_us > 0 ? cfg->activity_thresh_us : (long long)(1e6 / cfg->projector_fps);  // pipe:65-68
@@ -131,7 +250,6 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   g->ring = cfg->result_ring > 0 ? cfg->result_ring : 8;
   const size_t cam_px = (size_t)h->tb.cam_w * h->tb.cam_h;
   const size_t px = (size_t)h->out_w * h->out_h;
-  const u32 nb_pkt = (u32)((g->max_packet + SCAN_BLOCK - 1) / SCAN_BLOCK), nb_buf = (u32)((g->capacity + SCAN_BLOCK - 1) / SCAN_BLOCK);
 #define ING_TRY(expr)                                                                 \
   do {                                                                                \
     hipError_t e_ = (expr);                                                           \
@@ -144,45 +262,49 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   int lo = 0, hi = 0;
   ING_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   ING_TRY(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, hi));
-  {  // H2D of a packet on a copy stream beside the kernels of the previous one
-    ING_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
-    for (auto& e : g->copied_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  for (int i = 0; i < 2; ++i) ING_TRY(hipMalloc((void**)&g->buf[i], g->capacity * 16));
-  ING_TRY(hipMalloc((void**)&g->first_idx, cam_px * 4));
-  ING_TRY(hipMalloc((void**)&g->last_ts, cam_px * 8));
-  {
+  ING_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));  // H2D of a packet beside the kernels of the previous one
+  for (auto& e : g->copied_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  IngestDev& d = g->dev;
+  d.cap = g->capacity;
+  d.max_packet = g->max_packet;
+  d.mirror = g->capacity / 2;  // frames of up to half the ring are contiguous wherever they start
+  d.pcap = g->capacity * 2;    // (a pause per live event + the stale head the trigger finder has not skipped yet)
+  ING_TRY(hipMalloc((void**)&d.buf, (d.cap + d.mirror) * 16));
+  ING_TRY(hipMalloc((void**)&d.pring, d.pcap * 8));
+  ING_TRY(hipMalloc((void**)&d.blk, sizeof(IngBlk) * ING_MAX_BLOCKS));
+  if (cfg->activity_filter) {
+    ING_TRY(hipMalloc((void**)&g->first_idx, cam_px * 4));
+    ING_TRY(hipMalloc((void**)&d.last_ts, cam_px * 8));
     std::vector<long long> init(cam_px, ING_NO_TS);
-    ING_TRY(hipMemcpy(g->last_ts, init.data(), cam_px * 8, hipMemcpyHostToDevice));
+    ING_TRY(hipMemcpy(d.last_ts, init.data(), cam_px * 8, hipMemcpyHostToDevice));
+    ING_TRY(hipMalloc((void**)&g->keep, g->max_packet * 4));
   }
-  ING_TRY(hipMalloc((void**)&g->keep, (g->max_packet * 2 + nb_pkt + 8) * 4));
-  g->pos = g->keep + g->max_packet;
-  g->sums = g->pos + g->max_packet;
-  g->total = g->sums + nb_pkt;
-  ING_TRY(hipMalloc((void**)&g->flags, (g->capacity * 3 + nb_buf + 8) * 4));
-  g->pos2 = g->flags + g->capacity;
-  g->pauses = g->pos2 + g->capacity;
-  g->sums2 = g->pauses + g->capacity;
-  g->n_pauses = g->sums2 + nb_buf;
-  ING_TRY(hipMalloc((void**)&g->st, sizeof(IngestState)));
-  ING_TRY(hipMemset(g->st, 0, sizeof(IngestState)));
-  ING_TRY(hipMalloc((void**)&g->desc, sizeof(FrameDesc)));
-  ING_TRY(hipMemset(g->desc, 0, sizeof(FrameDesc)));
-  ING_TRY(hipMalloc((void**)&g->key_frame, h->key_cells * sizeof(u64)));
-  ING_TRY(hipMalloc((void**)&g->slot, sizeof(SlotState)));
-  ING_TRY(hipMemset(g->slot, 0, sizeof(SlotState)));
+  d.cam_w = h->tb.cam_w;
+  d.cam_h = h->tb.cam_h;
+  d.pause_thresh = g->cfg.pause_thresh_us;
+  d.period = g->period;
+  d.min_events = (u32)g->cfg.min_events_per_frame;
+  d.ring = (u32)g->ring;
+  ING_TRY(hipMalloc((void**)&d.st, sizeof(IngestState)));
+  ING_TRY(hipMemset(d.st, 0, sizeof(IngestState)));
+  ING_TRY(hipMalloc((void**)&d.desc, sizeof(FrameDesc)));
+  ING_TRY(hipMemset(d.desc, 0, sizeof(FrameDesc)));
+  ING_TRY(hipMalloc((void**)&d.key_frame, h->key_cells * sizeof(u64)));
+  ING_TRY(hipMalloc((void**)&d.slot, sizeof(SlotState)));
+  ING_TRY(hipMemset(d.slot, 0, sizeof(SlotState)));
   // (a memset of device memory may return before it has run and g->stream does not wait for the default stream: k_reset_slot
   //  initialises the extrema slots inside these bytes -- seen once as a first frame with a wrong time normalisation)
   ING_TRY(hipDeviceSynchronize());
-  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->stream, g->slot, g->key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->stream, d.slot, d.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
   ING_TRY(hipGetLastError());
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
     ING_TRY(hipHostMalloc((void**)&g->h_pkt[i], g->max_packet * 16, hipHostMallocDefault));
     ING_TRY(hipMalloc((void**)&g->d_pkt[i], g->max_packet * 16));
-    ING_TRY(hipEventCreateWithFlags(&g->pkt_ev[i], hipEventDisableTiming));
   }
   ING_TRY(hipHostMalloc((void**)&g->h_status, sizeof(IngestStatus) * g->ring, hipHostMallocMapped));
   memset(g->h_status, 0, sizeof(IngestStatus) * g->ring);
+  ING_TRY(hipHostMalloc((void**)&g->h_pushes_done, 64, hipHostMallocMapped));
+  memset(g->h_pushes_done, 0, 64);
   g->h_depth.assign(g->ring, nullptr);
   g->h_bgr.assign(g->ring, nullptr);
   std::vector<float*> dd(g->ring, nullptr);
@@ -201,9 +323,15 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipMalloc((void**)&g->d_bgr_ring, sizeof(uint8_t*) * g->ring));
   ING_TRY(hipMemcpy(g->d_depth_ring, dd.data(), sizeof(float*) * g->ring, hipMemcpyHostToDevice));
   ING_TRY(hipMemcpy(g->d_bgr_ring, db.data(), sizeof(uint8_t*) * g->ring, hipMemcpyHostToDevice));
+  d.depth_ring = g->d_depth_ring;
+  d.bgr_ring = g->d_bgr_ring;
   ING_TRY(hipDeviceSynchronize());  // (the memsets above ran on the default stream, which the ingest's non-blocking streams do not wait for)
   g->est_frame_events = cfg->expected_events_per_frame;
 #undef ING_TRY
+  if (!(cfg->flags & XM_INGEST_NO_LAUNCH_THREAD)) {
+    g->threaded = true;
+    g->th = std::thread(ingest_thread_main, g);
+  }
   *out = g;
   return XM_OK;
 }
@@ -211,24 +339,33 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
 void xm_ingest_destroy(xm_ingest* g) {
   if (!g) return;
   (void)hipSetDevice(g->h->cfg.device);
+  if (g->threaded) {
+    xm_ingest::Job stop;
+    stop.kind = 2;
+    ingest_post(g, stop);
+    if (g->th.joinable()) g->th.join();
+    g->threaded = false;
+  }
   if (g->stream) (void)hipStreamSynchronize(g->stream);
-  for (int i = 0; i < 2; ++i) if (g->buf[i]) (void)hipFree(g->buf[i]);
+  IngestDev& d = g->dev;
+  if (d.buf) (void)hipFree(d.buf);
+  if (d.pring) (void)hipFree(d.pring);
+  if (d.blk) (void)hipFree(d.blk);
+  if (d.last_ts) (void)hipFree(d.last_ts);
+  if (d.st) (void)hipFree(d.st);
+  if (d.desc) (void)hipFree(d.desc);
+  if (d.key_frame) (void)hipFree(d.key_frame);
+  if (d.slot) (void)hipFree(d.slot);
   if (g->first_idx) (void)hipFree(g->first_idx);
-  if (g->last_ts) (void)hipFree(g->last_ts);
   if (g->keep) (void)hipFree(g->keep);
-  if (g->flags) (void)hipFree(g->flags);
-  if (g->st) (void)hipFree(g->st);
-  if (g->desc) (void)hipFree(g->desc);
-  if (g->key_frame) (void)hipFree(g->key_frame);
-  if (g->slot) (void)hipFree(g->slot);
   if (g->d_depth_ring) (void)hipFree(g->d_depth_ring);
   if (g->d_bgr_ring) (void)hipFree(g->d_bgr_ring);
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
     if (g->h_pkt[i]) (void)hipHostFree(g->h_pkt[i]);
     if (g->d_pkt[i]) (void)hipFree(g->d_pkt[i]);
-    if (g->pkt_ev[i]) (void)hipEventDestroy(g->pkt_ev[i]);
   }
   if (g->h_status) (void)hipHostFree(g->h_status);
+  if (g->h_pushes_done) (void)hipHostFree(g->h_pushes_done);
   for (auto p : g->h_depth) if (p) (void)hipHostFree(p);
   for (auto p : g->h_bgr) if (p) (void)hipHostFree(p);
   if (g->copy_stream) {
@@ -244,54 +381,80 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
 int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n) { return ingest_push(g, eventcd16, n, false); }
 int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n) { return ingest_push(g, eventcd16_pinned, n, true); }
 
-// everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation, the frame kernels, publish.  hp = the packet
-// in host memory (the activity filter splits it into sub-packets by time stamps there); NULL for a packet decoded on the device
-static int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp);
-
 static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinned) {
   if (!g || (n && !eventcd16)) return fail(XM_ERR_INVALID, "NULL argument");
+  const double c0 = ingest_now();
   xm_handle* h = g->h;
-  HIP_TRY(hipSetDevice(h->cfg.device));
   if (n > g->max_packet) return fail(XM_ERR_TOO_MANY, "packet of %zu events exceeds max_packet_events %llu", n, (unsigned long long)g->max_packet);
-  hipStream_t s = g->stream;
+  if (const int e = g->q_error.load(std::memory_order_acquire)) {  // an earlier packet's launches failed
+    g->q_error.store(0, std::memory_order_release);
+    return fail(e, "%s (reported by the ingest's launch thread)", g->q_error_text.c_str());
+  }
+  if (!g->threaded) HIP_TRY(hipSetDevice(h->cfg.device));
   const int k = g->pkt_next;
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
   const uint4* hp = pinned ? (const uint4*)eventcd16 : g->h_pkt[k];
+  int rc = XM_OK;
   if (n) {
-    if (g->pkt_used[k]) HIP_TRY(hipEventSynchronize(g->pkt_ev[k]));  // the staging entry's previous packet has been consumed
+    if ((rc = ingest_wait_entry(g, k))) return rc;
     if (!pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
-    if (g->copy_stream) {  // the copy overlaps the previous packets' kernels; the kernels of this packet wait for it
-      HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
-      HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
-      HIP_TRY(hipStreamWaitEvent(s, g->copied_ev[k], 0));
-    } else {
-      HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, s));
-    }
   }
-  return ingest_process(g, k, n, hp);
+  g->posted += 1;
+  g->pkt_push[k] = g->posted;
+  if (g->threaded) {
+    xm_ingest::Job j;
+    j.kind = 0; j.k = k; j.n = n; j.host = hp; j.push_no = g->posted;
+    ingest_post(g, j);
+  } else {
+    rc = ingest_issue_records(g, k, n, hp);
+  }
+  g->push_host_s += ingest_now() - c0;
+  g->push_calls += 1;
+  return rc;
 }
 
-static int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp) {
+}  // extern "C"
+
+namespace {
+
+int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev) {
   xm_handle* h = g->h;
   hipStream_t s = g->stream;
   if (g->pushes_since_clear >= g->clear_every) {  // (stream-ordered behind every frame cut so far)
-    hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s, g->slot, g->key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s, g->dev.slot, g->dev.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
     HIP_TRY(hipGetLastError());
     g->pushes_since_clear = 0;
   }
   g->pushes_since_clear += 1;
-  // room for this packet behind the write cursor (device-side decision; the live part moves to the other buffer)
-  hipLaunchKernelGGL(k_ing_compact, dim3(256), dim3(BLOCK), 0, s, g->st, g->buf[0], g->buf[1], g->capacity, (u64)g->max_packet);
-  hipLaunchKernelGGL(k_ing_compact_commit, dim3(1), dim3(1), 0, s, g->st, g->capacity, (u64)g->max_packet);
-  const int use_pol = g->cfg.use_polarity ? 1 : 0, act = g->cfg.activity_filter ? 1 : 0;
+  const int act = g->cfg.activity_filter && hp ? 1 : 0;
   const int cw = h->tb.cam_w, ch = h->tb.cam_h;
-  // sub-packets whose time span (max - min) stays within the activity threshold (see xmaps_ingest.hpp)
-  size_t a = 0;
-  while (a < n) {
-    size_t b = n;
-    if (act && hp) {
+  IngestPush p{};
+  p.flags = g->cfg.use_polarity ? ING_F_POLARITY : 0u;
+  const auto launch3 = [&](const IngestPush& pp, u32 bound) {  // count, append (blocks of the packet), commit / segment (one block)
+    const unsigned nb = (bound + ING_EPB - 1) / ING_EPB;
+    if (nb) {
+      hipLaunchKernelGGL(k_ing_count, dim3(nb), dim3(ING_THREADS), 0, s, g->dev, pp);
+      hipLaunchKernelGGL(k_ing_append, dim3(nb), dim3(ING_THREADS), 0, s, g->dev, pp);
+    }
+    hipLaunchKernelGGL(k_ing_segment, dim3(1), dim3(ING_THREADS), 0, s, g->dev, pp);
+  };
+  if (!act) {
+    p.src = g->d_pkt[k];
+    p.n = (u32)n;
+    p.n_dev = n_dev;
+    p.flags |= ING_F_SEGMENT;
+    launch3(p, (u32)n);
+  } else {
+    // sub-packets whose time span (max - min) stays within the activity threshold (see xmaps_ingest.hpp); the trigger finder
+    // runs once, behind the last one
+    size_t a = 0;
+    if (n == 0) {
+      p.flags |= ING_F_SEGMENT;
+      launch3(p, 0);
+    }
+    while (a < n) {
       long long lo = rec_t_host(hp[a]), hi = lo;
-      b = a + 1;
+      size_t b = a + 1;
       while (b < n) {
         const long long t = rec_t_host(hp[b]);
         const long long nlo = t < lo ? t : lo, nhi = t > hi ? t : hi;
@@ -299,61 +462,52 @@ static int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp) {
         lo = nlo; hi = nhi;
         ++b;
       }
-    }
-    const u32 m = (u32)(b - a);
-    const uint4* dp = g->d_pkt[k] + a;
-    const u32 nb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (act) {
+      const u32 m = (u32)(b - a);
+      const uint4* dp = g->d_pkt[k] + a;
       HIP_TRY(hipMemsetAsync(g->first_idx, 0xff, (size_t)cw * ch * 4, s));
-      hipLaunchKernelGGL(k_ing_first, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, use_pol, cw, ch, g->first_idx);
+      hipLaunchKernelGGL(k_ing_first, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), cw, ch, g->first_idx);
+      hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), 1, g->act_thresh, cw, ch,
+                         (const u32*)g->first_idx, (const long long*)g->dev.last_ts, g->keep);
+      IngestPush sp = p;
+      sp.src = dp;
+      sp.keep = g->keep;
+      sp.n = m;
+      if (b == n) sp.flags |= ING_F_SEGMENT;
+      launch3(sp, m);
+      a = b;
     }
-    hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, use_pol, act, g->act_thresh, cw, ch,
-                       (const u32*)g->first_idx, (const long long*)g->last_ts, g->keep);
-    hipLaunchKernelGGL(k_filter_scan_blocks, dim3(nb), dim3(SCAN_BLOCK), 0, s, (const u32*)g->keep, m, g->pos, g->sums);
-    hipLaunchKernelGGL(k_filter_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, g->sums, nb, g->total);
-    hipLaunchKernelGGL(k_ing_append, dim3(nb), dim3(SCAN_BLOCK), 0, s, dp, m, use_pol, cw, ch, (const u32*)g->keep, (const u32*)g->pos,
-                       (const u32*)g->sums, (const u32*)g->total, g->st, g->buf[0], g->buf[1], g->capacity, act ? g->last_ts : nullptr);
-    hipLaunchKernelGGL(k_ing_commit, dim3(1), dim3(1), 0, s, g->st, (const u32*)g->total, g->capacity);
-    a = b;
-  }
-  if (n) {
-    HIP_TRY(hipEventRecord(g->pkt_ev[k], s));
-    g->pkt_used[k] = true;
   }
   g->pushed += n;
-  g->pushes += 1;
-  g->ub_live = std::min<u64>(g->capacity, g->ub_live + n);
-  g->recent.emplace_back(g->pushes, (uint64_t)n);
-  if (g->recent.size() > 4096) {  // many pushes without a poll: fold the older half into one entry under its LAST push number (a
-    uint64_t sum = 0;              // frame that reports an earlier push then counts all of it: the bound stays an upper bound)
-    for (size_t i = 0; i < 2048; ++i) sum += g->recent[i].second;
-    g->recent[2047] = std::make_pair(g->recent[2047].first, sum);
-    g->recent.erase(g->recent.begin(), g->recent.begin() + 2047);
+  const uint64_t push_no = g->pushes.load(std::memory_order_relaxed) + 1;
+  u64 bound64, est;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->ub_live = std::min<u64>(g->capacity, g->ub_live + n);
+    g->recent.emplace_back(push_no, (uint64_t)n);
+    if (g->recent.size() > 4096) {  // many pushes without a poll: fold the older half into one entry under its LAST push number (a
+      uint64_t sum = 0;              // frame that reports an earlier push then counts all of it: the bound stays an upper bound)
+      for (size_t i = 0; i < 2048; ++i) sum += g->recent[i].second;
+      g->recent[2047] = std::make_pair(g->recent[2047].first, sum);
+      g->recent.erase(g->recent.begin(), g->recent.begin() + 2047);
+    }
+    bound64 = std::min<u64>(g->ub_live, g->dev.mirror);
+    est = g->est_frame_events;
   }
-  // segmentation over the live part (its size is known to the device only: the grids cover the host's upper bound)
-  const u64 bound64 = g->ub_live;
-  const u32 n_bound = (u32)bound64;
-  hipLaunchKernelGGL(k_ing_begin, dim3(1), dim3(1), 0, s, g->st, (const uint4*)g->buf[0], (const uint4*)g->buf[1], g->period, g->desc);
-  if (n_bound >= 2) {
-    const u32 nb = (n_bound + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_ing_pause_flags, dim3(nb), dim3(SCAN_BLOCK), 0, s, (const IngestState*)g->st, (const uint4*)g->buf[0],
-                       (const uint4*)g->buf[1], (long long)g->cfg.pause_thresh_us, n_bound, g->flags);
-    hipLaunchKernelGGL(k_filter_scan_blocks, dim3(nb), dim3(SCAN_BLOCK), 0, s, (const u32*)g->flags, n_bound, g->pos2, g->sums2);
-    hipLaunchKernelGGL(k_filter_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, g->sums2, nb, g->n_pauses);
-    hipLaunchKernelGGL(k_pause_emit, dim3(nb), dim3(SCAN_BLOCK), 0, s, (const u32*)g->flags, (const u32*)g->pos2, (const u32*)g->sums2,
-                       n_bound, g->pauses);
-    hipLaunchKernelGGL(k_ing_segment, dim3(1), dim3(BLOCK), 0, s, g->st, (const uint4*)g->buf[0], (const uint4*)g->buf[1],
-                       (const u32*)g->pauses, (const u32*)g->n_pauses, g->period, (u32)g->cfg.min_events_per_frame, g->desc,
-                       g->key_frame, g->slot, (float* const*)g->d_depth_ring, (uint8_t* const*)g->d_bgr_ring, (u32)g->ring);
-    // the frame kernels run on whatever the device cut (FrameDesc in device memory); nothing to do when desc.valid == 0
-    const u64 est = g->est_frame_events ? g->est_frame_events : 0;
+  // the frame kernels run on whatever the device cut (FrameDesc in device memory; its size is known to the device only: the
+  // grids cover the host's upper bound of the live part); nothing to do when desc.valid == 0
+  if (bound64 >= 2) {
     int rc = batch_path(h, est) ? ingest_launch_frame<false>(g, bound64, est) : ingest_launch_frame<true>(g, bound64, est);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->st, (const FrameDesc*)g->desc, g->h_status, (u64)g->pushes);
   }
+  hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->dev.st, (const FrameDesc*)g->dev.desc, g->h_status, (u64)push_no, g->h_pushes_done);
   HIP_TRY(hipGetLastError());
+  g->pushes.store(push_no, std::memory_order_release);
   return XM_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   if (!g || !out) return fail(XM_ERR_INVALID, "NULL argument");
@@ -386,8 +540,9 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->overflow = v.overflow;
   out->depth = g->h_depth[slot];
   out->bgr = g->h_bgr[slot];
-  g->est_frame_events = v.n_events;  // the next frames' K1 variant / block size follow the stream's density
   {  // after that frame's cut `live_after` events were left; everything pushed since may have been appended
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->est_frame_events = v.n_events;  // the next frames' K1 variant / block size follow the stream's density
     uint64_t later = 0;
     size_t keep_from = g->recent.size();
     for (size_t i = g->recent.size(); i-- > 0;) {
@@ -405,6 +560,8 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
 int xm_ingest_flush(xm_ingest* g) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(g->h->cfg.device));
+  int rc = ingest_drain(g);
+  if (rc) return rc;
   if (g->copy_stream) HIP_TRY(hipStreamSynchronize(g->copy_stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
   return XM_OK;
@@ -413,16 +570,32 @@ int xm_ingest_flush(xm_ingest* g) {
 int xm_ingest_reset(xm_ingest* g) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(g->h->cfg.device));
+  int rc = ingest_drain(g);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g->stream));
+  // RobustTriggerFinder.reset(): the buffered events are discarded (trigger_finder.py:116-119).  The stream indices start over
+  // (nothing live refers to the old ones); the frame / push counters and the sticky overflow count go on.
   IngestState z;
-  HIP_TRY(hipMemcpy(&z, g->st, sizeof z, hipMemcpyDeviceToHost));
-  z.buf_start = z.write = 0;  // RobustTriggerFinder.reset(): the buffered events are discarded (trigger_finder.py:116-119)
-  HIP_TRY(hipMemcpy(g->st, &z, sizeof z, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(&z, g->dev.st, sizeof z, hipMemcpyDeviceToHost));
+  z.start_abs = z.write_abs = z.p_head = z.p_tail = 0;
+  z.last_t = 0;
+  z.span_ok = 0;
+  HIP_TRY(hipMemcpy(g->dev.st, &z, sizeof z, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());  // (default-stream work: the ingest's non-blocking streams do not wait for it)
-  g->ub_live = 0;
-  g->recent.clear();
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->ub_live = 0;
+    g->recent.clear();
+  }
   return XM_OK;
 }
 
+int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits) {
+  if (!g) return fail(XM_ERR_INVALID, "NULL argument");
+  if (pushes) *pushes = g->push_calls;
+  if (host_seconds_in_push) *host_seconds_in_push = g->push_host_s;
+  if (staging_waits) *staging_waits = g->stage_waits;
+  return XM_OK;
+}
 
 }  // extern "C"

@@ -150,6 +150,13 @@ int process_common(xm_handle* h, EventsView ev, int mem, float* depth_out, uint8
   if (rc) return rc;
   const size_t px = (size_t)h->out_w * h->out_h;
   if (h->ab_max >= 2 && mem == XM_MEM_DEVICE && !profile && !h->capturing && !stats) {  // adaptive batching (see xm_handle::pending)
+    // One group = one kernel template (AoS or SoA, the time stamps' type, polarity column or not), chosen from its first frame:
+    // a frame of another layout closes the group that is pending and opens its own.
+    if (!h->pending.empty()) {
+      const EventsView& e0 = h->pending.front().ev;
+      if ((e0.aos != nullptr) != (ev.aos != nullptr) || e0.t_dtype != ev.t_dtype || e0.use_p != ev.use_p || (e0.p != nullptr) != (ev.p != nullptr))
+        if ((rc = flush_pending(h))) return rc;
+    }
     h->pending.push_back(xm_handle::Deferred{ev, depth_out, bgr_out});
     int in_flight = 0;
     for (hipEvent_t e : h->ab_inflight)

@@ -5,10 +5,22 @@
 //   buffer packets until they span one projector period; pauses = nonzero(diff(t) >= 40 us); the first pair of consecutive
 //   pauses more than half a period apart decides: at most one period apart and > 1000 events -> frame = evs[prev+2 : next-2],
 //   keep evs[next-2:]; otherwise drop everything up to next; no such pair -> the whole buffer is dropped.
-// Here the same chain runs as kernels over a device-resident event buffer; the frame that is cut is described by a FrameDesc
-// written BY THE DEVICE (pointer into the buffer + count), which the multi-frame K0/K1/K2 launches read -- no index ever
-// travels to the host, the host only enqueues a fixed sequence of launches per packet and later finds finished frames in a
-// pinned ring.
+// Here the same chain runs as THREE kernels per packet over a device-resident event ring (round 4; seventeen launches until
+// then -- a kernel boundary costs ~1.5 us on this chip and a launch ~3.5 us of host time, and a live camera's quarter-period
+// packets make 4-6 pushes per frame):
+//   k_ing_count    per block of 2048 packet events: how many pass the filters, how many pauses lie between them, the first and
+//                  last kept time stamp
+//   k_ing_append   the same block-local work again + the blocks' records summed in front of it (every block sums its
+//                  predecessors itself: <= 1024 records, no scan kernel): kept events -> the ring in stream order, the pauses
+//                  between them -> the pause ring (absolute stream indices, ascending).  Pauses are found ONCE, when an event
+//                  is appended, not by re-scanning the whole buffer with every packet as the reference does
+//   k_ing_segment  one block: commits the counters, then RobustTriggerFinder.find_trigger over the pause ring; the frame that is
+//                  cut is described by a FrameDesc written BY THE DEVICE (pointer into the ring + count), which the multi-frame
+//                  K0/K1/K2 launches read -- no index ever travels to the host
+// The ring holds `cap` (a power of two) events at absolute stream index & (cap - 1); its first `mirror` entries are written a
+// second time behind its end, so that any frame of <= mirror events is CONTIGUOUS in memory wherever it starts (the frame
+// kernels take a pointer + count) and nothing is ever moved (until round 4 the live part was copied to a second buffer
+// whenever the next packet might not fit).
 //
 // Activity-noise filter: Metavision's ActivityNoiseFilterAlgorithm is closed source, so its exact rule is unpinned
 // (SURVEY.md 8(c)).  OWN DEFINITION, implemented identically in oracle/ingest_oracle.py:
@@ -22,17 +34,19 @@
 
 namespace xm {
 
+constexpr int ING_THREADS = 256, ING_EPT = 8, ING_EPB = ING_THREADS * ING_EPT;  // packet events per block
+constexpr int ING_MAX_BLOCKS = 1024;                                            // => packets of up to 2 M events
+
 struct IngestState {      // device
-  u64 buf_start;          // first live event of the current buffer
-  u64 write;              // one past the last live event
-  u32 cur;                // which of the two buffers is current (compaction copies the live part to the other one)
-  u32 overflow;           // events dropped because the buffer was full (sticky)
+  u64 start_abs;          // absolute stream index of the first live event
+  u64 write_abs;          // one past the last live event (events appended so far, minus nothing: indices never restart)
+  u64 p_head, p_tail;     // live part of the pause ring (absolute counters; entry = index i with t[i+1] - t[i] >= thresh)
   u64 frames;             // frames cut so far
   u64 appended;           // events appended so far (after the filters)
-  u32 n_pauses;           // scratch: pauses found in the live part this round
-  u32 decided;            // scratch
+  u64 pushes_done;        // packets whose kernels have run (k_ing_publish counts them)
+  long long last_t;       // time stamp of event write_abs - 1 (valid when write_abs > 0)
+  u32 overflow;           // events dropped because the ring was full (sticky)
   u32 span_ok;            // scratch: the live part spans at least one period
-  u32 pad;
 };
 
 struct IngestStatus {     // pinned host ring entry, written by k_ing_publish when a frame has been produced
@@ -46,11 +60,56 @@ struct IngestStatus {     // pinned host ring entry, written by k_ing_publish wh
   u32 pad;
 };
 
+struct IngBlk {           // what one block of k_ing_count found in its 2048 packet events
+  u32 kept;               // events that pass the filters
+  u32 pauses;             // pauses between consecutive kept events INSIDE the block (the one in front of its first kept event
+                          // depends on an earlier block: k_ing_append / k_ing_segment add it from first_t / last_t)
+  long long first_t, last_t;
+  u64 pad;
+};
+static_assert(sizeof(IngBlk) == 32, "IngBlk layout");
+
+struct IngestDev {        // by value to every ingest kernel
+  IngestState* st;
+  uint4* buf;             // cap + mirror records
+  u64 cap, mirror;        // cap: power of two
+  u64 max_packet;         // largest packet the host hands in
+  u64* pring;             // pause ring, pcap entries (power of two)
+  u64 pcap;
+  IngBlk* blk;            // ING_MAX_BLOCKS records of the current packet
+  long long* last_ts;     // activity filter: per-pixel latest time stamp (NULL: filter off)
+  int cam_w, cam_h;
+  long long pause_thresh;
+  double period;
+  u32 min_events, ring;
+  FrameDesc* desc;
+  u64* key_frame;
+  SlotState* slot;
+  float* const* depth_ring;
+  uint8_t* const* bgr_ring;
+};
+
+struct IngestPush {       // one packet
+  const uint4* src;       // its records (device memory)
+  const u32* keep;        // non-NULL: keep flags computed by k_ing_mark (activity filter); NULL: the polarity rule alone
+  const u32* n_dev;       // non-NULL: the packet's event count lives on the device (a chunk decoded there)
+  u32 n;                  // ... else this many (with n_dev: the room of the packet's slot)
+  u32 flags;              // ING_F_*
+};
+constexpr u32 ING_F_POLARITY = 1u;  // keep p == 1 only
+constexpr u32 ING_F_SEGMENT = 2u;   // k_ing_segment: run the trigger finder (else: commit the packet only -- sub-packets)
+
 constexpr long long ING_NO_TS = (long long)0x8000000000000000ull;
 
 __device__ inline long long rec_t(const uint4& r) { return (long long)(((u64)r.w << 32) | r.z); }
+// (a count on the device: n is the room of the packet's slot -- a chunk that decoded to more has been truncated to that)
+__device__ inline u32 ing_packet_n(const IngestPush& p) {
+  if (!p.n_dev) return p.n;
+  const u32 m = *p.n_dev;
+  return m < p.n ? m : p.n;
+}
 
-// ---- filters ----------------------------------------------------------------------------------------------------------
+// ---- filters (activity rule: separate passes, the first-index map must be complete before any event is judged) ------------
 // first event index of the sub-packet per pixel (positive events only)
 __global__ __launch_bounds__(BLOCK) void k_ing_first(const uint4* __restrict__ pkt, u32 m, int use_pol, int cam_w, int cam_h,
                                                      u32* __restrict__ first_idx) {
@@ -93,146 +152,382 @@ __global__ __launch_bounds__(BLOCK) void k_ing_mark(const uint4* __restrict__ pk
   keep[i] = k ? 1u : 0u;
 }
 
-// compact the kept events behind the write cursor; every positive event becomes its pixel's latest event
-__global__ __launch_bounds__(SCAN_BLOCK) void k_ing_append(const uint4* __restrict__ pkt, u32 m, int use_pol, int cam_w, int cam_h,
-                                                          const u32* __restrict__ keep, const u32* __restrict__ pos,
-                                                          const u32* __restrict__ sums, const u32* __restrict__ total,
-                                                          IngestState* st, uint4* __restrict__ buf0, uint4* __restrict__ buf1,
-                                                          u64 capacity, long long* __restrict__ last_ts) {
-  const u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  if (i >= m) return;
-  const uint4 r = pkt[i];
-  const bool positive = !use_pol || (short)(r.y & 0xffff) == 1;
-  if (positive && last_ts) {
-    const u32 x = r.x & 0xffff, y = r.x >> 16;
-    if (x < (u32)cam_w && y < (u32)cam_h)
-      __hip_atomic_fetch_max(&last_ts[y * (u32)cam_w + x], rec_t(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- the block-local part shared by k_ing_count and k_ing_append -----------------------------------------------------------
+// Thread `tid` holds events i = block * 2048 + j * 256 + tid, j = 0..7 (coalesced 16-byte loads).  Kept events are ranked in
+// stream order inside the block (ballots per slab of 256, a 32-entry prefix over (slab, wave)); their time stamps go to LDS in
+// rank order, where every kept event but the block's first finds its predecessor.
+struct IngLocal {
+  uint4 r[ING_EPT];
+  u32 rank[ING_EPT];     // rank among the block's kept events (valid where the keep bit is set)
+  u32 keep_bits;         // bit j: event j of this thread is kept
+  u32 pause_bits;        // bit j: a pause lies between event j and the kept event before it (never set for rank 0)
+  u32 n_kept;            // block totals
+  u32 n_pauses;
+};
+
+struct IngShared {
+  long long t[ING_EPB];
+  u32 cnt[ING_EPT][ING_THREADS / 64];
+  u32 off[ING_EPT][ING_THREADS / 64];
+  u32 total, ptotal;
+};
+
+__device__ inline void ing_block_local(const IngestPush& p, u32 n, u32 block, long long thresh, IngShared& s, IngLocal& L) {
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  const bool use_pol = (p.flags & ING_F_POLARITY) != 0;
+  u32 before[ING_EPT];
+  L.keep_bits = 0;
+#pragma unroll
+  for (int j = 0; j < ING_EPT; ++j) {
+    const u32 i = block * ING_EPB + j * ING_THREADS + tid;
+    const bool valid = i < n;
+    L.r[j] = valid ? p.src[i] : make_uint4(0, 0, 0, 0);
+    bool k = valid && (p.keep ? p.keep[i] != 0 : (!use_pol || (short)(L.r[j].y & 0xffff) == 1));
+    const u64 b = __ballot(k);
+    before[j] = __popcll(b & lt_mask);
+    if (lane == 0) s.cnt[j][wave] = __popcll(b);
+    L.keep_bits |= k ? (1u << j) : 0u;
   }
-  if (!keep[i]) return;
-  const u64 w = st->write;  // not modified by this kernel (k_ing_commit advances it)
-  if (w + *total > capacity) return;  // buffer full: the packet is dropped (k_ing_commit counts it)
-  uint4* buf = st->cur ? buf1 : buf0;
-  uint4 o = r;
-  o.y = (o.y & 0xffff0000u) | 1u;  // p = 1 (like the filters' outputs)
-  buf[w + sums[blockIdx.x] + pos[i]] = o;
+  __syncthreads();
+  if (tid < ING_EPT * (ING_THREADS / 64)) {  // 32 entries in (slab, wave) order = stream order: exclusive prefix by one wave
+    const u32 v = (&s.cnt[0][0])[tid];
+    u32 incl = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const u32 up = __shfl_up(incl, o, 64);
+      if ((int)tid >= o) incl += up;
+    }
+    (&s.off[0][0])[tid] = incl - v;
+    if (tid == ING_EPT * (ING_THREADS / 64) - 1) s.total = incl;
+  }
+  __syncthreads();
+  L.n_kept = s.total;
+#pragma unroll
+  for (int j = 0; j < ING_EPT; ++j) {
+    L.rank[j] = s.off[j][wave] + before[j];
+    if (L.keep_bits & (1u << j)) s.t[L.rank[j]] = rec_t(L.r[j]);
+  }
+  __syncthreads();
+  L.pause_bits = 0;
+  u32 np = 0;
+#pragma unroll
+  for (int j = 0; j < ING_EPT; ++j) {
+    if ((L.keep_bits & (1u << j)) && L.rank[j] > 0 && rec_t(L.r[j]) - s.t[L.rank[j] - 1] >= thresh) {
+      L.pause_bits |= 1u << j;
+      np += 1;
+    }
+  }
+  // block total of the pauses (their order inside the block follows from the ranks: see ing_pause_rank)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o, 64);
+  __syncthreads();  // (s.cnt is reused)
+  if (lane == 0) s.cnt[0][wave] = np;
+  __syncthreads();
+  L.n_pauses = s.cnt[0][0] + s.cnt[0][1] + s.cnt[0][2] + s.cnt[0][3];
 }
 
-__global__ void k_ing_commit(IngestState* st, const u32* __restrict__ total, u64 capacity) {
-  if (threadIdx.x || blockIdx.x) return;
-  const u64 n = *total;
-  if (st->write + n > capacity) {
-    st->overflow += (u32)n;
-    return;
+__global__ __launch_bounds__(ING_THREADS) void k_ing_count(IngestDev d, IngestPush p) {
+  __shared__ IngShared s;
+  const u32 n = ing_packet_n(p);
+  const u32 nb = (n + ING_EPB - 1) / ING_EPB;
+  if (blockIdx.x >= nb) return;
+  IngLocal L;
+  ing_block_local(p, n, blockIdx.x, d.pause_thresh, s, L);
+  if (threadIdx.x == 0) {
+    IngBlk o;
+    o.kept = L.n_kept;
+    o.pauses = L.n_pauses;
+    o.first_t = L.n_kept ? s.t[0] : 0;
+    o.last_t = L.n_kept ? s.t[L.n_kept - 1] : 0;
+    o.pad = 0;
+    d.blk[blockIdx.x] = o;
   }
-  st->write += n;
-  st->appended += n;
 }
 
-// make room: when the next packet might not fit behind the write cursor, the live part moves to the front of the OTHER buffer
-__global__ __launch_bounds__(BLOCK) void k_ing_compact(IngestState* st, uint4* __restrict__ buf0, uint4* __restrict__ buf1,
-                                                       u64 capacity, u64 incoming_max) {
-  const u64 start = st->buf_start, write = st->write;  // read-only here (k_ing_compact_commit flips the buffers)
-  if (write + incoming_max <= capacity) return;
-  const uint4* src = st->cur ? buf1 : buf0;
-  uint4* dst = st->cur ? buf0 : buf1;
-  const u64 live = write - start, stride = (u64)gridDim.x * BLOCK;
-  for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < live; i += stride) dst[i] = src[start + i];
+// The packet's block records -> what lies in front of block `b` (kept events, pauses) and the packet's totals.  A pause in
+// front of a block's FIRST kept event is decided here: against the last kept event of the nearest earlier block that kept
+// anything, or against the stream's last event (tail_t) when there is none.  Every thread of the block takes part; nb <= 1024.
+struct IngScan {
+  u32 kept_before, pauses_before;  // of block b
+  u32 kept_total, pauses_total;
+  long long prev_t;                // time stamp in front of block b's first kept event
+  bool has_prev, boundary_pause;   // ... whether there is one, and whether a pause lies between the two
+};
+
+struct IngScanShared {
+  u32 kept[ING_MAX_BLOCKS];
+  long long last_t[ING_MAX_BLOCKS];
+  int group_last[ING_MAX_BLOCKS / 64];
+  u32 red[4][ING_THREADS / 64];
+  int pred_b, bp_b;
+};
+
+__device__ inline IngScan ing_scan_blocks(const IngBlk* __restrict__ blk, u32 nb, u32 b, bool has_tail, long long tail_t,
+                                          long long thresh, IngScanShared& s) {
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  // pass 1: kept / last_t to LDS, the last block of every group of 64 that kept anything
+  for (u32 base = 0; base < nb; base += ING_THREADS) {
+    const u32 j = base + tid;
+    const u32 k = j < nb ? blk[j].kept : 0u;
+    if (j < nb) {
+      s.kept[j] = k;
+      s.last_t[j] = blk[j].last_t;
+    }
+    const u64 bal = __ballot(k != 0);
+    if (lane == 0) s.group_last[(base >> 6) + wave] = bal ? (int)(base + wave * 64 + 63 - __builtin_clzll(bal)) : -1;
+  }
+  __syncthreads();
+  // pass 2: per block j its predecessor, the boundary pause, the sums
+  u32 kb = 0, pb = 0, kt = 0, pt = 0;
+  for (u32 base = 0; base < nb; base += ING_THREADS) {
+    const u32 j = base + tid;
+    const u32 k = j < nb ? s.kept[j] : 0u;
+    const u64 bal = __ballot(k != 0);
+    if (j < nb) {
+      int pred = -1;
+      const u64 below = bal & lt_mask;
+      if (below) pred = (int)(base + wave * 64 + 63 - __builtin_clzll(below));
+      else
+        for (int g = (int)(j >> 6) - 1; g >= 0 && pred < 0; --g) pred = s.group_last[g];
+      bool bp = false;
+      if (k) {
+        const long long ft = blk[j].first_t;
+        bp = pred >= 0 ? ft - s.last_t[pred] >= thresh : (has_tail && ft - tail_t >= thresh);
+      }
+      const u32 add_p = blk[j].pauses + (bp ? 1u : 0u);
+      if (j == b) {
+        s.pred_b = pred;
+        s.bp_b = bp ? 1 : 0;
+      }
+      if (j < b) {
+        kb += k;
+        pb += add_p;
+      }
+      kt += k;
+      pt += add_p;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kb += __shfl_xor(kb, o, 64);
+    pb += __shfl_xor(pb, o, 64);
+    kt += __shfl_xor(kt, o, 64);
+    pt += __shfl_xor(pt, o, 64);
+  }
+  if (lane == 0) {
+    s.red[0][wave] = kb;
+    s.red[1][wave] = pb;
+    s.red[2][wave] = kt;
+    s.red[3][wave] = pt;
+  }
+  __syncthreads();
+  IngScan o;
+  o.kept_before = s.red[0][0] + s.red[0][1] + s.red[0][2] + s.red[0][3];
+  o.pauses_before = s.red[1][0] + s.red[1][1] + s.red[1][2] + s.red[1][3];
+  o.kept_total = s.red[2][0] + s.red[2][1] + s.red[2][2] + s.red[2][3];
+  o.pauses_total = s.red[3][0] + s.red[3][1] + s.red[3][2] + s.red[3][3];
+  o.has_prev = false;
+  o.boundary_pause = false;
+  o.prev_t = 0;
+  if (b < nb) {
+    const int pred = s.pred_b;
+    o.boundary_pause = s.bp_b != 0;
+    o.has_prev = pred >= 0 || has_tail;
+    o.prev_t = pred >= 0 ? s.last_t[pred] : tail_t;
+  }
+  return o;
 }
-__global__ void k_ing_compact_commit(IngestState* st, u64 capacity, u64 incoming_max) {
-  if (threadIdx.x || blockIdx.x) return;
-  if (st->write + incoming_max <= capacity) return;
-  const u64 live = st->write - st->buf_start;
-  st->cur ^= 1u;
-  st->buf_start = 0;
-  st->write = live;
-  if (live + incoming_max > capacity) {  // even the live part alone leaves no room: drop it (counted)
-    st->overflow += (u32)live;
-    st->write = 0;
+
+// kept events -> the ring, pauses -> the pause ring; every positive event becomes its pixel's latest event (activity filter)
+__global__ __launch_bounds__(ING_THREADS) void k_ing_append(IngestDev d, IngestPush p) {
+  __shared__ IngShared s;
+  __shared__ IngScanShared ss;
+  __shared__ u32 s_prank[ING_EPT][ING_THREADS / 64];
+  const u32 n = ing_packet_n(p);
+  const u32 nb = (n + ING_EPB - 1) / ING_EPB;
+  if (blockIdx.x >= nb) return;
+  const IngestState st = *d.st;  // (not modified by this kernel: k_ing_segment commits)
+  const IngScan sc = ing_scan_blocks(d.blk, nb, blockIdx.x, st.write_abs > 0, st.last_t, d.pause_thresh, ss);
+  IngLocal L;
+  ing_block_local(p, n, blockIdx.x, d.pause_thresh, s, L);
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  // the block's first kept event: the pause in front of it was decided by the scan
+  u32 pb = L.pause_bits;
+#pragma unroll
+  for (int j = 0; j < ING_EPT; ++j)
+    if ((L.keep_bits & (1u << j)) && L.rank[j] == 0 && sc.boundary_pause) pb |= 1u << j;
+  // order of the pauses inside the block = order of their events: ballots per slab again
+  u32 pbefore[ING_EPT];
+#pragma unroll
+  for (int j = 0; j < ING_EPT; ++j) {
+    const u64 b = __ballot((pb >> j) & 1u);
+    pbefore[j] = __popcll(b & lt_mask);
+    if (lane == 0) s_prank[j][wave] = __popcll(b);
+  }
+  __syncthreads();
+  if (tid < ING_EPT * (ING_THREADS / 64)) {
+    const u32 v = (&s_prank[0][0])[tid];
+    u32 incl = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const u32 up = __shfl_up(incl, o, 64);
+      if ((int)tid >= o) incl += up;
+    }
+    (&s_prank[0][0])[tid] = incl - v;
+  }
+  __syncthreads();
+  const u64 limit = st.start_abs + d.cap;  // the ring is full beyond: such events are dropped (k_ing_segment counts them)
+  const u64 base = st.write_abs + sc.kept_before;
+  const u64 pbase = st.p_tail + sc.pauses_before;
+#pragma unroll
+  for (int j = 0; j < ING_EPT; ++j) {
+    const u32 i = blockIdx.x * ING_EPB + j * ING_THREADS + tid;
+    if (i >= n) continue;
+    const uint4 r = L.r[j];
+    if (d.last_ts && (!(p.flags & ING_F_POLARITY) || (short)(r.y & 0xffff) == 1)) {
+      const u32 x = r.x & 0xffff, y = r.x >> 16;
+      if (x < (u32)d.cam_w && y < (u32)d.cam_h)
+        __hip_atomic_fetch_max(&d.last_ts[y * (u32)d.cam_w + x], rec_t(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!(L.keep_bits & (1u << j))) continue;
+    const u64 abs = base + L.rank[j];
+    if (abs >= limit) continue;
+    uint4 o = r;
+    o.y = (o.y & 0xffff0000u) | 1u;  // p = 1 (like the filters' outputs)
+    const u64 pos = abs & (d.cap - 1);
+    d.buf[pos] = o;
+    if (pos < d.mirror) d.buf[d.cap + pos] = o;
+    if ((pb >> j) & 1u) d.pring[(pbase + s_prank[j][wave] + pbefore[j]) & (d.pcap - 1)] = abs - 1;  // t[abs] - t[abs - 1] >= thresh
   }
 }
 
 // ---- segmentation -------------------------------------------------------------------------------------------------------
-// does the live part span a period?  (trigger_finder.py:137-139)  Also clears the per-round scratch.
-__global__ void k_ing_begin(IngestState* st, const uint4* __restrict__ buf0, const uint4* __restrict__ buf1, double period,
-                            FrameDesc* desc) {
-  if (threadIdx.x || blockIdx.x) return;
-  st->n_pauses = 0;
-  st->decided = 0;
-  st->span_ok = 0;
-  desc->valid = 0;
-  if (st->write == st->buf_start) return;
-  const uint4* buf = st->cur ? buf1 : buf0;
-  const long long span = rec_t(buf[st->write - 1]) - rec_t(buf[st->buf_start]);
-  st->span_ok = !((double)span < period);
-}
-
-// pauses of the live part: flags[i] = t[i+1] - t[i] >= thresh for live-relative i (grid covers the host's upper bound)
-__global__ __launch_bounds__(SCAN_BLOCK) void k_ing_pause_flags(const IngestState* __restrict__ st, const uint4* __restrict__ buf0,
-                                                               const uint4* __restrict__ buf1, long long thresh, u32 n_bound,
-                                                               u32* __restrict__ flags) {
-  const u32 i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  if (i >= n_bound) return;
-  u32 f = 0;
-  if (st->span_ok) {
-    const u64 live = st->write - st->buf_start;
-    if ((u64)i + 1 < live) {
-      const uint4* buf = (st->cur ? buf1 : buf0) + st->buf_start;
-      f = (rec_t(buf[i + 1]) - rec_t(buf[i])) >= thresh ? 1u : 0u;
+// The decision of find_trigger (trigger_finder.py:137-189) over the live pauses; every thread of the block takes part.
+__device__ inline void ing_find_trigger(const IngestDev& d, u64& s_first) {
+  IngestState* st = d.st;
+  const u32 tid = threadIdx.x;
+  const u64 start = st->start_abs, write = st->write_abs;
+  if (write == start) return;
+  const u64 mask = d.cap - 1;
+  {
+    const long long span = rec_t(d.buf[(write - 1) & mask]) - rec_t(d.buf[start & mask]);
+    if ((double)span < d.period) return;  // fewer than one period buffered: wait for more (trigger_finder.py:137-139)
+  }
+  // pauses in front of the live part have left the buffer with their events (the list is ascending: skip its stale head)
+  u64 ph = st->p_head;
+  const u64 pt = st->p_tail;
+  for (;;) {  // (block-uniform loop)
+    const u64 k = ph + tid;
+    const bool stale = k < pt && d.pring[k & (d.pcap - 1)] < start;
+    const int cnt = __syncthreads_count(stale);
+    ph += (u64)cnt;
+    if (cnt < ING_THREADS) break;
+  }
+  // the first pair of consecutive pauses more than half a period apart
+  for (u64 k0 = ph; k0 + 1 < pt; k0 += ING_THREADS) {
+    const u64 k = k0 + tid;
+    if (k + 1 < pt) {
+      const long long gap = rec_t(d.buf[d.pring[(k + 1) & (d.pcap - 1)] & mask]) - rec_t(d.buf[d.pring[k & (d.pcap - 1)] & mask]);
+      if ((double)gap > d.period / 2) atomicMin((unsigned long long*)&s_first, (unsigned long long)k);
     }
+    __syncthreads();
+    const u64 found = s_first;
+    __syncthreads();  // (nobody moves on to the next chunk's atomicMin before everybody has read this chunk's verdict)
+    if (found != ~0ull) break;
   }
-  flags[i] = f;
-}
-
-// The decision of find_trigger (trigger_finder.py:146-189) over the compacted pause list (live-relative indices, ascending).
-// One block: the first pair (k, k+1) whose pauses are more than half a period apart is found with a block-wide minimum,
-// thread 0 then applies the rule and writes the frame's descriptor.
-__global__ __launch_bounds__(BLOCK) void k_ing_segment(IngestState* st, const uint4* __restrict__ buf0, const uint4* __restrict__ buf1,
-                                                       const u32* __restrict__ pauses, const u32* __restrict__ n_pauses_dev,
-                                                       double period, u32 min_events, FrameDesc* desc, u64* key_frame,
-                                                       SlotState* slot, float* const* depth_ring, uint8_t* const* bgr_ring,
-                                                       u32 ring) {
-  __shared__ u32 s_first;
-  if (threadIdx.x == 0) s_first = 0xffffffffu;
-  __syncthreads();
-  if (!st->span_ok) return;  // fewer than one period buffered: wait for more (trigger_finder.py:137-139)
-  const uint4* buf = (st->cur ? buf1 : buf0) + st->buf_start;
-  const u32 np = *n_pauses_dev;
-  for (u32 k = threadIdx.x; k + 1 < np; k += BLOCK) {
-    const long long gap = rec_t(buf[pauses[k + 1]]) - rec_t(buf[pauses[k]]);
-    if ((double)gap > period / 2) atomicMin(&s_first, k);
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const u32 k = s_first;
-  if (k == 0xffffffffu) {  // no plausible pair: the reference has popped the whole buffer and pushes nothing back
-    st->buf_start = st->write;
+  if (tid != 0) return;
+  st->span_ok = 1;
+  const u64 k = s_first;
+  if (k == ~0ull) {  // no plausible pair: the reference has popped the whole buffer and pushes nothing back
+    st->start_abs = write;
+    st->p_head = pt;
     return;
   }
-  const u32 prev = pauses[k], next = pauses[k + 1];
-  const long long gap = rec_t(buf[next]) - rec_t(buf[prev]);
-  if ((double)gap <= period && next - prev > min_events) {
-    const u64 first = (u64)prev + 2, last = (u64)next - 2;  // evs[prev + 2 : next - 2]
-    const u32 slot_i = (u32)(st->frames % ring);
-    desc->x = nullptr; desc->y = nullptr; desc->t = nullptr; desc->p = nullptr;
-    desc->aos = buf + first;
-    desc->n = last - first;
-    desc->key_frame = key_frame;
-    desc->st = slot;
-    desc->depth = depth_ring ? depth_ring[slot_i] : nullptr;
-    desc->bgr = bgr_ring ? bgr_ring[slot_i] : nullptr;
-    desc->pad = slot_i;
-    desc->valid = 1;
-    st->buf_start += last;  // push(evs[next - 2 :])
-    st->decided = 1;
+  const u64 prev = d.pring[k & (d.pcap - 1)], next = d.pring[(k + 1) & (d.pcap - 1)];
+  const long long gap = rec_t(d.buf[next & mask]) - rec_t(d.buf[prev & mask]);
+  st->p_head = k + 1;  // (entries below `next` are stale from here on; the exact head is found again next time)
+  if ((double)gap <= d.period && next - prev > d.min_events) {
+    const u64 first = prev + 2, last = next - 2;  // evs[prev + 2 : next - 2]
+    if (last - first <= d.mirror) {
+      const u32 slot_i = (u32)(st->frames % d.ring);
+      FrameDesc* desc = d.desc;
+      desc->x = nullptr; desc->y = nullptr; desc->t = nullptr; desc->p = nullptr;
+      desc->aos = d.buf + (first & mask);  // contiguous: the ring's head is mirrored behind its end
+      desc->n = last - first;
+      desc->key_frame = d.key_frame;
+      desc->st = d.slot;
+      desc->depth = d.depth_ring ? d.depth_ring[slot_i] : nullptr;
+      desc->bgr = d.bgr_ring ? d.bgr_ring[slot_i] : nullptr;
+      desc->pad = slot_i;
+      desc->valid = 1;
+    } else {
+      st->overflow += (u32)(last - first);  // a frame longer than the mirrored part cannot be handed out in one piece
+    }
+    st->start_abs = last;  // push(evs[next - 2 :])
   } else {
-    st->buf_start += next;  // "trigger not found correctly, drop these events": push(evs[next:])
+    st->start_abs = next;  // "trigger not found correctly, drop these events": push(evs[next:])
+  }
+}
+
+// Commits the packet (write cursor, pause ring, overflow), then -- ING_F_SEGMENT -- the trigger finder.  One block.
+__global__ __launch_bounds__(ING_THREADS) void k_ing_segment(IngestDev d, IngestPush p) {
+  __shared__ IngScanShared ss;
+  __shared__ u64 s_first;
+  IngestState* st = d.st;
+  const u32 n = ing_packet_n(p);
+  const u32 nb = (n + ING_EPB - 1) / ING_EPB;
+  const u32 tid = threadIdx.x;
+  {
+    const IngestState cur = *st;
+    const IngScan sc = ing_scan_blocks(d.blk, nb, nb, cur.write_abs > 0, cur.last_t, d.pause_thresh, ss);
+    __syncthreads();
+    if (tid == 0) {
+      const u64 limit = cur.start_abs + d.cap;
+      u64 w = cur.write_abs + sc.kept_total, pt = cur.p_tail + sc.pauses_total;
+      if (w > limit) {  // ring full: the packet's tail was not stored; its pauses go too
+        st->overflow += (u32)(w - limit);
+        w = limit;
+        while (pt > cur.p_tail && d.pring[(pt - 1) & (d.pcap - 1)] + 1 >= w) --pt;
+      }
+      if (p.n_dev && *p.n_dev > p.n) st->overflow += *p.n_dev - p.n;  // (a chunk decoded on the device that did not fit its slot)
+      st->appended += w - cur.write_abs;
+      st->write_abs = w;
+      st->p_tail = pt;
+      if (w > 0) st->last_t = rec_t(d.buf[(w - 1) & (d.cap - 1)]);
+      if (p.flags & ING_F_SEGMENT) {
+        d.desc->valid = 0;
+        st->span_ok = 0;
+      }
+      s_first = ~0ull;
+    }
+    __syncthreads();
+  }
+  if (!(p.flags & ING_F_SEGMENT)) return;
+  ing_find_trigger(d, s_first);
+  __syncthreads();
+  // No room for another full packet behind what is still live (a stream without a usable pause: the reference's buffer would
+  // grow without bound): the live part is dropped and counted, as if the trigger finder had given up on it.
+  if (tid == 0 && st->write_abs - st->start_abs + d.max_packet > d.cap) {
+    st->overflow += (u32)(st->write_abs - st->start_abs);
+    st->start_abs = st->write_abs;
+    st->p_head = st->p_tail;
   }
 }
 
 // after the frame kernels: statistics + sequence number into the pinned ring (system scope: the host polls it)
 __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const FrameDesc* __restrict__ desc, IngestStatus* ring_status,
-                                                    u64 push_seq) {
-  if (!desc->valid) return;
+                                                    u64 push_seq, u64* pushes_done_host) {
+  if (threadIdx.x == 0) st->pushes_done = push_seq;
+  if (!desc->valid) {
+    // (a store to host memory keeps the kernel alive for a PCIe round trip: every fourth packet is often enough for the staging
+    //  ring's flow control -- 16 entries)
+    if (threadIdx.x == 0 && pushes_done_host && (push_seq & 3) == 0)
+      __hip_atomic_store(pushes_done_host, push_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   const SlotState* s = desc->st;
   const u32 tag = s->tag_a, parity = tag & 1;
   u64 inl = 0, oob = 0, used = 0;
@@ -255,12 +550,13 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
   out->n_inliers = inl;
   out->n_index_errors = oob;
   out->n_used = used;
-  out->live_after = st->write - st->buf_start;
+  out->live_after = st->write_abs - st->start_abs;
   out->push_seq = push_seq;
   out->overflow = st->overflow;
   st->frames += 1;
   __threadfence_system();
   __hip_atomic_store(&out->seq, st->frames, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (pushes_done_host) __hip_atomic_store(pushes_done_host, push_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace xm

@@ -194,10 +194,15 @@ class DeviceEvt3Decoder:
             o += len(e)
         return cat
 
-    def push(self, ingest, words: np.ndarray, pinned: bool = False) -> int:
-        """pinned=True: `words` lies in pinned host memory (XMapsEngine.host_empty): no staging copy"""
+    def push(self, ingest, words: np.ndarray, pinned: bool = False, count: bool = True):
+        """One chunk = one packet of `ingest`.  pinned=True: `words` lies in pinned host memory (XMapsEngine.host_empty): no
+        staging copy.  count=True: waits for the decoder and returns the chunk's event count; count=False: nothing is waited
+        for (the ingest's kernels read the count on the device), returns None."""
         C = self._C
         w = np.ascontiguousarray(words, dtype="<u2")
+        if not count:
+            self._N.check(self._lib.xm_ingest_push_evt3(ingest._g, self._d, C.c_void_p(w.ctypes.data), len(w), int(bool(pinned)), None))
+            return None
         n = C.c_size_t(0)
         self._N.check(self._lib.xm_ingest_push_evt3(ingest._g, self._d, C.c_void_p(w.ctypes.data), len(w), int(bool(pinned)), C.byref(n)))
         return int(n.value)
@@ -245,6 +250,7 @@ def encode_evt3(evs: np.ndarray, use_vectors: bool = True) -> np.ndarray:
         if hi != cur_hi:
             words.append((T_TIME_HIGH << 12) | hi)
             cur_hi = hi
+            cur_lo = None  # a TIME_HIGH that changes the high field restarts the low field at 0 in the decoders: always re-send it
         if lo != cur_lo:
             words.append((T_TIME_LOW << 12) | lo)
             cur_lo = lo
@@ -270,7 +276,7 @@ def encode_evt3(evs: np.ndarray, use_vectors: bool = True) -> np.ndarray:
 
 def encode_evt3_singles(evs: np.ndarray) -> np.ndarray:
     """EventCD (time-ordered) -> EVT 3.0 words without vector words, vectorised (the file writer above is a Python loop): per
-    event [TIME_HIGH if the high field changed] [TIME_LOW if the low field changed] [ADDR_Y if the row changed] ADDR_X."""
+    event [TIME_HIGH if the high field changed] [TIME_LOW if the low or the high field changed] [ADDR_Y if the row changed] ADDR_X."""
     n = len(evs)
     if n == 0:
         return np.zeros(0, "<u2")
@@ -279,7 +285,7 @@ def encode_evt3_singles(evs: np.ndarray) -> np.ndarray:
     first = np.zeros(n, bool)
     first[0] = True
     c_hi = first | (np.concatenate(([0], hi[:-1])) != hi)
-    c_lo = first | (np.concatenate(([0], lo[:-1])) != lo)
+    c_lo = first | c_hi | (np.concatenate(([0], lo[:-1])) != lo)  # (a changed high field restarts the low field: re-send it)
     c_y = first | (np.concatenate(([0], y[:-1])) != y)
     per = c_hi.astype(np.int64) + c_lo + c_y + 1
     end = np.cumsum(per)  # one past the event's ADDR_X word

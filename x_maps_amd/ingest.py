@@ -40,7 +40,8 @@ class IngestFrame:
 class DeviceIngest:
     def __init__(self, engine, projector_fps: int, use_polarity: bool = True, activity_filter: bool = False,
                  activity_thresh_us: int = 0, capacity_events: int = 0, max_packet_events: int = 0, result_ring: int = 8,
-                 expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True, min_events_per_frame: int = 0):
+                 expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True, min_events_per_frame: int = 0,
+                 launch_thread: bool = True):
         self._e = engine
         self._lib = engine._lib
         cfg = N.xm_ingest_config()
@@ -56,10 +57,14 @@ class DeviceIngest:
         cfg.max_packet_events = int(max_packet_events)
         cfg.expected_events_per_frame = int(expected_events_per_frame)
         cfg.want_depth, cfg.want_bgr = int(want_depth), int(want_bgr)
+        cfg.flags = 0 if launch_thread else N.XM_INGEST_NO_LAUNCH_THREAD  # (default: push() posts to the ingest's launch thread)
         self._g = C.c_void_p(None)
         N.check(self._lib.xm_ingest_create(engine._h, C.byref(cfg), C.byref(self._g)))
         self.max_packet = int(max_packet_events) or (1 << 19)
         self.shape = (engine.out_h, engine.out_w)
+        self._views = {}
+        self._fr = N.xm_ingest_frame()
+        self._fr_ref = C.byref(self._fr)
 
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:
@@ -99,29 +104,48 @@ class DeviceIngest:
             part = evs[a:a + self.max_packet]
             N.check(self._lib.xm_ingest_push_pinned(self._g, C.c_void_p(part.ctypes.data), len(part)))
 
+    def _view(self, ptr, shape, ctype):
+        """NumPy view of one buffer of the pinned result ring (built once per buffer, from the address: np.ctypeslib.as_array on
+        a pointer costs ~0.2 ms for a 2 M-pixel frame)."""
+        v = self._views.get(ptr)
+        if v is None:
+            n = int(np.prod(shape))
+            v = np.frombuffer((ctype * n).from_address(ptr), dtype=np.dtype(ctype)).reshape(shape)
+            self._views[ptr] = v
+        return v
+
     def poll(self, copy: bool = True) -> list[IngestFrame]:
         """Frames finished since the last call.  copy=True (default): depth / bgr are fresh NumPy arrays, as the reference's
         frame_callback gets them (for a 1080 x 1920 projector that copy -- 14.5 MB per frame -- is 1.2 ms of host time);
-        copy=False: views into the pinned result ring, valid until `result_ring` further frames have been cut."""
+        copy=False: views into the pinned result ring, valid until `result_ring` - 1 further frames have been cut (the
+        lifetime xm_ingest_frame documents) -- what a display or an encoder that consumes the frame at once wants."""
         out = []
-        fr = N.xm_ingest_frame()
+        fr = self._fr
         h, w = self.shape
+        poll = self._lib.xm_ingest_poll
         while True:
-            rc = self._lib.xm_ingest_poll(self._g, C.byref(fr))
+            rc = poll(self._g, self._fr_ref)
             if rc < 0:
                 N.check(rc)
             if rc == 0:
                 break
             depth = bgr = None
             if fr.depth:
-                depth = np.ctypeslib.as_array(C.cast(fr.depth, C.POINTER(C.c_float)), shape=(h, w))
+                depth = self._view(fr.depth, (h, w), C.c_float)
                 depth = depth.copy() if copy else depth
             if fr.bgr:
-                bgr = np.ctypeslib.as_array(C.cast(fr.bgr, C.POINTER(C.c_uint8)), shape=(h, w, 3))
+                bgr = self._view(fr.bgr, (h, w, 3), C.c_uint8)
                 bgr = bgr.copy() if copy else bgr
             out.append(IngestFrame(int(fr.seq), int(fr.n_events), int(fr.t_first), int(fr.t_last), int(fr.n_inliers),
                                    int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), bool(fr.lost), depth, bgr))
         return out
+
+    def host_stats(self) -> dict:
+        """What the calling thread has paid inside push() so far (xm_ingest_host_stats)."""
+        n, sec, waits = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0)
+        N.check(self._lib.xm_ingest_host_stats(self._g, C.byref(n), C.byref(sec), C.byref(waits)))
+        return {"pushes": int(n.value), "host_seconds_in_push": float(sec.value), "staging_waits": int(waits.value),
+                "us_per_push": (float(sec.value) / n.value * 1e6) if n.value else 0.0}
 
     def flush(self):
         N.check(self._lib.xm_ingest_flush(self._g))
