@@ -254,7 +254,8 @@ def test_packets_of_any_size_and_empty_packets():
     for p in pk:
         tf.process_events(IO.polarity_filter(p))
     assert len(tf.frames) >= 4
-    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 14, max_packet_events=1 << 13) as ing:
+    # (the ring must hold what the trigger finder may keep -- up to two periods -- plus a full packet: 1 << 16)
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 16, max_packet_events=1 << 13) as ing:
         got = []
         for p in pk:
             ing.push(p)
@@ -281,8 +282,8 @@ def test_a_ring_without_room_drops_its_live_part_and_says_so():
         ing.flush()
         got = ing.poll()
     assert len(got) >= 2 and all(f.overflow == 16_000 and not f.lost for f in got)
-    x, y, t, _ = S.to_soa(tail)
-    for f in got:  # every frame is a contiguous piece of the tail stream, processed like any other
+    x, y, t, _ = S.to_soa(IO.polarity_filter(tail))
+    for f in got:  # every frame is a contiguous piece of the tail stream's positive events, processed like any other
         a = int(np.searchsorted(t, f.t_first))
         while not (t[a + f.n_events - 1] == f.t_last):
             a += 1
