@@ -806,7 +806,7 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
     tf = RobustTriggerFinder(60, on_frame)
     for a, b in zip(cuts[:-1], cuts[1:]):
         tf.process_events(stream[a:b])
-    with DeviceIngest(eng, 60, capacity_events=1 << 22, max_packet_events=1 << 20, expected_events_per_frame=n_ev,
+    with DeviceIngest(eng, 60, capacity_events=1 << 23, max_packet_events=1 << 20, expected_events_per_frame=n_ev,
                       result_ring=max(8, n_frames)) as ing:
         for a, b in zip(cuts[:4], cuts[1:5]):  # warm-up: first launches of every kernel
             ing.push_pinned(stream[a:b])
@@ -817,8 +817,10 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
         for a, b in zip(cuts[:-1], cuts[1:]):
             ing.push_pinned(stream[a:b])
         ing.flush()
-        got = ing.poll()
+        got = ing.poll(copy=False)  # views into the pinned result ring (it holds every frame of this run)
         dt = time.perf_counter() - c0
+        hs = ing.host_stats()
+        got = [type(f)(**{**f.__dict__, "depth": None if f.depth is None else f.depth.copy(), "bgr": None}) for f in got]  # (kept past the ring)
     same_cut = [(f.t_first, f.n_events) for f in got] == cut_frames
     # the same stream as the recording stores it: EVT 3.0 words (about 4 bytes per event here: every event its own row word),
     # decoded on the device in front of the ingest (xm_ingest_push_evt3) -- a quarter of the bytes cross PCIe
@@ -838,7 +840,7 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
                     pw[:] = w
                     chunks.append(pw)
             n_words = int(sum(len(c) for c in chunks))
-            with DeviceIngest(eng, 60, capacity_events=1 << 22, max_packet_events=1 << 20, expected_events_per_frame=n_ev,
+            with DeviceIngest(eng, 60, capacity_events=1 << 23, max_packet_events=1 << 20, expected_events_per_frame=n_ev,
                               result_ring=max(8, n_frames)) as ing, \
                     evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
                 for c in chunks[:4]:
@@ -849,10 +851,11 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
                 dec.reset()
                 c0 = time.perf_counter()
                 for c in chunks:
-                    dec.push(ing, c, pinned=True)
+                    dec.push(ing, c, pinned=True, count=False)  # nothing waited for: the chunk's event count stays on the device
                 ing.flush()
-                got3 = ing.poll()
+                got3 = ing.poll(copy=False)
                 dt3 = time.perf_counter() - c0
+                got3 = [type(f)(**{**f.__dict__, "depth": None if f.depth is None else f.depth.copy(), "bgr": None}) for f in got3]
             leg = {"Mevents_per_s_end_to_end": round(total / dt3 / 1e6, 2), "chunks": len(chunks),
                    "bytes_per_event_over_pcie": round(2.0 * n_words / total, 2), "pcie_GBps_in": round(2.0 * n_words / dt3 / 1e9, 2),
                    "frames_cut": len(got3)}
@@ -867,8 +870,8 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
                 leg["same_frames_as_host_trigger_finder"] = bool([(f.t_first & t_mask, f.n_events) for f in got3] == leg.pop("_cut"))
             evt3_leg[label] = leg
         evt3_leg["note"] = ("the same stream as EVT 3.0 words in pinned host memory -> H2D -> decoded by three scan kernels straight into "
-                            "the ingest's packet slot (xm_ingest_push_evt3: one synchronisation of the decoder's stream per chunk for its "
-                            "event count) -> the same device pipeline; quarter_period_chunks = the packets of the EventCD run, "
+                            "the ingest's packet slot (xm_ingest_push_evt3 with n_events = NULL: nothing is waited for, the ingest's kernels read the "
+                            "chunk's event count on the device) -> the same device pipeline; quarter_period_chunks = the packets of the EventCD run, "
                             "period_chunks = one projector period per chunk (an offline replay chooses its chunks)")
     except Exception as e:  # never lose the line to the extra leg
         evt3_leg = {"error": repr(e)[:200]}
@@ -881,9 +884,13 @@ def ingest_leg(eng, host_frames, n_ev, O, tables, camera, n_frames=24):
         ok = bool(np.array_equal(f0.depth, ref["depth"]))
     return {"Mevents_per_s_end_to_end": round(total / dt / 1e6, 2), "frames_cut": len(got), "frames_in_stream": n_frames,
             "same_frames_as_host_trigger_finder": bool(same_cut), "first_frame_depth_equals_oracle": ok,
-            "pcie_GBps_in": round(total * 16 / dt / 1e9, 2), "from_evt3_words": evt3_leg,
+            "pcie_GBps_in": round(total * 16 / dt / 1e9, 2), "pushes": hs["pushes"],
+            "host_us_per_push": round(hs["us_per_push_without_waits"], 2), "host_us_per_push_incl_backpressure": round(hs["us_per_push"], 2),
+            "staging_waits": hs["staging_waits"], "from_evt3_words": evt3_leg,
             "note": "raw 16-byte EventCD packets in pinned host memory -> H2D -> filter / segment / K0-K1-K2 on the device "
-                    "(the event stream never returns to the host) -> depth + BGR in pinned host memory; pushed back to back, "
+                    "(the event stream never returns to the host; three ingest launches + the frame kernels per packet, issued by "
+                    "the ingest's launch thread: host_us_per_push is what the calling thread pays) -> depth + BGR in pinned host "
+                    "memory, handed out as views into the result ring; pushed back to back, "
                     "i.e. faster than the 60 Hz it was stamped for; the reference's trigger finder cannot cut the first and "
                     "the last frame of a stream"}
 
@@ -1177,55 +1184,13 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         eng.process_events(host[i % nf], want_depth=False, want_bgr=True)
         lat.append(time.perf_counter() - c0)
     lat = np.array(lat) * 1e3
-    # a camera-like stream through the device-side ingest, end to end
+    # a camera-like stream through the device-side ingest and through the processor, end to end
     ingest = None
     if not args.no_host_path and world == 1:
-        stream, _ = rig.render_stream(cp, tables, n_frames=16, row_stride=13, seed=9)
-        pin = eng.host_empty((len(stream),), S.EVENT_CD_DTYPE)
-        pin[:] = stream
-        packet = int(1e6 / 60 / 4)
-        cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
-        with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=int(n_mean),
-                          result_ring=32) as ing:
-            for a, b in zip(cuts[:4], cuts[1:5]):
-                ing.push_pinned(pin[a:b])
-            ing.flush(), ing.reset(), ing.poll()
-            c0 = time.perf_counter()
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                ing.push_pinned(pin[a:b])
-            ing.flush()
-            got = ing.poll()
-            dt = time.perf_counter() - c0
-        ingest = {"Mevents_per_s_end_to_end": round(len(stream) / dt / 1e6, 2), "frames_cut": len(got), "frames_in_stream": 16,
-                  "stream_seconds_at_60Hz": round(16 / 60, 3), "processed_in_seconds": round(dt, 4),
-                  "note": "raw packets (10 % negative polarity, gap noise) in pinned host memory -> frames in pinned host memory"}
-        try:  # the same stream as the recording stores it (EVT 3.0 words), one projector period per chunk, decoded on the device
-            from x_maps_amd import evt3
-            cuts3 = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + 4 * packet, 4 * packet))
-            chunks = []
-            for a, b in zip(cuts3[:-1], cuts3[1:]):
-                if b > a:
-                    w = evt3.encode_evt3_singles(pin[a:b])
-                    pw = eng.host_empty(w.shape, np.uint16)
-                    pw[:] = w
-                    chunks.append(pw)
-            n_words = int(sum(len(c) for c in chunks))
-            with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=int(n_mean),
-                              result_ring=32) as ing, evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
-                for c in chunks[:3]:
-                    dec.push(ing, c, pinned=True)
-                ing.flush(), ing.reset(), ing.poll(), dec.reset()
-                c0 = time.perf_counter()
-                for c in chunks:
-                    dec.push(ing, c, pinned=True)
-                ing.flush()
-                got3 = ing.poll()
-                dt3 = time.perf_counter() - c0
-            ingest["from_evt3_words_period_chunks"] = {
-                "Mevents_per_s_end_to_end": round(len(stream) / dt3 / 1e6, 2), "frames_cut": len(got3), "chunks": len(chunks),
-                "bytes_per_event_over_pcie": round(2.0 * n_words / len(stream), 2), "processed_in_seconds": round(dt3, 4)}
-        except Exception as e:  # never lose the line to the extra leg
-            ingest["from_evt3_words_period_chunks"] = {"error": repr(e)[:200]}
+        try:
+            ingest = esl_stream_legs(eng, cp, tables, int(n_mean), O, camera, local_rank)
+        except Exception as e:  # never lose the line to the extra legs
+            ingest = {"error": repr(e)[:300]}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         e0 = host[0]
@@ -1255,9 +1220,156 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
                                                                       "(BASELINE.md section 1; other hardware, real data: context only)"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
                    "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6)},
-        "roofline": roofline, "other_modes": other or None, "ingest_path": ingest, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "other_modes": other or None,
+        "ingest_path": (ingest or {}).get("ingest_path") if ingest and "error" not in ingest else ingest,
+        "stream_legs": {k: v for k, v in (ingest or {}).items() if k != "ingest_path"} or None,
+        "cpu_baseline": cpu, "parity": parity,
     }
     eng.close()
+    return out
+
+
+def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
+    """BASELINE config 3 stand-in, the way the reference runs it (depth_reprojection_pipe.py:110-119 -> trigger_finder.py:146-189):
+    a camera-like ESL-like stream (10 % negative events, gap noise, 60 Hz frames) as quarter-period packets of raw EventCD records.
+      device ingest   xm_ingest_push_pinned: filters, buffering, pause detection, frame cut and K0/K1/K2 on the device, frames into
+                      the pinned result ring (BGR only = what the reference's frame_callback gets; + depth; as fresh arrays)
+      processor       DepthReprojectionProcessor.process_events, host trigger finder + one fused call per cut frame (the reference's
+                      structure), and the same processor with device_ingest=True"""
+    from x_maps_amd import rig
+    from x_maps_amd import synthetic as S
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor, RuntimeParams
+    from x_maps_amd.ingest import DeviceIngest
+    from x_maps_amd.trigger_finder import RobustTriggerFinder
+    stream, _ = rig.render_stream(cp, tables, n_frames=n_frames, row_stride=13, seed=9)
+    pin = eng.host_empty((len(stream),), S.EVENT_CD_DTYPE)
+    pin[:] = stream
+    packet = int(1e6 / 60 / 4)
+    cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
+    packets = [pin[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    # what the reference's own chain cuts out of these packets (polarity filter + RobustTriggerFinder on the host)
+    want, want_frames = [], []
+
+    def on_frame(e):
+        want.append((int(e["t"][0]), int(e["t"][-1]), len(e)))
+        if len(want_frames) < 1:
+            want_frames.append(np.array(e))
+    tf = RobustTriggerFinder(60, on_frame)
+    for pk in packets:
+        tf.process_events(pk[pk["p"] == 1])
+    out = {"stream": {"frames_rendered": n_frames, "events": int(len(stream)), "packets": len(packets), "packet_us": packet,
+                      "frames_the_host_trigger_finder_cuts": len(want),
+                      "note": "ESL-like stand-in (rig.render_stream: real calibration geometry, rendered scene, 10 % negative events, "
+                              "gap noise); the reference's trigger finder loses lock on some frames by design -- the device cuts the "
+                              "same ones"}}
+
+    def run(want_depth, views, label):
+        with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=n_mean,
+                          result_ring=n_frames + 2, want_depth=want_depth, want_bgr=True) as ing:
+            for pk in packets[:4]:  # warm-up: first launches of every kernel
+                ing.push_pinned(pk)
+            ing.flush(), ing.reset(), ing.poll(copy=False)
+            hs0 = ing.host_stats()
+            c0 = time.perf_counter()
+            for pk in packets:
+                ing.push_pinned(pk)
+            c1 = time.perf_counter()
+            ing.flush()
+            got = ing.poll(copy=not views)
+            dt = time.perf_counter() - c0
+            hs = ing.host_stats()
+            same = [(f.t_first, f.t_last, f.n_events) for f in got] == want and not any(f.lost or f.overflow for f in got)
+            ok = None
+            if got and same and O is not None:
+                e0 = want_frames[0]
+                ref = O.process_ev_frame(tables, e0["x"].astype(np.int64), e0["y"].astype(np.int64), np.ascontiguousarray(e0["t"]),
+                                         camera_perspective=camera, want_bgr=True)
+                ok = bool(np.array_equal(got[0].bgr, ref["bgr"])) and (not want_depth or bool(np.array_equal(got[0].depth, ref["depth"])))
+            n_push = hs["pushes"] - hs0["pushes"]
+            out[label] = {"Mevents_per_s_end_to_end": round(len(stream) / dt / 1e6, 2), "frames_per_s": round(len(got) / dt, 1),
+                          "ms_per_cut_frame": round(dt / max(len(got), 1) * 1e3, 4), "frames_cut": len(got),
+                          "same_frames_as_host_trigger_finder": bool(same), "first_frame_equals_oracle": ok,
+                          "host_us_per_push": round((hs["host_seconds_in_push"] - hs["seconds_waiting_for_the_gpu"] - hs0["host_seconds_in_push"]
+                                                     + hs0["seconds_waiting_for_the_gpu"]) / max(n_push, 1) * 1e6, 2),
+                          "host_us_per_push_incl_backpressure": round((hs["host_seconds_in_push"] - hs0["host_seconds_in_push"]) / max(n_push, 1) * 1e6, 2),
+                          "push_loop_ms": round((c1 - c0) * 1e3, 3), "staging_waits": hs["staging_waits"] - hs0["staging_waits"],
+                          "outputs": ("BGR u8" + (" + depth f32" if want_depth else "")) + (", views into the pinned result ring" if views else ", fresh arrays (copied out of the ring)"),
+                          "pcie_GBps_out": round(len(got) * eng.out_h * eng.out_w * (3 + (4 if want_depth else 0)) / dt / 1e9, 2)}
+    run(False, True, "ingest_path")                      # what frame_callback gets in the reference: the BGR frame
+    run(True, True, "ingest_path_depth_and_bgr")
+    run(False, False, "ingest_path_fresh_arrays")
+    try:  # the same stream as the recording stores it (EVT 3.0 words), one projector period per chunk, decoded on the device
+        from x_maps_amd import evt3
+        cuts3 = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + 4 * packet, 4 * packet))
+        chunks = []
+        for a, b in zip(cuts3[:-1], cuts3[1:]):
+            if b > a:
+                w = evt3.encode_evt3_singles(pin[a:b])
+                pw = eng.host_empty(w.shape, np.uint16)
+                pw[:] = w
+                chunks.append(pw)
+        n_words = int(sum(len(c) for c in chunks))
+        with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 19, expected_events_per_frame=n_mean,
+                          result_ring=n_frames + 2, want_depth=False) as ing, \
+                evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
+            for c in chunks[:3]:
+                dec.push(ing, c, pinned=True, count=False)
+            ing.flush(), ing.reset(), ing.poll(copy=False), dec.reset()
+            c0 = time.perf_counter()
+            for c in chunks:
+                dec.push(ing, c, pinned=True, count=False)
+            ing.flush()
+            got3 = ing.poll(copy=False)
+            dt3 = time.perf_counter() - c0
+            over = max([f.overflow for f in got3] + [0])
+        out["from_evt3_words_period_chunks"] = {
+            "Mevents_per_s_end_to_end": round(len(stream) / dt3 / 1e6, 2), "frames_cut": len(got3), "chunks": len(chunks), "overflow": over,
+            "bytes_per_event_over_pcie": round(2.0 * n_words / len(stream), 2), "processed_in_seconds": round(dt3, 4)}
+    except Exception as e:
+        out["from_evt3_words_period_chunks"] = {"error": repr(e)[:200]}
+
+    # the reference's own structure: DepthReprojectionProcessor.process_events per packet (pageable packets, as Metavision hands them)
+    def run_processor(device_ingest, views, label):
+        shown = []
+
+        class Window:
+            def should_close(self):
+                return False
+
+            def show_async(self, img):
+                shown.append((img.shape, int(img[::97, ::89].sum())))  # (consumes the frame inside the callback)
+        params = RuntimeParams(camera_width=640, camera_height=480, projector_width=tables["proj_w"], projector_height=tables["proj_h"],
+                               projector_fps=60, z_near=tables.get("z_near", 0.1), z_far=tables.get("z_far", 1.2), calib=None,
+                               projector_time_map=None, no_frame_dropping=True, camera_perspective=camera, tables=tables, device=device,
+                               device_ingest=device_ingest, ingest_frame_views=views, ingest_result_ring=8)
+        pk_pageable = [np.array(pk) for pk in packets]
+        with DepthReprojectionProcessor(params, window=Window()) as proc:
+            for pk in pk_pageable[:6]:
+                proc.process_events(pk)
+            proc.flush(), proc.reset()
+            shown.clear()
+            c0 = time.perf_counter()
+            for pk in pk_pageable:
+                proc.process_events(pk)
+            proc.flush()
+            dt = time.perf_counter() - c0
+        out[label] = {"Mevents_per_s_end_to_end": round(len(stream) / dt / 1e6, 2), "frames_per_s": round(len(shown) / dt, 1),
+                      "ms_per_shown_frame": round(dt / max(len(shown), 1) * 1e3, 4), "frames_shown": len(shown),
+                      "same_number_of_frames_as_host_trigger_finder": len(shown) == len(want)}
+        return shown
+    try:
+        a = run_processor(False, False, "full_replay_through_processor_host_trigger_finder")
+        b = run_processor(True, True, "full_replay_through_processor_device_ingest")
+        out["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"] = bool(a == b)
+        out["full_replay_through_processor_host_trigger_finder"]["note"] = (
+            "DepthReprojectionProcessor.process_events(packet): polarity filter + RobustTriggerFinder in NumPy on the host, one "
+            "synchronous fused call (H2D + K1 + K2 + D2H of the BGR frame) per cut frame: the reference's structure "
+            "(reference_published_ms_per_frame 2.67 on a Threadripper PRO 5955WX for the frame stage alone)")
+        out["full_replay_through_processor_device_ingest"]["note"] = (
+            "the same calls with RuntimeParams(device_ingest=True, ingest_frame_views=True): packets are staged and pushed, frames are "
+            "polled after every packet and handed to the window as views into the pinned result ring")
+    except Exception as e:
+        out["full_replay_through_processor"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -442,9 +442,10 @@ int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n);
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
 int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */
 int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events */
-/* what the calling thread has paid so far: number of xm_ingest_push* calls, seconds spent inside them, and how often a push had
- * to wait for a staging entry (the GPU more than 16 packets behind).  Any pointer may be NULL. */
-int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits);
+/* what the calling thread has paid so far: number of xm_ingest_push* calls, seconds spent inside them, how often a push had to
+ * wait for a staging entry (the GPU more than 16 packets behind) and the seconds spent waiting (part of host_seconds_in_push).
+ * Any pointer may be NULL. */
+int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits, double* seconds_waiting);
 
 /* ---- EVT 3.0 words -> EventCD records on the device --------------------------------------------------------------
  * The reader in front of the ingest for recordings (Prophesee RAW files, EVT 3.0: a public format; the reference reads them

@@ -178,7 +178,7 @@ SYMBOLS = {
     "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
     "xm_ingest_flush": (C.c_int, [_P]),
     "xm_ingest_reset": (C.c_int, [_P]),
-    "xm_ingest_host_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "xm_ingest_host_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "xm_evt3_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xm_evt3_destroy": (None, [_P]),
     "xm_evt3_reset": (C.c_int, [_P]),

@@ -147,7 +147,7 @@ int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const
 // chunk's event count returned (and checked against max_packet_events: XM_ERR_TOO_MANY leaves decoder and ingest as they were).
 // n_events == NULL: nothing is waited for -- the ingest's kernels read the count from device memory (round 4); a chunk that
 // decodes to more than max_packet_events events is truncated to that many and the excess counted in the frames' `overflow`;
-// pinned words are handed to the ingest's launch thread like a pinned packet of records.
+// the words are handed to the ingest's launch thread like a packet of records (pageable words: the call returns once they have been copied).
 int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events) {
   if (!g || !d || (n_words && !words_host)) return fail(XM_ERR_INVALID, "NULL argument");
   if (g->h != d->h) return fail(XM_ERR_INVALID, "the decoder and the ingest belong to different handles");
@@ -156,32 +156,28 @@ int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, si
   if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
   const double c0 = ingest_now();
   HIP_TRY(hipSetDevice(g->h->cfg.device));
-  const int k = g->pkt_next;
-  int rc = ingest_wait_entry(g, k);  // the staging entry's previous packet has been consumed
+  int rc = ingest_take_error(g);
   if (rc) return rc;
-  const bool async_job = g->threaded && !n_events && words_pinned;
-  if (!async_job && (rc = ingest_drain(g))) return rc;  // this thread issues the launches itself: behind everything posted so far
+  const int k = g->pkt_next;
+  if ((rc = ingest_wait_entry(g, k))) return rc;  // the staging entry's previous packet has been consumed
+  xm_ingest::Job j;
+  j.k = k;
   if (n_events) {
+    // the decoder runs here, on its own stream (the launch thread touches neither the decoder nor this packet slot meanwhile);
+    // the records then go to the launch side like a packet that is already on the device
     size_t n = 0;
-    rc = evt3_run(d, words_host, n_words, words_pinned != 0, g->d_pkt[k], (size_t)g->max_packet, d->stream, &n);  // records straight into the packet's slot
+    rc = evt3_run(d, words_host, n_words, words_pinned != 0, g->d_pkt[k], (size_t)g->max_packet, d->stream, &n);
     *n_events = n;
     if (rc) return rc;  // (XM_ERR_TOO_MANY: neither the decoder nor the ingest has advanced -- push the chunk again in halves)
-    g->pkt_next = (k + 1) % xm_ingest::STAGE;
-    g->posted += 1;
-    g->pkt_push[k] = g->posted;
-    rc = ingest_process(g, k, n, nullptr);
+    j.kind = 3; j.n = n;
   } else {
-    g->pkt_next = (k + 1) % xm_ingest::STAGE;
-    g->posted += 1;
-    g->pkt_push[k] = g->posted;
-    if (async_job) {
-      xm_ingest::Job j;
-      j.kind = 1; j.k = k; j.n = n_words; j.host = words_host; j.dec = d; j.push_no = g->posted;
-      ingest_post(g, j);
-    } else {
-      rc = ingest_issue_evt3(g, d, k, words_host, n_words, words_pinned != 0);
-    }
+    j.kind = 1; j.n = n_words; j.host = words_host; j.dec = d; j.pinned = words_pinned != 0;
   }
+  g->pkt_next = (k + 1) % xm_ingest::STAGE;
+  g->posted += 1;
+  g->pkt_push[k] = g->posted;
+  // (pageable words are copied by the launch side: wait until it has done so)
+  rc = ingest_submit(g, j, j.kind == 1 && !j.pinned);
   g->push_host_s += ingest_now() - c0;
   g->push_calls += 1;
   return rc;

@@ -3,97 +3,124 @@
 #pragma once
 
 // ---- N2: device-side ingest ----------------------------------------------------------------------------------------
+// Who does what (round 4):
+//   caller thread   xm_ingest_push*: stages the packet (pageable memory: one memcpy into a pinned ring entry) and posts a job
+//   launch thread   per packet: H2D on the copy stream, then k_ing_count / k_ing_append / k_ing_segment on the INGEST stream.
+//                   k_ing_segment leaves a 16-byte verdict in pinned memory (did the packet cut a frame, of how many events);
+//                   the thread reads the verdicts in packet order and, for a packet that cut a frame, launches K0 -> K1 -> K2 ->
+//                   DMA to the pinned result ring -> publish on the FRAME stream with exact grids.
+//   xm_ingest_poll  reads the result ring's sequence numbers (pinned memory, no API call)
+// The ingest stream may be `ahead` packets in front of the verdict the thread has handled last (0 on small rings: each packet's
+// verdict is awaited before the next is issued); k_ing_segment's room rule keeps that many packets' worth of the ring free, and
+// the ingest stream waits (on the device) for K1 of a frame before anything issued after it appends.  XM_INGEST_NO_LAUNCH_THREAD:
+// the caller does the launch thread's work inside xm_ingest_push* (and waits for each packet's verdict).
 
 struct xm_ingest {
   xm_handle* h = nullptr;
   xm_ingest_config cfg{};
-  hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // H2D of packet k+1 runs beside the kernels of packet k
-  u64 capacity = 0, max_packet = 0;   // capacity: a power of two (the request rounded up)
+  hipStream_t stream = nullptr;        // ingest kernels
+  hipStream_t frame_stream = nullptr;  // K0 / K1 / K2 / publish of the frames that were cut
+  hipStream_t copy_stream = nullptr;   // H2D of packet k+1 runs beside the kernels of packet k
+  u64 capacity = 0, max_packet = 0;    // capacity: a power of two (the request rounded up)
   double period = 0.0;
   long long act_thresh = 0;
+  int ahead = 0;                       // packets the ingest stream may run ahead of the handled verdicts
   // device
-  IngestDev dev{};                    // what every ingest kernel gets by value (ring, pause ring, state, descriptor, result ring)
-  u32* first_idx = nullptr;           // activity filter: first event index of the sub-packet per pixel
-  u32* keep = nullptr;                // activity filter: keep flags of the (sub-)packet
-  float** d_depth_ring = nullptr;
+  IngestDev dev{};                     // what every ingest kernel gets by value (ring, pause ring, state, result ring, ...)
+  static constexpr int VRING = 64;     // per-packet rings: frame descriptor, frame info (device), verdict (pinned host)
+  FrameDesc* d_descs = nullptr;
+  IngFrameInfo* d_infos = nullptr;
+  IngVerdict* h_verdicts = nullptr;    // pinned host ...
+  IngVerdict* d_verdicts = nullptr;    // ... and the address the device writes it at
+  u32* first_idx = nullptr;            // activity filter: first event index of the sub-packet per pixel
+  u32* keep = nullptr;                 // activity filter: keep flags of the (sub-)packet
+  static constexpr int NOUT = 2;       // device-side output frames (K2 writes them, a DMA copy takes them to the pinned result ring)
+  float* d_out_depth[NOUT] = {};
+  uint8_t* d_out_bgr[NOUT] = {};
+  float** d_depth_ring = nullptr;      // the NOUT pointers above, in device memory (k_ing_segment picks one per frame)
   uint8_t** d_bgr_ring = nullptr;
   // staging (pinned host -> device), a small ring so that the copy of packet k+1 does not wait for packet k's kernels
   static constexpr int STAGE = 16;
   uint4* h_pkt[STAGE] = {};
   uint4* d_pkt[STAGE] = {};
-  hipEvent_t copied_ev[STAGE] = {};   // per staging entry: its H2D has finished (the compute stream waits for it)
-  uint64_t pkt_push[STAGE] = {};      // number of the push that used the entry last (0: never): free once that push has run
+  hipEvent_t copied_ev[STAGE] = {};    // per staging entry: its H2D has finished (the ingest stream waits for it)
+  uint64_t pkt_push[STAGE] = {};       // number of the push that used the entry last (0: never): free once that push's verdict is in
   int pkt_next = 0;
+  hipEvent_t k1_ev[8] = {};            // frame stream: K1 of a frame has run (the ingest stream waits for it before appending more)
   // results (pinned host, written by the kernels)
   int ring = 0;
   IngestStatus* h_status = nullptr;
-  u64* h_pushes_done = nullptr;       // pinned: number of the last push whose kernels have run (written by k_ing_publish)
   std::vector<float*> h_depth;
   std::vector<uint8_t*> h_bgr;
-  uint64_t next_seq = 0;     // frames delivered through xm_ingest_poll so far
-  uint64_t pushed = 0;       // events handed in
-  std::atomic<uint64_t> pushes{0};  // packets whose launches have been issued (by the launch thread, if there is one)
-  // The slot's frame tag advances on the device by one per cut frame (<= one per push) and the host never reads it: the slot is
-  // cleared (k_reset_slot: tags back to 0, key frame emptied) before the pushes since the last clear can have brought the tag to
-  // KEY_MAX_TAG -- the tag field of the packed keys is 19 bits wide, and at 2^20 the shifted tag would leave the 64-bit key
-  uint64_t pushes_since_clear = 0, clear_every = KEY_MAX_TAG - 16;
-  // Upper bound of the live part of the device buffer (its real size is known to the device only): grows with every push,
-  // shrinks when a delivered frame reports how much was left after its cut.  Sizes the grids of the frame kernels.
-  uint64_t ub_live = 0;
-  std::vector<std::pair<uint64_t, uint64_t>> recent;  // (push number, events) of the pushes a frame may still report on
-  uint64_t est_frame_events = 0;
+  uint64_t next_seq = 0;               // frames delivered through xm_ingest_poll so far
+  // launch side (the launch thread, or the caller without one)
+  uint64_t issued = 0;                 // packets whose ingest kernels have been launched
+  uint64_t next_verdict = 1;           // the first packet whose verdict has not been handled
+  uint64_t frames_issued = 0;          // frames whose kernels have been launched
+  std::atomic<uint64_t> handled{0};    // = next_verdict - 1, readable by the caller (staging flow control)
+  // The slot's frame tag advances by one per cut frame: the slot is cleared (k_reset_slot: tags back to 0, key frame emptied)
+  // before the tag can reach KEY_MAX_TAG -- the tag field of the packed keys is 19 bits wide
+  uint64_t frames_since_clear = 0, clear_every = KEY_MAX_TAG - 16;
   // host time spent inside xm_ingest_push* (what the calling thread pays per packet), for xm_ingest_host_stats
-  double push_host_s = 0.0;
+  double push_host_s = 0.0, push_wait_s = 0.0;
   uint64_t push_calls = 0, stage_waits = 0;
-  // The launch thread (default; XM_INGEST_NO_LAUNCH_THREAD turns it off): xm_ingest_push* stages the packet and posts a job, the
-  // thread issues the copy and the launches (~10 API calls, 35 us per packet) -- the caller pays ~2 us for a pinned packet.
-  // `mu` guards what both sides touch: ub_live, recent, est_frame_events (xm_ingest_poll tightens them, the launches read them).
+  // the launch thread's queue
   struct Job {
-    int kind = 0;                       // 0: records, 1: EVT 3.0 words (pinned), 2: stop
-    int k = 0;                          // staging entry
-    size_t n = 0;                       // events (records) / words
-    const void* host = nullptr;         // pinned source (the staging entry or the caller's pinned memory)
+    int kind = 0;                      // 0: records (pinned host), 1: EVT 3.0 words, 2: stop, 3: records already in d_pkt[k], 4: flush
+    int k = 0;                         // staging entry
+    size_t n = 0;                      // events (records) / words
+    const void* host = nullptr;        // pinned source (the staging entry or the caller's pinned memory); words
     xm_evt3* dec = nullptr;
-    uint64_t push_no = 0;
+    bool pinned = true;
   };
   static constexpr unsigned QCAP = 64;
   Job queue[QCAP];
   std::atomic<unsigned long long> q_head{0}, q_tail{0}, q_done{0};
   std::atomic<int> q_error{0};
   std::string q_error_text;
-  std::mutex q_mu, mu;
+  std::mutex q_mu;
   std::condition_variable q_cv;
   std::atomic<bool> q_sleeping{false};
   std::thread th;
   bool threaded = false;
-  uint64_t posted = 0;                  // pushes accepted so far (the caller's count; `pushes` = issued, the launch side's)
+  uint64_t posted = 0;                 // pushes accepted so far (the caller's count)
+  double t_block_s = 0.0, t_frames_s = 0.0, t_jobs_s = 0.0;  // launch side: waiting for verdicts / issuing frames / inside jobs (XM_INGEST_TRACE)
 };
 
 namespace {
 
-template <bool DIRECT>
-int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
+inline double ingest_now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// K0 -> K1 -> K2 -> publish for the frame that packet `push_no` cut (n events), on the frame stream
+int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   xm_handle* h = g->h;
-  hipStream_t s = g->stream;
-  const FrameDesc* desc = g->dev.desc;
-  // K0 over the frame (general path: the cut frame is sorted whenever the camera stream is, but nothing here relies on it)
-  {
-    unsigned gx = grid_for(n_bound, BLOCK * 4);
+  hipStream_t s = g->frame_stream;
+  const int vi = (int)(push_no % xm_ingest::VRING);
+  const FrameDesc* desc = g->d_descs + vi;
+  if (g->frames_since_clear >= g->clear_every) {  // (stream-ordered behind every frame so far)
+    hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s, g->dev.slot, g->dev.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
+    g->frames_since_clear = 0;
+  }
+  g->frames_since_clear += 1;
+  const u64 nb = n < 2 ? 2 : n;
+  {  // K0 (general path: the cut frame is sorted whenever the camera stream is, but nothing here relies on it)
+    unsigned gx = grid_for(nb, BLOCK * 4);
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL((k_minmax_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, desc);
   }
-  if constexpr (DIRECT) {
-    const unsigned gx = grid_for(n_bound, BLOCK);
+  if (!batch_path(h, n)) {  // sparse frame: one thread per event
+    const unsigned gx = grid_for(nb, BLOCK);
     if (h->cfg.view == XM_VIEW_PROJECTOR)
       hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 0>), dim3(gx, 1), dim3(BLOCK), 0, s, desc, h->tb, 0);
     else
       hipLaunchKernelGGL((k_scatter_direct_batch<long long, true, false, 1>), dim3(gx, 1), dim3(BLOCK), 0, s, desc, h->tb, 0);
   } else {
-    const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)est_n / (double)h->tb.xmap_w : 0.0;
+    const double max_ev = h->tb.xmap_w > 0 ? (h->w_ts - 1.5) * (double)n / (double)h->tb.xmap_w : 0.0;
     unsigned threads = TILE_THREADS;
     while (threads > 1024 / TILE_EPT && (double)(threads * TILE_EPT) > max_ev) threads >>= 1;
-    const unsigned gx = grid_for(n_bound, threads * TILE_EPT);
+    const unsigned gx = grid_for(nb, threads * TILE_EPT);
     auto launch = [&](auto view_tag) -> int {
       constexpr int VIEW = decltype(view_tag)::value;
       auto kern = k_scatter_tiled_batch<long long, true, false, VIEW, false>;
@@ -105,44 +132,138 @@ int ingest_launch_frame(xm_ingest* g, u64 n_bound, u64 est_n) {
     int rc = h->cfg.view == XM_VIEW_PROJECTOR ? launch(std::integral_constant<int, 0>{}) : launch(std::integral_constant<int, 1>{});
     if (rc) return rc;
   }
+  // the ingest stream must not append over the frame's events (dead, but still in the ring) before K1 has read them: whatever
+  // is issued on it from now on waits for this event; what has been issued already fits the room k_ing_segment keeps (`ahead`)
+  hipEvent_t ev = g->k1_ev[g->frames_issued % 8];
+  HIP_TRY(hipEventRecord(ev, s));
+  HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
-    if (!h->k2_direct) {
-      launch_k2_batch<0>(h, s, desc, 1);
-    } else {
-      return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");
-    }
+    if (h->k2_direct) return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");
+    launch_k2_batch<0>(h, s, desc, 1);
   } else {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     hipLaunchKernelGGL(k_frame_direct_batch, dim3(grid_for(px, BLOCK), 1), dim3(BLOCK), 0, s, desc, px, h->tb.dlut);
   }
+  {  // device -> pinned result ring by DMA (frame numbers count on both sides: the verdicts arrive in packet order)
+    const size_t px = (size_t)h->out_w * h->out_h;
+    const int slot = (int)(g->frames_issued % (uint64_t)g->ring), o = (int)(g->frames_issued % xm_ingest::NOUT);
+    if (g->h_bgr[slot]) HIP_TRY(hipMemcpyAsync(g->h_bgr[slot], g->d_out_bgr[o], px * 3, hipMemcpyDeviceToHost, s));
+    if (g->h_depth[slot]) HIP_TRY(hipMemcpyAsync(g->h_depth[slot], g->d_out_depth[o], px * 4, hipMemcpyDeviceToHost, s));
+  }
+  hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->dev.st, desc, (const IngFrameInfo*)(g->d_infos + vi), g->h_status, (u64)push_no);
   HIP_TRY(hipGetLastError());
+  g->frames_issued += 1;
   return XM_OK;
 }
 
-inline double ingest_now() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// the staging entry's previous packet has been consumed once the push that used it has run (k_ing_publish reports the number of
-// a finished push in pinned memory -- every fourth one and every one that cut a frame: no API call, no event)
-int ingest_wait_entry(xm_ingest* g, int k) {
-  const uint64_t need = g->pkt_push[k];
-  if (!need || __atomic_load_n(g->h_pushes_done, __ATOMIC_ACQUIRE) >= need) return XM_OK;
-  g->stage_waits += 1;
-  while (g->pushes.load(std::memory_order_acquire) < std::min<uint64_t>(g->posted, (need + 3) & ~3ull)) __builtin_ia32_pause();  // (still queued)
-  unsigned spins = 0;
-  while (__atomic_load_n(g->h_pushes_done, __ATOMIC_ACQUIRE) < need) {
-    __builtin_ia32_pause();
-    if ((++spins & 0xfff) == 0) {  // make sure the runtime has handed the launches to the GPU; stop once the stream is empty
-      hipError_t q = hipStreamQuery(g->stream);
-      if (q == hipSuccess && g->pushes.load(std::memory_order_acquire) >= g->posted) break;
-      if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(q);
+// Verdicts in packet order; for a packet that cut a frame, its kernels.  block_upto: wait for the verdicts of packets <= that
+// number (0: take what is there).
+int ingest_handle_verdicts(xm_ingest* g, uint64_t block_upto) {
+  while (g->next_verdict <= g->issued) {
+    const uint64_t v = g->next_verdict;
+    const IngVerdict* e = g->h_verdicts + (v % xm_ingest::VRING);
+    if (__atomic_load_n(&e->push_no, __ATOMIC_ACQUIRE) != v) {
+      if (v > block_upto) return XM_OK;
+      const double cb = ingest_now();
+      struct Acc { double& a; double t0; ~Acc() { a += ingest_now() - t0; } } acc{g->t_block_s, cb};
+      unsigned spins = 0;
+      while (__atomic_load_n(&e->push_no, __ATOMIC_ACQUIRE) != v) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3ff) == 0) {  // make sure the runtime has handed the launches to the GPU; an idle stream without the
+          hipError_t q = hipStreamQuery(g->stream);  // verdict would be a lost launch: report it instead of spinning for ever
+          if (q == hipSuccess && __atomic_load_n(&e->push_no, __ATOMIC_ACQUIRE) != v)
+            return fail(XM_ERR_HIP, "ingest: packet %llu left no verdict", (unsigned long long)v);
+          if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(q);
+        }
+      }
     }
+    const u64 info = __atomic_load_n(&e->info, __ATOMIC_RELAXED);
+    if (info >> 63) {
+      const double cf = ingest_now();
+      int rc = ingest_issue_frame(g, v, info & ~(1ull << 63));
+      g->t_frames_s += ingest_now() - cf;
+      if (rc) return rc;
+    }
+    g->next_verdict = v + 1;
+    g->handled.store(v, std::memory_order_release);
   }
   return XM_OK;
 }
 
-int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr);
+// the three ingest launches of one (sub-)packet
+void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
+  const unsigned nb = (bound + ING_EPB - 1) / ING_EPB;
+  if (nb) {
+    hipLaunchKernelGGL(k_ing_count, dim3(nb), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
+    hipLaunchKernelGGL(k_ing_append, dim3(nb), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
+  }
+  hipLaunchKernelGGL(k_ing_segment, dim3(1), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
+}
+
+// everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation.  hp = the packet in host memory (the
+// activity filter splits it into sub-packets by time stamps there); NULL for a packet decoded on the device, whose event count
+// then lives at n_dev (device memory) and n is the room of its slot
+int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr) {
+  xm_handle* h = g->h;
+  hipStream_t s = g->stream;
+  // the ingest stream stays at most `ahead` packets in front of the verdicts handled here
+  int rc = XM_OK;
+  while (g->issued + 1 - g->next_verdict > (uint64_t)g->ahead)
+    if ((rc = ingest_handle_verdicts(g, g->next_verdict))) return rc;
+  const uint64_t push_no = g->issued + 1;
+  const int vi = (int)(push_no % xm_ingest::VRING);
+  g->dev.desc = g->d_descs + vi;
+  g->dev.info = g->d_infos + vi;
+  g->dev.verdict = g->d_verdicts + vi;
+  const int act = g->cfg.activity_filter && hp ? 1 : 0;
+  const int cw = h->tb.cam_w, ch = h->tb.cam_h;
+  IngestPush p{};
+  p.flags = g->cfg.use_polarity ? ING_F_POLARITY : 0u;
+  p.push_no = push_no;
+  if (!act) {
+    p.src = g->d_pkt[k];
+    p.n = (u32)n;
+    p.n_dev = n_dev;
+    p.flags |= ING_F_SEGMENT;
+    ingest_launch3(g, p, (u32)n);
+  } else {
+    // sub-packets whose time span (max - min) stays within the activity threshold (see xmaps_ingest.hpp); the trigger finder
+    // runs once, behind the last one
+    size_t a = 0;
+    if (n == 0) {
+      p.flags |= ING_F_SEGMENT;
+      ingest_launch3(g, p, 0);
+    }
+    while (a < n) {
+      long long lo = rec_t_host(hp[a]), hi = lo;
+      size_t b = a + 1;
+      while (b < n) {
+        const long long t = rec_t_host(hp[b]);
+        const long long nlo = t < lo ? t : lo, nhi = t > hi ? t : hi;
+        if (nhi - nlo > g->act_thresh) break;
+        lo = nlo; hi = nhi;
+        ++b;
+      }
+      const u32 m = (u32)(b - a);
+      const uint4* dp = g->d_pkt[k] + a;
+      HIP_TRY(hipMemsetAsync(g->first_idx, 0xff, (size_t)cw * ch * 4, s));
+      hipLaunchKernelGGL(k_ing_first, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), cw, ch, g->first_idx);
+      hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), 1, g->act_thresh, cw, ch,
+                         (const u32*)g->first_idx, (const long long*)g->dev.last_ts, g->keep);
+      IngestPush sp = p;
+      sp.src = dp;
+      sp.keep = g->keep;
+      sp.n = m;
+      if (b == n) sp.flags |= ING_F_SEGMENT;
+      ingest_launch3(g, sp, m);
+      a = b;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  g->issued = push_no;
+  // the frame (if this or an earlier packet cut one) as soon as its verdict is in: at once when nothing else is waiting
+  return ingest_handle_verdicts(g, 0);
+}
 
 // the launches of one packet of records: H2D on the copy stream (beside the previous packets' kernels), then everything else
 int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
@@ -154,16 +275,52 @@ int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
   return ingest_process(g, k, n, hp);
 }
 
-int evt3_enqueue(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream);
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned);
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned);  // (xm_api_evt3.hpp)
+
+// every verdict in, every frame's kernels launched and run
+int ingest_finish(xm_ingest* g) {
+  int rc = ingest_handle_verdicts(g, g->issued);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g->copy_stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  HIP_TRY(hipStreamSynchronize(g->frame_stream));
+  return XM_OK;
+}
+
+int ingest_run_job(xm_ingest* g, const xm_ingest::Job& j) {
+  switch (j.kind) {
+    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host);
+    case 1: return ingest_issue_evt3(g, j.dec, j.k, (const uint16_t*)j.host, j.n, j.pinned);
+    case 3: return ingest_process(g, j.k, j.n, nullptr);
+    case 4: return ingest_finish(g);
+    default: return XM_OK;
+  }
+}
 
 void ingest_thread_main(xm_ingest* g) {
   (void)hipSetDevice(g->h->cfg.device);
+  const auto note = [&](int rc) {
+    if (rc != XM_OK && g->q_error.load(std::memory_order_relaxed) == 0) {
+      g->q_error_text = g_err;  // thread-local text of this thread
+      g->q_error.store(rc, std::memory_order_release);
+    }
+  };
   for (;;) {
     unsigned long long t = g->q_tail.load(std::memory_order_relaxed);
-    if (t == g->q_head.load(std::memory_order_acquire)) {  // empty: spin a little, then sleep
+    if (t == g->q_head.load(std::memory_order_acquire)) {
+      // Nothing to launch: verdicts first -- a frame's kernels go out the moment its packet's verdict arrives (a live camera's
+      // packets are milliseconds apart: the frame must not wait for the next one) -- then spin a little, then sleep.  Never
+      // asleep with a verdict outstanding (it is at most a few ten microseconds away).
       bool got = false;
-      for (int i = 0; i < 20000 && !got; ++i) {
+      for (int i = 0; !got; ++i) {
+        if (g->next_verdict <= g->issued) {
+          note(ingest_handle_verdicts(g, 0));
+          if (g->q_error.load(std::memory_order_relaxed)) g->next_verdict = g->issued + 1;  // (do not spin on a failed stream)
+          if ((i & 0x3ff) == 0x3ff) (void)hipStreamQuery(g->stream);  // (a query makes the runtime hand over what it may still hold back)
+          if (i >= 1 << 20) i = 0;
+        } else if (i >= 20000) {
+          break;
+        }
         __builtin_ia32_pause();
         got = t != g->q_head.load(std::memory_order_acquire);
       }
@@ -176,21 +333,17 @@ void ingest_thread_main(xm_ingest* g) {
     }
     const xm_ingest::Job j = g->queue[t % xm_ingest::QCAP];
     g->q_tail.store(t + 1, std::memory_order_release);
-    if (j.kind == 2) {
-      g->q_done.store(t + 1, std::memory_order_release);
-      return;
-    }
-    const int rc = j.kind == 0 ? ingest_issue_records(g, j.k, j.n, (const uint4*)j.host)
-                               : ingest_issue_evt3(g, j.dec, j.k, (const uint16_t*)j.host, j.n, true);
-    if (rc != XM_OK && g->q_error.load(std::memory_order_relaxed) == 0) {
-      g->q_error_text = g_err;  // thread-local text of this thread
-      g->q_error.store(rc, std::memory_order_release);
+    if (j.kind != 2) {
+      const double cj = ingest_now();
+      note(ingest_run_job(g, j));
+      g->t_jobs_s += ingest_now() - cj;
     }
     g->q_done.store(t + 1, std::memory_order_release);
+    if (j.kind == 2) return;
   }
 }
 
-void ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
+unsigned long long ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
   const unsigned long long hd = g->q_head.load(std::memory_order_relaxed);
   while (hd - g->q_tail.load(std::memory_order_acquire) >= xm_ingest::QCAP) __builtin_ia32_pause();  // queue full: back-pressure
   g->queue[hd % xm_ingest::QCAP] = j;
@@ -199,20 +352,38 @@ void ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
     std::lock_guard<std::mutex> lk(g->q_mu);
     g->q_cv.notify_one();
   }
+  return hd + 1;
 }
 
-// wait until the launch thread has issued everything posted so far (the GPU may still be running it); reports a failed job
-int ingest_drain(xm_ingest* g) {
-  if (g->threaded) {
-    const unsigned long long hd = g->q_head.load(std::memory_order_acquire);
-    while (g->q_done.load(std::memory_order_acquire) < hd) __builtin_ia32_pause();
-  }
+int ingest_take_error(xm_ingest* g) {
   const int e = g->q_error.load(std::memory_order_acquire);
-  if (e) {
-    g->q_error.store(0, std::memory_order_release);
-    return fail(e, "%s (reported by the ingest's launch thread)", g->q_error_text.c_str());
+  if (!e) return XM_OK;
+  g->q_error.store(0, std::memory_order_release);
+  return fail(e, "%s (reported by the ingest's launch thread)", g->q_error_text.c_str());
+}
+
+// hand a job to the launch thread (or run it here); wait: until it has run
+int ingest_submit(xm_ingest* g, const xm_ingest::Job& j, bool wait) {
+  if (!g->threaded) return ingest_run_job(g, j);
+  const unsigned long long idx = ingest_post(g, j);
+  if (wait) {
+    while (g->q_done.load(std::memory_order_acquire) < idx) __builtin_ia32_pause();
+    return ingest_take_error(g);
   }
   return XM_OK;
+}
+
+// The staging entry's previous packet has been consumed once that packet's verdict has been handled (k_ing_segment runs behind
+// the kernels that read the packet): no API call, no event.
+int ingest_wait_entry(xm_ingest* g, int k) {
+  const uint64_t need = g->pkt_push[k];
+  if (!need || g->handled.load(std::memory_order_acquire) >= need) return XM_OK;
+  if (!g->threaded) return ingest_handle_verdicts(g, need);
+  const double c0 = ingest_now();
+  g->stage_waits += 1;
+  while (g->handled.load(std::memory_order_acquire) < need && !g->q_error.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+  g->push_wait_s += ingest_now() - c0;
+  return ingest_take_error(g);
 }
 
 }  // namespace
@@ -238,6 +409,8 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
     return fail(XM_ERR_INVALID, "capacity must be < 2^31 events and at least twice max_packet_events (itself at most %llu)",
                 (unsigned long long)ING_MAX_BLOCKS * ING_EPB);
   }
+  // packets the ingest stream may run ahead of the frame kernels: each costs one packet's worth of ring (the room rule)
+  g->ahead = g->capacity >= 8 * g->max_packet ? (int)std::min<u64>(3, g->capacity / g->max_packet / 4) : 0;
   g->period = 1e6 / (double)cfg->projector_fps;                       // trigger_finder.py: 1e6 / self.projector_fps (float)
   g->act_thresh = cfg->activity_thresh_us > 0 ? cfg->activity_thresh_us : (long long)(1e6 / cfg->projector_fps);  // pipe:65-68
   if (g->cfg.pause_thresh_us <= 0) g->cfg.pause_thresh_us = 40;       // trigger_finder.py:98
@@ -262,11 +435,13 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   int lo = 0, hi = 0;
   ING_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   ING_TRY(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, hi));
+  ING_TRY(hipStreamCreateWithPriority(&g->frame_stream, hipStreamNonBlocking, hi));
   ING_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));  // H2D of a packet beside the kernels of the previous one
   for (auto& e : g->copied_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : g->k1_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   IngestDev& d = g->dev;
   d.cap = g->capacity;
-  d.max_packet = g->max_packet;
+  d.room = g->max_packet * (u64)(1 + g->ahead);
   d.mirror = g->capacity / 2;  // frames of up to half the ring are contiguous wherever they start
   d.pcap = g->capacity * 2;    // (a pause per live event + the stale head the trigger finder has not skipped yet)
   ING_TRY(hipMalloc((void**)&d.buf, (d.cap + d.mirror) * 16));
@@ -287,15 +462,20 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   d.ring = (u32)g->ring;
   ING_TRY(hipMalloc((void**)&d.st, sizeof(IngestState)));
   ING_TRY(hipMemset(d.st, 0, sizeof(IngestState)));
-  ING_TRY(hipMalloc((void**)&d.desc, sizeof(FrameDesc)));
-  ING_TRY(hipMemset(d.desc, 0, sizeof(FrameDesc)));
+  ING_TRY(hipMalloc((void**)&g->d_descs, sizeof(FrameDesc) * xm_ingest::VRING));
+  ING_TRY(hipMemset(g->d_descs, 0, sizeof(FrameDesc) * xm_ingest::VRING));
+  ING_TRY(hipMalloc((void**)&g->d_infos, sizeof(IngFrameInfo) * xm_ingest::VRING));
+  ING_TRY(hipMemset(g->d_infos, 0, sizeof(IngFrameInfo) * xm_ingest::VRING));
+  ING_TRY(hipHostMalloc((void**)&g->h_verdicts, sizeof(IngVerdict) * xm_ingest::VRING, hipHostMallocMapped));
+  memset(g->h_verdicts, 0, sizeof(IngVerdict) * xm_ingest::VRING);
+  ING_TRY(hipHostGetDevicePointer((void**)&g->d_verdicts, g->h_verdicts, 0));
   ING_TRY(hipMalloc((void**)&d.key_frame, h->key_cells * sizeof(u64)));
   ING_TRY(hipMalloc((void**)&d.slot, sizeof(SlotState)));
   ING_TRY(hipMemset(d.slot, 0, sizeof(SlotState)));
-  // (a memset of device memory may return before it has run and g->stream does not wait for the default stream: k_reset_slot
-  //  initialises the extrema slots inside these bytes -- seen once as a first frame with a wrong time normalisation)
+  // (a memset of device memory may return before it has run and the ingest's streams do not wait for the default stream:
+  //  k_reset_slot initialises the extrema slots inside these bytes -- seen once as a first frame with a wrong time normalisation)
   ING_TRY(hipDeviceSynchronize());
-  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->stream, d.slot, d.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->frame_stream, d.slot, d.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
   ING_TRY(hipGetLastError());
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
     ING_TRY(hipHostMalloc((void**)&g->h_pkt[i], g->max_packet * 16, hipHostMallocDefault));
@@ -303,30 +483,24 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   }
   ING_TRY(hipHostMalloc((void**)&g->h_status, sizeof(IngestStatus) * g->ring, hipHostMallocMapped));
   memset(g->h_status, 0, sizeof(IngestStatus) * g->ring);
-  ING_TRY(hipHostMalloc((void**)&g->h_pushes_done, 64, hipHostMallocMapped));
-  memset(g->h_pushes_done, 0, 64);
   g->h_depth.assign(g->ring, nullptr);
   g->h_bgr.assign(g->ring, nullptr);
-  std::vector<float*> dd(g->ring, nullptr);
-  std::vector<uint8_t*> db(g->ring, nullptr);
   for (int i = 0; i < g->ring; ++i) {
-    if (cfg->want_depth) {
-      ING_TRY(hipHostMalloc((void**)&g->h_depth[i], px * 4, hipHostMallocMapped));
-      ING_TRY(hipHostGetDevicePointer((void**)&dd[i], g->h_depth[i], 0));
-    }
-    if (cfg->want_bgr) {
-      ING_TRY(hipHostMalloc((void**)&g->h_bgr[i], px * 3, hipHostMallocMapped));
-      ING_TRY(hipHostGetDevicePointer((void**)&db[i], g->h_bgr[i], 0));
-    }
+    if (cfg->want_depth) ING_TRY(hipHostMalloc((void**)&g->h_depth[i], px * 4, hipHostMallocDefault));
+    if (cfg->want_bgr) ING_TRY(hipHostMalloc((void**)&g->h_bgr[i], px * 3, hipHostMallocDefault));
   }
-  ING_TRY(hipMalloc((void**)&g->d_depth_ring, sizeof(float*) * g->ring));
-  ING_TRY(hipMalloc((void**)&g->d_bgr_ring, sizeof(uint8_t*) * g->ring));
-  ING_TRY(hipMemcpy(g->d_depth_ring, dd.data(), sizeof(float*) * g->ring, hipMemcpyHostToDevice));
-  ING_TRY(hipMemcpy(g->d_bgr_ring, db.data(), sizeof(uint8_t*) * g->ring, hipMemcpyHostToDevice));
+  for (int i = 0; i < xm_ingest::NOUT; ++i) {
+    if (cfg->want_depth) ING_TRY(hipMalloc((void**)&g->d_out_depth[i], px * 4));
+    if (cfg->want_bgr) ING_TRY(hipMalloc((void**)&g->d_out_bgr[i], px * 3));
+  }
+  ING_TRY(hipMalloc((void**)&g->d_depth_ring, sizeof(float*) * xm_ingest::NOUT));
+  ING_TRY(hipMalloc((void**)&g->d_bgr_ring, sizeof(uint8_t*) * xm_ingest::NOUT));
+  ING_TRY(hipMemcpy(g->d_depth_ring, g->d_out_depth, sizeof(float*) * xm_ingest::NOUT, hipMemcpyHostToDevice));
+  ING_TRY(hipMemcpy(g->d_bgr_ring, g->d_out_bgr, sizeof(uint8_t*) * xm_ingest::NOUT, hipMemcpyHostToDevice));
+  d.nout = xm_ingest::NOUT;
   d.depth_ring = g->d_depth_ring;
   d.bgr_ring = g->d_bgr_ring;
   ING_TRY(hipDeviceSynchronize());  // (the memsets above ran on the default stream, which the ingest's non-blocking streams do not wait for)
-  g->est_frame_events = cfg->expected_events_per_frame;
 #undef ING_TRY
   if (!(cfg->flags & XM_INGEST_NO_LAUNCH_THREAD)) {
     g->threaded = true;
@@ -346,34 +520,45 @@ void xm_ingest_destroy(xm_ingest* g) {
     if (g->th.joinable()) g->th.join();
     g->threaded = false;
   }
+  if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->frame_stream) (void)hipStreamSynchronize(g->frame_stream);
+  if (getenv("XM_INGEST_TRACE"))
+    fprintf(stderr, "[ingest] %llu packets, %llu frames, ahead %d: launch side %.3f ms in jobs, of which %.3f ms waiting for verdicts and %.3f ms "
+            "issuing frames; caller %.3f ms in push, %.3f ms of it waiting for staging entries\n", (unsigned long long)g->issued,
+            (unsigned long long)g->frames_issued, g->ahead, g->t_jobs_s * 1e3, g->t_block_s * 1e3, g->t_frames_s * 1e3, g->push_host_s * 1e3,
+            g->push_wait_s * 1e3);
   IngestDev& d = g->dev;
   if (d.buf) (void)hipFree(d.buf);
   if (d.pring) (void)hipFree(d.pring);
   if (d.blk) (void)hipFree(d.blk);
   if (d.last_ts) (void)hipFree(d.last_ts);
   if (d.st) (void)hipFree(d.st);
-  if (d.desc) (void)hipFree(d.desc);
   if (d.key_frame) (void)hipFree(d.key_frame);
   if (d.slot) (void)hipFree(d.slot);
+  if (g->d_descs) (void)hipFree(g->d_descs);
+  if (g->d_infos) (void)hipFree(g->d_infos);
+  if (g->h_verdicts) (void)hipHostFree(g->h_verdicts);
   if (g->first_idx) (void)hipFree(g->first_idx);
   if (g->keep) (void)hipFree(g->keep);
   if (g->d_depth_ring) (void)hipFree(g->d_depth_ring);
   if (g->d_bgr_ring) (void)hipFree(g->d_bgr_ring);
+  for (int i = 0; i < xm_ingest::NOUT; ++i) {
+    if (g->d_out_depth[i]) (void)hipFree(g->d_out_depth[i]);
+    if (g->d_out_bgr[i]) (void)hipFree(g->d_out_bgr[i]);
+  }
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
     if (g->h_pkt[i]) (void)hipHostFree(g->h_pkt[i]);
     if (g->d_pkt[i]) (void)hipFree(g->d_pkt[i]);
   }
   if (g->h_status) (void)hipHostFree(g->h_status);
-  if (g->h_pushes_done) (void)hipHostFree(g->h_pushes_done);
   for (auto p : g->h_depth) if (p) (void)hipHostFree(p);
   for (auto p : g->h_bgr) if (p) (void)hipHostFree(p);
-  if (g->copy_stream) {
-    (void)hipStreamSynchronize(g->copy_stream);
-    (void)hipStreamDestroy(g->copy_stream);
-  }
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   for (auto& e : g->copied_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : g->k1_ev) if (e) (void)hipEventDestroy(e);
   if (g->stream) (void)hipStreamDestroy(g->stream);
+  if (g->frame_stream) (void)hipStreamDestroy(g->frame_stream);
   delete g;
 }
 
@@ -386,131 +571,30 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   const double c0 = ingest_now();
   xm_handle* h = g->h;
   if (n > g->max_packet) return fail(XM_ERR_TOO_MANY, "packet of %zu events exceeds max_packet_events %llu", n, (unsigned long long)g->max_packet);
-  if (const int e = g->q_error.load(std::memory_order_acquire)) {  // an earlier packet's launches failed
-    g->q_error.store(0, std::memory_order_release);
-    return fail(e, "%s (reported by the ingest's launch thread)", g->q_error_text.c_str());
-  }
+  int rc = ingest_take_error(g);  // an earlier packet's launches failed
+  if (rc) return rc;
   if (!g->threaded) HIP_TRY(hipSetDevice(h->cfg.device));
   const int k = g->pkt_next;
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
   const uint4* hp = pinned ? (const uint4*)eventcd16 : g->h_pkt[k];
-  int rc = XM_OK;
-  if (n) {
-    if ((rc = ingest_wait_entry(g, k))) return rc;
-    if (!pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
-  }
+  if ((rc = ingest_wait_entry(g, k))) return rc;
+  if (n && !pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
   g->posted += 1;
   g->pkt_push[k] = g->posted;
-  if (g->threaded) {
-    xm_ingest::Job j;
-    j.kind = 0; j.k = k; j.n = n; j.host = hp; j.push_no = g->posted;
-    ingest_post(g, j);
-  } else {
-    rc = ingest_issue_records(g, k, n, hp);
-  }
+  xm_ingest::Job j;
+  j.kind = 0; j.k = k; j.n = n; j.host = hp;
+  rc = ingest_submit(g, j, false);
   g->push_host_s += ingest_now() - c0;
   g->push_calls += 1;
   return rc;
 }
 
-}  // extern "C"
-
-namespace {
-
-int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev) {
-  xm_handle* h = g->h;
-  hipStream_t s = g->stream;
-  if (g->pushes_since_clear >= g->clear_every) {  // (stream-ordered behind every frame cut so far)
-    hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s, g->dev.slot, g->dev.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
-    HIP_TRY(hipGetLastError());
-    g->pushes_since_clear = 0;
-  }
-  g->pushes_since_clear += 1;
-  const int act = g->cfg.activity_filter && hp ? 1 : 0;
-  const int cw = h->tb.cam_w, ch = h->tb.cam_h;
-  IngestPush p{};
-  p.flags = g->cfg.use_polarity ? ING_F_POLARITY : 0u;
-  const auto launch3 = [&](const IngestPush& pp, u32 bound) {  // count, append (blocks of the packet), commit / segment (one block)
-    const unsigned nb = (bound + ING_EPB - 1) / ING_EPB;
-    if (nb) {
-      hipLaunchKernelGGL(k_ing_count, dim3(nb), dim3(ING_THREADS), 0, s, g->dev, pp);
-      hipLaunchKernelGGL(k_ing_append, dim3(nb), dim3(ING_THREADS), 0, s, g->dev, pp);
-    }
-    hipLaunchKernelGGL(k_ing_segment, dim3(1), dim3(ING_THREADS), 0, s, g->dev, pp);
-  };
-  if (!act) {
-    p.src = g->d_pkt[k];
-    p.n = (u32)n;
-    p.n_dev = n_dev;
-    p.flags |= ING_F_SEGMENT;
-    launch3(p, (u32)n);
-  } else {
-    // sub-packets whose time span (max - min) stays within the activity threshold (see xmaps_ingest.hpp); the trigger finder
-    // runs once, behind the last one
-    size_t a = 0;
-    if (n == 0) {
-      p.flags |= ING_F_SEGMENT;
-      launch3(p, 0);
-    }
-    while (a < n) {
-      long long lo = rec_t_host(hp[a]), hi = lo;
-      size_t b = a + 1;
-      while (b < n) {
-        const long long t = rec_t_host(hp[b]);
-        const long long nlo = t < lo ? t : lo, nhi = t > hi ? t : hi;
-        if (nhi - nlo > g->act_thresh) break;
-        lo = nlo; hi = nhi;
-        ++b;
-      }
-      const u32 m = (u32)(b - a);
-      const uint4* dp = g->d_pkt[k] + a;
-      HIP_TRY(hipMemsetAsync(g->first_idx, 0xff, (size_t)cw * ch * 4, s));
-      hipLaunchKernelGGL(k_ing_first, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), cw, ch, g->first_idx);
-      hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), 1, g->act_thresh, cw, ch,
-                         (const u32*)g->first_idx, (const long long*)g->dev.last_ts, g->keep);
-      IngestPush sp = p;
-      sp.src = dp;
-      sp.keep = g->keep;
-      sp.n = m;
-      if (b == n) sp.flags |= ING_F_SEGMENT;
-      launch3(sp, m);
-      a = b;
-    }
-  }
-  g->pushed += n;
-  const uint64_t push_no = g->pushes.load(std::memory_order_relaxed) + 1;
-  u64 bound64, est;
-  {
-    std::lock_guard<std::mutex> lk(g->mu);
-    g->ub_live = std::min<u64>(g->capacity, g->ub_live + n);
-    g->recent.emplace_back(push_no, (uint64_t)n);
-    if (g->recent.size() > 4096) {  // many pushes without a poll: fold the older half into one entry under its LAST push number (a
-      uint64_t sum = 0;              // frame that reports an earlier push then counts all of it: the bound stays an upper bound)
-      for (size_t i = 0; i < 2048; ++i) sum += g->recent[i].second;
-      g->recent[2047] = std::make_pair(g->recent[2047].first, sum);
-      g->recent.erase(g->recent.begin(), g->recent.begin() + 2047);
-    }
-    bound64 = std::min<u64>(g->ub_live, g->dev.mirror);
-    est = g->est_frame_events;
-  }
-  // the frame kernels run on whatever the device cut (FrameDesc in device memory; its size is known to the device only: the
-  // grids cover the host's upper bound of the live part); nothing to do when desc.valid == 0
-  if (bound64 >= 2) {
-    int rc = batch_path(h, est) ? ingest_launch_frame<false>(g, bound64, est) : ingest_launch_frame<true>(g, bound64, est);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->dev.st, (const FrameDesc*)g->dev.desc, g->h_status, (u64)push_no, g->h_pushes_done);
-  HIP_TRY(hipGetLastError());
-  g->pushes.store(push_no, std::memory_order_release);
-  return XM_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   if (!g || !out) return fail(XM_ERR_INVALID, "NULL argument");
+  if (!g->threaded && g->next_verdict <= g->issued) {  // (no launch thread: a frame whose verdict has arrived meanwhile goes out now)
+    int rc = ingest_handle_verdicts(g, 0);
+    if (rc) return rc;
+  }
   const int slot = (int)(g->next_seq % (uint64_t)g->ring);
   const IngestStatus* st = g->h_status + slot;
   const uint64_t want = g->next_seq + 1;  // the entry's seq once frame next_seq has been published
@@ -525,8 +609,8 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->seq = g->next_seq;
   out->lost = lapped ? 1 : 0;
   if (lapped) {
-    // Nothing of the entry can be trusted for frame next_seq (no statistics, no images: depth / bgr stay NULL).  The host's bound of
-    // the live part is left as it is (an upper bound stays one).  Resume with the oldest frame the ring may still hold intact.
+    // Nothing of the entry can be trusted for frame next_seq (no statistics, no images: depth / bgr stay NULL).
+    // Resume with the oldest frame the ring may still hold intact.
     const uint64_t newest = std::max(seq, seq2);  // >= want + ring - 1
     g->next_seq = std::max<uint64_t>(g->next_seq + 1, newest >= (uint64_t)g->ring ? newest - (uint64_t)g->ring : 0);
     return 1;
@@ -540,19 +624,6 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->overflow = v.overflow;
   out->depth = g->h_depth[slot];
   out->bgr = g->h_bgr[slot];
-  {  // after that frame's cut `live_after` events were left; everything pushed since may have been appended
-    std::lock_guard<std::mutex> lk(g->mu);
-    g->est_frame_events = v.n_events;  // the next frames' K1 variant / block size follow the stream's density
-    uint64_t later = 0;
-    size_t keep_from = g->recent.size();
-    for (size_t i = g->recent.size(); i-- > 0;) {
-      if (g->recent[i].first <= v.push_seq) break;
-      later += g->recent[i].second;
-      keep_from = i;
-    }
-    g->recent.erase(g->recent.begin(), g->recent.begin() + keep_from);
-    g->ub_live = std::min<uint64_t>(g->capacity, v.live_after + later);
-  }
   g->next_seq += 1;
   return 1;
 }
@@ -560,21 +631,17 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
 int xm_ingest_flush(xm_ingest* g) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(g->h->cfg.device));
-  int rc = ingest_drain(g);
-  if (rc) return rc;
-  if (g->copy_stream) HIP_TRY(hipStreamSynchronize(g->copy_stream));
-  HIP_TRY(hipStreamSynchronize(g->stream));
-  return XM_OK;
+  xm_ingest::Job j;
+  j.kind = 4;
+  return ingest_submit(g, j, true);
 }
 
 int xm_ingest_reset(xm_ingest* g) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
-  HIP_TRY(hipSetDevice(g->h->cfg.device));
-  int rc = ingest_drain(g);
+  int rc = xm_ingest_flush(g);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(g->stream));
   // RobustTriggerFinder.reset(): the buffered events are discarded (trigger_finder.py:116-119).  The stream indices start over
-  // (nothing live refers to the old ones); the frame / push counters and the sticky overflow count go on.
+  // (nothing live refers to the old ones); the frame counter and the sticky overflow count go on.
   IngestState z;
   HIP_TRY(hipMemcpy(&z, g->dev.st, sizeof z, hipMemcpyDeviceToHost));
   z.start_abs = z.write_abs = z.p_head = z.p_tail = 0;
@@ -582,19 +649,15 @@ int xm_ingest_reset(xm_ingest* g) {
   z.span_ok = 0;
   HIP_TRY(hipMemcpy(g->dev.st, &z, sizeof z, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());  // (default-stream work: the ingest's non-blocking streams do not wait for it)
-  {
-    std::lock_guard<std::mutex> lk(g->mu);
-    g->ub_live = 0;
-    g->recent.clear();
-  }
   return XM_OK;
 }
 
-int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits) {
+int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits, double* seconds_waiting) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   if (pushes) *pushes = g->push_calls;
   if (host_seconds_in_push) *host_seconds_in_push = g->push_host_s;
   if (staging_waits) *staging_waits = g->stage_waits;
+  if (seconds_waiting) *seconds_waiting = g->push_wait_s;
   return XM_OK;
 }
 

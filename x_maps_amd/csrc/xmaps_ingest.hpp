@@ -17,6 +17,13 @@
 //   k_ing_segment  one block: commits the counters, then RobustTriggerFinder.find_trigger over the pause ring; the frame that is
 //                  cut is described by a FrameDesc written BY THE DEVICE (pointer into the ring + count), which the multi-frame
 //                  K0/K1/K2 launches read -- no index ever travels to the host
+// k_ing_segment ends by telling the HOST, in pinned memory, whether this packet cut a frame and how many events it has (16 bytes,
+// the only thing the host ever learns about the stream): the frame kernels K0 -> K1 -> K2 and the publishing launch are issued
+// only for packets that did cut one, with exact grids, on a SECOND stream; K2 writes the frame into device memory and a DMA copy
+// behind it on that stream takes it to the pinned result ring (6 MB of BGR = ~115 us per frame at PCIe speed on the reference's
+// projector), which no longer holds up the next packets' ingest kernels.  (K2 storing straight into host memory, as it did until
+// round 4, blocks every other kernel's stores behind its own for as long as it runs: measured, profiles/r04_ingest.md.)  The ingest stream may run `ahead` packets in front of the frame kernels; the room rule below leaves that many
+// packets' worth of space, so that nothing is appended over events a frame kernel is still reading.
 // The ring holds `cap` (a power of two) events at absolute stream index & (cap - 1); its first `mirror` entries are written a
 // second time behind its end, so that any frame of <= mirror events is CONTIGUOUS in memory wherever it starts (the frame
 // kernels take a pointer + count) and nothing is ever moved (until round 4 the live part was copied to a second buffer
@@ -43,7 +50,7 @@ struct IngestState {      // device
   u64 p_head, p_tail;     // live part of the pause ring (absolute counters; entry = index i with t[i+1] - t[i] >= thresh)
   u64 frames;             // frames cut so far
   u64 appended;           // events appended so far (after the filters)
-  u64 pushes_done;        // packets whose kernels have run (k_ing_publish counts them)
+  u64 published;          // frames whose kernels have run (k_ing_publish counts them)
   long long last_t;       // time stamp of event write_abs - 1 (valid when write_abs > 0)
   u32 overflow;           // events dropped because the ring was full (sticky)
   u32 span_ok;            // scratch: the live part spans at least one period
@@ -56,6 +63,18 @@ struct IngestStatus {     // pinned host ring entry, written by k_ing_publish wh
   u64 n_inliers, n_index_errors, n_used;
   u64 live_after;         // events left in the buffer after the cut
   u64 push_seq;           // number of the xm_ingest_push call whose launches cut this frame (the host tightens its bounds with it)
+  u32 overflow;
+  u32 pad;
+};
+
+struct IngVerdict {       // pinned host ring entry (one per packet, 64 entries), written by k_ing_segment
+  u64 info;               // bit 63: the packet cut a frame; low bits: its number of events
+  u64 push_no;            // written LAST (system-scope release): the entry describes this packet
+};
+
+struct IngFrameInfo {     // device, one per verdict entry: what k_ing_segment knew when it cut the frame (k_ing_publish reads it)
+  u64 frame_no;
+  u64 live_after;         // events left in the ring after the cut
   u32 overflow;
   u32 pad;
 };
@@ -73,7 +92,7 @@ struct IngestDev {        // by value to every ingest kernel
   IngestState* st;
   uint4* buf;             // cap + mirror records
   u64 cap, mirror;        // cap: power of two
-  u64 max_packet;         // largest packet the host hands in
+  u64 room;               // events that must stay free behind the live part: (1 + packets the ingest stream may run ahead) x the largest packet
   u64* pring;             // pause ring, pcap entries (power of two)
   u64 pcap;
   IngBlk* blk;            // ING_MAX_BLOCKS records of the current packet
@@ -81,8 +100,11 @@ struct IngestDev {        // by value to every ingest kernel
   int cam_w, cam_h;
   long long pause_thresh;
   double period;
-  u32 min_events, ring;
-  FrameDesc* desc;
+  u32 min_events, ring;   // ring: entries of the pinned result ring (status slot = frame number % ring)
+  u32 nout, pad0;         // device-side output buffers K2 writes (frame number % nout); copied to the result ring by DMA
+  FrameDesc* desc;        // this packet's entries of the descriptor / frame-info / verdict rings
+  IngFrameInfo* info;
+  IngVerdict* verdict;    // (pinned host memory)
   u64* key_frame;
   SlotState* slot;
   float* const* depth_ring;
@@ -95,6 +117,7 @@ struct IngestPush {       // one packet
   const u32* n_dev;       // non-NULL: the packet's event count lives on the device (a chunk decoded there)
   u32 n;                  // ... else this many (with n_dev: the room of the packet's slot)
   u32 flags;              // ING_F_*
+  u64 push_no;            // number of the packet (from 1)
 };
 constexpr u32 ING_F_POLARITY = 1u;  // keep p == 1 only
 constexpr u32 ING_F_SEGMENT = 2u;   // k_ing_segment: run the trigger finder (else: commit the packet only -- sub-packets)
@@ -452,15 +475,17 @@ __device__ inline void ing_find_trigger(const IngestDev& d, u64& s_first) {
   if ((double)gap <= d.period && next - prev > d.min_events) {
     const u64 first = prev + 2, last = next - 2;  // evs[prev + 2 : next - 2]
     if (last - first <= d.mirror) {
-      const u32 slot_i = (u32)(st->frames % d.ring);
+      const u64 frame_no = st->frames++;
+      const u32 slot_i = (u32)(frame_no % d.ring);
+      d.info->frame_no = frame_no;
       FrameDesc* desc = d.desc;
       desc->x = nullptr; desc->y = nullptr; desc->t = nullptr; desc->p = nullptr;
       desc->aos = d.buf + (first & mask);  // contiguous: the ring's head is mirrored behind its end
       desc->n = last - first;
       desc->key_frame = d.key_frame;
       desc->st = d.slot;
-      desc->depth = d.depth_ring ? d.depth_ring[slot_i] : nullptr;
-      desc->bgr = d.bgr_ring ? d.bgr_ring[slot_i] : nullptr;
+      desc->depth = d.depth_ring ? d.depth_ring[frame_no % d.nout] : nullptr;
+      desc->bgr = d.bgr_ring ? d.bgr_ring[frame_no % d.nout] : nullptr;
       desc->pad = slot_i;
       desc->valid = 1;
     } else {
@@ -508,26 +533,27 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_segment(IngestDev d, Ingest
   if (!(p.flags & ING_F_SEGMENT)) return;
   ing_find_trigger(d, s_first);
   __syncthreads();
-  // No room for another full packet behind what is still live (a stream without a usable pause: the reference's buffer would
-  // grow without bound): the live part is dropped and counted, as if the trigger finder had given up on it.
-  if (tid == 0 && st->write_abs - st->start_abs + d.max_packet > d.cap) {
+  // No room for the packets that may follow before the next decision (d.room) behind what is still live -- a stream without a
+  // usable pause: the reference's buffer would grow without bound -- : the live part is dropped and counted, as if the trigger
+  // finder had given up on it.
+  if (tid != 0) return;
+  if (st->write_abs - st->start_abs + d.room > d.cap) {
     st->overflow += (u32)(st->write_abs - st->start_abs);
     st->start_abs = st->write_abs;
     st->p_head = st->p_tail;
   }
+  d.info->live_after = st->write_abs - st->start_abs;
+  d.info->overflow = st->overflow;
+  // the verdict for the host: did this packet cut a frame, and of how many events (the frame kernels' grids)
+  const u64 info = d.desc->valid ? ((1ull << 63) | d.desc->n) : 0ull;
+  __hip_atomic_store(&d.verdict->info, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&d.verdict->push_no, p.push_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// after the frame kernels: statistics + sequence number into the pinned ring (system scope: the host polls it)
-__global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const FrameDesc* __restrict__ desc, IngestStatus* ring_status,
-                                                    u64 push_seq, u64* pushes_done_host) {
-  if (threadIdx.x == 0) st->pushes_done = push_seq;
-  if (!desc->valid) {
-    // (a store to host memory keeps the kernel alive for a PCIe round trip: every fourth packet is often enough for the staging
-    //  ring's flow control -- 16 entries)
-    if (threadIdx.x == 0 && pushes_done_host && (push_seq & 3) == 0)
-      __hip_atomic_store(pushes_done_host, push_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
+// after the frame kernels (same stream): statistics + sequence number into the pinned ring (system scope: the host polls it)
+__global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const FrameDesc* __restrict__ desc, const IngFrameInfo* __restrict__ info,
+                                                    IngestStatus* ring_status, u64 push_seq) {
+  if (!desc->valid) return;
   const SlotState* s = desc->st;
   const u32 tag = s->tag_a, parity = tag & 1;
   u64 inl = 0, oob = 0, used = 0;
@@ -550,13 +576,12 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
   out->n_inliers = inl;
   out->n_index_errors = oob;
   out->n_used = used;
-  out->live_after = st->write_abs - st->start_abs;
+  out->live_after = info->live_after;
   out->push_seq = push_seq;
-  out->overflow = st->overflow;
-  st->frames += 1;
+  out->overflow = info->overflow;
+  st->published = info->frame_no + 1;
   __threadfence_system();
-  __hip_atomic_store(&out->seq, st->frames, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (pushes_done_host) __hip_atomic_store(pushes_done_host, push_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&out->seq, info->frame_no + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace xm

@@ -83,18 +83,22 @@ class DepthReprojectionPipe:
         if getattr(p, "device_ingest", False):
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
-                                       activity_filter=getattr(p, "activity_filter", False), want_depth=False)
+                                       activity_filter=getattr(p, "activity_filter", False), want_depth=False,
+                                       result_ring=int(getattr(p, "ingest_result_ring", 8)))
+            self._ingest_views = bool(getattr(p, "ingest_frame_views", False))
 
     # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------
     def _deliver_ingest_frames(self):
-        for fr in self.ingest.poll():
+        for fr in self.ingest.poll(copy=not self._ingest_views):
             if fr.lost:  # the result ring was lapped before the host polled: the frame's images are gone (never shown)
                 self.stats_printer.count("frame lost")
                 continue
             self.stats_printer.count("trig ✅")
             self.stats_printer.add_metric("frame len [ms]", (fr.t_last - fr.t_first) / 1000)
             self.last_ingest_frame = fr
-            self.frame_callback(fr.bgr)  # a fresh array, copied out of the pinned result ring
+            # a fresh array copied out of the pinned result ring, or (RuntimeParams.ingest_frame_views) a view into it that stays
+            # valid until ingest_result_ring - 1 further frames have been produced
+            self.frame_callback(fr.bgr)
 
     def flush(self):
         if self.ingest is not None:

@@ -44,6 +44,13 @@ class RuntimeParams:
     device: int = 0
     device_ingest: bool = False  # polarity / activity filter + frame segmentation on the GPU (x_maps_amd/ingest.py)
     activity_filter: bool = False  # device ingest only: the own-definition activity-noise rule (see xmaps_ingest.hpp)
+    # device ingest only: hand frame_callback / window.show_async a VIEW into the ingest's ring of pinned result buffers instead of
+    # a fresh array (the reference hands out fresh arrays; for its 1080 x 1920 projector that copy is 6.2 MB = ~0.5 ms of host
+    # time per frame).  LIFETIME of such a frame: until `ingest_result_ring` - 1 further frames have been produced -- a window or
+    # encoder that consumes the frame inside the callback, or within the next few frames, never notices; a consumer that keeps
+    # frames longer copies them itself.
+    ingest_frame_views: bool = False
+    ingest_result_ring: int = 8
 
     @property
     def should_drop_frames(self):

@@ -142,10 +142,13 @@ class DeviceIngest:
 
     def host_stats(self) -> dict:
         """What the calling thread has paid inside push() so far (xm_ingest_host_stats)."""
-        n, sec, waits = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0)
-        N.check(self._lib.xm_ingest_host_stats(self._g, C.byref(n), C.byref(sec), C.byref(waits)))
+        n, sec, waits, wsec = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0), C.c_double(0.0)
+        N.check(self._lib.xm_ingest_host_stats(self._g, C.byref(n), C.byref(sec), C.byref(waits), C.byref(wsec)))
+        work = float(sec.value) - float(wsec.value)
         return {"pushes": int(n.value), "host_seconds_in_push": float(sec.value), "staging_waits": int(waits.value),
-                "us_per_push": (float(sec.value) / n.value * 1e6) if n.value else 0.0}
+                "seconds_waiting_for_the_gpu": float(wsec.value),
+                "us_per_push": (float(sec.value) / n.value * 1e6) if n.value else 0.0,
+                "us_per_push_without_waits": (work / n.value * 1e6) if n.value else 0.0}
 
     def flush(self):
         N.check(self._lib.xm_ingest_flush(self._g))
