@@ -90,6 +90,7 @@ def parse_args():
                     help="launch from the calling thread (default: XM_FLAG_LAUNCH_WORKERS, one launch thread per slot stream -- the "
                          "two kernel launches of a frame cost a Python caller ~10 us, about what the GPU needs for the frame)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra loops (forced general, declared sorted, ...)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of the other BASELINE configs (esl, graph60, sharded_c10m)")
     ap.add_argument("--single-block", action="store_true", help="one timed block of K steps (no repetition)")
     return ap.parse_args()
 
@@ -308,6 +309,83 @@ def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=Non
     r["empty_event_pair_us"] = round(eng.profile_event_overhead_ms(15) * 1e3, 2)
     r["group_us_serial" if group else "frame_us_serial"] = round(float(k_ms[3]) * 1e3, 2)
     return r, alg, pt, wl
+
+
+def parity_ok(p):
+    """every boolean of a parity record true, every relative error within the north star's 1e-4"""
+    if p is None:
+        return None
+    if isinstance(p, bool):
+        return p
+    if isinstance(p, dict):
+        ok = True
+        for k, v in p.items():
+            if k.endswith("rel_err") and isinstance(v, (int, float)):
+                ok = ok and v <= 1e-4
+            elif isinstance(v, (bool, dict)):
+                r = parity_ok(v)
+                ok = ok and (r is not False)
+        return ok
+    return None
+
+
+def other_config_legs(args, torch, dist, dev, local_rank):
+    """The other BASELINE configs, compact, inside the default line (the driver runs only that one): configs[0]/[2] stand-in
+    (--esl, groups of 32 ESL-like frames + the camera-like stream through the device ingest), configs[4] (--graph) and configs[3]
+    (--sharded, on this one rank).  Each leg is the corresponding bench mode with fewer steps and without its own extra legs."""
+    import copy
+    legs = {}
+
+    def compact(out, seconds):
+        r = out.get("roofline") or {}
+        leg = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "steps": out["steps"],
+               "workload": out["config"]["workload"][:110],
+               "roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_counter_bytes", "traffic") if k in r},
+               "parity_ok": parity_ok(out.get("parity")), "leg_seconds": round(seconds, 1)}
+        if "frames_per_step" in out["config"]:
+            leg["frames_per_step"] = out["config"]["frames_per_step"]
+        if "us_per_frame" in out["config"]:
+            leg["us_per_frame"] = out["config"]["us_per_frame"]
+        if "latency_us" in out:
+            leg["latency_us"] = {k: v for k, v in out["latency_us"].items() if k != "definition"}
+        if "collective_ms" in out:
+            leg["collective_ms"] = out["collective_ms"]
+        ip = out.get("ingest_path")
+        if isinstance(ip, dict):
+            leg["ingest_path"] = {k: ip[k] for k in ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "frames_cut",
+                                                     "same_frames_as_host_trigger_finder", "first_frame_equals_oracle",
+                                                     "host_us_per_push", "outputs") if k in ip}
+        sl = out.get("stream_legs")
+        if isinstance(sl, dict):
+            for k in ("full_replay_through_processor_host_trigger_finder", "full_replay_through_processor_device_ingest"):
+                if isinstance(sl.get(k), dict):
+                    leg[k] = {a: b for a, b in sl[k].items() if a != "note"}
+        return leg
+
+    plan = (("esl", bench_esl, dict(steps=10, esl=True, no_host_path=False)),
+            ("graph60", bench_graph, dict(steps=120, graph=True, no_host_path=True, slots=0, frames=0)),
+            ("sharded_c10m", bench_sharded, dict(steps=20, sharded=True, no_host_path=True, slots=0, frames=0)))
+    for name, fn, over in plan:
+        a = copy.copy(args)
+        a.no_cpu_baseline, a.no_other_modes, a.single_block, a.batch, a.groups_in_flight = True, True, False, 32, 4
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            d = dist
+            if name == "sharded_c10m" and d is None:
+                import tempfile
+                import torch.distributed as d
+                d.init_process_group("nccl", init_method=f"file://{tempfile.mkdtemp()}/rdzv", rank=0, world_size=1,
+                                     device_id=torch.device("cuda", local_rank))
+            try:
+                legs[name] = compact(fn(a, torch, d, dev, 0, local_rank, 1), time.perf_counter() - t0)
+            finally:
+                if name == "sharded_c10m" and dist is None:
+                    d.destroy_process_group()
+        except BaseException as e:  # (a leg's parity gate exits: never lose the default line to it)
+            legs[name] = {"error": repr(e)[:300]}
+    return legs
 
 
 def spawn_ranks(args):
@@ -776,6 +854,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         out["host_path"] = host_path
     if ingest_path:
         out["ingest_path"] = ingest_path
+    if world == 1 and not args.no_other_modes and not args.no_other_configs and B and not camera:
+        out["other_configs"] = other_config_legs(args, torch, dist, dev, local_rank)
     return out
 
 

@@ -47,7 +47,7 @@ def test_default_line_as_the_driver_calls_it():
 
 
 def test_the_default_line_carries_the_other_engine_settings():
-    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path")
+    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path", "--no-other-configs")
     om = d["other_modes"]
     for k in ("eventcd_records", "one_frame_per_call", "one_frame_per_call_eager", "forced_general", "camera_view"):
         assert om[k]["value"] > 1000 and om[k]["unit"] == "Mevents/s", k
@@ -113,8 +113,39 @@ def test_multi_gpu_line_carries_the_sharded_frame_beside_the_replicas():
     """With N > 1 ranks the default line reports frame-level replicas (no collective) and, beside it, one C-10M frame sharded by
     event index over the same ranks with the collective time listed separately.  One GPU here: the leg is forced through a
     one-rank process group (RCCL kernels run, nothing crosses xGMI)."""
-    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path",
+    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path", "--no-other-configs",
              XM_BENCH_FORCE_DIST="1", XM_BENCH_FORCE_SHARDED_LEG="1")
     sh = d["other_modes"]["one_frame_sharded_over_the_ranks"]
     assert sh["scaling"] == "strong" and sh["value"] > 1000 and sh["parity"]["depth_bit_exact"]
     assert sh["collective_ms"]["key_frame_merge"] > 0 and sh["kernels_us"]["k_scatter"] > 0
+
+
+def test_the_default_line_carries_the_other_baseline_configs():
+    """the one line the driver records proves every BASELINE config: compact legs for the ESL-like stand-in (configs 0 / 2, with the
+    camera-like stream through the device ingest and through the processor), the 60-frame graph (config 4) and the sharded C-10M
+    frame (config 3), each with value, ms_per_step, roofline fractions and parity"""
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["rccl_ranks_seen"] is None
+    oc = d["other_configs"]
+    for name in ("esl", "graph60", "sharded_c10m"):
+        leg = oc[name]
+        assert "error" not in leg, leg
+        assert leg["value"] > 100 and leg["ms_per_step"] > 0 and leg["parity_ok"] is True, (name, leg)
+        assert 0.0 < leg["roofline"]["frac"] < 1.5 and "frac_counter_bytes" in leg["roofline"], name
+    ip = oc["esl"]["ingest_path"]
+    assert ip["same_frames_as_host_trigger_finder"] and ip["first_frame_equals_oracle"] and ip["Mevents_per_s_end_to_end"] > 200
+    assert ip["host_us_per_push"] < 20
+    assert oc["esl"]["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
+    assert oc["graph60"]["latency_us"]["batch_of_60_frames"]["p50"] > 0 and oc["sharded_c10m"]["collective_ms"]["key_frame_merge"] > 0
+
+
+def test_esl_line_carries_the_stream_legs():
+    d = _run("--esl", "--steps", "20", "--no-cpu-baseline", "--no-other-modes")
+    ip = d["ingest_path"]
+    assert ip["same_frames_as_host_trigger_finder"] and ip["first_frame_equals_oracle"] and ip["frames_cut"] > 20
+    sl = d["stream_legs"]
+    for k in ("ingest_path_depth_and_bgr", "ingest_path_fresh_arrays"):
+        assert sl[k]["same_frames_as_host_trigger_finder"] and sl[k]["first_frame_equals_oracle"], k
+    assert sl["full_replay_through_processor_host_trigger_finder"]["frames_shown"] == ip["frames_cut"]
+    assert sl["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
+    assert sl["from_evt3_words_period_chunks"]["overflow"] == 0 and sl["from_evt3_words_period_chunks"]["frames_cut"] > 20
