@@ -339,6 +339,23 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
  * depth_out / bgr_out are full-size projector frames: pixels of other ranks' tiles are left as they were (zero them first; a MAX
  * all-reduce over the ranks -- depth >= 0, an owner's BGR >= the zeros of the others -- assembles the frame).  Projector view. */
 int xm_shard_finish_u16_band(xm_handle* h, const uint16_t* disp_frame, int col_lo, int col_hi, float* depth_out, uint8_t* bgr_out);
+
+/* ---- one frame over several GPUs of ONE process (xm_create_sharded owns the RCCL communicators) ----------------
+ * The entry for hosts that are not Python / torch.distributed (x_maps_amd/sharded.py is the multi-process form of the same
+ * exchange).  dev_ids[n_dev]: distinct HIP devices; the tables of cfg are uploaded to each (cfg->device is ignored).  Per frame
+ * the event buffer (HOST memory, pageable or pinned) is split by index -- device g takes [g n / n_dev, (g + 1) n / n_dev) --,
+ * one host thread per device enqueues on its device's stream: H2D, the shard's extrema, ncclAllReduce(MIN) of {tmin, -tmax},
+ * the scatter with GLOBAL event indices in the packed keys, ncclAllReduce(MAX, uint64) of the key frame, and device dev_ids[0]
+ * runs the frame kernel and copies depth / BGR to the caller's host buffers (either may be NULL).  Synchronous.  Results equal
+ * xm_process_frame on one device bit for bit (the largest global index wins a cell = NumPy's last-writer-wins).
+ * RCCL is looked up at run time (the copy already loaded into the process, else ROCm's librccl); without it only n_dev = 1 works.
+ * stats (may be NULL): n_events, t_min / t_max, gpu_ms[0] / gpu_ms[1] = the two all-reduces on dev_ids[0]'s stream. */
+typedef struct xm_sharded xm_sharded;
+int xm_create_sharded(const int* dev_ids, int n_dev, const xm_config* cfg, xm_sharded** out);
+int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
+                             int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
+int xm_sharded_info(xm_sharded* s, int* n_dev, int* uses_rccl, uint64_t* key_frame_bytes);
+void xm_sharded_destroy(xm_sharded* s);
 int xm_k2_patch_cols_max(xm_handle* h, int* cols_out);
 /* the stream the shard calls run on (hipStream_t as void*), so the caller can order its collective */
 void* xm_stream(xm_handle* h, int slot);

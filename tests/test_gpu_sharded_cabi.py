@@ -1,0 +1,74 @@
+"""-m gpu: xm_create_sharded / xm_sharded_process_frame (last row: the C-ABI entry that owns the RCCL
+communicators) -- one frame sharded by event index over the devices of ONE process, against the oracle: with one device (the
+all-reduces run through RCCL on a one-rank communicator) and with every visible device when there is more than one."""
+import numpy as np
+import pytest
+
+import xmaps_oracle as O
+from x_maps_amd import synthetic as S
+from x_maps_amd.sharded import ShardedDevices
+
+pytestmark = pytest.mark.gpu
+
+
+def _devices():
+    import torch
+    return list(range(torch.cuda.device_count()))
+
+
+def _check(tb, sh, evs, camera=False, p=None):
+    x, y, t, pp = S.to_soa(evs)
+    depth, bgr, st = sh.process_frame(x, y, t, p=pp if p else None)
+    if p:
+        x, y, t = x[pp == 1], y[pp == 1], t[pp == 1]
+    ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
+    assert np.array_equal(depth, ref["depth"]) and np.array_equal(bgr, ref["bgr"])
+    if len(t):
+        assert (st["t_min"], st["t_max"]) == (float(t.min()), float(t.max()))
+    return st
+
+
+@pytest.mark.parametrize("camera", [False, True])
+def test_one_device(camera):
+    tb = S.make_tables(S.C_TINY)
+    with ShardedDevices(tb, devices=[0], camera_perspective=camera) as sh:
+        assert sh.n_dev == 1 and sh.uses_rccl
+        for f in range(3):
+            st = _check(tb, sh, S.make_events(S.C_TINY, frame=f, n=30_000), camera)
+        assert st["key_frame_all_reduce_ms"] > 0
+        _check(tb, sh, S.make_events(S.C_TINY, frame=5, n=20_000)[::-1].copy(), camera)          # not sorted
+        _check(tb, sh, S.make_events(S.C_TINY, frame=6, n=20_000, p_zero_fraction=0.3), camera, p=True)  # polarity column
+        depth, bgr, _ = sh.process_frame(np.zeros(0, np.uint16), np.zeros(0, np.uint16), np.zeros(0, np.int64))  # defined: empty frame
+        assert not depth.any() and (bgr == 255).all()
+
+
+def test_float_time_stamps_one_device():
+    tb = S.make_tables(S.C_TINY)
+    evs = S.make_events(S.C_TINY, frame=2, n=25_000)
+    x, y, t, _ = S.to_soa(evs)
+    with ShardedDevices(tb, devices=[0]) as sh:
+        for dt in (np.float64, np.float32):
+            tf = t.astype(dt)
+            depth, _, _ = sh.process_frame(x, y, tf, want_bgr=False)
+            ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), tf, want_bgr=False)
+            assert np.array_equal(depth, ref["depth"]), dt
+
+
+def test_c1m_frame_one_device_and_all_devices():
+    """a C-1M frame: one device, then every visible device (on a one-GPU box the two are the same handle shape; on the driver's
+    multi-GPU node the second run crosses xGMI) -- the same frame as the oracle's either way"""
+    tb = S.make_tables(S.C_1M)
+    evs = S.make_events(S.C_1M, frame=3)
+    devs = _devices()
+    for ids in ([0], devs):
+        with ShardedDevices(tb, devices=ids) as sh:
+            assert sh.n_dev == len(ids)
+            _check(tb, sh, evs)
+
+
+def test_bad_device_lists_are_rejected():
+    from x_maps_amd._native import XMapsNativeError
+    tb = S.make_tables(S.C_TINY)
+    for ids in ([0, 0], [99], []):
+        with pytest.raises((XMapsNativeError, ValueError)):
+            ShardedDevices(tb, devices=ids)

@@ -1,0 +1,292 @@
+// xm_api_sharded.hpp -- C-ABI: one frame sharded by event index over several GPUs of ONE process (last row:
+// xm_create_sharded owning the RCCL communicators; 8(e): the partitioning and the exchange)
+// (part of libxmaps_hip.so's host side: included by ../xmaps_hip.hip, one translation unit; see that file for the order)
+//
+//   device g owns events [g N / W, (g + 1) N / W) of the frame; tables are replicated (one xm_handle per device).
+//   per frame, one host thread per device, everything on that device's stream:
+//     H2D of the shard -> xm_shard_minmax_device -> ncclAllReduce(MIN, {tmin, -tmax}) -> xm_shard_clear + xm_shard_scatter_device
+//     (global event indices in the packed keys) -> ncclAllReduce(MAX, uint64 key frame) -> device 0: xm_shard_finish -> D2H.
+//   MAX over packed keys = the event with the largest GLOBAL index wins = NumPy's last-writer-wins across shards, bit for bit
+//   (x_maps_amd/sharded.py is the same exchange for multi-process hosts on torch.distributed).
+// RCCL is not linked: librccl is looked up at run time (the copy a host process has loaded already -- PyTorch ships its own --
+// else ROCm's), so that the library keeps loading on hosts without it; xm_create_sharded reports its absence for n_dev > 1.
+#pragma once
+
+#include <dlfcn.h>
+
+namespace {
+
+// the few RCCL entry points and enum values used here (rccl.h: ncclDataType_t / ncclRedOp_t)
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  static constexpr int Int64 = 4, Uint64 = 5, Float64 = 8, Max = 2, Min = 3;
+  bool ok() const { return CommInitAll && CommDestroy && AllReduce; }
+};
+
+RcclApi load_rccl() {
+  RcclApi r;
+  const char* loaded[] = {"librccl.so.1", "librccl.so"};
+  for (const char* n : loaded)
+    if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // a copy the process has already (PyTorch's)
+  const char* fresh[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  for (const char* n : fresh)
+    if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  if (!r.lib) return r;
+  r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+  return r;
+}
+
+}  // namespace
+
+struct xm_sharded {
+  struct Dev {
+    int id = 0;
+    xm_handle* h = nullptr;
+    void* comm = nullptr;
+    DevBuf x, y, t, p, depth, bgr;
+    uint64_t* key = nullptr;
+    void* mm = nullptr;            // {tmin, -tmax} of the shard, then of the frame (16 bytes, int64 or float64)
+    hipEvent_t ev[4] = {};         // device 0: around the two all-reduces
+    std::thread th;
+    int rc = XM_OK;
+    std::string err;
+  };
+  std::vector<std::unique_ptr<Dev>> devs;
+  RcclApi rccl;
+  bool use_rccl = false;
+  // the frame in flight (set by xm_sharded_process_frame, read by the device threads)
+  const uint16_t *x = nullptr, *y = nullptr;
+  const void* t = nullptr;
+  const int16_t* p = nullptr;
+  size_t n = 0;
+  int t_dtype = XM_T_INT64;
+  float* depth_out = nullptr;
+  uint8_t* bgr_out = nullptr;
+  u32 tag = 0;
+  double mm_host[2] = {0, 0};
+  float coll_ms[2] = {0, 0};
+  // start / done hand-shake
+  std::mutex mu;
+  std::condition_variable cv;
+  unsigned long long gen = 0;
+  int done = 0;
+  bool stop = false;
+};
+
+namespace {
+
+void sharded_frame_on(xm_sharded* s, int g) {
+  xm_sharded::Dev& d = *s->devs[g];
+  const int W = (int)s->devs.size();
+  d.rc = XM_OK;
+  const auto run = [&]() -> int {
+    HIP_TRY(hipSetDevice(d.id));
+    hipStream_t st = (hipStream_t)xm_stream(d.h, 0);
+    const size_t a = (size_t)(((unsigned __int128)g * s->n) / (unsigned)W), b = (size_t)(((unsigned __int128)(g + 1) * s->n) / (unsigned)W);
+    const size_t m = b - a, tsz = t_size(s->t_dtype);
+    int rc;
+    if ((rc = stage_in(d.x, s->x + a, m * 2, st))) return rc;
+    if ((rc = stage_in(d.y, s->y + a, m * 2, st))) return rc;
+    if ((rc = stage_in(d.t, (const char*)s->t + a * tsz, m * tsz, st))) return rc;
+    if (s->p && (rc = stage_in(d.p, s->p + a, m * 2, st))) return rc;
+    const int16_t* dp = s->p ? (const int16_t*)d.p.p : nullptr;
+    if ((rc = xm_shard_minmax_device(d.h, d.t.p, dp, m, s->t_dtype, d.mm))) return rc;
+    if (g == 0) HIP_TRY(hipEventRecord(d.ev[0], st));
+    if (s->use_rccl) {
+      const int e = s->rccl.AllReduce(d.mm, d.mm, 2, s->t_dtype == XM_T_INT64 ? RcclApi::Int64 : RcclApi::Float64, RcclApi::Min, d.comm, st);
+      if (e) return fail(XM_ERR_HIP, "ncclAllReduce(MIN, extrema) failed: %s", s->rccl.GetErrorString ? s->rccl.GetErrorString(e) : "?");
+    }
+    if (g == 0) HIP_TRY(hipEventRecord(d.ev[1], st));
+    if ((rc = xm_shard_clear(d.h, d.key))) return rc;
+    if ((rc = xm_shard_scatter_device(d.h, (const uint16_t*)d.x.p, (const uint16_t*)d.y.p, d.t.p, dp, m, s->t_dtype, (uint64_t)a, d.mm,
+                                      s->tag, d.key)))
+      return rc;
+    if (g == 0) HIP_TRY(hipEventRecord(d.ev[2], st));
+    if (s->use_rccl) {
+      const int e = s->rccl.AllReduce(d.key, d.key, d.h->key_cells, RcclApi::Uint64, RcclApi::Max, d.comm, st);
+      if (e) return fail(XM_ERR_HIP, "ncclAllReduce(MAX, key frame) failed: %s", s->rccl.GetErrorString ? s->rccl.GetErrorString(e) : "?");
+    }
+    if (g == 0) {
+      HIP_TRY(hipEventRecord(d.ev[3], st));
+      const size_t px = (size_t)d.h->out_w * d.h->out_h;
+      float* dd = nullptr;
+      uint8_t* db = nullptr;
+      if (s->depth_out) {
+        if ((rc = d.depth.reserve(px * 4))) return rc;
+        dd = (float*)d.depth.p;
+      }
+      if (s->bgr_out) {
+        if ((rc = d.bgr.reserve(px * 3))) return rc;
+        db = (uint8_t*)d.bgr.p;
+      }
+      if ((rc = xm_shard_finish(d.h, d.key, s->tag, dd, db))) return rc;
+      if (dd) HIP_TRY(hipMemcpyAsync(s->depth_out, dd, px * 4, hipMemcpyDeviceToHost, st));
+      if (db) HIP_TRY(hipMemcpyAsync(s->bgr_out, db, px * 3, hipMemcpyDeviceToHost, st));
+      unsigned char mmb[16];
+      HIP_TRY(hipMemcpyAsync(mmb, d.mm, 16, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (s->t_dtype == XM_T_INT64) {
+        long long v[2];
+        memcpy(v, mmb, 16);
+        s->mm_host[0] = (double)v[0];
+        s->mm_host[1] = -(double)v[1];
+      } else {
+        double v[2];
+        memcpy(v, mmb, 16);
+        s->mm_host[0] = v[0];
+        s->mm_host[1] = -v[1];
+      }
+      HIP_TRY(hipEventElapsedTime(&s->coll_ms[0], d.ev[0], d.ev[1]));
+      HIP_TRY(hipEventElapsedTime(&s->coll_ms[1], d.ev[2], d.ev[3]));
+    } else {
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    return XM_OK;
+  };
+  d.rc = run();
+  if (d.rc) d.err = g_err;
+}
+
+void sharded_thread_main(xm_sharded* s, int g) {
+  unsigned long long seen = 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [&] { return s->stop || s->gen != seen; });
+      if (s->stop) return;
+      seen = s->gen;
+    }
+    sharded_frame_on(s, g);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->done += 1;
+    }
+    s->cv.notify_all();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void xm_sharded_destroy(xm_sharded* s) {
+  if (!s) return;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->stop = true;
+  }
+  s->cv.notify_all();
+  for (auto& d : s->devs)
+    if (d->th.joinable()) d->th.join();
+  for (auto& d : s->devs) {
+    (void)hipSetDevice(d->id);
+    if (d->h) (void)xm_sync(d->h);
+    if (d->comm && s->rccl.CommDestroy) (void)s->rccl.CommDestroy(d->comm);
+    d->x.release(); d->y.release(); d->t.release(); d->p.release(); d->depth.release(); d->bgr.release();
+    if (d->key) (void)hipFree(d->key);
+    if (d->mm) (void)hipFree(d->mm);
+    for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
+    if (d->h) xm_destroy(d->h);
+  }
+  delete s;
+}
+
+int xm_create_sharded(const int* dev_ids, int n_dev, const xm_config* cfg, xm_sharded** out) {
+  if (!dev_ids || n_dev <= 0 || !cfg || !out) return fail(XM_ERR_INVALID, "bad argument");
+  *out = nullptr;
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return fail(XM_ERR_HIP, "no AMD GPU visible");
+  for (int i = 0; i < n_dev; ++i) {
+    if (dev_ids[i] < 0 || dev_ids[i] >= have) return fail(XM_ERR_INVALID, "device %d is not one of the %d visible", dev_ids[i], have);
+    for (int j = 0; j < i; ++j)
+      if (dev_ids[j] == dev_ids[i]) return fail(XM_ERR_INVALID, "device %d is listed twice", dev_ids[i]);
+  }
+  xm_sharded* s = new (std::nothrow) xm_sharded();
+  if (!s) return fail(XM_ERR_NOMEM, "out of host memory");
+  s->rccl = load_rccl();
+  s->use_rccl = s->rccl.ok();
+  if (n_dev > 1 && !s->use_rccl) {
+    delete s;
+    return fail(XM_ERR_INVALID, "librccl was not found: a sharded handle over %d devices needs it", n_dev);
+  }
+  int rc = XM_OK;
+  for (int i = 0; i < n_dev && !rc; ++i) {
+    s->devs.emplace_back(new xm_sharded::Dev());
+    xm_sharded::Dev& d = *s->devs.back();
+    d.id = dev_ids[i];
+    xm_config c = *cfg;
+    c.device = d.id;
+    if ((rc = xm_create(&c, &d.h))) break;
+    hipError_t e = hipSetDevice(d.id);
+    if (e == hipSuccess) e = hipMalloc((void**)&d.key, d.h->key_cells * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&d.mm, 16);
+    for (auto& ev : d.ev)
+      if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) rc = fail(XM_ERR_HIP, "device %d: %s", d.id, hipGetErrorString(e));
+  }
+  if (!rc && s->use_rccl) {  // one communicator per device, all in this process
+    std::vector<void*> comms(n_dev, nullptr);
+    const int e = s->rccl.CommInitAll(comms.data(), n_dev, dev_ids);
+    if (e) rc = fail(XM_ERR_HIP, "ncclCommInitAll failed: %s", s->rccl.GetErrorString ? s->rccl.GetErrorString(e) : "?");
+    else
+      for (int i = 0; i < n_dev; ++i) s->devs[i]->comm = comms[i];
+  }
+  if (rc) {
+    const std::string keep = g_err;
+    xm_sharded_destroy(s);
+    return fail(rc, "%s", keep.c_str());
+  }
+  for (int i = 0; i < n_dev; ++i) s->devs[i]->th = std::thread(sharded_thread_main, s, i);
+  *out = s;
+  return XM_OK;
+}
+
+int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n, int t_dtype,
+                             float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats) {
+  if (!s || (n && (!x || !y || !t))) return fail(XM_ERR_INVALID, "NULL argument");
+  if (t_dtype != XM_T_INT64 && t_dtype != XM_T_FLOAT32 && t_dtype != XM_T_FLOAT64) return fail(XM_ERR_INVALID, "unknown t_dtype");
+  if (n >= XM_KEY_MAX_EVENTS) return fail(XM_ERR_TOO_MANY, "a frame of %zu events exceeds the packed keys' 2^%d", n, XM_KEY_IDX_BITS);
+  s->x = x; s->y = y; s->t = t; s->p = p; s->n = n; s->t_dtype = t_dtype;
+  s->depth_out = depth_out;
+  s->bgr_out = bgr_out;
+  s->tag = s->tag >= 1000 ? 1 : s->tag + 1;  // (the key frames are cleared every frame: any tag in [1, 2^19) would do)
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->done = 0;
+    s->gen += 1;
+  }
+  s->cv.notify_all();
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return s->done == (int)s->devs.size(); });
+  }
+  for (auto& d : s->devs)
+    if (d->rc) return fail(d->rc, "device %d: %s", d->id, d->err.c_str());
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    stats->n_events = n;
+    stats->n_used = n;
+    stats->t_min = n ? s->mm_host[0] : 0.0;
+    stats->t_max = n ? s->mm_host[1] : 0.0;
+    stats->gpu_ms[0] = s->coll_ms[0];  // the two all-reduces on device 0's stream (HIP events around them)
+    stats->gpu_ms[1] = s->coll_ms[1];
+  }
+  return XM_OK;
+}
+
+int xm_sharded_info(xm_sharded* s, int* n_dev, int* uses_rccl, uint64_t* key_frame_bytes) {
+  if (!s) return fail(XM_ERR_INVALID, "NULL argument");
+  if (n_dev) *n_dev = (int)s->devs.size();
+  if (uses_rccl) *uses_rccl = s->use_rccl ? 1 : 0;
+  if (key_frame_bytes) *key_frame_bytes = (uint64_t)s->devs[0]->h->key_cells * 8;
+  return XM_OK;
+}
+
+}  // extern "C"

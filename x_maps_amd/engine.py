@@ -60,6 +60,38 @@ def _time_col(t) -> tuple[np.ndarray, int]:
     return np.ascontiguousarray(t), _T_DTYPES[t.dtype]
 
 
+def make_config(tables: dict, camera_perspective: bool = False, device: int = 0, n_slots: int = 1, flags: int = 0):
+    """xm_config for `tables` (see XMapsEngine) + the arrays its pointers refer to (keep them alive until xm_create has returned)."""
+    mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
+    mapy = np.ascontiguousarray(tables["cam_mapy_i16"], dtype=np.int16)
+    xmap = np.ascontiguousarray(tables["proj_x_map"], dtype=np.int16)
+    pmap = tables.get("disp_proj_mapxy_i16")
+    if pmap is not None:
+        pmap = np.ascontiguousarray(pmap, dtype=np.int16)
+    if mapx.shape != mapy.shape or mapx.ndim != 2 or xmap.ndim != 2:
+        raise ValueError("bad table shapes")
+    cam_h, cam_w = mapx.shape
+    proj_h, proj_w = (pmap.shape[:2] if pmap is not None else (0, 0))
+    cfg = N.xm_config()
+    cfg.struct_size = C.sizeof(N.xm_config)
+    cfg.device = device
+    cfg.cam_width, cfg.cam_height = cam_w, cam_h
+    cfg.proj_width, cfg.proj_height = proj_w, proj_h
+    cfg.rect_width, cfg.rect_height = int(tables["rect_w"]), int(tables["rect_h"])
+    cfg.xmap_height, cfg.xmap_width = xmap.shape
+    cfg.x_offset = int(tables.get("x_offset", 4242))
+    cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
+    cfg.n_slots = n_slots
+    cfg.flags = flags
+    cfg.p03 = float(tables["p03"])
+    cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
+    cfg.cam_mapx_i16 = mapx.ctypes.data
+    cfg.cam_mapy_i16 = mapy.ctypes.data
+    cfg.proj_x_map = xmap.ctypes.data
+    cfg.disp_proj_mapxy_i16 = pmap.ctypes.data if pmap is not None else None
+    return cfg, (mapx, mapy, xmap, pmap)
+
+
 class XMapsEngine:
     """One GPU handle: tables resident in HBM + the fused per-frame kernels.
 
@@ -78,38 +110,16 @@ class XMapsEngine:
         assume_time_sorted=True declares the frames sorted (verified, reported instead of redone for asynchronous calls)."""
         self._lib = N.load_library()
         self._h = C.c_void_p(None)
-        mapx = np.ascontiguousarray(tables["cam_mapx_i16"], dtype=np.int16)
-        mapy = np.ascontiguousarray(tables["cam_mapy_i16"], dtype=np.int16)
-        xmap = np.ascontiguousarray(tables["proj_x_map"], dtype=np.int16)
-        pmap = tables.get("disp_proj_mapxy_i16")
-        if pmap is not None:
-            pmap = np.ascontiguousarray(pmap, dtype=np.int16)
-        if mapx.shape != mapy.shape or mapx.ndim != 2 or xmap.ndim != 2:
-            raise ValueError("bad table shapes")
+        flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0)
+                 | (N.XM_FLAG_GENERAL if (force_general or not try_sorted) else 0)
+                 | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0)
+                 | (N.XM_FLAG_LAUNCH_WORKERS if launch_workers else 0)
+                 | (N.XM_FLAG_ADAPTIVE_BATCH if adaptive_batch else 0))
+        cfg, keep = make_config(tables, camera_perspective, device, n_slots, flags)
+        mapx, xmap, pmap = keep[0], keep[2], keep[3]
         cam_h, cam_w = mapx.shape
         proj_h, proj_w = (pmap.shape[:2] if pmap is not None else (0, 0))
-        cfg = N.xm_config()
-        cfg.struct_size = C.sizeof(N.xm_config)
-        cfg.device = device
-        cfg.cam_width, cfg.cam_height = cam_w, cam_h
-        cfg.proj_width, cfg.proj_height = proj_w, proj_h
-        cfg.rect_width, cfg.rect_height = int(tables["rect_w"]), int(tables["rect_h"])
-        cfg.xmap_height, cfg.xmap_width = xmap.shape
-        cfg.x_offset = int(tables.get("x_offset", 4242))
-        cfg.view = N.XM_VIEW_CAMERA if camera_perspective else N.XM_VIEW_PROJECTOR
-        cfg.n_slots = n_slots
-        cfg.flags = ((N.XM_FLAG_TIME_SORTED if assume_time_sorted else 0)
-                     | (N.XM_FLAG_GENERAL if (force_general or not try_sorted) else 0)
-                     | (N.XM_FLAG_DEFAULT_STREAMS if default_priority_streams else 0)
-                     | (N.XM_FLAG_LAUNCH_WORKERS if launch_workers else 0)
-                     | (N.XM_FLAG_ADAPTIVE_BATCH if adaptive_batch else 0))
-        cfg.p03 = float(tables["p03"])
         self.p03 = cfg.p03
-        cfg.z_near, cfg.z_far = float(tables["z_near"]), float(tables["z_far"])
-        cfg.cam_mapx_i16 = mapx.ctypes.data
-        cfg.cam_mapy_i16 = mapy.ctypes.data
-        cfg.proj_x_map = xmap.ctypes.data
-        cfg.disp_proj_mapxy_i16 = pmap.ctypes.data if pmap is not None else None
         N.check(self._lib.xm_create(C.byref(cfg), C.byref(self._h)))
         self._pinned = []
         self.camera_perspective = camera_perspective

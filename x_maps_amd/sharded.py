@@ -280,3 +280,65 @@ class ShardedFrameProcessor:
             self.collectives_issued += 1
         else:
             full[:chunk.numel()].copy_(chunk)
+
+
+class ShardedDevices:
+    """One frame sharded over several GPUs of THIS process through the C-ABI's own entry (xm_create_sharded: one host thread and
+    one RCCL communicator per device, owned by the handle) -- what a host that is not Python / torch.distributed binds.
+    Host event columns in, depth / BGR out; synchronous.
+
+        with ShardedDevices(tables, devices=[0, 1, 2, 3]) as sh:
+            depth, bgr, stats = sh.process_frame(x, y, t)
+    """
+
+    def __init__(self, tables: dict, devices=(0,), camera_perspective: bool = False):
+        import ctypes as C
+
+        from . import _native as N
+        from .engine import make_config
+        self._C, self._N = C, N
+        self._lib = N.load_library()
+        cfg, keep = make_config(tables, camera_perspective, 0, 1, 0)
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._s = C.c_void_p(None)
+        N.check(self._lib.xm_create_sharded(ids, len(devices), C.byref(cfg), C.byref(self._s)))
+        del keep
+        mapx = np.asarray(tables["cam_mapx_i16"])
+        pm = tables.get("disp_proj_mapxy_i16")
+        self.out_h, self.out_w = mapx.shape if camera_perspective else np.asarray(pm).shape[:2]
+        nd, rc, kb = C.c_int(0), C.c_int(0), C.c_uint64(0)
+        N.check(self._lib.xm_sharded_info(self._s, C.byref(nd), C.byref(rc), C.byref(kb)))
+        self.n_dev, self.uses_rccl, self.key_frame_bytes = int(nd.value), bool(rc.value), int(kb.value)
+
+    def process_frame(self, x, y, t, p=None, want_depth=True, want_bgr=True):
+        C, N = self._C, self._N
+        x = np.ascontiguousarray(x, dtype=np.uint16)
+        y = np.ascontiguousarray(y, dtype=np.uint16)
+        t = np.ascontiguousarray(t)
+        td = {np.dtype(np.int64): N.XM_T_INT64, np.dtype(np.float32): N.XM_T_FLOAT32, np.dtype(np.float64): N.XM_T_FLOAT64}[t.dtype]
+        p = None if p is None else np.ascontiguousarray(p, dtype=np.int16)
+        depth = np.empty((self.out_h, self.out_w), np.float32) if want_depth else None
+        bgr = np.empty((self.out_h, self.out_w, 3), np.uint8) if want_bgr else None
+        st = N.xm_frame_stats()
+        ptr = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        N.check(self._lib.xm_sharded_process_frame(self._s, ptr(x), ptr(y), ptr(t), ptr(p), len(x), td, ptr(depth), ptr(bgr), C.byref(st)))
+        return depth, bgr, {"n_events": int(st.n_events), "t_min": float(st.t_min), "t_max": float(st.t_max),
+                            "extrema_all_reduce_ms": float(st.gpu_ms[0]), "key_frame_all_reduce_ms": float(st.gpu_ms[1])}
+
+    def close(self):
+        if getattr(self, "_s", None) is not None and self._s.value:
+            self._lib.xm_sharded_destroy(self._s)
+            self._s = self._C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
