@@ -91,6 +91,8 @@ def parse_args():
                          "two kernel launches of a frame cost a Python caller ~10 us, about what the GPU needs for the frame)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra loops (forced general, declared sorted, ...)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact legs of the other BASELINE configs (esl, graph60, sharded_c10m)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="variant switch of the library for experiments (xm_debug_option), e.g. XM_COLS=0, XM_K2_PIPE=0; repeatable")
     ap.add_argument("--single-block", action="store_true", help="one timed block of K steps (no repetition)")
     return ap.parse_args()
 
@@ -467,6 +469,11 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.lib_option:
+        from x_maps_amd import _native as xm_native
+        for kv in args.lib_option:
+            k, _, v = kv.partition("=")
+            xm_native.debug_option(k, v)
     ranks_seen = 1
     if dist is not None:  # the ranks count each other over RCCL before anything is measured
         one = torch.ones(1, device=dev)
@@ -1421,7 +1428,7 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
         params = RuntimeParams(camera_width=640, camera_height=480, projector_width=tables["proj_w"], projector_height=tables["proj_h"],
                                projector_fps=60, z_near=tables.get("z_near", 0.1), z_far=tables.get("z_far", 1.2), calib=None,
                                projector_time_map=None, no_frame_dropping=True, camera_perspective=camera, tables=tables, device=device,
-                               device_ingest=device_ingest, ingest_frame_views=views, ingest_result_ring=8)
+                               device_ingest=device_ingest, ingest_frame_views=views, ingest_result_ring=64)
         pk_pageable = [np.array(pk) for pk in packets]
         with DepthReprojectionProcessor(params, window=Window()) as proc:
             for pk in pk_pageable[:6]:

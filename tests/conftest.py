@@ -32,3 +32,20 @@ def _torch_touches_the_gpu_first():
     except Exception:
         pass
     yield
+
+
+def xm_option(name, value):
+    """a variant switch of the library for the current test (removed again by the fixture below); value None removes it"""
+    from x_maps_amd import _native as N
+    N.debug_option(name, value)
+
+
+@pytest.fixture(autouse=True)
+def _no_library_options_leak_between_tests():
+    yield
+    try:
+        from x_maps_amd import _native as N
+        if os.path.exists(N.LIB_PATH):
+            N.debug_option(None)
+    except Exception:
+        pass

@@ -5,6 +5,8 @@ show because the frame kernel zeroes every pixel it reads.  Each is exercised he
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
 from x_maps_amd import synthetic as S
@@ -106,7 +108,7 @@ def test_groups_of_camera_frames_and_the_event_index_limit():
 
 
 def test_switch(monkeypatch):
-    monkeypatch.setenv("XM_KEY32", "0")
+    xm_option("XM_KEY32", "0")
     cfg = S.C_1M
     tb = S.make_tables(cfg)
     with XMapsEngine(tb, camera_perspective=True) as eng:

@@ -7,6 +7,8 @@ deterministic function of (stream, column).  Each is exercised here against the 
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
 from x_maps_amd import synthetic as S
@@ -18,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def _column_tiles_for_single_frames_too(monkeypatch):
     """By default only groups of frames (xm_process_batch) take the column tiles -- a single frame's boundary pass is a third
     dependent launch; XM_COLS=2 sends single-frame calls there as well, which is how most cases below reach the kernel."""
-    monkeypatch.setenv("XM_COLS", "2")
+    xm_option("XM_COLS", "2")
 
 
 def _ref(tb, evs, **kw):
@@ -240,9 +242,9 @@ def test_switches(monkeypatch):
     res = {}
     for mode in ("2", None, "0"):
         if mode is None:
-            monkeypatch.delenv("XM_COLS")
+            xm_option("XM_COLS", None)
         else:
-            monkeypatch.setenv("XM_COLS", mode)
+            xm_option("XM_COLS", mode)
         with XMapsEngine(tb, n_slots=2) as eng:
             d, b, st = _run(eng, evs)
             single = eng.path_counts()
@@ -400,7 +402,7 @@ def test_offline_replay_of_event_frames_through_groups(monkeypatch):
     """DepthReprojectionPipe.process_ev_frames: a list of EventCD frames (as the trigger finder cuts them) through groups of
     multi-frame launches, one callback per frame, the same frames as process_ev_frame gives one by one -- an unsorted frame in
     the middle included (redone on the general path)."""
-    monkeypatch.delenv("XM_COLS")  # library defaults: groups take the column tiles
+    xm_option("XM_COLS", None)  # library defaults: groups take the column tiles
     from x_maps_amd.depth_reprojection_pipe import DepthReprojectionPipe
     from x_maps_amd.depth_reprojection_processor import RuntimeParams
     from x_maps_amd.stats import StatsPrinter

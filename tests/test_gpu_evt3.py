@@ -135,9 +135,9 @@ def test_in_front_of_the_device_ingest():
     chunks = [evt3.encode_evt3(pk) for pk in TI._packets(stream, int(1e6 / fps / 4)) if len(pk)]  # a quarter of a period per chunk
     sm = EO.Evt3StateMachine()
     with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2, XMapsEngine(tb) as e3:
-        ing1 = DeviceIngest(e1, fps, max_packet_events=8192, capacity_events=65536)
-        ing2 = DeviceIngest(e2, fps, max_packet_events=8192, capacity_events=65536)
-        ing3 = DeviceIngest(e3, fps, max_packet_events=8192, capacity_events=65536)
+        ing1 = DeviceIngest(e1, fps, max_packet_events=8192, capacity_events=65536, result_ring=64)
+        ing2 = DeviceIngest(e2, fps, max_packet_events=8192, capacity_events=65536, result_ring=64)
+        ing3 = DeviceIngest(e3, fps, max_packet_events=8192, capacity_events=65536, result_ring=64)
         out1, out2, out3 = [], [], []
         pinned = []
         with evt3.DeviceEvt3Decoder(e1, max_words=max(len(c) for c in chunks)) as dec, \

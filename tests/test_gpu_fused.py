@@ -4,6 +4,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
 from x_maps_amd import synthetic as S
@@ -194,8 +196,8 @@ def test_c1m_direct_kernels_match_tiled(monkeypatch):
     x, y, t, _ = S.to_soa(evs)
     with XMapsEngine(tb) as eng:
         d0, b0, s0 = eng.process_frame(x, y, t)
-    monkeypatch.setenv("XM_K1_DIRECT", "1")
-    monkeypatch.setenv("XM_K2_DIRECT", "1")
+    xm_option("XM_K1_DIRECT", "1")
+    xm_option("XM_K2_DIRECT", "1")
     with XMapsEngine(tb) as eng:
         d1, b1, s1 = eng.process_frame(x, y, t)
     assert np.array_equal(d0, d1) and np.array_equal(b0, b1) and s0.n_inliers == s1.n_inliers
@@ -230,7 +232,7 @@ def test_order_invariance_property_full_size():
 def test_dirty_line_flags_option_gives_the_same_frames(monkeypatch):
     """XM_K2_FLAGS=1 (K1 marks dirty key-frame lines, K2 skips clean ones): an optional byte-saving path, same frames,
     also across consecutive frames on one slot (stale flags must only ever be false positives)."""
-    monkeypatch.setenv("XM_K2_FLAGS", "1")
+    xm_option("XM_K2_FLAGS", "1")
     tb = S.make_tables(S.C_1M)
     with XMapsEngine(tb) as eng:
         for f, kw in ((0, {}), (1, {"shuffled": True}), (2, {"n": 50_000}), (3, {})):

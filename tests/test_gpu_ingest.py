@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import ingest_oracle as IO
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
@@ -45,7 +47,7 @@ def _tiny_stream(n_frames, seed, per_frame=2600, neg=0.1, gap_noise=3):
 def _check_frames(tb, got, want_frames, camera=False):
     assert len(got) == len(want_frames), (len(got), len(want_frames))
     for fr, evs in zip(got, want_frames):
-        assert (fr.n_events, fr.t_first, fr.t_last) == (len(evs), int(evs["t"][0]), int(evs["t"][-1])), fr.seq
+        assert (fr.n_events, fr.t_first, fr.t_last) == (len(evs), int(evs["t"][0]), int(evs["t"][-1])), (fr.seq, fr.lost, fr.overflow)
         x, y, t, _ = S.to_soa(evs)
         ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t, camera_perspective=camera)
         assert fr.n_inliers == int(ref["mask"].sum()) and fr.n_index_errors == 0 and not fr.lost and fr.overflow == 0
@@ -59,7 +61,7 @@ def test_golden_trigger_stream_is_cut_on_the_device_like_the_reference(golden_di
     ev = np.zeros(len(g["t"]), S.EVENT_CD_DTYPE)
     ev["x"], ev["y"], ev["t"], ev["p"] = g["x"], g["y"], g["t"], 1
     tb = S.make_tables(S.C_TINY)
-    with XMapsEngine(tb) as eng, DeviceIngest(eng, int(g["fps"]), capacity_events=1 << 16, max_packet_events=1 << 13) as ing:
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, int(g["fps"]), capacity_events=1 << 16, max_packet_events=1 << 13, result_ring=64) as ing:
         got = []
         cuts = g["packet_cuts"]
         for a, b in zip(cuts[:-1], cuts[1:]):
@@ -91,7 +93,7 @@ def test_filters_and_segmentation_match_the_cpu_chain(camera, activity):
         tf.process_events(act.process(pos) if activity else pos)
     assert len(tf.frames) >= 4  # the reference finder loses lock easily (a buffer with a single pause is dropped): by design
     with XMapsEngine(tb, camera_perspective=camera) as eng, \
-            DeviceIngest(eng, 60, activity_filter=activity, capacity_events=1 << 13, max_packet_events=1 << 11) as ing:
+            DeviceIngest(eng, 60, activity_filter=activity, capacity_events=1 << 13, max_packet_events=1 << 11, result_ring=64) as ing:
         got = []
         for p in pk:
             ing.push(p)
@@ -112,7 +114,7 @@ def test_activity_filter_with_packets_longer_than_its_threshold():
         tf.process_events(act.process(IO.polarity_filter(p)))
     assert len(tf.frames) >= 2
     with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, activity_filter=True, activity_thresh_us=2_000,
-                                              capacity_events=1 << 14, max_packet_events=1 << 12) as ing:
+                                              capacity_events=1 << 14, max_packet_events=1 << 12, result_ring=64) as ing:
         got = []
         for p in pk:  # 4.2 ms packets against a 2 ms threshold
             ing.push(p)
@@ -132,7 +134,7 @@ def test_esl_like_stream_stays_on_the_device():
     for p in pk:
         tf.process_events(IO.polarity_filter(p))
     assert len(tf.frames) >= 4
-    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 20, max_packet_events=1 << 17) as ing:
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 20, max_packet_events=1 << 17, result_ring=64) as ing:
         got = []
         for p in pk:
             ing.push(p)
@@ -181,7 +183,7 @@ def test_the_slot_is_cleared_before_its_frame_tag_can_wrap(monkeypatch):
     """The ingest slot's tag advances on the device (one per cut frame) and is 19 bits wide in the packed keys: the host clears
     the slot every KEY_MAX_TAG - 16 pushes at the latest.  XM_INGEST_CLEAR_EVERY=3 makes that happen every third push here: the
     frames must come out exactly as without it (every clear lands between two frames of the stream)."""
-    monkeypatch.setenv("XM_INGEST_CLEAR_EVERY", "3")
+    xm_option("XM_INGEST_CLEAR_EVERY", "3")
     tb = S.make_tables(S.C_TINY)
     stream = _tiny_stream(14, seed=31)
     pk = _packets(stream, int(1e6 / 60 / 4))
@@ -189,7 +191,7 @@ def test_the_slot_is_cleared_before_its_frame_tag_can_wrap(monkeypatch):
     for p in pk:
         tf.process_events(IO.polarity_filter(p))
     assert len(tf.frames) >= 4
-    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 11) as ing:
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 11, result_ring=64) as ing:
         got = []
         for p in pk:
             ing.push(p)
@@ -205,7 +207,7 @@ def test_min_events_per_frame_below_four_is_rejected():
     tb = S.make_tables(S.C_TINY)
     with XMapsEngine(tb) as eng:
         with pytest.raises((XMapsNativeError, ValueError)):
-            DeviceIngest(eng, 60, min_events_per_frame=2)
+            DeviceIngest(eng, 60, min_events_per_frame=2, result_ring=64)
 
 
 @pytest.mark.parametrize("launch_thread", [True, False])
@@ -255,7 +257,7 @@ def test_packets_of_any_size_and_empty_packets():
         tf.process_events(IO.polarity_filter(p))
     assert len(tf.frames) >= 4
     # (the ring must hold what the trigger finder may keep -- up to two periods -- plus a full packet: 1 << 16)
-    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 16, max_packet_events=1 << 13) as ing:
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 16, max_packet_events=1 << 13, result_ring=64) as ing:
         got = []
         for p in pk:
             ing.push(p)
@@ -274,7 +276,7 @@ def test_a_ring_without_room_drops_its_live_part_and_says_so():
     ev["t"] = 1_000_000 + np.arange(n) // 4  # 4 events per us for 5 ms: no pause, less than a period
     ev["x"], ev["y"], ev["p"] = 3, 3, 1
     tail = _tiny_stream(8, seed=2)
-    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 12) as ing:
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 12, result_ring=64) as ing:
         for a in range(0, n, 4000):
             ing.push(ev[a:a + 4000])  # 4000 live: room; 8000 live: no room for 4096 more -> dropped; and again
         for p in _packets(tail, int(1e6 / 60 / 4)):
@@ -298,7 +300,7 @@ def test_views_into_the_result_ring():
     pk = _packets(stream, int(1e6 / 60 / 4))
     with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2, DeviceIngest(e1, 60, capacity_events=1 << 14, max_packet_events=1 << 12,
                                                                        result_ring=2) as a, \
-            DeviceIngest(e2, 60, capacity_events=1 << 14, max_packet_events=1 << 12) as b:
+            DeviceIngest(e2, 60, capacity_events=1 << 14, max_packet_events=1 << 12, result_ring=64) as b:
         n = 0
         addrs = set()
         for p in pk:

@@ -9,6 +9,8 @@ BGR only, output rows at odd addresses."""
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
 from x_maps_amd import synthetic as S
@@ -56,15 +58,15 @@ def _check_group(tb, cfg, n_frames=5, **kw):
 @pytest.mark.parametrize("kind,proj_w", [("cols", 256), ("cols", 264), ("cols", 260), ("cols", 250), ("own", 270), ("own", 320),
                                          ("fine", 640), ("fine", 600), ("fine", 604), ("fine", 570), ("tall", 256)])
 def test_every_variant_against_the_oracle(monkeypatch, kind, proj_w, ppt, consec):
-    monkeypatch.setenv("XM_K2_PIPE", "2")
-    monkeypatch.setenv("XM_K2_PIPE_PPT", ppt)
-    monkeypatch.setenv("XM_K2_CONSEC", consec)
+    xm_option("XM_K2_PIPE", "2")
+    xm_option("XM_K2_PIPE_PPT", ppt)
+    xm_option("XM_K2_CONSEC", consec)
     cfg, tb = _rig(kind, proj_w)
     assert _check_group(tb, cfg) == 10
 
 
 def test_a_fine_projector_takes_the_wide_tiles_by_default(monkeypatch):
-    monkeypatch.setenv("XM_K2_PIPE", "2")
+    xm_option("XM_K2_PIPE", "2")
     cfg, tb = _rig("fine", 640)
     assert _check_group(tb, cfg, n_frames=3) == 6
 
@@ -72,17 +74,17 @@ def test_a_fine_projector_takes_the_wide_tiles_by_default(monkeypatch):
 @pytest.mark.parametrize("consec", ["0", "1"])
 @pytest.mark.parametrize("nlds", ["1", "24", "40"])
 def test_disparities_beyond_the_lds_copy_of_the_table_read_the_global_one(monkeypatch, nlds, consec):
-    monkeypatch.setenv("XM_K2_PIPE", "2")
-    monkeypatch.setenv("XM_K2_NLDS_MAX", nlds)  # the shared-cell rig's disparities are around 30
-    monkeypatch.setenv("XM_K2_CONSEC", consec)
+    xm_option("XM_K2_PIPE", "2")
+    xm_option("XM_K2_NLDS_MAX", nlds)  # the shared-cell rig's disparities are around 30
+    xm_option("XM_K2_CONSEC", consec)
     cfg, tb = _rig("own", 272)
     assert _check_group(tb, cfg, n_frames=3) == 6
 
 
 @pytest.mark.parametrize("consec", ["0", "1"])
 def test_depth_only_and_bgr_only(monkeypatch, consec):
-    monkeypatch.setenv("XM_K2_PIPE", "2")
-    monkeypatch.setenv("XM_K2_CONSEC", consec)
+    xm_option("XM_K2_PIPE", "2")
+    xm_option("XM_K2_CONSEC", consec)
     cfg, tb = _rig("cols", 256)
     assert _check_group(tb, cfg, n_frames=3, want_bgr=False) == 6
     assert _check_group(tb, cfg, n_frames=3, want_depth=False) == 6
@@ -93,9 +95,9 @@ def test_depth_only_and_bgr_only(monkeypatch, consec):
 def test_output_rows_at_any_address(monkeypatch, shift, consec):
     """the BGR rows leave as 16 / 8 / 4-byte or single-byte stores, whichever the frame's address and row length allow"""
     torch = pytest.importorskip("torch")
-    monkeypatch.setenv("XM_K2_PIPE", "2")
-    monkeypatch.setenv("XM_K2_CONSEC", consec)
-    monkeypatch.setenv("XM_K2_PIPE_PPT", "4")
+    xm_option("XM_K2_PIPE", "2")
+    xm_option("XM_K2_CONSEC", consec)
+    xm_option("XM_K2_PIPE_PPT", "4")
     cfg, tb = _rig("cols", 256)
     frames = [S.make_events(cfg, frame=90 + f) for f in range(3)]
     dev = torch.device("cuda", 0)

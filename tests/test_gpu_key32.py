@@ -6,6 +6,8 @@ kept unambiguous by clearing the frame at least every 15 frames of a slot."""
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
 from x_maps_amd import synthetic as S
@@ -16,7 +18,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _keyed_path_only(monkeypatch):
     """The column tiles (tests/test_gpu_cols.py) take precedence on rigs that qualify for both: switch them off here."""
-    monkeypatch.setenv("XM_COLS", "0")
+    xm_option("XM_COLS", "0")
 
 
 def _ref(tb, evs):
@@ -123,7 +125,7 @@ def test_switch_off_gives_the_same_frames(monkeypatch):
     evs = S.make_events(cfg, frame=15)
     with XMapsEngine(tb) as eng:
         d0, b0, s0 = _run(eng, evs)
-    monkeypatch.setenv("XM_KEY32", "0")
+    xm_option("XM_KEY32", "0")
     with XMapsEngine(tb) as eng:
         d1, b1, s1 = _run(eng, evs)
     assert np.array_equal(d0, d1) and np.array_equal(b0, b1) and s0.n_inliers == s1.n_inliers

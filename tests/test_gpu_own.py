@@ -8,6 +8,8 @@ and the ESL-like rig (real calibration geometry)."""
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd import XMapsEngine
 from x_maps_amd import synthetic as S
@@ -17,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _tiles_for_single_frames_too(monkeypatch):
-    monkeypatch.setenv("XM_COLS", "2")  # single-frame calls take the tiles as well (default: groups only)
+    xm_option("XM_COLS", "2")  # single-frame calls take the tiles as well (default: groups only)
 
 
 def _ref(tb, evs, **kw):
@@ -50,7 +52,7 @@ def test_shared_cell_rig_qualifies_and_matches_the_oracle():
 
 @pytest.mark.parametrize("w", ["4", "12", "16"])
 def test_tile_widths(monkeypatch, w):
-    monkeypatch.setenv("XM_OWN_W", w)
+    xm_option("XM_OWN_W", w)
     cfg = S.C_SHARED
     tb = S.make_tables_shared_cells(cfg)
     with XMapsEngine(tb) as eng:
@@ -65,7 +67,7 @@ def test_tile_widths(monkeypatch, w):
 def test_unsheared_frame(monkeypatch):
     """XM_OWN_SHEAR=0: the frame keeps its plain [rect_w][rect_h] layout; the bands of the (tile, 8-row group)s absorb the slant
     on their own (the shear only makes the flush's stores fall into fewer frame columns)."""
-    monkeypatch.setenv("XM_OWN_SHEAR", "0")
+    xm_option("XM_OWN_SHEAR", "0")
     cfg = S.C_SHARED
     tb = S.make_tables_shared_cells(cfg)
     with XMapsEngine(tb) as eng:

@@ -5,6 +5,8 @@ import time
 import numpy as np
 import pytest
 
+from conftest import xm_option
+
 import xmaps_oracle as O
 from x_maps_amd.proj_time_map import generate_linear_projector_time_map
 from x_maps_amd.x_map import compute_x_map_from_time_map
@@ -78,7 +80,7 @@ def test_sorted_row_builder_equals_the_exhaustive_scan_and_the_oracle(monkeypatc
     (the reference's loop, python/x_map.py:26-52) stays as XM_XMAP_SCAN=1: both must agree bit for bit, with the oracle too."""
     tm, tw, S_, nsl = _adversarial_time_map(seed)
     xm, td = compute_x_map_from_time_map(tm, tw, S_, 4242, nsl)
-    monkeypatch.setenv("XM_XMAP_SCAN", "1")
+    xm_option("XM_XMAP_SCAN", "1")
     xm_s, td_s = compute_x_map_from_time_map(tm, tw, S_, 4242, nsl)
     assert np.array_equal(xm, xm_s) and np.array_equal(td, td_s), seed
     if not np.isnan(tm).any():

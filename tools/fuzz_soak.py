@@ -9,7 +9,7 @@ import test_gpu_cols as C
 import test_gpu_own as W
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-os.environ["XM_COLS"] = "2"
+from x_maps_amd import _native as _N; _N.debug_option("XM_COLS", "2")
 t0 = time.time()
 bad, skipped = [], 0
 for seed in range(first, first + n):

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """ESL-like stream through the device ingest (BGR views): where the launch side's time goes (XM_INGEST_TRACE) + rates"""
 import os, sys, time
-os.environ["XM_INGEST_TRACE"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from x_maps_amd import XMapsEngine, rig, synthetic as S
 from x_maps_amd.ingest import DeviceIngest
+from x_maps_amd import _native as _N
+_N.debug_option("XM_INGEST_TRACE", "1")
 cp, tables, evs0, _ = rig.make_esl_like(row_stride=13)
 stream, _ = rig.render_stream(cp, tables, n_frames=48, row_stride=13, seed=9)
 cap = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21

@@ -38,8 +38,8 @@ timeout 200 python bench.py --graph > $OUT/bench_graph60.json 2> $OUT/bench_grap
 timeout 200 python bench.py --sharded > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
 timeout 300 python bench.py --esl > $OUT/bench_esl.json 2> $OUT/bench_esl.err
 timeout 200 python bench.py --esl --batch 0 --no-cpu-baseline --no-host-path > $OUT/bench_esl_one_frame_per_call.json 2> $OUT/bench_esl_one.err
-XM_COLS=0 timeout 200 python bench.py --esl --no-cpu-baseline --no-host-path --no-other-modes > $OUT/bench_esl_round2_path.json 2> $OUT/bench_esl_r2.err  # the packed-key path of round 2 on the same frames
-XM_K2_PIPE=0 timeout 200 python bench.py --no-cpu-baseline --no-host-path --no-other-modes > $OUT/bench_default_k2_one_block_per_tile.json 2> $OUT/bench_k2old.err
+timeout 200 python bench.py --lib-option XM_COLS=0 --esl --no-cpu-baseline --no-host-path --no-other-modes > $OUT/bench_esl_round2_path.json 2> $OUT/bench_esl_r2.err  # the packed-key path of round 2 on the same frames
+timeout 200 python bench.py --lib-option XM_K2_PIPE=0 --no-cpu-baseline --no-host-path --no-other-modes > $OUT/bench_default_k2_one_block_per_tile.json 2> $OUT/bench_k2old.err
 timeout 200 python bench.py --batch 0 --no-cpu-baseline --no-host-path --no-other-modes > $OUT/bench_one_frame_per_call.json 2> $OUT/bench_one.err
 timeout 200 python bench.py --camera-perspective --no-cpu-baseline --no-other-modes --no-host-path > $OUT/bench_camera.json 2> $OUT/bench_camera.err
 python tools/r03/collect_profiles.py $TAG > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log

@@ -127,6 +127,7 @@ class xm_eval_result(C.Structure):
 _P = C.c_void_p
 SYMBOLS = {
     "xm_api_version": (C.c_int, []),
+    "xm_debug_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "xm_last_error": (C.c_char_p, []),
     "xm_create": (C.c_int, [C.POINTER(xm_config), C.POINTER(_P)]),
     "xm_destroy": (None, [_P]),
@@ -250,3 +251,9 @@ def check(rc: int, *, index_error_ok: bool = False) -> int:
     if rc == XM_ERR_NOMEM:
         raise MemoryError(msg)
     raise XMapsNativeError(f"libxmaps_hip error {rc}: {msg}")
+
+
+def debug_option(name, value=None):
+    """Variant switch for tests / experiments (xm_debug_option): value None removes it, name None removes all."""
+    lib = load_library()
+    lib.xm_debug_option(None if name is None else name.encode(), None if value is None else str(value).encode())

@@ -107,7 +107,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   h->tb.z_near = cfg->z_near;
   h->tb.z_far = cfg->z_far;
   if (h->d_pmap) {  // K2's static per-tile patch rectangles and per-pixel offsets, for both of its geometries
-    if (const char* e = getenv("XM_K2_PPT")) h->k2_force_ppt = atoi(e);
+    if (const char* e = dbg_opt("XM_K2_PPT")) h->k2_force_ppt = atoi(e);
     double mean_cells2 = 0.0;
     bool pipe_ok_g[3] = {false, false, false};
     for (int g = 0; g < 3; ++g) {
@@ -152,7 +152,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       // 128 x 16 tiles -- was built and measured on the ESL-like rig: 94 VGPRs, five blocks per CU, K2 7.3-7.9 against 5.9-6.7 us
       // per frame; removed.)
       if (g == 2) {
-        const char* e4 = getenv("XM_K2_PIPE_PPT");  // experiments / tests: 2 / 4
+        const char* e4 = dbg_opt("XM_K2_PIPE_PPT");  // experiments / tests: 2 / 4
         const bool small = mean_cells2 < 2.0 * (2 * K2_TX * K2_TY);
         const int want = e4 ? atoi(e4) : small ? 4 : 2;
         h->k2_pipe_g = h->k2_pipe_rig_ok && want >= 4 && pipe_ok_g[2] ? 2 : 1;
@@ -169,7 +169,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     for (size_t i = 0; i < cam_px; ++i) xr_min = std::min<int>(xr_min, cfg->cam_mapx_i16[i]);
     for (size_t i = 0; i < xm_cells; ++i) xp_max = std::max<int>(xp_max, cfg->proj_x_map[i]);
     const long max_disp = std::max<long>((long)xp_max - xr_min - cfg->x_offset, (long)0 - xr_min - cfg->x_offset);
-    const char* e32 = getenv("XM_KEY32");
+    const char* e32 = dbg_opt("XM_KEY32");
     // (camera view: (event index + 1) << 12 | disparity on the camera frame -- only the disparity range matters)
     h->key32_ok = (cfg->view != XM_VIEW_PROJECTOR || (cfg->rect_height & 3) == 0) && max_disp < (1l << KEY32_DISP_BITS) &&
                   !(e32 && e32[0] == '0');
@@ -178,13 +178,13 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     //  a larger disparity -- the reference's ESL calibration allows 3808 through LUT entries far outside the frame, no rendered
     //  frame comes near -- reads the global table)
     int nlds_max = 2048;
-    if (const char* e = getenv("XM_K2_NLDS_MAX")) nlds_max = std::max(1, std::min(4096, atoi(e)));  // experiments
+    if (const char* e = dbg_opt("XM_K2_NLDS_MAX")) nlds_max = std::max(1, std::min(4096, atoi(e)));  // experiments
     h->k2_pipe_nlds = (int)std::max<long>(1, std::min<long>(std::min<long>(max_disp + 1, 65536), nlds_max));
-    if (const char* e = getenv("XM_K2_PIPE")) {
+    if (const char* e = dbg_opt("XM_K2_PIPE")) {
       h->k2_pipe = e[0] != '0';
       h->k2_pipe_force = e[0] == '2';
     }
-    if (const char* e = getenv("XM_K2_CONSEC")) h->k2_consec = e[0] != '0' ? 1 : 0;  // experiments / tests: the strided pixel assignment
+    if (const char* e = dbg_opt("XM_K2_CONSEC")) h->k2_consec = e[0] != '0' ? 1 : 0;  // experiments / tests: the strided pixel assignment
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
   }
@@ -198,7 +198,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       xp_min = std::min<int>(xp_min, cfg->proj_x_map[i]);
       xp_max = std::max<int>(xp_max, cfg->proj_x_map[i]);
     }
-    const char* ec = getenv("XM_COLS");
+    const char* ec = dbg_opt("XM_COLS");
     // the reference's int16 wrap-around in disp = xp - xr - x_offset (xmd:27) must never trigger on this rig: then
     // disp >= 0 <=> xp - x_offset >= xr, which is what makes "dead" X-map cells recognisable
     const bool no_wrap = (long)xp_max - xr_min - cfg->x_offset <= 32767 && (long)xp_min - xr_max - cfg->x_offset >= -32768;
@@ -249,11 +249,11 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   }
 
   {  // K1 LDS windows (w_ts X-map columns, w_x camera columns) within the LDS budget
-    const char* e1 = getenv("XM_K1_DIRECT");
-    const char* e2 = getenv("XM_K2_DIRECT");
+    const char* e1 = dbg_opt("XM_K1_DIRECT");
+    const char* e2 = dbg_opt("XM_K2_DIRECT");
     h->k1_direct = e1 && e1[0] == '1';
     h->k2_direct = e2 && e2[0] == '1';
-    if (const char* e3 = getenv("XM_K2_FLAGS")) h->k2_flags = e3[0] == '1';
+    if (const char* e3 = dbg_opt("XM_K2_FLAGS")) h->k2_flags = e3[0] == '1';
     // C-1M needs 44 KB (w_ts = 5, w_x = 16): three blocks per CU beside K2's 12 KB blocks
     size_t budget = 76 * 1024;
     int w_ts = 5, w_x = 16;  // 5 time columns, 16 camera columns: 70 KB at C-1M
@@ -287,7 +287,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     if (h->cols_w_max < 1 && !h->own_mode) h->cols_ok = false;
   }
 #ifdef XM_ABLATE
-  if (const char* e = getenv("XM_ABLATE")) {
+  if (const char* e = dbg_opt("XM_ABLATE")) {
     int v = atoi(e);
     XM_TRY_CREATE(hipMemcpyToSymbol(HIP_SYMBOL(xm::g_ablate), &v, sizeof v));
   }
@@ -378,7 +378,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
   //  may overtake them)
   XM_TRY_CREATE(hipDeviceSynchronize());
   {  // launch workers: one per distinct slot stream (XM_FLAG_LAUNCH_WORKERS; off: launches stay in the calling thread)
-    const char* we = getenv("XM_WORKERS");  // overrides the flag either way
+    const char* we = dbg_opt("XM_WORKERS");  // overrides the flag either way
     const bool want = we ? we[0] != '0' : (cfg->flags & XM_FLAG_LAUNCH_WORKERS) != 0;
     if (want) {
       std::vector<hipStream_t> seen;

@@ -419,7 +419,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
     delete g;                             // two pauses would be an empty frame, on which the reference's t.min() raises
     return fail(XM_ERR_INVALID, "min_events_per_frame must be >= 4 (the frame is evs[prev + 2 : next - 2])");
   }
-  if (const char* e = getenv("XM_INGEST_CLEAR_EVERY")) g->clear_every = (uint64_t)std::max(1, atoi(e));  // tests: exercise the tag clear
+  if (const char* e = dbg_opt("XM_INGEST_CLEAR_EVERY")) g->clear_every = (uint64_t)std::max(1, atoi(e));  // tests: exercise the tag clear
   g->ring = cfg->result_ring > 0 ? cfg->result_ring : 8;
   const size_t cam_px = (size_t)h->tb.cam_w * h->tb.cam_h;
   const size_t px = (size_t)h->out_w * h->out_h;
@@ -530,7 +530,7 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->frame_stream) (void)hipStreamSynchronize(g->frame_stream);
-  if (getenv("XM_INGEST_TRACE"))
+  if (dbg_opt("XM_INGEST_TRACE"))
     fprintf(stderr, "[ingest] %llu packets, %llu frames, ahead %d: launch side %.3f ms in jobs, of which %.3f ms waiting for verdicts and %.3f ms "
             "issuing frames; caller %.3f ms in push, %.3f ms of it waiting for staging entries\n", (unsigned long long)g->issued,
             (unsigned long long)g->frames_issued, g->ahead, g->t_jobs_s * 1e3, g->t_block_s * 1e3, g->t_frames_s * 1e3, g->push_host_s * 1e3,
@@ -616,6 +616,9 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->seq = g->next_seq;
   out->lost = lapped ? 1 : 0;
   if (lapped) {
+    if (dbg_opt("XM_INGEST_TRACE")) fprintf(stderr, "[ingest] lapped: slot %d want %llu seq %llu seq2 %llu (frames issued %llu, pushes issued %llu)\n", slot,
+                                            (unsigned long long)want, (unsigned long long)seq, (unsigned long long)seq2,
+                                            (unsigned long long)g->frames_issued, (unsigned long long)g->issued);
     // Nothing of the entry can be trusted for frame next_seq (no statistics, no images: depth / bgr stay NULL).
     // Resume with the oldest frame the ring may still hold intact.
     const uint64_t newest = std::max(seq, seq2);  // >= want + ring - 1

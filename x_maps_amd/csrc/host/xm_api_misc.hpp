@@ -4,6 +4,16 @@
 
 extern "C" {
 
+// value == NULL removes the option; name == NULL removes all of them
+int xm_debug_option(const char* name, const char* value) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  if (!name) g_opts.clear();
+  else if (!value) g_opts.erase(name);
+  else g_opts[name] = value;
+  return XM_OK;
+}
+
+
 // ---- N1: X-map construction ----------------------------------------------------------------------------------
 int xm_build_x_map(int device, const float* time_map, int height, int width, int x_map_width, int t_px_scale,
                    int x_offset, int num_scanlines, int16_t* x_map_out, float* t_diffs_out) {
@@ -29,7 +39,7 @@ int xm_build_x_map(int device, const float* time_map, int height, int width, int
     }
     int wp = 2;
     while (wp < width) wp <<= 1;
-    const char* es = getenv("XM_XMAP_SCAN");  // tests: XM_XMAP_SCAN=1 takes the exhaustive scan (read at every call)
+    const char* es = dbg_opt("XM_XMAP_SCAN");  // tests: XM_XMAP_SCAN=1 takes the exhaustive scan (read at every call)
     const bool brute = es && es[0] == '1';
     if (wp <= 8192 && !brute) {  // rows of up to 8192 columns: the sorted-row kernel (96 KB of LDS at most)
       const size_t lds = (size_t)wp * sizeof(u64) + (size_t)width * sizeof(float);

@@ -183,7 +183,7 @@ int enqueue_frame(xm_handle* h, Slot& s, const EventsView& ev, float* depth, uin
     if (rc) return rc;
   }
 #ifdef XM_ABLATE
-  static const int skip = getenv("XM_SKIP_MASK") ? atoi(getenv("XM_SKIP_MASK")) : 0;  // experiments: 1=K0 2=K1 4=K2
+  static const int skip = dbg_opt("XM_SKIP_MASK") ? atoi(dbg_opt("XM_SKIP_MASK")) : 0;  // experiments: 1=K0 2=K1 4=K2
 #else
   constexpr int skip = 0;
 #endif

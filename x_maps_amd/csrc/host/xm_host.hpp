@@ -23,6 +23,17 @@ int fail(int code, const char* fmt, ...) {
                                       __FILE__, __LINE__);                                          \
   } while (0)
 
+// Variant switches for tests and experiments (XM_COLS, XM_K2_PIPE, XM_OWN_W, ...): set through xm_debug_option(), never read from
+// the environment -- the library's behaviour does not depend on what the calling process happens to have exported.  Read when a
+// handle (or an ingest) is created.
+std::mutex g_opt_mu;
+std::map<std::string, std::string> g_opts;
+const char* dbg_opt(const char* name) {  // (the text stays valid until the option is set again or removed)
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  auto it = g_opts.find(name);
+  return it == g_opts.end() ? nullptr : it->second.c_str();
+}
+
 struct DevBuf {  // grow-only device scratch
   void* p = nullptr;
   size_t cap = 0;

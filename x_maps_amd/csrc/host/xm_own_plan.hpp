@@ -29,7 +29,7 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   if (r_hi < r_lo) return;
   const int hr = r_hi - r_lo + 1, hrp = (hr + 7) & ~7;
   int W = 8;
-  if (const char* e = getenv("XM_OWN_W")) W = atoi(e);
+  if (const char* e = dbg_opt("XM_OWN_W")) W = atoi(e);
   W = std::max(OWN_BW, std::min(W, 64)) / OWN_BW * OWN_BW;
   // 1. owner column of every cell, row by row: delta = column - first column of the row that maps to the same cell
   std::vector<uint16_t>& packed = pl.packed;  // [c][row], as tb.xmap
@@ -81,7 +81,7 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   }
   int m = 0;
   if (std::fabs(slope) * hr >= 24.0) m = (int)std::lround(-slope * 8.0 * 4096.0);
-  if (const char* e = getenv("XM_OWN_SHEAR")) m = atoi(e);  // experiments
+  if (const char* e = dbg_opt("XM_OWN_SHEAR")) m = atoi(e);  // experiments
   int sh_min = 0, sh_max = 0;
   for (int g = 0; g <= (rect_h - 1) >> 3; ++g) {
     const int sh = (g * m) >> 12;

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <cmath>
 #include <limits>
+#include <map>
 #include <memory>
 #include <algorithm>
 #include <new>

@@ -84,7 +84,8 @@ class DepthReprojectionPipe:
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
                                        activity_filter=getattr(p, "activity_filter", False), want_depth=False,
-                                       result_ring=int(getattr(p, "ingest_result_ring", 8)))
+                                       result_ring=int(getattr(p, "ingest_result_ring", 8)),
+                                       lossless=not p.should_drop_frames)  # no_frame_dropping (the default): never lap the ring
             self._ingest_views = bool(getattr(p, "ingest_frame_views", False))
 
     # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------

@@ -200,6 +200,7 @@ class DeviceEvt3Decoder:
         for (the ingest's kernels read the count on the device), returns None."""
         C = self._C
         w = np.ascontiguousarray(words, dtype="<u2")
+        ingest._backpressure(1)
         if not count:
             self._N.check(self._lib.xm_ingest_push_evt3(ingest._g, self._d, C.c_void_p(w.ctypes.data), len(w), int(bool(pinned)), None))
             return None

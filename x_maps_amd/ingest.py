@@ -41,7 +41,7 @@ class DeviceIngest:
     def __init__(self, engine, projector_fps: int, use_polarity: bool = True, activity_filter: bool = False,
                  activity_thresh_us: int = 0, capacity_events: int = 0, max_packet_events: int = 0, result_ring: int = 8,
                  expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True, min_events_per_frame: int = 0,
-                 launch_thread: bool = True):
+                 launch_thread: bool = True, lossless: bool = False):
         self._e = engine
         self._lib = engine._lib
         cfg = N.xm_ingest_config()
@@ -63,6 +63,13 @@ class DeviceIngest:
         self.max_packet = int(max_packet_events) or (1 << 19)
         self.shape = (engine.out_h, engine.out_w)
         self._views = {}
+        # lossless: a caller that polls after every push never loses a frame to the result ring being lapped -- at most one frame
+        # is cut per push, so after result_ring - 1 pushes without a synchronisation the next push waits for the GPU first (the
+        # frames cut so far are then published and the caller's poll behind this push picks them up).  Off: the reference's own
+        # behaviour under load -- frames the host did not fetch in time are dropped and reported (`lost`).
+        self._lossless = bool(lossless)
+        self._ring = int(result_ring) if int(result_ring) > 0 else 8
+        self._pushes_unsynced = 0
         self._fr = N.xm_ingest_frame()
         self._fr_ref = C.byref(self._fr)
 
@@ -90,6 +97,7 @@ class DeviceIngest:
         if evs.dtype != EVENT_CD_DTYPE:
             evs = evs.astype(EVENT_CD_DTYPE)
         evs = np.ascontiguousarray(evs)
+        self._backpressure(max(1, -(-len(evs) // self.max_packet)))
         if len(evs) == 0:
             N.check(self._lib.xm_ingest_push(self._g, None, 0))
             return
@@ -100,9 +108,17 @@ class DeviceIngest:
     def push_pinned(self, evs: np.ndarray):
         """A packet that already lives in pinned host memory (XMapsEngine.host_empty): no staging copy."""
         assert evs.dtype == EVENT_CD_DTYPE and evs.flags.c_contiguous
+        self._backpressure(max(1, -(-len(evs) // self.max_packet)))
         for a in range(0, len(evs), self.max_packet):
             part = evs[a:a + self.max_packet]
             N.check(self._lib.xm_ingest_push_pinned(self._g, C.c_void_p(part.ctypes.data), len(part)))
+
+    def _backpressure(self, n_pushes):
+        if not self._lossless:
+            return
+        if self._pushes_unsynced + n_pushes > self._ring - 1:
+            self.flush()
+        self._pushes_unsynced += n_pushes
 
     def _view(self, ptr, shape, ctype):
         """NumPy view of one buffer of the pinned result ring (built once per buffer, from the address: np.ctypeslib.as_array on
@@ -152,6 +168,7 @@ class DeviceIngest:
 
     def flush(self):
         N.check(self._lib.xm_ingest_flush(self._g))
+        self._pushes_unsynced = 0
 
     def reset(self):
         N.check(self._lib.xm_ingest_reset(self._g))
