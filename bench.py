@@ -68,8 +68,10 @@ def parse_args():
     ap.add_argument("--sharded", action="store_true", help="config 4: C-10M sharded by event index over the ranks (RCCL)")
     ap.add_argument("--esl", action="store_true",
                     help="configs 1/3 stand-in: ESL-like frames (real calibration geometry, ~150 k events, projector 1080x1920)")
-    ap.add_argument("--merge", choices=("all_reduce", "reduce_scatter", "bands"), default="all_reduce",
-                    help="--sharded: how the shards' key frames are merged (x_maps_amd/sharded.py)")
+    ap.add_argument("--merge", choices=("columns", "all_reduce", "reduce_scatter", "bands"), default="columns",
+                    help="--sharded: how the shards are merged (x_maps_amd/sharded.py).  columns (default): every time column on one rank, "
+                         "plain u16 frames merged by SUM (falls back to all_reduce on rigs that do not take the column tiles); the others: "
+                         "packed 64-bit keys merged by MAX")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
                          "launches, grid = frames x tiles); 0 = a step is one frame through one asynchronous call (round 2's "
@@ -1483,7 +1485,18 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         shards.append(tuple(torch.from_numpy(v[a:b].copy()).to(dev) for v in (x.view(np.int16), y.view(np.int16), t)) + (None,))
     torch.cuda.synchronize()
     prov = GpuShardProvider(eng, dev)
-    proc = ShardedFrameProcessor(prov, dist, always_reduce=True, merge=args.merge)  # world 1: the collectives are issued all the same
+    merge = args.merge
+    if merge == "columns" and (camera or eng.shard_cols_info(n_ev) is None):
+        merge = "all_reduce"  # (camera view / rigs whose X-map is not injective: the packed keys)
+    proc = ShardedFrameProcessor(prov, dist, always_reduce=True, merge=merge)  # world 1: the collectives are issued all the same
+    resident = None
+    if merge == "columns":  # the shards as a host keeps them resident for this path: headroom in front for the predecessor's last column
+        resident = [proc.columns_resident(sh, n_ev) for sh in shards]
+
+    def process(i, want_bgr):
+        if merge == "columns":
+            return proc.process_shard_columns(*resident[i % nf], want_bgr=want_bgr)
+        return proc.process_shard(shards[i % nf], a, want_bgr=want_bgr)
 
     # collective time: torch events on the engine's stream around the two all-reduces
     ev_pairs = []
@@ -1504,8 +1517,9 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
 
     parity = None
     O = None
-    depth, bgr = proc.process_shard(shards[0], a, want_bgr=not args.no_bgr)
+    depth, bgr = process(0, not args.no_bgr)
     sync()
+    cols_failed = proc.columns_failed() if merge == "columns" else None  # (a collective: every rank)
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import xmaps_oracle as O
@@ -1515,13 +1529,15 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         if bgr is not None:
             parity["bgr_equal"] = bool(np.array_equal(bgr.cpu().numpy(), ref["bgr"]))
         parity["checker"] = "C/OpenMP oracle, unsharded frame 0"
-        if not (parity["depth_max_rel_err"] <= 1e-4 and parity["empty_mask_equal"] and parity.get("bgr_equal", True)) and not args.no_parity:
+        if cols_failed is not None:
+            parity["no_piece_objected"] = not cols_failed
+        if not (parity["depth_max_rel_err"] <= 1e-4 and parity.get("no_piece_objected", True) and parity["empty_mask_equal"] and parity.get("bgr_equal", True)) and not args.no_parity:
             print(json.dumps({"error": "parity check failed", "parity": parity}))
             sys.exit(1)
     tm = Timer(torch, dist, dev, sync)
 
     def step(i):
-        proc.process_shard(shards[i % nf], a, want_bgr=not args.no_bgr)
+        process(i, not args.no_bgr)
 
     for i in range(min(args.warmup, 50)):
         step(i)
@@ -1536,7 +1552,7 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         setattr(proc, k, timed(f))
     # ... and the shard's three kernels the same way (K0 extrema of the shard, K1 scatter with global event indices, K2 on the
     # merged key frame): torch events on the engine's stream, which is torch's current stream inside process_shard
-    k_pairs = {"minmax_into": [], "scatter": [], "finish": [], "finish_u16": [], "finish_u16_band": []}
+    k_pairs = {"minmax_into": [], "scatter": [], "finish": [], "finish_u16": [], "finish_u16_band": [], "cols_pack": [], "cols_scatter": [], "cols_finish": []}
     p_orig = {k: getattr(prov, k) for k in k_pairs}
 
     def timed_k(name, fn):
@@ -1557,11 +1573,14 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         setattr(proc, k, f)
     for k, f in p_orig.items():
         setattr(prov, k, f)
-    k_ms = [float(np.median([e0.elapsed_time(e1) for e0, e1 in k_pairs[k]])) if k_pairs[k] else 0.0
-            for k in ("minmax_into", "scatter", {"all_reduce": "finish", "reduce_scatter": "finish_u16", "bands": "finish_u16_band"}[args.merge])]
+    med = lambda k: float(np.median([e0.elapsed_time(e1) for e0, e1 in k_pairs[k]])) if k_pairs[k] else 0.0
+    if merge == "columns":  # (the pack of the shard's last events in the helper slot; K1 = prepare + boundary pass + column tiles)
+        k_ms = [med("cols_pack"), med("cols_scatter"), med("cols_finish")]
+    else:
+        k_ms = [med(k) for k in ("minmax_into", "scatter", {"all_reduce": "finish", "reduce_scatter": "finish_u16", "bands": "finish_u16_band"}[merge])]
     # extrema + key frame | extrema + reduce-scatter + all-gather | extrema + reduce-scatter + depth + BGR (the halo exchange is
-    # point to point and not timed here)
-    per_frame = {"all_reduce": 2, "reduce_scatter": 3, "bands": 3 if args.no_bgr else 4}[args.merge]
+    # point to point and not timed here) | headers + last events + u16 frame
+    per_frame = {"all_reduce": 2, "reduce_scatter": 3, "bands": 3 if args.no_bgr else 4, "columns": 2}[merge]
     coll = np.array([e0.elapsed_time(e1) for e0, e1 in ev_pairs]).reshape(-1, per_frame)
     coll_ms = torch.tensor([float(np.median(coll[:, 0])), float(np.median(coll[:, 1:].sum(axis=1)))], dtype=torch.float64, device=dev)
     if world > 1:
@@ -1575,7 +1594,8 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                                       "torch.cuda.Event pairs recorded on the engine's stream (torch's current stream inside "
                                       "process_shard) around the shard's three kernel launches, 20 frames, median; k_minmax = the "
                                       "shard's extrema pass K0; k_scatter processes THIS rank's events (events_per_rank); k_frame "
-                                      "runs on the merged key frame on every rank", cell_bytes=8 if args.merge == "all_reduce" else 2)
+                                      "runs on the merged key frame on every rank; merge = columns: k_minmax = the pack of the shard's last events, "
+                                      "k_scatter = prepare (extrema, own / predecessor's last column) + boundary pass + column-tile K1", cell_bytes=8 if merge == "all_reduce" else 2)
     pipeline_fractions(roofline, alg, pt, ("camera" if camera else "projector") + "_sharded", value, 1, elapsed / steps, 1)
     roofline["event_stream_read_roofline_frac_note"] = "whole frame (all ranks' events) per step time against ONE GPU's HBM read peak"
     cpu = None
@@ -1597,18 +1617,23 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         "unit": "Mevents/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 5),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
         "config": {"workload": f"C-10M: synthetic 10M events/frame, 1280x720 cam/proj, rect 3520x1980, event buffer sharded by "
-                               f"index over {world} rank(s), packed-key frame MAX-all-reduced over RCCL" +
+                               f"index over {world} rank(s), " + ("every time column on one rank, u16 frames SUM-all-reduced over RCCL" if merge == "columns"
+                                                                    else "packed-key frame MAX-all-reduced over RCCL") +
                                (" (camera view)" if camera else " (projector view)"),
                    "events_per_frame": n_ev, "events_per_rank": b - a, "key_frame_MB": round(kshape[0] * kshape[1] * 8 / 1e6, 1),
                    "host_synchronisations_per_frame": 0,
-                   "merge": args.merge,
-                   "collectives_per_frame": ["all_reduce MIN int64[2] (frame extrema)"] +
-                                            (["all_reduce MAX int64[key frame]"] if args.merge == "all_reduce" else
+                   "merge": merge, "collective_bytes_per_frame_and_rank": getattr(proc, "collective_bytes_per_frame", None),
+                   "collectives_per_frame": (["all_gather of {first / last stamp, the shard's last events} (carries the extrema and every last column)",
+                                              "all_reduce SUM uint32[u16 frame / 2] (disjoint cells)"] if merge == "columns" else
+                                             ["all_reduce MIN int64[2] (frame extrema)"]) +
+                                            ([] if merge == "columns" else
+                                             ["all_reduce MAX int64[key frame]"] if merge == "all_reduce" else
                                              ["reduce_scatter MAX int64[key frame]", "all_gather u16[key frame] (decoded disparities)"]
-                                             if args.merge == "reduce_scatter" else
+                                             if merge == "reduce_scatter" else
                                              ["reduce_scatter MAX int64[key frame]", "send / recv of the band's halos (neighbours)",
                                               "all_reduce MAX of the partial projector frames (depth as int32, BGR u8)"])},
-        "collective_ms": {"extrema_min_all_reduce": round(float(coll_ms[0]), 4), "key_frame_merge": round(float(coll_ms[1]), 4),
+        "collective_ms": {("last_events_all_gather" if merge == "columns" else "extrema_min_all_reduce"): round(float(coll_ms[0]), 4),
+                          "key_frame_merge": round(float(coll_ms[1]), 4),
                           "note": "median over 20 frames, torch events on the engine's stream around each all-reduce, max over ranks; "
                                   "with one rank RCCL still runs its kernels (always_reduce) but nothing crosses xGMI"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),

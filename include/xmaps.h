@@ -345,6 +345,32 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
  * all-reduce over the ranks -- depth >= 0, an owner's BGR >= the zeros of the others -- assembles the frame).  Projector view. */
 int xm_shard_finish_u16_band(xm_handle* h, const uint16_t* disp_frame, int col_lo, int col_hi, float* depth_out, uint8_t* bgr_out);
 
+/* ---- shards on the column tiles (time-sorted int64 frames on rigs whose X-map is injective: the path xm_process_batch takes) ----
+ * A shard is a contiguous index range of the sorted stream = whole time columns, except that its last column may go on in the
+ * next shard.  Each rank but the last leaves the events of its last column to its successor; then every column is processed by
+ * ONE rank, the ranks' plain u16 disparity frames are disjoint and merge by SUM (2 bytes per cell on the wire instead of the
+ * 8-byte packed keys; no atomics, no extrema pass).  Per frame and rank, all enqueued on xm_stream(h, 0), TWO collectives:
+ *   xm_shard_cols_pack      send_buf <- {t[0], t[n-1], n, count | x[cap] | y[cap] | t[cap]}: the shard's first / last stamp and its last
+ *                           min(n, cap) events                               then ALL-GATHER of the send buffers (send_bytes each)
+ *   xm_shard_cols_scatter   the frame's extrema out of the gathered headers; the own part ends where the own last column starts
+ *                           (not on the last rank); the predecessor's last column out of its buffer in front of the own events
+ *                           -- x / y / t (16-byte aligned) MUST have cap_events + 8 events of writable headroom in front of them
+ *                           and 8 behind --; boundary pass + column-tile K1 into frame16
+ *                                                                            then SUM all-reduce of reduce_u32 uint32 of frame16
+ *   xm_shard_finish_u16     the frame kernel on the merged frame
+ * xm_shard_cols_info: sizes for frames of n_frame_events events (frame16 holds frame_bytes: the frame + the boundary pass'
+ * scratch behind it; XM_ERR_INVALID when the rig / density does not qualify).  A piece that cannot be handled (a shard without
+ * events or inside one column, a last column beyond cap_events, events out of order, >= 2^32 us) raises a sticky flag instead
+ * of producing a wrong frame: xm_shard_cols_failed (synchronises) reports and clears it -- MAX-all-reduce it over the ranks and
+ * redo the frames since the last check with the packed keys (xm_shard_scatter_device ...). */
+int xm_shard_cols_info(xm_handle* h, uint64_t n_frame_events, size_t* frame_bytes, size_t* reduce_u32, size_t* send_bytes,
+                       size_t* cap_events);
+int xm_shard_cols_pack(xm_handle* h, const uint16_t* x, const uint16_t* y, const int64_t* t, size_t n, void* send_buf_dev,
+                       size_t cap_events);
+int xm_shard_cols_scatter(xm_handle* h, uint16_t* x, uint16_t* y, int64_t* t, size_t n, uint64_t n_frame_events,
+                          const void* gathered_dev, size_t send_bytes, int rank, int world, size_t cap_events, uint16_t* frame16);
+int xm_shard_cols_failed(xm_handle* h, int* failed);
+
 /* ---- one frame over several GPUs of ONE process (xm_create_sharded owns the RCCL communicators) ----------------
  * The entry for hosts that are not Python / torch.distributed (x_maps_amd/sharded.py is the multi-process form of the same
  * exchange).  dev_ids[n_dev]: distinct HIP devices; the tables of cfg are uploaded to each (cfg->device is ignored).  Per frame

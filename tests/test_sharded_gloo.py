@@ -98,6 +98,83 @@ class OracleShardProvider:
         bgr = O.generate_color_map(O.clip_normalize_uint8_depth_frame(depth, self.tb["z_near"], self.tb["z_far"]))
         return depth, bgr
 
+    # ---- merge = "columns" (CPU stand-in for xm_shard_cols_*: the same protocol, the frame row-major like this provider's others) ----
+    def _columns(self, t, mm):
+        tmin, tmax = int(mm[0]), -int(mm[1])
+        if tmax == tmin:
+            return np.zeros(len(t), np.int64)
+        return np.rint(((t - tmin) / (tmax - tmin)) * self.tb["t_px_scale"]).astype(np.int16).astype(np.int64)
+
+    def cols_setup(self, n_frame_events):
+        if self.camera:
+            return None
+        cap = 64 + 4 * n_frame_events // max(int(self.tb["t_px_scale"]), 1)
+        cells = self.shape[0] * self.shape[1]
+        self._fail = False
+        return {"cap_events": cap, "send_bytes": 32 + 12 * cap, "reduce_u32": (cells + 1) // 2, "frame_bytes": 4 * ((cells + 1) // 2),
+                "frame": torch.zeros(4 * ((cells + 1) // 2), dtype=torch.uint8), "send": torch.zeros(32 + 12 * cap, dtype=torch.uint8)}
+
+    def cols_resident(self, shard, cap):
+        x, y, t, p = shard
+        assert p is None and t.dtype == np.int64
+        return tuple(np.concatenate((np.zeros(cap, a.dtype), a)) for a in (x, y, t))
+
+    def cols_pack(self, res, n, cap, send):
+        x, y, t = (a[cap:cap + n] for a in res)
+        buf = send.numpy()
+        cnt = min(n, cap)
+        buf[:32].view(np.int64)[:] = (int(t[0]) if n else 0, int(t[-1]) if n else 0, n, cnt)
+        buf[32:32 + 2 * cap].view(np.uint16)[:cnt] = x[n - cnt:]
+        buf[32 + 2 * cap:32 + 4 * cap].view(np.uint16)[:cnt] = y[n - cnt:]
+        buf[32 + 4 * cap:32 + 12 * cap].view(np.int64)[:cnt] = t[n - cnt:]
+
+    def cols_scatter(self, res, n, cap, n_frame, gathered, send_bytes, rank, world, frame):
+        g = gathered.numpy()
+        hdrs = [g[r * send_bytes:r * send_bytes + 32].view(np.int64) for r in range(world)]
+        cells = self.shape[0] * self.shape[1]
+        out = frame.numpy()[:2 * cells].view(np.uint16)
+        out[:] = 0
+        if any(h[2] <= 0 for h in hdrs):
+            self._fail = True
+            return
+        tmin, tmax = min(int(h[0]) for h in hdrs), max(int(h[1]) for h in hdrs)
+        mm = (tmin, -tmax)
+        x, y, t = (a[cap:cap + n] for a in res)
+        own_n, bad = n, False
+        if rank < world - 1:
+            col = self._columns(t, mm)
+            own_n = int(np.searchsorted(col, col[-1], side="left")) if np.all(np.diff(col) >= 0) else 0
+            bad = own_n == 0 or n - own_n > cap
+        px = py = pt = np.zeros(0, np.int64)
+        if rank > 0 and not bad:
+            pb = g[(rank - 1) * send_bytes:rank * send_bytes]
+            pc = int(hdrs[rank - 1][3])
+            px = pb[32:32 + 2 * cap].view(np.uint16)[:pc]
+            py = pb[32 + 2 * cap:32 + 4 * cap].view(np.uint16)[:pc]
+            pt = pb[32 + 4 * cap:32 + 12 * cap].view(np.int64)[:pc]
+            col = self._columns(pt, mm)
+            j0 = int(np.searchsorted(col, self._columns(np.array([hdrs[rank - 1][1]]), mm)[0], side="left")) if np.all(np.diff(col) >= 0) else 0
+            bad = bad or j0 == 0
+            px, py, pt = px[j0:], py[j0:], pt[j0:]
+        if bad:
+            self._fail = True
+            return
+        x, y, t = np.concatenate((px, x[:own_n])), np.concatenate((py, y[:own_n])), np.concatenate((pt, t[:own_n]))
+        if len(t):
+            if bool(np.any(np.diff(t) < 0)) or bool(t.min() < tmin) or bool(t.max() > tmax):
+                self._fail = True  # (the device's tiles object and the frame is discarded: nothing sensible to compute)
+                return
+            kf = self.O.key_frame(self.tb, x.astype(np.int64), y.astype(np.int64), t, np.int64(tmin), np.int64(tmax), idx_offset=0, tag=1)
+            out[:] = self.O.decode_key_frame(kf.astype(np.uint64), 1).astype(np.uint16).reshape(-1)
+
+    def cols_failed(self):
+        f, self._fail = self._fail, False
+        return f
+
+    def cols_finish(self, frame, want_bgr=True):
+        cells = self.shape[0] * self.shape[1]
+        return self.finish_u16(frame[:2 * cells].view(torch.int16), want_bgr)
+
     def as_tensor(self, a):
         return a
 
@@ -172,3 +249,58 @@ def test_four_ranks_with_uneven_shards_equal_single_process(tmp_path, merge):
         for r in range(4):
             got = np.load(os.path.join(str(tmp_path), f"r{r}_f{frame}.npz"))
             assert np.array_equal(got["depth"], ref["depth"]) and np.array_equal(got["bgr"], ref["bgr"]), (frame, r)
+
+
+def _cols_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from x_maps_amd import synthetic as S
+    from x_maps_amd.sharded import ShardedFrameProcessor, shard_bounds
+    tb = S.make_tables(S.C_TINY)
+    proc = ShardedFrameProcessor(OracleShardProvider(tb, False), dist, merge="columns")
+    flags = []
+    for frame, n, kind in ((0, 6000, "even"), (1, 6000, "lopsided"), (2, 6000, "empty_shard"), (3, 6000, "unsorted")):
+        evs = S.make_events(S.C_TINY, frame=frame, n=n, shuffled=(kind == "unsorted"))
+        x, y, t, _ = S.to_soa(evs)
+        if kind == "even":
+            a, b = shard_bounds(n, rank, world)
+        else:
+            e = {2: [0, n // 7, n], 4: [0, n // 10, n // 10 + (0 if kind == "empty_shard" else 700), (n * 65) // 100, n]}[world]
+            a, b = e[rank], e[rank + 1]
+        res, n_own = proc.columns_resident((x[a:b], y[a:b], t[a:b], None), n)
+        depth, bgr = proc.process_shard_columns(res, n_own)
+        failed = proc.columns_failed()
+        flags.append(failed)
+        if failed:  # what a caller does then: the packed keys for this frame
+            fb = ShardedFrameProcessor(OracleShardProvider(tb, False), dist, merge="all_reduce")
+            depth, bgr = fb.process_shard((x[a:b], y[a:b], t[a:b], None), a)
+        np.savez(os.path.join(out_dir, f"r{rank}_f{frame}.npz"), depth=np.asarray(depth), bgr=np.asarray(bgr), failed=failed)
+    assert proc.collective_bytes_per_frame["u16_frame_sum_all_reduce"] < 8 * tb["rect_w"] * tb["rect_h"] / 3
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_column_shards_equal_single_process(tmp_path, world):
+    """merge="columns": every time column on one rank (each rank but the last hands its last column's events on), the u16 frames
+    merged by SUM.  Even and lopsided shards reproduce the single-process frame; a shard without events (world 4) and a stream
+    that is not sorted raise the flag ON EVERY RANK, and the fallback (packed keys) gives the frame."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_cols_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import xmaps_oracle as O
+    from x_maps_amd import synthetic as S
+    tb = S.make_tables(S.C_TINY)
+    for frame, kind in ((0, "even"), (1, "lopsided"), (2, "empty_shard"), (3, "unsorted")):
+        evs = S.make_events(S.C_TINY, frame=frame, n=6000, shuffled=(kind == "unsorted"))
+        x, y, t, _ = S.to_soa(evs)
+        ref = O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t)
+        for r in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"r{r}_f{frame}.npz"))
+            assert np.array_equal(got["depth"], ref["depth"]) and np.array_equal(got["bgr"], ref["bgr"]), (kind, r)
+            want_fail = kind == "unsorted" or (kind == "empty_shard" and world == 4)
+            assert bool(got["failed"]) == want_fail, (kind, r)

@@ -179,6 +179,10 @@ SYMBOLS = {
     "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
     "xm_ingest_flush": (C.c_int, [_P]),
     "xm_ingest_reset": (C.c_int, [_P]),
+    "xm_shard_cols_info": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "xm_shard_cols_pack": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, C.c_size_t]),
+    "xm_shard_cols_scatter": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _P]),
+    "xm_shard_cols_failed": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "xm_create_sharded": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(xm_config), C.POINTER(_P)]),
     "xm_sharded_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_sharded_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),

@@ -433,6 +433,7 @@ void xm_destroy(xm_handle* h) {
   for (auto& e : h->graph_ev) if (e) (void)hipEventDestroy(e);
   if (h->h_descs) (void)hipHostFree(h->h_descs);
   if (h->d_descs) (void)hipFree(h->d_descs);
+  if (h->d_shard_n) (void)hipFree(h->d_shard_n);
   for (auto gs : h->gstreams) if (gs) (void)hipStreamDestroy(gs);
   for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);

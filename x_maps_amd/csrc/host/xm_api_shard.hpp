@@ -155,4 +155,73 @@ int xm_shard_finish_u16(xm_handle* h, const uint16_t* disp_frame, float* depth_o
 }
 
 
+// ---- shards on the column tiles: every time column processed by one rank, u16 frames merged by SUM (xmaps_k1cols.hpp) ----
+int xm_shard_cols_info(xm_handle* h, uint64_t n_frame_events, size_t* frame_bytes, size_t* reduce_u32, size_t* send_bytes, size_t* cap_events) {
+  if (!h) return fail(XM_ERR_INVALID, "NULL handle");
+  const int W = h->own_mode ? 0 : cols_width(h, n_frame_events);
+  if (!h->cols_ok || h->own_mode || W == 0 || h->cfg.view != XM_VIEW_PROJECTOR || h->k2_direct)
+    return fail(XM_ERR_INVALID, "this rig / frame density does not take the column tiles (injective X-map, projector view, >= 1024 events per tile)");
+  const size_t cells = frame16_cells(h->tb);
+  // room for the events of four mean time columns (a shard's last column), a multiple of 8
+  const size_t cap = ((size_t)(4.0 * (double)n_frame_events / (double)h->tb.xmap_w) + 1024 + 7) & ~(size_t)7;
+  if (frame_bytes) *frame_bytes = cols_frame_bytes(cells, h->tb.xmap_w);
+  if (reduce_u32) *reduce_u32 = (cells + 1) / 2;
+  if (send_bytes) *send_bytes = sizeof(ShardColsHeader) + cap * 12;
+  if (cap_events) *cap_events = cap;
+  return XM_OK;
+}
+
+int xm_shard_cols_pack(xm_handle* h, const uint16_t* x, const uint16_t* y, const int64_t* t, size_t n, void* send_buf_dev, size_t cap_events) {
+  if (!h || !send_buf_dev || (n && (!x || !y || !t))) return fail(XM_ERR_INVALID, "NULL argument");
+  XM_ENTER(h);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(32, (std::min(n, cap_events) + 1023) / 1024));
+  hipLaunchKernelGGL(k_shard_cols_pack, dim3(blocks), dim3(256), 0, h->slots[0].stream, x, y, (const long long*)t, (u64)n,
+                     (unsigned char*)send_buf_dev, (u64)cap_events);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_shard_cols_scatter(xm_handle* h, uint16_t* x, uint16_t* y, int64_t* t, size_t n, uint64_t n_frame_events, const void* gathered_dev,
+                          size_t send_bytes, int rank, int world, size_t cap_events, uint16_t* frame16) {
+  if (!h || !gathered_dev || !frame16 || !x || !y || !t) return fail(XM_ERR_INVALID, "NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(XM_ERR_INVALID, "bad rank / world");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)t) & 15) return fail(XM_ERR_INVALID, "x / y / t must be 16-byte aligned");
+  XM_ENTER(h);
+  const int W = cols_width(h, n_frame_events);
+  if (!h->cols_ok || h->own_mode || W == 0) return fail(XM_ERR_INVALID, "this rig / frame density does not take the column tiles");
+  if (!h->d_shard_n) HIP_TRY(hipMalloc((void**)&h->d_shard_n, 64 + sizeof(FrameDesc)));
+  hipStream_t s = h->slots[0].stream;
+  long long* mm = reinterpret_cast<long long*>(h->d_shard_n);  // {tmin, -tmax} of the frame
+  FrameDesc* desc = reinterpret_cast<FrameDesc*>(reinterpret_cast<unsigned char*>(h->d_shard_n) + 64);
+  hipLaunchKernelGGL(k_shard_cols_prepare, dim3(1), dim3(256), 0, s, x, y, (long long*)t, (u64)n, (const unsigned char*)gathered_dev,
+                     (u64)send_bytes, rank, world, h->tb, (u64)cap_events, mm, frame16, h->aux_st, desc);
+  const int flags = h->cols_flags | COLS_F_EXT_EXTREMA;
+  hipLaunchKernelGGL(k_cols_bounds_batch<false>, dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, COLS_BOUNDS_PER_BLOCK), 1), dim3(256), 0, s,
+                     (const FrameDesc*)desc, h->tb, W, flags);
+  auto kern = k_scatter_cols_batch<false, true>;  // (the piece starts 8-aligned: 16-byte event loads)
+  const size_t lds = cols_lds_bytes(h, W);
+  int rc;
+  if ((rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds))) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid_for(h->tb.xmap_w, W), 1), dim3(cols_threads(h, n_frame_events, W)), lds, s, (const FrameDesc*)desc, h->tb, W,
+                     h->w_x, h->cols_xr_min, flags);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// did any piece of the frames since the last call object (see xmaps_k1cols.hpp)?  Synchronises the handle's stream.
+int xm_shard_cols_failed(xm_handle* h, int* failed) {
+  if (!h || !failed) return fail(XM_ERR_INVALID, "NULL argument");
+  XM_ENTER(h);
+  hipStream_t s = h->slots[0].stream;
+  u32 v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, &h->aux_st->unsorted_sticky, sizeof v, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *failed = v ? 1 : 0;
+  if (v) {
+    HIP_TRY(hipMemsetAsync(&h->aux_st->unsorted_sticky, 0, sizeof(u32), s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return XM_OK;
+}
+
 }  // extern "C"

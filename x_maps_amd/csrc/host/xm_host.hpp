@@ -163,6 +163,7 @@ struct xm_handle {
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
   SlotState* aux_st = nullptr;
+  u64* d_shard_n = nullptr;  // shards on the column tiles: the piece's own event count (device) + its FrameDesc behind it
   std::vector<Slot> slots;
   int next_slot = 0;
   int last_slot = 0;

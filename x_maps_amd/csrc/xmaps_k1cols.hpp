@@ -58,7 +58,10 @@ typedef XM_GLOBAL SlotState* gp_state;
 #endif
 
 constexpr int COLS_EPT = 8;          // events per thread and pass
-enum { COLS_F_DEVICE_REDO = 1, COLS_F_ALL_IN_FRAME = 2 };
+enum { COLS_F_DEVICE_REDO = 1, COLS_F_ALL_IN_FRAME = 2, COLS_F_EXT_EXTREMA = 4 };
+// COLS_F_EXT_EXTREMA (shards: a contiguous piece of a frame's sorted stream): the FRAME's extrema come from a 16-byte device buffer
+// {tmin, -tmax} (FrameDesc.p carries its address; the path has no polarity column) instead of the piece's first / last stamp, and a
+// piece without events still writes its zeros
 constexpr u32 COLS_MAX_TILE_EVENTS = 65535u - 8u;  // the slot value carries (local index + 1) in 16 bits
 
 // ---- xm_create: is cell(row, column) injective over the live pairs?  One block per rectified row. -----------------------
@@ -215,7 +218,8 @@ __host__ __device__ inline size_t cols_frame_bytes(size_t key_cells, int xmap_w)
 
 template <bool AOS>
 __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos, const int n, const DevTables& tb, const int W,
-                                                 XM_GLOBAL unsigned char* frame_base, const u32 blk) {
+                                                 XM_GLOBAL unsigned char* frame_base, const u32 blk, gp_i64 ext_mm = nullptr,
+                                                 const int first = 0) {  // first: events [0, first) are filler (shards: alignment)
   typedef long long T;
   const size_t key_cells = frame16_cells(tb);
   XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
@@ -228,7 +232,10 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   if (!__any(live)) return;       // wave-uniform
   const int j = min(j_raw, nb);
   T t_first, t_last;
-  if constexpr (AOS) {
+  if (ext_mm) {  // the frame's extrema as the shards agreed on them ({tmin, -tmax})
+    t_first = ext_mm[0];
+    t_last = -ext_mm[1];
+  } else if constexpr (AOS) {
     const uint4 a = aos[0], b = aos[n - 1];
     t_first = (T)(((u64)a.w << 32) | a.z);
     t_last = (T)(((u64)b.w << 32) | b.z);
@@ -241,7 +248,7 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   // depend on anything loaded.  A wave of this kernel is a chain of dependent round trips at loaded-memory latency (its
   // arithmetic hides behind them): stamps -> probes -> probes -> x was four of them, now it is two.
   const int c = min(j * W, tb.xmap_w);
-  const bool search = live && c > 0 && c < tb.xmap_w;  // else: boundary 0 is event 0, the last tile takes whatever is left
+  const bool search = live && c > 0 && c < tb.xmap_w && n > 0;  // else: boundary 0 is event 0, the last tile takes whatever is left
   int q[FIN];
   bool act[FIN], pr[FIN];
   T tv[FIN];
@@ -272,7 +279,7 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   }
   A = __shfl(A, gl, 64);
   int lo = -1, hi = n;
-  if (c <= 0 || !live) hi = 0;
+  if (c <= 0 || !live || n == 0) hi = 0;
   else if (c >= tb.xmap_w) lo = n - 1;
   if (hi - lo > 1) {  // == search
     act[0] = true;
@@ -311,15 +318,15 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
     }
     cols_narrow(q, act, pr, gl, lo, hi);
   }
-  const int lb = hi;
+  const int lb = max(hi, first);
   // median x of the three events at / behind the boundary and of the three in front of it: from the last round's probes where
   // they cover them, else loaded now
-  const int i = sl < 3 ? min(lb + sl, n - 1) : max(lb - 1 - (sl - 3), 0);
+  const int i = max(sl < 3 ? min(lb + sl, n - 1) : max(lb - 1 - (sl - 3), 0), 0);
   const int src = i - x_base;
   const bool from_probe = x_base >= 0 && src >= 0 && src < x_cnt;
   const u64 got = __shfl(x4, gl + ((src >> 2) & (G - 1)), 64);
   int xv = (int)((got >> (16 * (src & 3))) & 0xffffull);
-  if (sl < 6 && live && !from_probe) xv = cols_x_at<AOS>(xs, aos, i);
+  if (sl < 6 && live && !from_probe && n > 0) xv = cols_x_at<AOS>(xs, aos, i);
   const int a0 = __shfl(xv, gl + 0, 64), a1 = __shfl(xv, gl + 1, 64), a2 = __shfl(xv, gl + 2, 64);
   const int e0 = __shfl(xv, gl + 3, 64), e1 = __shfl(xv, gl + 4, 64), e2 = __shfl(xv, gl + 5, 64);
   if (sl == 0 && live)
@@ -334,10 +341,12 @@ __global__ __launch_bounds__(256) void k_cols_bounds(const uint16_t* __restrict_
 }
 
 template <bool AOS>
-__global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W) {
+__global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W, int flags = 0) {
   const FrameDesc d = descs[blockIdx.y];
-  if (!d.valid || d.n == 0) return;
-  cols_bounds_body<AOS>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x);
+  const bool ext = flags & COLS_F_EXT_EXTREMA;
+  if (!d.valid || (d.n == 0 && !ext)) return;
+  cols_bounds_body<AOS>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x,
+                        ext ? (gp_i64)d.p : nullptr, ext ? (int)d.pad : 0);
 }
 
 // ---- the kernel body ---------------------------------------------------------------------------------------------------------
@@ -346,7 +355,8 @@ __global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __re
 template <bool AOS, bool VEC>
 __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 ts, gp_u4 aos, const u32 n_ev, const DevTables& tb,
                                                   gp_state st, XM_GLOBAL uint16_t* frame16, const int W, const int w_x,
-                                                  const int xr_min, const u32 blk, const u32 nblk, const int flags = 0) {
+                                                  const int xr_min, const u32 blk, const u32 nblk, const int flags = 0,
+                                                  gp_i64 ext_mm = nullptr) {
   // flags: COLS_F_DEVICE_REDO = inside a hipGraph (a failing tile leaves the frame's tag in SlotState.pad[1] for the redo kernels
   // behind this one instead of telling the host); COLS_F_ALL_IN_FRAME = every live (row, column) pair of this rig has its cell
   // inside the frame (xm_create), so an event that passes xmd:29 cannot be an IndexError: no per-event cell test
@@ -393,7 +403,10 @@ __device__ __forceinline__ void scatter_cols_body(gp_u16 xs, gp_u16 ys, gp_i64 t
 #pragma unroll
   for (int i = 0; i < A_PRE; ++i) A_in[i] = thr[c0 + min(1 + i, Wc)];
   T t_first, t_last;
-  if constexpr (AOS) {
+  if (ext_mm) {
+    t_first = ext_mm[0];
+    t_last = -ext_mm[1];
+  } else if constexpr (AOS) {
     const uint4 a = aos[0], b = aos[n - 1];
     t_first = (T)(((u64)a.w << 32) | a.z);
     t_last = (T)(((u64)b.w << 32) | b.z);
@@ -747,9 +760,192 @@ __global__ __launch_bounds__(COLS_MAX_THREADS, XM_COLS_WAVES_PER_EU) void k_scat
                                                                                                 DevTables tb, int W, int w_x,
                                                                                                 int xr_min, int flags) {
   const FrameDesc d = descs[blockIdx.y];  // block-uniform: scalar loads
-  if (!d.valid || d.n == 0) return;       // (the host sends frames without events down the general path)
+  const bool ext = flags & COLS_F_EXT_EXTREMA;
+  if (!d.valid || (d.n == 0 && !ext)) return;  // (the host sends frames without events down the general path)
   scatter_cols_body<AOS, VEC>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
-                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x, flags);
+                              (XM_GLOBAL uint16_t*)d.key_frame, W, w_x, xr_min, blockIdx.x, gridDim.x, flags,
+                              ext ? (gp_i64)d.p : nullptr);
+}
+
+// ---- shards on the column tiles (SURVEY.md 8(e) / BASELINE configs[3]) --------------------------------------------------------
+// A shard = a contiguous index range of the frame's time-sorted stream = whole time columns, except that its LAST column may go on
+// in the next shard.  Every cell of the u16 frame has one (row, column) pair (injective rigs), so once every column is processed
+// by ONE rank the ranks' frames are disjoint and merge by a plain SUM -- 2 bytes per cell on the wire, no packed keys, no
+// atomics, no extrema pass.  To get there each rank (but the last) leaves the events of its last column to its successor:
+//   k_shard_cols_pack     send buffer <- {t[0], t[m-1], m | the shard's last min(m, cap) events}  (nothing depends on other ranks)
+//   (ONE all-gather of the send buffers: it carries the frame's extrema and every predecessor's last events)
+//   k_shard_cols_prepare  the frame's extrema from the headers (under the sorted assumption that K1 verifies per event); the
+//                         first event of the own last column (256-ary search) = where the own part ends; the events of the
+//                         PREDECESSOR's last column out of its buffer into the headroom in front of the own events (padded to
+//                         an 8-aligned start with copies of the first event: the 16-byte loads of K1); the piece's FrameDesc
+//   k_cols_bounds_batch / k_scatter_cols_batch with COLS_F_EXT_EXTREMA on that piece (tiles of columns the piece does not hold
+//   write their zeros), then the SUM all-reduce and K2.
+// A piece that cannot be handled this way (a shard without events or inside ONE column, a last column of more than cap events, a
+// frame of >= 2^32 us, events out of order) raises the slot's sticky flag: the caller redoes the frame with the packed keys.
+struct ShardColsHeader {
+  long long t_first, t_last;
+  long long m;       // events of the shard
+  long long count;   // events in the buffer: the shard's last min(m, cap)
+};
+static_assert(sizeof(ShardColsHeader) == 32, "ShardColsHeader layout");
+
+__global__ __launch_bounds__(256) void k_shard_cols_pack(const uint16_t* __restrict__ x, const uint16_t* __restrict__ y,
+                                                         const long long* __restrict__ t, u64 m, unsigned char* __restrict__ send, u64 cap) {
+  ShardColsHeader* hdr = reinterpret_cast<ShardColsHeader*>(send);
+  uint16_t* sx = reinterpret_cast<uint16_t*>(send + sizeof(ShardColsHeader));
+  uint16_t* sy = sx + cap;
+  long long* stt = reinterpret_cast<long long*>(sy + cap);
+  const u64 cnt = m < cap ? m : cap, from = m - cnt;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    hdr->t_first = m ? t[0] : 0;
+    hdr->t_last = m ? t[m - 1] : 0;
+    hdr->m = (long long)m;
+    hdr->count = (long long)cnt;
+  }
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (u64)gridDim.x * 256) {
+    sx[i] = x[from + i];
+    sy[i] = y[from + i];
+    stt[i] = t[from + i];
+  }
+}
+
+// first index in [0, n) with (u64)(t[i] - tmin) >= A, n if none: 256-ary search by one block (every thread calls it; a stream that
+// is not sorted gets some deterministic answer and K1 objects)
+__device__ inline u64 shard_lower_bound(const long long* __restrict__ t, u64 n, long long tmin, u32 A, u64* s_rng, int* s_first) {
+  const int tid = threadIdx.x;
+  if (n == 0) return 0;
+  if (tid == 0) {
+    s_rng[0] = 0;  // the answer lies in [lo, hi]; hi == n means "none so far"
+    s_rng[1] = n;
+  }
+  __syncthreads();
+  for (int round = 0; round < 9; ++round) {
+    const u64 lo = s_rng[0], hi = s_rng[1];
+    __syncthreads();
+    if (hi <= lo) break;
+    const u64 width = hi - lo, stride = (width + 255) / 256;
+    const u64 q = lo + (u64)tid * stride;
+    const bool ge = q < hi && (u64)(t[q] - tmin) >= (u64)A;
+    const u64 bal = __ballot(ge);
+    if ((tid & 63) == 0) s_first[tid >> 6] = bal ? (tid & ~63) + (int)__builtin_ctzll(bal) : -1;
+    __syncthreads();
+    if (tid == 0) {
+      int f = -1;
+      for (int w = 0; w < 4 && f < 0; ++w) f = s_first[w];
+      if (f < 0) {  // every probe lies in front of the boundary
+        s_rng[0] = lo + ((width - 1) / stride) * stride + 1;
+      } else {
+        const u64 qf = lo + (u64)f * stride;
+        s_rng[1] = qf;
+        if (f > 0) s_rng[0] = qf - stride + 1;
+      }
+    }
+    __syncthreads();
+  }
+  return s_rng[1];
+}
+
+// x / y / t point at the shard's own m events and have >= cap + 8 events of writable headroom in front of them (and 8 behind)
+__global__ __launch_bounds__(256) void k_shard_cols_prepare(uint16_t* x, uint16_t* y, long long* t, u64 m,
+                                                            const unsigned char* __restrict__ gathered, u64 send_bytes, int rank, int world,
+                                                            DevTables tb, u64 cap, long long* mm, uint16_t* frame16, SlotState* st,
+                                                            FrameDesc* desc) {
+  __shared__ u64 s_rng[2];
+  __shared__ int s_first[4];
+  __shared__ long long s_mm[2];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  // the slot's bookkeeping starts over with every frame (what k_reset_slot does; the sticky flag stays)
+  if (tid == 0) {
+    st->tag_a = 0;
+    st->tag_b = 0;
+    st->pad[1] = 0;
+    long long lo = 0x7fffffffffffffffll, hi = (long long)0x8000000000000000ull;
+    int fail = 0;
+    for (int r = 0; r < world; ++r) {
+      const ShardColsHeader* h = reinterpret_cast<const ShardColsHeader*>(gathered + (u64)r * send_bytes);
+      if (h->m <= 0) {
+        fail = 1;  // a shard without events breaks the chain of columns
+        continue;
+      }
+      lo = h->t_first < lo ? h->t_first : lo;
+      hi = h->t_last > hi ? h->t_last : hi;
+    }
+    if (hi < lo) {
+      lo = hi = 0;
+      fail = 1;
+    }
+    if ((u64)(hi - lo) >= 0xffffffffull) fail = 1;
+    s_mm[0] = lo;
+    s_mm[1] = hi;
+    s_fail = fail;
+    mm[0] = lo;
+    mm[1] = -hi;
+  }
+  for (int i = tid; i < 2 * MM_SLOTS; i += 256) {
+    st->mm[i / MM_SLOTS][i % MM_SLOTS][0] = MM_INIT_MIN;
+    st->mm[i / MM_SLOTS][i % MM_SLOTS][1] = MM_INIT_MAX;
+  }
+  for (int i = tid; i < 2 * CNT_SLOTS * CNT_STRIDE; i += 256) (&st->cnt[0][0][0])[i] = 0;
+  __syncthreads();
+  const long long tmin = s_mm[0], tmax = s_mm[1];
+  bool fail = s_fail != 0;
+  u64 own_n = m, cnt = 0, j0 = 0;
+  const ShardColsHeader* ph = rank > 0 ? reinterpret_cast<const ShardColsHeader*>(gathered + (u64)(rank - 1) * send_bytes) : nullptr;
+  if (!fail) {
+    const TimeNorm<long long> tn(tmin, tmax, tb.t_px_scale);
+    const u32 span = (u32)(tmax - tmin);
+    if (rank < world - 1) {  // the own last column goes to the successor
+      const u32 A = cols_threshold(tn, tmin, span, tn.column(t[m - 1]), tb.t_px_scale);
+      own_n = shard_lower_bound(t, m, tmin, A, s_rng, s_first);
+      if (own_n == 0 || m - own_n > cap) fail = true;  // the whole shard lies in one column / its last column does not fit the buffer
+    }
+    if (ph) {  // the predecessor's last column: a suffix of its buffer
+      const u64 pc = (u64)ph->count;
+      const long long* pt = reinterpret_cast<const long long*>(reinterpret_cast<const unsigned char*>(ph) + sizeof(ShardColsHeader) + 4 * cap);
+      const u32 A = cols_threshold(tn, tmin, span, tn.column(ph->t_last), tb.t_px_scale);
+      __syncthreads();
+      j0 = shard_lower_bound(pt, pc, tmin, A, s_rng, s_first);
+      if (j0 == 0) fail = true;  // (its last column may start in front of what the buffer holds)
+      cnt = pc - j0;
+    }
+  }
+  if (fail) {
+    own_n = m;
+    cnt = 0;
+  }
+  // the piece: [pad: copies of its first event, up to an 8-aligned start | the predecessor's last column | the own part]
+  const u64 pad = (8 - (cnt & 7)) & 7;  // (the own events start 8-aligned: cap is a multiple of 8 and so is the headroom)
+  if (ph && cnt) {
+    const uint16_t* px = reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(ph) + sizeof(ShardColsHeader));
+    const uint16_t* py = px + cap;
+    const long long* pt = reinterpret_cast<const long long*>(py + cap);
+    for (u64 i = tid; i < cnt; i += 256) {
+      x[(long long)i - (long long)cnt] = px[j0 + i];
+      y[(long long)i - (long long)cnt] = py[j0 + i];
+      t[(long long)i - (long long)cnt] = pt[j0 + i];
+    }
+    if ((u64)tid < pad) {
+      x[-(long long)(cnt + pad) + tid] = px[j0];
+      y[-(long long)(cnt + pad) + tid] = py[j0];
+      t[-(long long)(cnt + pad) + tid] = pt[j0];
+    }
+  }
+  if (tid == 0) {
+    if (fail) atomicAdd(&st->unsorted_sticky, 1u);
+    desc->x = x - (cnt + pad);
+    desc->y = y - (cnt + pad);
+    desc->t = t - (cnt + pad);
+    desc->p = reinterpret_cast<const int16_t*>(mm);  // COLS_F_EXT_EXTREMA: the frame's {tmin, -tmax}
+    desc->aos = nullptr;
+    desc->n = pad + cnt + own_n;
+    desc->key_frame = reinterpret_cast<u64*>(frame16);
+    desc->st = st;
+    desc->depth = nullptr;
+    desc->bgr = nullptr;
+    desc->valid = 1;
+    desc->pad = (u32)pad;  // events [0, pad) of the piece are filler: the first tile starts behind them
+  }
 }
 
 }  // namespace xm

@@ -519,6 +519,28 @@ class XMapsEngine:
     def shard_finish_u16(self, disp_ptr, depth_ptr=None, bgr_ptr=None):
         N.check(self._lib.xm_shard_finish_u16(self._h, _ptr(disp_ptr), _ptr(depth_ptr), _ptr(bgr_ptr)))
 
+    # ---- shards on the column tiles (include/xmaps.h: xm_shard_cols_*) ----
+    def shard_cols_info(self, n_frame_events):
+        """{frame_bytes, reduce_u32, send_bytes, cap_events} for frames of that many events, or None when the rig / the density
+        does not take the column tiles"""
+        fb, ru, sb, ce = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = self._lib.xm_shard_cols_info(self._h, int(n_frame_events), C.byref(fb), C.byref(ru), C.byref(sb), C.byref(ce))
+        if rc != 0:
+            return None
+        return {"frame_bytes": int(fb.value), "reduce_u32": int(ru.value), "send_bytes": int(sb.value), "cap_events": int(ce.value)}
+
+    def shard_cols_pack(self, x_ptr, y_ptr, t_ptr, n, send_ptr, cap_events):
+        N.check(self._lib.xm_shard_cols_pack(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), int(n), _ptr(send_ptr), int(cap_events)))
+
+    def shard_cols_scatter(self, x_ptr, y_ptr, t_ptr, n, n_frame_events, gathered_ptr, send_bytes, rank, world, cap_events, frame16_ptr):
+        N.check(self._lib.xm_shard_cols_scatter(self._h, _ptr(x_ptr), _ptr(y_ptr), _ptr(t_ptr), int(n), int(n_frame_events),
+                                                _ptr(gathered_ptr), int(send_bytes), int(rank), int(world), int(cap_events), _ptr(frame16_ptr)))
+
+    def shard_cols_failed(self) -> bool:
+        v = C.c_int(0)
+        N.check(self._lib.xm_shard_cols_failed(self._h, C.byref(v)))
+        return bool(v.value)
+
     # ---- pinned host memory + asynchronous host path ---------------------------------------------------------
     def host_empty(self, shape, dtype) -> np.ndarray:
         """NumPy array backed by pinned host memory (freed with the engine).  For process_frame_pinned."""

@@ -126,6 +126,48 @@ class GpuShardProvider:
         self.eng.shard_finish(key_frame.data_ptr(), tag, depth.data_ptr(), None if bgr is None else bgr.data_ptr())
         return depth, bgr
 
+    # ---- merge = "columns": every time column on one rank, plain u16 frames merged by SUM (xm_shard_cols_*) ----
+    def cols_setup(self, n_frame_events):
+        """buffers for frames of that many events, or None when this rig / density does not take the column tiles"""
+        info = self.eng.shard_cols_info(n_frame_events)
+        if info is None:
+            return None
+        torch = self.torch
+        info["frame"] = self._zeros(info["frame_bytes"], torch.uint8)
+        info["send"] = self._zeros(info["send_bytes"], torch.uint8)
+        return info
+
+    def cols_resident(self, shard, cap_events):
+        """the shard's columns once more with `cap_events` of headroom in front (the predecessor's last column goes there): the
+        layout a host that keeps its shards resident allocates in the first place"""
+        torch = self.torch
+        x, y, t, p = shard
+        assert p is None and t.dtype == torch.int64
+        out = []
+        for a in (x, y, t):  # [cap + 8 of headroom | the own events | 8 of slack for the last 16-byte load]
+            buf = torch.zeros(cap_events + 8 + len(a) + 8, dtype=a.dtype, device=self.device)
+            buf[cap_events + 8:cap_events + 8 + len(a)].copy_(a)
+            out.append(buf)
+        torch.cuda.current_stream(self.device).synchronize()
+        return tuple(out)
+
+    @staticmethod
+    def _own(buf, cap):
+        return buf.data_ptr() + (cap + 8) * buf.element_size()  # the first own event (an empty slice has no data_ptr)
+
+    def cols_pack(self, res, n, cap, send):
+        self.eng.shard_cols_pack(self._own(res[0], cap), self._own(res[1], cap), self._own(res[2], cap), n, send.data_ptr(), cap)
+
+    def cols_scatter(self, res, n, cap, n_frame, gathered, send_bytes, rank, world, frame):
+        self.eng.shard_cols_scatter(self._own(res[0], cap), self._own(res[1], cap), self._own(res[2], cap), n, n_frame, gathered.data_ptr(),
+                                    send_bytes, rank, world, cap, frame.data_ptr())
+
+    def cols_failed(self):
+        return self.eng.shard_cols_failed()
+
+    def cols_finish(self, frame, want_bgr=True):
+        return self.finish_u16(frame, want_bgr)
+
     def as_tensor(self, a):
         return a
 
@@ -148,13 +190,24 @@ class ShardedFrameProcessor:
         partial projector frames are MAX-all-reduced (K2 sharded as well; what crosses the links after the
         reduce-scatter is 2 halos + the projector frame instead of the whole disparity frame).  Projector view; falls back to
         "reduce_scatter" when a band is narrower than the halo."""
-        assert merge in ("all_reduce", "reduce_scatter", "bands")
+        assert merge in ("all_reduce", "reduce_scatter", "bands", "columns")
         self.p = provider
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.merge = merge
+        self.cols = None  # merge == "columns": set up by process_shard_columns for the frame size at hand
+        if merge == "columns":
+            merge = self.merge = "columns"
+            self.key_frame = None
+            self.always_reduce = always_reduce
+            self.mm = None
+            self._mm_for = None
+            self.tag = 0
+            self.collectives_issued = 0
+            self.collective_bytes_per_frame = None
+            return
         self.key_frame = provider.new_key_frame(self.world) if merge != "all_reduce" else provider.new_key_frame()
         if merge != "all_reduce":
             chunk = self.key_frame.numel() // self.world
@@ -210,6 +263,54 @@ class ShardedFrameProcessor:
             if finish_on_all_ranks or self.rank == 0:
                 return self.p.finish(self.key_frame, tag, want_bgr)
         return None, None
+
+    # ---- merge = "columns" ----------------------------------------------------------------------------------------------
+    def columns_resident(self, shard, n_frame_events):
+        """Prepare THIS rank's shard for merge="columns": (resident, n_own) to hand to process_shard_columns, or None when the rig /
+        the frame density does not take the column tiles (use another merge).  The resident copy has headroom in front of the
+        events for the predecessor's last column -- the layout a host that keeps its shards in HBM allocates in the first place."""
+        if self.cols is None or self.cols.get("n_frame") != n_frame_events:
+            info = self.p.cols_setup(n_frame_events)
+            if info is None:
+                return None
+            info["n_frame"] = n_frame_events
+            info["gathered"] = info["send"].new_zeros(info["send_bytes"] * self.world)
+            self.cols = info
+            # what crosses the links per frame and rank: the gathered headers + last events, the u16 frame
+            self.collective_bytes_per_frame = {"last_events_all_gather": info["send_bytes"] * self.world,
+                                               "u16_frame_sum_all_reduce": info["reduce_u32"] * 4}
+        return self.p.cols_resident(shard, self.cols["cap_events"]), len(shard[2])
+
+    def process_shard_columns(self, resident, n_own, want_bgr=True, finish_on_all_ranks=True):
+        """One frame, this rank's shard as columns_resident() returned it.  Every time column ends up on one rank (each rank but
+        the last hands its last column's events to its successor), the plain u16 frames are disjoint and merge by SUM: 2 bytes
+        per cell on the wire, no packed keys, no atomics, no extrema pass.  Asynchronous; columns_failed() (a synchronisation +
+        a one-word all-reduce) tells whether any frame since the last check has to be redone with the packed keys."""
+        import contextlib
+        import torch
+        c = self.cols
+        ctx = self.p.collective_stream() if hasattr(self.p, "collective_stream") else contextlib.nullcontext()
+        with ctx:
+            self.p.cols_pack(resident, n_own, c["cap_events"], c["send"])
+            self._all_gather(c["gathered"], c["send"])  # the frame's extrema and every predecessor's last events in ONE collective
+            self.p.cols_scatter(resident, n_own, c["cap_events"], c["n_frame"], c["gathered"], c["send_bytes"], self.rank, self.world, c["frame"])
+            if "red" not in c:  # (the view is built once: per frame it is a few microseconds of host time, and this loop is host-bound)
+                c["red"] = self.p.as_tensor(c["frame"])[:c["reduce_u32"] * 4].view(torch.int32)
+            self._all_reduce(c["red"], self.dist.ReduceOp.SUM)  # (disjoint cells: SUM of the packed pairs = the union)
+            if finish_on_all_ranks or self.rank == 0:
+                return self.p.cols_finish(c["frame"], want_bgr)
+        return None, None
+
+    def columns_failed(self):
+        """did any rank object to any frame since the last call?  (synchronises; the frames in question are redone with another merge)"""
+        import torch
+        f = torch.tensor([1 if self.p.cols_failed() else 0], dtype=torch.int32)
+        dev = getattr(self.p, "device", None)
+        if dev is not None:
+            f = f.to(dev)
+        if self.world > 1 or self.always_reduce:
+            self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX, group=self.group)
+        return bool(int(f.item()))
 
     # ---- merge = "bands" ------------------------------------------------------------------------------------------------
     def _frame_geometry(self):
