@@ -1590,13 +1590,13 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         return None
     kshape = eng.key_shape
     roofline, alg, pt = roofline_dict(np.array(k_ms + [elapsed / steps * 1e3]), None, b - a, 1, tables, camera, 0 if args.no_bgr else 3,
-                                      ("camera" if camera else "projector") + "_sharded",
+                                      ("camera" if camera else "projector") + ("_sharded" if merge == "columns" else "_sharded_keys"),
                                       "torch.cuda.Event pairs recorded on the engine's stream (torch's current stream inside "
                                       "process_shard) around the shard's three kernel launches, 20 frames, median; k_minmax = the "
                                       "shard's extrema pass K0; k_scatter processes THIS rank's events (events_per_rank); k_frame "
                                       "runs on the merged key frame on every rank; merge = columns: k_minmax = the pack of the shard's last events, "
                                       "k_scatter = prepare (extrema, own / predecessor's last column) + boundary pass + column-tile K1", cell_bytes=8 if merge == "all_reduce" else 2)
-    pipeline_fractions(roofline, alg, pt, ("camera" if camera else "projector") + "_sharded", value, 1, elapsed / steps, 1)
+    pipeline_fractions(roofline, alg, pt, ("camera" if camera else "projector") + ("_sharded" if merge == "columns" else "_sharded_keys"), value, 1, elapsed / steps, 1)
     roofline["event_stream_read_roofline_frac_note"] = "whole frame (all ranks' events) per step time against ONE GPU's HBM read peak"
     cpu = None
     if not args.no_cpu_baseline and world == 1:
