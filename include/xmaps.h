@@ -490,6 +490,10 @@ int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n);
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
 int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */
 int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events */
+/* the device's counters once everything pushed so far has run (synchronises like xm_ingest_flush): frames cut, events appended
+ * behind the filters, events dropped because the ring had no room (also the `overflow` of every frame), events still buffered.
+ * Any pointer may be NULL. */
+int xm_ingest_device_stats(xm_ingest* g, uint64_t* frames_cut, uint64_t* events_appended, uint64_t* events_dropped, uint64_t* events_live);
 /* what the calling thread has paid so far: number of xm_ingest_push* calls, seconds spent inside them, how often a push had to
  * wait for a staging entry (the GPU more than 16 packets behind) and the seconds spent waiting (part of host_seconds_in_push).
  * Any pointer may be NULL. */

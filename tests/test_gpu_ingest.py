@@ -283,7 +283,9 @@ def test_a_ring_without_room_drops_its_live_part_and_says_so():
             ing.push(p)
         ing.flush()
         got = ing.poll()
+        ds = ing.device_stats()
     assert len(got) >= 2 and all(f.overflow == 16_000 and not f.lost for f in got)
+    assert ds["events_dropped"] == 16_000 and ds["frames_cut"] == len(got) and ds["events_appended"] > 0
     x, y, t, _ = S.to_soa(IO.polarity_filter(tail))
     for f in got:  # every frame is a contiguous piece of the tail stream's positive events, processed like any other
         a = int(np.searchsorted(t, f.t_first))

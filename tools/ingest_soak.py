@@ -83,11 +83,12 @@ with XMapsEngine(tb) as eng:
                     got += ing.poll()
             ing.flush()
             got += ing.poll()
+            dstat = ing.device_stats()
             if dec is not None:
                 dec.close()
         desc = dict(seed=seed, frames=n_frames, packets=len(pk), mode=mode, activity=activity, thread=thread, words=words, pinned=pinned,
                     poll_each=poll_each, cap=cap, max_pk=max_pk)
-        overflow = max([f.overflow for f in got] + [0])
+        overflow = max([f.overflow for f in got] + [dstat["events_dropped"]])
         if overflow or any(f.lost for f in got):
             if cap >= 16 * max_pk and not any(f.lost for f in got):
                 bad.append(("overflow on a roomy ring", desc))

@@ -662,6 +662,20 @@ int xm_ingest_reset(xm_ingest* g) {
   return XM_OK;
 }
 
+// the device's counters after everything pushed so far has run (synchronises like xm_ingest_flush)
+int xm_ingest_device_stats(xm_ingest* g, uint64_t* frames_cut, uint64_t* events_appended, uint64_t* events_dropped, uint64_t* events_live) {
+  if (!g) return fail(XM_ERR_INVALID, "NULL argument");
+  int rc = xm_ingest_flush(g);
+  if (rc) return rc;
+  IngestState z;
+  HIP_TRY(hipMemcpy(&z, g->dev.st, sizeof z, hipMemcpyDeviceToHost));
+  if (frames_cut) *frames_cut = z.frames;
+  if (events_appended) *events_appended = z.appended;
+  if (events_dropped) *events_dropped = z.overflow;
+  if (events_live) *events_live = z.write_abs - z.start_abs;
+  return XM_OK;
+}
+
 int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits, double* seconds_waiting) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   if (pushes) *pushes = g->push_calls;

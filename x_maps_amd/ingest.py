@@ -156,6 +156,14 @@ class DeviceIngest:
                                    int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), bool(fr.lost), depth, bgr))
         return out
 
+    def device_stats(self) -> dict:
+        """The device's counters once everything pushed so far has run (synchronises): frames cut, events appended behind the
+        filters, events dropped because the ring had no room, events still buffered."""
+        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        N.check(self._lib.xm_ingest_device_stats(self._g, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self._pushes_unsynced = 0
+        return {"frames_cut": int(a.value), "events_appended": int(b.value), "events_dropped": int(c.value), "events_live": int(d.value)}
+
     def host_stats(self) -> dict:
         """What the calling thread has paid inside push() so far (xm_ingest_host_stats)."""
         n, sec, waits, wsec = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0), C.c_double(0.0)
