@@ -650,7 +650,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     if (world > 1 or os.environ.get("XM_BENCH_FORCE_SHARDED_LEG") == "1") and dist is not None and not args.no_other_modes:
         import copy  # (XM_BENCH_FORCE_SHARDED_LEG + XM_BENCH_FORCE_DIST: the tests exercise this leg on a one-GPU box)
         a2 = copy.copy(args)
-        a2.steps, a2.no_cpu_baseline, a2.single_block = 40, True, False
+        a2.steps, a2.no_cpu_baseline, a2.single_block, a2.as_leg = 40, True, False, True
         try:
             sharded_leg = bench_sharded(a2, torch, dist, dev, rank, local_rank, world)
         except Exception as e:  # never lose the replicas' line to the extra leg
@@ -1488,17 +1488,71 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     merge = args.merge
     if merge == "columns" and (camera or eng.shard_cols_info(n_ev) is None):
         merge = "all_reduce"  # (camera view / rigs whose X-map is not injective: the packed keys)
-    proc = ShardedFrameProcessor(prov, dist, always_reduce=True, merge=merge)  # world 1: the collectives are issued all the same
-    resident = None
-    if merge == "columns":  # the shards as a host keeps them resident for this path: headroom in front for the predecessor's last column
-        resident = [proc.columns_resident(sh, n_ev) for sh in shards]
+    state = {}
+
+    def make(merge):
+        proc = ShardedFrameProcessor(prov, dist, always_reduce=True, merge=merge)  # world 1: the collectives are issued all the same
+        # the shards as a host keeps them resident for the columns path: headroom in front for the predecessor's last column
+        resident = [proc.columns_resident(sh, n_ev) for sh in shards] if merge == "columns" else None
+        state.update(proc=proc, resident=resident, merge=merge)
+
+    make(merge)
 
     def process(i, want_bgr):
-        if merge == "columns":
-            return proc.process_shard_columns(*resident[i % nf], want_bgr=want_bgr)
-        return proc.process_shard(shards[i % nf], a, want_bgr=want_bgr)
+        if state["merge"] == "columns":
+            return state["proc"].process_shard_columns(*state["resident"][i % nf], want_bgr=want_bgr)
+        return state["proc"].process_shard(shards[i % nf], a, want_bgr=want_bgr)
 
-    # collective time: torch events on the engine's stream around the two all-reduces
+    def sync():
+        eng.sync()
+        torch.cuda.synchronize()
+
+    # Parity of frame 0 against the unsharded C oracle.  The verdict is COLLECTIVE (rank 0 checks, every rank hears): a rank
+    # that left on its own would strand the others in the next collective.  A columns merge that fails falls back to the packed
+    # keys and says so; a failure of those ends the leg on every rank together.
+    ref = None
+    fell_back = None
+    while True:
+        merge = state["merge"]
+        depth, bgr = process(0, not args.no_bgr)
+        sync()
+        cols_failed = state["proc"].columns_failed() if merge == "columns" else None  # (a collective: every rank)
+        parity = None
+        ok = True
+        if rank == 0:
+            if ref is None:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                from c_oracle import COracle
+                ref = COracle(tables, camera, omp=True).process_ev_frame(*host0, want_events=False)
+            parity = depth_parity(depth.cpu().numpy(), ref["depth"])
+            if bgr is not None:
+                parity["bgr_equal"] = bool(np.array_equal(bgr.cpu().numpy(), ref["bgr"]))
+            parity["checker"] = "C/OpenMP oracle, unsharded frame 0"
+            if cols_failed is not None:
+                parity["no_piece_objected"] = not cols_failed
+            ok = bool(parity["depth_max_rel_err"] <= 1e-4 and parity.get("no_piece_objected", True) and parity["empty_mask_equal"]
+                      and parity.get("bgr_equal", True)) or args.no_parity
+            if merge == "columns" and os.environ.get("XM_BENCH_TEST_FAIL_COLUMNS") == "1":  # (the tests walk the fall-back)
+                ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() != "gloo" else "cpu")
+        dist.broadcast(flag, src=0)
+        if int(flag.item()):
+            break
+        if merge == "columns":
+            fell_back = {"from": "columns", "parity_of_columns": parity}
+            if rank == 0:
+                print(f"[bench] sharded: the columns merge failed parity ({parity}); falling back to the packed keys", file=sys.stderr)
+            make("all_reduce")
+            continue
+        if rank == 0:
+            print(json.dumps({"error": "parity check failed", "parity": parity}))
+        if getattr(args, "as_leg", False):
+            raise RuntimeError("sharded leg: parity check failed")
+        sys.exit(1)
+    merge = state["merge"]
+    proc = state["proc"]
+
+    # collective time: torch events on the engine's stream around the collectives
     ev_pairs = []
     orig = {"_all_reduce": proc._all_reduce, "_reduce_scatter_max": proc._reduce_scatter_max, "_all_gather": proc._all_gather}
 
@@ -1511,29 +1565,6 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
             ev_pairs.append((e0, e1))
         return wrapped
 
-    def sync():
-        eng.sync()
-        torch.cuda.synchronize()
-
-    parity = None
-    O = None
-    depth, bgr = process(0, not args.no_bgr)
-    sync()
-    cols_failed = proc.columns_failed() if merge == "columns" else None  # (a collective: every rank)
-    if rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import xmaps_oracle as O
-        from c_oracle import COracle
-        ref = COracle(tables, camera, omp=True).process_ev_frame(*host0, want_events=False)
-        parity = depth_parity(depth.cpu().numpy(), ref["depth"])
-        if bgr is not None:
-            parity["bgr_equal"] = bool(np.array_equal(bgr.cpu().numpy(), ref["bgr"]))
-        parity["checker"] = "C/OpenMP oracle, unsharded frame 0"
-        if cols_failed is not None:
-            parity["no_piece_objected"] = not cols_failed
-        if not (parity["depth_max_rel_err"] <= 1e-4 and parity.get("no_piece_objected", True) and parity["empty_mask_equal"] and parity.get("bgr_equal", True)) and not args.no_parity:
-            print(json.dumps({"error": "parity check failed", "parity": parity}))
-            sys.exit(1)
     tm = Timer(torch, dist, dev, sync)
 
     def step(i):
@@ -1622,7 +1653,7 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                                (" (camera view)" if camera else " (projector view)"),
                    "events_per_frame": n_ev, "events_per_rank": b - a, "key_frame_MB": round(kshape[0] * kshape[1] * 8 / 1e6, 1),
                    "host_synchronisations_per_frame": 0,
-                   "merge": merge, "collective_bytes_per_frame_and_rank": getattr(proc, "collective_bytes_per_frame", None),
+                   "merge": merge, "fell_back": fell_back, "collective_bytes_per_frame_and_rank": getattr(proc, "collective_bytes_per_frame", None),
                    "collectives_per_frame": (["all_gather of {first / last stamp, the shard's last events} (carries the extrema and every last column)",
                                               "all_reduce SUM uint32[u16 frame / 2] (disjoint cells)"] if merge == "columns" else
                                              ["all_reduce MIN int64[2] (frame extrema)"]) +
