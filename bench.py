@@ -72,6 +72,15 @@ def parse_args():
                     help="--sharded: how the shards are merged (x_maps_amd/sharded.py).  columns (default): every time column on one rank, "
                          "plain u16 frames merged by SUM (falls back to all_reduce on rigs that do not take the column tiles); the others: "
                          "packed 64-bit keys merged by MAX")
+    ap.add_argument("--comm", choices=("library", "torch"), default="library",
+                    help="--sharded: who issues the collectives.  library (default): xm_shard_comm_* -- the library owns an RCCL "
+                         "communicator per lane and one native call per frame enqueues kernels and collectives (merges: columns, "
+                         "all_reduce); torch: x_maps_amd.sharded.ShardedFrameProcessor over torch.distributed (every merge; also "
+                         "the fall-back when the library's communicator cannot be set up on every rank)")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2, 4),
+                    help="--sharded: frames in flight.  Each lane is an engine of its own (stream, frame buffers, helper slots) "
+                         "taking every lanes-th frame: one frame's latency-bound ends (pack, all-gather, boundary pass; all-reduce, "
+                         "K2) run beside the next frame's K1.  1 = one frame at a time (rounds 1-3)")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
                          "launches, grid = frames x tiles); 0 = a step is one frame through one asynchronous call (round 2's "
@@ -354,6 +363,10 @@ def other_config_legs(args, torch, dist, dev, local_rank):
             leg["latency_us"] = {k: v for k, v in out["latency_us"].items() if k != "definition"}
         if "collective_ms" in out:
             leg["collective_ms"] = out["collective_ms"]
+            for k in ("merge", "fell_back", "frames_in_flight", "collectives_issued_by", "comm_note", "Mevents_per_s_via_torch_distributed",
+                      "Mevents_per_s_one_frame_at_a_time"):
+                if k in out["config"]:
+                    leg[k] = out["config"][k]
         ip = out.get("ingest_path")
         if isinstance(ip, dict):
             leg["ingest_path"] = {k: ip[k] for k in ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "frames_cut",
@@ -854,9 +867,16 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             "workload": sharded_leg["config"]["workload"], "events_per_rank": sharded_leg["config"]["events_per_rank"],
             "collective_ms": sharded_leg["collective_ms"], "kernels_us": sharded_leg["roofline"]["avg_launch_us"],
             "parity": sharded_leg["parity"],
-            "note": "bench.py --sharded on the same ranks: C-10M, the event buffer split by index, MIN all-reduce of the extrema + MAX "
-                    "all-reduce of the packed-key frame (collective time listed separately); the headline `value` is frame-level "
-                    "weak scaling without any collective"}
+            "merge": sharded_leg["config"]["merge"], "fell_back": sharded_leg["config"]["fell_back"],
+            "frames_in_flight": sharded_leg["config"]["frames_in_flight"],
+            "collectives_issued_by": sharded_leg["config"]["collectives_issued_by"], "comm_note": sharded_leg["config"]["comm_note"],
+            "Mevents_per_s_via_torch_distributed": sharded_leg["config"]["Mevents_per_s_via_torch_distributed"],
+            "Mevents_per_s_one_frame_at_a_time": sharded_leg["config"]["Mevents_per_s_one_frame_at_a_time"],
+            "collective_bytes_per_frame_and_rank": sharded_leg["config"]["collective_bytes_per_frame_and_rank"],
+            "note": "bench.py --sharded on the same ranks: C-10M, the event buffer split by index; merge = columns: every time column "
+                    "on one rank (all-gather of the shards' last events), plain u16 frames SUM-all-reduced; merge = all_reduce: MIN "
+                    "all-reduce of the extrema + MAX all-reduce of the packed-key frame; collective time (one frame at a time) "
+                    "listed separately; the headline `value` is frame-level weak scaling without any collective"}
     if other_modes:
         out["other_modes"] = other_modes
     if host_path:
@@ -1477,11 +1497,14 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     nf = min(args.frames or 4, 4)
     a, b = shard_bounds(n_ev, rank, world)
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank)
-    shards, host0 = [], None
+    K = max(1, min(args.lanes, nf))
+    shards, host0, host_f = [], None, {}
     for f in range(nf):
         x, y, t, _ = S.to_soa(S.make_events(cfg, frame=f))
         if f == 0 and rank == 0:
             host0 = (x, y, t)
+        if f < K and rank == 0:
+            host_f[f] = (x, y, t)  # (lane k's first frame is frame k: each lane is checked against the oracle)
         shards.append(tuple(torch.from_numpy(v[a:b].copy()).to(dev) for v in (x.view(np.int16), y.view(np.int16), t)) + (None,))
     torch.cuda.synchronize()
     prov = GpuShardProvider(eng, dev)
@@ -1491,43 +1514,60 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     state = {}
 
     def make(merge):
-        proc = ShardedFrameProcessor(prov, dist, always_reduce=True, merge=merge)  # world 1: the collectives are issued all the same
-        # the shards as a host keeps them resident for the columns path: headroom in front for the predecessor's last column
-        resident = [proc.columns_resident(sh, n_ev) for sh in shards] if merge == "columns" else None
-        state.update(proc=proc, resident=resident, merge=merge)
+        for ln in state.get("lanes", [])[1:]:
+            ln["eng"].close()
+        lanes = []
+        for k in range(K):  # lane k: frames k, k + K, ... on an engine of its own
+            e = eng if k == 0 else XMapsEngine(tables, camera_perspective=camera, device=local_rank)
+            pv = prov if k == 0 else GpuShardProvider(e, dev)
+            pr = ShardedFrameProcessor(pv, dist, always_reduce=True, merge=merge)  # world 1: the collectives are issued all the same
+            # the shards as a host keeps them resident for the columns path: headroom in front for the predecessor's last column
+            res = {f: pr.columns_resident(shards[f], n_ev) for f in range(nf) if f % K == k} if merge == "columns" else None
+            lanes.append(dict(eng=e, prov=pv, proc=pr, resident=res))
+        state.update(lanes=lanes, merge=merge, proc=lanes[0]["proc"])
 
     make(merge)
 
-    def process(i, want_bgr):
+    def process(i, want_bgr, lane=None):
+        """frame i (of the nf resident ones) on its lane; lane = k: the i-th of lane k's own frames"""
+        f = i % nf if lane is None else lane + K * (i % (nf // K))
+        ln = state["lanes"][f % K]
         if state["merge"] == "columns":
-            return state["proc"].process_shard_columns(*state["resident"][i % nf], want_bgr=want_bgr)
-        return state["proc"].process_shard(shards[i % nf], a, want_bgr=want_bgr)
+            return ln["proc"].process_shard_columns(*ln["resident"][f], want_bgr=want_bgr)
+        return ln["proc"].process_shard(shards[f], a, want_bgr=want_bgr)
 
     def sync():
-        eng.sync()
+        for ln in state["lanes"]:
+            ln["eng"].sync()
         torch.cuda.synchronize()
 
     # Parity of frame 0 against the unsharded C oracle.  The verdict is COLLECTIVE (rank 0 checks, every rank hears): a rank
     # that left on its own would strand the others in the next collective.  A columns merge that fails falls back to the packed
     # keys and says so; a failure of those ends the leg on every rank together.
-    ref = None
+    refs = {}
     fell_back = None
     while True:
         merge = state["merge"]
-        depth, bgr = process(0, not args.no_bgr)
+        outs = [process(k, not args.no_bgr) for k in range(K)]  # every lane's first frame
         sync()
-        cols_failed = state["proc"].columns_failed() if merge == "columns" else None  # (a collective: every rank)
+        cols_failed = any([ln["proc"].columns_failed() for ln in state["lanes"]]) if merge == "columns" else None  # (collectives: every rank)
         parity = None
         ok = True
         if rank == 0:
-            if ref is None:
-                sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                from c_oracle import COracle
-                ref = COracle(tables, camera, omp=True).process_ev_frame(*host0, want_events=False)
-            parity = depth_parity(depth.cpu().numpy(), ref["depth"])
-            if bgr is not None:
-                parity["bgr_equal"] = bool(np.array_equal(bgr.cpu().numpy(), ref["bgr"]))
-            parity["checker"] = "C/OpenMP oracle, unsharded frame 0"
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from c_oracle import COracle
+            for k, (depth, bgr) in enumerate(outs):
+                if k not in refs:
+                    r_ = COracle(tables, camera, omp=True).process_ev_frame(*host_f[k], want_events=False)
+                    refs[k] = {q: (v.copy() if isinstance(v, np.ndarray) else v) for q, v in r_.items()}
+                p = depth_parity(depth.cpu().numpy(), refs[k]["depth"])
+                if bgr is not None:
+                    p["bgr_equal"] = bool(np.array_equal(bgr.cpu().numpy(), refs[k]["bgr"]))
+                if parity is None:
+                    parity = p
+                else:  # (the line shows the worst lane)
+                    parity = {q: (max(parity[q], p[q]) if q == "depth_max_rel_err" else (parity[q] and p[q])) for q in parity}
+            parity["checker"] = f"C/OpenMP oracle, unsharded frames 0..{K - 1} (one per lane)"
             if cols_failed is not None:
                 parity["no_piece_objected"] = not cols_failed
             ok = bool(parity["depth_max_rel_err"] <= 1e-4 and parity.get("no_piece_objected", True) and parity["empty_mask_equal"]
@@ -1567,8 +1607,55 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
 
     tm = Timer(torch, dist, dev, sync)
 
+    # The library's own communicators (xm_shard_comm_*), one per lane: the timed loop runs on them when every rank could set
+    # them up and their frames pass the same check; the torch.distributed lanes above stay for the per-kernel / per-collective
+    # timing pass and as the fall-back.  Every decision here is collective (an all-reduce / broadcast of the verdict).
+    comms, comm_note = None, None
+    on = dev if dist.get_backend() != "gloo" else "cpu"
+    if args.comm == "library" and merge in ("columns", "all_reduce"):
+        from x_maps_amd.sharded import ShardComm
+        try:
+            ShardComm.new_id()  # (local probe: is librccl there with the entry points?)
+            can = 1
+        except Exception as e:
+            can, comm_note = 0, repr(e)[:200]
+        flag = torch.tensor([can], dtype=torch.int32, device=on)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            comms = [ShardComm.over_torch_dist(ln["eng"], dist, n_ev, dev) for ln in state["lanes"]]
+
+            def process_lib(i, want_bgr):
+                f = i % nf
+                if merge == "columns":
+                    return comms[f % K].frame(*state["lanes"][f % K]["resident"][f], want_bgr=want_bgr)
+                return comms[f % K].frame_keys(shards[f], a, want_bgr=want_bgr)
+
+            outs = [process_lib(k, not args.no_bgr) for k in range(K)]
+            sync()
+            bad = any([c.failed() for c in comms]) if merge == "columns" else False  # (collectives)
+            ok = True
+            if rank == 0:
+                for k, (depth, bgr) in enumerate(outs):
+                    ok = ok and np.array_equal(depth.cpu().numpy(), refs[k]["depth"]) and (bgr is None or np.array_equal(bgr.cpu().numpy(), refs[k]["bgr"]))
+                ok = bool(ok and not bad) or args.no_parity
+                parity["library_communicator_frames_equal_oracle"] = bool(ok)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=on)
+            dist.broadcast(flag, src=0)
+            if not int(flag.item()):
+                comm_note = "frames through the library's communicator differed from the oracle: torch.distributed path timed instead"
+                if rank == 0:
+                    print("[bench] sharded: " + comm_note, file=sys.stderr)
+                for c in comms:
+                    c.close()
+                comms = None
+        else:
+            comm_note = comm_note or "another rank could not set the library's communicator up"
+
     def step(i):
-        process(i, not args.no_bgr)
+        if comms is not None:
+            process_lib(i, not args.no_bgr)
+        else:
+            process(i, not args.no_bgr)
 
     for i in range(min(args.warmup, 50)):
         step(i)
@@ -1578,6 +1665,13 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     el, enq = tm.blocks(lambda: [step(i) for i in range(steps)], R)
     elapsed = float(np.median(el))
     value = float(n_ev) * steps / elapsed / 1e6  # the frame is shared by all ranks: strong scaling
+    one_lane, via_torch, enq_torch = None, None, None
+    if comms is not None:  # the same lanes with Python / torch.distributed issuing the collectives (x_maps_amd.sharded)
+        elt, enqt = tm.blocks(lambda: [process(i, not args.no_bgr) for i in range(steps)], max(3, R // 2))
+        via_torch, enq_torch = float(n_ev) * steps / float(np.median(elt)) / 1e6, float(np.median(enqt)) / steps * 1e6
+    if K > 1:  # the same frames one at a time (lane 0 alone, torch.distributed): what rounds 1-3 measured
+        el1, _ = tm.blocks(lambda: [process(i, not args.no_bgr, lane=0) for i in range(steps)], max(3, R // 2))
+        one_lane = float(n_ev) * steps / float(np.median(el1)) / 1e6
     # collective time, measured in a separate short pass (event records between the enqueues cost host time)
     for k, f in orig.items():
         setattr(proc, k, timed(f))
@@ -1597,8 +1691,8 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         return wrapped
     for k, f in p_orig.items():
         setattr(prov, k, timed_k(k, f))
-    for i in range(20):
-        step(i)
+    for i in range(20):  # (lane 0 alone: a frame at a time, so that an event pair brackets one kernel chain and nothing else)
+        process(i, not args.no_bgr, lane=0)
     sync()
     for k, f in orig.items():
         setattr(proc, k, f)
@@ -1616,8 +1710,11 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
     coll_ms = torch.tensor([float(np.median(coll[:, 0])), float(np.median(coll[:, 1:].sum(axis=1)))], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(coll_ms, op=dist.ReduceOp.MAX)
+    for c in comms or []:
+        c.close()
     if rank != 0:
-        eng.close()
+        for ln in state["lanes"]:
+            ln["eng"].close()
         return None
     kshape = eng.key_shape
     roofline, alg, pt = roofline_dict(np.array(k_ms + [elapsed / steps * 1e3]), None, b - a, 1, tables, camera, 0 if args.no_bgr else 3,
@@ -1653,7 +1750,12 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                                (" (camera view)" if camera else " (projector view)"),
                    "events_per_frame": n_ev, "events_per_rank": b - a, "key_frame_MB": round(kshape[0] * kshape[1] * 8 / 1e6, 1),
                    "host_synchronisations_per_frame": 0,
-                   "merge": merge, "fell_back": fell_back, "collective_bytes_per_frame_and_rank": getattr(proc, "collective_bytes_per_frame", None),
+                   "merge": merge, "fell_back": fell_back, "frames_in_flight": K,
+                   "collectives_issued_by": "the library (xm_shard_comm_frame: one native call per frame, an RCCL communicator per lane)"
+                   if comms is not None else "torch.distributed (x_maps_amd.sharded.ShardedFrameProcessor)", "comm_note": comm_note,
+                   "Mevents_per_s_via_torch_distributed": None if via_torch is None else round(via_torch, 1),
+                   "host_enqueue_us_per_frame_via_torch_distributed": None if enq_torch is None else round(enq_torch, 2),
+                   "Mevents_per_s_one_frame_at_a_time": None if one_lane is None else round(one_lane, 1), "collective_bytes_per_frame_and_rank": getattr(proc, "collective_bytes_per_frame", None),
                    "collectives_per_frame": (["all_gather of {first / last stamp, the shard's last events} (carries the extrema and every last column)",
                                               "all_reduce SUM uint32[u16 frame / 2] (disjoint cells)"] if merge == "columns" else
                                              ["all_reduce MIN int64[2] (frame extrema)"]) +
@@ -1668,10 +1770,12 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                           "note": "median over 20 frames, torch events on the engine's stream around each all-reduce, max over ranks; "
                                   "with one rank RCCL still runs its kernels (always_reduce) but nothing crosses xGMI"},
         "timing": {"prewarm_s": PREWARM_S, "blocks": int(R), "block_s_median": round(elapsed, 6),
-                   "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6)},
+                   "block_s_min": round(float(el.min()), 6), "block_s_max": round(float(el.max()), 6),
+                   "host_enqueue_us_per_frame": round(float(np.median(enq)) / steps * 1e6, 2)},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
     }
-    eng.close()
+    for ln in state["lanes"]:
+        ln["eng"].close()
     return out
 
 

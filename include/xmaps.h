@@ -387,6 +387,36 @@ int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y
                              int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
 int xm_sharded_info(xm_sharded* s, int* n_dev, int* uses_rccl, uint64_t* key_frame_bytes);
 void xm_sharded_destroy(xm_sharded* s);
+
+/* ---- one rank of a frame sharded over several PROCESSES (one per GPU), the library driving RCCL itself (new, round 4) --------
+ * The xm_shard_* calls above leave the collectives to the host (x_maps_amd/sharded.py issues them through torch.distributed:
+ * five calls and two collectives from Python per frame, ~64 us of host time).  Here the library owns the communicator: ONE
+ * call per frame enqueues kernels and collectives on xm_stream(h, 0) (~15 us of host time), and a C / C++ host needs no Python.
+ *   xm_shard_comm_id        rank 0: XM_SHARD_COMM_ID_BYTES opaque bytes (an RCCL unique id) for the host to hand to every rank
+ *                           by whatever transport it has (MPI_Bcast, a file, torch.distributed.broadcast ...)
+ *   xm_shard_comm_create    every rank, collective: the communicator on h's device + the exchange buffers for frames of
+ *                           n_frame_events events.  Destroy it BEFORE h.  Several communicators per process (one per handle:
+ *                           frames in flight on different streams) are fine -- each from an id of its own.
+ *   xm_shard_comm_frame     the columns merge (see xm_shard_cols_*): pack -> ncclAllGather -> prepare + boundary pass +
+ *                           column-tile K1 -> ncclAllReduce(SUM) of the u16 frame -> frame kernel into depth_out / bgr_out
+ *                           (DEVICE pointers; both NULL: the merged frame stays in the communicator, e.g. on ranks that do not
+ *                           need the result).  x / y / t: this rank's shard, 16-byte aligned, with cap_events + 8 events of
+ *                           writable headroom in front and 8 behind (xm_shard_comm_info).  Asynchronous.
+ *   xm_shard_comm_frame_keys  the packed-key merge (any rig, any event order, optional polarity column p): extrema ->
+ *                           ncclAllReduce(MIN) -> clear + scatter with global indices (first_index = the shard's offset in the
+ *                           frame) -> ncclAllReduce(MAX, uint64) -> frame kernel.  Also the redo of flagged columns frames.
+ *   xm_shard_comm_failed    collective + synchronises: did ANY rank flag a columns frame since the last call?
+ * RCCL is looked up at run time like for xm_create_sharded. */
+#define XM_SHARD_COMM_ID_BYTES 128
+typedef struct xm_shard_comm xm_shard_comm;
+int xm_shard_comm_id(void* id_out);
+int xm_shard_comm_create(xm_handle* h, const void* id, int rank, int world, uint64_t n_frame_events, xm_shard_comm** out);
+int xm_shard_comm_info(xm_shard_comm* c, int* takes_columns, size_t* cap_events, size_t* send_bytes, size_t* frame_bytes);
+int xm_shard_comm_frame(xm_shard_comm* c, uint16_t* x, uint16_t* y, int64_t* t, size_t n_own, float* depth_out, uint8_t* bgr_out);
+int xm_shard_comm_frame_keys(xm_shard_comm* c, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n_own,
+                             int t_dtype, uint64_t first_index, float* depth_out, uint8_t* bgr_out);
+int xm_shard_comm_failed(xm_shard_comm* c, int* failed);
+void xm_shard_comm_destroy(xm_shard_comm* c);
 int xm_k2_patch_cols_max(xm_handle* h, int* cols_out);
 /* the stream the shard calls run on (hipStream_t as void*), so the caller can order its collective */
 void* xm_stream(xm_handle* h, int slot);

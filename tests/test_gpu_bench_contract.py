@@ -91,6 +91,9 @@ def test_a_columns_merge_that_fails_parity_falls_back_to_the_packed_keys_on_ever
     assert d["config"]["merge"] == "all_reduce" and d["config"]["fell_back"]["from"] == "columns" and d["parity"]["depth_bit_exact"]
     d = _run("--sharded", "--steps", "5", "--no-cpu-baseline")
     assert d["config"]["merge"] == "columns" and d["config"]["fell_back"] is None and d["parity"]["no_piece_objected"]
+    assert d["config"]["collectives_issued_by"].startswith("the library") and d["parity"]["library_communicator_frames_equal_oracle"]
+    d = _run("--sharded", "--steps", "5", "--no-cpu-baseline", "--comm", "torch", "--lanes", "1")  # rounds 1-3's form
+    assert d["config"]["collectives_issued_by"].startswith("torch.distributed") and d["config"]["frames_in_flight"] == 1
 
 
 def _check_roofline(r):
@@ -129,6 +132,9 @@ def test_multi_gpu_line_carries_the_sharded_frame_beside_the_replicas():
     sh = d["other_modes"]["one_frame_sharded_over_the_ranks"]
     assert sh["scaling"] == "strong" and sh["value"] > 1000 and sh["parity"]["depth_bit_exact"]
     assert sh["collective_ms"]["key_frame_merge"] > 0 and sh["kernels_us"]["k_scatter"] > 0
+    # the leg runs on the library's own communicators (one per lane), the torch.distributed form timed beside it
+    assert sh["merge"] == "columns" and sh["frames_in_flight"] == 2 and sh["collectives_issued_by"].startswith("the library")
+    assert sh["parity"]["library_communicator_frames_equal_oracle"] and sh["Mevents_per_s_via_torch_distributed"] > 1000
 
 
 def test_the_default_line_carries_the_other_baseline_configs():

@@ -187,6 +187,13 @@ SYMBOLS = {
     "xm_sharded_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_sharded_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "xm_sharded_destroy": (None, [_P]),
+    "xm_shard_comm_id": (C.c_int, [_P]),
+    "xm_shard_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.POINTER(_P)]),
+    "xm_shard_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "xm_shard_comm_frame": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, _P]),
+    "xm_shard_comm_frame_keys": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_uint64, _P, _P]),
+    "xm_shard_comm_failed": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "xm_shard_comm_destroy": (None, [_P]),
     "xm_ingest_device_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xm_ingest_host_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "xm_evt3_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),

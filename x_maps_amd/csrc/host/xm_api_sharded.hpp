@@ -19,12 +19,18 @@ namespace {
 // the few RCCL entry points and enum values used here (rccl.h: ncclDataType_t / ncclRedOp_t)
 struct RcclApi {
   void* lib = nullptr;
+  struct UniqueId { char bytes[128]; };  // ncclUniqueId: 128 opaque bytes, passed by value
   int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*GetUniqueId)(UniqueId* id) = nullptr;
+  int (*CommInitRank)(void** comm, int nranks, UniqueId id, int rank) = nullptr;
   int (*CommDestroy)(void* comm) = nullptr;
   int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t sendcount, int dtype, void* comm, hipStream_t stream) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
-  static constexpr int Int64 = 4, Uint64 = 5, Float64 = 8, Max = 2, Min = 3;
+  static constexpr int Uint8 = 1, Int32 = 2, Int64 = 4, Uint64 = 5, Float64 = 8, Sum = 0, Max = 2, Min = 3;
   bool ok() const { return CommInitAll && CommDestroy && AllReduce; }
+  bool ok_ranks() const { return ok() && GetUniqueId && CommInitRank && AllGather; }
+  const char* err(int e) const { return GetErrorString ? GetErrorString(e) : "?"; }
 };
 
 RcclApi load_rccl() {
@@ -37,6 +43,9 @@ RcclApi load_rccl() {
     if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
   if (!r.lib) return r;
   r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));

@@ -46,6 +46,7 @@ using namespace xm;
 #include "host/xm_api_stage.hpp"    // debug + stage API
 #include "host/xm_api_shard.hpp"    // shards (multi-GPU)
 #include "host/xm_api_sharded.hpp"  // one frame over several GPUs of one process (RCCL communicators owned by the handle)
+#include "host/xm_api_shardcomm.hpp"  // one rank of a frame sharded over several processes: the library drives RCCL itself
 #include "host/xm_api_filters.hpp"  // frame event filters, pause detection
 #include "host/xm_api_ingest.hpp"   // device-side ingest
 #include "host/xm_api_evt3.hpp"     // EVT 3.0 decoder on the device (alone / in front of the ingest)

@@ -443,3 +443,114 @@ class ShardedDevices:
             self.close()
         except Exception:
             pass
+
+
+class ShardComm:
+    """One rank of a frame sharded over several PROCESSES (one per GPU) with the LIBRARY driving RCCL (xm_shard_comm_*): one native
+    call per frame enqueues the kernels and both collectives on the engine's stream -- ~15 us of host time where
+    ShardedFrameProcessor pays ~64 us for five calls and two torch.distributed collectives.  torch.distributed (or anything else)
+    is only needed once, to hand rank 0's 128-byte id to the other ranks.
+
+        comm = ShardComm.over_torch_dist(engine, dist, n_frame_events, device)      # collective
+        res, n_own = comm.resident(shard)                                           # the shard with headroom in front
+        depth, bgr = comm.frame(res, n_own)                                         # asynchronous; outputs are device tensors
+        ... comm.failed()                                                           # collective: redo with frame_keys() when True
+
+    Outputs rotate through `n_out` buffers: a frame's tensors stay valid until n_out more frames have been enqueued."""
+
+    ID_BYTES = 128
+
+    def __init__(self, engine, comm_id: bytes, rank: int, world: int, n_frame_events: int, device, n_out: int = 2):
+        import ctypes as C
+
+        import torch
+
+        from . import _native as N
+        assert len(comm_id) == self.ID_BYTES
+        self._C, self._N, self.torch = C, N, torch
+        self._lib = N.load_library()
+        self.eng, self.device, self.rank, self.world, self.n_frame = engine, device, int(rank), int(world), int(n_frame_events)
+        self._c = C.c_void_p(None)
+        idb = (C.c_char * self.ID_BYTES).from_buffer_copy(comm_id)
+        N.check(self._lib.xm_shard_comm_create(engine._h, idb, self.rank, self.world, self.n_frame, C.byref(self._c)))
+        tc, cap, sb, fb = C.c_int(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        N.check(self._lib.xm_shard_comm_info(self._c, C.byref(tc), C.byref(cap), C.byref(sb), C.byref(fb)))
+        self.takes_columns, self.cap_events, self.send_bytes, self.frame_bytes = bool(tc.value), int(cap.value), int(sb.value), int(fb.value)
+        self.collective_bytes_per_frame = ({"last_events_all_gather": self.send_bytes * self.world, "u16_frame_sum_all_reduce": self.frame_bytes}
+                                           if self.takes_columns else {"extrema_min_all_reduce": 16, "key_frame_max_all_reduce": self.frame_bytes})
+        self._outs = [(torch.empty((engine.out_h, engine.out_w), dtype=torch.float32, device=device),
+                       torch.empty((engine.out_h, engine.out_w, 3), dtype=torch.uint8, device=device)) for _ in range(max(1, n_out))]
+        torch.cuda.current_stream(device).synchronize()
+        self._i = 0
+
+    @classmethod
+    def new_id(cls) -> bytes:
+        import ctypes as C
+
+        from . import _native as N
+        buf = (C.c_char * cls.ID_BYTES)()
+        N.check(N.load_library().xm_shard_comm_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def over_torch_dist(cls, engine, dist, n_frame_events, device, group=None, n_out=2):
+        """rank 0 draws the id, torch.distributed carries it to the others (the only use of it); collective"""
+        import torch
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on = "cpu" if dist.get_backend(group) == "gloo" else device
+        idt = torch.zeros(cls.ID_BYTES, dtype=torch.uint8, device=on)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(cls.new_id()), dtype=torch.uint8).to(on)
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast(idt, src=src, group=group)
+        return cls(engine, bytes(idt.cpu().numpy().tobytes()), rank, world, n_frame_events, device, n_out=n_out)
+
+    def resident(self, shard):
+        """(x, y, t) of the shard once more with cap_events + 8 events of headroom in front and 8 behind, and its length"""
+        return GpuShardProvider.cols_resident(self, shard, self.cap_events), len(shard[2])
+
+    def _next_out(self, want_depth, want_bgr):
+        d, b = self._outs[self._i % len(self._outs)]
+        self._i += 1
+        return (d if want_depth else None), (b if want_bgr else None)
+
+    def frame(self, resident, n_own, want_depth=True, want_bgr=True):
+        """the columns merge; asynchronous on the engine's stream"""
+        d, b = self._next_out(want_depth, want_bgr)
+        own = lambda a: GpuShardProvider._own(a, self.cap_events)
+        self._N.check(self._lib.xm_shard_comm_frame(self._c, own(resident[0]), own(resident[1]), own(resident[2]), int(n_own),
+                                                    None if d is None else d.data_ptr(), None if b is None else b.data_ptr()))
+        return d, b
+
+    def frame_keys(self, shard, first_index, want_depth=True, want_bgr=True):
+        """the packed-key merge of the same frame (any rig / order / polarity column); asynchronous"""
+        x, y, t, p = shard
+        d, b = self._next_out(want_depth, want_bgr)
+        n = len(t)
+        ptr = lambda a: None if (a is None or n == 0) else a.data_ptr()
+        self._N.check(self._lib.xm_shard_comm_frame_keys(self._c, ptr(x), ptr(y), ptr(t), ptr(p), n, GpuShardProvider._t_dtype(t), int(first_index),
+                                                         None if d is None else d.data_ptr(), None if b is None else b.data_ptr()))
+        return d, b
+
+    def failed(self) -> bool:
+        v = self._C.c_int(0)
+        self._N.check(self._lib.xm_shard_comm_failed(self._c, self._C.byref(v)))
+        return bool(v.value)
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._lib.xm_shard_comm_destroy(self._c)
+            self._c = self._C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
