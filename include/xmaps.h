@@ -386,6 +386,11 @@ int xm_create_sharded(const int* dev_ids, int n_dev, const xm_config* cfg, xm_sh
 int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y, const void* t, const int16_t* p, size_t n,
                              int t_dtype, float* depth_out, uint8_t* bgr_out, xm_frame_stats* stats);
 int xm_sharded_info(xm_sharded* s, int* n_dev, int* uses_rccl, uint64_t* key_frame_bytes);
+/* Which exchange the frames so far took: time-sorted int64 frames without a polarity column on rigs whose X-map is injective go
+ * through the columns exchange (xm_shard_cols_*: all-gather of the shards' last events + SUM all-reduce of plain u16 frames, 2
+ * bytes per cell on the wire); a frame one of whose pieces objected is redone with the packed keys (frames_redone); everything
+ * else takes the keys (frames_keys).  Results are the same bit for bit. */
+int xm_sharded_stats(xm_sharded* s, uint64_t* frames_columns, uint64_t* frames_keys, uint64_t* frames_redone);
 void xm_sharded_destroy(xm_sharded* s);
 
 /* ---- one rank of a frame sharded over several PROCESSES (one per GPU), the library driving RCCL itself (new, round 4) --------

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import xmaps_oracle as O
+from conftest import xm_option
 from x_maps_amd import synthetic as S
 from x_maps_amd.sharded import ShardedDevices
 
@@ -64,6 +65,34 @@ def test_c1m_frame_one_device_and_all_devices():
         with ShardedDevices(tb, devices=ids) as sh:
             assert sh.n_dev == len(ids)
             _check(tb, sh, evs)
+
+
+def test_which_exchange_a_frame_takes():
+    """time-sorted int64 frames on an injective rig: the columns exchange (all-gather + SUM of u16 frames); a frame that objects is
+    redone with the packed keys; polarity columns, float stamps, the camera view and XM_SHARDED_KEYS=1 take the keys -- the same
+    frames as the oracle's every time"""
+    tb = S.make_tables(S.C_1M)
+    evs = S.make_events(S.C_1M, frame=4)
+    with ShardedDevices(tb, devices=[0]) as sh:
+        _check(tb, sh, evs)
+        _check(tb, sh, S.make_events(S.C_1M, frame=5))  # (a second frame on the same buffers: nothing stale)
+        assert sh.stats() == {"frames_columns": 2, "frames_keys": 0, "frames_redone": 0}
+        shuffled = evs[np.random.default_rng(1).permutation(len(evs))]
+        _check(tb, sh, shuffled)
+        assert sh.stats() == {"frames_columns": 3, "frames_keys": 0, "frames_redone": 1}
+        _check(tb, sh, evs)  # (and the columns again after the redo)
+        _check(tb, sh, S.make_events(S.C_1M, frame=6, p_zero_fraction=0.2), p=True)
+        x, y, t, _ = S.to_soa(evs)
+        depth, _, _ = sh.process_frame(x, y, t.astype(np.float64), want_bgr=False)
+        assert np.array_equal(depth, O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t.astype(np.float64), want_bgr=False)["depth"])
+        assert sh.stats() == {"frames_columns": 4, "frames_keys": 2, "frames_redone": 1}
+        xm_option("XM_SHARDED_KEYS", "1")
+        _check(tb, sh, evs)
+        assert sh.stats()["frames_keys"] == 3
+    xm_option("XM_SHARDED_KEYS", "0")
+    with ShardedDevices(tb, devices=[0], camera_perspective=True) as sh:
+        _check(tb, sh, evs, camera=True)
+        assert sh.stats() == {"frames_columns": 0, "frames_keys": 1, "frames_redone": 0}
 
 
 def test_bad_device_lists_are_rejected():

@@ -187,6 +187,7 @@ SYMBOLS = {
     "xm_sharded_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_sharded_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "xm_sharded_destroy": (None, [_P]),
+    "xm_sharded_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xm_shard_comm_id": (C.c_int, [_P]),
     "xm_shard_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.POINTER(_P)]),
     "xm_shard_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -6,6 +6,9 @@
 //   per frame, one host thread per device, everything on that device's stream:
 //     H2D of the shard -> xm_shard_minmax_device -> ncclAllReduce(MIN, {tmin, -tmax}) -> xm_shard_clear + xm_shard_scatter_device
 //     (global event indices in the packed keys) -> ncclAllReduce(MAX, uint64 key frame) -> device 0: xm_shard_finish -> D2H.
+//   Time-sorted int64 frames on rigs whose X-map is injective take the COLUMNS exchange instead (xm_shard_cols_*: ncclAllGather of
+//   the shards' headers + last events, every time column on one device, ncclAllReduce(SUM) of the plain u16 frames: 2 bytes per
+//   cell on the wire, no atomics, no extrema pass); a frame one of whose pieces objects is redone with the keys (xm_sharded_stats).
 //   MAX over packed keys = the event with the largest GLOBAL index wins = NumPy's last-writer-wins across shards, bit for bit
 //   (x_maps_amd/sharded.py is the same exchange for multi-process hosts on torch.distributed).
 // RCCL is not linked: librccl is looked up at run time (the copy a host process has loaded already -- PyTorch ships its own --
@@ -60,6 +63,9 @@ struct xm_sharded {
     xm_handle* h = nullptr;
     void* comm = nullptr;
     DevBuf x, y, t, p, depth, bgr;
+    DevBuf send, gathered;         // columns exchange: this device's header + last events, every device's
+    uint16_t* frame16 = nullptr;   // columns exchange: the plain u16 disparity frame (+ the boundary pass' scratch)
+    int flagged = 0;               // columns exchange: this device's piece could not be handled
     uint64_t* key = nullptr;
     void* mm = nullptr;            // {tmin, -tmax} of the shard, then of the frame (16 bytes, int64 or float64)
     hipEvent_t ev[4] = {};         // device 0: around the two all-reduces
@@ -79,6 +85,10 @@ struct xm_sharded {
   float* depth_out = nullptr;
   uint8_t* bgr_out = nullptr;
   u32 tag = 0;
+  // the exchange of the frame in flight: every time column on one device + SUM of u16 frames (xm_shard_cols_*), or packed keys
+  bool cols_now = false;
+  size_t cols_cap = 0, cols_send_bytes = 0, cols_reduce_u32 = 0, cols_frame_bytes = 0;
+  unsigned long long frames_columns = 0, frames_keys = 0, frames_redone = 0;
   double mm_host[2] = {0, 0};
   float coll_ms[2] = {0, 0};
   // start / done hand-shake
@@ -101,6 +111,65 @@ void sharded_frame_on(xm_sharded* s, int g) {
     const size_t a = (size_t)(((unsigned __int128)g * s->n) / (unsigned)W), b = (size_t)(((unsigned __int128)(g + 1) * s->n) / (unsigned)W);
     const size_t m = b - a, tsz = t_size(s->t_dtype);
     int rc;
+    d.flagged = 0;
+    if (s->cols_now) {
+      // every time column on one device, the plain u16 frames merged by SUM (xm_api_shard.hpp: xm_shard_cols_*): the shard goes
+      // into its buffers behind cap + 8 events of headroom (the predecessor's last column is copied there on the device)
+      const size_t hr = s->cols_cap + 8;
+      if ((rc = d.x.reserve((hr + m + 8) * 2)) || (rc = d.y.reserve((hr + m + 8) * 2)) || (rc = d.t.reserve((hr + m + 8) * 8))) return rc;
+      if ((rc = d.send.reserve(s->cols_send_bytes)) || (rc = d.gathered.reserve(s->cols_send_bytes * (size_t)W))) return rc;
+      if (!d.frame16) {
+        HIP_TRY(hipMalloc((void**)&d.frame16, s->cols_frame_bytes));
+        HIP_TRY(hipMemsetAsync(d.frame16, 0, s->cols_frame_bytes, st));
+      }
+      uint16_t *dx = (uint16_t*)d.x.p + hr, *dy = (uint16_t*)d.y.p + hr;
+      int64_t* dt = (int64_t*)d.t.p + hr;
+      HIP_TRY(hipMemcpyAsync(dx, s->x + a, m * 2, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(dy, s->y + a, m * 2, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(dt, (const int64_t*)s->t + a, m * 8, hipMemcpyHostToDevice, st));
+      if ((rc = xm_shard_cols_pack(d.h, dx, dy, dt, m, d.send.p, s->cols_cap))) return rc;
+      if (g == 0) HIP_TRY(hipEventRecord(d.ev[0], st));
+      const void* gathered = d.send.p;  // (one device without RCCL: its own send buffer is the gathered buffer)
+      if (s->use_rccl) {
+        const int e = s->rccl.AllGather(d.send.p, d.gathered.p, s->cols_send_bytes, RcclApi::Uint8, d.comm, st);
+        if (e) return fail(XM_ERR_HIP, "ncclAllGather(headers + last events) failed: %s", s->rccl.err(e));
+        gathered = d.gathered.p;
+      }
+      if (g == 0) HIP_TRY(hipEventRecord(d.ev[1], st));
+      if ((rc = xm_shard_cols_scatter(d.h, dx, dy, dt, m, s->n, gathered, s->cols_send_bytes, g, W, s->cols_cap, d.frame16))) return rc;
+      if (g == 0) HIP_TRY(hipEventRecord(d.ev[2], st));
+      if (s->use_rccl) {
+        const int e = s->rccl.AllReduce(d.frame16, d.frame16, s->cols_reduce_u32, RcclApi::Int32, RcclApi::Sum, d.comm, st);
+        if (e) return fail(XM_ERR_HIP, "ncclAllReduce(SUM, u16 frame) failed: %s", s->rccl.err(e));
+      }
+      if (g == 0) {
+        HIP_TRY(hipEventRecord(d.ev[3], st));
+        const size_t px = (size_t)d.h->out_w * d.h->out_h;
+        float* dd = nullptr;
+        uint8_t* db = nullptr;
+        if (s->depth_out) {
+          if ((rc = d.depth.reserve(px * 4))) return rc;
+          dd = (float*)d.depth.p;
+        }
+        if (s->bgr_out) {
+          if ((rc = d.bgr.reserve(px * 3))) return rc;
+          db = (uint8_t*)d.bgr.p;
+        }
+        if ((dd || db) && (rc = xm_shard_finish_u16(d.h, d.frame16, dd, db))) return rc;
+        if (dd) HIP_TRY(hipMemcpyAsync(s->depth_out, dd, px * 4, hipMemcpyDeviceToHost, st));
+        if (db) HIP_TRY(hipMemcpyAsync(s->bgr_out, db, px * 3, hipMemcpyDeviceToHost, st));
+        long long v[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(v, d.h->d_shard_n, 16, hipMemcpyDeviceToHost, st));  // {tmin, -tmax} of the frame (prepare left them there)
+        if ((rc = xm_shard_cols_failed(d.h, &d.flagged))) return rc;                 // (synchronises the stream)
+        s->mm_host[0] = (double)v[0];
+        s->mm_host[1] = -(double)v[1];
+        HIP_TRY(hipEventElapsedTime(&s->coll_ms[0], d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&s->coll_ms[1], d.ev[2], d.ev[3]));
+      } else if ((rc = xm_shard_cols_failed(d.h, &d.flagged))) {
+        return rc;
+      }
+      return XM_OK;
+    }
     if ((rc = stage_in(d.x, s->x + a, m * 2, st))) return rc;
     if ((rc = stage_in(d.y, s->y + a, m * 2, st))) return rc;
     if ((rc = stage_in(d.t, (const char*)s->t + a * tsz, m * tsz, st))) return rc;
@@ -199,6 +268,8 @@ void xm_sharded_destroy(xm_sharded* s) {
     if (d->h) (void)xm_sync(d->h);
     if (d->comm && s->rccl.CommDestroy) (void)s->rccl.CommDestroy(d->comm);
     d->x.release(); d->y.release(); d->t.release(); d->p.release(); d->depth.release(); d->bgr.release();
+    d->send.release(); d->gathered.release();
+    if (d->frame16) (void)hipFree(d->frame16);
     if (d->key) (void)hipFree(d->key);
     if (d->mm) (void)hipFree(d->mm);
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -266,18 +337,42 @@ int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y
   s->depth_out = depth_out;
   s->bgr_out = bgr_out;
   s->tag = s->tag >= 1000 ? 1 : s->tag + 1;  // (the key frames are cleared every frame: any tag in [1, 2^19) would do)
-  {
-    std::lock_guard<std::mutex> lk(s->mu);
-    s->done = 0;
-    s->gen += 1;
+  const auto run_frame = [&]() -> int {
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->done = 0;
+      s->gen += 1;
+    }
+    s->cv.notify_all();
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [&] { return s->done == (int)s->devs.size(); });
+    }
+    for (auto& d : s->devs)
+      if (d->rc) return fail(d->rc, "device %d: %s", d->id, d->err.c_str());
+    return XM_OK;
+  };
+  // Time-sorted int64 frames on rigs whose X-map is injective take the columns exchange (2-byte cells on the wire, no atomics,
+  // no extrema pass); a frame one of whose pieces objects (a shard inside one column, events out of order ...) is redone with
+  // the packed keys -- as is everything else.
+  const char* force = dbg_opt("XM_SHARDED_KEYS");
+  s->cols_now = t_dtype == XM_T_INT64 && !p && n >= 64 * s->devs.size() && !(force && force[0] == '1') &&
+                (!s->use_rccl || s->rccl.AllGather) &&
+                xm_shard_cols_info(s->devs[0]->h, n, &s->cols_frame_bytes, &s->cols_reduce_u32, &s->cols_send_bytes, &s->cols_cap) == XM_OK;
+  int rc = run_frame();
+  if (rc) return rc;
+  if (s->cols_now) {
+    bool flagged = false;
+    for (auto& d : s->devs) flagged = flagged || d->flagged;
+    s->frames_columns += 1;
+    if (flagged) {
+      s->frames_redone += 1;
+      s->cols_now = false;
+      if ((rc = run_frame())) return rc;
+    }
+  } else {
+    s->frames_keys += 1;
   }
-  s->cv.notify_all();
-  {
-    std::unique_lock<std::mutex> lk(s->mu);
-    s->cv.wait(lk, [&] { return s->done == (int)s->devs.size(); });
-  }
-  for (auto& d : s->devs)
-    if (d->rc) return fail(d->rc, "device %d: %s", d->id, d->err.c_str());
   if (stats) {
     memset(stats, 0, sizeof *stats);
     stats->n_events = n;
@@ -287,6 +382,14 @@ int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y
     stats->gpu_ms[0] = s->coll_ms[0];  // the two all-reduces on device 0's stream (HIP events around them)
     stats->gpu_ms[1] = s->coll_ms[1];
   }
+  return XM_OK;
+}
+
+int xm_sharded_stats(xm_sharded* s, uint64_t* frames_columns, uint64_t* frames_keys, uint64_t* frames_redone) {
+  if (!s) return fail(XM_ERR_INVALID, "NULL argument");
+  if (frames_columns) *frames_columns = s->frames_columns;
+  if (frames_keys) *frames_keys = s->frames_keys;
+  if (frames_redone) *frames_redone = s->frames_redone;
   return XM_OK;
 }
 

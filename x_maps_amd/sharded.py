@@ -426,6 +426,13 @@ class ShardedDevices:
         return depth, bgr, {"n_events": int(st.n_events), "t_min": float(st.t_min), "t_max": float(st.t_max),
                             "extrema_all_reduce_ms": float(st.gpu_ms[0]), "key_frame_all_reduce_ms": float(st.gpu_ms[1])}
 
+    def stats(self) -> dict:
+        """which exchange the frames so far took (columns / packed keys / columns redone with the keys)"""
+        C = self._C
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._N.check(self._lib.xm_sharded_stats(self._s, C.byref(a), C.byref(b), C.byref(c)))
+        return {"frames_columns": int(a.value), "frames_keys": int(b.value), "frames_redone": int(c.value)}
+
     def close(self):
         if getattr(self, "_s", None) is not None and self._s.value:
             self._lib.xm_sharded_destroy(self._s)
