@@ -59,8 +59,8 @@ def pmc_rows(pattern):
 SETS = (("groups", "C-1M (BASELINE configs[1]), projector view, groups of 32 frames, ONE group at a time", "python bench.py --groups-in-flight 1", 32, "projector_groups"),
         ("esl", "ESL-like frames (configs[0]/[2] stand-in), groups of 32, one group at a time", "python bench.py --esl --groups-in-flight 1", 32, "projector_groups_esl"),
         ("camg", "C-1M camera view, groups of 32, one group at a time", "python bench.py --groups-in-flight 1 --camera-perspective", 32, "camera_groups"),
-        ("sharded", "C-10M (configs[3]) on one rank, merge = columns: pack / prepare + boundary pass + column-tile K1 + K2, RCCL all-gather + SUM all-reduce", "python bench.py --sharded", 1, "projector_sharded"),
-        ("shardedkeys", "C-10M on one rank, merge = all_reduce (packed 64-bit keys: K0 + event-tile K1 with atomics + K2, two RCCL all-reduces)", "python bench.py --sharded --merge all_reduce", 1, "projector_sharded_keys"),
+        ("sharded", "C-10M (configs[3]) on one rank, merge = columns: pack / prepare + boundary pass + column-tile K1 + K2, RCCL all-gather + SUM all-reduce", "python bench.py --sharded --lanes 1 --comm torch", 1, "projector_sharded"),
+        ("shardedkeys", "C-10M on one rank, merge = all_reduce (packed 64-bit keys: K0 + event-tile K1 with atomics + K2, two RCCL all-reduces)", "python bench.py --sharded --merge all_reduce --lanes 1 --comm torch", 1, "projector_sharded_keys"),
         ("single", "C-1M, one frame per call, one slot (single-frame launches)", "python bench.py --batch 0 --slots 1", 1, "projector"))
 Q = "--no-cpu-baseline --no-other-modes --no-host-path"
 avg_us = {}
@@ -70,6 +70,7 @@ with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
             "(k_cols_bounds_batch), K1 (k_scatter_cols_batch: column tiles; k_scatter_own_batch: owner tiles) and K2 (k_frame_proj_pipe:\n"
             "persistent, software-pipelined blocks).  Per-frame cost = avg us / 32.\n\n")
     for key, title, cmd, fpl, wl in SETS + (("groups3", "the default bench command (4 groups in flight: launches of different groups overlap)", "python bench.py", 32, None),
+                                            ("sharded2", "C-10M on one rank as bench.py --sharded runs it by default: 2 frames in flight (lanes), the library issuing the RCCL collectives (xm_shard_comm_frame) -- one frame's small kernels run beside the other's K1, so their durations stretch", "python bench.py --sharded", 1, None),
                                             ("graph", "60 frames x 1 M events from one captured hipGraph (configs[4])", "python bench.py --graph", 60, None),
                                             ("evt3", "the EVT 3.0 decoder alone: 20 chunks of 2 M events = 4 M words each (tools/evt3_probe.py)", None, 1, None),
                                             ("ingest", "the default bench's host / ingest legs (C-1M camera-like stream: records and EVT 3.0 words through the device ingest)", "python bench.py --no-cpu-baseline --no-other-modes --no-other-configs", 1, None),

@@ -25,8 +25,10 @@ run_set () {  # name, bench flags...
 run_set groups --groups-in-flight 1
 run_set esl --esl --groups-in-flight 1
 PMC_SETS=2 run_set camg --groups-in-flight 1 --camera-perspective
-PMC_SETS=2 run_set sharded --sharded
-PMC_SETS=2 run_set shardedkeys --sharded --merge all_reduce
+# (a frame at a time from Python: every kernel of the chain alone on the GPU, as bench.py's own timing pass takes them)
+PMC_SETS=2 run_set sharded --sharded --lanes 1 --comm torch
+PMC_SETS=2 run_set shardedkeys --sharded --merge all_reduce --lanes 1 --comm torch
+$T rocprofv3 --kernel-trace --stats -d $OUT -o trace_sharded2 -- python bench.py --sharded $Q > $OUT/trace_sharded2.log 2>&1  # the default: 2 lanes, the library's communicators
 PMC_SETS=2 run_set single --batch 0 --slots 1
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_groups3 -- python bench.py $Q > $OUT/trace_groups3.log 2>&1
 $T rocprofv3 --kernel-trace --stats -d $OUT -o trace_graph -- python bench.py --graph $Q > $OUT/trace_graph.log 2>&1
@@ -38,6 +40,8 @@ timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
 timeout 200 python bench.py --graph > $OUT/bench_graph60.json 2> $OUT/bench_graph60.err
 timeout 200 python bench.py --sharded > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
+timeout 200 python bench.py --sharded --lanes 4 --no-cpu-baseline > $OUT/bench_sharded_4_lanes.json 2> $OUT/bench_sharded4.err
+timeout 200 python bench.py --sharded --lanes 1 --comm torch --no-cpu-baseline > $OUT/bench_sharded_one_frame_at_a_time_from_python.json 2> $OUT/bench_sharded1.err
 timeout 200 python bench.py --sharded --merge all_reduce --no-cpu-baseline > $OUT/bench_sharded_key_merge.json 2> $OUT/bench_sharded_keys.err
 timeout 300 python bench.py --esl > $OUT/bench_esl.json 2> $OUT/bench_esl.err
 timeout 200 python bench.py --esl --batch 0 --no-cpu-baseline --no-host-path > $OUT/bench_esl_one_frame_per_call.json 2> $OUT/bench_esl_one.err
