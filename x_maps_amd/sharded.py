@@ -37,6 +37,26 @@ def shard_bounds(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
 
 
+def resident_with_headroom(torch, device, shard, cap_events):
+    """The shard's columns (x, y, t device tensors; no polarity column, int64 stamps) once more with `cap_events` + 8 events of
+    headroom in front -- the predecessor's last column is copied there on the device -- and 8 of slack behind for the last 16-byte
+    load: the layout a host that keeps its shards resident for the columns exchange allocates in the first place."""
+    x, y, t, p = shard
+    assert p is None and t.dtype == torch.int64
+    out = []
+    for a in (x, y, t):
+        buf = torch.zeros(cap_events + 8 + len(a) + 8, dtype=a.dtype, device=device)
+        buf[cap_events + 8:cap_events + 8 + len(a)].copy_(a)
+        out.append(buf)
+    torch.cuda.current_stream(device).synchronize()
+    return tuple(out)
+
+
+def first_own_event(buf, cap_events):
+    """address of the first own event in a resident_with_headroom() buffer (an empty slice has no data_ptr)"""
+    return buf.data_ptr() + (cap_events + 8) * buf.element_size()
+
+
 class GpuShardProvider:
     """Shard compute on one MI355X through the C-ABI.  Event columns are torch CUDA tensors."""
 
@@ -138,22 +158,9 @@ class GpuShardProvider:
         return info
 
     def cols_resident(self, shard, cap_events):
-        """the shard's columns once more with `cap_events` of headroom in front (the predecessor's last column goes there): the
-        layout a host that keeps its shards resident allocates in the first place"""
-        torch = self.torch
-        x, y, t, p = shard
-        assert p is None and t.dtype == torch.int64
-        out = []
-        for a in (x, y, t):  # [cap + 8 of headroom | the own events | 8 of slack for the last 16-byte load]
-            buf = torch.zeros(cap_events + 8 + len(a) + 8, dtype=a.dtype, device=self.device)
-            buf[cap_events + 8:cap_events + 8 + len(a)].copy_(a)
-            out.append(buf)
-        torch.cuda.current_stream(self.device).synchronize()
-        return tuple(out)
+        return resident_with_headroom(self.torch, self.device, shard, cap_events)
 
-    @staticmethod
-    def _own(buf, cap):
-        return buf.data_ptr() + (cap + 8) * buf.element_size()  # the first own event (an empty slice has no data_ptr)
+    _own = staticmethod(lambda buf, cap: first_own_event(buf, cap))
 
     def cols_pack(self, res, n, cap, send):
         self.eng.shard_cols_pack(self._own(res[0], cap), self._own(res[1], cap), self._own(res[2], cap), n, send.data_ptr(), cap)
@@ -514,7 +521,7 @@ class ShardComm:
 
     def resident(self, shard):
         """(x, y, t) of the shard once more with cap_events + 8 events of headroom in front and 8 behind, and its length"""
-        return GpuShardProvider.cols_resident(self, shard, self.cap_events), len(shard[2])
+        return resident_with_headroom(self.torch, self.device, shard, self.cap_events), len(shard[2])
 
     def _next_out(self, want_depth, want_bgr):
         d, b = self._outs[self._i % len(self._outs)]
@@ -524,7 +531,7 @@ class ShardComm:
     def frame(self, resident, n_own, want_depth=True, want_bgr=True):
         """the columns merge; asynchronous on the engine's stream"""
         d, b = self._next_out(want_depth, want_bgr)
-        own = lambda a: GpuShardProvider._own(a, self.cap_events)
+        own = lambda a: first_own_event(a, self.cap_events)
         self._N.check(self._lib.xm_shard_comm_frame(self._c, own(resident[0]), own(resident[1]), own(resident[2]), int(n_own),
                                                     None if d is None else d.data_ptr(), None if b is None else b.data_ptr()))
         return d, b
