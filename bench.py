@@ -72,6 +72,8 @@ def parse_args():
                     help="--sharded: how the shards are merged (x_maps_amd/sharded.py).  columns (default): every time column on one rank, "
                          "plain u16 frames merged by SUM (falls back to all_reduce on rigs that do not take the column tiles); the others: "
                          "packed 64-bit keys merged by MAX")
+    ap.add_argument("--esl-stream-child", action="store_true",
+                    help=argparse.SUPPRESS)  # (internal: --esl's stream legs once more in a process that never imports torch)
     ap.add_argument("--comm", choices=("library", "torch"), default="library",
                     help="--sharded: who issues the collectives.  library (default): xm_shard_comm_* -- the library owns an RCCL "
                          "communicator per lane and one native call per frame enqueues kernels and collectives (merges: columns, "
@@ -377,6 +379,9 @@ def other_config_legs(args, torch, dist, dev, local_rank):
             for k in ("full_replay_through_processor_host_trigger_finder", "full_replay_through_processor_device_ingest"):
                 if isinstance(sl.get(k), dict):
                     leg[k] = {a: b for a, b in sl[k].items() if a != "note"}
+            ch = sl.get("in_a_process_without_torch")
+            if isinstance(ch, dict):  # (the ingest leg and the processor's device-ingest leg: the two the reference's application runs)
+                leg["in_a_process_without_torch"] = {k: ch[k] for k in ("ingest_path", "full_replay_through_processor_device_ingest", "error") if k in ch}
         return leg
 
     plan = (("esl", bench_esl, dict(steps=10, esl=True, no_host_path=False)),
@@ -463,6 +468,8 @@ def main():
         sys.exit(2)
     if os.environ.get("XM_BENCH_DRY") == "1":
         return dry_run(args, rank, world)
+    if args.esl_stream_child:
+        return esl_stream_child(args, local_rank)
 
     import torch
 
@@ -1300,6 +1307,17 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
             ingest = esl_stream_legs(eng, cp, tables, int(n_mean), O, camera, local_rank)
         except Exception as e:  # never lose the line to the extra legs
             ingest = {"error": repr(e)[:300]}
+        # ... and once more in a process that never imports torch -- the reference's own situation (Metavision + NumPy + OpenCV):
+        # there the library runs on ROCm's HIP runtime instead of the older copy PyTorch ships and loads first in this process
+        if "error" not in ingest and not getattr(args, "no_stream_child", False):
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--esl-stream-child"] + (["--camera-perspective"] if camera else []),
+                                   capture_output=True, text=True, timeout=240)
+                ch = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "no output")[-300:]}
+            except Exception as e:
+                ch = {"error": repr(e)[:300]}
+            ingest["in_a_process_without_torch"] = ch
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         e0 = host[0]
@@ -1336,6 +1354,27 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
     }
     eng.close()
     return out
+
+
+def esl_stream_child(args, device):
+    """--esl's stream legs in a process of their own that never imports torch (bench.py --esl starts it): prints one JSON line"""
+    assert "torch" not in sys.modules
+    from x_maps_amd import XMapsEngine
+    from x_maps_amd import rig
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xmaps_oracle as O
+    camera = args.camera_perspective
+    cp, tables, _, _ = rig.make_esl_like(row_stride=13, device=device)
+    n_mean = float(np.mean([len(rig.render_events(cp, tables, row_stride=13, seed=f)[0]) for f in range(8)]))
+    with XMapsEngine(tables, camera_perspective=camera, device=device, n_slots=4) as eng:
+        legs = esl_stream_legs(eng, cp, tables, int(n_mean), O, camera, device)
+    assert "torch" not in sys.modules
+    keep = ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "ms_per_shown_frame", "frames_cut", "frames_shown",
+            "same_frames_as_host_trigger_finder", "first_frame_equals_oracle", "host_us_per_push", "same_frames_as_host_path")
+    out = {k: {q: v[q] for q in keep if q in v} for k, v in legs.items() if isinstance(v, dict) and k != "stream"}
+    out["note"] = ("the same legs in a process without torch (NumPy + the library only, as in the reference's application): the library runs "
+                   "on ROCm's own HIP runtime")
+    print(json.dumps(out), flush=True)
 
 
 def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):

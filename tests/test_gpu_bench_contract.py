@@ -153,6 +153,7 @@ def test_the_default_line_carries_the_other_baseline_configs():
     assert ip["same_frames_as_host_trigger_finder"] and ip["first_frame_equals_oracle"] and ip["Mevents_per_s_end_to_end"] > 200
     assert ip["host_us_per_push"] < 20
     assert oc["esl"]["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
+    assert oc["esl"]["in_a_process_without_torch"]["ingest_path"]["same_frames_as_host_trigger_finder"]
     assert oc["graph60"]["latency_us"]["batch_of_60_frames"]["p50"] > 0 and oc["sharded_c10m"]["collective_ms"]["key_frame_merge"] > 0
 
 
@@ -166,3 +167,8 @@ def test_esl_line_carries_the_stream_legs():
     assert sl["full_replay_through_processor_host_trigger_finder"]["frames_shown"] == ip["frames_cut"]
     assert sl["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
     assert sl["from_evt3_words_period_chunks"]["overflow"] == 0 and sl["from_evt3_words_period_chunks"]["frames_cut"] > 20
+    # the same legs in a child process that never imports torch (the reference's situation): same frames, checked the same way
+    ch = sl["in_a_process_without_torch"]
+    assert "error" not in ch, ch
+    assert ch["ingest_path"]["same_frames_as_host_trigger_finder"] and ch["ingest_path"]["first_frame_equals_oracle"]
+    assert ch["ingest_path"]["frames_cut"] == ip["frames_cut"] and ch["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
