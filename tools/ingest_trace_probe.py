@@ -11,6 +11,7 @@ from x_maps_amd import _native as _N
 _N.debug_option("XM_INGEST_TRACE", "1")
 cp, tables, evs0, _ = rig.make_esl_like(row_stride=13)
 stream, _ = rig.render_stream(cp, tables, n_frames=48, row_stride=13, seed=9)
+WANT_BGR = os.environ.get("PROBE_NO_OUT") != "1"  # (PROBE_NO_OUT=1: no result frames cross PCIe -- what is left is the ingest itself)
 cap = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21
 mp = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
 with XMapsEngine(tables) as eng:
@@ -19,7 +20,7 @@ with XMapsEngine(tables) as eng:
     packet = int(1e6 / 60 / 4)
     cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
     for rep in range(3):
-        with DeviceIngest(eng, 60, capacity_events=cap, max_packet_events=mp, result_ring=64, want_depth=False, want_bgr=True) as ing:
+        with DeviceIngest(eng, 60, capacity_events=cap, max_packet_events=mp, result_ring=64, want_depth=False, want_bgr=WANT_BGR) as ing:
             for a, b in zip(cuts[:4], cuts[1:5]):
                 ing.push_pinned(pin[a:b])
             ing.flush(), ing.reset(), ing.poll(copy=False)
