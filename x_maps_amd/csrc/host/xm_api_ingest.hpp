@@ -21,6 +21,7 @@ struct xm_ingest {
   hipStream_t stream = nullptr;        // ingest kernels
   hipStream_t frame_stream = nullptr;  // K0 / K1 / K2 / publish of the frames that were cut
   hipStream_t copy_stream = nullptr;   // H2D of packet k+1 runs beside the kernels of packet k
+  hipStream_t out_stream = nullptr;    // DMA of a finished frame to the pinned result ring + its publish, beside the next frame's kernels
   u64 capacity = 0, max_packet = 0;    // capacity: a power of two (the request rounded up)
   double period = 0.0;
   long long act_thresh = 0;
@@ -34,7 +35,10 @@ struct xm_ingest {
   IngVerdict* d_verdicts = nullptr;    // ... and the address the device writes it at
   u32* first_idx = nullptr;            // activity filter: first event index of the sub-packet per pixel
   u32* keep = nullptr;                 // activity filter: keep flags of the (sub-)packet
-  static constexpr int NOUT = 2;       // device-side output frames (K2 writes them, a DMA copy takes them to the pinned result ring)
+  static constexpr int NOUT = 3;       // device-side output frames (K2 writes them, a DMA copy takes them to the pinned result ring)
+  hipEvent_t k2_ev[NOUT] = {};         // frame stream: K2 has written output frame o (the out stream's DMA waits for it)
+  hipEvent_t out_ev[NOUT] = {};        // out stream: output frame o has left for the result ring (the next K2 into it waits for that)
+  bool out_used[NOUT] = {};
   float* d_out_depth[NOUT] = {};
   uint8_t* d_out_bgr[NOUT] = {};
   float** d_depth_ring = nullptr;      // the NOUT pointers above, in device memory (k_ing_segment picks one per frame)
@@ -137,6 +141,10 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   hipEvent_t ev = g->k1_ev[g->frames_issued % 8];
   HIP_TRY(hipEventRecord(ev, s));
   HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
+  // K2 writes device output frame o = frame number % NOUT (k_ing_segment put its address into the descriptor) -- once the DMA of
+  // the frame that used it last has left
+  const int o = (int)(g->frames_issued % xm_ingest::NOUT);
+  if (g->out_used[o]) HIP_TRY(hipStreamWaitEvent(s, g->out_ev[o], 0));
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (h->k2_direct) return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");
     launch_k2_batch<0>(h, s, desc, 1);
@@ -144,14 +152,23 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
     const u64 px = (u64)h->tb.cam_w * h->tb.cam_h;
     hipLaunchKernelGGL(k_frame_direct_batch, dim3(grid_for(px, BLOCK), 1), dim3(BLOCK), 0, s, desc, px, h->tb.dlut);
   }
-  {  // device -> pinned result ring by DMA (frame numbers count on both sides: the verdicts arrive in packet order)
-    const size_t px = (size_t)h->out_w * h->out_h;
-    const int slot = (int)(g->frames_issued % (uint64_t)g->ring), o = (int)(g->frames_issued % xm_ingest::NOUT);
-    if (g->h_bgr[slot]) HIP_TRY(hipMemcpyAsync(g->h_bgr[slot], g->d_out_bgr[o], px * 3, hipMemcpyDeviceToHost, s));
-    if (g->h_depth[slot]) HIP_TRY(hipMemcpyAsync(g->h_depth[slot], g->d_out_depth[o], px * 4, hipMemcpyDeviceToHost, s));
-  }
+  // the frame's statistics into its status entry while the slot's counters and the frame's events are still the frame's ...
   hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->dev.st, desc, (const IngFrameInfo*)(g->d_infos + vi), g->h_status, (u64)push_no);
+  // ... device -> pinned result ring by DMA and the entry's sequence number behind it on the OUT stream: a 6 MB frame is 140 us
+  // on the link, during which the frame stream already runs the next frame's kernels (on one stream the frames came out one DMA
+  // + one kernel chain apart).  (frame numbers count on both sides: the verdicts arrive in packet order)
+  HIP_TRY(hipEventRecord(g->k2_ev[o], s));
+  HIP_TRY(hipStreamWaitEvent(g->out_stream, g->k2_ev[o], 0));
+  const int slot = (int)(g->frames_issued % (uint64_t)g->ring);
+  {
+    const size_t px = (size_t)h->out_w * h->out_h;
+    if (g->h_bgr[slot]) HIP_TRY(hipMemcpyAsync(g->h_bgr[slot], g->d_out_bgr[o], px * 3, hipMemcpyDeviceToHost, g->out_stream));
+    if (g->h_depth[slot]) HIP_TRY(hipMemcpyAsync(g->h_depth[slot], g->d_out_depth[o], px * 4, hipMemcpyDeviceToHost, g->out_stream));
+  }
+  hipLaunchKernelGGL(k_ing_publish_seq, dim3(1), dim3(64), 0, g->out_stream, g->dev.st, desc, g->h_status + slot, (u64)g->frames_issued);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(g->out_ev[o], g->out_stream));
+  g->out_used[o] = true;
   g->frames_issued += 1;
   return XM_OK;
 }
@@ -284,6 +301,7 @@ int ingest_finish(xm_ingest* g) {
   HIP_TRY(hipStreamSynchronize(g->copy_stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
   HIP_TRY(hipStreamSynchronize(g->frame_stream));
+  HIP_TRY(hipStreamSynchronize(g->out_stream));
   return XM_OK;
 }
 
@@ -439,6 +457,9 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));  // H2D of a packet beside the kernels of the previous one
   for (auto& e : g->copied_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : g->k1_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : g->k2_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : g->out_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  ING_TRY(hipStreamCreateWithPriority(&g->out_stream, hipStreamNonBlocking, hi));
   IngestDev& d = g->dev;
   d.cap = g->capacity;
   d.room = g->max_packet * (u64)(1 + g->ahead);
@@ -530,6 +551,7 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->frame_stream) (void)hipStreamSynchronize(g->frame_stream);
+  if (g->out_stream) (void)hipStreamSynchronize(g->out_stream);
   if (dbg_opt("XM_INGEST_TRACE"))
     fprintf(stderr, "[ingest] %llu packets, %llu frames, ahead %d: launch side %.3f ms in jobs, of which %.3f ms waiting for verdicts and %.3f ms "
             "issuing frames; caller %.3f ms in push, %.3f ms of it waiting for staging entries\n", (unsigned long long)g->issued,
@@ -564,6 +586,9 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   for (auto& e : g->copied_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : g->k1_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : g->k2_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : g->out_ev) if (e) (void)hipEventDestroy(e);
+  if (g->out_stream) (void)hipStreamDestroy(g->out_stream);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   if (g->frame_stream) (void)hipStreamDestroy(g->frame_stream);
   delete g;

@@ -550,7 +550,9 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_segment(IngestDev d, Ingest
   __hip_atomic_store(&d.verdict->push_no, p.push_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// after the frame kernels (same stream): statistics + sequence number into the pinned ring (system scope: the host polls it)
+// after the frame kernels (same stream, before the next frame's kernels touch the slot's counters): the frame's statistics into
+// its entry of the pinned status ring -- everything but the sequence number, which k_ing_publish_seq writes once the frame's
+// outputs have arrived in host memory
 __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const FrameDesc* __restrict__ desc, const IngFrameInfo* __restrict__ info,
                                                     IngestStatus* ring_status, u64 push_seq) {
   if (!desc->valid) return;
@@ -579,9 +581,15 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
   out->live_after = info->live_after;
   out->push_seq = push_seq;
   out->overflow = info->overflow;
-  st->published = info->frame_no + 1;
   __threadfence_system();
-  __hip_atomic_store(&out->seq, info->frame_no + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// behind the DMA copies of the frame's outputs (out stream): the sequence number, written last (system scope: the host polls it)
+__global__ __launch_bounds__(64) void k_ing_publish_seq(IngestState* st, const FrameDesc* __restrict__ desc, IngestStatus* out, u64 frame_no) {
+  if (threadIdx.x != 0 || !desc->valid) return;
+  st->published = frame_no + 1;
+  __threadfence_system();
+  __hip_atomic_store(&out->seq, frame_no + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace xm
