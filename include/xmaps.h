@@ -158,7 +158,7 @@ typedef struct xm_frame_stats {
 /* ---- lifetime ---------------------------------------------------------------------------------- */
 /* Variant switches for tests and experiments ("XM_COLS", "XM_K2_PIPE", "XM_K2_PIPE_PPT", "XM_K2_CONSEC", "XM_K2_NLDS_MAX",
  * "XM_K2_PPT", "XM_K2_FLAGS", "XM_K1_DIRECT", "XM_K2_DIRECT", "XM_KEY32", "XM_OWN_W", "XM_OWN_SHEAR", "XM_WORKERS", "XM_XMAP_SCAN",
- * "XM_INGEST_CLEAR_EVERY", "XM_INGEST_TRACE"; values as text).  Process-wide, read when a handle / an ingest is created (XM_XMAP_SCAN:
+ * "XM_INGEST_CLEAR_EVERY", "XM_INGEST_TRACE", "XM_INGEST_OUT_PIECE", "XM_INGEST_OUT_SERIAL", "XM_SHARDED_KEYS"; values as text).  Process-wide, read when a handle / an ingest is created (XM_XMAP_SCAN:
  * at every call).  The library never reads them from the environment.  value == NULL removes an option, name == NULL all. */
 int xm_debug_option(const char* name, const char* value);
 int xm_api_version(void);

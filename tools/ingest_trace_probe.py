@@ -4,6 +4,9 @@ import os, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("PROBE_TORCH") == "1":  # (PyTorch's bundled HIP runtime serves the process, as in bench.py)
+    import torch
+    torch.cuda.init()
 import numpy as np
 from x_maps_amd import XMapsEngine, rig, synthetic as S
 from x_maps_amd.ingest import DeviceIngest
@@ -21,7 +24,8 @@ with XMapsEngine(tables) as eng:
     cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
     for rep in range(3):
         with DeviceIngest(eng, 60, capacity_events=cap, max_packet_events=mp, result_ring=64, want_depth=False, want_bgr=WANT_BGR) as ing:
-            for a, b in zip(cuts[:4], cuts[1:5]):
+            nw = int(os.environ.get("PROBE_WARM", "4"))
+            for a, b in zip(cuts[:nw], cuts[1:nw + 1]):
                 ing.push_pinned(pin[a:b])
             ing.flush(), ing.reset(), ing.poll(copy=False)
             c0 = time.perf_counter()

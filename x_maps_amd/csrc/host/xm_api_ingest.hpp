@@ -8,7 +8,10 @@
 //   launch thread   per packet: H2D on the copy stream, then k_ing_count / k_ing_append / k_ing_segment on the INGEST stream.
 //                   k_ing_segment leaves a 16-byte verdict in pinned memory (did the packet cut a frame, of how many events);
 //                   the thread reads the verdicts in packet order and, for a packet that cut a frame, launches K0 -> K1 -> K2 ->
-//                   DMA to the pinned result ring -> publish on the FRAME stream with exact grids.
+//                   statistics on the FRAME stream with exact grids.
+//   out thread      per cut frame: the DMA copies of its outputs (one of three device frames -> the pinned result ring, in 4 MB
+//                   pieces) and its sequence number on the OUT stream, behind the frame's K2 -- beside the next frame's kernels.
+//                   (A thread of its own because enqueuing a copy behind a running one can block the caller.)
 //   xm_ingest_poll  reads the result ring's sequence numbers (pinned memory, no API call)
 // The ingest stream may be `ahead` packets in front of the verdict the thread has handled last (0 on small rings: each packet's
 // verdict is awaited before the next is issued); k_ing_segment's room rule keeps that many packets' worth of the ring free, and
@@ -21,7 +24,8 @@ struct xm_ingest {
   hipStream_t stream = nullptr;        // ingest kernels
   hipStream_t frame_stream = nullptr;  // K0 / K1 / K2 / publish of the frames that were cut
   hipStream_t copy_stream = nullptr;   // H2D of packet k+1 runs beside the kernels of packet k
-  hipStream_t out_stream = nullptr;    // DMA of a finished frame to the pinned result ring + its publish, beside the next frame's kernels
+  hipStream_t out_stream = nullptr;    // DMA of a finished frame to the pinned result ring + its sequence number, beside the next frame's
+                                       // kernels (two out streams taking turns were slower: two 6 MB copies at once share the link)
   u64 capacity = 0, max_packet = 0;    // capacity: a power of two (the request rounded up)
   double period = 0.0;
   long long act_thresh = 0;
@@ -38,7 +42,28 @@ struct xm_ingest {
   static constexpr int NOUT = 3;       // device-side output frames (K2 writes them, a DMA copy takes them to the pinned result ring)
   hipEvent_t k2_ev[NOUT] = {};         // frame stream: K2 has written output frame o (the out stream's DMA waits for it)
   hipEvent_t out_ev[NOUT] = {};        // out stream: output frame o has left for the result ring (the next K2 into it waits for that)
-  bool out_used[NOUT] = {};
+  // The out stream's work is enqueued by a thread of its own (with a launch thread; inline without): hipMemcpyAsync of a second
+  // copy onto a stream whose previous copy is still running BLOCKS its caller in the HIP 7.0 runtime PyTorch bundles (seen: 160 us
+  // per frame, 7 ms per 43 frames, whenever the copies ran slower than the frames came) -- it must not be the launch thread.
+  struct OutJob {
+    uint64_t frame_no = 0;
+    int slot = 0, o = 0;
+    const FrameDesc* desc = nullptr;
+  };
+  std::thread out_th;
+  bool out_threaded = false;
+  std::atomic<bool> out_stop{false}, out_sleeping{false};
+  std::mutex out_mu;
+  std::condition_variable out_cv;
+  OutJob out_ring[8];                  // (the launch side never runs more than NOUT frames ahead of out_done)
+  std::atomic<uint64_t> out_posted{0}; // frames handed to the out side
+  std::atomic<uint64_t> out_done{0};   // frames whose copies + sequence number have been ENQUEUED on the out stream (out_ev[o] recorded)
+  std::atomic<int> out_error{0};
+  std::string out_error_text;
+  bool out_on_frame_stream = false;    // "XM_INGEST_OUT_SERIAL" = 1: copies + sequence number on the frame stream, in order with the frames' kernels (A/B)
+  size_t out_piece = 4u << 20;         // bytes per D2H copy of a result frame ("XM_INGEST_OUT_PIECE")
+  double t_out_wait_s = 0.0;           // XM_INGEST_TRACE: launch side waiting for the out side to have enqueued frame f - NOUT
+  double t_out_s = 0.0;                // XM_INGEST_TRACE: host seconds the out side spent enqueuing
   float* d_out_depth[NOUT] = {};
   uint8_t* d_out_bgr[NOUT] = {};
   float** d_depth_ring = nullptr;      // the NOUT pointers above, in device memory (k_ing_segment picks one per frame)
@@ -97,7 +122,86 @@ inline double ingest_now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// K0 -> K1 -> K2 -> publish for the frame that packet `push_no` cut (n events), on the frame stream
+// one frame's work on the out stream: wait for its K2, copy its outputs to the pinned result ring, the sequence number behind them
+int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
+  xm_handle* h = g->h;
+  hipStream_t os = g->out_on_frame_stream ? g->frame_stream : g->out_stream;
+  // A copy enqueued behind one that is still running can block its caller for as long as that one runs -- inside the runtime,
+  // with other threads' calls waiting behind it: the previous frame's copies are seen off first (a query loop, no blocking call).
+  if (g->out_threaded && j.frame_no > 0 && !dbg_opt("XM_INGEST_OUT_NO_QUERY")) {
+    const int po = (int)((j.frame_no - 1) % xm_ingest::NOUT);
+    for (int i = 0; hipEventQuery(g->out_ev[po]) == hipErrorNotReady; ++i)
+      for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
+    (void)hipGetLastError();
+  }
+  const double t0 = ingest_now();
+  HIP_TRY(hipStreamWaitEvent(os, g->k2_ev[j.o], 0));
+  const size_t px = (size_t)h->out_w * h->out_h;
+  // In pieces of 4 MB: with one frame per packet (EVT 3.0 period chunks) whole 6 MB copies gave 620-870 Mev/s in an ingest's first
+  // minutes and 1170-1210 later, pieces 1130 every time (tools/esl_evt3_probe.py); 1 MB pieces overflow a queue of the runtime
+  // and stall for milliseconds (tools/ubench/dma_mix.cpp), so the option does not go below 2 MB.
+  const size_t piece = g->out_piece;
+  const auto copy_out = [&](void* dst, const void* src, size_t bytes) -> int {
+    for (size_t off = 0; off < bytes; off += piece)
+      HIP_TRY(hipMemcpyAsync((char*)dst + off, (const char*)src + off, std::min(piece, bytes - off), hipMemcpyDeviceToHost, os));
+    return XM_OK;
+  };
+  int rc;
+  if (g->h_bgr[j.slot] && (rc = copy_out(g->h_bgr[j.slot], g->d_out_bgr[j.o], px * 3))) return rc;
+  if (g->h_depth[j.slot] && (rc = copy_out(g->h_depth[j.slot], g->d_out_depth[j.o], px * 4))) return rc;
+  hipLaunchKernelGGL(k_ing_publish_seq, dim3(1), dim3(64), 0, os, g->dev.st, j.desc, g->h_status + j.slot, (u64)j.frame_no);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(g->out_ev[j.o], os));
+  // (nothing else is issued on this stream until the next frame: without a query the runtime kept the last copy and the sequence
+  //  number in its batch until some other call of the process flushed it -- seen in the copy trace: the second piece of a frame
+  //  starting 90 us after the first, together with the next packet's H2D copy)
+  (void)hipStreamQuery(os);
+  g->t_out_s += ingest_now() - t0;
+  return XM_OK;
+}
+
+void ingest_out_main(xm_ingest* g) {
+  (void)hipSetDevice(g->h->cfg.device);
+  uint64_t n = 0;  // the next frame to take
+  for (;;) {
+    // A frame's copy should start the moment its K2 is on the stream (with one frame per packet the copies are what bounds the
+    // pipe: a sleeping thread's wake-up would go straight into the frame period): spin for about a millisecond before sleeping.
+    for (int i = 0; g->out_posted.load(std::memory_order_acquire) == n; ++i) {
+      if (g->out_stop.load(std::memory_order_acquire)) return;
+      if (i < 40000) {
+        __builtin_ia32_pause();
+        continue;
+      }
+      std::unique_lock<std::mutex> lk(g->out_mu);
+      g->out_sleeping.store(true, std::memory_order_seq_cst);
+      g->out_cv.wait(lk, [&] { return g->out_stop.load(std::memory_order_acquire) || g->out_posted.load(std::memory_order_acquire) != n; });
+      g->out_sleeping.store(false, std::memory_order_relaxed);
+      i = 0;
+    }
+    const xm_ingest::OutJob j = g->out_ring[n % 8];
+    if (!g->out_error.load(std::memory_order_relaxed)) {
+      const int rc = ingest_out_frame(g, j);
+      if (rc) {
+        g->out_error_text = g_err;  // (thread-local text of this thread)
+        g->out_error.store(rc, std::memory_order_release);
+      }
+    }
+    n += 1;
+    g->out_done.store(n, std::memory_order_release);
+  }
+}
+
+// every frame issued so far has its out-stream work enqueued
+int ingest_out_drain(xm_ingest* g) {
+  while (g->out_done.load(std::memory_order_acquire) < g->frames_issued) {
+    if (g->out_error.load(std::memory_order_acquire)) break;
+    std::this_thread::yield();
+  }
+  if (g->out_error.load(std::memory_order_acquire)) return fail(g->out_error.load(), "ingest, out side: %s", g->out_error_text.c_str());
+  return XM_OK;
+}
+
+// K0 -> K1 -> K2 -> statistics for the frame that packet `push_no` cut (n events), on the frame stream; its copies to the out side
 int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   xm_handle* h = g->h;
   hipStream_t s = g->frame_stream;
@@ -143,8 +247,18 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
   // K2 writes device output frame o = frame number % NOUT (k_ing_segment put its address into the descriptor) -- once the DMA of
   // the frame that used it last has left
-  const int o = (int)(g->frames_issued % xm_ingest::NOUT);
-  if (g->out_used[o]) HIP_TRY(hipStreamWaitEvent(s, g->out_ev[o], 0));
+  const uint64_t f = g->frames_issued;
+  const int o = (int)(f % xm_ingest::NOUT);
+  if (f >= (uint64_t)xm_ingest::NOUT) {
+    // (the event must have been RECORDED by the out side before this stream can be told to wait for it)
+    const double tw = ingest_now();
+    while (g->out_done.load(std::memory_order_acquire) + xm_ingest::NOUT <= f) {
+      if (g->out_error.load(std::memory_order_acquire)) return fail(g->out_error.load(), "ingest, out side: %s", g->out_error_text.c_str());
+      __builtin_ia32_pause();
+    }
+    g->t_out_wait_s += ingest_now() - tw;
+    HIP_TRY(hipStreamWaitEvent(s, g->out_ev[o], 0));
+  }
   if (h->cfg.view == XM_VIEW_PROJECTOR) {
     if (h->k2_direct) return fail(XM_ERR_INVALID, "ingest needs the tiled frame kernel (XM_K2_DIRECT is set)");
     launch_k2_batch<0>(h, s, desc, 1);
@@ -154,21 +268,28 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   }
   // the frame's statistics into its status entry while the slot's counters and the frame's events are still the frame's ...
   hipLaunchKernelGGL(k_ing_publish, dim3(1), dim3(64), 0, s, g->dev.st, desc, (const IngFrameInfo*)(g->d_infos + vi), g->h_status, (u64)push_no);
+  HIP_TRY(hipGetLastError());
   // ... device -> pinned result ring by DMA and the entry's sequence number behind it on the OUT stream: a 6 MB frame is 140 us
   // on the link, during which the frame stream already runs the next frame's kernels (on one stream the frames came out one DMA
   // + one kernel chain apart).  (frame numbers count on both sides: the verdicts arrive in packet order)
   HIP_TRY(hipEventRecord(g->k2_ev[o], s));
-  HIP_TRY(hipStreamWaitEvent(g->out_stream, g->k2_ev[o], 0));
-  const int slot = (int)(g->frames_issued % (uint64_t)g->ring);
-  {
-    const size_t px = (size_t)h->out_w * h->out_h;
-    if (g->h_bgr[slot]) HIP_TRY(hipMemcpyAsync(g->h_bgr[slot], g->d_out_bgr[o], px * 3, hipMemcpyDeviceToHost, g->out_stream));
-    if (g->h_depth[slot]) HIP_TRY(hipMemcpyAsync(g->h_depth[slot], g->d_out_depth[o], px * 4, hipMemcpyDeviceToHost, g->out_stream));
+  xm_ingest::OutJob job;
+  job.frame_no = f;
+  job.slot = (int)(f % (uint64_t)g->ring);
+  job.o = o;
+  job.desc = desc;
+  if (g->out_threaded) {
+    g->out_ring[f % 8] = job;
+    g->out_posted.store(f + 1, std::memory_order_seq_cst);
+    if (g->out_sleeping.load(std::memory_order_seq_cst)) {
+      std::lock_guard<std::mutex> lk(g->out_mu);
+      g->out_cv.notify_one();
+    }
+  } else {
+    int rc = ingest_out_frame(g, job);
+    if (rc) return rc;
+    g->out_done.store(f + 1, std::memory_order_release);
   }
-  hipLaunchKernelGGL(k_ing_publish_seq, dim3(1), dim3(64), 0, g->out_stream, g->dev.st, desc, g->h_status + slot, (u64)g->frames_issued);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(g->out_ev[o], g->out_stream));
-  g->out_used[o] = true;
   g->frames_issued += 1;
   return XM_OK;
 }
@@ -301,6 +422,7 @@ int ingest_finish(xm_ingest* g) {
   HIP_TRY(hipStreamSynchronize(g->copy_stream));
   HIP_TRY(hipStreamSynchronize(g->stream));
   HIP_TRY(hipStreamSynchronize(g->frame_stream));
+  if ((rc = ingest_out_drain(g))) return rc;
   HIP_TRY(hipStreamSynchronize(g->out_stream));
   return XM_OK;
 }
@@ -459,7 +581,13 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   for (auto& e : g->k1_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : g->k2_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : g->out_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  ING_TRY(hipStreamCreateWithPriority(&g->out_stream, hipStreamNonBlocking, hi));
+  {
+    int prio = hi;  // "XM_INGEST_OUT_PRIO": h(igh, the default) / n(ormal) / l(ow) -- which pool of hardware queues the out stream lives in
+    if (const char* e = dbg_opt("XM_INGEST_OUT_PRIO")) prio = e[0] == 'l' ? lo : e[0] == 'n' ? (lo + hi) / 2 : hi;
+    ING_TRY(hipStreamCreateWithPriority(&g->out_stream, hipStreamNonBlocking, prio));
+  }
+  if (const char* e = dbg_opt("XM_INGEST_OUT_PIECE")) g->out_piece = std::max<size_t>(2u << 20, (size_t)atoll(e));
+  if (const char* e = dbg_opt("XM_INGEST_OUT_SERIAL")) g->out_on_frame_stream = e[0] == '1';
   IngestDev& d = g->dev;
   d.cap = g->capacity;
   d.room = g->max_packet * (u64)(1 + g->ahead);
@@ -522,10 +650,10 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   // (the first DMA into a pinned buffer is several times slower than the later ones -- seen as 0.2 ms per frame for the first
   //  round through the ring: every entry takes one copy now)
   for (int i = 0; i < g->ring; ++i) {
-    if (cfg->want_depth) ING_TRY(hipMemcpyAsync(g->h_depth[i], g->d_out_depth[0], px * 4, hipMemcpyDeviceToHost, g->frame_stream));
-    if (cfg->want_bgr) ING_TRY(hipMemcpyAsync(g->h_bgr[i], g->d_out_bgr[0], px * 3, hipMemcpyDeviceToHost, g->frame_stream));
+    if (cfg->want_depth) ING_TRY(hipMemcpyAsync(g->h_depth[i], g->d_out_depth[i % xm_ingest::NOUT], px * 4, hipMemcpyDeviceToHost, g->out_stream));
+    if (cfg->want_bgr) ING_TRY(hipMemcpyAsync(g->h_bgr[i], g->d_out_bgr[i % xm_ingest::NOUT], px * 3, hipMemcpyDeviceToHost, g->out_stream));
   }
-  ING_TRY(hipStreamSynchronize(g->frame_stream));
+  ING_TRY(hipStreamSynchronize(g->out_stream));
   d.depth_ring = g->d_depth_ring;
   d.bgr_ring = g->d_bgr_ring;
   ING_TRY(hipDeviceSynchronize());  // (the memsets above ran on the default stream, which the ingest's non-blocking streams do not wait for)
@@ -533,6 +661,10 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   if (!(cfg->flags & XM_INGEST_NO_LAUNCH_THREAD)) {
     g->threaded = true;
     g->th = std::thread(ingest_thread_main, g);
+    if (!g->out_on_frame_stream && !dbg_opt("XM_INGEST_OUT_INLINE")) {
+      g->out_threaded = true;
+      g->out_th = std::thread(ingest_out_main, g);
+    }
   }
   *out = g;
   return XM_OK;
@@ -548,6 +680,16 @@ void xm_ingest_destroy(xm_ingest* g) {
     if (g->th.joinable()) g->th.join();
     g->threaded = false;
   }
+  if (g->out_threaded) {  // (behind the launch thread: nobody posts any more; the queue is drained before the thread leaves)
+    (void)ingest_out_drain(g);  // (every posted frame is taken before the thread is told to leave)
+    {
+      std::lock_guard<std::mutex> lk(g->out_mu);
+      g->out_stop.store(true, std::memory_order_seq_cst);
+    }
+    g->out_cv.notify_all();
+    if (g->out_th.joinable()) g->out_th.join();
+    g->out_threaded = false;
+  }
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->frame_stream) (void)hipStreamSynchronize(g->frame_stream);
@@ -557,6 +699,10 @@ void xm_ingest_destroy(xm_ingest* g) {
             "issuing frames; caller %.3f ms in push, %.3f ms of it waiting for staging entries\n", (unsigned long long)g->issued,
             (unsigned long long)g->frames_issued, g->ahead, g->t_jobs_s * 1e3, g->t_block_s * 1e3, g->t_frames_s * 1e3, g->push_host_s * 1e3,
             g->push_wait_s * 1e3);
+  if (dbg_opt("XM_INGEST_TRACE"))
+    fprintf(stderr, "[ingest] out side (%s): %.3f ms enqueuing %llu frames' copies + sequence numbers; the launch side waited %.3f ms for it\n",
+            g->cfg.flags & XM_INGEST_NO_LAUNCH_THREAD ? "inline" : "a thread of its own", g->t_out_s * 1e3, (unsigned long long)g->out_done.load(),
+            g->t_out_wait_s * 1e3);
   IngestDev& d = g->dev;
   if (d.buf) (void)hipFree(d.buf);
   if (d.pring) (void)hipFree(d.pring);

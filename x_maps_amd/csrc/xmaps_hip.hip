@@ -17,6 +17,7 @@
 #include <mutex>
 #include <thread>
 #include <cstdarg>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

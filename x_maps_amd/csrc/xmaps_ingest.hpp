@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
 // behind the DMA copies of the frame's outputs (out stream): the sequence number, written last (system scope: the host polls it)
 __global__ __launch_bounds__(64) void k_ing_publish_seq(IngestState* st, const FrameDesc* __restrict__ desc, IngestStatus* out, u64 frame_no) {
   if (threadIdx.x != 0 || !desc->valid) return;
-  st->published = frame_no + 1;
+  atomicMax((unsigned long long*)&st->published, (unsigned long long)(frame_no + 1));  // (two out streams: not always in frame order)
   __threadfence_system();
   __hip_atomic_store(&out->seq, frame_no + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
