@@ -572,6 +572,10 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
   }
   if (threadIdx.x != 0) return;
   IngestStatus* out = ring_status + desc->pad;
+  // (a reader that the ring has lapped may be copying this entry right now: the sequence number goes first, so that its second
+  //  look at it fails -- the new one follows only when the frame's outputs have arrived, a whole copy later)
+  __hip_atomic_store(&out->seq, (u64)0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
   out->n_events = desc->n;
   out->t_first = desc->n ? rec_t(desc->aos[0]) : 0;
   out->t_last = desc->n ? rec_t(desc->aos[desc->n - 1]) : 0;
