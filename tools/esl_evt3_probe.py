@@ -33,7 +33,7 @@ with XMapsEngine(tables) as eng:
     for piece in pieces:
         N.debug_option("XM_INGEST_OUT_PIECE", str(abs(piece)))
         N.debug_option("XM_INGEST_OUT_SERIAL", "1" if piece < 0 else "0")
-        N.debug_option("XM_INGEST_OUT_PRIO", os.environ.get("PROBE_OUT_PRIO", "h"))
+        N.debug_option("XM_INGEST_PRIOS", os.environ.get("PROBE_PRIOS"))
         N.debug_option("XM_INGEST_OUT_INLINE", "1" if os.environ.get("PROBE_OUT_INLINE") == "1" else None)
         if os.environ.get("PROBE_RECORDS_FIRST") == "1":
             with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, result_ring=64, want_depth=False) as ing:

@@ -60,6 +60,8 @@ struct xm_ingest {
   std::atomic<uint64_t> out_done{0};   // frames whose copies + sequence number have been ENQUEUED on the out stream (out_ev[o] recorded)
   std::atomic<int> out_error{0};
   std::string out_error_text;
+  bool streams_borrowed = false;       // the four streams are the handle's (xm_host.hpp), else own_streams
+  hipStream_t own_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   bool out_on_frame_stream = false;    // "XM_INGEST_OUT_SERIAL" = 1: copies + sequence number on the frame stream, in order with the frames' kernels (A/B)
   size_t out_piece = 4u << 20;         // bytes per D2H copy of a result frame ("XM_INGEST_OUT_PIECE")
   double t_out_wait_s = 0.0;           // XM_INGEST_TRACE: launch side waiting for the out side to have enqueued frame f - NOUT
@@ -574,18 +576,24 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   } while (0)
   int lo = 0, hi = 0;
   ING_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  ING_TRY(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, hi));
-  ING_TRY(hipStreamCreateWithPriority(&g->frame_stream, hipStreamNonBlocking, hi));
-  ING_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));  // H2D of a packet beside the kernels of the previous one
+  // "XM_INGEST_PRIOS": four letters h / n / l = the priority pools of the ingest, frame, copy and out stream (A/B; default below).
+  // The streams are the handle's (see xm_host.hpp): the first ingest on it creates them, one ingest at a time borrows them.
+  const char* pr = dbg_opt("XM_INGEST_PRIOS");
+  if (!pr || strlen(pr) != 4) pr = "hhnh";
+  const auto prio_of = [&](char c) { return c == 'l' ? lo : c == 'n' ? (lo + hi) / 2 : hi; };
+  g->streams_borrowed = !h->ing_streams_lent && !dbg_opt("XM_INGEST_OWN_STREAMS");
+  hipStream_t* set = g->streams_borrowed ? h->ing_streams : g->own_streams;
+  if (g->streams_borrowed) h->ing_streams_lent = true;
+  for (int i = 0; i < 4; ++i)
+    if (!set[i]) ING_TRY(hipStreamCreateWithPriority(&set[i], hipStreamNonBlocking, prio_of(pr[i])));
+  g->stream = set[0];        // ingest kernels
+  g->frame_stream = set[1];  // the cut frames' kernels
+  g->copy_stream = set[2];   // H2D of a packet beside the kernels of the previous one
+  g->out_stream = set[3];    // the result frames' copies + sequence numbers
   for (auto& e : g->copied_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : g->k1_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : g->k2_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : g->out_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  {
-    int prio = hi;  // "XM_INGEST_OUT_PRIO": h(igh, the default) / n(ormal) / l(ow) -- which pool of hardware queues the out stream lives in
-    if (const char* e = dbg_opt("XM_INGEST_OUT_PRIO")) prio = e[0] == 'l' ? lo : e[0] == 'n' ? (lo + hi) / 2 : hi;
-    ING_TRY(hipStreamCreateWithPriority(&g->out_stream, hipStreamNonBlocking, prio));
-  }
   if (const char* e = dbg_opt("XM_INGEST_OUT_PIECE")) g->out_piece = std::max<size_t>(2u << 20, (size_t)atoll(e));
   if (const char* e = dbg_opt("XM_INGEST_OUT_SERIAL")) g->out_on_frame_stream = e[0] == '1';
   IngestDev& d = g->dev;
@@ -729,14 +737,13 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->h_status) (void)hipHostFree(g->h_status);
   for (auto p : g->h_depth) if (p) (void)hipHostFree(p);
   for (auto p : g->h_bgr) if (p) (void)hipHostFree(p);
-  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+
   for (auto& e : g->copied_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : g->k1_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : g->k2_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : g->out_ev) if (e) (void)hipEventDestroy(e);
-  if (g->out_stream) (void)hipStreamDestroy(g->out_stream);
-  if (g->stream) (void)hipStreamDestroy(g->stream);
-  if (g->frame_stream) (void)hipStreamDestroy(g->frame_stream);
+  for (auto& s : g->own_streams) if (s) (void)hipStreamDestroy(s);
+  if (g->streams_borrowed) g->h->ing_streams_lent = false;
   delete g;
 }
 
