@@ -434,7 +434,6 @@ void xm_destroy(xm_handle* h) {
   if (h->h_descs) (void)hipHostFree(h->h_descs);
   if (h->d_descs) (void)hipFree(h->d_descs);
   if (h->d_shard_n) (void)hipFree(h->d_shard_n);
-  for (auto& s : h->ing_streams) if (s) (void)hipStreamDestroy(s);
   for (auto gs : h->gstreams) if (gs) (void)hipStreamDestroy(gs);
   for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);

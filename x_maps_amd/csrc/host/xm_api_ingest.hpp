@@ -60,7 +60,7 @@ struct xm_ingest {
   std::atomic<uint64_t> out_done{0};   // frames whose copies + sequence number have been ENQUEUED on the out stream (out_ev[o] recorded)
   std::atomic<int> out_error{0};
   std::string out_error_text;
-  bool streams_borrowed = false;       // the four streams are the handle's (xm_host.hpp), else own_streams
+  bool streams_borrowed = false;       // the four streams are the process's set for the device (ingest_stream_set), else own_streams
   hipStream_t own_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   bool out_on_frame_stream = false;    // "XM_INGEST_OUT_SERIAL" = 1: copies + sequence number on the frame stream, in order with the frames' kernels (A/B)
   size_t out_piece = 4u << 20;         // bytes per D2H copy of a result frame ("XM_INGEST_OUT_PIECE")
@@ -119,6 +119,37 @@ struct xm_ingest {
 };
 
 namespace {
+
+// The ingest's four streams (ingest / frame / copy / out) come from ONE set per device and process: created by the first ingest,
+// lent to one ingest at a time (another one that is alive at the same time makes its own), never destroyed.  Which hardware
+// resources a set of streams lands on decides how well the ingest's stages overlap, and it depends on what the process created
+// before: the FIRST set runs a stream of records packets at 1055-1105 Mev/s, a set created after another one was destroyed at
+// 680-750 (the other way round for one-frame-per-packet EVT 3.0 chunks: 840-890 against 1100-1200) -- measured, not understood
+// (profiles/r04_ingest.md section 5).  Keeping the first set makes every ingest of the process behave like its first one.
+struct IngestStreamSet {
+  hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool lent = false;
+};
+std::mutex g_ing_sets_mu;
+std::map<int, IngestStreamSet> g_ing_sets;
+
+// take = true: borrow the device's set (false when somebody has it); take = false: hand out the borrowed set's array
+bool ingest_stream_set(int device, bool take, hipStream_t** out) {
+  std::lock_guard<std::mutex> lk(g_ing_sets_mu);
+  IngestStreamSet& e = g_ing_sets[device];
+  if (take) {
+    if (e.lent) return false;
+    e.lent = true;
+    return true;
+  }
+  if (out) *out = e.s;
+  return true;
+}
+
+void ingest_stream_release(int device) {
+  std::lock_guard<std::mutex> lk(g_ing_sets_mu);
+  g_ing_sets[device].lent = false;
+}
 
 inline double ingest_now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -577,13 +608,13 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   int lo = 0, hi = 0;
   ING_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   // "XM_INGEST_PRIOS": four letters h / n / l = the priority pools of the ingest, frame, copy and out stream (A/B; default below).
-  // The streams are the handle's (see xm_host.hpp): the first ingest on it creates them, one ingest at a time borrows them.
+  // The streams come from the process's set for this device (ingest_stream_set below) when nobody else has it.
   const char* pr = dbg_opt("XM_INGEST_PRIOS");
   if (!pr || strlen(pr) != 4) pr = "hhnh";
   const auto prio_of = [&](char c) { return c == 'l' ? lo : c == 'n' ? (lo + hi) / 2 : hi; };
-  g->streams_borrowed = !h->ing_streams_lent && !dbg_opt("XM_INGEST_OWN_STREAMS");
-  hipStream_t* set = g->streams_borrowed ? h->ing_streams : g->own_streams;
-  if (g->streams_borrowed) h->ing_streams_lent = true;
+  g->streams_borrowed = !dbg_opt("XM_INGEST_OWN_STREAMS") && ingest_stream_set(h->cfg.device, true, nullptr);
+  hipStream_t* set = g->own_streams;
+  if (g->streams_borrowed) (void)ingest_stream_set(h->cfg.device, false, &set);
   for (int i = 0; i < 4; ++i)
     if (!set[i]) ING_TRY(hipStreamCreateWithPriority(&set[i], hipStreamNonBlocking, prio_of(pr[i])));
   g->stream = set[0];        // ingest kernels
@@ -743,7 +774,7 @@ void xm_ingest_destroy(xm_ingest* g) {
   for (auto& e : g->k2_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : g->out_ev) if (e) (void)hipEventDestroy(e);
   for (auto& s : g->own_streams) if (s) (void)hipStreamDestroy(s);
-  if (g->streams_borrowed) g->h->ing_streams_lent = false;
+  if (g->streams_borrowed) ingest_stream_release(g->h->cfg.device);
   delete g;
 }
 

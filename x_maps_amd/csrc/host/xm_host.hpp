@@ -163,12 +163,6 @@ struct xm_handle {
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line
   SlotState* d_states = nullptr;  // n_slots + 1 (last = aux state for stage / shard calls)
   SlotState* aux_st = nullptr;
-  // The ingest's four streams (ingest / frame / copy / out) belong to the HANDLE: created by its first xm_ingest_create, lent to
-  // one ingest at a time, destroyed with the handle.  (Which hardware queues a set of streams lands on decides how well the
-  // ingest's stages overlap -- the first set a process creates runs a records stream 50 % faster than a later set does,
-  // profiles/r04_ingest.md section 5 -- so the set is kept instead of being recreated per ingest.)
-  hipStream_t ing_streams[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ing_streams_lent = false;
   u64* d_shard_n = nullptr;  // shards on the column tiles: the piece's own event count (device) + its FrameDesc behind it
   std::vector<Slot> slots;
   int next_slot = 0;
