@@ -56,6 +56,7 @@ int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned
 
 // decode + everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
 int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned) {
+  g->out_serial_now = !dbg_opt("XM_INGEST_EVT3_OUT_STREAM");  // (see xm_ingest::out_serial_now)
   if (n_words) {
     int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream);
     if (rc) return rc;

@@ -49,6 +49,7 @@ struct xm_ingest {
     uint64_t frame_no = 0;
     int slot = 0, o = 0;
     const FrameDesc* desc = nullptr;
+    bool serial = false;               // on the frame stream, in order with the frames' kernels (see out_serial_now)
   };
   std::thread out_th;
   bool out_threaded = false;
@@ -62,7 +63,11 @@ struct xm_ingest {
   std::string out_error_text;
   bool streams_borrowed = false;       // the four streams are the process's set for the device (ingest_stream_set), else own_streams
   hipStream_t own_streams[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool out_on_frame_stream = false;    // "XM_INGEST_OUT_SERIAL" = 1: copies + sequence number on the frame stream, in order with the frames' kernels (A/B)
+  bool out_on_frame_stream = false;    // "XM_INGEST_OUT_SERIAL" = 1: copies + sequence number ALWAYS on the frame stream, in order with the frames' kernels (A/B)
+  // Launch side: the frames cut from now on leave on the frame stream.  Set while the packets are EVT 3.0 chunks decoded on the
+  // device (typically one frame per chunk: there the in-order form measured 1000 Mev/s against 840-920 on the out stream,
+  // tools/esl_evt3_probe.py), cleared for packets of records (1055-1105 on the out stream against 950).
+  bool out_serial_now = false;
   size_t out_piece = 4u << 20;         // bytes per D2H copy of a result frame ("XM_INGEST_OUT_PIECE")
   double t_out_wait_s = 0.0;           // XM_INGEST_TRACE: launch side waiting for the out side to have enqueued frame f - NOUT
   double t_out_s = 0.0;                // XM_INGEST_TRACE: host seconds the out side spent enqueuing
@@ -158,10 +163,10 @@ inline double ingest_now() {
 // one frame's work on the out stream: wait for its K2, copy its outputs to the pinned result ring, the sequence number behind them
 int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
   xm_handle* h = g->h;
-  hipStream_t os = g->out_on_frame_stream ? g->frame_stream : g->out_stream;
+  hipStream_t os = j.serial ? g->frame_stream : g->out_stream;
   // A copy enqueued behind one that is still running can block its caller for as long as that one runs -- inside the runtime,
   // with other threads' calls waiting behind it: the previous frame's copies are seen off first (a query loop, no blocking call).
-  if (g->out_threaded && j.frame_no > 0 && !dbg_opt("XM_INGEST_OUT_NO_QUERY")) {
+  if (g->out_threaded && !j.serial && j.frame_no > 0 && !dbg_opt("XM_INGEST_OUT_NO_QUERY")) {
     const int po = (int)((j.frame_no - 1) % xm_ingest::NOUT);
     for (int i = 0; hipEventQuery(g->out_ev[po]) == hipErrorNotReady; ++i)
       for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
@@ -211,8 +216,16 @@ void ingest_out_main(xm_ingest* g) {
       g->out_sleeping.store(false, std::memory_order_relaxed);
       i = 0;
     }
+    {  // frames below out_done are done (the launch side took them itself while this thread slept): their entries may be gone
+      const uint64_t d = g->out_done.load(std::memory_order_acquire);
+      if (d > n) {
+        n = d;
+        continue;
+      }
+    }
     const xm_ingest::OutJob j = g->out_ring[n % 8];
-    if (!g->out_error.load(std::memory_order_relaxed)) {
+    // (a frame the launch side took itself -- out_serial_now -- is only counted: its entry says so, or holds another frame by now)
+    if (j.frame_no == n && !j.serial && !g->out_error.load(std::memory_order_relaxed)) {
       const int rc = ingest_out_frame(g, j);
       if (rc) {
         g->out_error_text = g_err;  // (thread-local text of this thread)
@@ -220,8 +233,19 @@ void ingest_out_main(xm_ingest* g) {
       }
     }
     n += 1;
-    g->out_done.store(n, std::memory_order_release);
+    for (uint64_t cur = g->out_done.load(std::memory_order_acquire); cur < n;)
+      if (g->out_done.compare_exchange_weak(cur, n, std::memory_order_release)) break;
   }
+}
+
+// frames below `upto` have their out work enqueued
+int ingest_out_drain_upto(xm_ingest* g, uint64_t upto) {
+  while (g->out_done.load(std::memory_order_acquire) < upto) {
+    if (g->out_error.load(std::memory_order_acquire)) break;
+    __builtin_ia32_pause();
+  }
+  if (g->out_error.load(std::memory_order_acquire)) return fail(g->out_error.load(), "ingest, out side: %s", g->out_error_text.c_str());
+  return XM_OK;
 }
 
 // every frame issued so far has its out-stream work enqueued
@@ -311,7 +335,8 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   job.slot = (int)(f % (uint64_t)g->ring);
   job.o = o;
   job.desc = desc;
-  if (g->out_threaded) {
+  job.serial = g->out_on_frame_stream || g->out_serial_now;
+  if (g->out_threaded && !job.serial) {
     g->out_ring[f % 8] = job;
     g->out_posted.store(f + 1, std::memory_order_seq_cst);
     if (g->out_sleeping.load(std::memory_order_seq_cst)) {
@@ -319,8 +344,13 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
       g->out_cv.notify_one();
     }
   } else {
-    int rc = ingest_out_frame(g, job);
+    int rc = g->out_threaded ? ingest_out_drain_upto(g, f) : XM_OK;  // (frames posted before the mode changed come first)
+    if (!rc) rc = ingest_out_frame(g, job);
     if (rc) return rc;
+    if (g->out_threaded) {  // (the out thread only counts this one)
+      g->out_ring[f % 8] = job;
+      g->out_posted.store(f + 1, std::memory_order_seq_cst);
+    }
     g->out_done.store(f + 1, std::memory_order_release);
   }
   g->frames_issued += 1;
@@ -438,6 +468,7 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
 
 // the launches of one packet of records: H2D on the copy stream (beside the previous packets' kernels), then everything else
 int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
+  g->out_serial_now = false;
   if (n) {
     HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
     HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
