@@ -166,6 +166,46 @@ def test_in_front_of_the_device_ingest():
         ing1.close(); ing2.close(); ing3.close()
 
 
+def test_words_and_records_take_turns_on_one_ingest():
+    """a stream that arrives now as EVT 3.0 chunks, now as records (frames cut from chunks leave on the frame stream, frames cut
+    from records on the out stream: the two take turns inside one ingest) == the same packets as records throughout"""
+    from x_maps_amd.ingest import DeviceIngest
+    import test_gpu_ingest as TI
+    tb = S.make_tables(S.C_TINY)
+    fps = 60
+    stream = TI._tiny_stream(30, seed=11)
+    packets = [pk for pk in TI._packets(stream, int(1e6 / fps / 3)) if len(pk)]
+    with XMapsEngine(tb) as e1, XMapsEngine(tb) as e2:
+        with DeviceIngest(e1, fps, max_packet_events=8192, capacity_events=65536, result_ring=64) as mixed, \
+                DeviceIngest(e2, fps, max_packet_events=8192, capacity_events=65536, result_ring=64) as plain, \
+                evt3.DeviceEvt3Decoder(e1, max_words=8 * 8192) as dec:
+            got, want, keep = [], [], []
+            for i, pk in enumerate(packets):
+                if (i // 7) % 2 == 0:  # seven packets as words (count left on the device / waited for), seven as records, ...
+                    w = evt3.encode_evt3(pk)
+                    if i % 2:
+                        pw = e1.host_empty(w.shape, np.uint16)
+                        pw[:] = w
+                        keep.append(pw)
+                        dec.push(mixed, pw, pinned=True, count=False)
+                    else:
+                        assert dec.push(mixed, w) == len(pk)
+                    # (each chunk was encoded on its own and starts with TIME_HIGH / TIME_LOW: the packets the decoder did not see
+                    #  in between do not matter to it)
+                else:
+                    mixed.push(pk)
+                plain.push(pk)
+                if i % 5 == 0:
+                    got += mixed.poll()
+                    want += plain.poll()
+            mixed.flush(); plain.flush()
+            got += mixed.poll(); want += plain.poll()
+    assert len(got) == len(want) >= 20 and not any(f.lost or f.overflow for f in got)
+    for a, b in zip(got, want):
+        assert (a.seq, a.n_events, a.t_first, a.t_last, a.n_inliers) == (b.seq, b.n_events, b.t_first, b.t_last, b.n_inliers)
+        assert np.array_equal(a.depth, b.depth) and np.array_equal(a.bgr, b.bgr)
+
+
 def test_a_raw_file_through_the_processor(tmp_path):
     """DepthReprojectionProcessor.process_evt3_words (device ingest: words decoded on the GPU; host ingest: on the host) shows the
     same frames as process_events on the decoded packets"""
