@@ -158,7 +158,8 @@ typedef struct xm_frame_stats {
 /* ---- lifetime ---------------------------------------------------------------------------------- */
 /* Variant switches for tests and experiments ("XM_COLS", "XM_K2_PIPE", "XM_K2_PIPE_PPT", "XM_K2_CONSEC", "XM_K2_NLDS_MAX",
  * "XM_K2_PPT", "XM_K2_FLAGS", "XM_K1_DIRECT", "XM_K2_DIRECT", "XM_KEY32", "XM_OWN_W", "XM_OWN_SHEAR", "XM_WORKERS", "XM_XMAP_SCAN",
- * "XM_INGEST_CLEAR_EVERY", "XM_INGEST_TRACE", "XM_INGEST_OUT_PIECE", "XM_INGEST_OUT_SERIAL", "XM_SHARDED_KEYS"; values as text).  Process-wide, read when a handle / an ingest is created (XM_XMAP_SCAN:
+ * "XM_INGEST_CLEAR_EVERY", "XM_INGEST_TRACE", "XM_INGEST_OUT_PIECE", "XM_INGEST_OUT_SERIAL", "XM_INGEST_OUT_INLINE",
+ * "XM_INGEST_OUT_NO_QUERY", "XM_INGEST_EVT3_OUT_STREAM", "XM_INGEST_OWN_STREAMS", "XM_INGEST_PRIOS", "XM_SHARDED_KEYS"; values as text).  Process-wide, read when a handle / an ingest is created (XM_XMAP_SCAN:
  * at every call).  The library never reads them from the environment.  value == NULL removes an option, name == NULL all. */
 int xm_debug_option(const char* name, const char* value);
 int xm_api_version(void);
@@ -474,10 +475,14 @@ int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t
  * a power of two; its first half is mirrored behind its end, so a frame of up to capacity / 2 events is contiguous wherever it
  * starts and nothing is ever moved).  Per packet: three ingest launches (count, append, trigger finder -- pauses are found once,
  * when an event is appended, and kept in a ring of stream indices), the frame kernels K0 -> K1 -> K2 on the frame the DEVICE
- * described (a record in device memory, grids sized for the host's upper bound: no index and no event count ever travels to
- * the host), and one launch that publishes the result.  xm_ingest_push only copies the packet H2D (pinned staging ring, its
- * own stream) and enqueues those launches; finished frames appear in a ring of pinned host buffers and are picked up with
- * xm_ingest_poll.  One frame at most is cut per push, exactly like RobustTriggerFinder.process_events.
+ * described (a record in device memory; the host learns from a 16-byte verdict per packet WHETHER it cut a frame and launches
+ * the frame kernels with exact grids only then), the frame's statistics, and -- on a stream of their own, beside the next frame's
+ * kernels -- the DMA copies of its outputs to the result ring and the sequence number behind them.  xm_ingest_push only copies
+ * the packet H2D (pinned staging ring, its own stream) and enqueues those launches; finished frames appear in a ring of pinned
+ * host buffers and are picked up with xm_ingest_poll.  One frame at most is cut per push, exactly like
+ * RobustTriggerFinder.process_events.  Threads: a launch thread (per packet: the copy and the launches) and an out thread (per
+ * cut frame: the result copies) unless XM_INGEST_NO_LAUNCH_THREAD.  The four HIP streams come from one set per device and
+ * process, lent to one ingest at a time and never destroyed (an ingest alive beside another one creates its own).
  * Activity filter: Metavision's ActivityNoiseFilterAlgorithm is closed source; the rule implemented here (own definition,
  * same in oracle/ingest_oracle.py): an event is kept iff an EARLIER event of the stream at one of its 8 neighbouring
  * pixels has t - t' <= activity_thresh_us; every (positive) event then becomes its pixel's latest event. */
