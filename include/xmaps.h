@@ -562,6 +562,15 @@ int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const
  * n_events == NULL: nothing is waited for -- the ingest's kernels read the chunk's event count from device memory; a chunk that
  * decodes to more than max_packet_events is truncated to that and the excess counted in the frames' `overflow`. */
 int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events);
+/* The same for EVT 2.0 ("EVT2/EVT3 RAW reader"), the older of Prophesee's two public RAW encodings: 32-bit
+ * little-endian words, [31:28] type -- 0x0 CD_OFF / 0x1 CD_ON {t[5:0], x[10:0], y[10:0]}: one event, p = type; 0x8 EVT_TIME_HIGH
+ * {t[33:6]}: the time base of the words behind it; triggers and vendor words are skipped (x_maps_amd/csrc/xmaps_evt2.hpp; host
+ * form x_maps_amd/evt2.py, independent checker oracle/evt2_oracle.py).  xm_evt2_create makes a decoder OBJECT OF THE SAME TYPE
+ * for that encoding: xm_evt3_destroy / xm_evt3_reset serve it, xm_evt2_decode / xm_ingest_push_evt2 take its 32-bit words (the
+ * EVT 3.0 entry points refuse it and vice versa).  max_events = 0: max_words (a word is at most one event). */
+int xm_evt2_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out);
+int xm_evt2_decode(xm_evt3* d, const uint32_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
+int xm_ingest_push_evt2(xm_ingest* g, xm_evt3* d, const uint32_t* words_host, size_t n_words, int words_pinned, size_t* n_events);
 
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out);

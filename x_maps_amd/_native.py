@@ -202,6 +202,9 @@ SYMBOLS = {
     "xm_evt3_reset": (C.c_int, [_P]),
     "xm_evt3_decode": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "xm_ingest_push_evt3": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
+    "xm_evt2_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "xm_evt2_decode": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "xm_ingest_push_evt2": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
     "xm_eval_stats": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(xm_eval_result)]),
     "xm_build_x_map": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "xm_stream": (_P, [_P, C.c_int]),

@@ -1,4 +1,5 @@
-// xm_api_evt3.hpp -- C-ABI: EVT 3.0 words -> EventCD records on the device (xmaps_evt3.hpp), alone or straight into the ingest
+// xm_api_evt3.hpp -- C-ABI: EVT 3.0 / EVT 2.0 words -> EventCD records on the device (xmaps_evt3.hpp, xmaps_evt2.hpp), alone or
+// straight into the ingest.  One decoder object for both encodings (`format`): same buffers, same state record, same three launches.
 // (part of libxmaps_hip.so's host side: included by ../xmaps_hip.hip, one translation unit; see that file for the order)
 #pragma once
 
@@ -7,7 +8,9 @@ struct xm_evt3 {
   int device = 0;  // (kept here: the decoder may be destroyed after its handle)
   hipStream_t stream = nullptr;
   size_t max_words = 0, max_events = 0;
-  uint16_t* h_words = nullptr;   // pinned staging
+  int format = 3;                // 3: 16-bit EVT 3.0 words; 2: 32-bit EVT 2.0 words
+  size_t word_bytes = 2;
+  uint16_t* h_words = nullptr;   // pinned staging (max_words * word_bytes)
   uint16_t* d_words = nullptr;
   Evt3Scan* d_agg = nullptr;
   Evt3State* d_state = nullptr;  // [2]: in / out, swapped per chunk
@@ -20,16 +23,26 @@ namespace {
 
 // words (host) -> records at `out` (device, room for out_cap) enqueued on `stream`; the chunk's event count is left in
 // d->d_state[d->cur ^ 1].n_events (device memory) -- evt3_commit() flips `cur` once the caller has decided to keep the chunk
-int evt3_enqueue(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream) {
+int evt3_enqueue(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream) {
   if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
   if (!pinned) {  // pageable memory: through the pinned staging buffer, once its previous chunk has been copied out of it
     HIP_TRY(hipStreamSynchronize(stream));
-    memcpy(d->h_words, words_host, n_words * 2);
+    memcpy(d->h_words, words_host, n_words * d->word_bytes);
   }
-  HIP_TRY(hipMemcpyAsync(d->d_words, pinned ? words_host : d->h_words, n_words * 2, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(d->d_words, pinned ? words_host : (const void*)d->h_words, n_words * d->word_bytes, hipMemcpyHostToDevice, stream));
   const u32 n = (u32)n_words, nb = (u32)grid_for(n_words, EVT3_PER_BLOCK);
   Evt3State* st_in = d->d_state + d->cur;
   Evt3State* st_out = d->d_state + (d->cur ^ 1);
+  if (d->format == 2) {
+    const u32* w32 = reinterpret_cast<const u32*>(d->d_words);
+    Evt2Scan* agg = reinterpret_cast<Evt2Scan*>(d->d_agg);
+    hipLaunchKernelGGL(k_evt2_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, w32, n, agg);
+    hipLaunchKernelGGL(k_evt2_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, nb, agg, (const Evt3State*)st_in, st_out);
+    hipLaunchKernelGGL(k_evt2_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, w32, n, (const Evt2Scan*)agg, (const Evt3State*)st_in, out,
+                       (u32)std::min<size_t>(out_cap, 0xffffffffu));
+    HIP_TRY(hipGetLastError());
+    return XM_OK;
+  }
   hipLaunchKernelGGL(k_evt3_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, d->d_agg);
   hipLaunchKernelGGL(k_evt3_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, nb, d->d_agg, (const Evt3State*)st_in, st_out);
   hipLaunchKernelGGL(k_evt3_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, (const Evt3Scan*)d->d_agg,
@@ -39,7 +52,7 @@ int evt3_enqueue(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pi
 }
 
 // the synchronous form: *n_events once the count is back (synchronises the stream)
-int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
+int evt3_run(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream, size_t* n_events) {
   *n_events = 0;
   if (!n_words) return XM_OK;
   int rc = evt3_enqueue(d, words_host, n_words, pinned, out, out_cap, stream);
@@ -55,7 +68,7 @@ int evt3_run(xm_evt3* d, const uint16_t* words_host, size_t n_words, bool pinned
 }
 
 // decode + everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned) {
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned) {
   g->out_serial_now = !dbg_opt("XM_INGEST_EVT3_OUT_STREAM");  // (see xm_ingest::out_serial_now)
   if (n_words) {
     int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream);
@@ -65,8 +78,8 @@ int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, si
   }
   const Evt3State* st_out = d->d_state + (d->cur ^ 1);
   if (n_words) d->cur ^= 1;
-  // (upper bound of the chunk's events for the host's bookkeeping: a vector word yields up to 12, everything else at most one)
-  const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * 12);
+  // (upper bound of the chunk's events for the host's bookkeeping: an EVT 3.0 vector word yields up to 12, everything else at most one)
+  const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * (d->format == 2 ? 1 : 12));
   return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? reinterpret_cast<const u32*>(&st_out->n_events) : nullptr);
 }
 
@@ -74,7 +87,7 @@ int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, si
 
 extern "C" {
 
-int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out) {
+static int evt_create(xm_handle* h, int format, size_t max_words, size_t max_events, xm_evt3** out) {
   if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
   *out = nullptr;
   XM_ENTER(h);
@@ -82,8 +95,10 @@ int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** 
   if (!d) return fail(XM_ERR_NOMEM, "out of host memory");
   d->h = h;
   d->device = h->cfg.device;
+  d->format = format;
+  d->word_bytes = format == 2 ? 4 : 2;
   d->max_words = max_words ? max_words : (size_t)1 << 20;
-  d->max_events = max_events ? max_events : 2 * d->max_words;
+  d->max_events = max_events ? max_events : (format == 2 ? d->max_words : 2 * d->max_words);
   if (d->max_words >= 0x7fffffffull || d->max_events >= 0x7fffffffull) {
     delete d;
     return fail(XM_ERR_INVALID, "max_words and max_events must be < 2^31");
@@ -99,9 +114,9 @@ int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** 
     }                                                                            \
   } while (0)
   EV_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-  EV_TRY(hipHostMalloc((void**)&d->h_words, d->max_words * 2, hipHostMallocDefault));
+  EV_TRY(hipHostMalloc((void**)&d->h_words, d->max_words * d->word_bytes, hipHostMallocDefault));
   EV_TRY(hipHostMalloc((void**)&d->h_state, sizeof(Evt3State), hipHostMallocDefault));
-  EV_TRY(hipMalloc((void**)&d->d_words, d->max_words * 2 + 64));
+  EV_TRY(hipMalloc((void**)&d->d_words, d->max_words * d->word_bytes + 64));
   EV_TRY(hipMalloc((void**)&d->d_agg, (nb + 1) * sizeof(Evt3Scan)));
   EV_TRY(hipMalloc((void**)&d->d_state, 2 * sizeof(Evt3State)));
   EV_TRY(hipMemsetAsync(d->d_state, 0, 2 * sizeof(Evt3State), d->stream));  // (on the decoder's stream: it does not wait for the default one)
@@ -111,6 +126,9 @@ int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** 
   *out = d;
   return XM_OK;
 }
+
+int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out) { return evt_create(h, 3, max_words, max_events, out); }
+int xm_evt2_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out) { return evt_create(h, 2, max_words, max_events, out); }
 
 void xm_evt3_destroy(xm_evt3* d) {
   if (!d) return;
@@ -136,11 +154,19 @@ int xm_evt3_reset(xm_evt3* d) {
   return XM_OK;
 }
 
-int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events) {
+static int evt_decode(xm_evt3* d, int format, const void* words_host, size_t n_words, const void** events_dev, size_t* n_events) {
   if (!d || (n_words && !words_host) || !n_events) return fail(XM_ERR_INVALID, "NULL argument");
+  if (d->format != format) return fail(XM_ERR_INVALID, "this decoder was created for EVT %d.0 words", d->format);
   HIP_TRY(hipSetDevice(d->device));
   if (events_dev) *events_dev = d->d_out;
   return evt3_run(d, words_host, n_words, false, d->d_out, d->max_events, d->stream, n_events);
+}
+
+int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events) {
+  return evt_decode(d, 3, words_host, n_words, events_dev, n_events);
+}
+int xm_evt2_decode(xm_evt3* d, const uint32_t* words_host, size_t n_words, const void** events_dev, size_t* n_events) {
+  return evt_decode(d, 2, words_host, n_words, events_dev, n_events);
 }
 
 // The chunk is decoded on the DECODER's stream into the packet slot (free: its previous packet has been consumed) while the frame
@@ -149,8 +175,9 @@ int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const
 // n_events == NULL: nothing is waited for -- the ingest's kernels read the count from device memory (round 4); a chunk that
 // decodes to more than max_packet_events events is truncated to that many and the excess counted in the frames' `overflow`;
 // the words are handed to the ingest's launch thread like a packet of records (pageable words: the call returns once they have been copied).
-int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events) {
+static int ingest_push_words(xm_ingest* g, xm_evt3* d, int format, const void* words_host, size_t n_words, int words_pinned, size_t* n_events) {
   if (!g || !d || (n_words && !words_host)) return fail(XM_ERR_INVALID, "NULL argument");
+  if (d->format != format) return fail(XM_ERR_INVALID, "this decoder was created for EVT %d.0 words", d->format);
   if (g->h != d->h) return fail(XM_ERR_INVALID, "the decoder and the ingest belong to different handles");
   if (g->cfg.activity_filter)
     return fail(XM_ERR_INVALID, "the activity filter splits a packet by time stamps on the host: not for packets decoded on the device");
@@ -182,6 +209,13 @@ int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, si
   g->push_host_s += ingest_now() - c0;
   g->push_calls += 1;
   return rc;
+}
+
+int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, size_t n_words, int words_pinned, size_t* n_events) {
+  return ingest_push_words(g, d, 3, words_host, n_words, words_pinned, n_events);
+}
+int xm_ingest_push_evt2(xm_ingest* g, xm_evt3* d, const uint32_t* words_host, size_t n_words, int words_pinned, size_t* n_events) {
+  return ingest_push_words(g, d, 2, words_host, n_words, words_pinned, n_events);
 }
 
 }  // extern "C"

@@ -477,7 +477,7 @@ int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
   return ingest_process(g, k, n, hp);
 }
 
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const uint16_t* words, size_t n_words, bool pinned);  // (xm_api_evt3.hpp)
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned);  // (xm_api_evt3.hpp)
 
 // every verdict in, every frame's kernels launched and run
 int ingest_finish(xm_ingest* g) {
@@ -494,7 +494,7 @@ int ingest_finish(xm_ingest* g) {
 int ingest_run_job(xm_ingest* g, const xm_ingest::Job& j) {
   switch (j.kind) {
     case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host);
-    case 1: return ingest_issue_evt3(g, j.dec, j.k, (const uint16_t*)j.host, j.n, j.pinned);
+    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned);
     case 3: return ingest_process(g, j.k, j.n, nullptr);
     case 4: return ingest_finish(g);
     default: return XM_OK;

@@ -8,6 +8,7 @@
 #include "xmaps_k2pipe.hpp"
 #include "xmaps_ingest.hpp"
 #include "xmaps_evt3.hpp"
+#include "xmaps_evt2.hpp"
 
 #include <hip/hip_ext.h>
 

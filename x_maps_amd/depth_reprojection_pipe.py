@@ -79,7 +79,7 @@ class DepthReprojectionPipe:
         # device-side ingest (row N2): raw packets go to the GPU, which filters, buffers, cuts frames and runs the hot path on
         # them without the event stream (or any index into it) coming back to the host
         self.ingest = None
-        self._evt3_dev = self._evt3_host = None  # EVT 3.0 decoders (process_evt3_words), created on first use
+        self._raw_dev, self._raw_host = {}, {}  # EVT 3.0 / 2.0 decoders (process_evt3_words / process_evt2_words), created on first use
         if getattr(p, "device_ingest", False):
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
@@ -110,18 +110,29 @@ class DepthReprojectionPipe:
         """A chunk of a recording's EVT 3.0 words (x_maps_amd.evt3.read_raw_words) instead of an EventCD packet: decoded on the
         device in front of the ingest when `device_ingest` is on (the words cross PCIe as the file stores them), on the host
         otherwise.  What Metavision's reader + process_events do together in the reference (bias_events_iterator.py:53-96)."""
-        from . import evt3
+        self._process_raw_words(words, 3)
+
+    def process_evt2_words(self, words):
+        """the same for EVT 2.0 words (x_maps_amd.evt2.read_raw_words): 32-bit words, the encoding of older sensors"""
+        self._process_raw_words(words, 2)
+
+    def _process_raw_words(self, words, fmt):
+        from . import evt2, evt3
+        mod, dt = (evt2, "<u4") if fmt == 2 else (evt3, "<u2")
         if self.ingest is not None and not getattr(self.params, "activity_filter", False):
-            if self._evt3_dev is None:
-                self._evt3_dev = evt3.DeviceEvt3Decoder(self.calib_maps.engine, max_words=1 << 20)
-            w = np.ascontiguousarray(words, dtype="<u2")
-            for a in range(0, len(w), self._evt3_dev.max_words):
-                self._evt3_dev.push(self.ingest, w[a:a + self._evt3_dev.max_words])
+            dev = self._raw_dev.get(fmt)
+            if dev is None:
+                cls = evt2.DeviceEvt2Decoder if fmt == 2 else evt3.DeviceEvt3Decoder
+                dev = self._raw_dev[fmt] = cls(self.calib_maps.engine, max_words=1 << 20)
+            w = np.ascontiguousarray(words, dtype=dt)
+            for a in range(0, len(w), dev.max_words):
+                dev.push(self.ingest, w[a:a + dev.max_words])
                 self._deliver_ingest_frames()
             return
-        if self._evt3_host is None:
-            self._evt3_host = evt3.Evt3Decoder()
-        evs = self._evt3_host.decode(words)
+        host = self._raw_host.get(fmt)
+        if host is None:
+            host = self._raw_host[fmt] = mod.Evt2Decoder() if fmt == 2 else mod.Evt3Decoder()
+        evs = host.decode(words)
         if len(evs):
             self.process_events(evs)
 
@@ -213,9 +224,9 @@ class DepthReprojectionPipe:
         if getattr(self, "_replay_engine", None) is not None:
             self._replay_engine.close()
             self._replay_engine = None
-        if getattr(self, "_evt3_dev", None) is not None:  # (before the engine it belongs to)
-            self._evt3_dev.close()
-            self._evt3_dev = None
+        for dev in getattr(self, "_raw_dev", {}).values():  # (before the engine they belong to)
+            dev.close()
+        self._raw_dev = {}
         if self.ingest is not None:
             self.ingest.close()
         self.calib_maps.engine.close()

@@ -129,6 +129,12 @@ class DepthReprojectionProcessor:
         self._pipe.process_evt3_words(words)
         self.stats_printer.print_stats_if_needed()
 
+    def process_evt2_words(self, words):
+        """the same for a chunk of EVT 2.0 words (x_maps_amd.evt2.read_raw_words)"""
+        self.stats_printer.print_stats_if_needed()
+        self._pipe.process_evt2_words(words)
+        self.stats_printer.print_stats_if_needed()
+
     def flush(self):
         """Device ingest: wait for the packets pushed so far and deliver the frames they produced."""
         self._pipe.flush()
