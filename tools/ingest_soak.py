@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the device ingest (round 4's form: event ring, verdicts, launch thread, frame stream + DMA): random streams in random
 packets through random configurations -- launch thread on / off, activity filter on / off, rings from tiny (many wrap-arounds,
-no run-ahead) to roomy (run-ahead 3), pageable / pinned packets, EVT 3.0 words with the count left on the device, polling after
+no run-ahead) to roomy (run-ahead 3), pageable / pinned packets, EVT 3.0 / EVT 2.0 words with the count left on the device, polling after
 every push or only at the end -- against the CPU chain (oracle/ingest_oracle.py + xmaps_oracle.py): the same frames (first / last
 stamp, length, inliers, depth) every time.
 
@@ -17,7 +17,7 @@ import numpy as np
 
 import ingest_oracle as IO
 import xmaps_oracle as O
-from x_maps_amd import XMapsEngine, evt3, synthetic as S
+from x_maps_amd import XMapsEngine, evt2, evt3, synthetic as S
 from x_maps_amd.ingest import DeviceIngest
 import test_gpu_ingest as TI
 
@@ -45,7 +45,8 @@ with XMapsEngine(tb) as eng:
             pk = [p for q in pk for p in (q, stream[:0])][:len(pk) + 5]  # empty packets in between
         activity = bool(rng.random() < 0.25)
         thread = bool(rng.random() < 0.7)
-        words = (not activity) and bool(rng.random() < 0.25)
+        words = (not activity) and bool(rng.random() < 0.35)
+        fmt = 2 if (words and rng.random() < 0.5) else 3  # EVT 2.0 or EVT 3.0 words
         pinned = bool(rng.random() < 0.5)
         poll_each = bool(rng.random() < 0.5)
         max_pk = max(2048, 1 << int(np.ceil(np.log2(max(len(p) for p in pk) + 1))))
@@ -61,12 +62,12 @@ with XMapsEngine(tb) as eng:
         keep = []
         with DeviceIngest(eng, 60, activity_filter=activity, capacity_events=cap, max_packet_events=max_pk, result_ring=64,
                           launch_thread=thread) as ing:
-            dec = evt3.DeviceEvt3Decoder(eng, max_words=8 * max_pk) if words else None
+            dec = (evt2.DeviceEvt2Decoder(eng, max_words=8 * max_pk) if fmt == 2 else evt3.DeviceEvt3Decoder(eng, max_words=8 * max_pk)) if words else None
             for p in pk:
                 if words:
-                    w = evt3.encode_evt3(p)
+                    w = evt2.encode_evt2(p, time_high_every_us=16) if fmt == 2 else evt3.encode_evt3(p)
                     if pinned and len(w):
-                        pw = eng.host_empty(w.shape, np.uint16)
+                        pw = eng.host_empty(w.shape, w.dtype)
                         pw[:] = w
                         keep.append(pw)
                         dec.push(ing, pw, pinned=True, count=False)
@@ -86,7 +87,7 @@ with XMapsEngine(tb) as eng:
             dstat = ing.device_stats()
             if dec is not None:
                 dec.close()
-        desc = dict(seed=seed, frames=n_frames, packets=len(pk), mode=mode, activity=activity, thread=thread, words=words, pinned=pinned,
+        desc = dict(seed=seed, frames=n_frames, packets=len(pk), mode=mode, activity=activity, thread=thread, words=words, fmt=fmt, pinned=pinned,
                     poll_each=poll_each, cap=cap, max_pk=max_pk)
         overflow = max([f.overflow for f in got] + [dstat["events_dropped"]])
         if overflow or any(f.lost for f in got):

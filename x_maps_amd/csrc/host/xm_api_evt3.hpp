@@ -23,7 +23,10 @@ namespace {
 
 // words (host) -> records at `out` (device, room for out_cap) enqueued on `stream`; the chunk's event count is left in
 // d->d_state[d->cur ^ 1].n_events (device memory) -- evt3_commit() flips `cur` once the caller has decided to keep the chunk
-int evt3_enqueue(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream) {
+// count_out (device, may be NULL): the chunk's event count once more, in a cell of the caller's (the state record's copy is
+// overwritten two chunks later -- too soon for a consumer on another stream)
+int evt3_enqueue(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, uint4* out, size_t out_cap, hipStream_t stream,
+                 u32* count_out = nullptr) {
   if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
   if (!pinned) {  // pageable memory: through the pinned staging buffer, once its previous chunk has been copied out of it
     HIP_TRY(hipStreamSynchronize(stream));
@@ -37,14 +40,15 @@ int evt3_enqueue(xm_evt3* d, const void* words_host, size_t n_words, bool pinned
     const u32* w32 = reinterpret_cast<const u32*>(d->d_words);
     Evt2Scan* agg = reinterpret_cast<Evt2Scan*>(d->d_agg);
     hipLaunchKernelGGL(k_evt2_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, w32, n, agg);
-    hipLaunchKernelGGL(k_evt2_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, nb, agg, (const Evt3State*)st_in, st_out);
+    hipLaunchKernelGGL(k_evt2_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, nb, agg, (const Evt3State*)st_in, st_out, count_out);
     hipLaunchKernelGGL(k_evt2_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, w32, n, (const Evt2Scan*)agg, (const Evt3State*)st_in, out,
                        (u32)std::min<size_t>(out_cap, 0xffffffffu));
     HIP_TRY(hipGetLastError());
     return XM_OK;
   }
   hipLaunchKernelGGL(k_evt3_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, d->d_agg);
-  hipLaunchKernelGGL(k_evt3_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, nb, d->d_agg, (const Evt3State*)st_in, st_out);
+  hipLaunchKernelGGL(k_evt3_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, nb, d->d_agg, (const Evt3State*)st_in, st_out,
+                     count_out);
   hipLaunchKernelGGL(k_evt3_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, (const Evt3Scan*)d->d_agg,
                      (const Evt3State*)st_in, out, (u32)std::min<size_t>(out_cap, 0xffffffffu));
   HIP_TRY(hipGetLastError());
@@ -71,16 +75,15 @@ int evt3_run(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, ui
 int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned) {
   g->out_serial_now = !dbg_opt("XM_INGEST_EVT3_OUT_STREAM");  // (see xm_ingest::out_serial_now)
   if (n_words) {
-    int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream);
+    int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream, g->d_pkt_n + k);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->copied_ev[k], d->stream));
     HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
   }
-  const Evt3State* st_out = d->d_state + (d->cur ^ 1);
   if (n_words) d->cur ^= 1;
   // (upper bound of the chunk's events for the host's bookkeeping: an EVT 3.0 vector word yields up to 12, everything else at most one)
   const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * (d->format == 2 ? 1 : 12));
-  return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? reinterpret_cast<const u32*>(&st_out->n_events) : nullptr);
+  return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? g->d_pkt_n + k : nullptr);
 }
 
 }  // namespace

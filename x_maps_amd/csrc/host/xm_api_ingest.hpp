@@ -79,6 +79,8 @@ struct xm_ingest {
   static constexpr int STAGE = 16;
   uint4* h_pkt[STAGE] = {};
   uint4* d_pkt[STAGE] = {};
+  u32* d_pkt_n = nullptr;              // [STAGE] event counts of chunks decoded on the device (written by the decoder's prefix kernel,
+                                       // read by the ingest kernels of the packet: one cell per staging entry, free when the entry is)
   hipEvent_t copied_ev[STAGE] = {};    // per staging entry: its H2D has finished (the ingest stream waits for it)
   uint64_t pkt_push[STAGE] = {};       // number of the push that used the entry last (0: never): free once that push's verdict is in
   int pkt_next = 0;
@@ -699,6 +701,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
     ING_TRY(hipHostMalloc((void**)&g->h_pkt[i], g->max_packet * 16, hipHostMallocDefault));
     ING_TRY(hipMalloc((void**)&g->d_pkt[i], g->max_packet * 16));
+    if (!g->d_pkt_n) ING_TRY(hipMalloc((void**)&g->d_pkt_n, xm_ingest::STAGE * sizeof(u32)));
   }
   ING_TRY(hipHostMalloc((void**)&g->h_status, sizeof(IngestStatus) * g->ring, hipHostMallocMapped));
   memset(g->h_status, 0, sizeof(IngestStatus) * g->ring);
@@ -785,6 +788,7 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->d_infos) (void)hipFree(g->d_infos);
   if (g->h_verdicts) (void)hipHostFree(g->h_verdicts);
   if (g->first_idx) (void)hipFree(g->first_idx);
+  if (g->d_pkt_n) (void)hipFree(g->d_pkt_n);
   if (g->keep) (void)hipFree(g->keep);
   if (g->d_depth_ring) (void)hipFree(g->d_depth_ring);
   if (g->d_bgr_ring) (void)hipFree(g->d_bgr_ring);

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_aggregate(const u32* __re
 // 2. one block: exclusive scan of the aggregates, seeded with the previous chunk's state; the chunk's event count and the state
 //    for the next chunk (the EVT 3.0 record: only t_high, t_loops and n_events are used)
 __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_prefix(u32 n_blocks, Evt2Scan* __restrict__ agg, const Evt3State* __restrict__ st_in,
-                                                             Evt3State* __restrict__ st_out) {
+                                                             Evt3State* __restrict__ st_out, u32* __restrict__ count_out) {
   __shared__ Evt2Scan buf[2][EVT3_THREADS];
   __shared__ Evt2Scan s_incl[EVT3_THREADS];
   const Evt3State s = *st_in;
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_prefix(u32 n_blocks, Evt2
     o.t_loops = s.t_loops + carry.hi_wraps;
     o.n_events = carry.n_ev;
     *st_out = o;
+    if (count_out) *count_out = carry.n_ev;  // (a cell of the consumer's: this record is rewritten two chunks from now)
   }
 }
 

@@ -138,7 +138,8 @@ __device__ __forceinline__ void evt3_resolve(const Evt3Scan& r, const Evt3State&
 // 2. one block: exclusive scan of the aggregates, seeded with the previous chunk's state; the chunk's event count and the state
 //    for the next chunk
 __global__ __launch_bounds__(EVT3_THREADS) void k_evt3_prefix(const uint16_t* __restrict__ words, u32 n_blocks, Evt3Scan* __restrict__ agg,
-                                                             const Evt3State* __restrict__ st_in, Evt3State* __restrict__ st_out) {
+                                                             const Evt3State* __restrict__ st_in, Evt3State* __restrict__ st_out,
+                                                             u32* __restrict__ count_out) {
   __shared__ Evt3Scan buf[2][EVT3_THREADS];
   const Evt3State s = *st_in;
   Evt3Scan carry = evt3_seed(s);
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt3_prefix(const uint16_t* __
     o.t_loops = loops;
     o.n_events = carry.n_ev;
     *st_out = o;
+    if (count_out) *count_out = carry.n_ev;  // (a cell of the consumer's: this record is rewritten two chunks from now)
   }
 }
 
