@@ -194,8 +194,14 @@ static int ingest_push_words(xm_ingest* g, xm_evt3* d, int format, const void* w
   xm_ingest::Job j;
   j.k = k;
   if (n_events) {
-    // the decoder runs here, on its own stream (the launch thread touches neither the decoder nor this packet slot meanwhile);
-    // the records then go to the launch side like a packet that is already on the device
+    // the decoder runs here, on its own stream -- once the launch thread is done with every chunk handed to it before (those
+    // use the same decoder: its state index and buffers are not to be touched from two threads) -- and the records then go to
+    // the launch side like a packet that is already on the device
+    if (g->threaded) {
+      const unsigned long long posted = g->q_head.load(std::memory_order_acquire);
+      while (g->q_done.load(std::memory_order_acquire) < posted && !g->q_error.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+      if ((rc = ingest_take_error(g))) return rc;
+    }
     size_t n = 0;
     rc = evt3_run(d, words_host, n_words, words_pinned != 0, g->d_pkt[k], (size_t)g->max_packet, d->stream, &n);
     *n_events = n;
