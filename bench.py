@@ -1420,16 +1420,27 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
             for pk in packets:
                 ing.push_pinned(pk)
             ing.flush(), ing.reset(), ing.poll(copy=False)
-            hs0 = ing.host_stats()
-            c0 = time.perf_counter()
-            for pk in packets:
-                ing.push_pinned(pk)
-            c1 = time.perf_counter()
-            ing.flush()
-            got = ing.poll(copy=not views)
-            dt = time.perf_counter() - c0
-            hs = ing.host_stats()
-            same = [(f.t_first, f.t_last, f.n_events) for f in got] == want and not any(f.lost or f.overflow for f in got)
+            # three timed passes over the stream, the median one reported (under the HIP runtime PyTorch bundles a fresh ingest's
+            # first passes run at anything between 0.45 and 1.0 of its settled rate; in a process without torch they do not)
+            passes = []
+            for rep in range(3):
+                if rep:
+                    ing.reset(), ing.poll(copy=False)
+                hs0 = ing.host_stats()
+                c0 = time.perf_counter()
+                for pk in packets:
+                    ing.push_pinned(pk)
+                c1 = time.perf_counter()
+                ing.flush()
+                got = ing.poll(copy=not views)
+                t_pass = time.perf_counter() - c0
+                same_pass = [(f.t_first, f.t_last, f.n_events) for f in got] == want and not any(f.lost or f.overflow for f in got)
+                passes.append((t_pass, c1 - c0, len(got), hs0, ing.host_stats(), same_pass))
+            all_dt = [round(p[0] * 1e3, 3) for p in passes]
+            dt, push_dt, n_got, hs0, hs, _ = sorted(passes, key=lambda p: p[0])[1]
+            c1 = c0 + push_dt
+            same_all = all(p[5] for p in passes)  # (every pass cut the reference's frames; `got` = the last pass: its views are intact)
+            same = same_all
             ok = None
             if got and same and O is not None:
                 e0 = want_frames[0]
@@ -1444,6 +1455,7 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                                                      + hs0["seconds_waiting_for_the_gpu"]) / max(n_push, 1) * 1e6, 2),
                           "host_us_per_push_incl_backpressure": round((hs["host_seconds_in_push"] - hs0["host_seconds_in_push"]) / max(n_push, 1) * 1e6, 2),
                           "push_loop_ms": round((c1 - c0) * 1e3, 3), "staging_waits": hs["staging_waits"] - hs0["staging_waits"],
+                          "passes_ms": all_dt,
                           "outputs": ("BGR u8" + (" + depth f32" if want_depth else "")) + (", views into the pinned result ring" if views else ", fresh arrays (copied out of the ring)"),
                           "pcie_GBps_out": round(len(got) * eng.out_h * eng.out_w * (3 + (4 if want_depth else 0)) / dt / 1e9, 2)}
     run(False, True, "ingest_path")                      # what frame_callback gets in the reference: the BGR frame
