@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XM_API_VERSION 2
+#define XM_API_VERSION 3
 
 /* error codes */
 #define XM_OK 0
@@ -473,7 +473,7 @@ int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t
  * (p == 1), activity-noise filter, buffering, pause detection (diff(t) >= 40 us), frame cut (> 1/2 period, <= 1 period,
  * > 1000 events, 2 events trimmed on both sides) -- as kernels over a device-resident event RING (capacity_events rounded up to
  * a power of two; its first half is mirrored behind its end, so a frame of up to capacity / 2 events is contiguous wherever it
- * starts and nothing is ever moved).  Per packet: three ingest launches (count, append, trigger finder -- pauses are found once,
+ * starts and nothing is ever moved).  Per packet: three ingest launches (four with the activity filter) (count, append, trigger finder -- pauses are found once,
  * when an event is appended, and kept in a ring of stream indices), the frame kernels K0 -> K1 -> K2 on the frame the DEVICE
  * described (a record in device memory; the host learns from a 16-byte verdict per packet WHETHER it cut a frame and launches
  * the frame kernels with exact grids only then), the frame's statistics, and -- on a stream of their own, beside the next frame's
@@ -483,9 +483,13 @@ int xm_find_pauses(xm_handle* h, const int64_t* t, const void* eventcd16, size_t
  * RobustTriggerFinder.process_events.  Threads: a launch thread (per packet: the copy and the launches) and an out thread (per
  * cut frame: the result copies) unless XM_INGEST_NO_LAUNCH_THREAD.  The four HIP streams come from one set per device and
  * process, lent to one ingest at a time and never destroyed (an ingest alive beside another one creates its own).
- * Activity filter: Metavision's ActivityNoiseFilterAlgorithm is closed source; the rule implemented here (own definition,
- * same in oracle/ingest_oracle.py): an event is kept iff an EARLIER event of the stream at one of its 8 neighbouring
- * pixels has t - t' <= activity_thresh_us; every (positive) event then becomes its pixel's latest event. */
+ * Activity filter (the reference builds and runs one unconditionally, depth_reprojection_pipe.py:65-67,116-117): Metavision's
+ * ActivityNoiseFilterAlgorithm comes as a binary with the SDK; the rule implemented here (own definition, same in
+ * oracle/ingest_oracle.py, which lists what is known of the differences): an event is kept iff an EARLIER event of the stream at
+ * one of its 8 neighbouring pixels has t - t' <= activity_thresh_us; every (positive) event then joins its pixel's history.
+ * Evaluated on the device for every kind of packet -- records, pinned records, EVT 3.0 / 2.0 chunks decoded there -- by one more
+ * launch per packet; exact for any event order (a packet whose stamps run backwards or span more than 8 thresholds is judged
+ * sequentially on the device: slow, same result).  A stricter comparison (t - t' < T) is activity_thresh_us = T - 1. */
 typedef struct xm_ingest xm_ingest;
 typedef struct xm_ingest_config {
   uint32_t struct_size;            /* = sizeof(xm_ingest_config) */
@@ -539,6 +543,23 @@ int xm_ingest_device_stats(xm_ingest* g, uint64_t* frames_cut, uint64_t* events_
  * Any pointer may be NULL. */
 int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in_push, uint64_t* staging_waits, double* seconds_waiting);
 
+/* ---- the activity filter alone ---------------------------------------------------------------------------------------
+ * For a host that keeps the trigger finder on the CPU (the default DepthReprojectionPipe of this build): what
+ * `self.act_filter.process_events(self.pos_events_buf, act_out_buf)` is in the reference (depth_reprojection_pipe.py:116-117,
+ * the filter built at :65-67 as ActivityNoiseFilterAlgorithm(width, height, int(1e6 / fps))).  One packet of 16-byte EventCD
+ * records in host memory, one keep flag (0 / 1) per event out; the per-pixel history stays on the device between calls.  EVERY
+ * event handed in takes part (the pipe hands the filter positive events only).  Same rule, kernels and exactness as the
+ * ingest's filter above.  Synchronous; thresh_us as activity_thresh_us there (but not defaulted: pass int(1e6 / fps)). */
+typedef struct xm_activity xm_activity;
+int xm_activity_create(xm_handle* h, int64_t thresh_us, size_t max_packet_events /* 0 => 2^19; longer packets go through in pieces */,
+                       xm_activity** out);
+void xm_activity_destroy(xm_activity* f);
+int xm_activity_process(xm_activity* f, const void* eventcd16, size_t n, uint8_t* keep_out, size_t* n_kept /* nullable */);
+int xm_activity_reset(xm_activity* f); /* forget the history */
+/* packets (pieces) so far whose stamps ran backwards or spanned more than 8 thresholds: judged sequentially on the device */
+int xm_activity_stats(xm_activity* f, uint64_t* sequential_packets);
+int xm_ingest_activity_stats(xm_ingest* g, uint64_t* sequential_packets); /* the same for an ingest's filter (synchronises) */
+
 /* ---- EVT 3.0 words -> EventCD records on the device --------------------------------------------------------------
  * The reader in front of the ingest for recordings (Prophesee RAW files, EVT 3.0: a public format; the reference reads them
  * through Metavision's closed RawReaderBase, python/bias_events_iterator.py:53-96).  The 16-bit words cross PCIe as they are
@@ -554,7 +575,7 @@ int xm_evt3_reset(xm_evt3* d); /* forget the state: the next chunk starts a stre
  * XM_ERR_TOO_MANY if the chunk has more words than max_words or decodes to more events than max_events. */
 int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
 /* One chunk of words as ONE packet of the ingest: decoded straight into the packet's slot on the decoder's own stream, then
- * everything xm_ingest_push does behind the copy.  Not with the activity filter (it splits a packet by time stamps on the host).
+ * everything xm_ingest_push does behind the copy (the activity filter included, when the ingest has it on).
  * words_pinned != 0: the words lie in pinned host memory (xm_host_alloc) and are copied from there (untouched until 16 further chunks have been
  * pushed or xm_ingest_flush() has returned).
  * n_events != NULL: the decoding is waited for and *n_events = the packet's events; a chunk that decodes to more than
@@ -568,9 +589,10 @@ int xm_ingest_push_evt3(xm_ingest* g, xm_evt3* d, const uint16_t* words_host, si
  * form x_maps_amd/evt2.py, independent checker oracle/evt2_oracle.py).  xm_evt2_create makes a decoder OBJECT OF THE SAME TYPE
  * for that encoding: xm_evt3_destroy / xm_evt3_reset serve it, xm_evt2_decode / xm_ingest_push_evt2 take its 32-bit words (the
  * EVT 3.0 entry points refuse it and vice versa).  max_events = 0: max_words (a word is at most one event). */
-int xm_evt2_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out);
-int xm_evt2_decode(xm_evt3* d, const uint32_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
-int xm_ingest_push_evt2(xm_ingest* g, xm_evt3* d, const uint32_t* words_host, size_t n_words, int words_pinned, size_t* n_events);
+typedef xm_evt3 xm_raw_decoder; /* the decoder object, whichever encoding it was created for */
+int xm_evt2_create(xm_handle* h, size_t max_words, size_t max_events, xm_raw_decoder** out);
+int xm_evt2_decode(xm_raw_decoder* d, const uint32_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);
+int xm_ingest_push_evt2(xm_ingest* g, xm_raw_decoder* d, const uint32_t* words_host, size_t n_words, int words_pinned, size_t* n_events);
 
 /* ---- pinned host memory for XM_MEM_HOST_PINNED ------------------------------------------------------------- */
 int xm_host_alloc(xm_handle* h, size_t bytes, void** out);

@@ -1,10 +1,23 @@
 """CPU restatement of the ingest chain in front of the hot path -- TEST INFRASTRUCTURE ONLY (see xmaps_oracle.py).
 
   polarity_filter        PolarityFilterAlgorithm(1) as the reference uses it (python/depth_reprojection_pipe.py:43,114)
-  activity_filter        OWN DEFINITION (Metavision's ActivityNoiseFilterAlgorithm is closed source): an event
-                         is kept iff an EARLIER event of the (positive) stream at one of its 8 neighbouring pixels has
-                         t - t' <= thresh (thresh = int(1e6 / fps), pipe:65-68); every event, kept or not, then becomes its
-                         pixel's latest event.  Sequential by construction; the device evaluates the same rule in parallel.
+  activity_filter        OWN DEFINITION (Metavision's ActivityNoiseFilterAlgorithm is installed as a binary with the SDK,
+                         SURVEY.md 8(c); parity unpinned): an event is kept iff an EARLIER event of the (positive) stream at one
+                         of its 8 neighbouring pixels has t - t' <= thresh (thresh = int(1e6 / fps), pipe:65-68); every event,
+                         kept or not, then joins its pixel's history (the pixel's LARGEST stamp so far).  Sequential by
+                         construction; the device evaluates the same rule in parallel (xmaps_ingest.hpp).
+                         Beside the published OpenEB header (sdk/modules/cv/.../activity_noise_filter_algorithm{,_impl}.h) AS
+                         REMEMBERED -- not readable offline, so every line here is to be checked by tools/pin_thirdparty.py
+                         where the SDK exists: it keeps one `last_ts` per pixel, stores the event's stamp there, and keeps
+                         the event iff a pixel of the 3 x 3 neighbourhood was written more recently than `t - threshold`.
+                         Known or possible differences, each a one-line change here and in act_keep():
+                           (1) comparison: this rule is `t - t' <= T`; a strict `t' > t - T` is thresh = T - 1 (integers);
+                           (2) history: this rule keeps the pixel's MAXIMUM stamp, OpenEB overwrites with the LATEST event's
+                               -- identical on a time-ordered stream, which a camera's is;
+                           (3) the event's own pixel: excluded here (an isolated hot pixel firing repeatedly is noise); if
+                               OpenEB's window includes the centre, events repeating at one pixel within T are kept there;
+                           (4) borders: the neighbourhood is clipped to the sensor here; coordinates outside the sensor are
+                               dropped (NumPy would raise), OpenEB's behaviour there is not known.
   TriggerFinderOracle    find_trigger / process_events of python/trigger_finder.py:128-189 written out over plain arrays
                          (pinned by tests/golden/g5_trigger.npz in tests/test_oracle_ingest.py)
 """
@@ -41,6 +54,33 @@ class ActivityFilterOracle:
                 last[y, x] = t
             has[y, x] = True
         return evs[keep]
+
+
+def activity_filter_c(lib, evs, state, thresh_us):
+    """The same rule through oracle/xmaps_oracle.c:xmo_activity_filter (fast; pinned to ActivityFilterOracle in
+    tests/test_oracle_ingest.py).  state = (last int64[h, w], has uint8[h, w]) carried by the caller."""
+    import ctypes as C
+    last, has = state
+    evs = np.ascontiguousarray(evs)
+    assert evs.dtype.itemsize == 16
+    keep = np.zeros(len(evs), np.uint8)
+    lib.xmo_activity_filter.restype = C.c_int64
+    lib.xmo_activity_filter(C.c_void_p(evs.ctypes.data), C.c_int64(len(evs)), C.c_int(has.shape[1]), C.c_int(has.shape[0]), C.c_int64(int(thresh_us)),
+                            C.c_void_p(last.ctypes.data), C.c_void_p(has.ctypes.data), C.c_void_p(keep.ctypes.data))
+    return evs[keep.view(bool)]
+
+
+class ActivityFilterC:
+    """ActivityFilterOracle's interface over the C form"""
+
+    def __init__(self, width, height, thresh_us):
+        import c_oracle
+        self.lib = c_oracle.load(False)
+        self.thresh = int(thresh_us)
+        self.state = (np.zeros((int(height), int(width)), np.int64), np.zeros((int(height), int(width)), np.uint8))
+
+    def process(self, evs):
+        return activity_filter_c(self.lib, evs, self.state, self.thresh)
 
 
 class TriggerFinderOracle:

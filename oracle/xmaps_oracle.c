@@ -146,3 +146,27 @@ int xmo_process_frame(const xmo_tables* tb, const uint16_t* x, const uint16_t* y
   if (!disp_map) free(frame);
   return err ? -1 : 0;
 }
+
+/* ---- activity-noise filter: the sequential definition of oracle/ingest_oracle.py:ActivityFilterOracle.process, in C so that
+ * streams of ESL size (and bench.py's cpu legs) can be judged in milliseconds; pinned against the Python form in
+ * tests/test_oracle_ingest.py.  rec: 16-byte EventCD records (x:u16@0, y:u16@2, p:i16@4, t:i64@8); every record takes part.
+ * last / has: the per-pixel history the caller keeps between packets (int64 / uint8, h x w).  Returns the number kept. */
+int64_t xmo_activity_filter(const void* rec, int64_t n, int w, int h, int64_t thresh, int64_t* last, uint8_t* has, uint8_t* keep) {
+  const uint8_t* r = (const uint8_t*)rec;
+  int64_t kept = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int x = *(const uint16_t*)(r + 16 * i), y = *(const uint16_t*)(r + 16 * i + 2);
+    const int64_t t = *(const int64_t*)(r + 16 * i + 8);
+    uint8_t k = 0;
+    const int y0 = y > 0 ? y - 1 : 0, y1 = y + 1 < h ? y + 1 : h - 1, x0 = x > 0 ? x - 1 : 0, x1 = x + 1 < w ? x + 1 : w - 1;
+    for (int yy = y0; yy <= y1; ++yy)
+      for (int xx = x0; xx <= x1; ++xx)
+        if ((yy != y || xx != x) && has[(int64_t)yy * w + xx] && t - last[(int64_t)yy * w + xx] <= thresh) k = 1;
+    keep[i] = k;
+    kept += k;
+    const int64_t c = (int64_t)y * w + x;
+    if (!has[c] || t > last[c]) last[c] = t;
+    has[c] = 1;
+  }
+  return kept;
+}

@@ -61,14 +61,17 @@ def test_stage_classes_have_reference_signatures_and_results():
     pipe.close()
 
 
-def test_processor_context_manager_end_to_end_stream():
-    """Packets -> polarity filter -> trigger finder -> hot path -> window.show_async, like the reference's loop."""
+@pytest.mark.parametrize("activity", [True, False])
+def test_processor_context_manager_end_to_end_stream(activity):
+    """Packets -> polarity filter -> activity filter (the default, as in the reference; one GPU call per packet on this path)
+    -> trigger finder -> hot path -> window.show_async, like the reference's loop (pipe:110-119)."""
+    import ingest_oracle as IO
     cfg = S.C_TINY
     tb = S.make_tables(cfg)
     rng = np.random.default_rng(7)
     chunks = []
-    for f in range(5):
-        n = 2500
+    for f in range(6):
+        n = 9000 if activity else 2500
         start = 1_000_000 + f * 16_600
         tt = np.unique(np.concatenate((np.sort(rng.integers(0, 13_000, n)) + start, np.arange(start, start + 13_000, 25))))
         ev = np.zeros(len(tt), S.EVENT_CD_DTYPE)
@@ -80,7 +83,11 @@ def test_processor_context_manager_end_to_end_stream():
     stream = np.concatenate(chunks)
     frames_seen = []
 
-    with DepthReprojectionProcessor(_params(cfg, tb)) as proc:
+    params = _params(cfg, tb)
+    if not activity:
+        params.activity_filter = False
+    with DepthReprojectionProcessor(params) as proc:
+        assert (proc._pipe.activity_filter is not None) == activity
         orig = proc._pipe.process_ev_frame
 
         def spy(evs):
@@ -99,6 +106,15 @@ def test_processor_context_manager_end_to_end_stream():
         last = proc._window.last_frame
     assert (frames_seen[-1]["p"] == 1).all()
     assert np.array_equal(last, _ref(tb, frames_seen[-1])["bgr"])
+    # the same frames as the CPU chain cuts from the same packets
+    tf = IO.TriggerFinderOracle(60)
+    act = IO.ActivityFilterC(cfg.cam_w, cfg.cam_h, int(1e6 / 60))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        pos = IO.polarity_filter(stream[a:b])
+        tf.process_events(act.process(pos) if activity else pos)
+    assert len(tf.frames) == len(frames_seen) and all(np.array_equal(a, b) for a, b in zip(tf.frames, frames_seen))
+    if activity:
+        assert sum(len(f) for f in frames_seen) < (stream["p"] == 1).sum() * 0.99  # (the filter did drop isolated events)
 
 
 def test_device_async_slots_and_graph_replay():

@@ -77,3 +77,20 @@ def test_activity_rule_on_a_hand_checked_example():
     ev2 = np.zeros(1, S.EVENT_CD_DTYPE)
     ev2["x"], ev2["y"], ev2["t"], ev2["p"] = 13, 12, 1480, 1
     assert len(f.process(ev2)) == 1
+
+
+def test_activity_rule_c_form_equals_the_python_form():
+    """oracle/xmaps_oracle.c:xmo_activity_filter (used on ESL-size streams) == ActivityFilterOracle, packet by packet, on sorted
+    and unsorted streams"""
+    rng = np.random.default_rng(3)
+    for sort in (True, False):
+        n = 4000
+        ev = np.zeros(n, S.EVENT_CD_DTYPE)
+        t = rng.integers(0, 30_000, n)
+        ev["t"] = 10_000 + (np.sort(t) if sort else t)
+        ev["x"], ev["y"], ev["p"] = rng.integers(0, 40, n), rng.integers(0, 30, n), 1
+        a, b = IO.ActivityFilterOracle(40, 30, 900), IO.ActivityFilterC(40, 30, 900)
+        for k in range(0, n, 700):
+            want, got = a.process(ev[k:k + 700]), b.process(ev[k:k + 700])
+            assert np.array_equal(want, got)
+        assert 0 < len(want) < 700

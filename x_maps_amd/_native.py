@@ -197,6 +197,12 @@ SYMBOLS = {
     "xm_shard_comm_destroy": (None, [_P]),
     "xm_ingest_device_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xm_ingest_host_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "xm_activity_create": (C.c_int, [_P, C.c_int64, C.c_size_t, C.POINTER(_P)]),
+    "xm_activity_destroy": (None, [_P]),
+    "xm_activity_process": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t)]),
+    "xm_activity_reset": (C.c_int, [_P]),
+    "xm_activity_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "xm_ingest_activity_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_evt3_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xm_evt3_destroy": (None, [_P]),
     "xm_evt3_reset": (C.c_int, [_P]),

@@ -73,7 +73,7 @@ int evt3_run(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, ui
 
 // decode + everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
 int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned) {
-  g->out_serial_now = !dbg_opt("XM_INGEST_EVT3_OUT_STREAM");  // (see xm_ingest::out_serial_now)
+  g->out_serial_now = !g->opt_evt3_out_stream;  // (see xm_ingest::out_serial_now)
   if (n_words) {
     int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream, g->d_pkt_n + k);
     if (rc) return rc;
@@ -182,8 +182,6 @@ static int ingest_push_words(xm_ingest* g, xm_evt3* d, int format, const void* w
   if (!g || !d || (n_words && !words_host)) return fail(XM_ERR_INVALID, "NULL argument");
   if (d->format != format) return fail(XM_ERR_INVALID, "this decoder was created for EVT %d.0 words", d->format);
   if (g->h != d->h) return fail(XM_ERR_INVALID, "the decoder and the ingest belong to different handles");
-  if (g->cfg.activity_filter)
-    return fail(XM_ERR_INVALID, "the activity filter splits a packet by time stamps on the host: not for packets decoded on the device");
   if (n_words > d->max_words) return fail(XM_ERR_TOO_MANY, "chunk of %zu words exceeds max_words %zu", n_words, d->max_words);
   const double c0 = ingest_now();
   HIP_TRY(hipSetDevice(g->h->cfg.device));

@@ -37,8 +37,8 @@ struct xm_ingest {
   IngFrameInfo* d_infos = nullptr;
   IngVerdict* h_verdicts = nullptr;    // pinned host ...
   IngVerdict* d_verdicts = nullptr;    // ... and the address the device writes it at
-  u32* first_idx = nullptr;            // activity filter: first event index of the sub-packet per pixel
-  u32* keep = nullptr;                 // activity filter: keep flags of the (sub-)packet
+  uint64_t entry_frame[VRING] = {};    // frame number + 1 that the packet which used the ring entry last cut (0: none): the entry is
+                                       // read by that frame's K2 / publishing launches, so it is reused only once the frame is out
   static constexpr int NOUT = 3;       // device-side output frames (K2 writes them, a DMA copy takes them to the pinned result ring)
   hipEvent_t k2_ev[NOUT] = {};         // frame stream: K2 has written output frame o (the out stream's DMA waits for it)
   hipEvent_t out_ev[NOUT] = {};        // out stream: output frame o has left for the result ring (the next K2 into it waits for that)
@@ -69,6 +69,10 @@ struct xm_ingest {
   // tools/esl_evt3_probe.py), cleared for packets of records (1055-1105 on the out stream against 950).
   bool out_serial_now = false;
   size_t out_piece = 4u << 20;         // bytes per D2H copy of a result frame ("XM_INGEST_OUT_PIECE")
+  // debug options are read ONCE, in xm_ingest_create (the ingest's threads must not look at the option table while another thread changes it)
+  bool opt_out_no_query = false;       // "XM_INGEST_OUT_NO_QUERY"
+  bool opt_evt3_out_stream = false;    // "XM_INGEST_EVT3_OUT_STREAM"
+  bool opt_trace = false;              // "XM_INGEST_TRACE"
   double t_out_wait_s = 0.0;           // XM_INGEST_TRACE: launch side waiting for the out side to have enqueued frame f - NOUT
   double t_out_s = 0.0;                // XM_INGEST_TRACE: host seconds the out side spent enqueuing
   float* d_out_depth[NOUT] = {};
@@ -158,6 +162,34 @@ void ingest_stream_release(int device) {
   g_ing_sets[device].lent = false;
 }
 
+// the activity filter's device state (xmaps_ingest.hpp: ActDev), for an ingest or for the filter alone (xm_activity_*)
+int act_alloc(ActDev* a, int cam_w, int cam_h, long long thresh, size_t max_packet) {
+  if (thresh < 0 || thresh >= (1ll << 31) - 2) return fail(XM_ERR_INVALID, "activity threshold must be in [0, 2^31 - 2) us");
+  const size_t cam_px = (size_t)cam_w * cam_h;
+  *a = ActDev{};
+  a->thresh = thresh;
+  a->cam_w = cam_w;
+  a->cam_h = cam_h;
+  HIP_TRY(hipMalloc((void**)&a->last_ts, cam_px * 8));
+  HIP_TRY(hipMalloc((void**)&a->cells, cam_px * sizeof(uint2) * ACT_NB));
+  HIP_TRY(hipMalloc((void**)&a->keep, max_packet ? max_packet : 1));
+  HIP_TRY(hipMalloc((void**)&a->ctl, 4 * sizeof(u32)));
+  std::vector<long long> init(cam_px, ING_NO_TS);
+  HIP_TRY(hipMemcpy(a->last_ts, init.data(), cam_px * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(a->cells, 0, cam_px * sizeof(uint2) * ACT_NB));
+  HIP_TRY(hipMemset(a->ctl, 0, 4 * sizeof(u32)));
+  HIP_TRY(hipDeviceSynchronize());  // (default-stream work: non-blocking streams do not wait for it)
+  return XM_OK;
+}
+
+void act_free(ActDev* a) {
+  if (a->last_ts) (void)hipFree(a->last_ts);
+  if (a->cells) (void)hipFree(a->cells);
+  if (a->keep) (void)hipFree(a->keep);
+  if (a->ctl) (void)hipFree(a->ctl);
+  *a = ActDev{};
+}
+
 inline double ingest_now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -168,7 +200,7 @@ int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
   hipStream_t os = j.serial ? g->frame_stream : g->out_stream;
   // A copy enqueued behind one that is still running can block its caller for as long as that one runs -- inside the runtime,
   // with other threads' calls waiting behind it: the previous frame's copies are seen off first (a query loop, no blocking call).
-  if (g->out_threaded && !j.serial && j.frame_no > 0 && !dbg_opt("XM_INGEST_OUT_NO_QUERY")) {
+  if (g->out_threaded && !j.serial && j.frame_no > 0 && !g->opt_out_no_query) {
     const int po = (int)((j.frame_no - 1) % xm_ingest::NOUT);
     for (int i = 0; hipEventQuery(g->out_ev[po]) == hipErrorNotReady; ++i)
       for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
@@ -355,6 +387,7 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
     }
     g->out_done.store(f + 1, std::memory_order_release);
   }
+  g->entry_frame[vi] = f + 1;
   g->frames_issued += 1;
   return XM_OK;
 }
@@ -415,53 +448,37 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
     if ((rc = ingest_handle_verdicts(g, g->next_verdict))) return rc;
   const uint64_t push_no = g->issued + 1;
   const int vi = (int)(push_no % xm_ingest::VRING);
+  // The entry's previous user (packet push_no - VRING) may have cut a frame, whose K2 and publishing launches read the
+  // descriptor and the frame info out of the entry -- the last of them on the out stream, behind the frame's copies.  The ingest
+  // stream waits only for that frame's K1, so the entry is handed to k_ing_segment again only once the frame's sequence number
+  // is out (a read of pinned memory: by now it is, except with > VRING packets between a cut and a stalled out side).
+  if (const uint64_t fe = g->entry_frame[vi]) {
+    const IngestStatus* stp = g->h_status + (fe - 1) % (uint64_t)g->ring;
+    unsigned spins = 0;
+    while (__atomic_load_n(&stp->seq, __ATOMIC_ACQUIRE) < fe) {
+      if (g->out_error.load(std::memory_order_acquire)) return fail(g->out_error.load(), "ingest, out side: %s", g->out_error_text.c_str());
+      __builtin_ia32_pause();
+      if ((++spins & 0xfff) == 0) (void)hipStreamQuery(g->out_stream);
+    }
+    g->entry_frame[vi] = 0;
+  }
   g->dev.desc = g->d_descs + vi;
   g->dev.info = g->d_infos + vi;
   g->dev.verdict = g->d_verdicts + vi;
-  const int act = g->cfg.activity_filter && hp ? 1 : 0;
-  const int cw = h->tb.cam_w, ch = h->tb.cam_h;
+  (void)hp;
+  (void)h;
   IngestPush p{};
-  p.flags = g->cfg.use_polarity ? ING_F_POLARITY : 0u;
+  p.flags = (g->cfg.use_polarity ? ING_F_POLARITY : 0u) | ING_F_SEGMENT;
   p.push_no = push_no;
-  if (!act) {
-    p.src = g->d_pkt[k];
-    p.n = (u32)n;
-    p.n_dev = n_dev;
-    p.flags |= ING_F_SEGMENT;
-    ingest_launch3(g, p, (u32)n);
-  } else {
-    // sub-packets whose time span (max - min) stays within the activity threshold (see xmaps_ingest.hpp); the trigger finder
-    // runs once, behind the last one
-    size_t a = 0;
-    if (n == 0) {
-      p.flags |= ING_F_SEGMENT;
-      ingest_launch3(g, p, 0);
-    }
-    while (a < n) {
-      long long lo = rec_t_host(hp[a]), hi = lo;
-      size_t b = a + 1;
-      while (b < n) {
-        const long long t = rec_t_host(hp[b]);
-        const long long nlo = t < lo ? t : lo, nhi = t > hi ? t : hi;
-        if (nhi - nlo > g->act_thresh) break;
-        lo = nlo; hi = nhi;
-        ++b;
-      }
-      const u32 m = (u32)(b - a);
-      const uint4* dp = g->d_pkt[k] + a;
-      HIP_TRY(hipMemsetAsync(g->first_idx, 0xff, (size_t)cw * ch * 4, s));
-      hipLaunchKernelGGL(k_ing_first, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), cw, ch, g->first_idx);
-      hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, s, dp, m, (int)(p.flags & ING_F_POLARITY), 1, g->act_thresh, cw, ch,
-                         (const u32*)g->first_idx, (const long long*)g->dev.last_ts, g->keep);
-      IngestPush sp = p;
-      sp.src = dp;
-      sp.keep = g->keep;
-      sp.n = m;
-      if (b == n) sp.flags |= ING_F_SEGMENT;
-      ingest_launch3(g, sp, m);
-      a = b;
-    }
-  }
+  p.src = g->d_pkt[k];
+  p.n = (u32)n;
+  p.n_dev = n_dev;
+  // activity filter: one more launch in front (the per-(bucket, pixel) cells of the packet; xmaps_ingest.hpp) -- the flags
+  // themselves are computed inside k_ing_count.  Nothing is decided here: a chunk decoded on the device is treated like records.
+  if (g->dev.act.last_ts && n)
+    hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_EPB - 1) / ING_EPB)), dim3(ING_THREADS), 0, s, g->dev.act, (const uint4*)g->d_pkt[k], n_dev,
+                       (u32)n, g->cfg.use_polarity ? 1 : 0);
+  ingest_launch3(g, p, (u32)n);
   HIP_TRY(hipGetLastError());
   g->issued = push_no;
   // the frame (if this or an earlier packet cut one) as soon as its verdict is in: at once when nothing else is waiting
@@ -660,6 +677,9 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   for (auto& e : g->out_ev) ING_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = dbg_opt("XM_INGEST_OUT_PIECE")) g->out_piece = std::max<size_t>(2u << 20, (size_t)atoll(e));
   if (const char* e = dbg_opt("XM_INGEST_OUT_SERIAL")) g->out_on_frame_stream = e[0] == '1';
+  g->opt_out_no_query = dbg_opt("XM_INGEST_OUT_NO_QUERY") != nullptr;
+  g->opt_evt3_out_stream = dbg_opt("XM_INGEST_EVT3_OUT_STREAM") != nullptr;
+  g->opt_trace = dbg_opt("XM_INGEST_TRACE") != nullptr;
   IngestDev& d = g->dev;
   d.cap = g->capacity;
   d.room = g->max_packet * (u64)(1 + g->ahead);
@@ -669,11 +689,11 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipMalloc((void**)&d.pring, d.pcap * 8));
   ING_TRY(hipMalloc((void**)&d.blk, sizeof(IngBlk) * ING_MAX_BLOCKS));
   if (cfg->activity_filter) {
-    ING_TRY(hipMalloc((void**)&g->first_idx, cam_px * 4));
-    ING_TRY(hipMalloc((void**)&d.last_ts, cam_px * 8));
-    std::vector<long long> init(cam_px, ING_NO_TS);
-    ING_TRY(hipMemcpy(d.last_ts, init.data(), cam_px * 8, hipMemcpyHostToDevice));
-    ING_TRY(hipMalloc((void**)&g->keep, g->max_packet * 4));
+    int rc_ = act_alloc(&d.act, h->tb.cam_w, h->tb.cam_h, g->act_thresh, (size_t)g->max_packet);
+    if (rc_) {
+      xm_ingest_destroy(g);
+      return rc_;
+    }
   }
   d.cam_w = h->tb.cam_w;
   d.cam_h = h->tb.cam_h;
@@ -699,7 +719,8 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->frame_stream, d.slot, d.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
   ING_TRY(hipGetLastError());
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
-    ING_TRY(hipHostMalloc((void**)&g->h_pkt[i], g->max_packet * 16, hipHostMallocDefault));
+    // (the pinned twin h_pkt[i] is allocated by the first PAGEABLE push that lands on the entry: callers that push pinned
+    //  packets or RAW words never pay for 16 x max_packet x 16 bytes of page-locked memory)
     ING_TRY(hipMalloc((void**)&g->d_pkt[i], g->max_packet * 16));
     if (!g->d_pkt_n) ING_TRY(hipMalloc((void**)&g->d_pkt_n, xm_ingest::STAGE * sizeof(u32)));
   }
@@ -767,12 +788,12 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->frame_stream) (void)hipStreamSynchronize(g->frame_stream);
   if (g->out_stream) (void)hipStreamSynchronize(g->out_stream);
-  if (dbg_opt("XM_INGEST_TRACE"))
+  if (g->opt_trace)
     fprintf(stderr, "[ingest] %llu packets, %llu frames, ahead %d: launch side %.3f ms in jobs, of which %.3f ms waiting for verdicts and %.3f ms "
             "issuing frames; caller %.3f ms in push, %.3f ms of it waiting for staging entries\n", (unsigned long long)g->issued,
             (unsigned long long)g->frames_issued, g->ahead, g->t_jobs_s * 1e3, g->t_block_s * 1e3, g->t_frames_s * 1e3, g->push_host_s * 1e3,
             g->push_wait_s * 1e3);
-  if (dbg_opt("XM_INGEST_TRACE"))
+  if (g->opt_trace)
     fprintf(stderr, "[ingest] out side (%s): %.3f ms enqueuing %llu frames' copies + sequence numbers; the launch side waited %.3f ms for it\n",
             g->cfg.flags & XM_INGEST_NO_LAUNCH_THREAD ? "inline" : "a thread of its own", g->t_out_s * 1e3, (unsigned long long)g->out_done.load(),
             g->t_out_wait_s * 1e3);
@@ -780,16 +801,14 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (d.buf) (void)hipFree(d.buf);
   if (d.pring) (void)hipFree(d.pring);
   if (d.blk) (void)hipFree(d.blk);
-  if (d.last_ts) (void)hipFree(d.last_ts);
+  act_free(&d.act);
   if (d.st) (void)hipFree(d.st);
   if (d.key_frame) (void)hipFree(d.key_frame);
   if (d.slot) (void)hipFree(d.slot);
   if (g->d_descs) (void)hipFree(g->d_descs);
   if (g->d_infos) (void)hipFree(g->d_infos);
   if (g->h_verdicts) (void)hipHostFree(g->h_verdicts);
-  if (g->first_idx) (void)hipFree(g->first_idx);
   if (g->d_pkt_n) (void)hipFree(g->d_pkt_n);
-  if (g->keep) (void)hipFree(g->keep);
   if (g->d_depth_ring) (void)hipFree(g->d_depth_ring);
   if (g->d_bgr_ring) (void)hipFree(g->d_bgr_ring);
   for (int i = 0; i < xm_ingest::NOUT; ++i) {
@@ -827,6 +846,7 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   if (!g->threaded) HIP_TRY(hipSetDevice(h->cfg.device));
   const int k = g->pkt_next;
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
+  if (!pinned && n && !g->h_pkt[k] && hipSetDevice(h->cfg.device) == hipSuccess) HIP_TRY(hipHostMalloc((void**)&g->h_pkt[k], g->max_packet * 16, hipHostMallocDefault));
   const uint4* hp = pinned ? (const uint4*)eventcd16 : g->h_pkt[k];
   if ((rc = ingest_wait_entry(g, k))) return rc;
   if (n && !pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
@@ -860,7 +880,7 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->seq = g->next_seq;
   out->lost = lapped ? 1 : 0;
   if (lapped) {
-    if (dbg_opt("XM_INGEST_TRACE")) fprintf(stderr, "[ingest] lapped: slot %d want %llu seq %llu seq2 %llu (frames issued %llu, pushes issued %llu)\n", slot,
+    if (g->opt_trace) fprintf(stderr, "[ingest] lapped: slot %d want %llu seq %llu seq2 %llu (frames issued %llu, pushes issued %llu)\n", slot,
                                             (unsigned long long)want, (unsigned long long)seq, (unsigned long long)seq2,
                                             (unsigned long long)g->frames_issued, (unsigned long long)g->issued);
     // Nothing of the entry can be trusted for frame next_seq (no statistics, no images: depth / bgr stay NULL).
@@ -926,6 +946,113 @@ int xm_ingest_host_stats(xm_ingest* g, uint64_t* pushes, double* host_seconds_in
   if (host_seconds_in_push) *host_seconds_in_push = g->push_host_s;
   if (staging_waits) *staging_waits = g->stage_waits;
   if (seconds_waiting) *seconds_waiting = g->push_wait_s;
+  return XM_OK;
+}
+
+// ---- the activity filter alone ------------------------------------------------------------------------------------------
+// What `act_filter.process_events(pos_events_buf, act_out_buf)` is in the reference's pipe (depth_reprojection_pipe.py:116-117)
+// for a host that keeps the trigger finder on the CPU: one packet of records in, a keep flag per event out.  Same kernels and
+// state as the ingest's filter (xmaps_ingest.hpp); every event handed in takes part (the pipe hands it positive events).
+struct xm_activity {
+  xm_handle* h = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t max_packet = 0;
+  ActDev act{};
+  uint4* h_pkt = nullptr;  // pinned staging
+  uint4* d_pkt = nullptr;
+  unsigned char* h_keep = nullptr;
+};
+
+int xm_activity_create(xm_handle* h, int64_t thresh_us, size_t max_packet_events, xm_activity** out) {
+  if (!h || !out) return fail(XM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  XM_ENTER(h);
+  xm_activity* f = new (std::nothrow) xm_activity();
+  if (!f) return fail(XM_ERR_NOMEM, "out of host memory");
+  f->h = h;
+  f->device = h->cfg.device;
+  f->max_packet = max_packet_events ? max_packet_events : ((size_t)1 << 19);
+  int rc = act_alloc(&f->act, h->tb.cam_w, h->tb.cam_h, thresh_us, f->max_packet);
+  const auto tr = [&](hipError_t e, const char* what) {
+    if (!rc && e != hipSuccess) rc = fail(XM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+  };
+  if (!rc) tr(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  if (!rc) tr(hipHostMalloc((void**)&f->h_pkt, f->max_packet * 16, hipHostMallocDefault), "hipHostMalloc");
+  if (!rc) tr(hipHostMalloc((void**)&f->h_keep, f->max_packet, hipHostMallocDefault), "hipHostMalloc");
+  if (!rc) tr(hipMalloc((void**)&f->d_pkt, f->max_packet * 16), "hipMalloc");
+  if (rc) {
+    xm_activity_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return XM_OK;
+}
+
+void xm_activity_destroy(xm_activity* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  act_free(&f->act);
+  if (f->h_pkt) (void)hipHostFree(f->h_pkt);
+  if (f->h_keep) (void)hipHostFree(f->h_keep);
+  if (f->d_pkt) (void)hipFree(f->d_pkt);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  delete f;
+}
+
+int xm_activity_process(xm_activity* f, const void* eventcd16, size_t n, uint8_t* keep_out, size_t* n_kept) {
+  if (!f || (n && (!eventcd16 || !keep_out))) return fail(XM_ERR_INVALID, "NULL argument");
+  if (n_kept) *n_kept = 0;
+  HIP_TRY(hipSetDevice(f->device));
+  size_t kept = 0;
+  for (size_t a = 0; a < n; a += f->max_packet) {  // (a longer packet: piece by piece -- the rule does not depend on the cut)
+    const size_t m = std::min(f->max_packet, n - a);
+    memcpy(f->h_pkt, (const char*)eventcd16 + a * 16, m * 16);
+    HIP_TRY(hipMemcpyAsync(f->d_pkt, f->h_pkt, m * 16, hipMemcpyHostToDevice, f->stream));
+    const unsigned nb = (unsigned)((m + ING_EPB - 1) / ING_EPB), gx = (unsigned)((m + ING_THREADS - 1) / ING_THREADS);
+    hipLaunchKernelGGL(k_act_first, dim3(nb), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (const u32*)nullptr, (u32)m, 0);
+    hipLaunchKernelGGL(k_act_mark, dim3(gx), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (u32)m, 0);
+    hipLaunchKernelGGL(k_act_update, dim3(gx), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (u32)m, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(f->h_keep, f->act.keep, m, hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    memcpy(keep_out + a, f->h_keep, m);
+    for (size_t i = 0; i < m; ++i) kept += f->h_keep[i] != 0;
+  }
+  if (n_kept) *n_kept = kept;
+  return XM_OK;
+}
+
+int xm_activity_stats(xm_activity* f, uint64_t* sequential_packets) {
+  if (!f) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(f->device));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  u32 c[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(c, f->act.ctl, sizeof c, hipMemcpyDeviceToHost));
+  if (sequential_packets) *sequential_packets = c[2];
+  return XM_OK;
+}
+
+int xm_ingest_activity_stats(xm_ingest* g, uint64_t* sequential_packets) {
+  if (!g) return fail(XM_ERR_INVALID, "NULL argument");
+  if (sequential_packets) *sequential_packets = 0;
+  if (!g->dev.act.last_ts) return XM_OK;
+  int rc = xm_ingest_flush(g);
+  if (rc) return rc;
+  u32 c[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(c, g->dev.act.ctl, sizeof c, hipMemcpyDeviceToHost));
+  if (sequential_packets) *sequential_packets = c[2];
+  return XM_OK;
+}
+
+int xm_activity_reset(xm_activity* f) {
+  if (!f) return fail(XM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(f->device));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  std::vector<long long> init((size_t)f->act.cam_w * f->act.cam_h, ING_NO_TS);
+  HIP_TRY(hipMemcpyAsync(f->act.last_ts, init.data(), init.size() * 8, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
   return XM_OK;
 }
 

@@ -29,13 +29,24 @@
 // kernels take a pointer + count) and nothing is ever moved (until round 4 the live part was copied to a second buffer
 // whenever the next packet might not fit).
 //
-// Activity-noise filter: Metavision's ActivityNoiseFilterAlgorithm is closed source, so its exact rule is unpinned
-// (SURVEY.md 8(c)).  OWN DEFINITION, implemented identically in oracle/ingest_oracle.py:
+// Activity-noise filter: Metavision's ActivityNoiseFilterAlgorithm ships as a binary in the SDK the reference installs
+// (SURVEY.md 8(c)), so its exact rule is unpinned here.  OWN DEFINITION, implemented identically in oracle/ingest_oracle.py
+// (which lists the differences from the published OpenEB header as far as they are known):
 //   a (positive) event e = (x, y, t) is KEPT iff some event e' EARLIER IN THE STREAM at one of the 8 neighbouring pixels has
 //   t - t' <= T (T = int(1e6 / fps)); every positive event, kept or not, then becomes its pixel's latest event.
-// Parallel evaluation, exact for any event order: the host splits packets into sub-packets whose time span (max - min) is
-// <= T; inside a sub-packet ANY earlier event at a neighbour qualifies (its t' is within the span), found through a
-// first-index map (atomicMin); events of earlier sub-packets qualify through the per-pixel maximum time stamp.
+// Parallel evaluation on the device, exact for any event order and any packet, with nothing decided on the host (round 5; until
+// then the host cut a packet into sub-packets by its time stamps, which a chunk decoded on the device does not have there):
+//   * events of EARLIER packets qualify through the per-pixel maximum time stamp `last_ts` (exact whatever the order);
+//   * inside the packet the time axis is cut into buckets of W = T + 1 us counted from the packet's first stamp.  Of two events
+//     in one bucket the earlier one always qualifies for the later one (|t - t'| <= T): a per-(bucket, pixel) MINIMUM packet
+//     index answers that.  An event of the bucket before qualifies iff its stamp is within T: a per-(bucket, pixel) MAXIMUM
+//     stamp answers that, PROVIDED every event of bucket b - 1 comes before every event of bucket b in the packet; buckets
+//     further back never qualify (t - t' >= W + 1).  k_act_first fills both cells with one pair of 32-bit atomics per event and
+//     checks the proviso (bucket numbers non-decreasing along the packet, at most ACT_NB of them);
+//   * a packet that fails the check (time stamps running backwards by more than a bucket, a chunk spanning more than ACT_NB
+//     thresholds) is judged by the LAST block of k_act_first to finish, sequentially in groups of 256 events against the
+//     running per-pixel maximum -- slow (~20 ms per million events) and exact.
+// The keep flags go to a byte per event (k_ing_count writes them, k_ing_append reads them and clears the cells it used).
 #pragma once
 #include "xmaps_kernels.hpp"
 
@@ -75,6 +86,7 @@ struct IngVerdict {       // pinned host ring entry (one per packet, 64 entries)
 struct IngFrameInfo {     // device, one per verdict entry: what k_ing_segment knew when it cut the frame (k_ing_publish reads it)
   u64 frame_no;
   u64 live_after;         // events left in the ring after the cut
+  long long t_first, t_last;  // the frame's first / last stamp (read at the cut: the ring is the frame's only up to its K1)
   u32 overflow;
   u32 pad;
 };
@@ -88,6 +100,20 @@ struct IngBlk {           // what one block of k_ing_count found in its 2048 pac
 };
 static_assert(sizeof(IngBlk) == 32, "IngBlk layout");
 
+// ---- activity filter state (see the header comment) -------------------------------------------------------------------------
+constexpr int ACT_NB = 8;          // time buckets of (threshold + 1) us a packet may span on the parallel path
+constexpr int ACT_GROUP = 256;     // events per step of the sequential path
+struct ActDev {
+  long long* last_ts;     // [cam_px] maximum time stamp of the pixel's events of EARLIER packets (ING_NO_TS: none)
+  uint2* cells;           // [ACT_NB][cam_px] per (bucket, pixel) of the current packet: .x = ~(smallest packet index), .y = largest
+                          // (stamp - bucket start) + 1; 0 = no event.  All zero between packets (k_ing_append / k_act_update clear)
+  unsigned char* keep;    // [max_packet] the packet's keep flags
+  u32* ctl;               // [0] != 0: the packet took the sequential path (the flags are in `keep` already); [1]: blocks of
+                          // k_act_first that have finished; [2]: packets judged sequentially so far (statistics)
+  long long thresh;       // T
+  int cam_w, cam_h;
+};
+
 struct IngestDev {        // by value to every ingest kernel
   IngestState* st;
   uint4* buf;             // cap + mirror records
@@ -96,7 +122,7 @@ struct IngestDev {        // by value to every ingest kernel
   u64* pring;             // pause ring, pcap entries (power of two)
   u64 pcap;
   IngBlk* blk;            // ING_MAX_BLOCKS records of the current packet
-  long long* last_ts;     // activity filter: per-pixel latest time stamp (NULL: filter off)
+  ActDev act;             // activity filter (act.last_ts == NULL: filter off)
   int cam_w, cam_h;
   long long pause_thresh;
   double period;
@@ -113,14 +139,13 @@ struct IngestDev {        // by value to every ingest kernel
 
 struct IngestPush {       // one packet
   const uint4* src;       // its records (device memory)
-  const u32* keep;        // non-NULL: keep flags computed by k_ing_mark (activity filter); NULL: the polarity rule alone
   const u32* n_dev;       // non-NULL: the packet's event count lives on the device (a chunk decoded there)
   u32 n;                  // ... else this many (with n_dev: the room of the packet's slot)
   u32 flags;              // ING_F_*
   u64 push_no;            // number of the packet (from 1)
 };
 constexpr u32 ING_F_POLARITY = 1u;  // keep p == 1 only
-constexpr u32 ING_F_SEGMENT = 2u;   // k_ing_segment: run the trigger finder (else: commit the packet only -- sub-packets)
+constexpr u32 ING_F_SEGMENT = 2u;   // k_ing_segment: run the trigger finder (else: commit the packet only)
 
 constexpr long long ING_NO_TS = (long long)0x8000000000000000ull;
 
@@ -132,47 +157,186 @@ __device__ inline u32 ing_packet_n(const IngestPush& p) {
   return m < p.n ? m : p.n;
 }
 
-// ---- filters (activity rule: separate passes, the first-index map must be complete before any event is judged) ------------
-// first event index of the sub-packet per pixel (positive events only)
-__global__ __launch_bounds__(BLOCK) void k_ing_first(const uint4* __restrict__ pkt, u32 m, int use_pol, int cam_w, int cam_h,
-                                                     u32* __restrict__ first_idx) {
-  const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= m) return;
-  const uint4 r = pkt[i];
-  if (use_pol && (short)(r.y & 0xffff) != 1) return;
-  const u32 x = r.x & 0xffff, y = r.x >> 16;
-  if (x >= (u32)cam_w || y >= (u32)cam_h) return;
-  __hip_atomic_fetch_min(&first_idx[y * (u32)cam_w + x], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- activity filter ----------------------------------------------------------------------------------------------------------
+struct ActEv {            // what the rule needs of one event
+  int x, y;
+  long long t;
+  bool part;              // takes part: passes the polarity rule and lies inside the sensor
+};
+__device__ inline ActEv act_event(const uint4& r, bool valid, bool use_pol, int cam_w, int cam_h) {
+  ActEv e;
+  e.x = (int)(r.x & 0xffff);
+  e.y = (int)(r.x >> 16);
+  e.t = rec_t(r);
+  e.part = valid && (!use_pol || (short)(r.y & 0xffff) == 1) && e.x < cam_w && e.y < cam_h;
+  return e;
+}
+// bucket of a stamp, counted from the packet's first stamp t0 in steps of W = T + 1: false if it lies in front of t0 or behind
+// the ACT_NB-th bucket (the subtraction wraps for stamps 2^63 apart: such a packet takes the sequential path, too)
+__device__ inline bool act_bucket(long long t, long long t0, long long W, int& b, u32& trel) {
+  if (t < t0) return false;
+  u64 d = (u64)t - (u64)t0;
+  const u64 w = (u64)W;
+  if (d >= w * ACT_NB) return false;
+  int k = 0;
+#pragma unroll
+  for (int s = ACT_NB / 2; s > 0; s >>= 1)
+    if (d >= w * (u64)s) {
+      d -= w * (u64)s;
+      k += s;
+    }
+  b = k;
+  trel = (u32)d;
+  return true;
 }
 
-// keep flags: polarity, then the activity rule (see the header comment)
-__global__ __launch_bounds__(BLOCK) void k_ing_mark(const uint4* __restrict__ pkt, u32 m, int use_pol, int activity,
-                                                    long long thresh, int cam_w, int cam_h, const u32* __restrict__ first_idx,
-                                                    const long long* __restrict__ last_ts, u32* __restrict__ keep) {
-  const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= m) return;
-  const uint4 r = pkt[i];
-  bool k = !use_pol || (short)(r.y & 0xffff) == 1;
-  if (k && activity) {
-    const int x = (int)(r.x & 0xffff), y = (int)(r.x >> 16);
-    const long long t = rec_t(r);
-    bool act = false;
-    if (x < cam_w && y < cam_h) {
+// the rule against the running per-pixel maximum alone (sequential path; `last_ts` is read past the caches: the block that
+// runs this has just updated it)
+__device__ inline bool act_seen_recently(const ActDev& a, const ActEv& e) {
+  bool act = false;
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+  for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          if (dx == 0 && dy == 0) continue;
-          const int xx = x + dx, yy = y + dy;
-          if (xx < 0 || xx >= cam_w || yy < 0 || yy >= cam_h) continue;
-          const u32 c = (u32)yy * (u32)cam_w + (u32)xx;
-          const long long lt = last_ts[c];
-          act = act || first_idx[c] < i || (lt != ING_NO_TS && t - lt <= thresh);
-        }
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (dx == 0 && dy == 0) continue;
+      const int xx = e.x + dx, yy = e.y + dy;
+      if (xx < 0 || xx >= a.cam_w || yy < 0 || yy >= a.cam_h) continue;
+      const long long lt = __hip_atomic_load(&a.last_ts[(u32)yy * (u32)a.cam_w + (u32)xx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      act = act || (lt != ING_NO_TS && e.t - lt <= a.thresh);
     }
-    k = act;
+  return act;
+}
+
+// The whole packet in stream order, 256 events at a time, by ONE block: inside a group an event looks at the group's earlier
+// events directly (LDS), at everything before the group through last_ts, which the group's events then join.  Leaves last_ts as
+// k_ing_append / k_act_update will leave it anyway (a maximum: idempotent).
+__device__ inline void act_sequential(const ActDev& a, const uint4* __restrict__ src, u32 n, bool use_pol) {
+  __shared__ int s_x[ACT_GROUP], s_y[ACT_GROUP];
+  __shared__ long long s_t[ACT_GROUP];
+  __shared__ unsigned char s_part[ACT_GROUP];
+  const u32 tid = threadIdx.x;
+  for (u32 base = 0; base < n; base += ACT_GROUP) {
+    const u32 i = base + tid;
+    const bool valid = i < n;
+    const ActEv e = act_event(valid ? src[i] : make_uint4(0, 0, 0, 0), valid, use_pol, a.cam_w, a.cam_h);
+    s_x[tid] = e.x;
+    s_y[tid] = e.y;
+    s_t[tid] = e.t;
+    s_part[tid] = e.part ? 1 : 0;
+    __syncthreads();
+    bool act = false;
+    if (e.part) {
+      act = act_seen_recently(a, e);
+      for (u32 j = 0; j < tid && !act; ++j) {
+        const int dx = s_x[j] - e.x, dy = s_y[j] - e.y;
+        act = s_part[j] && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && (dx | dy) != 0 && e.t - s_t[j] <= a.thresh;
+      }
+    }
+    if (valid) a.keep[i] = (e.part && act) ? 1 : 0;
+    __syncthreads();
+    if (e.part) __hip_atomic_fetch_max(&a.last_ts[(u32)e.y * (u32)a.cam_w + (u32)e.x], e.t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
   }
-  keep[i] = k ? 1u : 0u;
+}
+
+// Pass 1 of a packet: the (bucket, pixel) cells, the check that the buckets run forwards, and -- by the last block to finish,
+// only when the check failed -- the sequential path.  Same block shape as the ingest kernels (thread tid: events j * 256 + tid).
+__global__ __launch_bounds__(ING_THREADS) void k_act_first(ActDev a, const uint4* __restrict__ src, const u32* __restrict__ n_dev, u32 n_room,
+                                                           int use_pol) {
+  __shared__ u32 s_last;
+  u32 n = n_room;
+  if (n_dev) {
+    const u32 m = *n_dev;
+    n = m < n_room ? m : n_room;
+  }
+  const u32 nb = (n + ING_EPB - 1) / ING_EPB;
+  const u32 tid = threadIdx.x;
+  if (blockIdx.x < nb) {
+    const long long t0 = rec_t(src[0]), W = a.thresh + 1;
+    const u32 cam_px = (u32)a.cam_w * (u32)a.cam_h;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < ING_EPT; ++j) {
+      const u32 i = blockIdx.x * ING_EPB + j * ING_THREADS + tid;
+      if (i >= n) continue;
+      const uint4 r = src[i];
+      const ActEv e = act_event(r, true, use_pol != 0, a.cam_w, a.cam_h);
+      int b = 0, bp = 0;
+      u32 trel = 0, trp = 0;
+      if (!act_bucket(e.t, t0, W, b, trel)) {
+        bad = true;
+        continue;
+      }
+      if (i > 0 && (!act_bucket(rec_t(src[i - 1]), t0, W, bp, trp) || bp > b)) bad = true;
+      if (!e.part) continue;
+      uint2* c = a.cells + (size_t)b * cam_px + (u32)e.y * (u32)a.cam_w + (u32)e.x;
+      __hip_atomic_fetch_max(&c->x, ~i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(&c->y, trel + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__syncthreads_or(bad) && tid == 0) __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(&a.ctl[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(&a.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  if (tid == 0) a.ctl[2] += 1u;
+  act_sequential(a, src, n, use_pol != 0);
+}
+
+// Pass 2, per event (parallel path): is event i of the packet kept?  (cells complete: k_act_first has run)
+__device__ inline bool act_keep(const ActDev& a, const ActEv& e, u32 i, long long t0) {
+  if (!e.part) return false;
+  int b = 0;
+  u32 trel = 0;
+  (void)act_bucket(e.t, t0, a.thresh + 1, b, trel);  // (true for every event of a packet on this path)
+  const u32 cam_px = (u32)a.cam_w * (u32)a.cam_h;
+  const uint2* cb = a.cells + (size_t)b * cam_px;
+  bool act = false;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (dx == 0 && dy == 0) continue;
+      const int xx = e.x + dx, yy = e.y + dy;
+      if (xx < 0 || xx >= a.cam_w || yy < 0 || yy >= a.cam_h) continue;
+      const u32 q = (u32)yy * (u32)a.cam_w + (u32)xx;
+      const u32 first_inv = cb[q].x;                 // same bucket: an earlier event at q
+      act = act || (first_inv != 0u && ~first_inv < i);
+      if (b > 0) act = act || (cb - cam_px)[q].y >= trel + 2u;  // the bucket before: W + trel - trel' <= T  <=>  trel' > trel
+      const long long lt = a.last_ts[q];             // earlier packets
+      act = act || (lt != ING_NO_TS && e.t - lt <= a.thresh);
+    }
+  return act;
+}
+
+// Behind the flags: the event joins its pixel's history and its cells of this packet are emptied for the next one.
+__device__ inline void act_retire(const ActDev& a, const ActEv& e, long long t0) {
+  if (!e.part) return;
+  const u32 pix = (u32)e.y * (u32)a.cam_w + (u32)e.x;
+  __hip_atomic_fetch_max(&a.last_ts[pix], e.t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int b = 0;
+  u32 trel = 0;
+  if (act_bucket(e.t, t0, a.thresh + 1, b, trel)) a.cells[(size_t)b * ((u32)a.cam_w * (u32)a.cam_h) + pix] = make_uint2(0u, 0u);
+}
+
+// The filter alone (xm_activity_*: the host-side pipe's stand-in for ActivityNoiseFilterAlgorithm.process_events): flags ...
+__global__ __launch_bounds__(ING_THREADS) void k_act_mark(ActDev a, const uint4* __restrict__ src, u32 n, int use_pol) {
+  const u32 i = blockIdx.x * ING_THREADS + threadIdx.x;
+  if (i >= n) return;
+  if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (the sequential path has written them)
+  const ActEv e = act_event(src[i], true, use_pol != 0, a.cam_w, a.cam_h);
+  a.keep[i] = act_keep(a, e, i, rec_t(src[0])) ? 1 : 0;
+}
+// ... then history + clean cells
+__global__ __launch_bounds__(ING_THREADS) void k_act_update(ActDev a, const uint4* __restrict__ src, u32 n, int use_pol) {
+  const u32 i = blockIdx.x * ING_THREADS + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0) a.ctl[0] = 0u;  // (read by k_act_mark, in front of this kernel; the next packet's k_act_first sets it again)
+  act_retire(a, act_event(src[i], true, use_pol != 0, a.cam_w, a.cam_h), rec_t(src[0]));
 }
 
 // ---- the block-local part shared by k_ing_count and k_ing_append -----------------------------------------------------------
@@ -195,10 +359,20 @@ struct IngShared {
   u32 total, ptotal;
 };
 
-__device__ inline void ing_block_local(const IngestPush& p, u32 n, u32 block, long long thresh, IngShared& s, IngLocal& L) {
+// MARK: this is k_ing_count with the activity filter on -- the flags are computed here (or were, by the sequential path) and
+// left in act.keep, where k_ing_append (MARK = false) reads them
+template <bool MARK>
+__device__ inline void ing_block_local(const IngestPush& p, const ActDev& act, u32 n, u32 block, long long thresh, IngShared& s, IngLocal& L) {
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 lt_mask = (1ull << lane) - 1ull;
   const bool use_pol = (p.flags & ING_F_POLARITY) != 0;
+  const bool act_on = act.last_ts != nullptr;
+  bool compute = false;
+  long long t0 = 0;
+  if (MARK && act_on) {
+    compute = __hip_atomic_load(&act.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    t0 = rec_t(p.src[0]);
+  }
   u32 before[ING_EPT];
   L.keep_bits = 0;
 #pragma unroll
@@ -206,7 +380,15 @@ __device__ inline void ing_block_local(const IngestPush& p, u32 n, u32 block, lo
     const u32 i = block * ING_EPB + j * ING_THREADS + tid;
     const bool valid = i < n;
     L.r[j] = valid ? p.src[i] : make_uint4(0, 0, 0, 0);
-    bool k = valid && (p.keep ? p.keep[i] != 0 : (!use_pol || (short)(L.r[j].y & 0xffff) == 1));
+    bool k;
+    if (!act_on) {
+      k = valid && (!use_pol || (short)(L.r[j].y & 0xffff) == 1);
+    } else if (MARK && compute) {
+      k = valid && act_keep(act, act_event(L.r[j], valid, use_pol, act.cam_w, act.cam_h), i, t0);
+      if (valid) act.keep[i] = k ? 1 : 0;
+    } else {
+      k = valid && act.keep[i] != 0;
+    }
     const u64 b = __ballot(k);
     before[j] = __popcll(b & lt_mask);
     if (lane == 0) s.cnt[j][wave] = __popcll(b);
@@ -256,7 +438,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_count(IngestDev d, IngestPu
   const u32 nb = (n + ING_EPB - 1) / ING_EPB;
   if (blockIdx.x >= nb) return;
   IngLocal L;
-  ing_block_local(p, n, blockIdx.x, d.pause_thresh, s, L);
+  ing_block_local<true>(p, d.act, n, blockIdx.x, d.pause_thresh, s, L);
   if (threadIdx.x == 0) {
     IngBlk o;
     o.kept = L.n_kept;
@@ -363,7 +545,7 @@ __device__ inline IngScan ing_scan_blocks(const IngBlk* __restrict__ blk, u32 nb
   return o;
 }
 
-// kept events -> the ring, pauses -> the pause ring; every positive event becomes its pixel's latest event (activity filter)
+// kept events -> the ring, pauses -> the pause ring; every positive event joins its pixel's history (activity filter)
 __global__ __launch_bounds__(ING_THREADS) void k_ing_append(IngestDev d, IngestPush p) {
   __shared__ IngShared s;
   __shared__ IngScanShared ss;
@@ -374,7 +556,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_append(IngestDev d, IngestP
   const IngestState st = *d.st;  // (not modified by this kernel: k_ing_segment commits)
   const IngScan sc = ing_scan_blocks(d.blk, nb, blockIdx.x, st.write_abs > 0, st.last_t, d.pause_thresh, ss);
   IngLocal L;
-  ing_block_local(p, n, blockIdx.x, d.pause_thresh, s, L);
+  ing_block_local<false>(p, d.act, n, blockIdx.x, d.pause_thresh, s, L);
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 lt_mask = (1ull << lane) - 1ull;
   // the block's first kept event: the pause in front of it was decided by the scan
@@ -403,6 +585,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_append(IngestDev d, IngestP
   }
   __syncthreads();
   const u64 limit = st.start_abs + d.cap;  // the ring is full beyond: such events are dropped (k_ing_segment counts them)
+  const long long act_t0 = d.act.last_ts ? rec_t(p.src[0]) : 0;
   const u64 base = st.write_abs + sc.kept_before;
   const u64 pbase = st.p_tail + sc.pauses_before;
 #pragma unroll
@@ -410,11 +593,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_append(IngestDev d, IngestP
     const u32 i = blockIdx.x * ING_EPB + j * ING_THREADS + tid;
     if (i >= n) continue;
     const uint4 r = L.r[j];
-    if (d.last_ts && (!(p.flags & ING_F_POLARITY) || (short)(r.y & 0xffff) == 1)) {
-      const u32 x = r.x & 0xffff, y = r.x >> 16;
-      if (x < (u32)d.cam_w && y < (u32)d.cam_h)
-        __hip_atomic_fetch_max(&d.last_ts[y * (u32)d.cam_w + x], rec_t(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (d.act.last_ts) act_retire(d.act, act_event(r, true, (p.flags & ING_F_POLARITY) != 0, d.act.cam_w, d.act.cam_h), act_t0);
     if (!(L.keep_bits & (1u << j))) continue;
     const u64 abs = base + L.rank[j];
     if (abs >= limit) continue;
@@ -478,6 +657,8 @@ __device__ inline void ing_find_trigger(const IngestDev& d, u64& s_first) {
       const u64 frame_no = st->frames++;
       const u32 slot_i = (u32)(frame_no % d.ring);
       d.info->frame_no = frame_no;
+      d.info->t_first = rec_t(d.buf[first & mask]);
+      d.info->t_last = rec_t(d.buf[(last - 1) & mask]);
       FrameDesc* desc = d.desc;
       desc->x = nullptr; desc->y = nullptr; desc->t = nullptr; desc->p = nullptr;
       desc->aos = d.buf + (first & mask);  // contiguous: the ring's head is mirrored behind its end
@@ -526,6 +707,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_segment(IngestDev d, Ingest
         d.desc->valid = 0;
         st->span_ok = 0;
       }
+      if (d.act.last_ts) d.act.ctl[0] = 0u;  // (the packet's flags have been consumed: the next k_act_first decides afresh)
       s_first = ~0ull;
     }
     __syncthreads();
@@ -577,8 +759,8 @@ __global__ __launch_bounds__(64) void k_ing_publish(IngestState* st, const Frame
   __hip_atomic_store(&out->seq, (u64)0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
   out->n_events = desc->n;
-  out->t_first = desc->n ? rec_t(desc->aos[0]) : 0;
-  out->t_last = desc->n ? rec_t(desc->aos[desc->n - 1]) : 0;
+  out->t_first = info->t_first;
+  out->t_last = info->t_last;
   out->n_inliers = inl;
   out->n_index_errors = oob;
   out->n_used = used;

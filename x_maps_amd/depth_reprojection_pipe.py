@@ -8,8 +8,11 @@ hot path on the GPU.
 `process_ev_frame` is the function the trigger finder calls (trigger_finder.py:172).  In the reference it
 runs six NumPy/Numba/OpenCV stages; here it is one C-ABI call (xm_process_frame_aos) = three HIP kernels,
 and the frame handed to `frame_callback` is a fresh (H, W, 3) uint8 BGR array exactly as before.
-Out of scope in this build: Metavision's ActivityNoiseFilterAlgorithm (closed source), the
-timing watchdog.
+The packet side mirrors pipe:110-119: polarity filter -> activity-noise filter -> trigger finder.  The activity filter runs
+on every packet like the reference's (RuntimeParams.activity_filter, default True) -- as kernels of the device ingest, or, with
+the trigger finder on the host, as x_maps_amd.activity_filter.ActivityNoiseFilterAlgorithm (the same kernels behind one call);
+Metavision's own filter is a binary of the SDK, so the rule is this build's definition (oracle/ingest_oracle.py).
+Out of scope in this build: the timing watchdog.
 """
 from __future__ import annotations
 
@@ -36,7 +39,9 @@ class DepthReprojectionPipe:
     x_maps_disp: XMapsDisparity = field(init=False)
     disp_to_depth: DisparityToDepth = field(init=False)
     trigger_finder: RobustTriggerFinder = field(init=False)
-    activity_filter: Optional[Callable[[np.ndarray], np.ndarray]] = None  # plug a Metavision filter in here
+    # host path: callable(pos_events) -> kept events.  None = this build's filter when RuntimeParams.activity_filter is on
+    # (the default, as in the reference); plug Metavision's own filter in here where the SDK is installed
+    activity_filter: Optional[Callable[[np.ndarray], np.ndarray]] = None
     fused: bool = True  # False = run the reference's six stages one by one (each still a HIP kernel)
 
     def __post_init__(self):
@@ -83,10 +88,14 @@ class DepthReprojectionPipe:
         if getattr(p, "device_ingest", False):
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
-                                       activity_filter=getattr(p, "activity_filter", False), want_depth=False,
+                                       activity_filter=bool(getattr(p, "activity_filter", True)), want_depth=False,
                                        result_ring=int(getattr(p, "ingest_result_ring", 8)),
                                        lossless=not p.should_drop_frames)  # no_frame_dropping (the default): never lap the ring
             self._ingest_views = bool(getattr(p, "ingest_frame_views", False))
+        elif self.activity_filter is None and getattr(p, "activity_filter", True):
+            from .activity_filter import ActivityNoiseFilterAlgorithm
+            self._own_act_filter = ActivityNoiseFilterAlgorithm(self.calib_maps.engine, int(1e6 / p.projector_fps))  # pipe:65-67
+            self.activity_filter = self._own_act_filter
 
     # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------
     def _deliver_ingest_frames(self):
@@ -119,7 +128,7 @@ class DepthReprojectionPipe:
     def _process_raw_words(self, words, fmt):
         from . import evt2, evt3
         mod, dt = (evt2, "<u4") if fmt == 2 else (evt3, "<u2")
-        if self.ingest is not None and not getattr(self.params, "activity_filter", False):
+        if self.ingest is not None:
             dev = self._raw_dev.get(fmt)
             if dev is None:
                 cls = evt2.DeviceEvt2Decoder if fmt == 2 else evt3.DeviceEvt3Decoder
@@ -229,4 +238,7 @@ class DepthReprojectionPipe:
         self._raw_dev = {}
         if self.ingest is not None:
             self.ingest.close()
+        if getattr(self, "_own_act_filter", None) is not None:
+            self._own_act_filter.close()
+            self._own_act_filter = None
         self.calib_maps.engine.close()

@@ -43,7 +43,11 @@ class RuntimeParams:
     tables: Optional[dict] = None  # pre-built tables instead of `calib`
     device: int = 0
     device_ingest: bool = False  # polarity / activity filter + frame segmentation on the GPU (x_maps_amd/ingest.py)
-    activity_filter: bool = False  # device ingest only: the own-definition activity-noise rule (see xmaps_ingest.hpp)
+    # The activity-noise filter behind the polarity filter, on every packet, as the reference runs it unconditionally
+    # (depth_reprojection_pipe.py:65-67,116-117): kernels of the device ingest, or one GPU call per packet in front of the host's
+    # trigger finder.  The rule is this build's own definition (Metavision's is a binary: oracle/ingest_oracle.py); False
+    # switches the stage off (round 4's default).
+    activity_filter: bool = True
     # device ingest only: hand frame_callback / window.show_async a VIEW into the ingest's ring of pinned result buffers instead of
     # a fresh array (the reference hands out fresh arrays; for its 1080 x 1920 projector that copy is 6.2 MB = ~0.5 ms of host
     # time per frame).  LIFETIME of such a frame: until `ingest_result_ring` - 1 further frames have been produced -- a window or

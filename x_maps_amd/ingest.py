@@ -164,6 +164,13 @@ class DeviceIngest:
         self._pushes_unsynced = 0
         return {"frames_cut": int(a.value), "events_appended": int(b.value), "events_dropped": int(c.value), "events_live": int(d.value)}
 
+    def activity_sequential_packets(self) -> int:
+        """activity filter: packets so far that the device judged sequentially (synchronises)"""
+        n = C.c_uint64(0)
+        N.check(self._lib.xm_ingest_activity_stats(self._g, C.byref(n)))
+        self._pushes_unsynced = 0
+        return int(n.value)
+
     def host_stats(self) -> dict:
         """What the calling thread has paid inside push() so far (xm_ingest_host_stats)."""
         n, sec, waits, wsec = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0), C.c_double(0.0)
