@@ -370,12 +370,22 @@ def other_config_legs(args, torch, dist, dev, local_rank):
                 if k in out["config"]:
                     leg[k] = out["config"][k]
         ip = out.get("ingest_path")
+        ing_keys = ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "frames_cut", "activity_filter",
+                    "same_frames_as_host_trigger_finder", "first_frame_equals_oracle", "host_us_per_push", "outputs",
+                    "chunks_judged_sequentially", "overflow", "error")
         if isinstance(ip, dict):
-            leg["ingest_path"] = {k: ip[k] for k in ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "frames_cut",
-                                                     "same_frames_as_host_trigger_finder", "first_frame_equals_oracle",
-                                                     "host_us_per_push", "outputs") if k in ip}
+            leg["ingest_path"] = {k: ip[k] for k in ing_keys if k in ip}
+        if "per_frame_host_call_ms" in out:  # (configs[0]: one ESL-like frame through process_ev_frame's call, host to host)
+            leg["per_frame_host_call_ms"] = {k: v for k, v in out["per_frame_host_call_ms"].items() if k != "definition"}
+        if out.get("cpu_baseline"):
+            leg["cpu_baseline"] = out["cpu_baseline"]
         sl = out.get("stream_legs")
         if isinstance(sl, dict):
+            for k in ("ingest_path_filter_off", "from_evt3_words_period_chunks", "from_evt3_words_period_chunks_filter_off"):
+                if isinstance(sl.get(k), dict):
+                    leg[k] = {a: sl[k][a] for a in ing_keys if a in sl[k]}
+            if isinstance(sl.get("paced"), dict):
+                leg["paced"] = sl["paced"]
             for k in ("full_replay_through_processor_host_trigger_finder", "full_replay_through_processor_device_ingest"):
                 if isinstance(sl.get(k), dict):
                     leg[k] = {a: b for a, b in sl[k].items() if a != "note"}
@@ -390,6 +400,8 @@ def other_config_legs(args, torch, dist, dev, local_rank):
     for name, fn, over in plan:
         a = copy.copy(args)
         a.no_cpu_baseline, a.no_other_modes, a.single_block, a.batch, a.groups_in_flight = True, True, False, 32, 4
+        if name == "esl":  # (configs[0] is "single frame, CPU reference path": the port timed on an ESL-like frame, ~5 s)
+            a.no_cpu_baseline, a.cpu_seconds = False, min(args.cpu_seconds, 4.0)
         for k, v in over.items():
             setattr(a, k, v)
         t0 = time.perf_counter()
@@ -440,18 +452,99 @@ def dry_run(args, rank, world):
     import torch
     import torch.distributed as dist
     seen = 1
+    out = {"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int64+f64", "data": "synthetic", "config": {"workload": "dry"}, "ranks_seen": seen,
+           "spawned_by_bench": os.environ.get("XM_BENCH_SPAWNED") == "1"}
+    leg_failed = False
     if world > 1:
         dist.init_process_group("gloo")
         t = torch.ones(1)
         dist.all_reduce(t)
-        seen = int(t.item())
+        out["ranks_seen"] = int(t.item())
         dist.barrier()
-        dist.destroy_process_group()
+        # XM_BENCH_DRY_LEG = "ok" | "hang:<rank>" | "die:<rank>": a stand-in for the sharded leg behind the replicas -- two
+        # collectives, between which the named rank goes to sleep for ever / leaves -- under the very guard the real leg runs under
+        mode = os.environ.get("XM_BENCH_DRY_LEG")
+        if mode:
+            kind, _, who = mode.partition(":")
+
+            def fake_leg():
+                dist.all_reduce(torch.ones(1))
+                if kind == "hang" and rank == int(who):
+                    time.sleep(10_000)
+                if kind == "die" and rank == int(who):
+                    os._exit(7)
+                dist.all_reduce(torch.ones(1))
+                return None if rank else {"error": "dry"} if kind == "error" else {"dry_leg": "ok"}
+            leg = sharded_leg_guarded(fake_leg, out if rank == 0 else None, rank, what="the dry stand-in of the sharded leg")
+            if rank == 0:
+                out.setdefault("other_modes", {})["one_frame_sharded_over_the_ranks"] = leg
+            leg_failed = isinstance(leg, dict) and "error" in leg
+        if not leg_failed:
+            dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "int64+f64", "data": "synthetic", "config": {"workload": "dry"}, "ranks_seen": seen,
-                          "spawned_by_bench": os.environ.get("XM_BENCH_SPAWNED") == "1"}), flush=True)
+        print(json.dumps(out), flush=True)
+    if leg_failed:
+        os._exit(0)
+
+
+def attach_sharded_leg(out, sharded_leg):
+    """the sharded leg's figures under other_modes of the replicas' line (never `value`)"""
+    om = out.setdefault("other_modes", {}) if out.get("other_modes") is not None else out.__setitem__("other_modes", {}) or out["other_modes"]
+    if not isinstance(sharded_leg, dict) or "error" in sharded_leg:
+        om["one_frame_sharded_over_the_ranks"] = sharded_leg if isinstance(sharded_leg, dict) else {"error": "the leg produced nothing"}
+        return
+    om["one_frame_sharded_over_the_ranks"] = {
+        "value": sharded_leg["value"], "unit": sharded_leg["unit"], "ms_per_frame": sharded_leg["ms_per_step"], "scaling": "strong",
+        "workload": sharded_leg["config"]["workload"], "events_per_rank": sharded_leg["config"]["events_per_rank"],
+        "collective_ms": sharded_leg["collective_ms"], "kernels_us": sharded_leg["roofline"]["avg_launch_us"],
+        "parity": sharded_leg["parity"],
+        "merge": sharded_leg["config"]["merge"], "fell_back": sharded_leg["config"]["fell_back"],
+        "frames_in_flight": sharded_leg["config"]["frames_in_flight"],
+        "collectives_issued_by": sharded_leg["config"]["collectives_issued_by"], "comm_note": sharded_leg["config"]["comm_note"],
+        "Mevents_per_s_via_torch_distributed": sharded_leg["config"]["Mevents_per_s_via_torch_distributed"],
+        "Mevents_per_s_one_frame_at_a_time": sharded_leg["config"]["Mevents_per_s_one_frame_at_a_time"],
+        "collective_bytes_per_frame_and_rank": sharded_leg["config"]["collective_bytes_per_frame_and_rank"],
+        "note": "bench.py --sharded on the same ranks: C-10M, the event buffer split by index; merge = columns: every time column "
+                "on one rank (all-gather of the shards' last events), plain u16 frames SUM-all-reduced; merge = all_reduce: MIN "
+                "all-reduce of the extrema + MAX all-reduce of the packed-key frame; collective time (one frame at a time) "
+                "listed separately; the headline `value` is frame-level weak scaling without any collective"}
+
+
+def emit(out):
+    """the ONE JSON line, last on stdout"""
+    # RCCL prints its version banner through C stdio, which (redirected) is flushed at exit, i.e. AFTER Python's own
+    # buffer: flush it now so that the JSON line is the LAST line on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def leg_timeout_s():
+    return float(os.environ.get("XM_BENCH_LEG_TIMEOUT_S", "300"))
+
+
+def sharded_leg_guarded(run_leg, out, rank, what="the sharded leg (C-10M over the ranks)"):
+    """Runs `run_leg()` on every rank under a LegGuard.  If it does not come back (a collective that never completes, a rank that
+    died: SIGTERM from the launcher), rank 0 prints the replicas' line it already holds -- with the leg's error in it -- and
+    every rank leaves through os._exit(0), without destroying communicators that may be stuck.  Returns the leg's result."""
+    from benchmodes.guard import LegGuard
+
+    def on_expire(reason):
+        sys.stderr.write(f"[bench] rank {rank}: {reason}\n")
+        if rank == 0 and out is not None:
+            attach_sharded_leg(out, {"error": reason})
+            emit(out)
+    try:
+        with LegGuard(leg_timeout_s(), on_expire, exit_code=0, name=what):
+            return run_leg()
+    except Exception as e:  # never lose the replicas' line to the extra leg
+        sys.stderr.write("bench.py: sharded leg failed on rank %d: %r\n" % (rank, e))
+        return {"error": repr(e)[:300]}
 
 
 def main():
@@ -478,32 +571,39 @@ def main():
             print(json.dumps({"error": f"rank {rank} has no GPU (visible: {torch.cuda.device_count()})", "n_gpus_requested": args.gpus}), flush=True)
         sys.exit(2)
     dist = None
+    dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1 or args.sharded or os.environ.get("XM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
+        from benchmodes.guard import LegGuard
         dist = dist_mod
         torch.cuda.set_device(local_rank)
-        if "MASTER_ADDR" not in os.environ:  # single process (--sharded on one GPU): file rendezvous, nothing to resolve
-            import tempfile
-            dist.init_process_group("nccl", init_method=f"file://{tempfile.mkdtemp()}/rdzv", rank=0, world_size=1,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+        def no_rendezvous(reason):  # nothing is measured yet: an error line, a non-zero exit
+            if rank == 0:
+                emit({"error": "RCCL rendezvous / first all-reduce: " + reason, "n_gpus_requested": args.gpus})
+        with LegGuard(leg_timeout_s(), no_rendezvous, exit_code=3, name="the RCCL rendezvous of the ranks"):
+            if "MASTER_ADDR" not in os.environ:  # single process (--sharded on one GPU): file rendezvous, nothing to resolve
+                import tempfile
+                dist.init_process_group("nccl", init_method=f"file://{tempfile.mkdtemp()}/rdzv", rank=0, world_size=1,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the ranks count each other over RCCL before anything is measured
+            one = torch.ones(1, device=dev)
+            dist.all_reduce(one)
+            ranks_seen = int(one.item())
+        if ranks_seen != world:
+            raise SystemExit(f"RCCL all-reduce saw {ranks_seen} ranks, WORLD_SIZE is {world}")
     else:
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     if args.lib_option:
         from x_maps_amd import _native as xm_native
         for kv in args.lib_option:
             k, _, v = kv.partition("=")
             xm_native.debug_option(k, v)
-    ranks_seen = 1
-    if dist is not None:  # the ranks count each other over RCCL before anything is measured
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one)
-        ranks_seen = int(one.item())
-        if ranks_seen != world:
-            raise SystemExit(f"RCCL all-reduce saw {ranks_seen} ranks, WORLD_SIZE is {world}")
     out = None
+    leg_failed = False
     try:
         if args.sharded:
             out = bench_sharded(args, torch, dist, dev, rank, local_rank, world)
@@ -513,20 +613,32 @@ def main():
             out = bench_graph(args, torch, dist, dev, rank, local_rank, world)
         else:
             out = bench_stream(args, torch, dist, dev, rank, local_rank, world)
+            # N > 1: the frame-level replicas above need no collective.  The path's real exchange step -- one 10 M-event frame sharded
+            # by event index over the ranks (BASELINE configs[3]) -- is measured behind them on the same ranks (never `value`): every
+            # rank takes part, rank 0 keeps the figures.  Rank 0 holds the finished replicas' line by now: whatever happens inside
+            # the leg, that line is printed (sharded_leg_guarded).
+            if (world > 1 or os.environ.get("XM_BENCH_FORCE_SHARDED_LEG") == "1") and dist is not None and not args.no_other_modes:
+                import copy  # (XM_BENCH_FORCE_SHARDED_LEG + XM_BENCH_FORCE_DIST: the tests exercise this leg on a one-GPU box)
+                if rank == 0:
+                    out["n_gpus"], out["rccl_ranks_seen"] = world, ranks_seen
+                    sys.stderr.write("[bench] replicas measured: %s\n" % json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step")}))
+                    sys.stderr.flush()
+                a2 = copy.copy(args)
+                a2.steps, a2.no_cpu_baseline, a2.single_block, a2.as_leg = 40, True, False, True
+                leg = sharded_leg_guarded(lambda: bench_sharded(a2, torch, dist, dev, rank, local_rank, world), out, rank)
+                leg_failed = isinstance(leg, dict) and "error" in leg
+                if rank == 0 and (leg is not None):
+                    attach_sharded_leg(out, leg)
     finally:
-        if dist is not None:
+        if dist is not None and not leg_failed:  # (after a failed leg a communicator may be stuck: leave it alone)
             dist.destroy_process_group()
     if rank == 0 and out is not None:
         assert out["n_gpus"] == args.gpus == world, (out["n_gpus"], args.gpus, world)
         out["rccl_ranks_seen"] = ranks_seen if dist is not None else None
-        # RCCL prints its version banner through C stdio, which (redirected) is flushed at exit, i.e. AFTER Python's own
-        # buffer: flush it now so that the JSON line is the LAST line on stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+        emit(out)
+    if leg_failed:
+        sys.stdout.flush(), sys.stderr.flush()
+        os._exit(0)
 
 
 # =====================================================================================================================
@@ -663,19 +775,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     value = total_events / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     paths = eng.path_counts()
-    # N > 1: the frame-level replicas above need no collective.  The path's real exchange step -- one 10 M-event frame sharded by
-    # event index over the ranks, extrema MIN-reduce + packed-key MAX-merge over RCCL / xGMI (BASELINE configs[3]) -- is measured
-    # beside it on the same ranks (never `value`): every rank takes part, rank 0 keeps the figures
-    sharded_leg = None
-    if (world > 1 or os.environ.get("XM_BENCH_FORCE_SHARDED_LEG") == "1") and dist is not None and not args.no_other_modes:
-        import copy  # (XM_BENCH_FORCE_SHARDED_LEG + XM_BENCH_FORCE_DIST: the tests exercise this leg on a one-GPU box)
-        a2 = copy.copy(args)
-        a2.steps, a2.no_cpu_baseline, a2.single_block, a2.as_leg = 40, True, False, True
-        try:
-            sharded_leg = bench_sharded(a2, torch, dist, dev, rank, local_rank, world)
-        except Exception as e:  # never lose the replicas' line to the extra leg
-            sharded_leg = None
-            sys.stderr.write("bench.py: sharded leg failed on rank %d: %r\n" % (rank, e))
+    # (N > 1: the path's real exchange step -- one 10 M-event frame sharded over the same ranks -- is measured by main() BEHIND this
+    #  function, under a wall-clock guard, once rank 0 holds the finished replicas' line: sharded_leg_guarded)
     if rank != 0:
         eng.close()
         return None
@@ -867,23 +968,6 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "host_enqueue_us_per_step": round(float(np.median(enq)) / args.steps * 1e6, 2),
     }
-    if sharded_leg:
-        other_modes = other_modes or {}
-        other_modes["one_frame_sharded_over_the_ranks"] = {
-            "value": sharded_leg["value"], "unit": sharded_leg["unit"], "ms_per_frame": sharded_leg["ms_per_step"], "scaling": "strong",
-            "workload": sharded_leg["config"]["workload"], "events_per_rank": sharded_leg["config"]["events_per_rank"],
-            "collective_ms": sharded_leg["collective_ms"], "kernels_us": sharded_leg["roofline"]["avg_launch_us"],
-            "parity": sharded_leg["parity"],
-            "merge": sharded_leg["config"]["merge"], "fell_back": sharded_leg["config"]["fell_back"],
-            "frames_in_flight": sharded_leg["config"]["frames_in_flight"],
-            "collectives_issued_by": sharded_leg["config"]["collectives_issued_by"], "comm_note": sharded_leg["config"]["comm_note"],
-            "Mevents_per_s_via_torch_distributed": sharded_leg["config"]["Mevents_per_s_via_torch_distributed"],
-            "Mevents_per_s_one_frame_at_a_time": sharded_leg["config"]["Mevents_per_s_one_frame_at_a_time"],
-            "collective_bytes_per_frame_and_rank": sharded_leg["config"]["collective_bytes_per_frame_and_rank"],
-            "note": "bench.py --sharded on the same ranks: C-10M, the event buffer split by index; merge = columns: every time column "
-                    "on one rank (all-gather of the shards' last events), plain u16 frames SUM-all-reduced; merge = all_reduce: MIN "
-                    "all-reduce of the extrema + MAX all-reduce of the packed-key frame; collective time (one frame at a time) "
-                    "listed separately; the headline `value` is frame-level weak scaling without any collective"}
     if other_modes:
         out["other_modes"] = other_modes
     if host_path:
@@ -1323,6 +1407,9 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         e0 = host[0]
         cpu = cpu_baseline_leg(args, O, tables, (e0["x"].copy(), e0["y"].copy(), np.ascontiguousarray(e0["t"])), len(e0), camera,
                                bgr_out is not None)
+        cpu["ms_per_frame"] = round(len(e0) / cpu["value"] / 1e3, 3)
+        cpu["reference_published_ms_per_frame"] = ("2.67 +- 0.31 (Numba on a Threadripper PRO 5955WX, real ESL frames: BASELINE.md section 1; other "
+                                                   "hardware -- the port above is 3-17x slower than that and flatters any GPU / CPU ratio)")
     out = {
         "metric": "Mevents/s to depth frame, ESL-like frames (640x480 camera, 1080x1920 projector, ~150k ev/frame)",
         "value": round(value, 2), "unit": "Mevents/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -1369,7 +1456,7 @@ def esl_stream_child(args, device):
     with XMapsEngine(tables, camera_perspective=camera, device=device, n_slots=4) as eng:
         legs = esl_stream_legs(eng, cp, tables, int(n_mean), O, camera, device)
     assert "torch" not in sys.modules
-    keep = ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "ms_per_shown_frame", "frames_cut", "frames_shown",
+    keep = ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "ms_per_shown_frame", "frames_cut", "frames_shown", "activity_filter",
             "same_frames_as_host_trigger_finder", "first_frame_equals_oracle", "host_us_per_push", "same_frames_as_host_path")
     out = {k: {q: v[q] for q in keep if q in v} for k, v in legs.items() if isinstance(v, dict) and k != "stream"}
     out["note"] = ("the same legs in a process without torch (NumPy + the library only, as in the reference's application): the library runs "
@@ -1395,25 +1482,41 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
     packet = int(1e6 / 60 / 4)
     cuts = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + packet, packet))
     packets = [pin[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
-    # what the reference's own chain cuts out of these packets (polarity filter + RobustTriggerFinder on the host)
-    want, want_frames = [], []
+    # what the reference's own chain cuts out of these packets on the host: polarity filter -> activity filter (the checker's
+    # sequential form of this build's rule, oracle/ingest_oracle.py; `False`: the stage left out, round 4's pipeline) ->
+    # RobustTriggerFinder
+    import ingest_oracle as IO
+    want_by, want_frames_by, kept_by = {}, {}, {}
+    for act_on in (True, False):
+        want, want_frames = [], []
 
-    def on_frame(e):
-        want.append((int(e["t"][0]), int(e["t"][-1]), len(e)))
-        if len(want_frames) < 1:
-            want_frames.append(np.array(e))
-    tf = RobustTriggerFinder(60, on_frame)
-    for pk in packets:
-        tf.process_events(pk[pk["p"] == 1])
+        def on_frame(e, want=want, want_frames=want_frames):
+            want.append((int(e["t"][0]), int(e["t"][-1]), len(e)))
+            if len(want_frames) < 1:
+                want_frames.append(np.array(e))
+        tf = RobustTriggerFinder(60, on_frame)
+        act = IO.ActivityFilterC(640, 480, int(1e6 / 60))
+        kept = 0
+        for pk in packets:
+            pos = pk[pk["p"] == 1]
+            if act_on:
+                pos = act.process(pos)
+            kept += len(pos)
+            tf.process_events(pos)
+        want_by[act_on], want_frames_by[act_on], kept_by[act_on] = want, want_frames, kept
+    want = want_by[True]
     out = {"stream": {"frames_rendered": n_frames, "events": int(len(stream)), "packets": len(packets), "packet_us": packet,
-                      "frames_the_host_trigger_finder_cuts": len(want),
+                      "frames_the_host_trigger_finder_cuts": len(want_by[True]), "frames_without_the_activity_filter": len(want_by[False]),
+                      "events_behind_polarity_filter": kept_by[False], "events_behind_activity_filter": kept_by[True],
                       "note": "ESL-like stand-in (rig.render_stream: real calibration geometry, rendered scene, 10 % negative events, "
                               "gap noise); the reference's trigger finder loses lock on some frames by design -- the device cuts the "
-                              "same ones"}}
+                              "same ones.  Every leg runs the reference's chain polarity filter -> activity-noise filter -> trigger "
+                              "finder (depth_reprojection_pipe.py:110-119) unless its name says filter_off"}}
 
-    def run(want_depth, views, label):
+    def run(want_depth, views, label, act_on=True):
+        want, want_frames = want_by[act_on], want_frames_by[act_on]
         with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=n_mean,
-                          result_ring=n_frames + 2, want_depth=want_depth, want_bgr=True) as ing:
+                          result_ring=n_frames + 2, want_depth=want_depth, want_bgr=True, activity_filter=act_on) as ing:
             # warm-up = the whole stream once, untimed: first launches of every kernel, and one round of DMA through every pinned
             # buffer of the fresh result ring (the first copies into new pinned memory run at a third of the later rate under the
             # HIP runtime PyTorch bundles: a start-up cost of a ring that a live pipe allocates once)
@@ -1449,7 +1552,7 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                 ok = bool(np.array_equal(got[0].bgr, ref["bgr"])) and (not want_depth or bool(np.array_equal(got[0].depth, ref["depth"])))
             n_push = hs["pushes"] - hs0["pushes"]
             out[label] = {"Mevents_per_s_end_to_end": round(len(stream) / dt / 1e6, 2), "frames_per_s": round(len(got) / dt, 1),
-                          "ms_per_cut_frame": round(dt / max(len(got), 1) * 1e3, 4), "frames_cut": len(got),
+                          "ms_per_cut_frame": round(dt / max(len(got), 1) * 1e3, 4), "frames_cut": len(got), "activity_filter": bool(act_on),
                           "same_frames_as_host_trigger_finder": bool(same), "first_frame_equals_oracle": ok,
                           "host_us_per_push": round((hs["host_seconds_in_push"] - hs["seconds_waiting_for_the_gpu"] - hs0["host_seconds_in_push"]
                                                      + hs0["seconds_waiting_for_the_gpu"]) / max(n_push, 1) * 1e6, 2),
@@ -1459,8 +1562,54 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                           "outputs": ("BGR u8" + (" + depth f32" if want_depth else "")) + (", views into the pinned result ring" if views else ", fresh arrays (copied out of the ring)"),
                           "pcie_GBps_out": round(len(got) * eng.out_h * eng.out_w * (3 + (4 if want_depth else 0)) / dt / 1e9, 2)}
     run(False, True, "ingest_path")                      # what frame_callback gets in the reference: the BGR frame
+    run(False, True, "ingest_path_filter_off", act_on=False)
     run(True, True, "ingest_path_depth_and_bgr")
     run(False, False, "ingest_path_fresh_arrays")
+    # LIVE latency: the stream pushed at its own pace -- a packet becomes available at its last time stamp (speed 1 = the
+    # camera's 60 Hz, 10 = ten times as fast) -- while the host polls; per frame: xm_ingest_push_pinned of the packet that cut it
+    # called -> xm_ingest_poll hands the frame out (BGR view in the pinned ring).  The reference's loop is such a live system
+    # (depth_reprojection.py:62-78; timing_watchdog.py:17-33 measures how far it falls behind).
+    def run_paced(speed):
+        with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 18, expected_events_per_frame=n_mean,
+                          result_ring=n_frames + 2, want_depth=False, want_bgr=True, activity_filter=True) as ing:
+            for pk in packets:
+                ing.push_pinned(pk)
+            ing.flush(), ing.reset(), ing.poll(copy=False)
+            t_first = int(packets[0]["t"][0])
+            lat, push_at, got_n = [], {}, 0
+            base_push = ing.host_stats()["pushes"]
+            c0 = time.perf_counter()
+
+            def drain():
+                nonlocal got_n
+                for f in ing.poll(copy=False):
+                    now = time.perf_counter()
+                    got_n += 1
+                    if f.push_seq - base_push in push_at and not f.lost:
+                        lat.append(now - push_at[f.push_seq - base_push])
+            for k, pk in enumerate(packets):
+                due = c0 + (int(pk["t"][-1]) - t_first) / 1e6 / speed
+                while time.perf_counter() < due:
+                    drain()
+                push_at[k + 1] = time.perf_counter()
+                ing.push_pinned(pk)
+            end = time.perf_counter() + 0.05
+            while time.perf_counter() < end and got_n < len(want_by[True]):
+                drain()
+            ing.flush()
+            drain()
+        la = np.array(lat) * 1e3
+        return {"speed": speed, "frames": int(len(la)), "frames_expected": len(want_by[True]), "each_ms": [round(float(v), 3) for v in la],
+                "push_to_frame_visible_ms": {"p50": round(float(np.percentile(la, 50)), 4), "p99": round(float(np.percentile(la, 99)), 4),
+                                             "max": round(float(la.max()), 4)} if len(la) else None}
+    try:
+        out["paced"] = {"real_time": run_paced(1.0), "ten_times": run_paced(10.0),
+                        "definition": "ESL-like stream, quarter-period packets pushed when their last event's time has come (activity "
+                                      "filter on, BGR views); latency = call of xm_ingest_push_pinned for the packet that completes "
+                                      "a frame -> xm_ingest_poll returns that frame (H2D of the packet, ingest kernels, verdict, "
+                                      "K0/K1/K2, 6.2 MB D2H, sequence number)"}
+    except Exception as e:
+        out["paced"] = {"error": repr(e)[:300]}
     try:  # the same stream as the recording stores it (EVT 3.0 words), one projector period per chunk, decoded on the device
         from x_maps_amd import evt3
         cuts3 = np.searchsorted(pin["t"], np.arange(pin["t"][0], pin["t"][-1] + 4 * packet, 4 * packet))
@@ -1472,22 +1621,30 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                 pw[:] = w
                 chunks.append(pw)
         n_words = int(sum(len(c) for c in chunks))
-        with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 19, expected_events_per_frame=n_mean,
-                          result_ring=n_frames + 2, want_depth=False) as ing, \
-                evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
-            for c in chunks:  # (warm-up: the whole stream once, see above)
-                dec.push(ing, c, pinned=True, count=False)
-            ing.flush(), ing.reset(), ing.poll(copy=False), dec.reset()
-            c0 = time.perf_counter()
-            for c in chunks:
-                dec.push(ing, c, pinned=True, count=False)
-            ing.flush()
-            got3 = ing.poll(copy=False)
-            dt3 = time.perf_counter() - c0
-            over = max([f.overflow for f in got3] + [0])
-        out["from_evt3_words_period_chunks"] = {
-            "Mevents_per_s_end_to_end": round(len(stream) / dt3 / 1e6, 2), "frames_cut": len(got3), "chunks": len(chunks), "overflow": over,
-            "bytes_per_event_over_pcie": round(2.0 * n_words / len(stream), 2), "processed_in_seconds": round(dt3, 4)}
+        for act_on, label in ((True, "from_evt3_words_period_chunks"), (False, "from_evt3_words_period_chunks_filter_off")):
+            with DeviceIngest(eng, 60, capacity_events=1 << 21, max_packet_events=1 << 19, expected_events_per_frame=n_mean,
+                              result_ring=n_frames + 2, want_depth=False, activity_filter=act_on) as ing, \
+                    evt3.DeviceEvt3Decoder(eng, max_words=max(len(c) for c in chunks)) as dec:
+                for c in chunks:  # (warm-up: the whole stream once, see above)
+                    dec.push(ing, c, pinned=True, count=False)
+                ing.flush(), ing.reset(), ing.poll(copy=False), dec.reset()
+                hs0 = ing.host_stats()
+                c0 = time.perf_counter()
+                for c in chunks:
+                    dec.push(ing, c, pinned=True, count=False)
+                ing.flush()
+                got3 = ing.poll(copy=False)
+                dt3 = time.perf_counter() - c0
+                hs = ing.host_stats()
+                over = max([f.overflow for f in got3] + [0])
+                seq_pk = ing.activity_sequential_packets() if act_on else 0
+            out[label] = {
+                "Mevents_per_s_end_to_end": round(len(stream) / dt3 / 1e6, 2), "frames_cut": len(got3), "chunks": len(chunks), "overflow": over,
+                "activity_filter": act_on, "chunks_judged_sequentially": seq_pk,
+                "host_us_per_push": round((hs["host_seconds_in_push"] - hs["seconds_waiting_for_the_gpu"] - hs0["host_seconds_in_push"]
+                                           + hs0["seconds_waiting_for_the_gpu"]) / max(hs["pushes"] - hs0["pushes"], 1) * 1e6, 2),
+                "host_us_per_push_incl_backpressure": round((hs["host_seconds_in_push"] - hs0["host_seconds_in_push"]) / max(hs["pushes"] - hs0["pushes"], 1) * 1e6, 2),
+                "bytes_per_event_over_pcie": round(2.0 * n_words / len(stream), 2), "processed_in_seconds": round(dt3, 4)}
     except Exception as e:
         out["from_evt3_words_period_chunks"] = {"error": repr(e)[:200]}
 
@@ -1525,7 +1682,8 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
         b = run_processor(True, True, "full_replay_through_processor_device_ingest")
         out["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"] = bool(a == b)
         out["full_replay_through_processor_host_trigger_finder"]["note"] = (
-            "DepthReprojectionProcessor.process_events(packet): polarity filter + RobustTriggerFinder in NumPy on the host, one "
+            "DepthReprojectionProcessor.process_events(packet): polarity filter (NumPy) + activity filter (one GPU call per packet: "
+            "xm_activity_process) + RobustTriggerFinder in NumPy on the host, one "
             "synchronous fused call (H2D + K1 + K2 + D2H of the BGR frame) per cut frame: the reference's structure "
             "(reference_published_ms_per_frame 2.67 on a Threadripper PRO 5955WX for the frame stage alone)")
         out["full_replay_through_processor_device_ingest"]["note"] = (

@@ -522,6 +522,7 @@ typedef struct xm_ingest_frame {
   uint32_t lost;                   /* != 0: the ring was lapped, frames between the previous one and this were overwritten */
   const float* depth;              /* f32 [H][W] in the pinned ring (NULL if !want_depth); valid until result_ring - 1 */
   const uint8_t* bgr;              /* u8 [H][W][3]                   further frames have been produced                 */
+  uint64_t push_seq;               /* number (from 1) of the xm_ingest_push* call whose packet cut the frame (API version 3) */
 } xm_ingest_frame;
 int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out);
 void xm_ingest_destroy(xm_ingest* g);
@@ -532,8 +533,13 @@ int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n);
 int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n);
 /* next finished frame, if any: returns 1 and fills *out, 0 if none is ready (never blocks), < 0 on error */
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
+/* 1 if the result ring still holds frame `seq` (xm_ingest_frame.seq) intact, 0 if a later frame has been or is being written
+ * over it: a caller that copies a frame out of the ring asks this AFTER the copy (the ring is lapped only when the host falls
+ * result_ring - 1 frames behind; never in a pipe that polls after every push with result_ring >= 3) */
+int xm_ingest_frame_valid(xm_ingest* g, uint64_t seq);
 int xm_ingest_flush(xm_ingest* g); /* wait for everything pushed so far */
-int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events */
+int xm_ingest_reset(xm_ingest* g); /* RobustTriggerFinder.reset(): discard the buffered events (and the activity filter's
+                                     * per-pixel history: the stream starts over) */
 /* the device's counters once everything pushed so far has run (synchronises like xm_ingest_flush): frames cut, events appended
  * behind the filters, events dropped because the ring had no room (also the `overflow` of every frame), events still buffered.
  * Any pointer may be NULL. */

@@ -26,6 +26,9 @@ from __future__ import annotations
 import numpy as np
 
 
+_EVENT_CD = np.dtype({"names": ["x", "y", "p", "t"], "formats": ["<u2", "<u2", "<i2", "<i8"], "offsets": [0, 2, 4, 8], "itemsize": 16})
+
+
 def polarity_filter(evs):
     return evs[evs["p"] == 1]
 
@@ -61,11 +64,12 @@ def activity_filter_c(lib, evs, state, thresh_us):
     tests/test_oracle_ingest.py).  state = (last int64[h, w], has uint8[h, w]) carried by the caller."""
     import ctypes as C
     last, has = state
-    evs = np.ascontiguousarray(evs)
-    assert evs.dtype.itemsize == 16
+    rec = np.zeros(len(evs), _EVENT_CD)  # (np.concatenate of structured arrays drops the record's padding: always re-pack)
+    for k in ("x", "y", "p", "t"):
+        rec[k] = evs[k]
     keep = np.zeros(len(evs), np.uint8)
     lib.xmo_activity_filter.restype = C.c_int64
-    lib.xmo_activity_filter(C.c_void_p(evs.ctypes.data), C.c_int64(len(evs)), C.c_int(has.shape[1]), C.c_int(has.shape[0]), C.c_int64(int(thresh_us)),
+    lib.xmo_activity_filter(C.c_void_p(rec.ctypes.data), C.c_int64(len(rec)), C.c_int(has.shape[1]), C.c_int(has.shape[0]), C.c_int64(int(thresh_us)),
                             C.c_void_p(last.ctypes.data), C.c_void_p(has.ctypes.data), C.c_void_p(keep.ctypes.data))
     return evs[keep.view(bool)]
 

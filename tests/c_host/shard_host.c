@@ -2,7 +2,7 @@
  * torch in the process: the library runs on ROCm's own HIP runtime and looks librccl up itself).  tests/test_gpu_c_host.py writes
  * the rig's tables and one frame into a blob, this program runs the frame
  *   1. as one rank of a world of one through the library's shard communicator (xm_shard_comm_*: columns merge, then packed keys),
- *   2. through xm_create_sharded over device 0 (host columns in, host frames out),
+ *   2. through xm_create_sharded over device 0 (host columns in, host frames out), then over 2 / 4 / 8 virtual ranks on it,
  *   3. through xm_process_frame (the plain single-GPU entry),
  * and writes the depth / BGR frames of each back; the test compares them with the oracle's.
  *
@@ -141,6 +141,31 @@ int main(int argc, char** argv) {
     printf("sharded: n_dev=%d rccl=%d columns=%llu keys=%llu redone=%llu t=[%.0f, %.0f]\n", nd, rccl, (unsigned long long)fc,
            (unsigned long long)fk, (unsigned long long)fr, st.t_min, st.t_max);
     xm_sharded_destroy(s);
+  }
+
+  /* 2b. the same entry with 2 / 4 / 8 VIRTUAL ranks on device 0 (xm_debug_option: test switch of the library): the N > 1
+   *     orchestration -- shard bounds, gathered headers, predecessor columns, merge -- without a second GPU */
+  {
+    const int worlds[3] = {2, 4, 8};
+    for (int k = 0; k < 3; ++k) {
+      xm_sharded* s = NULL;
+      const int dev = 0;
+      int nd = 0, rccl = 0;
+      uint64_t fc = 0, fk = 0, fr = 0;
+      char w[8];
+      snprintf(w, sizeof w, "%d", worlds[k]);
+      CHECK(xm_debug_option("XM_SHARD_FAKE_RANKS", w));
+      CHECK(xm_create_sharded(&dev, 1, &cfg, &s));
+      CHECK(xm_debug_option("XM_SHARD_FAKE_RANKS", NULL));
+      CHECK(xm_sharded_info(s, &nd, &rccl, NULL));
+      CHECK(xm_sharded_process_frame(s, x, y, t, NULL, n, XM_T_INT64, depth, bgr, NULL));
+      CHECK(xm_sharded_stats(s, &fc, &fk, &fr));
+      snprintf(path, sizeof path, "%s.sharded_w%d", argv[2], worlds[k]);
+      if (write_frames(path, depth, bgr, proj)) return 3;
+      printf("virtual: n_dev=%d rccl=%d columns=%llu keys=%llu redone=%llu\n", nd, rccl, (unsigned long long)fc, (unsigned long long)fk,
+             (unsigned long long)fr);
+      xm_sharded_destroy(s);
+    }
   }
 
   /* 3. the plain entry */

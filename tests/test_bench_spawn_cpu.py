@@ -47,3 +47,39 @@ def test_more_ranks_than_gpus_fails_loudly():
     assert r.returncode != 0
     err = json.loads(r.stdout.strip().splitlines()[-1])
     assert err["n_gpus_requested"] == 64 and err["n_gpus_visible"] < 64
+
+
+# ---- the guard around the leg in which the ranks wait for one another (benchmodes/guard.py) -------------------------------------
+def _last_json(r):
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    return json.loads(lines[-1])
+
+
+def test_leg_behind_the_replicas_runs_under_the_guard():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"XM_BENCH_DRY_LEG": "ok", "XM_BENCH_LEG_TIMEOUT_S": "60"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["other_modes"]["one_frame_sharded_over_the_ranks"] == {"dry_leg": "ok"}
+
+
+def test_a_rank_that_hangs_inside_the_leg_does_not_cost_the_line():
+    """rank 1 goes to sleep between two collectives of the leg: rank 0 waits in the second one; after XM_BENCH_LEG_TIMEOUT_S the
+    guard prints the replicas' line with the leg's error in it and every rank leaves"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"XM_BENCH_DRY_LEG": "hang:1", "XM_BENCH_LEG_TIMEOUT_S": "6"}, timeout=120)
+    assert time.time() - t0 < 90
+    line = _last_json(r)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 3
+    assert "timeout" in line["other_modes"]["one_frame_sharded_over_the_ranks"]["error"]
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_a_rank_that_dies_inside_the_leg_does_not_cost_the_line():
+    """rank 1 leaves the process mid-leg: the launcher terminates rank 0 (SIGTERM) or its collective fails -- either way rank 0
+    has printed the replicas' line, with the leg's error, before it goes"""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"XM_BENCH_DRY_LEG": "die:1", "XM_BENCH_LEG_TIMEOUT_S": "30"}, timeout=180)
+    line = _last_json(r)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert "error" in line["other_modes"]["one_frame_sharded_over_the_ranks"]

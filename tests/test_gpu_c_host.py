@@ -49,7 +49,9 @@ def test_plain_c_host_runs_the_sharded_entries(tmp_path):
     assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
     assert "comm: columns=1" in r.stdout and "sharded: n_dev=1 rccl=1 columns=1 keys=0 redone=0" in r.stdout, r.stdout
     px = pmap.shape[0] * pmap.shape[1]
-    for leg in ("comm_columns", "comm_keys", "sharded", "single"):
+    for w in (2, 4, 8):
+        assert f"virtual: n_dev={w} rccl=0 columns=1 keys=0 redone=0" in r.stdout, r.stdout
+    for leg in ("comm_columns", "comm_keys", "sharded", "sharded_w2", "sharded_w4", "sharded_w8", "single"):
         raw = np.fromfile(tmp_path / f"out.{leg}", dtype=np.uint8)
         depth = raw[:px * 4].view(np.float32).reshape(pmap.shape[:2])
         bgr = raw[px * 4:].reshape(pmap.shape[:2] + (3,))

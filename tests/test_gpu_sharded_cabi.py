@@ -101,3 +101,50 @@ def test_bad_device_lists_are_rejected():
     for ids in ([0, 0], [99], []):
         with pytest.raises((XMapsNativeError, ValueError)):
             ShardedDevices(tb, devices=ids)
+
+
+# ---- N > 1 through the C entry on a one-GPU box: virtual ranks (XM_SHARD_FAKE_RANKS) ---------------------------------------------
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_virtual_ranks_run_the_whole_exchange_through_the_c_entry(W):
+    """xm_create_sharded with W virtual ranks on device 0: W handles and threads, shard bounds, the columns exchange (every rank's
+    header + last events gathered, the predecessor's last column, SUM of the u16 frames), the redo with packed keys (MIN of the
+    extrema, MAX of the keys), the agreement in front of every collective -- the collectives themselves emulated on the one device
+    (RCCL refuses two ranks on one GPU).  Every frame == the oracle's."""
+    xm_option("XM_SHARD_FAKE_RANKS", str(W))
+    tb = S.make_tables(S.C_1M)
+    evs = S.make_events(S.C_1M, frame=11)
+    with ShardedDevices(tb, devices=[0]) as sh:
+        assert sh.n_dev == W and not sh.uses_rccl
+        _check(tb, sh, evs)
+        _check(tb, sh, S.make_events(S.C_1M, frame=12, n=1_000_003))       # shards of unequal length
+        assert sh.stats() == {"frames_columns": 2, "frames_keys": 0, "frames_redone": 0}
+        shuffled = evs[np.random.default_rng(W).permutation(len(evs))]
+        _check(tb, sh, shuffled)                                            # every piece objects: redone with the keys
+        assert sh.stats()["frames_redone"] == 1
+        _check(tb, sh, S.make_events(S.C_1M, frame=13, p_zero_fraction=0.2), p=True)   # polarity column: keys
+        x, y, t, _ = S.to_soa(evs)
+        depth, _, _ = sh.process_frame(x, y, t.astype(np.float64), want_bgr=False)      # float stamps: keys, MIN over doubles
+        assert np.array_equal(depth, O.process_ev_frame(tb, x.astype(np.int64), y.astype(np.int64), t.astype(np.float64), want_bgr=False)["depth"])
+        _check(tb, sh, evs[:W * 64 + 5])                                    # hardly an event per rank
+        _check(tb, sh, evs[:3])                                             # fewer events than ranks: empty shards
+        _check(tb, sh, evs)                                                 # and the columns again
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("where", ["1:1", "2:2", "0:2"])
+def test_a_rank_failing_in_front_of_a_collective_fails_the_frame_on_every_rank(where):
+    """XM_SHARD_FAIL_AT = <rank>:<collective>: that rank's thread fails before entering the collective; the agreement barrier makes
+    every other rank skip it too -- the call returns an error naming the device instead of hanging"""
+    from x_maps_amd._native import XMapsNativeError
+    xm_option("XM_SHARD_FAKE_RANKS", "4")
+    xm_option("XM_SHARD_FAIL_AT", where)
+    tb = S.make_tables(S.C_1M)
+    evs = S.make_events(S.C_1M, frame=14, n=200_000)
+    x, y, t, _ = S.to_soa(evs)
+    with ShardedDevices(tb, devices=[0]) as sh:
+        for tt in (t, t.astype(np.float64)):  # the columns exchange, then the keys
+            with pytest.raises(XMapsNativeError, match="injected failure"):
+                sh.process_frame(x, y, tt)
+    xm_option("XM_SHARD_FAIL_AT", None)
+    with ShardedDevices(tb, devices=[0]) as sh:  # (a fresh handle in the same process works)
+        _check(tb, sh, evs)

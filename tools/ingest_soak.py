@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak of the device ingest (round 4's form: event ring, verdicts, launch thread, frame stream + DMA): random streams in random
-packets through random configurations -- launch thread on / off, activity filter on / off, rings from tiny (many wrap-arounds,
+"""Soak of the device ingest (event ring, verdicts, launch thread, frame stream + DMA): random streams in random
+packets through random configurations -- launch thread on / off, activity filter on (thresholds from one period down to 0.7 ms:
+one to many time buckets per packet, the sequential path; packets whose stamps step back) / off, rings from tiny (many wrap-arounds,
 no run-ahead) to roomy (run-ahead 3), pageable / pinned packets, EVT 3.0 / EVT 2.0 words with the count left on the device, polling after
 every push or only at the end -- against the CPU chain (oracle/ingest_oracle.py + xmaps_oracle.py): the same frames (first / last
 stamp, length, inliers, depth) every time.
@@ -43,16 +44,24 @@ with XMapsEngine(tb) as eng:
             pk = [stream[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         if rng.random() < 0.3:
             pk = [p for q in pk for p in (q, stream[:0])][:len(pk) + 5]  # empty packets in between
-        activity = bool(rng.random() < 0.25)
+        activity = bool(rng.random() < 0.5)
+        act_thresh = int(rng.choice([int(1e6 / 60), int(1e6 / 60), 3000, 700])) if activity else 0  # (700 us: > 8 buckets in many packets)
         thread = bool(rng.random() < 0.7)
-        words = (not activity) and bool(rng.random() < 0.35)
+        words = bool(rng.random() < 0.35)
+        if activity and not words and mode == "time" and rng.random() < 0.3 and len(pk) > 4:
+            # a glitch: one packet's second half steps back in time (the device judges that packet sequentially)
+            k = int(rng.integers(1, len(pk) - 1))
+            if len(pk[k]) > 8:
+                gl = pk[k].copy()
+                gl["t"][len(gl) // 2:] -= int(rng.choice([50, 5_000, 40_000]))
+                pk[k] = gl
         fmt = 2 if (words and rng.random() < 0.5) else 3  # EVT 2.0 or EVT 3.0 words
         pinned = bool(rng.random() < 0.5)
         poll_each = bool(rng.random() < 0.5)
         max_pk = max(2048, 1 << int(np.ceil(np.log2(max(len(p) for p in pk) + 1))))
         cap = max_pk * int(rng.choice([2, 4, 8, 16, 32]))
         tf = IO.TriggerFinderOracle(60)
-        act = IO.ActivityFilterOracle(cfg.cam_w, cfg.cam_h, int(1e6 / 60))
+        act = IO.ActivityFilterC(cfg.cam_w, cfg.cam_h, act_thresh or int(1e6 / 60))
         for p in pk:
             pos = IO.polarity_filter(p)
             tf.process_events(act.process(pos) if activity else pos)
@@ -60,8 +69,8 @@ with XMapsEngine(tb) as eng:
         # (a ring that cannot hold what the trigger finder may keep drops and says so: those runs only check that it says so)
         got = []
         keep = []
-        with DeviceIngest(eng, 60, activity_filter=activity, capacity_events=cap, max_packet_events=max_pk, result_ring=64,
-                          launch_thread=thread) as ing:
+        with DeviceIngest(eng, 60, activity_filter=activity, activity_thresh_us=act_thresh, capacity_events=cap, max_packet_events=max_pk,
+                          result_ring=64, launch_thread=thread) as ing:
             dec = (evt2.DeviceEvt2Decoder(eng, max_words=8 * max_pk) if fmt == 2 else evt3.DeviceEvt3Decoder(eng, max_words=8 * max_pk)) if words else None
             for p in pk:
                 if words:
@@ -87,7 +96,7 @@ with XMapsEngine(tb) as eng:
             dstat = ing.device_stats()
             if dec is not None:
                 dec.close()
-        desc = dict(seed=seed, frames=n_frames, packets=len(pk), mode=mode, activity=activity, thread=thread, words=words, fmt=fmt, pinned=pinned,
+        desc = dict(seed=seed, frames=n_frames, packets=len(pk), mode=mode, activity=activity, act_thresh=act_thresh, thread=thread, words=words, fmt=fmt, pinned=pinned,
                     poll_each=poll_each, cap=cap, max_pk=max_pk)
         overflow = max([f.overflow for f in got] + [dstat["events_dropped"]])
         if overflow or any(f.lost for f in got):

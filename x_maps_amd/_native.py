@@ -114,7 +114,7 @@ class xm_ingest_frame(C.Structure):
     _fields_ = [
         ("seq", C.c_uint64), ("n_events", C.c_uint64), ("t_first", C.c_int64), ("t_last", C.c_int64),
         ("n_inliers", C.c_uint64), ("n_index_errors", C.c_uint64), ("live_after", C.c_uint64),
-        ("overflow", C.c_uint32), ("lost", C.c_uint32), ("depth", C.c_void_p), ("bgr", C.c_void_p),
+        ("overflow", C.c_uint32), ("lost", C.c_uint32), ("depth", C.c_void_p), ("bgr", C.c_void_p), ("push_seq", C.c_uint64),
     ]
 
 
@@ -178,6 +178,7 @@ SYMBOLS = {
     "xm_ingest_push_pinned": (C.c_int, [_P, _P, C.c_size_t]),
     "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
     "xm_ingest_flush": (C.c_int, [_P]),
+    "xm_ingest_frame_valid": (C.c_int, [_P, C.c_uint64]),
     "xm_ingest_reset": (C.c_int, [_P]),
     "xm_shard_cols_info": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "xm_shard_cols_pack": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, C.c_size_t]),

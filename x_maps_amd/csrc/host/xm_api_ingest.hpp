@@ -163,7 +163,7 @@ void ingest_stream_release(int device) {
 }
 
 // the activity filter's device state (xmaps_ingest.hpp: ActDev), for an ingest or for the filter alone (xm_activity_*)
-int act_alloc(ActDev* a, int cam_w, int cam_h, long long thresh, size_t max_packet) {
+int act_alloc(ActDev* a, int cam_w, int cam_h, long long thresh, size_t max_packet, int n_sets = 1) {
   if (thresh < 0 || thresh >= (1ll << 31) - 2) return fail(XM_ERR_INVALID, "activity threshold must be in [0, 2^31 - 2) us");
   const size_t cam_px = (size_t)cam_w * cam_h;
   *a = ActDev{};
@@ -171,13 +171,13 @@ int act_alloc(ActDev* a, int cam_w, int cam_h, long long thresh, size_t max_pack
   a->cam_w = cam_w;
   a->cam_h = cam_h;
   HIP_TRY(hipMalloc((void**)&a->last_ts, cam_px * 8));
-  HIP_TRY(hipMalloc((void**)&a->cells, cam_px * sizeof(uint2) * ACT_NB));
+  HIP_TRY(hipMalloc((void**)&a->cells, cam_px * sizeof(uint2) * ACT_NB * (size_t)n_sets));
   HIP_TRY(hipMalloc((void**)&a->keep, max_packet ? max_packet : 1));
-  HIP_TRY(hipMalloc((void**)&a->ctl, 4 * sizeof(u32)));
+  HIP_TRY(hipMalloc((void**)&a->ctl, 4 * sizeof(u32) * (size_t)n_sets));
   std::vector<long long> init(cam_px, ING_NO_TS);
   HIP_TRY(hipMemcpy(a->last_ts, init.data(), cam_px * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(a->cells, 0, cam_px * sizeof(uint2) * ACT_NB));
-  HIP_TRY(hipMemset(a->ctl, 0, 4 * sizeof(u32)));
+  HIP_TRY(hipMemset(a->cells, 0, cam_px * sizeof(uint2) * ACT_NB * (size_t)n_sets));
+  HIP_TRY(hipMemset(a->ctl, 0, 4 * sizeof(u32) * (size_t)n_sets));
   HIP_TRY(hipDeviceSynchronize());  // (default-stream work: non-blocking streams do not wait for it)
   return XM_OK;
 }
@@ -473,11 +473,14 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
   p.src = g->d_pkt[k];
   p.n = (u32)n;
   p.n_dev = n_dev;
-  // activity filter: one more launch in front (the per-(bucket, pixel) cells of the packet; xmaps_ingest.hpp) -- the flags
-  // themselves are computed inside k_ing_count.  Nothing is decided here: a chunk decoded on the device is treated like records.
+  // activity filter: one more launch (the per-(bucket, pixel) cells of the packet, one event per thread; xmaps_ingest.hpp) -- the
+  // flags themselves are computed by k_ing_count as it counts.  Nothing is decided here: a chunk decoded on the device is treated
+  // like records.
+  // (On the ingest stream like the rest: a stream of its own -- a fifth one beside the handle's four hardware queues -- measured
+  //  61 us per packet against 47; on the stream the packet arrives on, beside the previous packet's kernels, no different.)
   if (g->dev.act.last_ts && n)
-    hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_EPB - 1) / ING_EPB)), dim3(ING_THREADS), 0, s, g->dev.act, (const uint4*)g->d_pkt[k], n_dev,
-                       (u32)n, g->cfg.use_polarity ? 1 : 0);
+    hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_THREADS - 1) / ING_THREADS)), dim3(ING_THREADS), 0, s, g->dev.act,
+                       (const uint4*)g->d_pkt[k], n_dev, (u32)n, g->cfg.use_polarity ? 1 : 0);
   ingest_launch3(g, p, (u32)n);
   HIP_TRY(hipGetLastError());
   g->issued = push_no;
@@ -898,8 +901,17 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->overflow = v.overflow;
   out->depth = g->h_depth[slot];
   out->bgr = g->h_bgr[slot];
+  out->push_seq = v.push_seq;
   g->next_seq += 1;
   return 1;
+}
+
+int xm_ingest_frame_valid(xm_ingest* g, uint64_t seq) {
+  if (!g) return fail(XM_ERR_INVALID, "NULL argument");
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // (k_ing_publish zeroes the slot's sequence number before anything of the next frame is written into the slot's buffers: the
+  //  frame kernels' K2 writes device memory, the copy into this slot comes behind k_ing_publish on the frame stream's event)
+  return __atomic_load_n(&g->h_status[seq % (uint64_t)g->ring].seq, __ATOMIC_ACQUIRE) == seq + 1 ? 1 : 0;
 }
 
 int xm_ingest_flush(xm_ingest* g) {
@@ -922,6 +934,14 @@ int xm_ingest_reset(xm_ingest* g) {
   z.last_t = 0;
   z.span_ok = 0;
   HIP_TRY(hipMemcpy(g->dev.st, &z, sizeof z, hipMemcpyHostToDevice));
+  // The activity filter's history goes too: a reset is "the stream starts over" (the reference resets when a recording loops,
+  // depth_reprojection.py:76) and its stamps then start below everything the history holds -- against the old history every
+  // event with a neighbour that ever fired would pass.  (Metavision's filter object keeps its state there; the frames behind
+  // the first period of a loop are what differs.)
+  if (g->dev.act.last_ts) {
+    std::vector<long long> init((size_t)g->dev.act.cam_w * g->dev.act.cam_h, ING_NO_TS);
+    HIP_TRY(hipMemcpy(g->dev.act.last_ts, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipDeviceSynchronize());  // (default-stream work: the ingest's non-blocking streams do not wait for it)
   return XM_OK;
 }
@@ -1010,9 +1030,9 @@ int xm_activity_process(xm_activity* f, const void* eventcd16, size_t n, uint8_t
     const size_t m = std::min(f->max_packet, n - a);
     memcpy(f->h_pkt, (const char*)eventcd16 + a * 16, m * 16);
     HIP_TRY(hipMemcpyAsync(f->d_pkt, f->h_pkt, m * 16, hipMemcpyHostToDevice, f->stream));
-    const unsigned nb = (unsigned)((m + ING_EPB - 1) / ING_EPB), gx = (unsigned)((m + ING_THREADS - 1) / ING_THREADS);
-    hipLaunchKernelGGL(k_act_first, dim3(nb), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (const u32*)nullptr, (u32)m, 0);
-    hipLaunchKernelGGL(k_act_mark, dim3(gx), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (u32)m, 0);
+    const unsigned gx = (unsigned)((m + ING_THREADS - 1) / ING_THREADS);
+    hipLaunchKernelGGL(k_act_first, dim3(gx), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (const u32*)nullptr, (u32)m, 0);
+    hipLaunchKernelGGL(k_act_mark, dim3(gx), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (const u32*)nullptr, (u32)m, 0);
     hipLaunchKernelGGL(k_act_update, dim3(gx), dim3(ING_THREADS), 0, f->stream, f->act, (const uint4*)f->d_pkt, (u32)m, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(f->h_keep, f->act.keep, m, hipMemcpyDeviceToHost, f->stream));

@@ -11,6 +11,13 @@
 //   cell on the wire, no atomics, no extrema pass); a frame one of whose pieces objects is redone with the keys (xm_sharded_stats).
 //   MAX over packed keys = the event with the largest GLOBAL index wins = NumPy's last-writer-wins across shards, bit for bit
 //   (x_maps_amd/sharded.py is the same exchange for multi-process hosts on torch.distributed).
+// Failure: everything that can fail on the host (allocations, launches that report at once) happens in front of an AGREEMENT
+// among the device threads (a host barrier that ORs their error codes) placed before every collective: either every thread
+// enters the collective or none does -- no thread is left waiting in RCCL for a peer that has returned.
+// xm_debug_option("XM_SHARD_FAKE_RANKS", "W") (tests; n_dev = 1): W VIRTUAL ranks on the one device -- W handles, W threads, the
+// same per-rank chain, the two collectives emulated by host barriers + a reduction kernel over the ranks' buffers -- so that the
+// N > 1 orchestration (shard bounds, the columns exchange's predecessor logic, the merge, the agreement) runs through this C
+// entry on a one-GPU box (RCCL refuses two ranks on one device).
 // RCCL is not linked: librccl is looked up at run time (the copy a host process has loaded already -- PyTorch ships its own --
 // else ROCm's), so that the library keeps loading on hosts without it; xm_create_sharded reports its absence for n_dev > 1.
 #pragma once
@@ -57,6 +64,21 @@ RcclApi load_rccl() {
 
 }  // namespace
 
+namespace xm {
+// out[i] = op over r of bufs[r][i]  (virtual ranks: every buffer lives on the one device)
+template <typename T, int OP>  // OP: 0 sum, 1 max, 2 min
+__global__ __launch_bounds__(256) void k_fake_reduce(const T* const* __restrict__ bufs, int W, size_t n, T* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    T v = bufs[0][i];
+    for (int r = 1; r < W; ++r) {
+      const T u = bufs[r][i];
+      v = OP == 0 ? (T)(v + u) : OP == 1 ? (u > v ? u : v) : (u < v ? u : v);
+    }
+    out[i] = v;
+  }
+}
+}  // namespace xm
+
 struct xm_sharded {
   struct Dev {
     int id = 0;
@@ -69,6 +91,11 @@ struct xm_sharded {
     uint64_t* key = nullptr;
     void* mm = nullptr;            // {tmin, -tmax} of the shard, then of the frame (16 bytes, int64 or float64)
     hipEvent_t ev[4] = {};         // device 0: around the two all-reduces
+    bool peer_only = false;        // this frame: the device itself was fine, it stopped because a peer had failed
+    long long mm_back[2] = {0, 0}; // device 0: the frame's {tmin, -tmax} copied back (the copy outlives an early return: not on the stack)
+    DevBuf fake_tmp;               // virtual ranks: the reduction's result before it replaces the rank's own buffer
+    const void** fake_ptrs = nullptr;  // virtual ranks: device array of the W ranks' buffers
+    const void* fake_cur = nullptr;    // virtual ranks: the buffer this rank brings to the collective in flight
     std::thread th;
     int rc = XM_OK;
     std::string err;
@@ -76,6 +103,13 @@ struct xm_sharded {
   std::vector<std::unique_ptr<Dev>> devs;
   RcclApi rccl;
   bool use_rccl = false;
+  bool fake = false;               // XM_SHARD_FAKE_RANKS: virtual ranks on one device, collectives emulated
+  int fail_dev = -1, fail_point = 0;  // XM_SHARD_FAIL_AT (tests)
+  // agreement / barrier among the device threads (sharded_agree)
+  std::mutex bmu;
+  std::condition_variable bcv;
+  int b_arrived = 0, b_rc = 0, b_rc_out = 0;
+  unsigned long long b_gen = 0;
   // the frame in flight (set by xm_sharded_process_frame, read by the device threads)
   const uint16_t *x = nullptr, *y = nullptr;
   const void* t = nullptr;
@@ -101,10 +135,77 @@ struct xm_sharded {
 
 namespace {
 
+// fault injection for the tests: xm_debug_option("XM_SHARD_FAIL_AT", "<device index>:<point>") makes that device thread fail in
+// front of collective <point> (1: the first of the frame, 2: the second) -- read when the handle is created
+bool dbg_fail_at(const xm_sharded* s, int g, int point) { return s->fail_dev == g && s->fail_point == point; }
+
+// Host barrier among the device threads; returns the first non-zero rc any of them brought (0: everybody is fine).
+int sharded_agree(xm_sharded* s, int rc) {
+  const int W = (int)s->devs.size();
+  if (W == 1) return rc;
+  std::unique_lock<std::mutex> lk(s->bmu);
+  if (rc && !s->b_rc) s->b_rc = rc;
+  const unsigned long long gen = s->b_gen;
+  if (++s->b_arrived == W) {
+    s->b_rc_out = s->b_rc;
+    s->b_rc = 0;
+    s->b_arrived = 0;
+    s->b_gen += 1;
+    s->bcv.notify_all();
+  } else {
+    s->bcv.wait(lk, [&] { return s->b_gen != gen; });
+  }
+  return s->b_rc_out;
+}
+// (a peer failed: this thread has nothing to report itself -- xm_sharded_process_frame reports the peer's error, not this one)
+int sharded_peer_failed(xm_sharded::Dev& d, int rc_agreed, int rc_own) {
+  if (rc_own) return rc_own;
+  d.peer_only = true;
+  return fail(rc_agreed, "another device of the sharded handle failed in front of a collective");
+}
+
+// virtual ranks: ncclAllGather / ncclAllReduce over buffers that all live on the one device.  Every rank: stream-sync (its
+// contribution is complete), barrier, read everybody's buffer on its own stream, barrier (nobody overwrites a buffer a peer is
+// still reading), [all-reduce: result -> own buffer].
+int fake_all_gather(xm_sharded* s, int g, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  xm_sharded::Dev& d = *s->devs[g];
+  const int W = (int)s->devs.size();
+  d.fake_cur = send;
+  int rc = hipStreamSynchronize(st) == hipSuccess ? XM_OK : fail(XM_ERR_HIP, "hipStreamSynchronize failed");
+  if ((rc = sharded_agree(s, rc))) return rc;
+  for (int r = 0; r < W && !rc; ++r)
+    if (hipMemcpyAsync((char*)recv + (size_t)r * bytes, s->devs[r]->fake_cur, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      rc = fail(XM_ERR_HIP, "hipMemcpyAsync (virtual all-gather) failed");
+  if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(XM_ERR_HIP, "hipStreamSynchronize failed");
+  return sharded_agree(s, rc);
+}
+
+template <typename T, int OP>
+int fake_all_reduce(xm_sharded* s, int g, T* buf, size_t count, hipStream_t st) {
+  xm_sharded::Dev& d = *s->devs[g];
+  const int W = (int)s->devs.size();
+  d.fake_cur = buf;
+  int rc = d.fake_tmp.reserve(count * sizeof(T));
+  if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(XM_ERR_HIP, "hipStreamSynchronize failed");
+  if ((rc = sharded_agree(s, rc))) return rc;
+  std::vector<const void*> ptrs(W);
+  for (int r = 0; r < W; ++r) ptrs[r] = s->devs[r]->fake_cur;
+  if (hipMemcpyAsync(d.fake_ptrs, ptrs.data(), sizeof(void*) * W, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(XM_ERR_HIP, "hipMemcpyAsync failed");
+  if (!rc) {
+    const unsigned gx = (unsigned)std::min<size_t>(4096, (count + 255) / 256);
+    hipLaunchKernelGGL((k_fake_reduce<T, OP>), dim3(gx ? gx : 1), dim3(256), 0, st, (const T* const*)d.fake_ptrs, W, count, (T*)d.fake_tmp.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(XM_ERR_HIP, "virtual all-reduce kernel failed");
+  }
+  if ((rc = sharded_agree(s, rc))) return rc;  // (everybody has read everybody's buffer)
+  if (hipMemcpyAsync(buf, d.fake_tmp.p, count * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(XM_ERR_HIP, "hipMemcpyAsync failed");
+  return XM_OK;
+}
+
 void sharded_frame_on(xm_sharded* s, int g) {
   xm_sharded::Dev& d = *s->devs[g];
   const int W = (int)s->devs.size();
   d.rc = XM_OK;
+  d.peer_only = false;
   const auto run = [&]() -> int {
     HIP_TRY(hipSetDevice(d.id));
     hipStream_t st = (hipStream_t)xm_stream(d.h, 0);
@@ -116,29 +217,54 @@ void sharded_frame_on(xm_sharded* s, int g) {
       // every time column on one device, the plain u16 frames merged by SUM (xm_api_shard.hpp: xm_shard_cols_*): the shard goes
       // into its buffers behind cap + 8 events of headroom (the predecessor's last column is copied there on the device)
       const size_t hr = s->cols_cap + 8;
-      if ((rc = d.x.reserve((hr + m + 8) * 2)) || (rc = d.y.reserve((hr + m + 8) * 2)) || (rc = d.t.reserve((hr + m + 8) * 8))) return rc;
-      if ((rc = d.send.reserve(s->cols_send_bytes)) || (rc = d.gathered.reserve(s->cols_send_bytes * (size_t)W))) return rc;
-      if (!d.frame16) {
-        HIP_TRY(hipMalloc((void**)&d.frame16, s->cols_frame_bytes));
-        HIP_TRY(hipMemsetAsync(d.frame16, 0, s->cols_frame_bytes, st));
-      }
-      uint16_t *dx = (uint16_t*)d.x.p + hr, *dy = (uint16_t*)d.y.p + hr;
-      int64_t* dt = (int64_t*)d.t.p + hr;
-      HIP_TRY(hipMemcpyAsync(dx, s->x + a, m * 2, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(dy, s->y + a, m * 2, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(dt, (const int64_t*)s->t + a, m * 8, hipMemcpyHostToDevice, st));
-      if ((rc = xm_shard_cols_pack(d.h, dx, dy, dt, m, d.send.p, s->cols_cap))) return rc;
-      if (g == 0) HIP_TRY(hipEventRecord(d.ev[0], st));
+      uint16_t *dx = nullptr, *dy = nullptr;
+      int64_t* dt = nullptr;
+      // everything that can fail before the all-gather, then the agreement: every device enters the collective or none does
+      const auto before_gather = [&]() -> int {
+        int rc;
+        if (dbg_fail_at(s, g, 1)) return fail(XM_ERR_HIP, "injected failure (XM_SHARD_FAIL_AT) on device index %d in front of the all-gather", g);
+        if ((rc = d.x.reserve((hr + m + 8) * 2)) || (rc = d.y.reserve((hr + m + 8) * 2)) || (rc = d.t.reserve((hr + m + 8) * 8))) return rc;
+        if ((rc = d.send.reserve(s->cols_send_bytes)) || (rc = d.gathered.reserve(s->cols_send_bytes * (size_t)W))) return rc;
+        if (g == 0 && s->depth_out && (rc = d.depth.reserve((size_t)d.h->out_w * d.h->out_h * 4))) return rc;
+        if (g == 0 && s->bgr_out && (rc = d.bgr.reserve((size_t)d.h->out_w * d.h->out_h * 3))) return rc;
+        if (!d.frame16) {
+          HIP_TRY(hipMalloc((void**)&d.frame16, s->cols_frame_bytes));
+          HIP_TRY(hipMemsetAsync(d.frame16, 0, s->cols_frame_bytes, st));
+        }
+        dx = (uint16_t*)d.x.p + hr;
+        dy = (uint16_t*)d.y.p + hr;
+        dt = (int64_t*)d.t.p + hr;
+        HIP_TRY(hipMemcpyAsync(dx, s->x + a, m * 2, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dy, s->y + a, m * 2, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dt, (const int64_t*)s->t + a, m * 8, hipMemcpyHostToDevice, st));
+        if ((rc = xm_shard_cols_pack(d.h, dx, dy, dt, m, d.send.p, s->cols_cap))) return rc;
+        if (g == 0) HIP_TRY(hipEventRecord(d.ev[0], st));
+        return XM_OK;
+      };
+      rc = before_gather();
+      if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
       const void* gathered = d.send.p;  // (one device without RCCL: its own send buffer is the gathered buffer)
-      if (s->use_rccl) {
+      if (s->fake) {
+        if ((rc = fake_all_gather(s, g, d.send.p, d.gathered.p, s->cols_send_bytes, st))) return rc;
+        gathered = d.gathered.p;
+      } else if (s->use_rccl) {
         const int e = s->rccl.AllGather(d.send.p, d.gathered.p, s->cols_send_bytes, RcclApi::Uint8, d.comm, st);
         if (e) return fail(XM_ERR_HIP, "ncclAllGather(headers + last events) failed: %s", s->rccl.err(e));
         gathered = d.gathered.p;
       }
-      if (g == 0) HIP_TRY(hipEventRecord(d.ev[1], st));
-      if ((rc = xm_shard_cols_scatter(d.h, dx, dy, dt, m, s->n, gathered, s->cols_send_bytes, g, W, s->cols_cap, d.frame16))) return rc;
-      if (g == 0) HIP_TRY(hipEventRecord(d.ev[2], st));
-      if (s->use_rccl) {
+      const auto before_reduce = [&]() -> int {
+        int rc;
+        if (dbg_fail_at(s, g, 2)) return fail(XM_ERR_HIP, "injected failure (XM_SHARD_FAIL_AT) on device index %d in front of the all-reduce", g);
+        if (g == 0) HIP_TRY(hipEventRecord(d.ev[1], st));
+        if ((rc = xm_shard_cols_scatter(d.h, dx, dy, dt, m, s->n, gathered, s->cols_send_bytes, g, W, s->cols_cap, d.frame16))) return rc;
+        if (g == 0) HIP_TRY(hipEventRecord(d.ev[2], st));
+        return XM_OK;
+      };
+      rc = before_reduce();
+      if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
+      if (s->fake) {
+        if ((rc = fake_all_reduce<u32, 0>(s, g, (u32*)d.frame16, s->cols_reduce_u32, st))) return rc;
+      } else if (s->use_rccl) {
         const int e = s->rccl.AllReduce(d.frame16, d.frame16, s->cols_reduce_u32, RcclApi::Int32, RcclApi::Sum, d.comm, st);
         if (e) return fail(XM_ERR_HIP, "ncclAllReduce(SUM, u16 frame) failed: %s", s->rccl.err(e));
       }
@@ -158,11 +284,13 @@ void sharded_frame_on(xm_sharded* s, int g) {
         if ((dd || db) && (rc = xm_shard_finish_u16(d.h, d.frame16, dd, db))) return rc;
         if (dd) HIP_TRY(hipMemcpyAsync(s->depth_out, dd, px * 4, hipMemcpyDeviceToHost, st));
         if (db) HIP_TRY(hipMemcpyAsync(s->bgr_out, db, px * 3, hipMemcpyDeviceToHost, st));
-        long long v[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(v, d.h->d_shard_n, 16, hipMemcpyDeviceToHost, st));  // {tmin, -tmax} of the frame (prepare left them there)
-        if ((rc = xm_shard_cols_failed(d.h, &d.flagged))) return rc;                 // (synchronises the stream)
-        s->mm_host[0] = (double)v[0];
-        s->mm_host[1] = -(double)v[1];
+        HIP_TRY(hipMemcpyAsync(d.mm_back, d.h->d_shard_n, 16, hipMemcpyDeviceToHost, st));  // {tmin, -tmax} of the frame (prepare left them there)
+        if ((rc = xm_shard_cols_failed(d.h, &d.flagged))) {                                 // (synchronises the stream)
+          (void)hipStreamSynchronize(st);
+          return rc;
+        }
+        s->mm_host[0] = (double)d.mm_back[0];
+        s->mm_host[1] = -(double)d.mm_back[1];
         HIP_TRY(hipEventElapsedTime(&s->coll_ms[0], d.ev[0], d.ev[1]));
         HIP_TRY(hipEventElapsedTime(&s->coll_ms[1], d.ev[2], d.ev[3]));
       } else if ((rc = xm_shard_cols_failed(d.h, &d.flagged))) {
@@ -170,54 +298,65 @@ void sharded_frame_on(xm_sharded* s, int g) {
       }
       return XM_OK;
     }
-    if ((rc = stage_in(d.x, s->x + a, m * 2, st))) return rc;
-    if ((rc = stage_in(d.y, s->y + a, m * 2, st))) return rc;
-    if ((rc = stage_in(d.t, (const char*)s->t + a * tsz, m * tsz, st))) return rc;
-    if (s->p && (rc = stage_in(d.p, s->p + a, m * 2, st))) return rc;
-    const int16_t* dp = s->p ? (const int16_t*)d.p.p : nullptr;
-    if ((rc = xm_shard_minmax_device(d.h, d.t.p, dp, m, s->t_dtype, d.mm))) return rc;
-    if (g == 0) HIP_TRY(hipEventRecord(d.ev[0], st));
-    if (s->use_rccl) {
+    const int16_t* dp = nullptr;
+    const auto before_min = [&]() -> int {
+      int rc;
+      if (dbg_fail_at(s, g, 1)) return fail(XM_ERR_HIP, "injected failure (XM_SHARD_FAIL_AT) on device index %d in front of the extrema all-reduce", g);
+      if ((rc = stage_in(d.x, s->x + a, m * 2, st))) return rc;
+      if ((rc = stage_in(d.y, s->y + a, m * 2, st))) return rc;
+      if ((rc = stage_in(d.t, (const char*)s->t + a * tsz, m * tsz, st))) return rc;
+      if (s->p && (rc = stage_in(d.p, s->p + a, m * 2, st))) return rc;
+      if (g == 0 && s->depth_out && (rc = d.depth.reserve((size_t)d.h->out_w * d.h->out_h * 4))) return rc;
+      if (g == 0 && s->bgr_out && (rc = d.bgr.reserve((size_t)d.h->out_w * d.h->out_h * 3))) return rc;
+      dp = s->p ? (const int16_t*)d.p.p : nullptr;
+      if ((rc = xm_shard_minmax_device(d.h, d.t.p, dp, m, s->t_dtype, d.mm))) return rc;
+      if (g == 0) HIP_TRY(hipEventRecord(d.ev[0], st));
+      return XM_OK;
+    };
+    rc = before_min();
+    if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
+    if (s->fake) {
+      rc = s->t_dtype == XM_T_INT64 ? fake_all_reduce<long long, 2>(s, g, (long long*)d.mm, 2, st) : fake_all_reduce<double, 2>(s, g, (double*)d.mm, 2, st);
+      if (rc) return rc;
+    } else if (s->use_rccl) {
       const int e = s->rccl.AllReduce(d.mm, d.mm, 2, s->t_dtype == XM_T_INT64 ? RcclApi::Int64 : RcclApi::Float64, RcclApi::Min, d.comm, st);
       if (e) return fail(XM_ERR_HIP, "ncclAllReduce(MIN, extrema) failed: %s", s->rccl.GetErrorString ? s->rccl.GetErrorString(e) : "?");
     }
-    if (g == 0) HIP_TRY(hipEventRecord(d.ev[1], st));
-    if ((rc = xm_shard_clear(d.h, d.key))) return rc;
-    if ((rc = xm_shard_scatter_device(d.h, (const uint16_t*)d.x.p, (const uint16_t*)d.y.p, d.t.p, dp, m, s->t_dtype, (uint64_t)a, d.mm,
-                                      s->tag, d.key)))
-      return rc;
-    if (g == 0) HIP_TRY(hipEventRecord(d.ev[2], st));
-    if (s->use_rccl) {
+    const auto before_max = [&]() -> int {
+      int rc;
+      if (dbg_fail_at(s, g, 2)) return fail(XM_ERR_HIP, "injected failure (XM_SHARD_FAIL_AT) on device index %d in front of the key all-reduce", g);
+      if (g == 0) HIP_TRY(hipEventRecord(d.ev[1], st));
+      if ((rc = xm_shard_clear(d.h, d.key))) return rc;
+      if ((rc = xm_shard_scatter_device(d.h, (const uint16_t*)d.x.p, (const uint16_t*)d.y.p, d.t.p, dp, m, s->t_dtype, (uint64_t)a, d.mm,
+                                        s->tag, d.key)))
+        return rc;
+      if (g == 0) HIP_TRY(hipEventRecord(d.ev[2], st));
+      return XM_OK;
+    };
+    rc = before_max();
+    if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
+    if (s->fake) {
+      if ((rc = fake_all_reduce<unsigned long long, 1>(s, g, (unsigned long long*)d.key, d.h->key_cells, st))) return rc;
+    } else if (s->use_rccl) {
       const int e = s->rccl.AllReduce(d.key, d.key, d.h->key_cells, RcclApi::Uint64, RcclApi::Max, d.comm, st);
       if (e) return fail(XM_ERR_HIP, "ncclAllReduce(MAX, key frame) failed: %s", s->rccl.GetErrorString ? s->rccl.GetErrorString(e) : "?");
     }
     if (g == 0) {
       HIP_TRY(hipEventRecord(d.ev[3], st));
       const size_t px = (size_t)d.h->out_w * d.h->out_h;
-      float* dd = nullptr;
-      uint8_t* db = nullptr;
-      if (s->depth_out) {
-        if ((rc = d.depth.reserve(px * 4))) return rc;
-        dd = (float*)d.depth.p;
-      }
-      if (s->bgr_out) {
-        if ((rc = d.bgr.reserve(px * 3))) return rc;
-        db = (uint8_t*)d.bgr.p;
-      }
+      float* dd = s->depth_out ? (float*)d.depth.p : nullptr;
+      uint8_t* db = s->bgr_out ? (uint8_t*)d.bgr.p : nullptr;
       if ((rc = xm_shard_finish(d.h, d.key, s->tag, dd, db))) return rc;
       if (dd) HIP_TRY(hipMemcpyAsync(s->depth_out, dd, px * 4, hipMemcpyDeviceToHost, st));
       if (db) HIP_TRY(hipMemcpyAsync(s->bgr_out, db, px * 3, hipMemcpyDeviceToHost, st));
-      unsigned char mmb[16];
-      HIP_TRY(hipMemcpyAsync(mmb, d.mm, 16, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(d.mm_back, d.mm, 16, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       if (s->t_dtype == XM_T_INT64) {
-        long long v[2];
-        memcpy(v, mmb, 16);
-        s->mm_host[0] = (double)v[0];
-        s->mm_host[1] = -(double)v[1];
+        s->mm_host[0] = (double)d.mm_back[0];
+        s->mm_host[1] = -(double)d.mm_back[1];
       } else {
         double v[2];
-        memcpy(v, mmb, 16);
+        memcpy(v, d.mm_back, 16);
         s->mm_host[0] = v[0];
         s->mm_host[1] = -v[1];
       }
@@ -268,7 +407,8 @@ void xm_sharded_destroy(xm_sharded* s) {
     if (d->h) (void)xm_sync(d->h);
     if (d->comm && s->rccl.CommDestroy) (void)s->rccl.CommDestroy(d->comm);
     d->x.release(); d->y.release(); d->t.release(); d->p.release(); d->depth.release(); d->bgr.release();
-    d->send.release(); d->gathered.release();
+    d->send.release(); d->gathered.release(); d->fake_tmp.release();
+    if (d->fake_ptrs) (void)hipFree(d->fake_ptrs);
     if (d->frame16) (void)hipFree(d->frame16);
     if (d->key) (void)hipFree(d->key);
     if (d->mm) (void)hipFree(d->mm);
@@ -290,9 +430,24 @@ int xm_create_sharded(const int* dev_ids, int n_dev, const xm_config* cfg, xm_sh
   }
   xm_sharded* s = new (std::nothrow) xm_sharded();
   if (!s) return fail(XM_ERR_NOMEM, "out of host memory");
+  std::vector<int> ids(dev_ids, dev_ids + n_dev);
+  if (const char* fr = dbg_opt("XM_SHARD_FAKE_RANKS")) {  // tests: W virtual ranks on the one device (see the header comment)
+    const int W = atoi(fr);
+    if (n_dev != 1 || W < 1 || W > 64) {
+      delete s;
+      return fail(XM_ERR_INVALID, "XM_SHARD_FAKE_RANKS = %s needs n_dev == 1 and 1 <= W <= 64", fr);
+    }
+    s->fake = W > 1;
+    ids.assign(W, dev_ids[0]);
+    n_dev = W;
+  }
+  if (const char* fa = dbg_opt("XM_SHARD_FAIL_AT")) {
+    if (sscanf(fa, "%d:%d", &s->fail_dev, &s->fail_point) != 2) s->fail_dev = -1;
+  }
+  dev_ids = ids.data();
   s->rccl = load_rccl();
-  s->use_rccl = s->rccl.ok();
-  if (n_dev > 1 && !s->use_rccl) {
+  s->use_rccl = !s->fake && s->rccl.ok();
+  if (n_dev > 1 && !s->use_rccl && !s->fake) {
     delete s;
     return fail(XM_ERR_INVALID, "librccl was not found: a sharded handle over %d devices needs it", n_dev);
   }
@@ -309,6 +464,7 @@ int xm_create_sharded(const int* dev_ids, int n_dev, const xm_config* cfg, xm_sh
     if (e == hipSuccess) e = hipMalloc(&d.mm, 16);
     for (auto& ev : d.ev)
       if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess && s->fake) e = hipMalloc((void**)&d.fake_ptrs, sizeof(void*) * 64);
     if (e != hipSuccess) rc = fail(XM_ERR_HIP, "device %d: %s", d.id, hipGetErrorString(e));
   }
   if (!rc && s->use_rccl) {  // one communicator per device, all in this process
@@ -348,8 +504,11 @@ int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y
       std::unique_lock<std::mutex> lk(s->mu);
       s->cv.wait(lk, [&] { return s->done == (int)s->devs.size(); });
     }
-    for (auto& d : s->devs)
-      if (d->rc) return fail(d->rc, "device %d: %s", d->id, d->err.c_str());
+    for (int pass = 0; pass < 2; ++pass)  // (the device that failed first, not the ones that stopped because of it)
+      for (size_t i = 0; i < s->devs.size(); ++i) {
+        auto& d = s->devs[i];
+        if (d->rc && (pass == 1 || !d->peer_only)) return fail(d->rc, "device %d (index %zu): %s", d->id, i, d->err.c_str());
+      }
     return XM_OK;
   };
   // Time-sorted int64 frames on rigs whose X-map is injective take the columns exchange (2-byte cells on the wire, no atomics,

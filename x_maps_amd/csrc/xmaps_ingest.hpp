@@ -8,10 +8,10 @@
 // Here the same chain runs as THREE kernels per packet over a device-resident event ring (round 4; seventeen launches until
 // then -- a kernel boundary costs ~1.5 us on this chip and a launch ~3.5 us of host time, and a live camera's quarter-period
 // packets make 4-6 pushes per frame):
-//   k_ing_count    per block of 2048 packet events: how many pass the filters, how many pauses lie between them, the first and
+//   k_ing_count    per block of 512 packet events: how many pass the filters, how many pauses lie between them, the first and
 //                  last kept time stamp
 //   k_ing_append   the same block-local work again + the blocks' records summed in front of it (every block sums its
-//                  predecessors itself: <= 1024 records, no scan kernel): kept events -> the ring in stream order, the pauses
+//                  predecessors itself: <= 4096 records, no scan kernel): kept events -> the ring in stream order, the pauses
 //                  between them -> the pause ring (absolute stream indices, ascending).  Pauses are found ONCE, when an event
 //                  is appended, not by re-scanning the whole buffer with every packet as the reference does
 //   k_ing_segment  one block: commits the counters, then RobustTriggerFinder.find_trigger over the pause ring; the frame that is
@@ -44,16 +44,17 @@
 //     further back never qualify (t - t' >= W + 1).  k_act_first fills both cells with one pair of 32-bit atomics per event and
 //     checks the proviso (bucket numbers non-decreasing along the packet, at most ACT_NB of them);
 //   * a packet that fails the check (time stamps running backwards by more than a bucket, a chunk spanning more than ACT_NB
-//     thresholds) is judged by the LAST block of k_act_first to finish, sequentially in groups of 256 events against the
-//     running per-pixel maximum -- slow (~20 ms per million events) and exact.
-// The keep flags go to a byte per event (k_ing_count writes them, k_ing_append reads them and clears the cells it used).
+//     thresholds) is judged sequentially in groups of 256 events against the running per-pixel maximum (by one block of
+//     k_act_mark, or by k_ing_count's blocks one after the other) -- slow (~20 ms per million events) and exact.
+// The keep flags go to a byte per event (the ingest: k_ing_count computes them as it counts, k_ing_append reads them and clears the
+// cells the packet used; the filter alone: k_act_mark / k_act_update).
 #pragma once
 #include "xmaps_kernels.hpp"
 
 namespace xm {
 
-constexpr int ING_THREADS = 256, ING_EPT = 8, ING_EPB = ING_THREADS * ING_EPT;  // packet events per block
-constexpr int ING_MAX_BLOCKS = 1024;                                            // => packets of up to 2 M events
+constexpr int ING_THREADS = 256, ING_EPT = 2, ING_EPB = ING_THREADS * ING_EPT;  // packet events per block
+constexpr int ING_MAX_BLOCKS = 4096;                                            // => packets of up to 2 M events
 
 struct IngestState {      // device
   u64 start_abs;          // absolute stream index of the first live event
@@ -91,7 +92,7 @@ struct IngFrameInfo {     // device, one per verdict entry: what k_ing_segment k
   u32 pad;
 };
 
-struct IngBlk {           // what one block of k_ing_count found in its 2048 packet events
+struct IngBlk {           // what one block of k_ing_count found in its 512 packet events
   u32 kept;               // events that pass the filters
   u32 pauses;             // pauses between consecutive kept events INSIDE the block (the one in front of its first kept event
                           // depends on an earlier block: k_ing_append / k_ing_segment add it from first_t / last_t)
@@ -108,8 +109,9 @@ struct ActDev {
   uint2* cells;           // [ACT_NB][cam_px] per (bucket, pixel) of the current packet: .x = ~(smallest packet index), .y = largest
                           // (stamp - bucket start) + 1; 0 = no event.  All zero between packets (k_ing_append / k_act_update clear)
   unsigned char* keep;    // [max_packet] the packet's keep flags
-  u32* ctl;               // [0] != 0: the packet took the sequential path (the flags are in `keep` already); [1]: blocks of
-                          // k_act_first that have finished; [2]: packets judged sequentially so far (statistics)
+  u32* ctl;               // [0] != 0: the packet failed k_act_first's check (judged sequentially: by block 0 of k_act_mark, or block
+                          // after block inside k_ing_count); [2]: packets judged sequentially so far (statistics); [3]: k_ing_count's
+                          // blocks that have done their part of a sequential packet
   long long thresh;       // T
   int cam_w, cam_h;
 };
@@ -207,15 +209,15 @@ __device__ inline bool act_seen_recently(const ActDev& a, const ActEv& e) {
   return act;
 }
 
-// The whole packet in stream order, 256 events at a time, by ONE block: inside a group an event looks at the group's earlier
+// Events [begin, n) of the packet in stream order, 256 at a time, by ONE block: inside a group an event looks at the group's earlier
 // events directly (LDS), at everything before the group through last_ts, which the group's events then join.  Leaves last_ts as
 // k_ing_append / k_act_update will leave it anyway (a maximum: idempotent).
-__device__ inline void act_sequential(const ActDev& a, const uint4* __restrict__ src, u32 n, bool use_pol) {
+__device__ inline void act_sequential(const ActDev& a, const uint4* __restrict__ src, u32 begin, u32 n, bool use_pol) {
   __shared__ int s_x[ACT_GROUP], s_y[ACT_GROUP];
   __shared__ long long s_t[ACT_GROUP];
   __shared__ unsigned char s_part[ACT_GROUP];
   const u32 tid = threadIdx.x;
-  for (u32 base = 0; base < n; base += ACT_GROUP) {
+  for (u32 base = begin; base < n; base += ACT_GROUP) {
     const u32 i = base + tid;
     const bool valid = i < n;
     const ActEv e = act_event(valid ? src[i] : make_uint4(0, 0, 0, 0), valid, use_pol, a.cam_w, a.cam_h);
@@ -240,51 +242,42 @@ __device__ inline void act_sequential(const ActDev& a, const uint4* __restrict__
   }
 }
 
-// Pass 1 of a packet: the (bucket, pixel) cells, the check that the buckets run forwards, and -- by the last block to finish,
-// only when the check failed -- the sequential path.  Same block shape as the ingest kernels (thread tid: events j * 256 + tid).
+// Pass 1 of a packet: the (bucket, pixel) cells and the check that the buckets run forwards.  One event per thread: a quarter-period packet of the reference's rig
+// (~42 k events) is 165 blocks -- the work is a divergent atomic or two per event, which wants the whole chip.
 __global__ __launch_bounds__(ING_THREADS) void k_act_first(ActDev a, const uint4* __restrict__ src, const u32* __restrict__ n_dev, u32 n_room,
                                                            int use_pol) {
-  __shared__ u32 s_last;
   u32 n = n_room;
   if (n_dev) {
     const u32 m = *n_dev;
     n = m < n_room ? m : n_room;
   }
-  const u32 nb = (n + ING_EPB - 1) / ING_EPB;
   const u32 tid = threadIdx.x;
-  if (blockIdx.x < nb) {
+  const u32 i = blockIdx.x * ING_THREADS + tid;
+  bool bad = false;
+  if (i < n) {
     const long long t0 = rec_t(src[0]), W = a.thresh + 1;
-    const u32 cam_px = (u32)a.cam_w * (u32)a.cam_h;
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < ING_EPT; ++j) {
-      const u32 i = blockIdx.x * ING_EPB + j * ING_THREADS + tid;
-      if (i >= n) continue;
-      const uint4 r = src[i];
-      const ActEv e = act_event(r, true, use_pol != 0, a.cam_w, a.cam_h);
-      int b = 0, bp = 0;
-      u32 trel = 0, trp = 0;
-      if (!act_bucket(e.t, t0, W, b, trel)) {
-        bad = true;
-        continue;
-      }
+    const ActEv e = act_event(src[i], true, use_pol != 0, a.cam_w, a.cam_h);
+    int b = 0, bp = 0, bl = 0;
+    u32 trel = 0, trp = 0;
+    if (!act_bucket(e.t, t0, W, b, trel)) {
+      bad = true;
+    } else {
       if (i > 0 && (!act_bucket(rec_t(src[i - 1]), t0, W, bp, trp) || bp > b)) bad = true;
-      if (!e.part) continue;
-      uint2* c = a.cells + (size_t)b * cam_px + (u32)e.y * (u32)a.cam_w + (u32)e.x;
-      __hip_atomic_fetch_max(&c->x, ~i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(&c->y, trel + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // The largest stamp of a (bucket, pixel) is read by events of the NEXT bucket only: the packet's last bucket (that of its
+      // last event, when the buckets run forwards -- and when they do not, the cells are not used) has no reader.  A camera's
+      // packets are a fraction of a threshold long: one bucket, and this atomic is never issued.
+      const bool last_bucket = act_bucket(rec_t(src[n - 1]), t0, W, bl, trp) && bl == b;
+      if (e.part) {
+        uint2* c = a.cells + (size_t)b * ((u32)a.cam_w * (u32)a.cam_h) + (u32)e.y * (u32)a.cam_w + (u32)e.x;
+        __hip_atomic_fetch_max(&c->x, ~i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!last_bucket) __hip_atomic_fetch_max(&c->y, trel + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    if (__syncthreads_or(bad) && tid == 0) __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(&a.ctl[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  if (tid == 0) __hip_atomic_store(&a.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-  if (tid == 0) a.ctl[2] += 1u;
-  act_sequential(a, src, n, use_pol != 0);
+  // (no fence, no hand-off between blocks here: an agent-scope release / acquire is an L2 write-back + invalidate on this chip --
+  //  measured as 20 us for this kernel with a "last block finishes the job" pattern against 5 without; the kernel boundary in
+  //  front of k_act_mark publishes the cells and the flag for free)
+  if (bad) __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Pass 2, per event (parallel path): is event i of the packet kept?  (cells complete: k_act_first has run)
@@ -323,11 +316,24 @@ __device__ inline void act_retire(const ActDev& a, const ActEv& e, long long t0)
   if (act_bucket(e.t, t0, a.thresh + 1, b, trel)) a.cells[(size_t)b * ((u32)a.cam_w * (u32)a.cam_h) + pix] = make_uint2(0u, 0u);
 }
 
-// The filter alone (xm_activity_*: the host-side pipe's stand-in for ActivityNoiseFilterAlgorithm.process_events): flags ...
-__global__ __launch_bounds__(ING_THREADS) void k_act_mark(ActDev a, const uint4* __restrict__ src, u32 n, int use_pol) {
+// Pass 2: the flags, one event per thread (in front of k_ing_count, which reads them; or the filter alone, xm_activity_*: the
+// host-side pipe's stand-in for ActivityNoiseFilterAlgorithm.process_events) ...
+__global__ __launch_bounds__(ING_THREADS) void k_act_mark(ActDev a, const uint4* __restrict__ src, const u32* __restrict__ n_dev, u32 n_room,
+                                                          int use_pol) {
+  u32 n = n_room;
+  if (n_dev) {
+    const u32 m = *n_dev;
+    n = m < n_room ? m : n_room;
+  }
+  if (a.ctl[0]) {  // the packet failed k_act_first's check: block 0 judges all of it sequentially, the others have nothing to do
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) a.ctl[2] += 1u;
+      act_sequential(a, src, 0, n, use_pol != 0);
+    }
+    return;
+  }
   const u32 i = blockIdx.x * ING_THREADS + threadIdx.x;
   if (i >= n) return;
-  if (__hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (the sequential path has written them)
   const ActEv e = act_event(src[i], true, use_pol != 0, a.cam_w, a.cam_h);
   a.keep[i] = act_keep(a, e, i, rec_t(src[0])) ? 1 : 0;
 }
@@ -340,8 +346,10 @@ __global__ __launch_bounds__(ING_THREADS) void k_act_update(ActDev a, const uint
 }
 
 // ---- the block-local part shared by k_ing_count and k_ing_append -----------------------------------------------------------
-// Thread `tid` holds events i = block * 2048 + j * 256 + tid, j = 0..7 (coalesced 16-byte loads).  Kept events are ranked in
-// stream order inside the block (ballots per slab of 256, a 32-entry prefix over (slab, wave)); their time stamps go to LDS in
+// Thread `tid` holds events i = block * 512 + j * 256 + tid, j = 0, 1 (coalesced 16-byte loads; until round 5 a block took 2048
+// events: a quarter-period packet of the reference's rig was 21 blocks on a 256-CU chip, k_ing_count 8.6 us and k_ing_append
+// 16.9 us; with 83 blocks 5.7 and 8.9).  Kept events are ranked in
+// stream order inside the block (ballots per slab of 256, a prefix over the (slab, wave) pairs); their time stamps go to LDS in
 // rank order, where every kept event but the block's first finds its predecessor.
 struct IngLocal {
   uint4 r[ING_EPT];
@@ -359,8 +367,10 @@ struct IngShared {
   u32 total, ptotal;
 };
 
-// MARK: this is k_ing_count with the activity filter on -- the flags are computed here (or were, by the sequential path) and
-// left in act.keep, where k_ing_append (MARK = false) reads them
+// MARK (k_ing_count with the activity filter on): the flags are computed here and left in act.keep, where k_ing_append
+// (MARK = false) reads them.  A packet that failed k_act_first's check is judged in stream order: block b waits for block b - 1
+// (blocks are dispatched in order, so the one waited for is always resident), then takes its 512 events through act_sequential
+// -- a chain over the blocks, slow and exact, fences only on this path.
 template <bool MARK>
 __device__ inline void ing_block_local(const IngestPush& p, const ActDev& act, u32 n, u32 block, long long thresh, IngShared& s, IngLocal& L) {
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -370,8 +380,21 @@ __device__ inline void ing_block_local(const IngestPush& p, const ActDev& act, u
   bool compute = false;
   long long t0 = 0;
   if (MARK && act_on) {
-    compute = __hip_atomic_load(&act.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-    t0 = rec_t(p.src[0]);
+    if (act.ctl[0]) {
+      if (tid == 0) {
+        while (__hip_atomic_load(&act.ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != block) __builtin_amdgcn_s_sleep(8);
+        if (block == 0) act.ctl[2] += 1u;
+      }
+      __syncthreads();
+      const u32 end = (block + 1) * ING_EPB < n ? (block + 1) * ING_EPB : n;
+      act_sequential(act, p.src, block * ING_EPB, end, use_pol);
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&act.ctl[3], block + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      compute = true;
+      t0 = rec_t(p.src[0]);
+    }
   }
   u32 before[ING_EPT];
   L.keep_bits = 0;
@@ -452,7 +475,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_count(IngestDev d, IngestPu
 
 // The packet's block records -> what lies in front of block `b` (kept events, pauses) and the packet's totals.  A pause in
 // front of a block's FIRST kept event is decided here: against the last kept event of the nearest earlier block that kept
-// anything, or against the stream's last event (tail_t) when there is none.  Every thread of the block takes part; nb <= 1024.
+// anything, or against the stream's last event (tail_t) when there is none.  Every thread of the block takes part; nb <= 4096.
 struct IngScan {
   u32 kept_before, pauses_before;  // of block b
   u32 kept_total, pauses_total;
@@ -707,7 +730,10 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_segment(IngestDev d, Ingest
         d.desc->valid = 0;
         st->span_ok = 0;
       }
-      if (d.act.last_ts) d.act.ctl[0] = 0u;  // (the packet's flags have been consumed: the next k_act_first decides afresh)
+      if (d.act.last_ts) {  // (the packet's flags have been consumed: the next packet on this set of cells decides afresh)
+        d.act.ctl[0] = 0u;
+        d.act.ctl[3] = 0u;
+      }
       s_first = ~0ull;
     }
     __syncthreads();

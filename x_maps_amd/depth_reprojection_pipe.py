@@ -225,7 +225,9 @@ class DepthReprojectionPipe:
     def reset(self):
         self.trigger_finder.reset()
         if self.ingest is not None:
-            self.ingest.reset()
+            self.ingest.reset()  # (buffered events and the activity filter's history: the stream starts over)
+        if getattr(self, "_own_act_filter", None) is not None:
+            self._own_act_filter.reset()
 
     replay_group = 16  # frames per group of process_ev_frames
 

@@ -35,6 +35,7 @@ class IngestFrame:
     lost: bool
     depth: np.ndarray | None
     bgr: np.ndarray | None
+    push_seq: int = 0  # number (from 1) of the push whose packet cut the frame
 
 
 class DeviceIngest:
@@ -152,8 +153,11 @@ class DeviceIngest:
             if fr.bgr:
                 bgr = self._view(fr.bgr, (h, w, 3), C.c_uint8)
                 bgr = bgr.copy() if copy else bgr
+            lost = bool(fr.lost)
+            if copy and not lost and (depth is not None or bgr is not None) and not self._lib.xm_ingest_frame_valid(self._g, fr.seq):
+                lost, depth, bgr = True, None, None  # the ring was lapped while the frame was being copied out: a torn copy is no frame
             out.append(IngestFrame(int(fr.seq), int(fr.n_events), int(fr.t_first), int(fr.t_last), int(fr.n_inliers),
-                                   int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), bool(fr.lost), depth, bgr))
+                                   int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), lost, depth, bgr, int(fr.push_seq)))
         return out
 
     def device_stats(self) -> dict:
