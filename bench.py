@@ -107,6 +107,9 @@ def parse_args():
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="variant switch of the library for experiments (xm_debug_option), e.g. XM_COLS=0, XM_K2_PIPE=0; repeatable")
     ap.add_argument("--single-block", action="store_true", help="one timed block of K steps (no repetition)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc, ~30 s); the committed "
+                         "profiles/pmc_traffic.json is quoted instead, with its age")
     return ap.parse_args()
 
 
@@ -296,6 +299,49 @@ def pipeline_fractions(roofline, alg, pt, wl, value, world, s_frame, frames_per_
         pass
 
 
+def traffic_file_age():
+    """how old the committed counter bytes are (profiles/pmc_traffic.json: the last commit that touched it, else the file's mtime)"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        import subprocess
+        r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%cs %h", "--", "profiles/pmc_traffic.json"], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return "committed " + r.stdout.strip()
+    except Exception:
+        pass
+    try:
+        return "file dated " + time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
+    except Exception:
+        return "unknown"
+
+
+def apply_measured_traffic(roofline, measured, detail, s_frame, frames_per_launch):
+    """roofline.traffic & co. from counters collected in THIS run (benchmodes/pmc.py) instead of the committed file"""
+    if not measured:
+        roofline["traffic_measured_in_run"] = False
+        roofline["traffic_in_run_note"] = (detail or {}).get("error", "not attempted")
+        if roofline.get("traffic_source"):
+            roofline["traffic_source"] += "; NOT re-measured in this run (" + roofline["traffic_in_run_note"] + "): " + traffic_file_age()
+        return
+    for name, k in roofline["kernels"].items():
+        if name in measured:
+            t_s = k["avg_launch_us"] * 1e-6
+            k["hbm_bytes_per_launch_counters"] = measured[name]
+            k["frac_counter_bytes"] = round(measured[name] / t_s / 1e9 / HBM_PEAK_GBS, 5)
+            k["counters"] = detail["kernels"].get(name)
+    dom = roofline["kernel"]
+    if dom in measured:
+        roofline["traffic"] = measured[dom]
+        roofline["frac_counter_bytes"] = roofline["kernels"][dom]["frac_counter_bytes"]
+    roofline["traffic_source"] = detail["source"]
+    roofline["traffic_measured_in_run"] = True
+    roofline["traffic_measure_seconds"] = detail["seconds"]
+    tot = sum(measured.get(k, 0) for k in ("k_minmax", "k_scatter", "k_frame")) / frames_per_launch
+    roofline["pipeline_hbm_traffic"] = {"hbm_bytes_per_frame_all_kernels": int(tot), "kernels": sorted(measured),
+                                        "GBps_at_measured_step_time": round(tot / s_frame / 1e9, 1),
+                                        "frac_of_peak": round(tot / s_frame / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def roofline_of(eng, frames, n_ev, outs, tables, camera, bgr_b, world, group=None, wl_suffix="", cell_bytes=None):
     """Per-kernel launch durations from HIP events attached to each dispatch.  One frame per launch: 300 serial frames, median
     of the last 200.  group = (B, call): 60 serial groups of B frames (multi-frame launches), median of the last 40."""
@@ -355,7 +401,8 @@ def other_config_legs(args, torch, dist, dev, local_rank):
         r = out.get("roofline") or {}
         leg = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "steps": out["steps"],
                "workload": out["config"]["workload"][:110],
-               "roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_counter_bytes", "traffic") if k in r},
+               "roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_counter_bytes", "traffic", "k_scatter_brackets",
+                                                  "frac_k1_alone") if k in r},
                "parity_ok": parity_ok(out.get("parity")), "leg_seconds": round(seconds, 1)}
         if "frames_per_step" in out["config"]:
             leg["frames_per_step"] = out["config"]["frames_per_step"]
@@ -785,6 +832,22 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     pipeline_fractions(roofline, alg, pt, wl, value, world, s_frame, fps,
                        helper_runs=bool(paths["general"] or paths["cols"] or args.general))
     frames_redone = eng.sorted_fallbacks()
+    # roofline.traffic from counters of THIS run (two short child runs of this very workload under rocprofv3 --pmc, one group at
+    # a time) -- the committed profiles/pmc_traffic.json only when that is not possible, and then with its age
+    if world == 1 and B and not args.no_pmc and not getattr(args, "as_leg", False) and os.environ.get("XM_BENCH_PMC_CHILD") != "1":
+        from benchmodes.pmc import measure_traffic
+        os.environ["XM_BENCH_PMC_CHILD"] = "1"
+        try:
+            flags = ["--steps", "6", "--warmup", "2", "--groups-in-flight", "1", "--batch", str(B), "--no-cpu-baseline", "--no-other-modes",
+                     "--no-host-path", "--no-other-configs", "--single-block", "--no-pmc"] + (["--camera-perspective"] if camera else []) + \
+                    (["--no-bgr"] if args.no_bgr else [])
+            measured, detail = measure_traffic(os.path.abspath(__file__), flags)
+        finally:
+            os.environ.pop("XM_BENCH_PMC_CHILD", None)
+        apply_measured_traffic(roofline, measured, detail, s_frame, fps)
+    elif roofline.get("traffic_source"):
+        roofline["traffic_measured_in_run"] = False
+        roofline["traffic_source"] += "; " + traffic_file_age()
 
     # ---- CPU baseline (rank 0 at N = 1 only) ---------------------------------------------------------------------------
     cpu = None
@@ -1903,9 +1966,17 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
         return wrapped
     for k, f in p_orig.items():
         setattr(prov, k, timed_k(k, f))
+    k1_alone = []
+    if merge == "columns":
+        from x_maps_amd import _native as xm_native
+        xm_native.debug_option("XM_SHARD_PROFILE", "1")
     for i in range(20):  # (lane 0 alone: a frame at a time, so that an event pair brackets one kernel chain and nothing else)
         process(i, not args.no_bgr, lane=0)
+        if merge == "columns":
+            k1_alone.append(eng.shard_cols_last_k1_ms())
     sync()
+    if merge == "columns":
+        xm_native.debug_option("XM_SHARD_PROFILE", None)
     for k, f in orig.items():
         setattr(proc, k, f)
     for k, f in p_orig.items():
@@ -1937,6 +2008,17 @@ def bench_sharded(args, torch, dist, dev, rank, local_rank, world):
                                       "runs on the merged key frame on every rank; merge = columns: k_minmax = the pack of the shard's last events, "
                                       "k_scatter = prepare (extrema, own / predecessor's last column) + boundary pass + column-tile K1", cell_bytes=8 if merge == "all_reduce" else 2)
     pipeline_fractions(roofline, alg, pt, ("camera" if camera else "projector") + ("_sharded" if merge == "columns" else "_sharded_keys"), value, 1, elapsed / steps, 1)
+    if merge == "columns":  # what the k_scatter figures bracket here, and K1 alone beside them
+        roofline["kernels"]["k_scatter"]["brackets"] = "k_shard_cols_prepare + k_cols_bounds_batch + k_scatter_cols_batch (three launches, one event pair)"
+        roofline["k_scatter_brackets"] = roofline["kernels"]["k_scatter"]["brackets"]
+        if k1_alone:
+            k1_us = float(np.median(k1_alone[5:])) * 1e3
+            a1 = 24.0 * (b - a)
+            roofline["kernels"]["k_scatter_cols_batch_alone"] = {
+                "avg_launch_us": round(k1_us, 2), "algorithmic_bytes_per_launch": a1, "frac_algorithmic": round(a1 / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                "timing": "HIP events tied to the K1 dispatch alone (hipExtLaunchKernelGGL; xm_shard_cols_last_k1_ms), 15 frames, median"}
+            roofline["frac_k1_alone"] = roofline["kernels"]["k_scatter_cols_batch_alone"]["frac_algorithmic"]
+
     roofline["event_stream_read_roofline_frac_note"] = "whole frame (all ranks' events) per step time against ONE GPU's HBM read peak"
     cpu = None
     if not args.no_cpu_baseline and world == 1:

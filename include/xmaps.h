@@ -371,6 +371,9 @@ int xm_shard_cols_pack(xm_handle* h, const uint16_t* x, const uint16_t* y, const
 int xm_shard_cols_scatter(xm_handle* h, uint16_t* x, uint16_t* y, int64_t* t, size_t n, uint64_t n_frame_events,
                           const void* gathered_dev, size_t send_bytes, int rank, int world, size_t cap_events, uint16_t* frame16);
 int xm_shard_cols_failed(xm_handle* h, int* failed);
+/* measurement: milliseconds of the column-tile K1 alone in the last xm_shard_cols_scatter issued while
+ * xm_debug_option("XM_SHARD_PROFILE", "1") was set (HIP events tied to that dispatch; synchronises the handle's stream) */
+int xm_shard_cols_last_k1_ms(xm_handle* h, float* ms);
 
 /* ---- one frame over several GPUs of ONE process (xm_create_sharded owns the RCCL communicators) ----------------
  * The entry for hosts that are not Python / torch.distributed (x_maps_amd/sharded.py is the multi-process form of the same

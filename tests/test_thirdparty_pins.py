@@ -1,0 +1,250 @@
+"""Pin-on-arrival: the rows whose arithmetic lives in OpenCV / Metavision, which this build's container does not have.
+
+`tools/pin_thirdparty.py`, run once where cv2 / metavision_* exist (a reference installation), writes tests/golden/g9_cv2.npz and
+tests/golden/g10_metavision.npz.  While those files are absent the tests below SKIP ("unpinned"); once they
+are committed they compare the oracle's restatements (CPU) AND the HIP path (-m gpu) with what the libraries really produced.
+The checkers themselves are exercised on every CPU run against MOCK fixtures -- the same file layout filled in by the oracle --
+so that the day the real files arrive the tests fail for the right reason only (a restatement that differs), never for a bug
+in a test that has never run.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import evt2_oracle
+import evt3_oracle
+import ingest_oracle as IO
+import xmaps_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _load(name):
+    path = os.path.join(os.environ.get("XM_PIN_DIR", GOLDEN), name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} absent: run tools/pin_thirdparty.py where cv2 / metavision are installed (this row stays unpinned)")
+    return np.load(path)
+
+
+def _events(d, prefix):
+    n = len(d[prefix + "_t"])
+    ev = np.zeros(n, IO._EVENT_CD)
+    for k in ("x", "y", "p", "t"):
+        ev[k] = d[f"{prefix}_{k}"]
+    return ev
+
+
+def _same_events(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[k], b[k]) for k in ("x", "y", "p", "t"))
+
+
+# ---- checkers (CPU: the oracle and the product's NumPy host code) -------------------------------------------------------------
+def check_cv2_oracle(d):
+    """A4 and A7 as the oracle restates them == cv2's outputs"""
+    assert np.array_equal(O.dilate7x7(d["dilate_in"]), d["dilate_out"]), "cv2.dilate(7x7): border rule / anchor differ from the restatement"
+    assert np.array_equal(O.remap_nearest_i16(d["remap_src"], d["remap_map_i16"]), d["remap_out"]), "cv2.remap(int16 map, NEAREST, CONSTANT)"
+    assert np.array_equal(O.remap_rectified_disp_map_to_proj(d["dilate_in"], d["remap_map_i16"]), d["remap_out"])
+    assert np.array_equal(np.asarray(O._turbo_bgr()).reshape(256, 3), d["turbo_bgr"]), "COLORMAP_TURBO table"
+
+
+def check_cv2_table_builder(d):
+    """x_maps_amd/calibration.py (NumPy, no GPU) == stereoRectify / undistortPoints / initUndistortRectifyMap / remap(float maps)"""
+    from x_maps_amd import calibration as C
+    g = np.load(os.path.join(GOLDEN, "g6_esl_calib.npz"))
+    rw, rh = (int(v) for v in d["rect_size"])
+    R1, R2, P1, P2, Q, roi1, roi2 = C.stereo_rectify(g["camera_K"], g["camera_D"], g["projector_K"], g["projector_D"], (rw, rh), g["R"], g["T"], alpha=-1, return_rois=True)
+    for name, got in (("R1", R1), ("R2", R2), ("P1", P1), ("P2", P2), ("Q", Q)):
+        assert np.allclose(got, d[name], rtol=0, atol=1e-9), name
+    assert tuple(roi1) == tuple(int(v) for v in d["roi1"]) and tuple(roi2) == tuple(int(v) for v in d["roi2"])
+    mx, my = C.init_undistort_rectify_map_inverse(g["camera_K"], g["camera_D"], d["R1"], d["P1"], (640, 480))
+    assert np.abs(mx - d["cam_inv_mapx_f32"]).max() < 2e-3 and np.abs(my - d["cam_inv_mapy_f32"]).max() < 2e-3, "undistortPoints"
+    for got, want, f in ((C.mapf_to_i16(mx), d["cam_inv_mapx_i16"], d["cam_inv_mapx_f32"]), (C.mapf_to_i16(my), d["cam_inv_mapy_i16"], d["cam_inv_mapy_f32"])):
+        diff = got != want
+        # a rounded LUT entry may differ only where cv2's float sits within the f32 error of a rounding tie
+        assert not diff.any() or (np.abs(np.abs(f[diff] - np.floor(f[diff])) - 0.5) < 2e-3).all(), int(diff.sum())
+    px, py = C.init_undistort_rectify_map_inverse(g["projector_K"], g["projector_D"], d["R2"], d["P2"], (1080, 1920))
+    assert (np.abs(C.mapf_to_i16(px)[::8, ::8].astype(int) - d["proj_inv_mapx_i16_s8"]) <= 1).all()
+    assert (np.abs(C.mapf_to_i16(py)[::8, ::8].astype(int) - d["proj_inv_mapy_i16_s8"]) <= 1).all()
+    fx, fy = C.init_undistort_rectify_map(g["projector_K"], np.zeros(5), d["R2"], d["P2"], (rw, rh))
+    assert np.abs(fx[::16, ::16] - d["proj_fwd_mapx_f32_s16"]).max() < 2e-3 and np.abs(fy[::16, ::16] - d["proj_fwd_mapy_f32_s16"]).max() < 2e-3
+    for border, key in (("constant", "remapf_out_constant"), ("replicate", "remapf_out_replicate")):
+        got = C.remap_nearest(d["remapf_src"], d["remapf_mapx"], d["remapf_mapy"], border)
+        assert np.array_equal(got, d[key]), f"cv2.remap(float maps, NEAREST, {border}): the rounding of x.5 targets differs"
+
+
+EVT3_CASES = ("plain", "no_first_time_high", "time_loop", "repeated_time_high", "vectors")
+EVT2_CASES = ("plain", "time_loop")
+
+
+def check_metavision_decoders_cpu(d):
+    """the independent word-at-a-time checkers and the product's host decoders == Metavision's reader, case by case"""
+    from x_maps_amd import evt2, evt3
+    for c in EVT3_CASES:
+        want = _events(d, f"evt3_{c}")
+        got = evt3_oracle.decode(d[f"evt3_{c}_words"])
+        assert _same_events(_events({f"e_{k}": got[k] for k in "xypt"}, "e"), want), f"EVT 3.0 oracle, case {c}"
+        assert _same_events(evt3.decode_evt3(d[f"evt3_{c}_words"]), want), f"EVT 3.0 host decoder, case {c}"
+    for c in EVT2_CASES:
+        want = _events(d, f"evt2_{c}")
+        got = evt2_oracle.decode(d[f"evt2_{c}_words"])
+        assert _same_events(_events({f"e_{k}": got[k] for k in "xypt"}, "e"), want), f"EVT 2.0 oracle, case {c}"
+        assert _same_events(evt2.decode_evt2(d[f"evt2_{c}_words"]), want), f"EVT 2.0 host decoder, case {c}"
+
+
+ACT_THRESHOLDS = (int(1e6 / 60), 2_000, 200)
+
+
+def check_metavision_activity_cpu(d):
+    """this build's OWN activity rule (oracle/ingest_oracle.py) == ActivityNoiseFilterAlgorithm; a failure here names which of the
+    documented differences (1)-(4) is real"""
+    for thr in ACT_THRESHOLDS:
+        ev, want, cuts = _events(d, f"act{thr}_in"), _events(d, f"act{thr}_kept"), d[f"act{thr}_packet_cuts"]
+        f = IO.ActivityFilterC(64, 48, thr)
+        got = np.concatenate([f.process(ev[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert _same_events(got, want), (thr, len(got), len(want))
+
+
+# ---- the real fixtures (skip while absent) -----------------------------------------------------------------------------------------
+def test_g9_cv2_oracle():
+    check_cv2_oracle(_load("g9_cv2.npz"))
+
+
+def test_g9_cv2_table_builder():
+    check_cv2_table_builder(_load("g9_cv2.npz"))
+
+
+def test_g10_metavision_decoders():
+    check_metavision_decoders_cpu(_load("g10_metavision.npz"))
+
+
+def test_g10_metavision_activity_filter():
+    check_metavision_activity_cpu(_load("g10_metavision.npz"))
+
+
+@pytest.mark.gpu
+def test_g9_cv2_hip_path():
+    """A4 through the HIP stage kernel (dilate and remap fused) and A7 through the device's colour table == cv2"""
+    d = _load("g9_cv2.npz")
+    _hip_a4_a7(d)
+
+
+@pytest.mark.gpu
+def test_g10_metavision_hip_path():
+    d = _load("g10_metavision.npz")
+    _hip_decoders_and_filter(d)
+
+
+def _hip_a4_a7(d):
+    from x_maps_amd import XMapsEngine
+    from x_maps_amd import synthetic as S
+    H, W = d["dilate_in"].shape
+    ph, pw = d["remap_map_i16"].shape[:2]
+    tb = S.make_tables(S.RigConfig("pin", 32, 24, pw, ph, 1000))
+    tb.update(rect_w=W, rect_h=H, disp_proj_mapxy_i16=np.ascontiguousarray(d["remap_map_i16"]),
+              proj_x_map=np.zeros((H, pw), np.int16), x_map_width=pw, t_px_scale=pw - 1)
+    with XMapsEngine(tb) as eng:
+        got = eng.remap_rectified_disp_map_to_proj(np.ascontiguousarray(d["dilate_in"]))  # (xm_stage_*: dilate and remap in one kernel)
+        assert np.array_equal(got, d["remap_out"])
+    # A7: the device's colour table is csrc/turbo_lut.inc, generated from x_maps_amd/turbo_lut.py (tests/test_turbo_lut_cpu.py)
+    from x_maps_amd import turbo_lut
+    assert np.array_equal(np.asarray(turbo_lut.TURBO_BGR_U8, np.uint8).reshape(256, 3), d["turbo_bgr"])
+
+
+def _hip_decoders_and_filter(d):
+    from x_maps_amd import XMapsEngine, evt2, evt3
+    from x_maps_amd import synthetic as S
+    from x_maps_amd.activity_filter import ActivityNoiseFilterAlgorithm
+    with XMapsEngine(S.make_tables(S.C_1M)) as eng:  # (a 640 x 480 sensor)
+        for c in EVT3_CASES:
+            with evt3.DeviceEvt3Decoder(eng, max_words=1 << 16) as dec:
+                assert _same_events(dec.decode(d[f"evt3_{c}_words"]), _events(d, f"evt3_{c}")), f"EVT 3.0 device decoder, case {c}"
+        for c in EVT2_CASES:
+            with evt2.DeviceEvt2Decoder(eng, max_words=1 << 16) as dec:
+                assert _same_events(dec.decode(d[f"evt2_{c}_words"]), _events(d, f"evt2_{c}")), f"EVT 2.0 device decoder, case {c}"
+    with XMapsEngine(S.make_tables(S.C_TINY)) as eng:  # (C-tiny's sensor is the 64 x 48 the filter cases use)
+        assert (S.C_TINY.cam_w, S.C_TINY.cam_h) == (64, 48)
+        for thr in ACT_THRESHOLDS:
+            ev, want, cuts = _events(d, f"act{thr}_in"), _events(d, f"act{thr}_kept"), d[f"act{thr}_packet_cuts"]
+            with ActivityNoiseFilterAlgorithm(eng, thr) as f:
+                got = np.concatenate([f.process_events(ev[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+            assert _same_events(got, want), thr
+
+
+# ---- mock fixtures: the checkers run on every CPU pass ------------------------------------------------------------------------------
+def _mock_g9():
+    """g9's layout with the oracle / the NumPy table builder in cv2's place"""
+    from x_maps_amd import calibration as C
+    rng = np.random.default_rng(9)
+    H, W = 96, 132
+    dil_in = np.zeros((H, W), np.float32)
+    idx = rng.integers(0, H * W, 900)
+    dil_in.ravel()[idx] = rng.integers(1, 400, len(idx)).astype(np.float32)
+    m = np.stack((rng.integers(-6, W + 6, (80, 70)), rng.integers(-6, H + 6, (80, 70))), axis=-1).astype(np.int16)
+    out = {"dilate_in": dil_in, "dilate_out": O.dilate7x7(dil_in), "remap_map_i16": m}
+    out["remap_src"] = out["dilate_out"]
+    out["remap_out"] = O.remap_nearest_i16(out["dilate_out"], m)
+    out["turbo_bgr"] = np.asarray(O._turbo_bgr()).reshape(256, 3)
+    g = np.load(os.path.join(GOLDEN, "g6_esl_calib.npz"))
+    rw, rh = int(640 * 2.75), int(480 * 2.75)
+    R1, R2, P1, P2, Q, roi1, roi2 = C.stereo_rectify(g["camera_K"], g["camera_D"], g["projector_K"], g["projector_D"], (rw, rh), g["R"], g["T"], alpha=-1, return_rois=True)
+    out.update(rect_size=np.array([rw, rh]), R1=R1, R2=R2, P1=P1, P2=P2, Q=Q, roi1=np.array(roi1), roi2=np.array(roi2))
+    mx, my = C.init_undistort_rectify_map_inverse(g["camera_K"], g["camera_D"], R1, P1, (640, 480))
+    out.update(cam_inv_mapx_f32=mx, cam_inv_mapy_f32=my, cam_inv_mapx_i16=C.mapf_to_i16(mx), cam_inv_mapy_i16=C.mapf_to_i16(my))
+    px, py = C.init_undistort_rectify_map_inverse(g["projector_K"], g["projector_D"], R2, P2, (1080, 1920))
+    out.update(proj_inv_mapx_i16_s8=C.mapf_to_i16(px)[::8, ::8], proj_inv_mapy_i16_s8=C.mapf_to_i16(py)[::8, ::8])
+    fx, fy = C.init_undistort_rectify_map(g["projector_K"], np.zeros(5), R2, P2, (rw, rh))
+    out.update(proj_fwd_mapx_f32_s16=fx[::16, ::16], proj_fwd_mapy_f32_s16=fy[::16, ::16])
+    src = rng.random((H, W)).astype(np.float32)
+    ffx = (rng.random((60, 50)) * (W + 8) - 4).astype(np.float32)
+    ffy = (rng.random((60, 50)) * (H + 8) - 4).astype(np.float32)
+    out.update(remapf_src=src, remapf_mapx=ffx, remapf_mapy=ffy, remapf_out_constant=C.remap_nearest(src, ffx, ffy, "constant"),
+               remapf_out_replicate=C.remap_nearest(src, ffx, ffy, "replicate"))
+    return out
+
+
+def _mock_g10():
+    import pin_thirdparty as P
+    out = {}
+    words3 = {"plain": P.evt3_words_singles(P.stream(1, 800, 50_000, 40_000)), "no_first_time_high": P.evt3_words_singles(P.stream(2, 100, 5_000, 9_000))[1:],
+              "time_loop": P.evt3_words_singles(P.stream(3, 600, (1 << 24) - 20_000, 40_000)),
+              "repeated_time_high": np.concatenate((P.evt3_words_singles(P.stream(4, 50, 70_000, 3_000)), np.array([0x8000 | 17, 0x8000 | 17], "<u2"),
+                                                    P.evt3_words_singles(P.stream(5, 50, 17 << 12, 3_000)))),
+              "vectors": np.array([0x8000 | 3, 0x6000 | 100, 77, 0x3000 | (1 << 11) | 200, 0x4000 | 0xA5A, 0x4000 | 0x0F0, 0x5000 | 0x81], "<u2")}
+    for c, w in words3.items():
+        out[f"evt3_{c}_words"] = w
+        ev = evt3_oracle.decode(w)
+        for k in "xypt":
+            out[f"evt3_{c}_{k}"] = ev[k]
+    for c, w in {"plain": P.evt2_words(P.stream(6, 800, 50_000, 40_000)), "time_loop": P.evt2_words(P.stream(7, 600, (1 << 34) - 20_000, 40_000))}.items():
+        out[f"evt2_{c}_words"] = w
+        ev = evt2_oracle.decode(w)
+        for k in "xypt":
+            out[f"evt2_{c}_{k}"] = ev[k]
+    for thr in ACT_THRESHOLDS:
+        ev = P.stream(10 + thr % 7, 1500, 100_000, 60_000, 64, 48)
+        ev["p"] = 1
+        cuts = list(range(0, len(ev), 700)) + [len(ev)]
+        f = IO.ActivityFilterOracle(64, 48, thr)
+        kept = np.concatenate([f.process(ev[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        for k in "xypt":
+            out[f"act{thr}_in_{k}"], out[f"act{thr}_kept_{k}"] = ev[k], kept[k]
+        out[f"act{thr}_packet_cuts"] = np.array(cuts)
+    return out
+
+
+def test_the_dormant_checkers_run_on_mock_fixtures():
+    g9, g10 = _mock_g9(), _mock_g10()
+    check_cv2_oracle(g9)
+    check_cv2_table_builder(g9)
+    check_metavision_decoders_cpu(g10)
+    check_metavision_activity_cpu(g10)
+
+
+@pytest.mark.gpu
+def test_the_dormant_hip_checkers_run_on_mock_fixtures():
+    _hip_a4_a7(_mock_g9())
+    _hip_decoders_and_filter(_mock_g10())

@@ -184,6 +184,7 @@ SYMBOLS = {
     "xm_shard_cols_pack": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, C.c_size_t]),
     "xm_shard_cols_scatter": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_uint64, _P, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _P]),
     "xm_shard_cols_failed": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "xm_shard_cols_last_k1_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "xm_create_sharded": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(xm_config), C.POINTER(_P)]),
     "xm_sharded_process_frame": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P, _P, C.POINTER(xm_frame_stats)]),
     "xm_sharded_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),

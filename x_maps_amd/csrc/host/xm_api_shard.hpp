@@ -202,9 +202,23 @@ int xm_shard_cols_scatter(xm_handle* h, uint16_t* x, uint16_t* y, int64_t* t, si
   const size_t lds = cols_lds_bytes(h, W);
   int rc;
   if ((rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds))) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid_for(h->tb.xmap_w, W), 1), dim3(cols_threads(h, n_frame_events, W)), lds, s, (const FrameDesc*)desc, h->tb, W,
-                     h->w_x, h->cols_xr_min, flags);
+  if (dbg_opt("XM_SHARD_PROFILE"))  // (measurement: HIP events tied to THIS dispatch -- xm_shard_cols_last_k1_ms -- beside the three-launch bracket a caller can take itself)
+    hipExtLaunchKernelGGL(kern, dim3(grid_for(h->tb.xmap_w, W), 1), dim3(cols_threads(h, n_frame_events, W)), (std::uint32_t)lds, s, h->prof_ev[2],
+                          h->prof_ev[3], 0u, (const FrameDesc*)desc, h->tb, W, h->w_x, h->cols_xr_min, flags);
+  else
+    hipLaunchKernelGGL(kern, dim3(grid_for(h->tb.xmap_w, W), 1), dim3(cols_threads(h, n_frame_events, W)), lds, s, (const FrameDesc*)desc, h->tb, W,
+                       h->w_x, h->cols_xr_min, flags);
   HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// duration of the column-tile K1 of the last xm_shard_cols_scatter issued while xm_debug_option("XM_SHARD_PROFILE", "1") was set
+// (synchronises the handle's stream)
+int xm_shard_cols_last_k1_ms(xm_handle* h, float* ms) {
+  if (!h || !ms) return fail(XM_ERR_INVALID, "NULL argument");
+  XM_ENTER(h);
+  HIP_TRY(hipStreamSynchronize(h->slots[0].stream));
+  HIP_TRY(hipEventElapsedTime(ms, h->prof_ev[2], h->prof_ev[3]));
   return XM_OK;
 }
 

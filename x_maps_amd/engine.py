@@ -520,6 +520,12 @@ class XMapsEngine:
         N.check(self._lib.xm_shard_finish_u16(self._h, _ptr(disp_ptr), _ptr(depth_ptr), _ptr(bgr_ptr)))
 
     # ---- shards on the column tiles (include/xmaps.h: xm_shard_cols_*) ----
+    def shard_cols_last_k1_ms(self) -> float:
+        """milliseconds of the column-tile K1 alone in the last shard_cols_scatter issued under XM_SHARD_PROFILE (synchronises)"""
+        ms = C.c_float(0.0)
+        N.check(self._lib.xm_shard_cols_last_k1_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def shard_cols_info(self, n_frame_events):
         """{frame_bytes, reduce_u32, send_bytes, cap_events} for frames of that many events, or None when the rig / the density
         does not take the column tiles"""
