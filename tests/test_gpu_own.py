@@ -81,13 +81,13 @@ def test_unsheared_frame(monkeypatch):
 
 @pytest.mark.parametrize("cpc,slant", [(2.0, 0.35), (4.6, -0.7), (1.4, 0.0), (7.5, -0.2)])
 def test_other_rig_shapes(cpc, slant):
-    """1.4 .. 7.5 time columns per cell (halo 2 .. 8), slanted either way or not at all."""
+    """1.4 .. 7.5 time columns per cell (halo 4 .. 8), slanted either way or not at all."""
     cfg = S.C_SHARED
     tb = S.make_tables_shared_cells(cfg, cols_per_cell=cpc, slant=slant)
     with XMapsEngine(tb) as eng:
         info = eng.cols_info()
         assert info["mode"] == "own", info
-        assert info["halo"] == {2.0: 2, 4.6: 4, 1.4: 2, 7.5: 8}[cpc], info  # the largest column distance inside a cell, rounded up to 2
+        assert info["halo"] == {2.0: 4, 4.6: 4, 1.4: 4, 7.5: 8}[cpc], info  # the largest column distance inside a cell, rounded up to K0b's boundary spacing (4)
         for f in range(2):
             evs = S.make_events(cfg, frame=20 + f)
             assert _same(_run(eng, evs), _ref(tb, evs)), f

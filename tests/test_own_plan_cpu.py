@@ -31,7 +31,7 @@ def _plan(tb):
     return dict(zip(keys, a))
 
 
-@pytest.mark.parametrize("cpc,slant,halo", [(3.3, -0.4, 4), (2.0, 0.35, 2), (4.6, -0.7, 4), (1.4, 0.0, 2), (7.5, -0.2, 8)])
+@pytest.mark.parametrize("cpc,slant,halo", [(3.3, -0.4, 4), (2.0, 0.35, 4), (4.6, -0.7, 4), (1.4, 0.0, 4), (7.5, -0.2, 8)])  # (halo: a multiple of K0b's boundary spacing, 4)
 def test_shared_cell_rigs_qualify(cpc, slant, halo):
     p = _plan(S.make_tables_shared_cells(S.C_SHARED, cols_per_cell=cpc, slant=slant))
     assert p["mode"] == 2 and p["halo"] == halo and p["w"] == 8 and 1 <= p["nxs_max"] <= 16, p
@@ -51,11 +51,11 @@ def test_too_many_columns_per_cell_or_too_wide_tiles_do_not_qualify():
 
 def test_esl_like_rig_qualifies():
     """The reference's calibration numbers through the (pinned) rectification: 1080 time columns on ~780 frame columns, slant
-    -0.40 columns per row: owner tiles of 8 columns + a halo of 2, a band of <= 12 frame columns, extras in the first and the last tiles
+    -0.40 columns per row: owner tiles of 8 columns + a halo of 4 (delta_max = 2, rounded up to K0b's boundary spacing), a band of <= 12 frame columns, extras in the first and the last tiles
     (where the rectified time map replicates its border or leaves the frame)."""
     cp, tb, evs, _ = rig.make_esl_like(row_stride=13, x_map_fn=lambda tm, *a: O.compute_x_map_from_time_map(np.asarray(tm, np.float32), *a))
     p = _plan(tb)
-    assert p["mode"] == 2 and p["w"] == 8 and p["halo"] == 2 * ((p["delta_max"] + 1) // 2) and 1 <= p["delta_max"] <= 3, p
+    assert p["mode"] == 2 and p["w"] == 8 and p["halo"] == 4 * ((p["delta_max"] + 3) // 4) and 1 <= p["delta_max"] <= 3, p
     assert p["nxs_max"] <= 12 and p["extras"] < 4000 and p["extras_max_per_tile"] <= 2048, p
     assert p["lds_bytes"] <= 60 * 1024, p  # two tiles per CU at least
     assert p["shear_m"] > 0 and p["shear_extra"] > 100, p  # the X-map is strongly slanted

@@ -70,6 +70,12 @@ struct xm_ingest {
   bool out_serial_now = false;
   size_t out_piece = 4u << 20;         // bytes per D2H copy of a result frame ("XM_INGEST_OUT_PIECE")
   // debug options are read ONCE, in xm_ingest_create (the ingest's threads must not look at the option table while another thread changes it)
+  // The out thread publishes a frame's sequence number ITSELF -- a store into the pinned status ring once the frame's copies have
+  // completed (it watches their event anyway) -- instead of a one-thread kernel behind them: the out stream then carries DMA copies
+  // only and never occupies a compute queue.  That matters: which hardware queue a stream lands on follows the order in which the
+  // process created its streams, and a queue whose head is a barrier packet waiting for a 126 us copy holds up the other queues of
+  // its pipe (profiles/r05_ingest.md section 2).  "XM_INGEST_HOST_SEQ" = 0: the kernel form (A/B).
+  bool host_seq = true;
   bool opt_out_no_query = false;       // "XM_INGEST_OUT_NO_QUERY"
   bool opt_evt3_out_stream = false;    // "XM_INGEST_EVT3_OUT_STREAM"
   bool opt_trace = false;              // "XM_INGEST_TRACE"
@@ -200,7 +206,8 @@ int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
   hipStream_t os = j.serial ? g->frame_stream : g->out_stream;
   // A copy enqueued behind one that is still running can block its caller for as long as that one runs -- inside the runtime,
   // with other threads' calls waiting behind it: the previous frame's copies are seen off first (a query loop, no blocking call).
-  if (g->out_threaded && !j.serial && j.frame_no > 0 && !g->opt_out_no_query) {
+  const bool host_seq = g->host_seq && g->out_threaded && !j.serial;
+  if (g->out_threaded && !j.serial && j.frame_no > 0 && !g->opt_out_no_query && !host_seq) {
     const int po = (int)((j.frame_no - 1) % xm_ingest::NOUT);
     for (int i = 0; hipEventQuery(g->out_ev[po]) == hipErrorNotReady; ++i)
       for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
@@ -221,14 +228,26 @@ int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
   int rc;
   if (g->h_bgr[j.slot] && (rc = copy_out(g->h_bgr[j.slot], g->d_out_bgr[j.o], px * 3))) return rc;
   if (g->h_depth[j.slot] && (rc = copy_out(g->h_depth[j.slot], g->d_out_depth[j.o], px * 4))) return rc;
-  hipLaunchKernelGGL(k_ing_publish_seq, dim3(1), dim3(64), 0, os, g->dev.st, j.desc, g->h_status + j.slot, (u64)j.frame_no);
-  HIP_TRY(hipGetLastError());
+  if (!host_seq) {
+    hipLaunchKernelGGL(k_ing_publish_seq, dim3(1), dim3(64), 0, os, g->dev.st, j.desc, g->h_status + j.slot, (u64)j.frame_no);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(g->out_ev[j.o], os));
   // (nothing else is issued on this stream until the next frame: without a query the runtime kept the last copy and the sequence
   //  number in its batch until some other call of the process flushed it -- seen in the copy trace: the second piece of a frame
   //  starting 90 us after the first, together with the next packet's H2D copy)
   (void)hipStreamQuery(os);
   g->t_out_s += ingest_now() - t0;
+  if (host_seq) {
+    // the copies have landed once their event has fired (a query loop: no blocking call of the runtime while the launch thread is
+    // issuing): then the sequence number, the last thing the poller looks at (xm_ingest_poll reads it with acquire)
+    for (hipError_t q; (q = hipEventQuery(g->out_ev[j.o])) != hipSuccess;) {
+      if (q != hipErrorNotReady) HIP_TRY(q);
+      for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
+    }
+    (void)hipGetLastError();
+    __atomic_store_n(&g->h_status[j.slot].seq, (uint64_t)j.frame_no + 1, __ATOMIC_RELEASE);
+  }
   return XM_OK;
 }
 
@@ -681,6 +700,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   if (const char* e = dbg_opt("XM_INGEST_OUT_PIECE")) g->out_piece = std::max<size_t>(2u << 20, (size_t)atoll(e));
   if (const char* e = dbg_opt("XM_INGEST_OUT_SERIAL")) g->out_on_frame_stream = e[0] == '1';
   g->opt_out_no_query = dbg_opt("XM_INGEST_OUT_NO_QUERY") != nullptr;
+  if (const char* e = dbg_opt("XM_INGEST_HOST_SEQ")) g->host_seq = e[0] != '0';
   g->opt_evt3_out_stream = dbg_opt("XM_INGEST_EVT3_OUT_STREAM") != nullptr;
   g->opt_trace = dbg_opt("XM_INGEST_TRACE") != nullptr;
   IngestDev& d = g->dev;

@@ -34,7 +34,7 @@
 
 namespace xm {
 
-constexpr int OWN_BW = 2;         // K0b's boundary spacing for this path (tile widths and halos are multiples of it)
+constexpr int OWN_BW = 4;         // K0b's boundary spacing for this path (tile widths and halos are multiples of it; 2 until round 5: half the boundaries, K0b 33.8 -> see profiles/r05_kernel_trace.md)
 constexpr int OWN_MAX_DELTA = 7;  // 3 bits in the packed X-map
 constexpr int OWN_XP_BITS = 13;   // xp < 8192
 constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile (the ownership masks are u16)
