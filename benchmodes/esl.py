@@ -366,7 +366,7 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                 ing.push_pinned(pk)
             ing.flush(), ing.reset(), ing.poll(copy=False)
             t_first = int(packets[0]["t"][0])
-            lat, push_at, got_n = [], {}, 0
+            lat, lib_lat, push_at, got_n = [], [], {}, 0
             base_push = ing.host_stats()["pushes"]
             c0 = time.perf_counter()
 
@@ -377,6 +377,7 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                     got_n += 1
                     if f.push_seq - base_push in push_at and not f.lost:
                         lat.append(now - push_at[f.push_seq - base_push])
+                        lib_lat.append(f.push_to_publish_us * 1e-3)
             for k, pk in enumerate(packets):
                 due = c0 + (int(pk["t"][-1]) - t_first) / 1e6 / speed
                 while time.perf_counter() < due:
@@ -388,8 +389,13 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                 drain()
             ing.flush()
             drain()
-        la = np.array(lat) * 1e3
+        la, ll = np.array(lat) * 1e3, np.array(lib_lat)
         return {"speed": speed, "frames": int(len(la)), "frames_expected": len(want_by[True]), "each_ms": [round(float(v), 3) for v in la],
+                "push_to_publish_ms_library_clock": {"p50": round(float(np.percentile(ll, 50)), 4), "p99": round(float(np.percentile(ll, 99)), 4),
+                                                     "max": round(float(ll.max()), 4),
+                                                     "note": "the same interval on the library's own clock (xm_ingest_frame.push_to_publish_us: "
+                                                             "push call entered -> sequence number published by the out thread): without the "
+                                                             "Python poll loop's jitter"} if len(ll) else None,
                 "push_to_frame_visible_ms": {"p50": round(float(np.percentile(la, 50)), 4), "p99": round(float(np.percentile(la, 99)), 4),
                                              "max": round(float(la.max()), 4)} if len(la) else None}
     try:

@@ -526,6 +526,9 @@ typedef struct xm_ingest_frame {
   const float* depth;              /* f32 [H][W] in the pinned ring (NULL if !want_depth); valid until result_ring - 1 */
   const uint8_t* bgr;              /* u8 [H][W][3]                   further frames have been produced                 */
   uint64_t push_seq;               /* number (from 1) of the xm_ingest_push* call whose packet cut the frame (API version 3) */
+  float push_to_publish_us;        /* live latency measured by the library: that push call entered -> the frame's sequence number
+                                      published (0 when the frame left in order on the frame stream: EVT chunks, no out thread) */
+  uint32_t reserved;
 } xm_ingest_frame;
 int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out);
 void xm_ingest_destroy(xm_ingest* g);

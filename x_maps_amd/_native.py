@@ -115,6 +115,7 @@ class xm_ingest_frame(C.Structure):
         ("seq", C.c_uint64), ("n_events", C.c_uint64), ("t_first", C.c_int64), ("t_last", C.c_int64),
         ("n_inliers", C.c_uint64), ("n_index_errors", C.c_uint64), ("live_after", C.c_uint64),
         ("overflow", C.c_uint32), ("lost", C.c_uint32), ("depth", C.c_void_p), ("bgr", C.c_void_p), ("push_seq", C.c_uint64),
+        ("push_to_publish_us", C.c_float), ("reserved", C.c_uint32),
     ]
 
 

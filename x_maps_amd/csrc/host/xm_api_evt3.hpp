@@ -211,6 +211,7 @@ static int ingest_push_words(xm_ingest* g, xm_evt3* d, int format, const void* w
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
   g->posted += 1;
   g->pkt_push[k] = g->posted;
+  g->push_t[g->posted % xm_ingest::VRING] = c0;
   // (pageable words are copied by the launch side: wait until it has done so)
   rc = ingest_submit(g, j, j.kind == 1 && !j.pinned);
   g->push_host_s += ingest_now() - c0;

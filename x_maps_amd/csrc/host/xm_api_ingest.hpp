@@ -37,6 +37,7 @@ struct xm_ingest {
   IngFrameInfo* d_infos = nullptr;
   IngVerdict* h_verdicts = nullptr;    // pinned host ...
   IngVerdict* d_verdicts = nullptr;    // ... and the address the device writes it at
+  double push_t[VRING] = {};           // when the xm_ingest_push* call of packet p entered (steady clock), p % VRING
   uint64_t entry_frame[VRING] = {};    // frame number + 1 that the packet which used the ring entry last cut (0: none): the entry is
                                        // read by that frame's K2 / publishing launches, so it is reused only once the frame is out
   static constexpr int NOUT = 3;       // device-side output frames (K2 writes them, a DMA copy takes them to the pinned result ring)
@@ -46,7 +47,7 @@ struct xm_ingest {
   // copy onto a stream whose previous copy is still running BLOCKS its caller in the HIP 7.0 runtime PyTorch bundles (seen: 160 us
   // per frame, 7 ms per 43 frames, whenever the copies ran slower than the frames came) -- it must not be the launch thread.
   struct OutJob {
-    uint64_t frame_no = 0;
+    uint64_t frame_no = 0, push_no = 0;
     int slot = 0, o = 0;
     const FrameDesc* desc = nullptr;
     bool serial = false;               // on the frame stream, in order with the frames' kernels (see out_serial_now)
@@ -246,6 +247,9 @@ int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
       for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
     }
     (void)hipGetLastError();
+    // (live latency as the library sees it: the push call of the packet that completed the frame entered -> now)
+    const double t_push = g->push_t[j.push_no % xm_ingest::VRING];
+    g->h_status[j.slot].latency_us = t_push > 0.0 ? (float)((ingest_now() - t_push) * 1e6) : 0.0f;
     __atomic_store_n(&g->h_status[j.slot].seq, (uint64_t)j.frame_no + 1, __ATOMIC_RELEASE);
   }
   return XM_OK;
@@ -385,6 +389,7 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   HIP_TRY(hipEventRecord(g->k2_ev[o], s));
   xm_ingest::OutJob job;
   job.frame_no = f;
+  job.push_no = push_no;
   job.slot = (int)(f % (uint64_t)g->ring);
   job.o = o;
   job.desc = desc;
@@ -875,6 +880,7 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   if (n && !pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
   g->posted += 1;
   g->pkt_push[k] = g->posted;
+  g->push_t[g->posted % xm_ingest::VRING] = c0;
   xm_ingest::Job j;
   j.kind = 0; j.k = k; j.n = n; j.host = hp;
   rc = ingest_submit(g, j, false);
@@ -922,6 +928,7 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->depth = g->h_depth[slot];
   out->bgr = g->h_bgr[slot];
   out->push_seq = v.push_seq;
+  out->push_to_publish_us = v.latency_us;
   g->next_seq += 1;
   return 1;
 }

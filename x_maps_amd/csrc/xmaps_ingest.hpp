@@ -76,7 +76,7 @@ struct IngestStatus {     // pinned host ring entry, written by k_ing_publish wh
   u64 live_after;         // events left in the buffer after the cut
   u64 push_seq;           // number of the xm_ingest_push call whose launches cut this frame (the host tightens its bounds with it)
   u32 overflow;
-  u32 pad;
+  float latency_us;       // written by the HOST (out thread, just before seq): xm_ingest_push* of that packet entered -> frame published
 };
 
 struct IngVerdict {       // pinned host ring entry (one per packet, 64 entries), written by k_ing_segment

@@ -36,6 +36,7 @@ class IngestFrame:
     depth: np.ndarray | None
     bgr: np.ndarray | None
     push_seq: int = 0  # number (from 1) of the push whose packet cut the frame
+    push_to_publish_us: float = 0.0  # the library's own clock: that push call entered -> the frame's sequence number published
 
 
 class DeviceIngest:
@@ -157,7 +158,7 @@ class DeviceIngest:
             if copy and not lost and (depth is not None or bgr is not None) and not self._lib.xm_ingest_frame_valid(self._g, fr.seq):
                 lost, depth, bgr = True, None, None  # the ring was lapped while the frame was being copied out: a torn copy is no frame
             out.append(IngestFrame(int(fr.seq), int(fr.n_events), int(fr.t_first), int(fr.t_last), int(fr.n_inliers),
-                                   int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), lost, depth, bgr, int(fr.push_seq)))
+                                   int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), lost, depth, bgr, int(fr.push_seq), float(fr.push_to_publish_us)))
         return out
 
     def device_stats(self) -> dict:
