@@ -583,6 +583,11 @@ typedef struct xm_evt3 xm_evt3;
 int xm_evt3_create(xm_handle* h, size_t max_words, size_t max_events, xm_evt3** out);
 void xm_evt3_destroy(xm_evt3* d);
 int xm_evt3_reset(xm_evt3* d); /* forget the state: the next chunk starts a stream */
+/* Start-of-stream rule (either encoding; takes effect from the next chunk).  off (default): events in front of the stream's first
+ * EVT_TIME_HIGH word are emitted with the time base at its initial 0 (only their low time bits are known); on: they are NOT
+ * emitted -- a reader that waits for the first time base.  Which of the two Metavision's reader does is unpinned here
+ * (tools/pin_thirdparty.py, case "no_first_time_high", decides). */
+int xm_evt3_wait_for_time_base(xm_evt3* d, int on);
 /* Synchronous.  *events_dev = the records in device memory (16-byte EventCD, valid until the next call), *n_events their number;
  * XM_ERR_TOO_MANY if the chunk has more words than max_words or decodes to more events than max_events. */
 int xm_evt3_decode(xm_evt3* d, const uint16_t* words_host, size_t n_words, const void** events_dev, size_t* n_events);

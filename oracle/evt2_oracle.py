@@ -17,9 +17,11 @@ EVENT_CD = np.dtype({"names": ["x", "y", "p", "t"], "formats": ["<u2", "<u2", "<
 
 
 class Evt2StateMachine:
-    def __init__(self):
+    def __init__(self, wait_for_time_base=False):
         self.time_high = 0
         self.loops = 0
+        self.wait = bool(wait_for_time_base)  # CD words in front of the stream's first EVT_TIME_HIGH are not emitted (see evt3_oracle.py)
+        self.have_high = False
 
     def feed(self, words):
         out = []
@@ -30,7 +32,8 @@ class Evt2StateMachine:
                 if self.time_high - value > (1 << 27):
                     self.loops += 1
                 self.time_high = value
-            elif kind in (0x0, 0x1):
+                self.have_high = True
+            elif kind in (0x0, 0x1) and not (self.wait and not self.have_high):
                 t = (self.loops << 34) | (self.time_high << 6) | ((w >> 22) & 0x3F)
                 out.append(((w >> 11) & 0x7FF, w & 0x7FF, kind, t))
         evs = np.zeros(len(out), EVENT_CD)
@@ -40,5 +43,5 @@ class Evt2StateMachine:
         return evs
 
 
-def decode(words):
-    return Evt2StateMachine().feed(words)
+def decode(words, wait_for_time_base=False):
+    return Evt2StateMachine(wait_for_time_base).feed(words)

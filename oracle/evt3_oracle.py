@@ -24,6 +24,17 @@ The state machine (one `if` chain per word; nothing is vectorised on purpose):
   others  EXT_TRIGGER (0xA), OTHERS (0xE), CONTINUED_4 (0x7), CONTINUED_12 (0xF), unassigned nibbles: skipped
 
   time of an event = loops * 2^24 + high * 2^12 + low (microseconds).  Initial state: everything 0.
+
+Choices this reading makes where the format description is silent, each next to what the published OpenEB decoder is REMEMBERED to
+do (not readable offline; tools/pin_thirdparty.py settles them where the SDK exists, cases "no_first_time_high", "time_loop",
+"repeated_time_high"):
+  * events in front of the stream's first EVT_TIME_HIGH: emitted with high = 0 (`wait_for_time_base=False`, the default here).
+    OpenEB's decoder is believed to wait for the first time base and drop them: `wait_for_time_base=True` is that rule -- an
+    OPTION of the product's decoders too (Evt3Decoder(wait_for_time_base=...), xm_evt3_wait_for_time_base);
+  * a loop of the 24-bit counter is counted when TIME_HIGH falls by more than HALF its range (0x800).  OpenEB is believed to
+    use a threshold near the full range (the new value far below the old one); the two differ only for a TIME_HIGH that steps
+    back by 0x800 .. ~0xff0 blocks (8-16 s backwards without being a wrap): not a stream a camera produces;
+  * a repeated TIME_HIGH (same value) leaves the low field alone; a changed one restarts it at 0 until the next EVT_TIME_LOW.
 """
 import numpy as np
 
@@ -33,13 +44,15 @@ EVENT_CD = np.dtype({"names": ["x", "y", "p", "t"], "formats": ["<u2", "<u2", "<
 class Evt3StateMachine:
     """Feed words in any chunking; the state carries over."""
 
-    def __init__(self):
+    def __init__(self, wait_for_time_base=False):
         self.row = 0
         self.vec_x = 0
         self.vec_p = 0
         self.low = 0
         self.high = 0
         self.loops = 0
+        self.wait = bool(wait_for_time_base)
+        self.have_high = False  # an EVT_TIME_HIGH word has been read
 
     def feed(self, words):
         out_x, out_y, out_p, out_t = [], [], [], []
@@ -50,6 +63,8 @@ class Evt3StateMachine:
             if kind == 0x0:
                 self.row = body & 0x7FF
             elif kind == 0x2:
+                if self.wait and not self.have_high:
+                    continue
                 out_x.append(body & 0x7FF)
                 out_y.append(self.row)
                 out_p.append(body >> 11)
@@ -61,7 +76,7 @@ class Evt3StateMachine:
                 width = 12 if kind == 0x4 else 8
                 stamp = (self.loops << 24) + (self.high << 12) + self.low
                 for bit in range(width):
-                    if (body >> bit) & 1:
+                    if (body >> bit) & 1 and not (self.wait and not self.have_high):
                         out_x.append(self.vec_x + bit)
                         out_y.append(self.row)
                         out_p.append(self.vec_p)
@@ -70,6 +85,7 @@ class Evt3StateMachine:
             elif kind == 0x6:
                 self.low = body
             elif kind == 0x8:
+                self.have_high = True
                 if body != self.high:
                     if self.high - body > 0x800:
                         self.loops += 1
@@ -86,5 +102,5 @@ class Evt3StateMachine:
         return ev
 
 
-def decode(words):
-    return Evt3StateMachine().feed(words)
+def decode(words, wait_for_time_base=False):
+    return Evt3StateMachine(wait_for_time_base).feed(words)

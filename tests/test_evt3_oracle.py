@@ -113,3 +113,32 @@ def test_encoders_round_trip_through_the_oracle(vectors):
     for enc in (evt3.encode_evt3, evt3.encode_evt3_singles):
         assert list(EO.decode(enc(tiny))["t"]) == [0x1005, 0x2005, 0x2006]
         assert list(evt3.decode_evt3(enc(tiny))["t"]) == [0x1005, 0x2005, 0x2006]
+
+
+def test_wait_for_time_base_is_an_option_of_every_decoder():
+    """Start-of-stream rule: events in front of the stream's first EVT_TIME_HIGH are emitted at time base 0 (default) or not at all
+    (wait_for_time_base=True: a reader that waits for the first time base) -- oracle and host decoder, EVT 3.0 and 2.0, whole
+    and chunked (the flag carries over: a chunk without any TIME_HIGH behind one that had it emits everything)."""
+    import evt2_oracle
+    import evt3_oracle
+    from x_maps_amd import evt2
+    pre3 = np.array([0x6000 | 77, 0x0000 | 9, 0x2000 | (1 << 11) | 5, 0x3000 | 40, 0x4000 | 0b101, 0x8000 | 2, 0x6000 | 3, 0x2000 | 6, 0x5000 | 0b11], "<u2")
+    a, b = evt3_oracle.decode(pre3), evt3_oracle.decode(pre3, wait_for_time_base=True)
+    assert len(a) == 1 + 2 + 1 + 2 and len(b) == 1 + 2 and list(a["t"][:3]) == [77, 77, 77] and list(b["t"]) == [(2 << 12) | 3] * 3
+    for wait in (False, True):
+        want = evt3_oracle.decode(pre3, wait)
+        assert np.array_equal(evt3.decode_evt3(pre3, wait_for_time_base=wait), want)
+        for cut in range(1, len(pre3)):
+            d = evt3.Evt3Decoder(wait_for_time_base=wait)
+            got = np.concatenate((d.decode(pre3[:cut]), d.decode(pre3[cut:])))
+            assert np.array_equal(got, want), (wait, cut)
+    pre2 = np.array([(1 << 28) | (5 << 22) | (7 << 11) | 3, (0 << 28) | (6 << 22) | (8 << 11) | 4, (8 << 28) | 100, (1 << 28) | (1 << 22) | (9 << 11) | 5,
+                     (0xA << 28) | 1, (1 << 28) | (2 << 22) | (10 << 11) | 6], "<u4")
+    for wait in (False, True):
+        want = evt2_oracle.decode(pre2, wait)
+        assert len(want) == (2 if wait else 4)
+        assert np.array_equal(evt2.decode_evt2(pre2, wait_for_time_base=wait), want)
+        for cut in range(1, len(pre2)):
+            d = evt2.Evt2Decoder(wait_for_time_base=wait)
+            got = np.concatenate((d.decode(pre2[:cut]), d.decode(pre2[cut:])))
+            assert np.array_equal(got, want), (wait, cut)

@@ -251,3 +251,35 @@ def test_a_raw_file_through_the_processor(tmp_path):
     for mode in ("words_device", "words_host", "records_device"):
         assert len(shown[mode]) == len(shown["records_host"]), mode
         assert all(np.array_equal(a, b) for a, b in zip(shown[mode], shown["records_host"])), mode
+
+
+@pytest.mark.parametrize("fmt", [3, 2])
+def test_wait_for_time_base_on_the_device(fmt):
+    """the start-of-stream option of the device decoders (xm_evt3_wait_for_time_base) == the oracle with the same option: streams
+    that start with events in front of their first EVT_TIME_HIGH, whole and in chunks (the flag lives in the decoder's device
+    state), random word soups, through the ingest with the count left on the device"""
+    import evt2_oracle
+    import evt3_oracle
+    from x_maps_amd import evt2
+    rng = np.random.default_rng(70 + fmt)
+    cfg = S.C_TINY
+    ora = evt3_oracle if fmt == 3 else evt2_oracle
+    with XMapsEngine(S.make_tables(cfg)) as eng:
+        cls = evt3.DeviceEvt3Decoder if fmt == 3 else evt2.DeviceEvt2Decoder
+        for trial in range(6):
+            ev = S.make_events(cfg, frame=trial, n=4000)
+            w = evt3.encode_evt3(ev) if fmt == 3 else evt2.encode_evt2(ev, time_high_every_us=16)
+            hi = np.nonzero((w >> 12) == 0x8)[0] if fmt == 3 else np.nonzero((w >> 28) == 0x8)[0]
+            w = np.delete(w, hi[:1 + trial % 3])            # the first one to three TIME_HIGH words are missing
+            if trial >= 4:                                  # arbitrary words: every type, any order
+                w = rng.integers(0, 1 << (16 if fmt == 3 else 32), 6000, dtype=np.uint64).astype(w.dtype)
+            for wait in (False, True):
+                want = ora.decode(w, wait)
+                with cls(eng, max_words=1 << 14, wait_for_time_base=wait) as dec:
+                    got = dec.decode(w)
+                    assert len(got) == len(want) and all(np.array_equal(got[k], want[k]) for k in "xypt"), (trial, wait)
+                    dec.reset()
+                    cuts = [0] + sorted(rng.integers(1, len(w), 3).tolist()) + [len(w)]
+                    parts = [dec.decode(w[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+                    got = np.concatenate(parts)
+                    assert len(got) == len(want) and all(np.array_equal(got[k], want[k]) for k in "xypt"), (trial, wait, cuts)

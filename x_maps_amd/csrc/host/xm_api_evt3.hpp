@@ -17,6 +17,7 @@ struct xm_evt3 {
   Evt3State* h_state = nullptr;  // pinned: the chunk's event count comes back here
   uint4* d_out = nullptr;        // records of the last xm_evt3_decode
   int cur = 0;
+  int wait_tb = 0;               // xm_evt3_wait_for_time_base: events in front of the stream's first TIME_HIGH word are not emitted
 };
 
 namespace {
@@ -40,17 +41,17 @@ int evt3_enqueue(xm_evt3* d, const void* words_host, size_t n_words, bool pinned
     const u32* w32 = reinterpret_cast<const u32*>(d->d_words);
     Evt2Scan* agg = reinterpret_cast<Evt2Scan*>(d->d_agg);
     hipLaunchKernelGGL(k_evt2_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, w32, n, agg);
-    hipLaunchKernelGGL(k_evt2_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, nb, agg, (const Evt3State*)st_in, st_out, count_out);
+    hipLaunchKernelGGL(k_evt2_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, nb, agg, (const Evt3State*)st_in, st_out, count_out, d->wait_tb);
     hipLaunchKernelGGL(k_evt2_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, w32, n, (const Evt2Scan*)agg, (const Evt3State*)st_in, out,
-                       (u32)std::min<size_t>(out_cap, 0xffffffffu));
+                       (u32)std::min<size_t>(out_cap, 0xffffffffu), d->wait_tb);
     HIP_TRY(hipGetLastError());
     return XM_OK;
   }
   hipLaunchKernelGGL(k_evt3_aggregate, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, d->d_agg);
   hipLaunchKernelGGL(k_evt3_prefix, dim3(1), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, nb, d->d_agg, (const Evt3State*)st_in, st_out,
-                     count_out);
+                     count_out, d->wait_tb);
   hipLaunchKernelGGL(k_evt3_emit, dim3(nb), dim3(EVT3_THREADS), 0, stream, (const uint16_t*)d->d_words, n, (const Evt3Scan*)d->d_agg,
-                     (const Evt3State*)st_in, out, (u32)std::min<size_t>(out_cap, 0xffffffffu));
+                     (const Evt3State*)st_in, out, (u32)std::min<size_t>(out_cap, 0xffffffffu), d->wait_tb);
   HIP_TRY(hipGetLastError());
   return XM_OK;
 }
@@ -145,6 +146,12 @@ void xm_evt3_destroy(xm_evt3* d) {
   if (d->d_out) (void)hipFree(d->d_out);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
+}
+
+int xm_evt3_wait_for_time_base(xm_evt3* d, int on) {
+  if (!d) return fail(XM_ERR_INVALID, "NULL argument");
+  d->wait_tb = on ? 1 : 0;
+  return XM_OK;
 }
 
 int xm_evt3_reset(xm_evt3* d) {

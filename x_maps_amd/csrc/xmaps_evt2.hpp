@@ -20,6 +20,7 @@ namespace xm {
 struct Evt2Scan {
   u32 hi_has, hi_first, hi_last, hi_wraps;  // TIME_HIGH words of the range
   u32 n_ev;
+  u32 hi_word, n_pre;                       // a TIME_HIGH WORD lies in the range (the seed is not one); events in front of its first one
 };
 static_assert(sizeof(Evt2Scan) <= sizeof(Evt3Scan), "the decoders share the aggregates' buffer");
 
@@ -27,6 +28,7 @@ __device__ __forceinline__ Evt2Scan evt2_identity() {
   Evt2Scan e;
   e.hi_has = e.hi_first = e.hi_last = e.hi_wraps = 0;
   e.n_ev = 0;
+  e.hi_word = e.n_pre = 0;
   return e;
 }
 
@@ -43,14 +45,16 @@ __device__ __forceinline__ Evt2Scan evt2_combine(const Evt2Scan& a, const Evt2Sc
     r.hi_wraps = a.hi_wraps + b.hi_wraps + (wrap ? 1u : 0u);
   }
   r.n_ev = a.n_ev + b.n_ev;
+  r.hi_word = a.hi_word | b.hi_word;
+  r.n_pre = a.hi_word ? a.n_pre : a.n_ev + b.n_pre;
   return r;
 }
 
 __device__ __forceinline__ Evt2Scan evt2_element(u32 w) {
   Evt2Scan e = evt2_identity();
   const u32 typ = w >> 28;
-  if (typ <= 1u) e.n_ev = 1;
-  else if (typ == 0x8u) { e.hi_has = 1; e.hi_first = e.hi_last = w & 0x0fffffffu; }
+  if (typ <= 1u) e.n_ev = e.n_pre = 1;
+  else if (typ == 0x8u) { e.hi_has = 1; e.hi_first = e.hi_last = w & 0x0fffffffu; e.hi_word = 1; }
   return e;
 }
 
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_aggregate(const u32* __re
 // 2. one block: exclusive scan of the aggregates, seeded with the previous chunk's state; the chunk's event count and the state
 //    for the next chunk (the EVT 3.0 record: only t_high, t_loops and n_events are used)
 __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_prefix(u32 n_blocks, Evt2Scan* __restrict__ agg, const Evt3State* __restrict__ st_in,
-                                                             Evt3State* __restrict__ st_out, u32* __restrict__ count_out) {
+                                                             Evt3State* __restrict__ st_out, u32* __restrict__ count_out, int wait) {
   __shared__ Evt2Scan buf[2][EVT3_THREADS];
   __shared__ Evt2Scan s_incl[EVT3_THREADS];
   const Evt3State s = *st_in;
@@ -114,21 +118,23 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_prefix(u32 n_blocks, Evt2
   }
   if (threadIdx.x == 0) {
     Evt3State o;
-    o.y = o.base_x = o.base_p = o.t_low = o.pad = 0;
+    o.y = o.base_x = o.base_p = o.t_low = 0;
+    o.have_high = s.have_high | carry.hi_word;
     o.t_high = carry.hi_last;
     o.t_loops = s.t_loops + carry.hi_wraps;
-    o.n_events = carry.n_ev;
+    o.n_events = carry.n_ev - evt_dropped(carry.n_pre, s.have_high, wait);
     *st_out = o;
-    if (count_out) *count_out = carry.n_ev;  // (a cell of the consumer's: this record is rewritten two chunks from now)
+    if (count_out) *count_out = (u32)o.n_events;  // (a cell of the consumer's: this record is rewritten two chunks from now)
   }
 }
 
 // 3. the records: every block re-scans its words from its exclusive prefix and writes its events
 __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_emit(const u32* __restrict__ words, u32 n, const Evt2Scan* __restrict__ prefix,
-                                                           const Evt3State* __restrict__ st_in, uint4* __restrict__ out, u32 out_cap) {
+                                                           const Evt3State* __restrict__ st_in, uint4* __restrict__ out, u32 out_cap, int wait) {
   __shared__ Evt2Scan buf[2][EVT3_THREADS];
   __shared__ Evt2Scan s_incl[EVT3_THREADS];
   const unsigned long long loops0 = st_in->t_loops;
+  const u32 have_high = st_in->have_high;
   const u32 i0 = blockIdx.x * EVT3_PER_BLOCK + threadIdx.x * EVT3_IPT;
   u32 w[EVT3_IPT];
   Evt2Scan acc = evt2_identity();
@@ -146,10 +152,11 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt2_emit(const u32* __restric
 #pragma unroll
   for (int k = 0; k < EVT3_IPT; ++k) {
     if (i0 + k >= n) break;
-    const u32 before = run.n_ev;
+    const u32 before = run.n_ev - evt_dropped(run.n_pre, have_high, wait);
     const Evt2Scan e = evt2_element(w[k]);
     run = evt2_combine(run, e);
     if (!e.n_ev || before >= out_cap) continue;
+    if (wait && !have_high && !run.hi_word) continue;  // in front of the stream's first EVT_TIME_HIGH: not emitted
     const unsigned long long t = ((loops0 + run.hi_wraps) << 34) | ((unsigned long long)run.hi_last << 6) | (unsigned long long)((w[k] >> 22) & 0x3fu);
     const u32 x = (w[k] >> 11) & 0x7ffu, y = w[k] & 0x7ffu;
     out[before] = make_uint4(x | (y << 16), w[k] >> 28, (u32)t, (u32)(t >> 32));

@@ -24,7 +24,8 @@ namespace xm {
 constexpr int EVT3_THREADS = 256, EVT3_IPT = 8, EVT3_PER_BLOCK = EVT3_THREADS * EVT3_IPT;
 
 struct Evt3State {  // what a chunk hands to the next one (Evt3Decoder's fields in x_maps_amd/evt3.py)
-  u32 y, base_x, base_p, t_high, t_low, pad;
+  u32 y, base_x, base_p, t_high, t_low;
+  u32 have_high;  // a TIME_HIGH word has been seen since the stream started (the "wait for the time base" option drops events before it)
   unsigned long long t_loops;
   unsigned long long n_events;  // of the chunk that wrote this state
 };
@@ -34,6 +35,7 @@ struct Evt3Scan {
   u32 hi_has, hi_first, hi_last, hi_first_idx, hi_wraps, hi_change_idx;  // TIME_HIGH (indices + 1, 0 = none)
   u32 adv_flag, adv_sum;     // columns consumed since the last VECT_BASE_X (flag: the range holds one)
   u32 n_ev;
+  u32 hi_word, n_pre;        // a TIME_HIGH WORD lies in the range (the seed is not one); events in front of the range's first one
 };
 
 __device__ __forceinline__ Evt3Scan evt3_identity() {
@@ -42,6 +44,7 @@ __device__ __forceinline__ Evt3Scan evt3_identity() {
   e.hi_has = e.hi_first = e.hi_last = e.hi_first_idx = e.hi_wraps = e.hi_change_idx = 0;
   e.adv_flag = e.adv_sum = 0;
   e.n_ev = 0;
+  e.hi_word = e.n_pre = 0;
   return e;
 }
 
@@ -66,8 +69,15 @@ __device__ __forceinline__ Evt3Scan evt3_combine(const Evt3Scan& a, const Evt3Sc
   r.adv_flag = a.adv_flag | b.adv_flag;
   r.adv_sum = b.adv_flag ? b.adv_sum : a.adv_sum + b.adv_sum;
   r.n_ev = a.n_ev + b.n_ev;
+  r.hi_word = a.hi_word | b.hi_word;
+  r.n_pre = a.hi_word ? a.n_pre : a.n_ev + b.n_pre;
   return r;
 }
+
+// Start-of-stream rule (an option of the decoder, xm_evt3_wait_for_time_base): events in front of the stream's FIRST TIME_HIGH word
+// carry a time of which only the low 12 bits are known.  Off (default): they are emitted with the high field at its initial 0,
+// like everything else the initial state defines.  On: they are not emitted (a reader that waits for the first time base).
+__device__ __forceinline__ u32 evt_dropped(const u32 n_pre, const u32 have_high, const int wait) { return wait && !have_high ? n_pre : 0u; }
 
 __device__ __forceinline__ Evt3Scan evt3_element(u32 w, u32 i) {  // word w at index i of the chunk
   Evt3Scan e = evt3_identity();
@@ -75,10 +85,11 @@ __device__ __forceinline__ Evt3Scan evt3_element(u32 w, u32 i) {  // word w at i
   if (typ == 0x6u) e.lo_idx = i + 1;
   else if (typ == 0x0u) e.y_idx = i + 1;
   else if (typ == 0x3u) { e.b_idx = i + 1; e.adv_flag = 1; }
-  else if (typ == 0x8u) { e.hi_has = 1; e.hi_first = e.hi_last = w & 0xfffu; e.hi_first_idx = i + 1; }
+  else if (typ == 0x8u) { e.hi_has = 1; e.hi_first = e.hi_last = w & 0xfffu; e.hi_first_idx = i + 1; e.hi_word = 1; }
   else if (typ == 0x2u) e.n_ev = 1;
   else if (typ == 0x4u) { e.adv_sum = 12; e.n_ev = __popc(w & 0xfffu); }
   else if (typ == 0x5u) { e.adv_sum = 8; e.n_ev = __popc(w & 0xffu); }
+  e.n_pre = e.n_ev;  // (no TIME_HIGH word in a range of one event word: all of its events lie in front of "the first one")
   return e;
 }
 
@@ -139,7 +150,7 @@ __device__ __forceinline__ void evt3_resolve(const Evt3Scan& r, const Evt3State&
 //    for the next chunk
 __global__ __launch_bounds__(EVT3_THREADS) void k_evt3_prefix(const uint16_t* __restrict__ words, u32 n_blocks, Evt3Scan* __restrict__ agg,
                                                              const Evt3State* __restrict__ st_in, Evt3State* __restrict__ st_out,
-                                                             u32* __restrict__ count_out) {
+                                                             u32* __restrict__ count_out, int wait) {
   __shared__ Evt3Scan buf[2][EVT3_THREADS];
   const Evt3State s = *st_in;
   Evt3Scan carry = evt3_seed(s);
@@ -161,17 +172,18 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt3_prefix(const uint16_t* __
     u32 y, th, tl, base, pol;
     unsigned long long loops;
     evt3_resolve(carry, s, words, y, th, tl, loops, base, pol);
-    o.y = y; o.base_x = base; o.base_p = pol; o.t_high = th; o.t_low = tl; o.pad = 0;
+    o.y = y; o.base_x = base; o.base_p = pol; o.t_high = th; o.t_low = tl;
+    o.have_high = s.have_high | carry.hi_word;
     o.t_loops = loops;
-    o.n_events = carry.n_ev;
+    o.n_events = carry.n_ev - evt_dropped(carry.n_pre, s.have_high, wait);
     *st_out = o;
-    if (count_out) *count_out = carry.n_ev;  // (a cell of the consumer's: this record is rewritten two chunks from now)
+    if (count_out) *count_out = (u32)o.n_events;  // (a cell of the consumer's: this record is rewritten two chunks from now)
   }
 }
 
 // 3. the records: every block re-scans its words from its exclusive prefix and writes its events
 __global__ __launch_bounds__(EVT3_THREADS) void k_evt3_emit(const uint16_t* __restrict__ words, u32 n, const Evt3Scan* __restrict__ prefix,
-                                                           const Evt3State* __restrict__ st_in, uint4* __restrict__ out, u32 out_cap) {
+                                                           const Evt3State* __restrict__ st_in, uint4* __restrict__ out, u32 out_cap, int wait) {
   __shared__ Evt3Scan buf[2][EVT3_THREADS];
   const Evt3State s = *st_in;
   const u32 i0 = blockIdx.x * EVT3_PER_BLOCK + threadIdx.x * EVT3_IPT;
@@ -193,10 +205,11 @@ __global__ __launch_bounds__(EVT3_THREADS) void k_evt3_emit(const uint16_t* __re
 #pragma unroll
   for (int k = 0; k < EVT3_IPT; ++k) {
     if (i0 + k >= n) break;
-    const u32 before = run.n_ev;
+    const u32 before = run.n_ev - evt_dropped(run.n_pre, s.have_high, wait);
     const Evt3Scan e = evt3_element(w[k], i0 + k);
     run = evt3_combine(run, e);
     if (!e.n_ev) continue;
+    if (wait && !s.have_high && !run.hi_word) continue;  // in front of the stream's first TIME_HIGH word: not emitted
     u32 y, th, tl, base, pol;
     unsigned long long loops;
     evt3_resolve(run, s, words, y, th, tl, loops, base, pol);

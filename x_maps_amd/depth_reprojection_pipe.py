@@ -132,7 +132,8 @@ class DepthReprojectionPipe:
             dev = self._raw_dev.get(fmt)
             if dev is None:
                 cls = evt2.DeviceEvt2Decoder if fmt == 2 else evt3.DeviceEvt3Decoder
-                dev = self._raw_dev[fmt] = cls(self.calib_maps.engine, max_words=1 << 20)
+                dev = self._raw_dev[fmt] = cls(self.calib_maps.engine, max_words=1 << 20,
+                                               wait_for_time_base=bool(getattr(self.params, "raw_wait_for_time_base", False)))
             w = np.ascontiguousarray(words, dtype=dt)
             for a in range(0, len(w), dev.max_words):
                 dev.push(self.ingest, w[a:a + dev.max_words])
@@ -140,7 +141,8 @@ class DepthReprojectionPipe:
             return
         host = self._raw_host.get(fmt)
         if host is None:
-            host = self._raw_host[fmt] = mod.Evt2Decoder() if fmt == 2 else mod.Evt3Decoder()
+            wait = bool(getattr(self.params, "raw_wait_for_time_base", False))
+            host = self._raw_host[fmt] = mod.Evt2Decoder(wait) if fmt == 2 else mod.Evt3Decoder(wait)
         evs = host.decode(words)
         if len(evs):
             self.process_events(evs)

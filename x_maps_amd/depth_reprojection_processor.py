@@ -55,6 +55,10 @@ class RuntimeParams:
     # frames longer copies them itself.
     ingest_frame_views: bool = False
     ingest_result_ring: int = 8
+    # process_evt3_words / process_evt2_words: events in front of a recording's first EVT_TIME_HIGH word are dropped (a reader that
+    # waits for the first time base) instead of emitted at time base 0.  Which of the two Metavision's reader does is unpinned
+    # (tools/pin_thirdparty.py decides); it matters for the first few words of a file only.
+    raw_wait_for_time_base: bool = False
 
     @property
     def should_drop_frames(self):

@@ -29,9 +29,11 @@ _FORMAT_NAMES = ("2.0", "2", "EVT2", "EVT2.0")
 class Evt2Decoder:
     """Streaming decoder: feed chunks of words, get EventCD arrays; the time base and the loop count carry over."""
 
-    def __init__(self):
+    def __init__(self, wait_for_time_base: bool = False):
         self.t_high = 0
         self.t_loops = 0
+        self.wait_for_time_base = bool(wait_for_time_base)  # CD words in front of the stream's first EVT_TIME_HIGH are not emitted (evt3.py)
+        self.have_time = False
 
     def decode(self, words: np.ndarray) -> np.ndarray:
         w = np.ascontiguousarray(words, dtype="<u4").astype(np.int64)
@@ -50,6 +52,9 @@ class Evt2Decoder:
             loops_at = np.where(ih >= 0, self.t_loops + wraps[np.searchsorted(hi_words, np.maximum(ih, 0))], self.t_loops)
         t_high = np.where(ih >= 0, w[np.maximum(ih, 0)] & 0x0fffffff, self.t_high)
         cd = np.nonzero(typ <= T_CD_ON)[0]
+        if self.wait_for_time_base and not self.have_time:
+            cd = cd[ih[cd] >= 0]
+        self.have_time = self.have_time or len(hi_words) > 0
         out = np.zeros(len(cd), EVENT_CD_DTYPE)
         wc = w[cd]
         out["x"] = (wc >> 11) & 0x7ff
@@ -60,8 +65,8 @@ class Evt2Decoder:
         return out
 
 
-def decode_evt2(words: np.ndarray) -> np.ndarray:
-    return Evt2Decoder().decode(words)
+def decode_evt2(words: np.ndarray, wait_for_time_base: bool = False) -> np.ndarray:
+    return Evt2Decoder(wait_for_time_base).decode(words)
 
 
 def encode_evt2(evs: np.ndarray, time_high_every_us: int = 0) -> np.ndarray:
@@ -122,7 +127,7 @@ class DeviceEvt2Decoder:
     """The same decoder as three kernels (csrc/xmaps_evt2.hpp): the words cross PCIe as the recording stores them (4-8 bytes per
     event), the records stay on the device.  Same interface as evt3.DeviceEvt3Decoder."""
 
-    def __init__(self, engine, max_words: int = 1 << 20, max_events: int = 0):
+    def __init__(self, engine, max_words: int = 1 << 20, max_events: int = 0, wait_for_time_base: bool = False):
         import ctypes as C
 
         from . import _native as N
@@ -131,6 +136,8 @@ class DeviceEvt2Decoder:
         self._d = C.c_void_p(None)
         self.max_words = int(max_words)
         N.check(self._lib.xm_evt2_create(engine._h, int(max_words), int(max_events), C.byref(self._d)))
+        if wait_for_time_base:
+            N.check(self._lib.xm_evt3_wait_for_time_base(self._d, 1))
 
     def close(self):
         if getattr(self, "_d", None) is not None and self._d.value:

@@ -51,14 +51,17 @@ def _ffill_index(mask: np.ndarray) -> np.ndarray:
 class Evt3Decoder:
     """Streaming decoder: feed chunks of words, get EventCD arrays; state (row, base column, time, overflow count) carries over."""
 
-    def __init__(self):
+    def __init__(self, wait_for_time_base: bool = False):
         self.y = 0
         self.base_x = 0
         self.base_p = 0
         self.t_low = 0
         self.t_high = 0
         self.t_loops = 0  # number of 24-bit wrap-arounds seen
-        self.have_time = False
+        # start-of-stream rule: True = events in front of the stream's first EVT_TIME_HIGH word are not emitted (a reader that waits
+        # for the first time base); False (default) = they carry the initial time base 0.  Unpinned against Metavision.
+        self.wait_for_time_base = bool(wait_for_time_base)
+        self.have_time = False  # an EVT_TIME_HIGH word has been read
 
     def decode(self, words: np.ndarray) -> np.ndarray:
         w = np.ascontiguousarray(words, dtype="<u2").astype(np.int64)
@@ -115,6 +118,10 @@ class Evt3Decoder:
         ps = np.concatenate(((w[sx] >> 11) & 1, pol[vi]))[order]
         ts = np.concatenate((t[sx], t[vi]))[order]
         out["x"], out["y"], out["p"], out["t"] = xs, ys, ps, ts
+        if self.wait_for_time_base and not self.have_time:
+            src = np.concatenate((sx, vi))[order]            # the word each event came from
+            out = out[ih[src] >= 0]                           # ... has a TIME_HIGH word at or before it in this chunk
+        self.have_time = self.have_time or len(hi_words) > 0
         # ---- carry the state over to the next chunk ----
         self.y = int(y[-1])
         self.t_high, self.t_low = int(t_high[-1]), int(t_low[-1])
@@ -125,8 +132,8 @@ class Evt3Decoder:
         return out
 
 
-def decode_evt3(words: np.ndarray) -> np.ndarray:
-    return Evt3Decoder().decode(words)
+def decode_evt3(words: np.ndarray, wait_for_time_base: bool = False) -> np.ndarray:
+    return Evt3Decoder(wait_for_time_base).decode(words)
 
 
 class DeviceEvt3Decoder:
@@ -140,7 +147,7 @@ class DeviceEvt3Decoder:
 
     State (row, time, vector base, 24-bit wraps) carries over from chunk to chunk, as in Evt3Decoder."""
 
-    def __init__(self, engine, max_words: int = 1 << 20, max_events: int = 0):
+    def __init__(self, engine, max_words: int = 1 << 20, max_events: int = 0, wait_for_time_base: bool = False):
         import ctypes as C
 
         from . import _native as N
@@ -149,6 +156,8 @@ class DeviceEvt3Decoder:
         self._d = C.c_void_p(None)
         self.max_words = int(max_words)
         N.check(self._lib.xm_evt3_create(engine._h, int(max_words), int(max_events), C.byref(self._d)))
+        if wait_for_time_base:  # (Evt3Decoder's option: events in front of the stream's first EVT_TIME_HIGH are not emitted)
+            N.check(self._lib.xm_evt3_wait_for_time_base(self._d, 1))
 
     def close(self):
         if getattr(self, "_d", None) is not None and self._d.value:
