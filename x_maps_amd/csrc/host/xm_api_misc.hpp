@@ -9,7 +9,12 @@ int xm_debug_option(const char* name, const char* value) {
   std::lock_guard<std::mutex> lk(g_opt_mu);
   if (!name) g_opts.clear();
   else if (!value) g_opts.erase(name);
-  else g_opts[name] = value;
+  else {
+    auto it = g_opts.find(name);
+    if (it != g_opts.end() && *it->second == value) return XM_OK;  // (unchanged: no new text)
+    g_opt_texts.emplace_back(value);
+    g_opts[name] = &g_opt_texts.back();  // (deque: growing it never moves an element)
+  }
   return XM_OK;
 }
 

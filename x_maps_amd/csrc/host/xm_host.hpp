@@ -25,13 +25,15 @@ int fail(int code, const char* fmt, ...) {
 
 // Variant switches for tests and experiments (XM_COLS, XM_K2_PIPE, XM_OWN_W, ...): set through xm_debug_option(), never read from
 // the environment -- the library's behaviour does not depend on what the calling process happens to have exported.  Read when a
-// handle (or an ingest) is created.
+// handle (or an ingest) is created, except the few per-call measurement switches ("XM_SHARDED_KEYS", "XM_SHARD_PROFILE").
 std::mutex g_opt_mu;
-std::map<std::string, std::string> g_opts;
-const char* dbg_opt(const char* name) {  // (the text stays valid until the option is set again or removed)
+std::map<std::string, const std::string*> g_opts;  // name -> its current text, in g_opt_texts
+std::deque<std::string> g_opt_texts;               // every text ever set: never erased, so a pointer handed out stays valid for the
+                                                   // life of the process whatever another thread sets or removes meanwhile
+const char* dbg_opt(const char* name) {
   std::lock_guard<std::mutex> lk(g_opt_mu);
   auto it = g_opts.find(name);
-  return it == g_opts.end() ? nullptr : it->second.c_str();
+  return it == g_opts.end() ? nullptr : it->second->c_str();
 }
 
 struct DevBuf {  // grow-only device scratch
