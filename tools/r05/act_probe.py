@@ -12,6 +12,8 @@ from x_maps_amd import XMapsEngine, rig, synthetic as S
 from x_maps_amd.ingest import DeviceIngest
 act = bool(int(sys.argv[1])) if len(sys.argv) > 1 else True
 from x_maps_amd import _native as N
+if os.environ.get("NO_COPY_THREAD"):
+    N.debug_option("XM_INGEST_NO_COPY_THREAD", "1")
 if os.environ.get("TRACE"):
     N.debug_option("XM_INGEST_TRACE", "1")
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -72,16 +72,23 @@ int evt3_run(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, ui
   return XM_OK;
 }
 
-// decode + everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned) {
-  g->out_serial_now = !g->opt_evt3_out_stream;  // (see xm_ingest::out_serial_now)
+// one chunk of words, the copy side: H2D + the three decode launches on the decoder's stream + the event behind them
+int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned) {
   if (n_words) {
     int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream, g->d_pkt_n + k);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->copied_ev[k], d->stream));
-    HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
+    d->cur ^= 1;
   }
-  if (n_words) d->cur ^= 1;
+  return XM_OK;
+}
+
+// ... the launch side: everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived) {
+  g->out_serial_now = !g->opt_evt3_out_stream;  // (see xm_ingest::out_serial_now)
+  int rc0 = arrived ? XM_OK : ingest_copy_evt3(g, d, k, words, n_words, pinned);
+  if (rc0) return rc0;
+  if (n_words) HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
   // (upper bound of the chunk's events for the host's bookkeeping: an EVT 3.0 vector word yields up to 12, everything else at most one)
   const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * (d->format == 2 ? 1 : 12));
   return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? g->d_pkt_n + k : nullptr);
@@ -203,7 +210,7 @@ static int ingest_push_words(xm_ingest* g, xm_evt3* d, int format, const void* w
     // use the same decoder: its state index and buffers are not to be touched from two threads) -- and the records then go to
     // the launch side like a packet that is already on the device
     if (g->threaded) {
-      const unsigned long long posted = g->q_head.load(std::memory_order_acquire);
+      const unsigned long long posted = ingest_posted(g);
       while (g->q_done.load(std::memory_order_acquire) < posted && !g->q_error.load(std::memory_order_relaxed)) __builtin_ia32_pause();
       if ((rc = ingest_take_error(g))) return rc;
     }

@@ -121,6 +121,7 @@ struct xm_ingest {
     const void* host = nullptr;        // pinned source (the staging entry or the caller's pinned memory); words
     xm_evt3* dec = nullptr;
     bool pinned = true;
+    bool arrived = false;              // the copy side has issued the packet's H2D copy / the chunk's decoding and recorded copied_ev[k]
   };
   static constexpr unsigned QCAP = 64;
   Job queue[QCAP];
@@ -132,6 +133,18 @@ struct xm_ingest {
   std::atomic<bool> q_sleeping{false};
   std::thread th;
   bool threaded = false;
+  // Copy side (round 5): a second thread IN FRONT of the launch thread issues what brings a packet to the device -- the H2D copy
+  // of records, or the H2D + the three decode launches of a RAW chunk, and the event behind them -- and forwards every job, in
+  // order, to the launch thread, which then issues one stream-wait and the ingest kernels.  With the activity filter the launch
+  // thread's 7 runtime calls per packet were what bounded the stream (profiles/r05_ingest.md); now 2-4 of them run beside the rest.
+  // "XM_INGEST_NO_COPY_THREAD": the launch thread does both (A/B).
+  Job cqueue[QCAP];
+  std::atomic<unsigned long long> c_head{0}, c_tail{0};
+  std::atomic<bool> c_sleeping{false};
+  std::mutex c_mu;
+  std::condition_variable c_cv;
+  std::thread copy_th;
+  bool copy_threaded = false;
   uint64_t posted = 0;                 // pushes accepted so far (the caller's count)
   double t_block_s = 0.0, t_frames_s = 0.0, t_jobs_s = 0.0;  // launch side: waiting for verdicts / issuing frames / inside jobs (XM_INGEST_TRACE)
 };
@@ -512,18 +525,26 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
   return ingest_handle_verdicts(g, 0);
 }
 
-// the launches of one packet of records: H2D on the copy stream (beside the previous packets' kernels), then everything else
-int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
-  g->out_serial_now = false;
+// one packet of records, the copy side: H2D on the copy stream (beside the previous packets' kernels) + the event behind it
+int ingest_copy_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
   if (n) {
     HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
     HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
   }
+  return XM_OK;
+}
+
+// ... the launch side: everything else (arrived: the copy side has done its part already)
+int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp, bool arrived) {
+  g->out_serial_now = false;
+  int rc = arrived ? XM_OK : ingest_copy_records(g, k, n, hp);
+  if (rc) return rc;
+  if (n) HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
   return ingest_process(g, k, n, hp);
 }
 
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned);  // (xm_api_evt3.hpp)
+int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned);                 // (xm_api_evt3.hpp)
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived);  // (xm_api_evt3.hpp)
 
 // every verdict in, every frame's kernels launched and run
 int ingest_finish(xm_ingest* g) {
@@ -539,8 +560,8 @@ int ingest_finish(xm_ingest* g) {
 
 int ingest_run_job(xm_ingest* g, const xm_ingest::Job& j) {
   switch (j.kind) {
-    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host);
-    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned);
+    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host, j.arrived);
+    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.arrived);
     case 3: return ingest_process(g, j.k, j.n, nullptr);
     case 4: return ingest_finish(g);
     default: return XM_OK;
@@ -593,7 +614,8 @@ void ingest_thread_main(xm_ingest* g) {
   }
 }
 
-unsigned long long ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
+// into the launch thread's queue (from the caller, or -- with a copy thread -- from that one: a single producer either way)
+unsigned long long ingest_post_launch(xm_ingest* g, const xm_ingest::Job& j) {
   const unsigned long long hd = g->q_head.load(std::memory_order_relaxed);
   while (hd - g->q_tail.load(std::memory_order_acquire) >= xm_ingest::QCAP) __builtin_ia32_pause();  // queue full: back-pressure
   g->queue[hd % xm_ingest::QCAP] = j;
@@ -603,6 +625,58 @@ unsigned long long ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
     g->q_cv.notify_one();
   }
   return hd + 1;
+}
+
+// The caller's door: the copy thread's queue when there is one (every job passes through it and is forwarded IN ORDER, so a job's
+// number is the same in both queues and q_done counts them alike), else the launch thread's.
+unsigned long long ingest_post(xm_ingest* g, const xm_ingest::Job& j) {
+  if (!g->copy_threaded) return ingest_post_launch(g, j);
+  const unsigned long long hd = g->c_head.load(std::memory_order_relaxed);
+  while (hd - g->c_tail.load(std::memory_order_acquire) >= xm_ingest::QCAP) __builtin_ia32_pause();
+  g->cqueue[hd % xm_ingest::QCAP] = j;
+  g->c_head.store(hd + 1, std::memory_order_seq_cst);
+  if (g->c_sleeping.load(std::memory_order_seq_cst)) {
+    std::lock_guard<std::mutex> lk(g->c_mu);
+    g->c_cv.notify_one();
+  }
+  return hd + 1;
+}
+
+// jobs handed in so far (the caller's count)
+unsigned long long ingest_posted(const xm_ingest* g) {
+  return g->copy_threaded ? g->c_head.load(std::memory_order_acquire) : g->q_head.load(std::memory_order_acquire);
+}
+
+void ingest_copy_thread_main(xm_ingest* g) {
+  (void)hipSetDevice(g->h->cfg.device);
+  for (;;) {
+    const unsigned long long t = g->c_tail.load(std::memory_order_relaxed);
+    for (int i = 0; t == g->c_head.load(std::memory_order_acquire); ++i) {
+      if (i < 20000) {
+        __builtin_ia32_pause();
+        continue;
+      }
+      std::unique_lock<std::mutex> lk(g->c_mu);
+      g->c_sleeping.store(true, std::memory_order_seq_cst);
+      g->c_cv.wait(lk, [&] { return t != g->c_head.load(std::memory_order_acquire); });
+      g->c_sleeping.store(false, std::memory_order_relaxed);
+    }
+    xm_ingest::Job j = g->cqueue[t % xm_ingest::QCAP];
+    g->c_tail.store(t + 1, std::memory_order_release);
+    if ((j.kind == 0 || j.kind == 1) && !g->q_error.load(std::memory_order_relaxed)) {
+      const int rc = j.kind == 0 ? ingest_copy_records(g, j.k, j.n, (const uint4*)j.host) : ingest_copy_evt3(g, j.dec, j.k, j.host, j.n, j.pinned);
+      if (rc != XM_OK) {
+        if (g->q_error.load(std::memory_order_relaxed) == 0) {
+          g->q_error_text = g_err;  // thread-local text of this thread
+          g->q_error.store(rc, std::memory_order_release);
+        }
+        j.kind = 5;  // (nothing arrived: the launch side only counts the job)
+      }
+      j.arrived = true;
+    }
+    ingest_post_launch(g, j);
+    if (j.kind == 2) return;
+  }
 }
 
 int ingest_take_error(xm_ingest* g) {
@@ -783,6 +857,10 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   if (!(cfg->flags & XM_INGEST_NO_LAUNCH_THREAD)) {
     g->threaded = true;
     g->th = std::thread(ingest_thread_main, g);
+    if (!dbg_opt("XM_INGEST_NO_COPY_THREAD")) {
+      g->copy_threaded = true;
+      g->copy_th = std::thread(ingest_copy_thread_main, g);
+    }
     if (!g->out_on_frame_stream && !dbg_opt("XM_INGEST_OUT_INLINE")) {
       g->out_threaded = true;
       g->out_th = std::thread(ingest_out_main, g);
@@ -799,8 +877,10 @@ void xm_ingest_destroy(xm_ingest* g) {
     xm_ingest::Job stop;
     stop.kind = 2;
     ingest_post(g, stop);
+    if (g->copy_th.joinable()) g->copy_th.join();  // (forwards the stop behind everything else, then leaves)
     if (g->th.joinable()) g->th.join();
     g->threaded = false;
+    g->copy_threaded = false;
   }
   if (g->out_threaded) {  // (behind the launch thread: nobody posts any more; the queue is drained before the thread leaves)
     (void)ingest_out_drain(g);  // (every posted frame is taken before the thread is told to leave)
