@@ -257,7 +257,6 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     // C-1M needs 44 KB (w_ts = 5, w_x = 16): three blocks per CU beside K2's 12 KB blocks
     size_t budget = 76 * 1024;
     int w_ts = 5, w_x = 16;  // 5 time columns, 16 camera columns: 70 KB at C-1M
-    if (const char* e = dbg_opt("XM_K0B_SPLIT")) h->k0b_split = e[0] != '0';
     if (const char* e = dbg_opt("XM_K1_WX")) w_x = std::max(2, std::min(64, atoi(e)));  // experiments: the LUT band's width in camera columns
     if (w_ts > 64) w_ts = 64;
     auto need = [&](int wt, int wx) {

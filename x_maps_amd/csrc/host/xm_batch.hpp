@@ -8,26 +8,6 @@ namespace {
 // One K0 / K1 / K2 launch each for a whole group of frames (grid = frames x tiles).  Frame f of the group runs on slot
 // slots[f] (its own key frame + state), all on ONE stream.  A single frame's launches leave the chip half empty while
 // they ramp up and drain (245 K1 blocks for 256 CUs, each a ~10 us dependent chain); a group's launch keeps every CU fed.
-// The boundary pass of a group: the one-kernel form (k_cols_bounds_batch: 78 VGPRs, never resident beside K1 / K2) or -- the
-// default since round 5 -- the thresholds and a lean search (k_cols_thr_batch + k_cols_search_batch: the search's waves fit into
-// the registers K1 leaves free, so with several groups in flight part of it runs beside the groups in front: step 0.1958 ->
-// 0.1937 / 0.1993 -> 0.1965 ms in alternating runs at C-1M, the pass alone 16.5 -> ~11 us).  "XM_K0B_SPLIT" = 0: the one-kernel
-// form.  Measured and removed: the pass on a high-priority stream of its own (events to and from the group's stream) -- 0.209 ms
-// per step against 0.1965, with the slots' streams in the normal pool or not: a fifth stream shares a hardware queue.  (Profile mode attaches its events to the FIRST of the two launches only: the pair is timed by the whole-group
-// figure.)
-template <bool AOS>
-void launch_bounds_pass(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, int n_frames, int W) {
-  if (!h->k0b_split) {
-    XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, COLS_BOUNDS_PER_BLOCK), n_frames), dim3(256), 0, stream, d_descs,
-              h->tb, W, 0);
-    return;
-  }
-  XM_LAUNCH(k_cols_thr_batch<AOS>, dim3(grid_for(h->tb.xmap_w + 1, 256), n_frames), dim3(256), 0, stream, d_descs, h->tb);
-  g_prof = ProfCtx{};
-  hipLaunchKernelGGL(k_cols_search_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, COLS_SEARCH_PER_BLOCK), n_frames), dim3(256), 0, stream,
-                     d_descs, h->tb, W);
-}
-
 template <typename T, bool AOS, bool HAS_P>
 int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_max, u64 n_mean, bool vec16, bool sorted,
                    hipStream_t stream, bool key32 = false, int cols_w = 0, hipEvent_t* prof = nullptr,
@@ -49,7 +29,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc) return rc;
         prof_slot(0);
-        launch_bounds_pass<AOS>(h, stream, d_descs, n_frames, OWN_BW);
+        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, OWN_BW) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
+                  dim3(256), 0, stream, d_descs, h->tb, OWN_BW, 0);
         prof_slot(1);
         XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                   cols_w, h->own_halo, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
@@ -62,7 +43,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
       if (rc) return rc;
       prof_slot(0);
-      launch_bounds_pass<AOS>(h, stream, d_descs, n_frames, cols_w);
+      XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
+                dim3(256), 0, stream, d_descs, h->tb, cols_w, 0);
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));

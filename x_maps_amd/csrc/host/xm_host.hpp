@@ -194,7 +194,6 @@ struct xm_handle {
   // owner tiles (xmaps_k1own.hpp): the rig's (row, column) -> cell map is not injective (the reference's own calibration), but
   // every cell's columns lie within own_halo columns of its first one: cols_ok with own_mode set; fixed tile width own_w
   bool own_mode = false;
-  bool k0b_split = true;  // "XM_K0B_SPLIT": the boundary pass of a group as thresholds + lean search (xm_batch.hpp: launch_bounds_pass)
   int own_w = 0, own_halo = 0;
   uint16_t* d_xmap_own = nullptr;
   uint16_t* d_xmap_extra = nullptr;

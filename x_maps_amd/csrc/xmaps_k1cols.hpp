@@ -349,100 +349,6 @@ __global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __re
                         ext ? (gp_i64)d.p : nullptr, ext ? (int)d.pad : 0);
 }
 
-// ---- K0b in two LEAN kernels (round 5; groups of frames) -------------------------------------------------------------------------
-// k_cols_bounds above is a latency chain (descriptor -> stamps + probes -> probes -> store: ~15 us per group of 32 C-1M frames)
-// whose waves need 78 VGPRs: beside K1 (6 waves x 80 VGPRs per SIMD) or K2 they do not become resident, so with several groups in
-// flight its 15 us stay serial -- 7.6 % of the step.  Split by what needs registers:
-//   k_cols_thr_batch     the thresholds thr[c], one thread per (frame, column): the FP64 conversion that is bit-exact with NumPy
-//   k_cols_search_batch  the boundaries' first events: 16 lanes per boundary, a 16-ary search with 32-bit compares against thr[c],
-//                        then the six x values around the boundary -- integer work in <= 32 VGPRs, so its waves fit into the
-//                        register space K1 leaves free and the search of group g + 1 runs BESIDE K1 / K2 of the groups before it
-// Same outputs as k_cols_bounds for a sorted stream (lb = the first event with t - tmin >= thr[c]); for an unsorted one a
-// deterministic function of (stream, thr) whose inconsistencies K1's per-event verification catches, as before.
-constexpr int COLS_SEARCH_LANES = 16, COLS_SEARCH_PER_BLOCK = 256 / COLS_SEARCH_LANES;
-
-template <bool AOS>
-__global__ __launch_bounds__(256) void k_cols_thr_batch(const FrameDesc* __restrict__ descs, DevTables tb) {
-  const FrameDesc d = descs[blockIdx.y];
-  if (!d.valid || d.n == 0) return;
-  const int c = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (c > tb.xmap_w) return;
-  const int n = (int)d.n;
-  long long t_first, t_last;
-  if constexpr (AOS) {
-    const uint4 a = ((gp_u4)d.aos)[0], b = ((gp_u4)d.aos)[n - 1];
-    t_first = (long long)(((u64)a.w << 32) | a.z);
-    t_last = (long long)(((u64)b.w << 32) | b.z);
-  } else {
-    t_first = ((gp_i64)d.t)[0];
-    t_last = ((gp_i64)d.t)[n - 1];
-  }
-  if (t_last < t_first) t_last = t_first;
-  const u64 span64 = (u64)(t_last - t_first);
-  if (span64 >= 0xffffffffull) return;  // (the search kernel marks the frame: not this path)
-  XM_GLOBAL u32* thr = (XM_GLOBAL u32*)((XM_GLOBAL unsigned char*)d.key_frame + cols_thr_offset(frame16_cells(tb), tb.xmap_w));
-  const TimeNorm<long long> tn(t_first, t_last, tb.t_px_scale);
-  thr[c] = cols_threshold(tn, t_first, (u32)span64, c, tb.t_px_scale);
-}
-
-template <bool AOS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void k_cols_search_batch(const FrameDesc* __restrict__ descs, DevTables tb,
-                                                                                              int W) {
-  const FrameDesc d = descs[blockIdx.y];
-  if (!d.valid || d.n == 0) return;
-  constexpr int G = COLS_SEARCH_LANES;
-  const int lane = threadIdx.x & 63, sl = lane & (G - 1), gl = lane & ~(G - 1);
-  const int nb = (tb.xmap_w + W - 1) / W;
-  const int j_raw = (int)blockIdx.x * COLS_SEARCH_PER_BLOCK + (int)threadIdx.x / G;
-  const bool live = j_raw <= nb;
-  if (!__any(live)) return;
-  const int j = min(j_raw, nb), n = (int)d.n;
-  const size_t key_cells = frame16_cells(tb);
-  XM_GLOBAL unsigned char* base = (XM_GLOBAL unsigned char*)d.key_frame;
-  XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(base + cols_bounds_offset(key_cells));
-  const XM_GLOBAL u32* thr = (const XM_GLOBAL u32*)(base + cols_thr_offset(key_cells, tb.xmap_w));
-  gp_i64 ts = (gp_i64)d.t;
-  gp_u4 aos = (gp_u4)d.aos;
-  long long t_first = cols_t_at<AOS>(ts, aos, 0), t_last = cols_t_at<AOS>(ts, aos, n - 1);
-  if (t_last < t_first) t_last = t_first;
-  if ((u64)(t_last - t_first) >= 0xffffffffull) {
-    if (sl == 0 && live) bounds[j] = make_int4(-1, 0, 0, 0);
-    return;
-  }
-  const int c = min(j * W, tb.xmap_w);
-  const u32 A = thr[c];
-  int lo = -1, hi = n;  // event lo is below the boundary (or lo == -1), event hi at or past it (or hi == n)
-  if (c <= 0 || !live) hi = 0;
-  else if (c >= tb.xmap_w) lo = n - 1;
-  const u64 gmask = ((1ull << G) - 1ull) << gl;
-  while (__any(hi - lo > 1)) {
-    const int unknown = hi - lo - 1;                 // positions lo + 1 .. hi - 1
-    const int stride = (unknown + G - 1) / G;        // >= 1 where unknown >= 1
-    const int q = lo + (sl + 1) * stride;            // ascending over the group's lanes; the last one may reach past hi - 1
-    const bool act = unknown >= 1 && q < hi;
-    const long long tv = cols_t_at<AOS>(ts, aos, act ? q : 0);
-    const bool pr = act && (u64)(tv - t_first) >= (u64)A;
-    const u64 bp = __ballot(pr) & gmask, ba = __ballot(act) & gmask;
-    if (unknown >= 1) {
-      if (bp) {                                      // the first probe at or past the boundary becomes hi, the one in front of it lo
-        const int f = __builtin_ctzll(bp) - gl;
-        hi = lo + (f + 1) * stride;
-        if (f > 0) lo = lo + f * stride;
-      } else if (ba) {                               // every probe is below: the last one becomes lo
-        lo = lo + (64 - __builtin_clzll(ba) - gl) * stride;
-      }
-    }
-  }
-  const int lb = hi;
-  // median x of the three events at / behind the boundary (lanes 0..2) and of the three in front of it (lanes 3..5)
-  const int i = max(sl < 3 ? min(lb + sl, n - 1) : max(lb - 1 - (sl - 3), 0), 0);
-  const int xv = sl < 6 && live ? cols_x_at<AOS>((gp_u16)d.x, aos, i) : 0;
-  const int a0 = __shfl(xv, gl + 0, 64), a1 = __shfl(xv, gl + 1, 64), a2 = __shfl(xv, gl + 2, 64);
-  const int e0 = __shfl(xv, gl + 3, 64), e1 = __shfl(xv, gl + 4, 64), e2 = __shfl(xv, gl + 5, 64);
-  if (sl == 0 && live)
-    bounds[j] = make_int4(lb, max(min(a0, a1), min(max(a0, a1), a2)), max(min(e0, e1), min(max(e0, e1), e2)), 0);
-}
-
 // ---- the kernel body ---------------------------------------------------------------------------------------------------------
 // blk / nblk: this block's index among the frame's ceil(xmap_w / W) blocks.  frame16: the slot's plain u16 disparity frame,
 // followed by what k_cols_bounds left for this frame (bounds, thresholds).
