@@ -446,9 +446,8 @@ void xm_destroy(xm_handle* h) {
   if (h->d_xmap_own) (void)hipFree(h->d_xmap_own);
   if (h->d_own_tiles) (void)hipFree(h->d_own_tiles);
   if (h->d_xmap_extra) (void)hipFree(h->d_xmap_extra);
-  if (h->d_own_base) (void)hipFree(h->d_own_base);
+  if (h->d_own_bm) (void)hipFree(h->d_own_bm);
   if (h->d_own_extra_cells) (void)hipFree(h->d_own_extra_cells);
-  if (h->d_own_masks) (void)hipFree(h->d_own_masks);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
   for (int g = 0; g < 3; ++g) {
@@ -499,7 +498,7 @@ int xm_own_plan_info(const xm_config* cfg, int32_t info[12]) {
   if (!pl.ok) return XM_OK;
   info[0] = 2; info[1] = pl.W; info[2] = pl.halo; info[3] = pl.nxs_max; info[4] = pl.m; info[5] = pl.extra_cols; info[6] = pl.r_lo;
   info[7] = pl.hr; info[8] = (int)pl.extra_flat.size() - 1; info[9] = pl.extra_max; info[10] = pl.delta_max;
-  info[11] = (int)own_plan_lds_bytes(pl.nxs_max, pl.hrp, pl.extra_max);
+  info[11] = (int)own_plan_lds_bytes(pl.nxs_max, pl.rp, pl.hrp, pl.extra_max);
   return XM_OK;
 }
 

@@ -21,7 +21,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
     if (cols_w) {  // column tiles: K1 grid = (tiles, frames), K2 on the plain u16 frames
       int rc;
       if (h->own_mode) {  // owner tiles (the rig's X-map is not injective): boundaries every OWN_BW columns, tiles of own_w + halo
-        auto kern = k_scatter_own_batch<AOS, false>;
+        const int ept = own_ept(h, n_mean, cols_w, !AOS && vec16);
+        auto kern = ept == 4 ? k_scatter_own_batch<AOS, false, 4> : k_scatter_own_batch<AOS, false>;
         if constexpr (!AOS) {
           if (vec16) kern = k_scatter_own_batch<false, true>;
         }
@@ -32,7 +33,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, OWN_BW) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
                   dim3(256), 0, stream, d_descs, h->tb, OWN_BW, 0);
         prof_slot(1);
-        XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
+        XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w, ept)), lds, stream, d_descs, h->tb,
                   cols_w, h->own_halo, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
       } else {
       auto kern = k_scatter_cols_batch<AOS, false>;

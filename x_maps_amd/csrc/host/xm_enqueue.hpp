@@ -18,10 +18,18 @@ int cols_width(const xm_handle* h, u64 n) {
   return W;
 }
 
-unsigned cols_threads(const xm_handle* h, u64 n, int W) {
+// owner tiles: events per thread -- four where 512 threads then hold a tile's own + halo columns in one pass (twice the waves at
+// half the registers: xmaps_k1own.hpp), else eight.  Not for 16-byte SoA loads (eight events each)
+int own_ept(const xm_handle* h, u64 n, int W, bool vec16) {
+  if (vec16 || h->own_ept_forced == 8) return 8;
+  const double per = (double)n / (double)h->tb.xmap_w * (W + h->own_halo);
+  return h->own_ept_forced == 4 || per * 1.12 <= 4.0 * COLS_MAX_THREADS ? 4 : 8;
+}
+
+unsigned cols_threads(const xm_handle* h, u64 n, int W, int ept = COLS_EPT) {
   if (h->own_mode) {  // own + halo columns in one pass where 512 threads hold them
     const double per = (double)n / (double)h->tb.xmap_w * (W + h->own_halo);
-    const unsigned t = ((unsigned)(per * 1.12 / COLS_EPT) + 63u) / 64u * 64u;
+    const unsigned t = ((unsigned)(per * 1.12 / ept) + 63u) / 64u * 64u;
     return std::max(128u, std::min(t, (unsigned)COLS_MAX_THREADS));
   }
   const double per_tile = (double)n / (double)h->tb.xmap_w * W;
@@ -49,13 +57,15 @@ void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, i
 int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint16_t* frame16, int W, hipStream_t stream) {
   const bool vec16 = !ev.aos && aligned(ev.x, 16) && aligned(ev.y, 16) && aligned(ev.t, 16);
   if (h->own_mode) {
+    const int ept = own_ept(h, ev.n, W, vec16);
     auto kern = k_scatter_own<false, false>;
-    if (ev.aos) kern = k_scatter_own<true, false>;
+    if (ev.aos) kern = ept == 4 ? k_scatter_own<true, false, 4> : k_scatter_own<true, false>;
     else if (vec16) kern = k_scatter_own<false, true>;
+    else if (ept == 4) kern = k_scatter_own<false, false, 4>;
     const size_t lds = own_lds_bytes(h);
     int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc) return rc;
-    XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, W)), dim3(cols_threads(h, ev.n, W)), lds, stream, ev.x, ev.y, (const long long*)ev.t,
+    XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, W)), dim3(cols_threads(h, ev.n, W, ept)), lds, stream, ev.x, ev.y, (const long long*)ev.t,
               (const uint4*)ev.aos, (u32)ev.n, h->tb, st, frame16, W, h->own_halo, h->cols_flags);
     return XM_OK;
   }

@@ -7,7 +7,7 @@ namespace {
 // ---- owner tiles (xmaps_k1own.hpp): the rig's ownership tables, worked out once on the host -------------------------------------
 struct OwnPlan {  // what own_plan() works out (host memory) and own_setup() uploads
   bool ok = false, all_in = true;
-  int W = 0, halo = 0, r_lo = 0, hr = 0, hrp = 0, nxs_max = 0, extra_max = 0, m = 0, bias = 0, extra_cols = 0, delta_max = 0;
+  int W = 0, halo = 0, r_lo = 0, hr = 0, hrp = 0, rp = 0, nxs_max = 0, extra_max = 0, m = 0, bias = 0, extra_cols = 0, delta_max = 0;
   std::vector<uint16_t> packed, xextra, masks;
   std::vector<int4> tiles;
   std::vector<int16_t> bases;
@@ -172,9 +172,16 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
     extra_max = std::max(extra_max, tiles[t].z);
   }
   extra_max = (extra_max + 3) & ~3;
-  if (own_plan_lds_bytes(nxs_max, hrp, extra_max) > 60 * 1024) return;  // LDS per block
+  // rows per pass of the tile's LDS slots: the fewest passes (<= 4) that leave room for OWN_LDS_TARGET-sized blocks -- the
+  // kernel is a chain of dependent round trips, what hides them is the number of tiles a CU holds at once
+  int passes = 1;
+  const auto rows_per_pass = [&](int P) { return ((hrp / 8 + P - 1) / P) * 8; };
+  while (passes < OWN_MAX_ROW_PASSES && own_plan_lds_bytes(nxs_max, rows_per_pass(passes), hrp, extra_max) > OWN_LDS_TARGET) passes += 1;
+  if (const char* e = dbg_opt("XM_OWN_ROW_PASSES")) passes = std::max(1, std::min(atoi(e), OWN_MAX_ROW_PASSES));
+  const int rp = rows_per_pass(passes);
+  if (own_plan_lds_bytes(nxs_max, rp, hrp, extra_max) > 60 * 1024) return;  // LDS per block
   extra_flat.push_back(0);
-  pl.W = W; pl.halo = halo; pl.r_lo = r_lo; pl.hr = hr; pl.hrp = hrp; pl.nxs_max = nxs_max; pl.extra_max = extra_max;
+  pl.W = W; pl.halo = halo; pl.r_lo = r_lo; pl.hr = hr; pl.hrp = hrp; pl.rp = rp; pl.nxs_max = nxs_max; pl.extra_max = extra_max;
   pl.m = m; pl.bias = bias; pl.extra_cols = extra; pl.delta_max = delta_max; pl.all_in = all_in;
   pl.ok = true;
 }
@@ -192,25 +199,29 @@ int own_setup(xm_handle* h, const xm_config* cfg, int xr_min) {
   HIP_TRY(up(&h->d_xmap_own, pl.packed));
   HIP_TRY(up(&h->d_xmap_extra, pl.xextra));
   HIP_TRY(up(&h->d_own_tiles, pl.tiles));
-  HIP_TRY(up(&h->d_own_base, pl.bases));
-  HIP_TRY(up(&h->d_own_masks, pl.masks));
+  {  // band position | ownership mask << 16 per (tile, row): one table, read by 16-byte loads at the head of every tile
+    std::vector<u32> bm(pl.bases.size());
+    for (size_t i = 0; i < bm.size(); ++i) bm[i] = (u32)(uint16_t)pl.bases[i] | ((u32)pl.masks[i] << 16);
+    HIP_TRY(up(&h->d_own_bm, bm));
+  }
   HIP_TRY(up(&h->d_own_extra_cells, pl.extra_flat));
   h->own_extras = (int)pl.extra_flat.size() - 1;
   h->tb.xmap_own = h->d_xmap_own;
   h->tb.xmap_extra = h->d_xmap_extra;
   h->tb.own_tiles = h->d_own_tiles;
-  h->tb.own_base = h->d_own_base;
-  h->tb.own_masks = h->d_own_masks;
+  h->tb.own_bm = h->d_own_bm;
   h->tb.own_extra_cells = h->d_own_extra_cells;
   h->tb.own_r_lo = pl.r_lo;
   h->tb.own_hr = pl.hr;
   h->tb.own_hrp = pl.hrp;
+  h->tb.own_rp = pl.rp;
   h->tb.own_nxs_max = pl.nxs_max;
   h->tb.own_extra_max = pl.extra_max;
   h->tb.shear_m = pl.m;
   h->tb.shear_bias = pl.bias;
   h->tb.shear_extra = pl.extra_cols;
   h->own_mode = true;
+  if (const char* e = dbg_opt("XM_OWN_EPT")) h->own_ept_forced = atoi(e);
   h->own_w = pl.W;
   h->own_halo = pl.halo;
   if (pl.all_in) h->cols_flags |= COLS_F_ALL_IN_FRAME;

@@ -39,15 +39,19 @@ constexpr int OWN_MAX_DELTA = 7;  // 3 bits in the packed X-map
 constexpr int OWN_XP_BITS = 13;   // xp < 8192
 constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile (the ownership masks are u16)
 constexpr int OWN_MAX_COLS = 72;  // own + halo columns of a tile (W <= 64, halo <= 8)
+constexpr int OWN_MAX_ROW_PASSES = 4;         // a tile's rows go through its LDS slots in up to this many passes (own_plan)
+constexpr size_t OWN_LDS_TARGET = 32 * 1024;  // ... as many as it takes to bring a block's LDS down to this
 
-template <bool AOS, bool VEC>
+// EPT = events per thread and event pass: 8 (the column tiles' figure) or 4 -- half the registers per wave and twice the waves for
+// the same tile: the kernel is bound by its own instruction issue at three to four waves per SIMD (profiles/r05_own_tiles.md)
+template <bool AOS, bool VEC, int EPT>
 __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts, gp_u4 aos, const u32 n_ev, const DevTables& tb,
                                                  gp_state st, XM_GLOBAL uint16_t* frame16, const int W, const int halo,
-                                                 const u32 blk, const u32 nblk, const int flags) {
+                                                 const u32 blk, const u32 nblk, const int flags, const u32 frame_in_grid = 0) {
   const bool device_redo = flags & COLS_F_DEVICE_REDO, all_in = flags & COLS_F_ALL_IN_FRAME;
   typedef long long T;
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
-  constexpr int EPT = COLS_EPT;
+  static_assert(EPT == 8 || (EPT == 4 && !VEC), "16-byte loads of x / y take eight events");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ u32 s_in, s_oob;
   // the interior thresholds of the tile's columns, thr[c0 + j] at s_thr[3 + j] (j = 1, 5, 9, ... start a 16-byte quad), padded
@@ -60,15 +64,17 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   gp_i4 bounds = (gp_i4)((const XM_GLOBAL unsigned char*)frame16 + cols_bounds_offset(cells16));
   const XM_GLOBAL u32* thr = (const XM_GLOBAL u32*)((const XM_GLOBAL unsigned char*)frame16 + cols_thr_offset(cells16, tb.xmap_w));
   const int HRp = tb.own_hrp, r_lo = tb.own_r_lo;
-  // LDS carve-up (mirrored by own_lds_bytes() on the host): band slots [nxs_max][HRp] | extra slots [extra_max] | per row: first
-  // frame column of the band, ownership mask
+  // LDS carve-up (mirrored by own_lds_bytes() on the host): band slots [nxs_max][RP] | extra slots [extra_max] | per row: first
+  // frame column of the band, ownership mask.  RP = rows per pass: the tile's rows go through the band slots in ceil(HRp / RP)
+  // passes (events and gathers stay in registers in between) -- a block's LDS is what limits the tiles a CU holds at once
   u32* slots = reinterpret_cast<u32*>(smem);
-  const int n_band_max = tb.own_nxs_max * HRp;
+  const int RP = tb.own_rp;
+  const int n_band_max = tb.own_nxs_max * RP;
   u32* slots_x = slots + n_band_max;
-  int16_t* s_base = reinterpret_cast<int16_t*>(slots_x + tb.own_extra_max);
-  uint16_t* s_mask = reinterpret_cast<uint16_t*>(s_base + HRp);
+  u32* s_bm = slots_x + tb.own_extra_max;  // [HRp] band position | ownership mask << 16
 
-  const u32 tile = xcd_contiguous(blk, nblk);
+  XM_CSTAMP(0);
+  const u32 tile = xcd_contiguous_in_frame(blk, nblk, frame_in_grid);
   const int c0 = (int)tile * W;
   const int Wc = min(W, tb.xmap_w - c0);
   const int c_end = min(c0 + W + halo, tb.xmap_w);
@@ -77,6 +83,13 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const int4 b_lo = bounds[c0 / OWN_BW], b_hi = bounds[(c_end + OWN_BW - 1) / OWN_BW];
   const u32 A_lo = thr[c0], A_hi = thr[c_end];
   const int4 trec = ((const XM_GLOBAL int4*)tb.own_tiles)[tile];  // {band columns, first extra, extras, -}
+  // the tile's band positions and ownership masks: 16-byte loads issued with the locating loads, parked in registers until
+  // the slots are cleared (a copy loop of 2-byte loads here was a third of the block's life: one round trip per iteration)
+  const XM_GLOBAL uint4* gbm = (const XM_GLOBAL uint4*)((const XM_GLOBAL u32*)tb.own_bm + (size_t)tile * (size_t)HRp);
+  const int n_bm4 = HRp >> 2;  // (HRp % 8 == 0)
+  uint4 bm_q[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) bm_q[q] = gbm[min(tid + q * nthreads, n_bm4 - 1)];
   T t_first, t_last;
   if constexpr (AOS) {
     const uint4 a = aos[0], b = aos[n - 1];
@@ -87,18 +100,18 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     t_last = ts[n - 1];
   }
   const u32 tag = st->tag_b + 1;
+  XM_CSTAMP(1);  // (tag_b: the last of the tile's locating loads)
   const int nxs = trec.x, x_first = trec.y, n_extra = trec.z;
-  const int nslots = nxs * HRp;
+  const int nslots = nxs * RP;
   {  // winner slots; the tile's ownership masks (one u16 per row) and band positions (one per 8-row group)
     uint4* l_slots = reinterpret_cast<uint4*>(slots);
     for (int i = tid; i < (nslots >> 2); i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);  // (HRp % 8 == 0)
     for (int i = tid; i < n_extra; i += nthreads) slots_x[i] = 0;
-    const XM_GLOBAL uint16_t* gm = (const XM_GLOBAL uint16_t*)tb.own_masks + (size_t)tile * (size_t)HRp;
-    const XM_GLOBAL int16_t* gb = (const XM_GLOBAL int16_t*)tb.own_base + (size_t)tile * (size_t)HRp;
-    for (int i = tid; i < HRp; i += nthreads) {
-      s_mask[i] = gm[i];
-      s_base[i] = gb[i];
-    }
+    uint4* l_bm = reinterpret_cast<uint4*>(s_bm);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (tid + q * nthreads < n_bm4) l_bm[tid + q * nthreads] = bm_q[q];
+    for (int i = tid + 2 * nthreads; i < n_bm4; i += nthreads) l_bm[i] = gbm[i];  // (more than 8 rows per thread: small blocks)
   }
   if (tid == 0) {
     s_in = 0;
@@ -172,14 +185,27 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     }
   }
   __syncthreads();  // slots cleared, masks in place
+  XM_CSTAMP(2);
 
   const u32* lut = tb.lut;
   const uint16_t* xmo = tb.xmap_own;
   u32 n_in = 0, n_oob = 0;
+  // per event: its slot (row pass << 24 | index inside the pass's slots; extras: pass 0, behind the band) or -1, and the value
+  int code[EPT];
+  u32 val[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    code[k] = -1;
+    val[k] = 0;
+  }
+  const bool cached = n_pass <= 1;  // the tile's events fit the block's registers: loaded and looked up once for all row passes
+  const int n_rp = (HRp + RP - 1) / RP;
+  for (int rp = 0; rp < n_rp; ++rp) {
   for (int pass = 0; pass < n_pass; ++pass) {
     const bool on = wave_on(pass);
     if (!on) continue;
-    if (pass > 0) load_events(pass);
+    if (rp == 0 || !cached) {
+    if (pass > 0 || rp > 0) load_events(pass);
     int e0;
     if constexpr (VEC) e0 = pass * cap + tid * EPT;
     else e0 = pass * cap + tid;
@@ -204,17 +230,20 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       for (int k = 0; k < EPT; ++k)
         tl[k] += (av[k] >= A4.x ? 1 : 0) + (av[k] >= A4.y ? 1 : 0) + (av[k] >= A4.z ? 1 : 0) + (av[k] >= A4.w ? 1 : 0);
     }
+    if (rp == 0 && pass == 0) XM_CSTAMP(3);  // events arrived, columns found
     // A1: the rectify LUT from L2, eight gathers in flight.  x / y outside the camera = map[y, x] IndexError in the reference
     // (calib:279-280): dropped and counted (once: by the tile whose own columns hold the event)
     u32 l[EPT];
+    u32 oob_here = 0, in_here = 0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u32 xk = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff, yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
       const bool inside = xk < (u32)tb.cam_w && yk < (u32)tb.cam_h;
-      n_oob += live[k] && !inside && tl[k] < Wc ? 1u : 0u;
+      oob_here += live[k] && !inside && tl[k] < Wc ? 1u : 0u;
       live[k] = live[k] && inside;
-      l[k] = lut[live[k] ? __umul24(xk, (u32)tb.cam_h) + yk : 0u];
+      l[k] = XM_CABL(5) ? ((yk * 2u + 100u) << 16) | (xk + 50u) : lut[live[k] ? __umul24(xk, (u32)tb.cam_h) + yk : 0u];
     }
+    if (rp == 0 && pass == 0) XM_CSTAMP(4);  // LUT gathers issued
     // A2: the packed X-map (xp | delta << 13) from L2
     u32 xm[EPT];
     int rr[EPT];
@@ -223,7 +252,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       const int yr = (int)(short)(l[k] >> 16);
       rr[k] = yr - r_lo;
       live[k] = live[k] && (u32)rr[k] < (u32)tb.own_hr;  // 0 <= yr < H - 1 (xmd:23): own_hr rows from r_lo on, all of them valid
-      xm[k] = xmo[live[k] ? __umul24((u32)(c0 + tl[k]), (u32)tb.xmap_h) + (u32)yr : 0u];
+      xm[k] = XM_CABL(5) ? (u32)(tb.x_offset + 300 + ((c0 + tl[k]) * 3 >> 2) + (yr >> 2)) : xmo[live[k] ? __umul24((u32)(c0 + tl[k]), (u32)tb.xmap_h) + (u32)yr : 0u];
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -235,23 +264,69 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       if (!all_in) {
         if (fc < 0) fc += tb.rect_w;  // NumPy's negative wrap
         const bool in_frame = (u32)fc < (u32)tb.rect_w && rr[k] + r_lo < tb.rect_h;
-        n_oob += write && !in_frame && tl[k] < Wc ? 1u : 0u;
+        oob_here += write && !in_frame && tl[k] < Wc ? 1u : 0u;
         write = write && in_frame;
       }
-      n_in += write && tl[k] < Wc ? 1u : 0u;  // counted by the tile whose own columns hold the event
-      const int jo = tl[k] - delta;            // the cell's owner column, relative to c0
+      in_here += write && tl[k] < Wc ? 1u : 0u;  // counted by the tile whose own columns hold the event
+      const int jo = tl[k] - delta;               // the cell's owner column, relative to c0
       write = write && (u32)jo < (u32)W;
       // the cell's column inside its row's band: its frame column (frame16_col) - the band's first
-      const int sx = fc + tb.shear_bias + ((((rr[k] + r_lo) >> 3) * tb.shear_m) >> 12) - (int)s_base[write ? rr[k] : 0];
-      int idx = __mul24(sx, HRp) + rr[k];
-      if (write && (u32)sx >= (u32)nxs) {  // an extra: its slot index comes from the second table, at the cell's OWNER pair
+      const int sx = fc + tb.shear_bias + ((((rr[k] + r_lo) >> 3) * tb.shear_m) >> 12) - (int)(s_bm[write ? rr[k] : 0] & 0xffffu);
+      const int rpo = (rr[k] >= RP ? 1 : 0) + (rr[k] >= 2 * RP ? 1 : 0) + (rr[k] >= 3 * RP ? 1 : 0);  // (OWN_MAX_ROW_PASSES = 4)
+      int idx = (rpo << 24) | (__mul24(sx, RP) + rr[k] - __mul24(rpo, RP));
+      if (n_extra > 0 && write && (u32)sx >= (u32)nxs) {  // (tile-uniform: most tiles have none) an extra: its slot index comes from the second table, at the cell's OWNER pair
         const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)(c0 + jo), (u32)tb.xmap_h) + (u32)(rr[k] + r_lo)];
         write = e != 0u;  // (always: xm_create lists every owner cell outside its band)
         idx = n_band_max + (int)e - 1;
       }
-      if (write) atomicMax(&slots[idx], ((u32)(e0 + (VEC ? k : k * nthreads) + 1) << 16) | (u32)disp);
+      code[k] = write ? idx : -1;
+      val[k] = ((u32)(e0 + (VEC ? k : k * nthreads) + 1) << 16) | (u32)disp;
     }
+    if (rp == 0 && pass == 0) XM_CSTAMP(5);  // both gathers arrived, slots worked out
+    if (rp == 0) {  // (a tile of several event passes looks its events up once per row pass: counted the first time)
+      n_in += in_here;
+      n_oob += oob_here;
+    }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+      if (code[k] >= 0 && (code[k] >> 24) == rp) atomicMax(&slots[code[k] & 0xffffff], val[k]);
   }
+  __syncthreads();
+  if (rp == 0) XM_CSTAMP(6);  // pass 0's ds_max done, barrier passed
+  // ---- flush of the pass's rows: lanes = consecutive rows, each walks its row's band (mask and band position read once per
+  //      row; the store of a wave = 64 consecutive rows of one sheared frame column); the slots are left cleared for the next pass
+  //      (an event only ever lands on a cell its tile owns: a mask bit)
+  {
+    XM_GLOBAL uint16_t* base = frame16 + (size_t)r_lo;
+    const u32 col_stride = (u32)tb.rect_h;
+    const int r_first = rp * RP, r_cnt = min(RP, HRp - r_first);
+    const bool more = rp + 1 < n_rp;
+    for (int r_l = tid; r_l < r_cnt; r_l += nthreads) {
+      const int r_i = r_first + r_l;
+      const u32 bm = s_bm[r_i];
+      u32 m = bm >> 16;
+      XM_GLOBAL uint16_t* p = base + (__umul24(bm & 0xffffu, col_stride) + (u32)r_i);
+      u32* sl = slots + r_l;
+      while (m) {  // eight band columns at a time: the LDS reads go out together, then the stores
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (m >> k) ? sl[k * RP] : 0u;  // (nothing past the row's last band column: the slots end there)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if ((m >> k) & 1u) {
+            if (!XM_CABL(4) || v[k] == 0x12345678u) p[(u32)k * col_stride] = (uint16_t)(v[k] & 0xffffu);
+            if (more) sl[k * RP] = 0;
+          }
+        m >>= 8;
+        p += 8u * col_stride;
+        sl += 8 * RP;
+      }
+    }
+    if (more) __syncthreads();
+  }
+  }
+  XM_CSTAMP(7);  // every row pass flushed
   if (__ballot(bad) && lane == 0) {
     if (device_redo) {
       st->pad[1] = tag;
@@ -272,35 +347,11 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   }
   __syncthreads();
 
-  // ---- flush: the tile's cell band in memory order; lanes walk consecutive rows of one (sheared) frame column
-  {
-    int k = 0, r_i = tid;
-    while (r_i >= HRp) {
-      r_i -= HRp;
-      k += 1;
-    }
-    int dk = 0, dr = nthreads;
-    while (dr >= HRp) {
-      dr -= HRp;
-      dk += 1;
-    }
-    XM_GLOBAL uint16_t* base = frame16 + (size_t)r_lo;
-    for (int i = tid; i < nslots; i += nthreads) {
-      const u32 v = slots[i];
-      const u32 m = s_mask[r_i];
-      if ((m >> k) & 1u) base[__umul24((u32)((int)s_base[r_i] + k), (u32)tb.rect_h) + (u32)r_i] = (uint16_t)(v & 0xffffu);
-      r_i += dr;
-      k += dk;
-      if (r_i >= HRp) {
-        r_i -= HRp;
-        k += 1;
-      }
-    }
-  }
   {  // the extras, one by one
     const XM_GLOBAL u32* xc = (const XM_GLOBAL u32*)tb.own_extra_cells + x_first;
     for (int i = tid; i < n_extra; i += nthreads) frame16[xc[i]] = (uint16_t)(slots_x[i] & 0xffffu);
   }
+  XM_CSTAMP(8);
   if (tid == 0) {
     XM_GLOBAL u32* c = st->cnt[parity][blk % CNT_SLOTS];
     if (s_in) __hip_atomic_fetch_add(&c[CNT_INLIER], s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -308,27 +359,27 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   }
 }
 
-template <bool AOS, bool VEC>
+template <bool AOS, bool VEC, int EPT = COLS_EPT>
 __global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts, const uint4* __restrict__ aos,
     u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int halo, int flags) {
   {  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
-    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)aos | (u64)tb.lut | (u64)tb.xmap_own | (u64)tb.own_tiles | (u64)tb.own_masks | (u64)tb.own_base | (u64)tb.xmap_extra | (u64)tb.own_extra_cells |
+    const u64 pp = (u64)xs | (u64)ys | (u64)ts | (u64)aos | (u64)tb.lut | (u64)tb.xmap_own | (u64)tb.own_tiles | (u64)tb.own_bm | (u64)tb.xmap_extra | (u64)tb.own_extra_cells |
                    (u64)st | (u64)frame16;
     const int pi = tb.cam_w | tb.cam_h | tb.xmap_w | tb.xmap_h | tb.x_offset | tb.rect_w | tb.rect_h | W | halo | tb.own_hrp | tb.own_r_lo;
     if ((long long)(pp | (u64)(long long)pi) < 0) return;
   }
-  scatter_own_body<AOS, VEC>((gp_u16)xs, (gp_u16)ys, (gp_i64)ts, (gp_u4)aos, n, tb, (gp_state)st, (XM_GLOBAL uint16_t*)frame16, W,
-                             halo, blockIdx.x, gridDim.x, flags);
+  scatter_own_body<AOS, VEC, EPT>((gp_u16)xs, (gp_u16)ys, (gp_i64)ts, (gp_u4)aos, n, tb, (gp_state)st, (XM_GLOBAL uint16_t*)frame16, W,
+                                  halo, blockIdx.x, gridDim.x, flags);
 }
 
-template <bool AOS, bool VEC>
+template <bool AOS, bool VEC, int EPT = COLS_EPT>
 __global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W,
                                                                         int halo, int flags) {
   const FrameDesc d = descs[blockIdx.y];
   if (!d.valid || d.n == 0) return;
-  scatter_own_body<AOS, VEC>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
-                             (XM_GLOBAL uint16_t*)d.key_frame, W, halo, blockIdx.x, gridDim.x, flags);
+  scatter_own_body<AOS, VEC, EPT>((gp_u16)d.x, (gp_u16)d.y, (gp_i64)d.t, (gp_u4)d.aos, (u32)d.n, tb, (gp_state)d.st,
+                                  (XM_GLOBAL uint16_t*)d.key_frame, W, halo, blockIdx.x, gridDim.x, flags, blockIdx.y);
 }
 
 }  // namespace xm

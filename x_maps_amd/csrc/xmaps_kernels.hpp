@@ -60,16 +60,16 @@ struct DevTables {
   float z_near, z_far;
   // owner tiles (xmaps_k1own.hpp; rigs whose (row, time column) -> cell map is not injective): the X-map once more with the
   // distance to the cell's owner column in the top bits; per tile {columns of its cell band, first extra, extras}; per (tile,
-  // row) the band's first frame column and the mask of the band cells the tile owns; cells outside the
+  // row) the band's first frame column and the mask of the band cells the tile owns (one u32); cells outside the
   // band ("extras") have a slot index in xmap_extra (at their owner pair) and their frame cell in own_extra_cells.  The rows
   // the rectify LUT can reach: own_hr rows from own_r_lo (a multiple of 8) on, padded to own_hrp (a multiple of 8)
   const uint16_t* xmap_own;     // [xmap_w][xmap_h]  xp | delta << 13, 0 = undefined
   const uint16_t* xmap_extra;   // [xmap_w][xmap_h]  extra slot + 1 at the owner pair of a cell outside its tile's band, else 0
   const int4* own_tiles;        // [tiles] {band columns, first extra, extras, 0}
-  const int16_t* own_base;      // [tiles][own_hrp]  first frame column of the row's band
-  const uint16_t* own_masks;    // [tiles][own_hrp]
+  const u32* own_bm;            // [tiles][own_hrp]  first frame column of the row's band | ownership mask << 16
   const u32* own_extra_cells;   // [extras] cell index in the (sheared) u16 frame
   int own_r_lo, own_hr, own_hrp, own_nxs_max, own_extra_max;
+  int own_rp;  // rows per pass of a tile's LDS slots (a multiple of 8; own_hrp = one pass): see scatter_own_body
   // the plain u16 disparity frame of the column / owner tiles is sheared by whole columns per 8-row group: cell (x, row) lives
   // in frame column x + shear_bias + ((row >> 3) * shear_m >> 12); the frame has rect_w + shear_extra columns.  All 0 unless
   // the rig's X-map is slanted (xm_create fits shear_m)
@@ -277,6 +277,21 @@ constexpr u32 N_XCD = 8;
 __device__ inline u32 xcd_contiguous(u32 b, u32 nb) {
   const u32 xcd = b % N_XCD, j = b / N_XCD, q = nb / N_XCD, r = nb % N_XCD;
   return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+// The same for frame `frame` of a (nb, frames) grid: workgroups are dealt to the XCDs in LINEAR order, so the frame's block b sits on
+// XCD (frame * nb + b) % 8 -- with nb % 8 != 0 every frame starts on another XCD, and xcd_contiguous(b, nb) would hand every XCD
+// every table slice over the frames of a group.  XCD x takes the x-th contiguous run of the frame's items, whatever the phase
+// (the runs' lengths move by one item between frames).  Bijective.
+__device__ inline u32 xcd_contiguous_in_frame(u32 b, u32 nb, u32 frame) {
+  const u32 s = (frame * nb) % N_XCD, bv = b + s, xcd = bv % N_XCD, end = nb + s;  // the frame's blocks: virtual indices [s, end)
+  u32 start = 0;
+  for (u32 x = 0; x < xcd; ++x) {
+    const u32 first = s + ((x + N_XCD - s) % N_XCD);
+    start += first < end ? (end - 1 - first) / N_XCD + 1 : 0;
+  }
+  const u32 first = s + ((xcd + N_XCD - s) % N_XCD);
+  return start + (bv - first) / N_XCD;
 }
 
 // experiments only (-DXM_ABLATE): every block of the three hot kernels logs {kind, slot state, tag, start, end} in the
