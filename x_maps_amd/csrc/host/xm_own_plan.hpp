@@ -178,6 +178,15 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   const auto rows_per_pass = [&](int P) { return ((hrp / 8 + P - 1) / P) * 8; };
   while (passes < OWN_MAX_ROW_PASSES && own_plan_lds_bytes(nxs_max, rows_per_pass(passes), hrp, extra_max) > OWN_LDS_TARGET) passes += 1;
   if (const char* e = dbg_opt("XM_OWN_ROW_PASSES")) passes = std::max(1, std::min(atoi(e), OWN_MAX_ROW_PASSES));
+  {  // the kernel finds a row's pass as row * ceil(2^20 / rp) >> 20
+    const auto magic_ok = [&](int rp_) {
+      const u32 inv = ((1u << 20) + (u32)rp_ - 1u) / (u32)rp_;
+      for (int r = 0; r < hrp; ++r)
+        if ((int)(((u32)r * inv) >> 20) != r / rp_) return false;
+      return true;
+    };
+    while (passes > 1 && !magic_ok(rows_per_pass(passes))) passes -= 1;
+  }
   const int rp = rows_per_pass(passes);
   if (own_plan_lds_bytes(nxs_max, rp, hrp, extra_max) > 60 * 1024) return;  // LDS per block
   extra_flat.push_back(0);
@@ -201,7 +210,11 @@ int own_setup(xm_handle* h, const xm_config* cfg, int xr_min) {
   HIP_TRY(up(&h->d_own_tiles, pl.tiles));
   {  // band position | ownership mask << 16 per (tile, row): one table, read by 16-byte loads at the head of every tile
     std::vector<u32> bm(pl.bases.size());
-    for (size_t i = 0; i < bm.size(); ++i) bm[i] = (u32)(uint16_t)pl.bases[i] | ((u32)pl.masks[i] << 16);
+    for (size_t i = 0; i < bm.size(); ++i) {  // (the band's origin BEFORE the frame's shear: an event's band column = cell column - origin)
+      const int row = (int)(i % (size_t)pl.hrp) + pl.r_lo;
+      const int org = (int)pl.bases[i] - pl.bias - (((row >> 3) * pl.m) >> 12);
+      bm[i] = (u32)(uint16_t)(int16_t)org | ((u32)pl.masks[i] << 16);
+    }
     HIP_TRY(up(&h->d_own_bm, bm));
   }
   HIP_TRY(up(&h->d_own_extra_cells, pl.extra_flat));

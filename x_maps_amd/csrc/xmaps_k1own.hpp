@@ -105,7 +105,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const int nslots = nxs * RP;
   {  // winner slots; the tile's ownership masks (one u16 per row) and band positions (one per 8-row group)
     uint4* l_slots = reinterpret_cast<uint4*>(slots);
-    for (int i = tid; i < (nslots >> 2); i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);  // (HRp % 8 == 0)
+    for (int i = tid; i < (XM_CABL(9) ? 0 : (nslots >> 2)); i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);  // (HRp % 8 == 0)
     for (int i = tid; i < n_extra; i += nthreads) slots_x[i] = 0;
     uint4* l_bm = reinterpret_cast<uint4*>(s_bm);
 #pragma unroll
@@ -127,17 +127,28 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const int a0 = VEC ? (lb_s & ~(EPT - 1)) : lb_s;
   int n_pass = 0;
   for (int left = lb_e > lb_s ? lb_e - a0 : 0; left > 0; left -= cap) n_pass += 1;
-  u32 xw[EPT / 2], yw[EPT / 2];
+  if (XM_CABL(7)) n_pass = 0;  // (experiments: no per-event work at all)
+  u32 xy[EPT];  // x | y << 16
   T tt[EPT];
   const auto load_events = [&](const int pass) {
+    if (XM_CABL(6)) {  // (experiments: no event loads)
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        xy[k] = (u32)(tid * 7 + k * 13) % 600u | ((u32)(tid * 3 + k) % 400u) << 16;
+        tt[k] = t_first + (T)A_lo + (T)((tid + k * 64) % 64);
+      }
+      return;
+    }
     if constexpr (VEC) {
       const int base_true = a0 + pass * cap + tid * EPT;
       const int last_grp = (n - 1) & ~(EPT - 1);
       const int base = min(base_true, last_grp);
       const uint4 xv = *(gp_u4)(xs + base);
       const uint4 yv = *(gp_u4)(ys + base);
-      xw[0] = xv.x; xw[1] = xv.y; xw[2] = xv.z; xw[3] = xv.w;
-      yw[0] = yv.x; yw[1] = yv.y; yw[2] = yv.z; yw[3] = yv.w;
+      const u32 xw[4] = {xv.x, xv.y, xv.z, xv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int k = 0; k < EPT; ++k)
+        xy[k] = (k & 1) ? (xw[k >> 1] >> 16) | (yw[k >> 1] & 0xffff0000u) : (xw[k >> 1] & 0xffffu) | (yw[k >> 1] << 16);
 #pragma unroll
       for (int q = 0; q < EPT / 2; ++q) {
         const longlong2 a = *(const XM_GLOBAL longlong2*)(ts + (base + 2 * q < n ? base + 2 * q : base));
@@ -146,19 +157,15 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < EPT / 2; ++q) xw[q] = yw[q] = 0;
-#pragma unroll
       for (int k = 0; k < EPT; ++k) {
         const int i = lb_s + pass * cap + k * nthreads + tid;
         const int ic = i < lb_e ? i : lb_s;
         if constexpr (AOS) {
           const uint4 r = aos[ic];
-          xw[k >> 1] |= (r.x & 0xffff) << ((k & 1) * 16);
-          yw[k >> 1] |= (r.x >> 16) << ((k & 1) * 16);
+          xy[k] = r.x;
           tt[k] = (T)(((u64)r.w << 32) | r.z);
         } else {
-          xw[k >> 1] |= (u32)xs[ic] << ((k & 1) * 16);
-          yw[k >> 1] |= (u32)ys[ic] << ((k & 1) * 16);
+          xy[k] = (u32)xs[ic] | ((u32)ys[ic] << 16);
           tt[k] = ts[ic];
         }
       }
@@ -188,8 +195,8 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   XM_CSTAMP(2);
 
   const u32* lut = tb.lut;
-  const uint16_t* xmo = tb.xmap_own;
-  u32 n_in = 0, n_oob = 0;
+  const uint16_t* xmo_tile = tb.xmap_own + (size_t)c0 * (size_t)tb.xmap_h;  // the tile's first column of the packed X-map
+  u32 n_in = 0, n_oob = 0;  // wave-uniform (counted with ballots)
   // per event: its slot (row pass << 24 | index inside the pass's slots; extras: pass 0, behind the band) or -1, and the value
   int code[EPT];
   u32 val[EPT];
@@ -200,6 +207,33 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   }
   const bool cached = n_pass <= 1;  // the tile's events fit the block's registers: loaded and looked up once for all row passes
   const int n_rp = (HRp + RP - 1) / RP;
+  const u32 rp_inv = n_rp > 1 ? ((1u << 20) + (u32)RP - 1u) / (u32)RP : 0u;  // row / RP = row * rp_inv >> 20 (own_plan has checked it)
+  const u32 A_span = A_hi - A_lo;
+  // The column of an event inside the tile: #{j >= 1 : thr[c0 + j] <= a}.  Thresholds are (c - 1/2) span / S rounded -- evenly
+  // spaced up to a unit --, so E(a) = floor((a - A_lo) ncols / A_span - 1/2) is the column or the one in front of it: one compare
+  // against thr[E + 1] settles it.  The wave verifies that on the tile's thresholds themselves (E is monotone: it is enough that
+  // E(thr[j]) >= j - 1 and E(thr[j] - 1) <= j - 1 for every j); a tile whose thresholds are not that regular (time stamps that
+  // stand still, spans of a few units) counts compares instead.
+  const float col_inv = (float)ncols / (float)max(A_span, 1u);
+  const auto col_est = [&](const u32 rel) { return __float2uint_rz(fmaxf((float)rel * col_inv - 0.5f, 0.0f)); };
+  bool col_lin;
+  {
+    const int j = lane + 1;  // (ncols <= OWN_MAX_COLS: two rounds of 64 lanes)
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int jq = j + 64 * q;
+      if (jq <= ncols) {
+        const u32 A = jq < ncols ? s_thr[3 + jq] : A_hi;
+        if (A < A_lo || A > A_hi) ok = false;
+        else {
+          if (A > A_lo && col_est(A - 1u - A_lo) > (u32)(jq - 1)) ok = false;
+          if (jq < ncols && col_est(A - A_lo) + 1u < (u32)jq) ok = false;
+        }
+      }
+    }
+    col_lin = !__any(!ok);
+  }
   for (int rp = 0; rp < n_rp; ++rp) {
   for (int pass = 0; pass < n_pass; ++pass) {
     const bool on = wave_on(pass);
@@ -209,37 +243,49 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     int e0;
     if constexpr (VEC) e0 = pass * cap + tid * EPT;
     else e0 = pass * cap + tid;
-    const u32 used_n = (u32)(lb_e - lb_s), A_span = A_hi - A_lo;
+    const u32 used_n = (u32)(lb_e - lb_s);
     const int u0 = VEC ? a0 + e0 - lb_s : e0;
     int tl[EPT];
-    u32 av[EPT];
+    u32 rel[EPT];
     bool live[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u64 a64 = (u64)(tt[k] - t_first);
-      av[k] = (u32)a64;
+      const u32 r = (u32)a64 - A_lo;
       const bool used = (u32)(u0 + (VEC ? k : k * nthreads)) < used_n;
-      const bool in_tile = (u32)(a64 >> 32) == 0u && av[k] - A_lo < A_span;
+      const bool in_tile = (u32)(a64 >> 32) == 0u && r < A_span;
       bad = bad || (used && !in_tile);
       live[k] = used && in_tile;
-      tl[k] = 0;
+      rel[k] = live[k] ? r : 0u;
     }
-    for (int j0 = 1; j0 < ncols; j0 += 4) {
-      const uint4 A4 = *reinterpret_cast<const uint4*>(&s_thr[3 + j0]);
+    if (col_lin) {
 #pragma unroll
-      for (int k = 0; k < EPT; ++k)
-        tl[k] += (av[k] >= A4.x ? 1 : 0) + (av[k] >= A4.y ? 1 : 0) + (av[k] >= A4.z ? 1 : 0) + (av[k] >= A4.w ? 1 : 0);
+      for (int k = 0; k < EPT; ++k) {
+        const u32 e = col_est(rel[k]);
+        tl[k] = (int)e + (rel[k] + A_lo >= s_thr[3 + 1 + e] ? 1 : 0);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) tl[k] = 0;
+      for (int j0 = 1; j0 < ncols; j0 += 4) {
+        const uint4 A4 = *reinterpret_cast<const uint4*>(&s_thr[3 + j0]);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const u32 av = rel[k] + A_lo;
+          tl[k] += (av >= A4.x ? 1 : 0) + (av >= A4.y ? 1 : 0) + (av >= A4.z ? 1 : 0) + (av >= A4.w ? 1 : 0);
+        }
+      }
     }
     if (rp == 0 && pass == 0) XM_CSTAMP(3);  // events arrived, columns found
-    // A1: the rectify LUT from L2, eight gathers in flight.  x / y outside the camera = map[y, x] IndexError in the reference
-    // (calib:279-280): dropped and counted (once: by the tile whose own columns hold the event)
+    // A1: the rectify LUT from L2, all of the thread's gathers in flight.  x / y outside the camera = map[y, x] IndexError in the
+    // reference (calib:279-280): dropped and counted (once: by the tile whose own columns hold the event)
     u32 l[EPT];
     u32 oob_here = 0, in_here = 0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const u32 xk = (xw[k >> 1] >> ((k & 1) * 16)) & 0xffff, yk = (yw[k >> 1] >> ((k & 1) * 16)) & 0xffff;
+      const u32 xk = xy[k] & 0xffffu, yk = xy[k] >> 16;
       const bool inside = xk < (u32)tb.cam_w && yk < (u32)tb.cam_h;
-      oob_here += live[k] && !inside && tl[k] < Wc ? 1u : 0u;
+      oob_here += (u32)__popcll(__ballot(live[k] && !inside && tl[k] < Wc));
       live[k] = live[k] && inside;
       l[k] = XM_CABL(5) ? ((yk * 2u + 100u) << 16) | (xk + 50u) : lut[live[k] ? __umul24(xk, (u32)tb.cam_h) + yk : 0u];
     }
@@ -249,38 +295,53 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     int rr[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const int yr = (int)(short)(l[k] >> 16);
+      const int yr = (int)l[k] >> 16;
       rr[k] = yr - r_lo;
       live[k] = live[k] && (u32)rr[k] < (u32)tb.own_hr;  // 0 <= yr < H - 1 (xmd:23): own_hr rows from r_lo on, all of them valid
-      xm[k] = XM_CABL(5) ? (u32)(tb.x_offset + 300 + ((c0 + tl[k]) * 3 >> 2) + (yr >> 2)) : xmo[live[k] ? __umul24((u32)(c0 + tl[k]), (u32)tb.xmap_h) + (u32)yr : 0u];
+      xm[k] = XM_CABL(5) ? (u32)(tb.x_offset + 300 + ((c0 + tl[k]) * 3 >> 2) + (yr >> 2)) : xmo_tile[live[k] ? __umul24((u32)tl[k], (u32)tb.xmap_h) + (u32)yr : 0u];
     }
+    const u32 val_base = (u32)(e0 + 1) << 16;
+    // (two copies of the loop, one per kind of rig, instead of a branch per event: the kernel is bound by its own instruction issue)
+    const auto finish = [&](auto all_in_c) {
+      constexpr bool ALL_IN = decltype(all_in_c)::value;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int xr = (int)(short)(l[k] & 0xffff);
-      const int delta = (int)(xm[k] >> OWN_XP_BITS), fu = (int)(xm[k] & ((1u << OWN_XP_BITS) - 1u)) - tb.x_offset;
-      const int disp = fu - xr;          // (xm_create has checked the range: xmd:27's wrap never triggers)
-      bool write = live[k] && disp >= 0;  // xmd:29; an undefined X-map cell is packed as 0: fu = -x_offset < xr_min <= xr
-      int fc = fu;
-      if (!all_in) {
-        if (fc < 0) fc += tb.rect_w;  // NumPy's negative wrap
-        const bool in_frame = (u32)fc < (u32)tb.rect_w && rr[k] + r_lo < tb.rect_h;
-        oob_here += write && !in_frame && tl[k] < Wc ? 1u : 0u;
-        write = write && in_frame;
+      for (int k = 0; k < EPT; ++k) {
+        const int xr = (int)(short)(l[k] & 0xffff);
+        const int delta = (int)(xm[k] >> OWN_XP_BITS), fu = (int)(xm[k] & ((1u << OWN_XP_BITS) - 1u)) - tb.x_offset;
+        const int disp = fu - xr;          // (xm_create has checked the range: xmd:27's wrap never triggers)
+        bool write = live[k] && disp >= 0;  // xmd:29; an undefined X-map cell is packed as 0: fu = -x_offset < xr_min <= xr
+        int fc = fu;
+        if constexpr (!ALL_IN) {
+          if (fc < 0) fc += tb.rect_w;  // NumPy's negative wrap
+          const bool in_frame = (u32)fc < (u32)tb.rect_w && rr[k] + r_lo < tb.rect_h;
+          oob_here += (u32)__popcll(__ballot(write && !in_frame && tl[k] < Wc));
+          write = write && in_frame;
+        }
+        in_here += (u32)__popcll(__ballot(write && tl[k] < Wc));  // counted by the tile whose own columns hold the event
+        const int jo = tl[k] - delta;                             // the cell's owner column, relative to c0
+        write = write && (u32)jo < (u32)W;
+        // the cell's column inside its row's band: its frame column - the band's origin (both before the frame's shear: the
+        // table holds the origin, the flush adds the row's shear)
+        const int row = write ? rr[k] : 0;
+        const int sx = fc - (int)(short)(s_bm[row] & 0xffffu);
+        const u32 rpo = __umul24((u32)row, rp_inv) >> 20;  // the row's pass
+        const int idx = (int)((rpo << 24) | (u32)(__mul24(sx, RP) + row - (int)__umul24(rpo, (u32)RP)));
+        // a cell outside the band (an "extra"): marked with its owner pair, looked up below in the tiles that have any
+        const int extra = (int)(0x80000000u | ((u32)jo << 16) | (u32)row);
+        code[k] = write ? ((u32)sx < (u32)nxs ? idx : extra) : -1;
+        val[k] = (val_base + ((u32)(VEC ? k : k * nthreads) << 16)) | (u32)disp;
       }
-      in_here += write && tl[k] < Wc ? 1u : 0u;  // counted by the tile whose own columns hold the event
-      const int jo = tl[k] - delta;               // the cell's owner column, relative to c0
-      write = write && (u32)jo < (u32)W;
-      // the cell's column inside its row's band: its frame column (frame16_col) - the band's first
-      const int sx = fc + tb.shear_bias + ((((rr[k] + r_lo) >> 3) * tb.shear_m) >> 12) - (int)(s_bm[write ? rr[k] : 0] & 0xffffu);
-      const int rpo = (rr[k] >= RP ? 1 : 0) + (rr[k] >= 2 * RP ? 1 : 0) + (rr[k] >= 3 * RP ? 1 : 0);  // (OWN_MAX_ROW_PASSES = 4)
-      int idx = (rpo << 24) | (__mul24(sx, RP) + rr[k] - __mul24(rpo, RP));
-      if (n_extra > 0 && write && (u32)sx >= (u32)nxs) {  // (tile-uniform: most tiles have none) an extra: its slot index comes from the second table, at the cell's OWNER pair
-        const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)(c0 + jo), (u32)tb.xmap_h) + (u32)(rr[k] + r_lo)];
-        write = e != 0u;  // (always: xm_create lists every owner cell outside its band)
-        idx = n_band_max + (int)e - 1;
-      }
-      code[k] = write ? idx : -1;
-      val[k] = ((u32)(e0 + (VEC ? k : k * nthreads) + 1) << 16) | (u32)disp;
+    };
+    if (all_in) finish(std::true_type{});
+    else finish(std::false_type{});
+    if (n_extra > 0) {  // tile-uniform (ESL rig: the first and the last tile): the extras' slots come from the second table, at the cell's OWNER pair
+#pragma unroll
+      for (int k = 0; k < EPT; ++k)
+        if (code[k] < -1) {
+          const u32 jo = ((u32)code[k] >> 16) & 0x7fffu, row = (u32)code[k] & 0xffffu;
+          const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)c0 + jo, (u32)tb.xmap_h) + row + (u32)r_lo];
+          code[k] = e != 0u ? n_band_max + (int)e - 1 : -1;  // (always != 0: xm_create lists every owner cell outside its band)
+        }
     }
     if (rp == 0 && pass == 0) XM_CSTAMP(5);  // both gathers arrived, slots worked out
     if (rp == 0) {  // (a tile of several event passes looks its events up once per row pass: counted the first time)
@@ -306,7 +367,8 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       const int r_i = r_first + r_l;
       const u32 bm = s_bm[r_i];
       u32 m = bm >> 16;
-      XM_GLOBAL uint16_t* p = base + (__umul24(bm & 0xffffu, col_stride) + (u32)r_i);
+      const int col = (int)(short)(bm & 0xffffu) + tb.shear_bias + ((((r_i + r_lo) >> 3) * tb.shear_m) >> 12);  // (frame16_col)
+      XM_GLOBAL uint16_t* p = base + (__umul24((u32)col, col_stride) + (u32)r_i);
       u32* sl = slots + r_l;
       while (m) {  // eight band columns at a time: the LDS reads go out together, then the stores
         u32 v[8];
@@ -327,6 +389,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   }
   }
   XM_CSTAMP(7);  // every row pass flushed
+  if (XM_CABL(6) || XM_CABL(7)) bad = false;
   if (__ballot(bad) && lane == 0) {
     if (device_redo) {
       st->pad[1] = tag;
@@ -336,14 +399,9 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
       if (u32* hf = st->host_flags) host_flag_store(hf, tag);
     }
   }
-  {
-    u32 cnt2 = n_in | (n_oob << 16);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt2 += __shfl_xor(cnt2, o, 64);
-    if (lane == 0) {
-      if (cnt2 & 0xffffu) atomicAdd(&s_in, cnt2 & 0xffffu);
-      if (cnt2 >> 16) atomicAdd(&s_oob, cnt2 >> 16);
-    }
+  if (lane == 0) {
+    if (n_in) atomicAdd(&s_in, n_in);
+    if (n_oob) atomicAdd(&s_oob, n_oob);
   }
   __syncthreads();
 
@@ -360,7 +418,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
 }
 
 template <bool AOS, bool VEC, int EPT = COLS_EPT>
-__global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own(
+__global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : 1) void k_scatter_own(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts, const uint4* __restrict__ aos,
     u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int halo, int flags) {
   {  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
@@ -374,7 +432,7 @@ __global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own(
 }
 
 template <bool AOS, bool VEC, int EPT = COLS_EPT>
-__global__ __launch_bounds__(COLS_MAX_THREADS) void k_scatter_own_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W,
+__global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : 1) void k_scatter_own_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W,
                                                                         int halo, int flags) {
   const FrameDesc d = descs[blockIdx.y];
   if (!d.valid || d.n == 0) return;
