@@ -215,7 +215,9 @@ def test_eventcd_records_and_unaligned_columns():
 
 
 def test_a_non_injective_x_map_keeps_the_keyed_paths():
-    """Two time columns of a row that map to the same frame cell: xm_create must notice and leave the column tiles off."""
+    """Two time columns of a row that map to the same frame cell: xm_create must notice and leave the plain column tiles off --
+    the owner tiles take such a rig where their tables fit (since round 5's row passes through the LDS slots: this one), else
+    the keyed paths."""
     cfg = S.C_1M
     tb = S.make_tables(cfg)
     xm = tb["proj_x_map"].copy()
@@ -224,8 +226,13 @@ def test_a_non_injective_x_map_keeps_the_keyed_paths():
     evs = S.make_events(cfg, frame=9, n=600_000)
     with XMapsEngine(tb) as eng:
         assert _same(_run(eng, evs), _ref(tb, evs))
-        pc = eng.path_counts()  # neither compact path: the tile-ordered 32-bit keys need the same property
-        assert pc["cols"] == 0 and pc["key32"] == 0 and pc["sorted_key64"] == 1
+        pc = eng.path_counts()
+        mode = eng.cols_info()["mode"]
+        assert mode in ("own", "none"), mode
+        if mode == "own":
+            assert pc["cols"] == 1 and pc["key32"] == 0 and eng.sorted_fallbacks() == 0
+        else:  # neither compact path: the tile-ordered 32-bit keys need the same property
+            assert pc["cols"] == 0 and pc["key32"] == 0 and pc["sorted_key64"] == 1
 
 
 def test_switches(monkeypatch):

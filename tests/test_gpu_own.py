@@ -42,7 +42,7 @@ def test_shared_cell_rig_qualifies_and_matches_the_oracle():
     tb = S.make_tables_shared_cells(cfg)
     with XMapsEngine(tb) as eng:
         info = eng.cols_info()
-        assert info["mode"] == "own" and info["halo"] == 4 and info["shear_m"] != 0, info
+        assert info["mode"] == "own" and info["halo"] in (3, 4) and info["shear_m"] != 0, info  # (3.3 columns per cell)
         for f in range(4):
             evs = S.make_events(cfg, frame=f)
             assert _same(_run(eng, evs), _ref(tb, evs)), f
@@ -81,13 +81,13 @@ def test_unsheared_frame(monkeypatch):
 
 @pytest.mark.parametrize("cpc,slant", [(2.0, 0.35), (4.6, -0.7), (1.4, 0.0), (7.5, -0.2)])
 def test_other_rig_shapes(cpc, slant):
-    """1.4 .. 7.5 time columns per cell (halo 4 .. 8), slanted either way or not at all."""
+    """1.4 .. 7.5 time columns per cell (halo 1 .. 7), slanted either way or not at all."""
     cfg = S.C_SHARED
     tb = S.make_tables_shared_cells(cfg, cols_per_cell=cpc, slant=slant)
     with XMapsEngine(tb) as eng:
         info = eng.cols_info()
         assert info["mode"] == "own", info
-        assert info["halo"] == {2.0: 4, 4.6: 4, 1.4: 4, 7.5: 8}[cpc], info  # the largest column distance inside a cell, rounded up to K0b's boundary spacing (4)
+        assert info["halo"] in {2.0: (1, 2), 4.6: (4, 5), 1.4: (1, 2), 7.5: (7,)}[cpc], info  # = the largest column distance inside a cell
         for f in range(2):
             evs = S.make_events(cfg, frame=20 + f)
             assert _same(_run(eng, evs), _ref(tb, evs)), f
@@ -287,3 +287,20 @@ def test_random_shared_cell_rigs_and_streams(seed):
         for e, (d, b) in zip(frames, out):
             r = _ref(tb, e)
             assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), (seed, len(e))
+
+
+@pytest.mark.parametrize("passes", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [40_000, 700_000])
+def test_row_passes_through_the_lds_slots(passes, n):
+    """A tile's rows go through its LDS slots in 1..4 passes (round 5: a block's LDS is what limits the tiles a CU holds at once):
+    sparse frames keep their events and gathers in registers between the passes, frames of more events per tile than a block
+    holds (700 k events over 34 tiles of 8 columns: > 4096 each) look them up again for every row pass.  Same frames either way,
+    also after each other on one slot (the flush of a pass clears its slots for the next one)."""
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg)
+    xm_option("XM_OWN_ROW_PASSES", str(passes))
+    with XMapsEngine(tb, n_slots=1) as eng:
+        for f in range(3):
+            evs = S.make_events(cfg, frame=f, n=n)
+            assert _same(_run(eng, evs), _ref(tb, evs)), (passes, n, f)
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 3

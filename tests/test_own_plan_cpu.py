@@ -31,10 +31,10 @@ def _plan(tb):
     return dict(zip(keys, a))
 
 
-@pytest.mark.parametrize("cpc,slant,halo", [(3.3, -0.4, 4), (2.0, 0.35, 4), (4.6, -0.7, 4), (1.4, 0.0, 4), (7.5, -0.2, 8)])  # (halo: a multiple of K0b's boundary spacing, 4)
-def test_shared_cell_rigs_qualify(cpc, slant, halo):
+@pytest.mark.parametrize("cpc,slant", [(3.3, -0.4), (2.0, 0.35), (4.6, -0.7), (1.4, 0.0), (7.5, -0.2)])
+def test_shared_cell_rigs_qualify(cpc, slant):
     p = _plan(S.make_tables_shared_cells(S.C_SHARED, cols_per_cell=cpc, slant=slant))
-    assert p["mode"] == 2 and p["halo"] == halo and p["w"] == 8 and 1 <= p["nxs_max"] <= 16, p
+    assert p["mode"] == 2 and p["halo"] == p["delta_max"] and p["w"] == 8 and 1 <= p["nxs_max"] <= 16, p  # (halo = the largest column distance inside a cell)
     assert p["delta_max"] == int(np.ceil(cpc)) - 1 or p["delta_max"] == int(np.ceil(cpc)), p
     assert (p["shear_m"] == 0) == (slant == 0.0), p
     # the frame's shear undoes the slant: (rows / 8) groups x m / 4096 columns
@@ -44,18 +44,17 @@ def test_shared_cell_rigs_qualify(cpc, slant, halo):
 
 def test_too_many_columns_per_cell_or_too_wide_tiles_do_not_qualify():
     assert _plan(S.make_tables_shared_cells(S.C_SHARED, cols_per_cell=9.5))["mode"] == 0  # delta > 7
-    # 2.1 cells per time column over 1320 rows: thousands of a tile's cells lie outside any 16-column band (such rigs are
-    # injective and take the plain column tiles anyway)
+    # an injective X-map (2.1 cells per time column): the plain column tiles' business
     assert _plan(S.make_tables(S.C_1M))["mode"] == 0
 
 
 def test_esl_like_rig_qualifies():
     """The reference's calibration numbers through the (pinned) rectification: 1080 time columns on ~780 frame columns, slant
-    -0.40 columns per row: owner tiles of 8 columns + a halo of 4 (delta_max = 2, rounded up to K0b's boundary spacing), a band of <= 12 frame columns, extras in the first and the last tiles
+    -0.40 columns per row: owner tiles of 8 columns + a halo of delta_max = 2, a band of <= 12 frame columns, extras in the first and the last tiles
     (where the rectified time map replicates its border or leaves the frame)."""
     cp, tb, evs, _ = rig.make_esl_like(row_stride=13, x_map_fn=lambda tm, *a: O.compute_x_map_from_time_map(np.asarray(tm, np.float32), *a))
     p = _plan(tb)
-    assert p["mode"] == 2 and p["w"] == 8 and p["halo"] == 4 * ((p["delta_max"] + 3) // 4) and 1 <= p["delta_max"] <= 3, p
+    assert p["mode"] == 2 and p["w"] == 8 and p["halo"] == p["delta_max"] and 1 <= p["delta_max"] <= 3, p
     assert p["nxs_max"] <= 12 and p["extras"] < 4000 and p["extras_max_per_tile"] <= 2048, p
     assert p["lds_bytes"] <= 60 * 1024, p  # two tiles per CU at least
     assert p["shear_m"] > 0 and p["shear_extra"] > 100, p  # the X-map is strongly slanted

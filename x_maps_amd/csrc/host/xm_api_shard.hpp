@@ -197,7 +197,7 @@ int xm_shard_cols_scatter(xm_handle* h, uint16_t* x, uint16_t* y, int64_t* t, si
                      (u64)send_bytes, rank, world, h->tb, (u64)cap_events, mm, frame16, h->aux_st, desc);
   const int flags = h->cols_flags | COLS_F_EXT_EXTREMA;
   hipLaunchKernelGGL(k_cols_bounds_batch<false>, dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, COLS_BOUNDS_PER_BLOCK), 1), dim3(256), 0, s,
-                     (const FrameDesc*)desc, h->tb, W, flags);
+                     (const FrameDesc*)desc, h->tb, W, flags, 0);
   auto kern = k_scatter_cols_batch<false, true>;  // (the piece starts 8-aligned: 16-byte event loads)
   const size_t lds = cols_lds_bytes(h, W);
   int rc;

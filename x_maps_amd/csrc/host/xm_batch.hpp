@@ -20,7 +20,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   if constexpr (std::is_same<T, long long>::value && !HAS_P) {
     if (cols_w) {  // column tiles: K1 grid = (tiles, frames), K2 on the plain u16 frames
       int rc;
-      if (h->own_mode) {  // owner tiles (the rig's X-map is not injective): boundaries every OWN_BW columns, tiles of own_w + halo
+      if (h->own_mode) {  // owner tiles (the rig's X-map is not injective): two boundaries per tile (its first column, the end of its halo), tiles of own_w + halo
         const int ept = own_ept(h, n_mean, cols_w, !AOS && vec16);
         auto kern = ept == 4 ? k_scatter_own_batch<AOS, false, 4> : k_scatter_own_batch<AOS, false>;
         if constexpr (!AOS) {
@@ -30,8 +30,8 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc) return rc;
         prof_slot(0);
-        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, OWN_BW) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
-                  dim3(256), 0, stream, d_descs, h->tb, OWN_BW, 0);
+        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(2 * grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
+                  dim3(256), 0, stream, d_descs, h->tb, cols_w, 0, h->own_halo);
         prof_slot(1);
         XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w, ept)), lds, stream, d_descs, h->tb,
                   cols_w, h->own_halo, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
@@ -45,7 +45,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       if (rc) return rc;
       prof_slot(0);
       XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
-                dim3(256), 0, stream, d_descs, h->tb, cols_w, 0);
+                dim3(256), 0, stream, d_descs, h->tb, cols_w, 0, 0);
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));

@@ -18,12 +18,12 @@ int cols_width(const xm_handle* h, u64 n) {
   return W;
 }
 
-// owner tiles: events per thread -- four where 512 threads then hold a tile's own + halo columns in one pass (twice the waves at
-// half the registers: xmaps_k1own.hpp), else eight.  Not for 16-byte SoA loads (eight events each)
+// owner tiles: events per thread -- eight; four (twice the waves at half the registers for the same tile: xmaps_k1own.hpp) measured
+// the same within the noise (profiles/r05_own_tiles.md) and is kept as an experiment switch ("XM_OWN_EPT" = 4; not for 16-byte SoA loads)
 int own_ept(const xm_handle* h, u64 n, int W, bool vec16) {
-  if (vec16 || h->own_ept_forced == 8) return 8;
+  if (vec16 || h->own_ept_forced != 4) return 8;
   const double per = (double)n / (double)h->tb.xmap_w * (W + h->own_halo);
-  return h->own_ept_forced == 4 || per * 1.12 <= 4.0 * COLS_MAX_THREADS ? 4 : 8;
+  return per * 1.12 <= 4.0 * COLS_MAX_THREADS ? 4 : 8;
 }
 
 unsigned cols_threads(const xm_handle* h, u64 n, int W, int ept = COLS_EPT) {
@@ -44,14 +44,14 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W, int ept = COLS_EPT) {
 
 // K0b: the tile boundaries + column thresholds of the frame (half a wave per boundary), left behind the slot's u16 frame
 void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
-  if (h->own_mode) W = OWN_BW;  // owner tiles: boundaries every OWN_BW columns (tile = own_w columns + a halo behind them)
-  const unsigned nb = grid_for(h->tb.xmap_w, W);
+  const int split = h->own_mode ? h->own_halo : 0;  // owner tiles: two boundaries per tile (tile = own_w columns + a halo behind them)
+  const unsigned nb = (split ? 2u : 1u) * grid_for(h->tb.xmap_w, W);
   if (ev.aos)
     XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
-              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16);
+              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
   else
     XM_LAUNCH(k_cols_bounds<false>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
-              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16);
+              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
 }
 
 int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint16_t* frame16, int W, hipStream_t stream) {

@@ -199,7 +199,7 @@ struct xm_handle {
   uint16_t* d_xmap_extra = nullptr;
   int4* d_own_tiles = nullptr;
   u32* d_own_bm = nullptr;
-  int own_ept_forced = 0;  // "XM_OWN_EPT" (experiments): 4 or 8 events per thread whatever the frame's size
+  int own_ept_forced = 0;  // "XM_OWN_EPT" (experiments): 4 = four events per thread where a tile then fits one pass
   u32* d_own_extra_cells = nullptr;
   int own_extras = 0;  // owner cells outside their tile's band, over all tiles
   // XM_FLAG_ADAPTIVE_BATCH: asynchronous device-pointer frames are submitted as GROUPS (multi-frame launches) whenever the GPU

@@ -30,7 +30,7 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   const int hr = r_hi - r_lo + 1, hrp = (hr + 7) & ~7;
   int W = 8;
   if (const char* e = dbg_opt("XM_OWN_W")) W = atoi(e);
-  W = std::max(OWN_BW, std::min(W, 64)) / OWN_BW * OWN_BW;
+  W = std::max(OWN_BW, std::min(W, 32)) / OWN_BW * OWN_BW;  // (K0b: half a wave per boundary computes the thresholds up to the next one)
   // 1. owner column of every cell, row by row: delta = column - first column of the row that maps to the same cell
   std::vector<uint16_t>& packed = pl.packed;  // [c][row], as tb.xmap
   packed.assign((size_t)xmap_w * xmap_h, 0);
@@ -61,7 +61,9 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
     for (int c = 0; c < xmap_w; ++c)
       if (fcs[c] >= 0) first[fcs[c]] = -1;
   }
-  const int halo = (delta_max + OWN_BW - 1) / OWN_BW * OWN_BW;
+  if (delta_max == 0) return;  // an injective X-map: the plain column tiles' business
+  const int halo = delta_max;  // (a tile reads its own columns and `halo` behind them: K0b finds that boundary too)
+  if (halo >= W) return;
   // 2. the shear: slope of the cell column against the row along the middle time columns (least squares over the live entries)
   double slope = 0.0;
   {

@@ -219,14 +219,16 @@ __host__ __device__ inline size_t cols_frame_bytes(size_t key_cells, int xmap_w)
 template <bool AOS>
 __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos, const int n, const DevTables& tb, const int W,
                                                  XM_GLOBAL unsigned char* frame_base, const u32 blk, gp_i64 ext_mm = nullptr,
-                                                 const int first = 0) {  // first: events [0, first) are filler (shards: alignment)
+                                                 const int first = 0,  // first: events [0, first) are filler (shards: alignment)
+                                                 const int split = 0) {  // owner tiles: boundaries at t W and t W + split (a tile's
+                                                                         // own columns and its halo's end), not every W columns
   typedef long long T;
   const size_t key_cells = frame16_cells(tb);
   XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
   XM_GLOBAL u32* thr = (XM_GLOBAL u32*)(frame_base + cols_thr_offset(key_cells, tb.xmap_w));
   constexpr int G = COLS_BOUNDS_LANES, FIN = COLS_BOUNDS_FIN;
   const int lane = threadIdx.x & 63, sl = lane & (G - 1), gl = lane & ~(G - 1);
-  const int nb = (tb.xmap_w + W - 1) / W;
+  const int nb = split ? 2 * ((tb.xmap_w + W - 1) / W) : (tb.xmap_w + W - 1) / W;
   const int j_raw = (int)blk * COLS_BOUNDS_PER_BLOCK + (int)threadIdx.x / G;
   const bool live = j_raw <= nb;  // (a group past the last boundary runs along with its wave and stores nothing)
   if (!__any(live)) return;       // wave-uniform
@@ -247,7 +249,8 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   // event of column c near n (c - 1/2) / S (the threshold itself is (c - 1/2) span / S rounded), so where to probe does not
   // depend on anything loaded.  A wave of this kernel is a chain of dependent round trips at loaded-memory latency (its
   // arithmetic hides behind them): stamps -> probes -> probes -> x was four of them, now it is two.
-  const int c = min(j * W, tb.xmap_w);
+  const int c = min(split ? (j >> 1) * W + (j & 1) * split : j * W, tb.xmap_w);
+  const int wj = split ? ((j & 1) ? W - split : split) : W;  // the columns in front of the next boundary (<= G: own_plan)
   const bool search = live && c > 0 && c < tb.xmap_w && n > 0;  // else: boundary 0 is event 0, the last tile takes whatever is left
   int q[FIN];
   bool act[FIN], pr[FIN];
@@ -273,7 +276,7 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   const TimeNorm<T> tn(t_first, t_last, tb.t_px_scale);
   // thresholds of this boundary's column and of the interior columns behind it (lane l of the group: column j W + l)
   u32 A = 0;
-  if (live && sl < W && c + sl <= tb.xmap_w && (sl == 0 || j < nb)) {
+  if (live && sl < wj && c + sl <= tb.xmap_w && (sl == 0 || j < nb)) {
     A = cols_threshold(tn, t_first, span, c + sl, tb.t_px_scale);
     thr[c + sl] = A;
   }
@@ -336,17 +339,19 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
 template <bool AOS>
 __global__ __launch_bounds__(256) void k_cols_bounds(const uint16_t* __restrict__ xs, const long long* __restrict__ ts,
                                                                         const uint4* __restrict__ aos, u32 n, DevTables tb, int W,
-                                                                        uint16_t* __restrict__ frame16) {
-  cols_bounds_body<AOS>((gp_u16)xs, (gp_i64)ts, (gp_u4)aos, (int)n, tb, W, (XM_GLOBAL unsigned char*)frame16, blockIdx.x);
+                                                                        uint16_t* __restrict__ frame16, int split = 0) {
+  cols_bounds_body<AOS>((gp_u16)xs, (gp_i64)ts, (gp_u4)aos, (int)n, tb, W, (XM_GLOBAL unsigned char*)frame16, blockIdx.x, nullptr, 0,
+                        split);
 }
 
 template <bool AOS>
-__global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W, int flags = 0) {
+__global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W, int flags = 0,
+                                                           int split = 0) {
   const FrameDesc d = descs[blockIdx.y];
   const bool ext = flags & COLS_F_EXT_EXTREMA;
   if (!d.valid || (d.n == 0 && !ext)) return;
   cols_bounds_body<AOS>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x,
-                        ext ? (gp_i64)d.p : nullptr, ext ? (int)d.pad : 0);
+                        ext ? (gp_i64)d.p : nullptr, ext ? (int)d.pad : 0, split);
 }
 
 // ---- the kernel body ---------------------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@
 
 namespace xm {
 
-constexpr int OWN_BW = 4;         // K0b's boundary spacing for this path (tile widths and halos are multiples of it; 2 until round 5: half the boundaries, K0b 33.8 -> see profiles/r05_kernel_trace.md)
+constexpr int OWN_BW = 4;         // tile widths are multiples of it (K0b finds two boundaries per tile: its first column and the end of its halo)
 constexpr int OWN_MAX_DELTA = 7;  // 3 bits in the packed X-map
 constexpr int OWN_XP_BITS = 13;   // xp < 8192
 constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile (the ownership masks are u16)
@@ -80,7 +80,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const int c_end = min(c0 + W + halo, tb.xmap_w);
   const int ncols = c_end - c0;  // own + halo columns
   // ---- 1. what locates the tile, in one round trip of uniform loads
-  const int4 b_lo = bounds[c0 / OWN_BW], b_hi = bounds[(c_end + OWN_BW - 1) / OWN_BW];
+  const int4 b_lo = bounds[2u * tile], b_hi = bounds[min(2u * tile + 3u, 2u * nblk)];  // (k_cols_bounds with split = halo: boundary 2 t at t W, 2 t + 1 at t W + halo)
   const u32 A_lo = thr[c0], A_hi = thr[c_end];
   const int4 trec = ((const XM_GLOBAL int4*)tb.own_tiles)[tile];  // {band columns, first extra, extras, -}
   // the tile's band positions and ownership masks: 16-byte loads issued with the locating loads, parked in registers until
