@@ -184,6 +184,10 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
       h->k2_pipe = e[0] != '0';
       h->k2_pipe_force = e[0] == '2';
     }
+    if (const char* e = dbg_opt("XM_K2_CHAIN")) h->k2_chain = e[0] != '0';
+    if (const char* e = dbg_opt("XM_K2_PER_CU")) {
+      h->k2_per_cu_max = std::max(1, atoi(e));
+    }
     if (const char* e = dbg_opt("XM_K2_CONSEC")) h->k2_consec = e[0] != '0' ? 1 : 0;  // experiments / tests: the strided pixel assignment
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
@@ -447,6 +451,8 @@ void xm_destroy(xm_handle* h) {
   if (h->d_own_tiles) (void)hipFree(h->d_own_tiles);
   if (h->d_xmap_extra) (void)hipFree(h->d_xmap_extra);
   if (h->d_own_bm) (void)hipFree(h->d_own_bm);
+  for (hipEvent_t e : h->k2_chain_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->d_own_extra_cells) (void)hipFree(h->d_own_extra_cells);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);

@@ -160,6 +160,13 @@ struct xm_handle {
   // pipelined K2 of the group launches (xmaps_k2pipe.hpp): table entries kept in LDS, CUs of the device, switch (XM_K2_PIPE=0: off)
   int k2_pipe_nlds = 0, n_cus = 256;
   uint64_t k2_pipe_frames = 0;  // frames finished by the pipelined K2 since xm_create (xm_debug_k2_pipe_frames)
+  int k2_per_cu_max = 8;        // "XM_K2_PER_CU": the pipelined K2's blocks per CU at most (what it leaves, the next group's K1 can take)
+  // "XM_K2_CHAIN": the pipelined K2 launches of different groups (different streams) wait for each other -- one K2 at a time, at
+  // k2_per_cu_max blocks per CU, and the following groups' boundary pass and K1 in what it leaves (profiles/r05_own_tiles.md)
+  bool k2_chain = false;
+  std::mutex k2_chain_mu;
+  hipEvent_t k2_chain_ev[16] = {};
+  unsigned k2_chain_n = 0;
   bool k2_pipe_force = false;   // XM_K2_PIPE=2 (tests): also for groups too small for the pipeline to matter
   bool k2_pipe = true, k2_pipe_rig_ok = false;  // (rig_ok: every tile's patch fits the pipelined loader, rect_h % 8 == 0)
   ulonglong2* d_zero16 = nullptr;  // 16 zero bytes: what K2 reads instead of a clean key-frame line

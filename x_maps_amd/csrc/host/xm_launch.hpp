@@ -189,7 +189,7 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
   const u32 gx = grid_for(h->tb.proj_w, K2_TX * ppt), gy = grid_for(h->tb.proj_h, K2_TY);
   const u64 total = (u64)gx * gy * (u64)n_frames;
   const size_t lds = k2_pipe_lds_bytes(h, g);
-  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 2048)));
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)h->k2_per_cu_max, (160 * 1024) / (lds + 2048)));
   unsigned blocks = (unsigned)h->n_cus * per_cu / 8 * 8;
   if (total < 3ull * blocks && !h->k2_pipe_force) return false;  // too few items per block for the pipeline to matter: one block per tile
   blocks = (unsigned)std::min<u64>(blocks, std::max<u64>(total, 1));
@@ -206,6 +206,11 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
   XM_LAUNCH((k_frame_proj_pipe<P, C, COND>), dim3(blocks), dim3(K2_TX * K2_TY), lds, stream, d_descs, (const int4*)h->d_k2_tiles[g],      \
             (const u32*)h->d_k2_pix[g], (const uint16_t*)h->d_k2_pix16[g], h->k2_pix_stride, h->tb.dlut, pa, h->k2_tile_cap[g],      \
             (u32)n_frames, gx, gy, h->k2_pipe_nlds, gx_magic)
+  std::unique_lock<std::mutex> chain_lock(h->k2_chain_mu, std::defer_lock);
+  if (h->k2_chain && COND == 0) {  // one K2 at a time: wait for the one launched last (whatever its stream)
+    chain_lock.lock();
+    if (h->k2_chain_n) (void)hipStreamWaitEvent(stream, h->k2_chain_ev[(h->k2_chain_n - 1) % 16], 0);
+  }
   if (g == 2) {
     if (cs) XM_K2P_LAUNCH(4, true);
     else XM_K2P_LAUNCH(4, false);
@@ -214,6 +219,11 @@ bool launch_k2_pipe(xm_handle* h, hipStream_t stream, const FrameDesc* d_descs, 
     else XM_K2P_LAUNCH(2, false);
   }
 #undef XM_K2P_LAUNCH
+  if (chain_lock.owns_lock()) {
+    hipEvent_t& ev = h->k2_chain_ev[h->k2_chain_n % 16];
+    if (!ev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (ev && hipEventRecord(ev, stream) == hipSuccess) h->k2_chain_n += 1;
+  }
   h->k2_pipe_frames += (uint64_t)n_frames;
   return true;
 }
