@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: the randomized differential tests (tests/test_gpu_fuzz.py, tests/test_gpu_cols.py, tests/test_gpu_own.py) over many more seeds than the
-suite runs:  python tools/fuzz_soak.py [first_seed=120] [n_seeds=1000]"""
+suite runs:  python tools/fuzz_soak.py [first_seed=120] [n_seeds=1000] [XM_OPTION=value ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,8 @@ import test_gpu_own as W
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 from x_maps_amd import _native as _N; _N.debug_option("XM_COLS", "2")
+for kv in sys.argv[3:]:  # library variant switches (e.g. XM_OWN_ROW_PASSES=3)
+    _N.debug_option(*kv.split("=", 1))
 t0 = time.time()
 bad, skipped = [], 0
 for seed in range(first, first + n):
