@@ -17,9 +17,13 @@ from x_maps_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _tiles_for_single_frames_too(monkeypatch):
+@pytest.fixture(autouse=True, params=["rows", "groups"])
+def _tiles_for_single_frames_too(request):
     xm_option("XM_COLS", "2")  # single-frame calls take the tiles as well (default: groups only)
+    # ownership of a cell per row (2-byte flush, small halo) / per 8-row group where the rig allows it (16-byte flush; the default)
+    if request.param == "rows":
+        xm_option("XM_OWN_GROUPED", "0")
+    return request.param
 
 
 def _ref(tb, evs, **kw):
@@ -42,7 +46,7 @@ def test_shared_cell_rig_qualifies_and_matches_the_oracle():
     tb = S.make_tables_shared_cells(cfg)
     with XMapsEngine(tb) as eng:
         info = eng.cols_info()
-        assert info["mode"] == "own" and info["halo"] in (3, 4) and info["shear_m"] != 0, info  # (3.3 columns per cell)
+        assert info["mode"] == "own" and 3 <= info["halo"] <= 7 and info["shear_m"] != 0, info  # (3.3 columns per cell; more with ownership per 8-row group)
         for f in range(4):
             evs = S.make_events(cfg, frame=f)
             assert _same(_run(eng, evs), _ref(tb, evs)), f
@@ -87,7 +91,7 @@ def test_other_rig_shapes(cpc, slant):
     with XMapsEngine(tb) as eng:
         info = eng.cols_info()
         assert info["mode"] == "own", info
-        assert info["halo"] in {2.0: (1, 2), 4.6: (4, 5), 1.4: (1, 2), 7.5: (7,)}[cpc], info  # = the largest column distance inside a cell
+        assert {2.0: 1, 4.6: 4, 1.4: 1, 7.5: 7}[cpc] <= info["halo"] <= 7, info  # >= the largest column distance inside a cell of a row
         for f in range(2):
             evs = S.make_events(cfg, frame=20 + f)
             assert _same(_run(eng, evs), _ref(tb, evs)), f
@@ -223,7 +227,7 @@ def test_esl_like_rig_real_calibration_geometry():
     frames = [evs0] + [rig.render_events(cp, tb, row_stride=13, seed=s, t0_us=7_000_000 + 16_600 * s)[0] for s in (1, 2, 3)]
     with XMapsEngine(tb, n_slots=4) as eng:
         info = eng.cols_info()
-        assert info["mode"] == "own" and info["halo"] in (2, 4) and info["nxs_max"] <= 12 and info["extras"] > 0, info
+        assert info["mode"] == "own" and info["halo"] in (2, 7) and info["nxs_max"] <= 24 and info["extras"] > 0, info  # (per row / per 8-row group, wide tiles)
         for f, evs in enumerate(frames[:2]):  # frame by frame
             d, b, st = eng.process_events(evs)
             r = _ref(tb, evs)
@@ -304,3 +308,22 @@ def test_row_passes_through_the_lds_slots(passes, n):
             evs = S.make_events(cfg, frame=f, n=n)
             assert _same(_run(eng, evs), _ref(tb, evs)), (passes, n, f)
         assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 3
+
+
+def test_two_plans_on_one_slot(_tiles_for_single_frames_too):
+    """A rig whose slant allows ownership per 8-row group gets two plans: wide tiles (16-byte flush; the halo grows by the slant over
+    8 rows) for frames whose tiles fit one event pass of a block, and the per-row plan's 8-column tiles for denser frames.  Both
+    rewrite every cell a pair maps to, so sparse and dense frames may follow each other on one slot: every frame == oracle."""
+    cfg = S.C_SHARED
+    tb = S.make_tables_shared_cells(cfg, cols_per_cell=1.4, slant=0.0)
+    with XMapsEngine(tb, n_slots=1) as eng:
+        info = eng.cols_info()
+        assert info["mode"] == "own", info
+        if _tiles_for_single_frames_too == "groups":
+            assert info["w"] > 8 and info["dense_w"] == 8 and info["dense_halo"] <= info["halo"], info
+        else:
+            assert info["w"] == 8 and info["dense_w"] == 0, info
+        for f, n in enumerate([40_000, 400_000, 30_000, 600_000, 45_000, 45_000, 500_000]):
+            evs = S.make_events(cfg, frame=f, n=n)
+            assert _same(_run(eng, evs), _ref(tb, evs)), (f, n)
+        assert eng.sorted_fallbacks() == 0 and eng.path_counts()["cols"] == 7

@@ -447,13 +447,15 @@ void xm_destroy(xm_handle* h) {
   if (h->d_states) (void)hipFree(h->d_states);
   if (h->d_lut) (void)hipFree(h->d_lut);
   if (h->d_xmap) (void)hipFree(h->d_xmap);
-  if (h->d_xmap_own) (void)hipFree(h->d_xmap_own);
-  if (h->d_own_tiles) (void)hipFree(h->d_own_tiles);
-  if (h->d_xmap_extra) (void)hipFree(h->d_xmap_extra);
-  if (h->d_own_bm) (void)hipFree(h->d_own_bm);
+  for (xm_handle::OwnSet& os : h->own) {
+    if (os.d_xmap_own) (void)hipFree(os.d_xmap_own);
+    if (os.d_tiles) (void)hipFree(os.d_tiles);
+    if (os.d_xmap_extra) (void)hipFree(os.d_xmap_extra);
+    if (os.d_bm) (void)hipFree(os.d_bm);
+    if (os.d_extra_cells) (void)hipFree(os.d_extra_cells);
+  }
   for (hipEvent_t e : h->k2_chain_ev)
     if (e) (void)hipEventDestroy(e);
-  if (h->d_own_extra_cells) (void)hipFree(h->d_own_extra_cells);
   if (h->d_pmap) (void)hipFree(h->d_pmap);
   if (h->d_dlut) (void)hipFree(h->d_dlut);
   for (int g = 0; g < 3; ++g) {
@@ -476,15 +478,18 @@ int xm_cols_info(xm_handle* h, int32_t info[12]) {
   for (int i = 0; i < 12; ++i) info[i] = 0;
   info[0] = !h->cols_ok ? 0 : h->own_mode ? 2 : 1;
   if (h->cols_ok && h->own_mode) {
-    info[1] = h->own_w;
-    info[2] = h->own_halo;
-    info[3] = h->tb.own_nxs_max;
+    const xm_handle::OwnSet& os = h->own[0];  // (the plan frames take by default; [10], [11]: width and halo of the one for denser frames)
+    info[1] = os.w;
+    info[2] = os.halo;
+    info[3] = os.nxs_max;
     info[4] = h->tb.shear_m;
     info[5] = h->tb.shear_extra;
-    info[6] = h->tb.own_r_lo;
-    info[7] = h->tb.own_hr;
-    info[8] = h->own_extras;
-    info[9] = h->tb.own_extra_max;
+    info[6] = os.r_lo;
+    info[7] = os.hr;
+    info[8] = os.extras;
+    info[9] = os.extra_max;
+    info[10] = h->own[1].ok ? h->own[1].w : 0;
+    info[11] = h->own[1].ok ? h->own[1].halo : 0;
   }
   return XM_OK;
 }
@@ -499,12 +504,13 @@ int xm_own_plan_info(const xm_config* cfg, int32_t info[12]) {
   const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
   int xr_min = 32767;
   for (size_t i = 0; i < (size_t)cfg->cam_width * cfg->cam_height; ++i) xr_min = std::min<int>(xr_min, cfg->cam_mapx_i16[i]);
-  OwnPlan pl;
-  own_plan(cfg, xmap_h, xr_min, pl);
+  OwnPlan pls[2];
+  own_plans(cfg, xmap_h, xr_min, pls);
+  const OwnPlan& pl = pls[0];  // (the plan frames take by default)
   if (!pl.ok) return XM_OK;
   info[0] = 2; info[1] = pl.W; info[2] = pl.halo; info[3] = pl.nxs_max; info[4] = pl.m; info[5] = pl.extra_cols; info[6] = pl.r_lo;
   info[7] = pl.hr; info[8] = (int)pl.extra_flat.size() - 1; info[9] = pl.extra_max; info[10] = pl.delta_max;
-  info[11] = (int)own_plan_lds_bytes(pl.nxs_max, pl.rp, pl.hrp, pl.extra_max);
+  info[11] = (int)own_plan_lds_bytes(pl.nxs_max, pl.rp, pl.hrp, pl.extra_max, pl.grouped);
   return XM_OK;
 }
 

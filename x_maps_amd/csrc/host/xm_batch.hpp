@@ -26,15 +26,18 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         if constexpr (!AOS) {
           if (vec16) kern = k_scatter_own_batch<false, true>;
         }
-        const size_t lds = own_lds_bytes(h);
+        const xm_handle::OwnSet& os = own_set(h, cols_w);
+        DevTables tbo = h->tb;
+        own_apply(os, tbo);
+        const size_t lds = own_lds_bytes(os);
         rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc) return rc;
         prof_slot(0);
         XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(2 * grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
-                  dim3(256), 0, stream, d_descs, h->tb, cols_w, 0, h->own_halo);
+                  dim3(256), 0, stream, d_descs, tbo, cols_w, 0, os.halo);
         prof_slot(1);
-        XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w, ept)), lds, stream, d_descs, h->tb,
-                  cols_w, h->own_halo, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
+        XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w, ept)), lds, stream, d_descs, tbo,
+                  cols_w, os.halo, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));
       } else {
       auto kern = k_scatter_cols_batch<AOS, false>;
       if constexpr (!AOS) {

@@ -6,9 +6,15 @@ namespace {
 
 // time columns per tile for frames of n events: about cols_target events per tile, within the LDS budget; 0 = not this path
 int cols_width(const xm_handle* h, u64 n) {
-  if (h->cols_ok && h->own_mode) {  // owner tiles: one fixed width (the ownership tables are built for it); not for nearly empty frames
-    const u64 tiles = grid_for(h->tb.xmap_w, h->own_w);
-    return n >= tiles * 128 && n < (1ull << 28) ? h->own_w : 0;
+  if (h->cols_ok && h->own_mode) {  // owner tiles: the widths the ownership tables are built for; not for nearly empty frames
+    // the default plan (wide tiles) while a tile's own + halo columns fit ONE event pass of a block (8 events x 512 threads: past
+    // that a tile looks its events up again for every row pass); denser frames take the second plan's narrow tiles
+    const xm_handle::OwnSet& a = h->own[0];
+    const xm_handle::OwnSet& b = h->own[1];
+    const double per_col = (double)n / (double)h->tb.xmap_w;
+    const xm_handle::OwnSet& os = b.ok && per_col * (a.w + a.halo) > (double)(COLS_EPT * COLS_MAX_THREADS) ? b : a;  // (the mean tile: measured on the ESL-like frames at 94 % of a block's events, the fuller tiles' second pass included)
+    const u64 tiles = grid_for(h->tb.xmap_w, os.w);
+    return n >= tiles * 128 && n < (1ull << 28) ? os.w : 0;
   }
   if (!h->cols_ok || h->cols_w_max < 1 || h->tb.xmap_w < 1 || n == 0 || n >= (1ull << 28)) return 0;
   const double per_col = (double)n / (double)h->tb.xmap_w;
@@ -20,15 +26,18 @@ int cols_width(const xm_handle* h, u64 n) {
 
 // owner tiles: events per thread -- eight; four (twice the waves at half the registers for the same tile: xmaps_k1own.hpp) measured
 // the same within the noise (profiles/r05_own_tiles.md) and is kept as an experiment switch ("XM_OWN_EPT" = 4; not for 16-byte SoA loads)
+// the plan whose tiles are W columns wide (cols_width picked it)
+const xm_handle::OwnSet& own_set(const xm_handle* h, int W) { return h->own[1].ok && h->own[1].w == W ? h->own[1] : h->own[0]; }
+
 int own_ept(const xm_handle* h, u64 n, int W, bool vec16) {
   if (vec16 || h->own_ept_forced != 4) return 8;
-  const double per = (double)n / (double)h->tb.xmap_w * (W + h->own_halo);
+  const double per = (double)n / (double)h->tb.xmap_w * (W + own_set(h, W).halo);
   return per * 1.12 <= 4.0 * COLS_MAX_THREADS ? 4 : 8;
 }
 
 unsigned cols_threads(const xm_handle* h, u64 n, int W, int ept = COLS_EPT) {
   if (h->own_mode) {  // own + halo columns in one pass where 512 threads hold them
-    const double per = (double)n / (double)h->tb.xmap_w * (W + h->own_halo);
+    const double per = (double)n / (double)h->tb.xmap_w * (W + own_set(h, W).halo);
     const unsigned t = ((unsigned)(per * 1.12 / ept) + 63u) / 64u * 64u;
     return std::max(128u, std::min(t, (unsigned)COLS_MAX_THREADS));
   }
@@ -44,7 +53,7 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W, int ept = COLS_EPT) {
 
 // K0b: the tile boundaries + column thresholds of the frame (half a wave per boundary), left behind the slot's u16 frame
 void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
-  const int split = h->own_mode ? h->own_halo : 0;  // owner tiles: two boundaries per tile (tile = own_w columns + a halo behind them)
+  const int split = h->own_mode ? own_set(h, W).halo : 0;  // owner tiles: two boundaries per tile (tile = W columns + a halo behind them)
   const unsigned nb = (split ? 2u : 1u) * grid_for(h->tb.xmap_w, W);
   if (ev.aos)
     XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
@@ -62,11 +71,14 @@ int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint1
     if (ev.aos) kern = ept == 4 ? k_scatter_own<true, false, 4> : k_scatter_own<true, false>;
     else if (vec16) kern = k_scatter_own<false, true>;
     else if (ept == 4) kern = k_scatter_own<false, false, 4>;
-    const size_t lds = own_lds_bytes(h);
+    const xm_handle::OwnSet& os = own_set(h, W);
+    DevTables tbo = h->tb;
+    own_apply(os, tbo);
+    const size_t lds = own_lds_bytes(os);
     int rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc) return rc;
     XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, W)), dim3(cols_threads(h, ev.n, W, ept)), lds, stream, ev.x, ev.y, (const long long*)ev.t,
-              (const uint4*)ev.aos, (u32)ev.n, h->tb, st, frame16, W, h->own_halo, h->cols_flags);
+              (const uint4*)ev.aos, (u32)ev.n, tbo, st, frame16, W, os.halo, h->cols_flags);
     return XM_OK;
   }
   auto kern = k_scatter_cols<false, false>;

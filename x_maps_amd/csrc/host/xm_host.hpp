@@ -201,14 +201,20 @@ struct xm_handle {
   // owner tiles (xmaps_k1own.hpp): the rig's (row, column) -> cell map is not injective (the reference's own calibration), but
   // every cell's columns lie within own_halo columns of its first one: cols_ok with own_mode set; fixed tile width own_w
   bool own_mode = false;
-  int own_w = 0, own_halo = 0;
-  uint16_t* d_xmap_own = nullptr;
-  uint16_t* d_xmap_extra = nullptr;
-  int4* d_own_tiles = nullptr;
-  u32* d_own_bm = nullptr;
+  // up to two plans (own_setup): [0] ownership per 8-row group, wide tiles -- frames whose tiles fit one event pass of a block;
+  // [1] ownership per row, tiles of 8 columns -- denser frames, and rigs whose slant rules [0] out (then it is [0]).  Both write
+  // the same frame (every cell a pair maps to, every frame), so consecutive frames of a slot may take different plans.
+  struct OwnSet {
+    bool ok = false, all_in = false;
+    int w = 0, halo = 0, extras = 0;
+    int r_lo = 0, hr = 0, hrp = 0, rp = 0, grouped = 0, nxs_max = 0, extra_max = 0;
+    uint16_t* d_xmap_own = nullptr;
+    uint16_t* d_xmap_extra = nullptr;
+    int4* d_tiles = nullptr;
+    u32* d_bm = nullptr;
+    u32* d_extra_cells = nullptr;
+  } own[2];
   int own_ept_forced = 0;  // "XM_OWN_EPT" (experiments): 4 = four events per thread where a tile then fits one pass
-  u32* d_own_extra_cells = nullptr;
-  int own_extras = 0;  // owner cells outside their tile's band, over all tiles
   // XM_FLAG_ADAPTIVE_BATCH: asynchronous device-pointer frames are submitted as GROUPS (multi-frame launches) whenever the GPU
   // is still busy with earlier ones: a frame is launched at once when no group is in flight (an idle GPU -- the 60 Hz live
   // case -- never waits), otherwise it joins the pending list, which goes out as one group with the first call that finds the

@@ -250,11 +250,11 @@ size_t cols_lds_bytes(const xm_handle* h, int W) {  // mirrors the carve-up at t
   return 16 * (lut_q + xm_q + slot_q);
 }
 
-size_t own_plan_lds_bytes(int nxs_max, int rp, int hrp, int extra_max) {  // mirrors the carve-up at the top of scatter_own_body
-  return (size_t)4 * nxs_max * rp + (size_t)4 * extra_max + (size_t)4 * hrp;
+size_t own_plan_lds_bytes(int nxs_max, int rp, int hrp, int extra_max, bool grouped) {  // mirrors the carve-up at the top of scatter_own_body
+  return (size_t)4 * nxs_max * rp + (size_t)4 * extra_max + (size_t)4 * own_tab_words(hrp, grouped);
 }
-size_t own_lds_bytes(const xm_handle* h) {
-  return own_plan_lds_bytes(h->tb.own_nxs_max, h->tb.own_rp, h->tb.own_hrp, h->tb.own_extra_max);
+size_t own_lds_bytes(const xm_handle::OwnSet& os) {
+  return own_plan_lds_bytes(os.nxs_max, os.rp, os.hrp, os.extra_max, os.grouped != 0);
 }
 
 

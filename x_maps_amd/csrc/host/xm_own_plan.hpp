@@ -6,16 +6,26 @@ namespace {
 
 // ---- owner tiles (xmaps_k1own.hpp): the rig's ownership tables, worked out once on the host -------------------------------------
 struct OwnPlan {  // what own_plan() works out (host memory) and own_setup() uploads
-  bool ok = false, all_in = true;
+  bool ok = false, all_in = true, grouped = false;
   int W = 0, halo = 0, r_lo = 0, hr = 0, hrp = 0, rp = 0, nxs_max = 0, extra_max = 0, m = 0, bias = 0, extra_cols = 0, delta_max = 0;
-  std::vector<uint16_t> packed, xextra, masks;
+  std::vector<uint16_t> packed, xextra;
+  std::vector<u32> masks;        // [tiles][entries] band columns the tile owns (entry = a row, or an 8-row group)
   std::vector<int4> tiles;
-  std::vector<int16_t> bases;
+  std::vector<int16_t> bases;    // [tiles][entries] first (sheared) frame column of the band
   std::vector<u32> extra_flat;
 };
 
 // Pure host code (no device needed: xm_own_plan_info runs it for the CPU tests).  pl.ok says whether the rig qualifies.
-void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
+//
+// Two ways to own a cell.  PER ROW: the owner column of cell (x, row) = the first time column of that row that maps to it; a tile
+// owns an arbitrary subset of every row's band (a mask per row) and flushes it in 2-byte lanes.  PER 8-ROW GROUP (grouped): the
+// owner column of (x, rows 8 g .. 8 g + 7) = the first time column of ANY of the eight rows that maps to column x -- a tile then
+// owns whole 16-byte pieces of the frame (8 rows of one column: the frame's shear is constant there) and flushes them as such, a
+// quarter of the texture addresser's cycles of the 2-byte flush (profiles/r05_own_tiles.md).  The price: delta = column - owner
+// column grows by the X-map's slant over 8 rows, and with it the halo a tile reads.  Rigs whose grouped delta exceeds the packed
+// X-map's 3 bits (or the tile) keep the per-row form.
+void own_plan_as(const xm_config* cfg, int xmap_h, int xr_min, bool grouped, int W, OwnPlan& pl) {
+  pl = OwnPlan{};
   const int xmap_w = cfg->xmap_width, rect_w = cfg->rect_width, rect_h = cfg->rect_height, x_off = cfg->x_offset;
   const int rows = std::min(xmap_h - 1, rect_h);
   if (rows <= 0 || rect_h < xmap_h - 1 || xr_min <= -x_off) return;  // (an undefined X-map cell, 0, must read as dead)
@@ -28,38 +38,55 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   const int r_lo = std::max(0, yr_min) & ~7, r_hi = std::min(yr_max, rows - 1);
   if (r_hi < r_lo) return;
   const int hr = r_hi - r_lo + 1, hrp = (hr + 7) & ~7;
-  int W = 8;
-  if (const char* e = dbg_opt("XM_OWN_W")) W = atoi(e);
+  const int sh = grouped ? 3 : 0, n_ent = hrp >> sh;  // entries of a tile's band table: rows, or 8-row groups
   W = std::max(OWN_BW, std::min(W, 32)) / OWN_BW * OWN_BW;  // (K0b: half a wave per boundary computes the thresholds up to the next one)
-  // 1. owner column of every cell, row by row: delta = column - first column of the row that maps to the same cell
+  // the frame column of a pair, as the kernel works it out: -1 = dead or outside the frame
+  bool all_in = true, bad_xp = false;
+  const auto cell_col = [&](int r, int c, bool& dead) {
+    const int xp = cfg->proj_x_map[(size_t)r * xmap_w + c], fu = xp - x_off;
+    dead = fu < xr_min;  // no LUT entry gives disp >= 0
+    if (dead) return -1;
+    if (xp < 0 || xp >= (1 << OWN_XP_BITS)) {
+      bad_xp = true;
+      return -1;
+    }
+    int fc = (int)(short)fu;
+    if (fc < 0) fc += rect_w;  // NumPy's negative wrap
+    const bool in = fc >= 0 && fc < rect_w;
+    if (!in || fu < 0) all_in = false;  // the kernel's lean path takes fu as the column
+    return in ? fc : -1;
+  };
+  // 1. owner column of every cell: delta = column - first column of the row (of the 8-row group) that maps to the same frame column
   std::vector<uint16_t>& packed = pl.packed;  // [c][row], as tb.xmap
   packed.assign((size_t)xmap_w * xmap_h, 0);
-  std::vector<int> first(rect_w, -1), fcs((size_t)xmap_w);
+  std::vector<int> first(rect_w, -1);
   int delta_max = 0;
-  bool all_in = true;
-  for (int r = r_lo; r <= r_hi; ++r) {
-    const int16_t* X = cfg->proj_x_map + (size_t)r * xmap_w;
-    for (int c = 0; c < xmap_w; ++c) {
-      fcs[c] = -1;
-      const int xp = X[c], fu = xp - x_off;
-      if (fu < xr_min) continue;  // dead: no LUT entry gives disp >= 0
-      if (xp < 0 || xp >= (1 << OWN_XP_BITS)) return;
-      int fc = (int)(short)fu;
-      if (fc < 0) fc += rect_w;  // NumPy's negative wrap
-      const bool in = fc >= 0 && fc < rect_w;
-      if (!in || fu < 0) all_in = false;  // the kernel's lean path takes fu as the column
-      int delta = 0;
-      if (in) {
-        if (first[fc] < 0) first[fc] = c;
-        delta = c - first[fc];
-        fcs[c] = fc;
+  const int unit = grouped ? 8 : 1;
+  for (int r0 = r_lo; r0 <= r_hi; r0 += unit) {
+    const int r1 = std::min(r0 + unit - 1, r_hi);
+    for (int r = r0; r <= r1; ++r)
+      for (int c = 0; c < xmap_w; ++c) {
+        bool dead;
+        const int fc = cell_col(r, c, dead);
+        if (fc >= 0 && (first[fc] < 0 || c < first[fc])) first[fc] = c;
       }
-      if (delta > OWN_MAX_DELTA) return;
-      delta_max = std::max(delta_max, delta);
-      packed[(size_t)c * xmap_h + r] = (uint16_t)(xp | (delta << OWN_XP_BITS));
-    }
-    for (int c = 0; c < xmap_w; ++c)
-      if (fcs[c] >= 0) first[fcs[c]] = -1;
+    if (bad_xp) return;
+    for (int r = r0; r <= r1; ++r)
+      for (int c = 0; c < xmap_w; ++c) {
+        bool dead;
+        const int fc = cell_col(r, c, dead);
+        if (dead) continue;
+        const int delta = fc >= 0 ? c - first[fc] : 0;
+        if (delta > OWN_MAX_DELTA) return;
+        delta_max = std::max(delta_max, delta);
+        packed[(size_t)c * xmap_h + r] = (uint16_t)(cfg->proj_x_map[(size_t)r * xmap_w + c] | (delta << OWN_XP_BITS));
+      }
+    for (int r = r0; r <= r1; ++r)
+      for (int c = 0; c < xmap_w; ++c) {
+        bool dead;
+        const int fc = cell_col(r, c, dead);
+        if (fc >= 0) first[fc] = -1;
+      }
   }
   if (delta_max == 0) return;  // an injective X-map: the plain column tiles' business
   const int halo = delta_max;  // (a tile reads its own columns and `halo` behind them: K0b finds that boundary too)
@@ -86,39 +113,43 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   if (const char* e = dbg_opt("XM_OWN_SHEAR")) m = atoi(e);  // experiments
   int sh_min = 0, sh_max = 0;
   for (int g = 0; g <= (rect_h - 1) >> 3; ++g) {
-    const int sh = (g * m) >> 12;
-    sh_min = std::min(sh_min, sh);
-    sh_max = std::max(sh_max, sh);
+    const int shv = (g * m) >> 12;
+    sh_min = std::min(sh_min, shv);
+    sh_max = std::max(sh_max, shv);
   }
   const int bias = -sh_min, extra = sh_max - sh_min;
   if (rect_w + extra > 32767) return;
-  // 3. per (tile, row): where its cells lie in the sheared frame.  The band of a row = the window of NX frame columns that
-  //    holds most of the row's owner cells (a tile's cells of one row are a short run; the run moves with the row by what the
-  //    frame's shear leaves of the X-map's slant); owner cells outside it are "extras" (where the rectified
-  //    time map replicates its border the X-map jumps by hundreds of columns: first / last tile of the ESL rig).  NX = the
-  //    narrowest band that leaves (almost) no more extras than the widest one.
-  const int nt = (xmap_w + W - 1) / W, ng = hrp;  // (one band position per row)
-  const auto owner_col = [&](int r, int c, int& xs) {  // owner pairs only: the cell's column in the sheared frame
+  // 3. per (tile, entry): where its cells lie in the sheared frame.  The band of an entry = the window of NX frame columns that
+  //    holds most of the columns the tile owns there (a short run; it moves from entry to entry by what the frame's shear leaves of
+  //    the X-map's slant); cells outside it are "extras" (where the rectified time map replicates its border the X-map jumps by
+  //    hundreds of columns: first / last tile of the ESL rig).  NX = the narrowest band that leaves (almost) no more extras than
+  //    the widest one.
+  const int nt = (xmap_w + W - 1) / W;
+  const int nx_cap = grouped ? 32 : OWN_MAX_NXS;  // (band columns: the bits of an entry's ownership word)
+  const auto pair_cell = [&](int r, int c, int& t, int& xs) {  // a live pair inside the frame: its owner tile, its column in the sheared frame
     const uint16_t pk = packed[(size_t)c * xmap_h + r];
-    if (!pk || (pk >> OWN_XP_BITS) != 0) return false;
+    if (!pk) return false;
     int fc = (int)(short)((int)(pk & ((1 << OWN_XP_BITS) - 1)) - x_off);
     if (fc < 0) fc += rect_w;
     if (fc < 0 || fc >= rect_w) return false;
+    t = (c - (int)(pk >> OWN_XP_BITS)) / W;
     xs = fc + bias + (((r >> 3) * m) >> 12);
     return true;
   };
-  std::vector<std::vector<int>> cells((size_t)nt * ng);  // sorted sheared columns of every (tile, row)'s owner cells
+  std::vector<std::vector<int>> cols((size_t)nt * n_ent);  // sorted, unique: the sheared columns a tile owns in an entry
   for (int r = r_lo; r <= r_hi; ++r)
     for (int c = 0; c < xmap_w; ++c) {
-      int xs;
-      if (owner_col(r, c, xs)) cells[(size_t)(c / W) * ng + (r - r_lo)].push_back(xs);
+      int t, xs;
+      if (pair_cell(r, c, t, xs)) cols[(size_t)t * n_ent + ((r - r_lo) >> sh)].push_back(xs);
     }
-  for (auto& v : cells) std::sort(v.begin(), v.end());
-  const auto best_window = [](const std::vector<int>& v, int nx, int& start) {  // most cells inside [start, start + nx)
+  for (auto& v : cols) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  }
+  const auto best_window = [](const std::vector<int>& v, int nx, int& start) {  // most columns inside [start, start + nx)
     size_t best = 0, j = 0;
     start = v.empty() ? 0 : v[0];
     for (size_t i = 0; i < v.size(); ++i) {
-      if (i && v[i] == v[i - 1]) continue;
       while (j < v.size() && v[j] < v[i] + nx) ++j;
       if (j - i > best) {
         best = j - i;
@@ -127,40 +158,47 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
     }
     return best;
   };
-  size_t extras_at[OWN_MAX_NXS + 1] = {};
-  for (int nx = 1; nx <= OWN_MAX_NXS; ++nx)
-    for (const auto& v : cells) {
+  std::vector<size_t> extras_at(nx_cap + 1, 0);
+  for (int nx = 1; nx <= nx_cap; ++nx)
+    for (const auto& v : cols) {
       int st;
       extras_at[nx] += v.size() - best_window(v, nx, st);
     }
-  int NX = OWN_MAX_NXS;
-  while (NX > 1 && extras_at[NX - 1] <= extras_at[OWN_MAX_NXS] + extras_at[OWN_MAX_NXS] / 8 + 64) NX -= 1;
+  int NX = nx_cap;
+  while (NX > 1 && extras_at[NX - 1] <= extras_at[nx_cap] + extras_at[nx_cap] / 8 + (grouped ? 8 : 64)) NX -= 1;
   std::vector<int4>& tiles = pl.tiles;
   std::vector<int16_t>& bases = pl.bases;
   tiles.assign(nt, make_int4(0, 0, 0, 0));
-  bases.assign((size_t)nt * ng, 0);
-  for (int t = 0; t < nt; ++t)
-    for (int g = 0; g < ng; ++g) {
-      int st;
-      best_window(cells[(size_t)t * ng + g], NX, st);
-      bases[(size_t)t * ng + g] = (int16_t)st;
-    }
-  std::vector<uint16_t>&masks = pl.masks, &xextra = pl.xextra;
-  masks.assign((size_t)nt * hrp, 0);
-  xextra.assign((size_t)xmap_w * xmap_h, 0);
+  bases.assign((size_t)nt * n_ent, 0);
+  for (size_t i = 0; i < cols.size(); ++i) {
+    int st;
+    best_window(cols[i], NX, st);
+    bases[i] = (int16_t)st;
+  }
+  std::vector<u32>& masks = pl.masks;
+  std::vector<uint16_t>& xextra = pl.xextra;
+  masks.assign((size_t)nt * n_ent, 0);
+  xextra.assign((size_t)xmap_w * xmap_h, 0);  // at EVERY pair whose cell is an extra: the cell's slot + 1
   std::vector<std::vector<u32>> extra_cells(nt);
+  std::vector<std::map<u32, uint16_t>> extra_ids(nt);
   for (int r = r_lo; r <= r_hi; ++r)
     for (int c = 0; c < xmap_w; ++c) {
-      int xs;
-      if (!owner_col(r, c, xs)) continue;
-      const int t = c / W, k = xs - bases[(size_t)t * ng + (r - r_lo)];
+      int t, xs;
+      if (!pair_cell(r, c, t, xs)) continue;
+      const size_t e = (size_t)t * n_ent + ((r - r_lo) >> sh);
+      const int k = xs - bases[e];
       if (k >= 0 && k < NX) {
-        masks[(size_t)t * hrp + (r - r_lo)] |= (uint16_t)(1u << k);
+        masks[e] |= 1u << k;
         tiles[t].x = std::max(tiles[t].x, k + 1);
       } else {
-        extra_cells[t].push_back((u32)xs * (u32)rect_h + (u32)r);
-        if (extra_cells[t].size() > 4096) return;  // (a wild X-map: the packed keys stay)
-        xextra[(size_t)c * xmap_h + r] = (uint16_t)extra_cells[t].size();
+        const u32 cell = (u32)xs * (u32)rect_h + (u32)r;
+        auto it = extra_ids[t].find(cell);
+        if (it == extra_ids[t].end()) {
+          extra_cells[t].push_back(cell);
+          if (extra_cells[t].size() > 4096) return;  // (a wild X-map: the packed keys stay)
+          it = extra_ids[t].emplace(cell, (uint16_t)extra_cells[t].size()).first;
+        }
+        xextra[(size_t)c * xmap_h + r] = it->second;
       }
     }
   int nxs_max = 1, extra_max = 0;
@@ -178,7 +216,7 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
   // kernel is a chain of dependent round trips, what hides them is the number of tiles a CU holds at once
   int passes = 1;
   const auto rows_per_pass = [&](int P) { return ((hrp / 8 + P - 1) / P) * 8; };
-  while (passes < OWN_MAX_ROW_PASSES && own_plan_lds_bytes(nxs_max, rows_per_pass(passes), hrp, extra_max) > OWN_LDS_TARGET) passes += 1;
+  while (passes < OWN_MAX_ROW_PASSES && own_plan_lds_bytes(nxs_max, rows_per_pass(passes), hrp, extra_max, grouped) > OWN_LDS_TARGET) passes += 1;
   if (const char* e = dbg_opt("XM_OWN_ROW_PASSES")) passes = std::max(1, std::min(atoi(e), OWN_MAX_ROW_PASSES));
   {  // the kernel finds a row's pass as row * ceil(2^20 / rp) >> 20
     const auto magic_ok = [&](int rp_) {
@@ -190,56 +228,104 @@ void own_plan(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan& pl) {
     while (passes > 1 && !magic_ok(rows_per_pass(passes))) passes -= 1;
   }
   const int rp = rows_per_pass(passes);
-  if (own_plan_lds_bytes(nxs_max, rp, hrp, extra_max) > 60 * 1024) return;  // LDS per block
+  if (own_plan_lds_bytes(nxs_max, rp, hrp, extra_max, grouped) > 60 * 1024) return;  // LDS per block
   extra_flat.push_back(0);
   pl.W = W; pl.halo = halo; pl.r_lo = r_lo; pl.hr = hr; pl.hrp = hrp; pl.rp = rp; pl.nxs_max = nxs_max; pl.extra_max = extra_max;
-  pl.m = m; pl.bias = bias; pl.extra_cols = extra; pl.delta_max = delta_max; pl.all_in = all_in;
+  pl.m = m; pl.bias = bias; pl.extra_cols = extra; pl.delta_max = delta_max; pl.all_in = all_in; pl.grouped = grouped;
   pl.ok = true;
+}
+
+// The rig's plans: out[0] = the one frames take by default, out[1] = the one for frames too dense for out[0]'s tiles (or !ok).
+// Default: [0] ownership per 8-row group at the widest tiles that fit (20, 16, 12, 8 columns: the halo of 4-7 columns costs
+// 1.35 x event reads at 20 against 1.9 x at 8), [1] ownership per row at 8 columns.  "XM_OWN_W" / "XM_OWN_GROUPED=0"
+// (experiments / tests): one plan, that width / per row only.
+void own_plans(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan (&out)[2]) {
+  out[0] = OwnPlan{};
+  out[1] = OwnPlan{};
+  const char* eg = dbg_opt("XM_OWN_GROUPED");
+  const char* ew = dbg_opt("XM_OWN_W");
+  const bool try_grouped = !(eg && eg[0] == '0');
+  if (ew) {
+    if (try_grouped) own_plan_as(cfg, xmap_h, xr_min, true, atoi(ew), out[0]);
+    if (!out[0].ok) own_plan_as(cfg, xmap_h, xr_min, false, atoi(ew), out[0]);
+    return;
+  }
+  if (try_grouped)
+    for (int W : {20, 16, 12, 8}) {
+      own_plan_as(cfg, xmap_h, xr_min, true, W, out[0]);
+      if (out[0].ok) break;
+    }
+  own_plan_as(cfg, xmap_h, xr_min, false, 8, out[out[0].ok ? 1 : 0]);
+  if (out[1].ok && out[1].W >= out[0].W) out[1] = OwnPlan{};  // (the second plan is for denser frames: narrower tiles)
+}
+
+// a plan's device tables and geometry into the kernel argument
+void own_apply(const xm_handle::OwnSet& os, DevTables& tb) {
+  tb.xmap_own = os.d_xmap_own;
+  tb.xmap_extra = os.d_xmap_extra;
+  tb.own_tiles = os.d_tiles;
+  tb.own_bm = os.d_bm;
+  tb.own_extra_cells = os.d_extra_cells;
+  tb.own_r_lo = os.r_lo;
+  tb.own_hr = os.hr;
+  tb.own_hrp = os.hrp;
+  tb.own_rp = os.rp;
+  tb.own_grouped = os.grouped;
+  tb.own_nxs_max = os.nxs_max;
+  tb.own_extra_max = os.extra_max;
 }
 
 // Returns XM_OK whether or not the rig qualifies (h->own_mode says); an error only for HIP failures.
 int own_setup(xm_handle* h, const xm_config* cfg, int xr_min) {
-  OwnPlan pl;
-  own_plan(cfg, h->tb.xmap_h, xr_min, pl);
-  if (!pl.ok) return XM_OK;
+  OwnPlan pls[2];
+  own_plans(cfg, h->tb.xmap_h, xr_min, pls);
+  if (!pls[0].ok) return XM_OK;
   const auto up = [](auto** dst, const auto& v) -> hipError_t {
     typedef typename std::remove_reference<decltype(v)>::type::value_type E;
     hipError_t e = hipMalloc((void**)dst, v.size() * sizeof(E) + 64);
     return e != hipSuccess ? e : hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice);
   };
-  HIP_TRY(up(&h->d_xmap_own, pl.packed));
-  HIP_TRY(up(&h->d_xmap_extra, pl.xextra));
-  HIP_TRY(up(&h->d_own_tiles, pl.tiles));
-  {  // band position | ownership mask << 16 per (tile, row): one table, read by 16-byte loads at the head of every tile
-    std::vector<u32> bm(pl.bases.size());
-    for (size_t i = 0; i < bm.size(); ++i) {  // (the band's origin BEFORE the frame's shear: an event's band column = cell column - origin)
-      const int row = (int)(i % (size_t)pl.hrp) + pl.r_lo;
-      const int org = (int)pl.bases[i] - pl.bias - (((row >> 3) * pl.m) >> 12);
-      bm[i] = (u32)(uint16_t)(int16_t)org | ((u32)pl.masks[i] << 16);
+  for (int i = 0; i < 2; ++i) {
+    const OwnPlan& pl = pls[i];
+    if (!pl.ok) continue;
+    xm_handle::OwnSet& os = h->own[i];
+    HIP_TRY(up(&os.d_xmap_own, pl.packed));
+    HIP_TRY(up(&os.d_xmap_extra, pl.xextra));
+    HIP_TRY(up(&os.d_tiles, pl.tiles));
+    {  // per tile ONE table, read by 16-byte loads at the head of the tile.  Per-row ownership: per row the band's first column before
+       // the frame's shear (an event's band column = cell column - that) | the row's ownership mask << 16.  Per 8-row group: per
+       // group that column | the band's first column in the sheared frame << 16, then per group the band columns the tile owns.
+      const int n_ent = pl.hrp >> (pl.grouped ? 3 : 0), words = own_tab_words(pl.hrp, pl.grouped), nt = (int)pl.tiles.size();
+      std::vector<u32> tab((size_t)nt * words, 0);
+      for (int t = 0; t < nt; ++t)
+        for (int e = 0; e < n_ent; ++e) {
+          const size_t k = (size_t)t * n_ent + e;
+          const int row = (pl.grouped ? e * 8 : e) + pl.r_lo;
+          const int org = (int)pl.bases[k] - pl.bias - (((row >> 3) * pl.m) >> 12);
+          if (pl.grouped) {
+            tab[(size_t)t * words + e] = (u32)(uint16_t)(int16_t)org | ((u32)(uint16_t)pl.bases[k] << 16);
+            tab[(size_t)t * words + n_ent + e] = pl.masks[k];
+          } else {
+            tab[(size_t)t * words + e] = (u32)(uint16_t)(int16_t)org | (pl.masks[k] << 16);
+          }
+        }
+      HIP_TRY(up(&os.d_bm, tab));
     }
-    HIP_TRY(up(&h->d_own_bm, bm));
+    HIP_TRY(up(&os.d_extra_cells, pl.extra_flat));
+    os.extras = (int)pl.extra_flat.size() - 1;
+    os.w = pl.W; os.halo = pl.halo; os.all_in = pl.all_in;
+    os.r_lo = pl.r_lo; os.hr = pl.hr; os.hrp = pl.hrp; os.rp = pl.rp; os.grouped = pl.grouped ? 1 : 0;
+    os.nxs_max = pl.nxs_max; os.extra_max = pl.extra_max;
+    os.ok = true;
   }
-  HIP_TRY(up(&h->d_own_extra_cells, pl.extra_flat));
-  h->own_extras = (int)pl.extra_flat.size() - 1;
-  h->tb.xmap_own = h->d_xmap_own;
-  h->tb.xmap_extra = h->d_xmap_extra;
-  h->tb.own_tiles = h->d_own_tiles;
-  h->tb.own_bm = h->d_own_bm;
-  h->tb.own_extra_cells = h->d_own_extra_cells;
-  h->tb.own_r_lo = pl.r_lo;
-  h->tb.own_hr = pl.hr;
-  h->tb.own_hrp = pl.hrp;
-  h->tb.own_rp = pl.rp;
-  h->tb.own_nxs_max = pl.nxs_max;
-  h->tb.own_extra_max = pl.extra_max;
-  h->tb.shear_m = pl.m;
-  h->tb.shear_bias = pl.bias;
-  h->tb.shear_extra = pl.extra_cols;
+  // (the frame's shear is the rig's: the same in every plan)
+  h->tb.shear_m = pls[0].m;
+  h->tb.shear_bias = pls[0].bias;
+  h->tb.shear_extra = pls[0].extra_cols;
+  own_apply(h->own[0], h->tb);  // (K2 and the other kernels read none of these fields; a launch of K0b / K1 applies its frame's plan)
   h->own_mode = true;
   if (const char* e = dbg_opt("XM_OWN_EPT")) h->own_ept_forced = atoi(e);
-  h->own_w = pl.W;
-  h->own_halo = pl.halo;
-  if (pl.all_in) h->cols_flags |= COLS_F_ALL_IN_FRAME;
+  if (pls[0].all_in) h->cols_flags |= COLS_F_ALL_IN_FRAME;
   return XM_OK;
 }
 

@@ -37,7 +37,9 @@ namespace xm {
 constexpr int OWN_BW = 4;         // tile widths are multiples of it (K0b finds two boundaries per tile: its first column and the end of its halo)
 constexpr int OWN_MAX_DELTA = 7;  // 3 bits in the packed X-map
 constexpr int OWN_XP_BITS = 13;   // xp < 8192
-constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile (the ownership masks are u16)
+constexpr int OWN_MAX_NXS = 16;   // sheared frame columns per tile with per-row ownership (the masks are u16; 32 per 8-row group)
+// a tile's band table (own_bm, own_setup): a u32 per row -- or, with ownership per 8-row group, two per group --, padded to 16 bytes
+__host__ __device__ inline int own_tab_words(int hrp, bool grouped) { return ((grouped ? (hrp >> 3) * 2 : hrp) + 3) & ~3; }
 constexpr int OWN_MAX_COLS = 72;  // own + halo columns of a tile (W <= 64, halo <= 8)
 constexpr int OWN_MAX_ROW_PASSES = 4;         // a tile's rows go through its LDS slots in up to this many passes (own_plan)
 constexpr size_t OWN_LDS_TARGET = 32 * 1024;  // ... as many as it takes to bring a block's LDS down to this
@@ -71,7 +73,9 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const int RP = tb.own_rp;
   const int n_band_max = tb.own_nxs_max * RP;
   u32* slots_x = slots + n_band_max;
-  u32* s_bm = slots_x + tb.own_extra_max;  // [HRp] band position | ownership mask << 16
+  u32* s_tab = slots_x + tb.own_extra_max;  // the tile's band table (own_tab_words): band positions and ownership per row / per 8-row group
+  const bool grouped = tb.own_grouped != 0;
+  const int ent_sh = grouped ? 3 : 0, n_ent = HRp >> ent_sh, tab_words = own_tab_words(HRp, grouped);
 
   XM_CSTAMP(0);
   const u32 tile = xcd_contiguous_in_frame(blk, nblk, frame_in_grid);
@@ -85,8 +89,8 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   const int4 trec = ((const XM_GLOBAL int4*)tb.own_tiles)[tile];  // {band columns, first extra, extras, -}
   // the tile's band positions and ownership masks: 16-byte loads issued with the locating loads, parked in registers until
   // the slots are cleared (a copy loop of 2-byte loads here was a third of the block's life: one round trip per iteration)
-  const XM_GLOBAL uint4* gbm = (const XM_GLOBAL uint4*)((const XM_GLOBAL u32*)tb.own_bm + (size_t)tile * (size_t)HRp);
-  const int n_bm4 = HRp >> 2;  // (HRp % 8 == 0)
+  const XM_GLOBAL uint4* gbm = (const XM_GLOBAL uint4*)((const XM_GLOBAL u32*)tb.own_bm + (size_t)tile * (size_t)tab_words);
+  const int n_bm4 = tab_words >> 2;
   uint4 bm_q[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) bm_q[q] = gbm[min(tid + q * nthreads, n_bm4 - 1)];
@@ -107,7 +111,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     uint4* l_slots = reinterpret_cast<uint4*>(slots);
     for (int i = tid; i < (XM_CABL(9) ? 0 : (nslots >> 2)); i += nthreads) l_slots[i] = make_uint4(0, 0, 0, 0);  // (HRp % 8 == 0)
     for (int i = tid; i < n_extra; i += nthreads) slots_x[i] = 0;
-    uint4* l_bm = reinterpret_cast<uint4*>(s_bm);
+    uint4* l_bm = reinterpret_cast<uint4*>(s_tab);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       if (tid + q * nthreads < n_bm4) l_bm[tid + q * nthreads] = bm_q[q];
@@ -323,23 +327,23 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
         // the cell's column inside its row's band: its frame column - the band's origin (both before the frame's shear: the
         // table holds the origin, the flush adds the row's shear)
         const int row = write ? rr[k] : 0;
-        const int sx = fc - (int)(short)(s_bm[row] & 0xffffu);
+        const int sx = fc - (int)(short)(s_tab[row >> ent_sh] & 0xffffu);
         const u32 rpo = __umul24((u32)row, rp_inv) >> 20;  // the row's pass
         const int idx = (int)((rpo << 24) | (u32)(__mul24(sx, RP) + row - (int)__umul24(rpo, (u32)RP)));
-        // a cell outside the band (an "extra"): marked with its owner pair, looked up below in the tiles that have any
-        const int extra = (int)(0x80000000u | ((u32)jo << 16) | (u32)row);
+        // a cell outside the band (an "extra"): marked with its pair, looked up below in the tiles that have any
+        const int extra = (int)(0x80000000u | ((u32)tl[k] << 16) | (u32)row);
         code[k] = write ? ((u32)sx < (u32)nxs ? idx : extra) : -1;
         val[k] = (val_base + ((u32)(VEC ? k : k * nthreads) << 16)) | (u32)disp;
       }
     };
     if (all_in) finish(std::true_type{});
     else finish(std::false_type{});
-    if (n_extra > 0) {  // tile-uniform (ESL rig: the first and the last tile): the extras' slots come from the second table, at the cell's OWNER pair
+    if (n_extra > 0) {  // tile-uniform (ESL rig: the first and the last tile): the extras' slots come from the second table, at the event's pair
 #pragma unroll
       for (int k = 0; k < EPT; ++k)
         if (code[k] < -1) {
-          const u32 jo = ((u32)code[k] >> 16) & 0x7fffu, row = (u32)code[k] & 0xffffu;
-          const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)c0 + jo, (u32)tb.xmap_h) + row + (u32)r_lo];
+          const u32 col = ((u32)code[k] >> 16) & 0x7fffu, row = (u32)code[k] & 0xffffu;
+          const u32 e = ((const XM_GLOBAL uint16_t*)tb.xmap_extra)[__umul24((u32)c0 + col, (u32)tb.xmap_h) + row + (u32)r_lo];
           code[k] = e != 0u ? n_band_max + (int)e - 1 : -1;  // (always != 0: xm_create lists every owner cell outside its band)
         }
     }
@@ -355,17 +359,44 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
   }
   __syncthreads();
   if (rp == 0) XM_CSTAMP(6);  // pass 0's ds_max done, barrier passed
+  // ---- flush of the pass's rows.  Ownership per 8-row group: a thread takes the eight rows of one group in one band column (the
+  //      band's position and the frame's shear are constant there): two 16-byte LDS reads, ONE 16-byte store; threads =
+  //      consecutive groups of one band column = consecutive 16 bytes of one frame column.  The slots are left cleared.
+  const bool more = rp + 1 < n_rp;
+  if (grouped) {
+    const u32 col_stride = (u32)tb.rect_h;
+    const int g_first = (rp * RP) >> 3, g_cnt = min(RP, HRp - rp * RP) >> 3;
+    const bool wide = (col_stride & 7u) == 0u;  // (16-byte stores: every frame column then starts 16-byte aligned)
+    const u32 n_items = (u32)g_cnt * (u32)nxs;
+    const u32 g_magic = (u32)(((1ull << 32) + (u32)g_cnt - 1u) / (u32)max(g_cnt, 1));  // item / g_cnt (exact: items < 2^14, groups < 2^9)
+    for (u32 it = (u32)tid; it < n_items; it += (u32)nthreads) {
+      const u32 k = g_cnt > 1 ? __umulhi(it, g_magic) : it, g = it - k * (u32)g_cnt, gi = (u32)g_first + g;
+      if (!((s_tab[n_ent + gi] >> k) & 1u)) continue;
+      uint4* sl = reinterpret_cast<uint4*>(slots + (__umul24(k, (u32)RP) + 8u * g));
+      const uint4 a = sl[0], b = sl[1];
+      if (more) sl[0] = sl[1] = make_uint4(0, 0, 0, 0);
+      XM_GLOBAL uint16_t* p = frame16 + (__umul24((s_tab[gi] >> 16) + k, col_stride) + (u32)r_lo + 8u * gi);
+      if (wide) {
+        *(XM_GLOBAL uint4*)p = make_uint4((a.x & 0xffffu) | (a.y << 16), (a.z & 0xffffu) | (a.w << 16), (b.x & 0xffffu) | (b.y << 16),
+                                          (b.z & 0xffffu) | (b.w << 16));
+      } else {
+        const u32 v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if ((int)(8u * gi) + r_lo + r < tb.rect_h) p[r] = (uint16_t)(v[r] & 0xffffu);  // (the last group's padding rows)
+      }
+    }
+  }
   // ---- flush of the pass's rows: lanes = consecutive rows, each walks its row's band (mask and band position read once per
   //      row; the store of a wave = 64 consecutive rows of one sheared frame column); the slots are left cleared for the next pass
   //      (an event only ever lands on a cell its tile owns: a mask bit)
-  {
+  if (!grouped) {
     XM_GLOBAL uint16_t* base = frame16 + (size_t)r_lo;
     const u32 col_stride = (u32)tb.rect_h;
     const int r_first = rp * RP, r_cnt = min(RP, HRp - r_first);
-    const bool more = rp + 1 < n_rp;
     for (int r_l = tid; r_l < r_cnt; r_l += nthreads) {
       const int r_i = r_first + r_l;
-      const u32 bm = s_bm[r_i];
+      const u32 bm = s_tab[r_i];
       u32 m = bm >> 16;
       const int col = (int)(short)(bm & 0xffffu) + tb.shear_bias + ((((r_i + r_lo) >> 3) * tb.shear_m) >> 12);  // (frame16_col)
       XM_GLOBAL uint16_t* p = base + (__umul24((u32)col, col_stride) + (u32)r_i);
@@ -385,8 +416,8 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
         sl += 8 * RP;
       }
     }
-    if (more) __syncthreads();
   }
+  if (more) __syncthreads();
   }
   XM_CSTAMP(7);  // every row pass flushed
   if (XM_CABL(6) || XM_CABL(7)) bad = false;

@@ -66,9 +66,10 @@ struct DevTables {
   const uint16_t* xmap_own;     // [xmap_w][xmap_h]  xp | delta << 13, 0 = undefined
   const uint16_t* xmap_extra;   // [xmap_w][xmap_h]  extra slot + 1 at the owner pair of a cell outside its tile's band, else 0
   const int4* own_tiles;        // [tiles] {band columns, first extra, extras, 0}
-  const u32* own_bm;            // [tiles][own_hrp]  first frame column of the row's band | ownership mask << 16
+  const u32* own_bm;            // [tiles][own_tab_words]  the tile's band table (own_setup): band positions and ownership per row / per 8-row group
   const u32* own_extra_cells;   // [extras] cell index in the (sheared) u16 frame
   int own_r_lo, own_hr, own_hrp, own_nxs_max, own_extra_max;
+  int own_grouped;  // 1: a tile owns whole 8-row pieces of a frame column (own_plan), 0: any cells of a row
   int own_rp;  // rows per pass of a tile's LDS slots (a multiple of 8; own_hrp = one pass): see scatter_own_body
   // the plain u16 disparity frame of the column / owner tiles is sheared by whole columns per 8-row group: cell (x, row) lives
   // in frame column x + shear_bias + ((row >> 3) * shear_m >> 12); the frame has rect_w + shear_extra columns.  All 0 unless

@@ -175,7 +175,8 @@ class XMapsEngine:
         a = (C.c_int32 * 12)()
         N.check(self._lib.xm_cols_info(self._h, a))
         return {"mode": ("none", "cols", "own")[a[0]], "w": a[1], "halo": a[2], "nxs_max": a[3], "shear_m": a[4],
-                "shear_extra": a[5], "r_lo": a[6], "rows": a[7], "extras": a[8], "extras_max_per_tile": a[9]}
+                "shear_extra": a[5], "r_lo": a[6], "rows": a[7], "extras": a[8], "extras_max_per_tile": a[9],
+                "dense_w": a[10], "dense_halo": a[11]}  # (the second plan: narrow tiles for frames too dense for the first; 0 = none)
 
     def stream(self, slot: int = 0) -> int:
         return int(self._lib.xm_stream(self._h, slot) or 0)
