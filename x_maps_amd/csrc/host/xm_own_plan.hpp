@@ -216,7 +216,9 @@ void own_plan_as(const xm_config* cfg, int xmap_h, int xr_min, bool grouped, int
   // kernel is a chain of dependent round trips, what hides them is the number of tiles a CU holds at once
   int passes = 1;
   const auto rows_per_pass = [&](int P) { return ((hrp / 8 + P - 1) / P) * 8; };
-  while (passes < OWN_MAX_ROW_PASSES && own_plan_lds_bytes(nxs_max, rows_per_pass(passes), hrp, extra_max, grouped) > OWN_LDS_TARGET) passes += 1;
+  // (wide tiles run as blocks of 512 threads, two per CU by their registers: 60 KB each is no limit -- and every further pass costs them 5-8 %)
+  const size_t lds_target = grouped && W > 8 ? (size_t)60 * 1024 : OWN_LDS_TARGET;
+  while (passes < OWN_MAX_ROW_PASSES && own_plan_lds_bytes(nxs_max, rows_per_pass(passes), hrp, extra_max, grouped) > lds_target) passes += 1;
   if (const char* e = dbg_opt("XM_OWN_ROW_PASSES")) passes = std::max(1, std::min(atoi(e), OWN_MAX_ROW_PASSES));
   {  // the kernel finds a row's pass as row * ceil(2^20 / rp) >> 20
     const auto magic_ok = [&](int rp_) {
