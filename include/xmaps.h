@@ -157,7 +157,8 @@ typedef struct xm_frame_stats {
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
 /* Variant switches for tests and experiments ("XM_COLS", "XM_K2_PIPE", "XM_K2_PIPE_PPT", "XM_K2_CONSEC", "XM_K2_NLDS_MAX",
- * "XM_K2_PPT", "XM_K2_FLAGS", "XM_K1_DIRECT", "XM_K2_DIRECT", "XM_KEY32", "XM_OWN_W", "XM_OWN_SHEAR", "XM_WORKERS", "XM_XMAP_SCAN",
+ * "XM_K2_PPT", "XM_K2_FLAGS", "XM_K1_DIRECT", "XM_K2_DIRECT", "XM_KEY32", "XM_OWN_W", "XM_OWN_SHEAR", "XM_OWN_GROUPED",
+ * "XM_OWN_ROW_PASSES", "XM_OWN_EPT", "XM_K2_PER_CU", "XM_K2_CHAIN", "XM_WORKERS", "XM_XMAP_SCAN",
  * "XM_INGEST_CLEAR_EVERY", "XM_INGEST_TRACE", "XM_INGEST_OUT_PIECE", "XM_INGEST_OUT_SERIAL", "XM_INGEST_OUT_INLINE",
  * "XM_INGEST_OUT_NO_QUERY", "XM_INGEST_EVT3_OUT_STREAM", "XM_INGEST_OWN_STREAMS", "XM_INGEST_PRIOS", "XM_SHARDED_KEYS"; values as text).  Process-wide, read when a handle / an ingest is created (XM_XMAP_SCAN:
  * at every call).  The library never reads them from the environment.  value == NULL removes an option, name == NULL all. */
@@ -180,7 +181,9 @@ int xm_path_counts(xm_handle* h, uint64_t counts[4]);
  * owner tiles: info[1] = time columns per tile, [2] = halo columns read behind them, [3] = widest cell band of a tile
  * (sheared frame columns), [4] = shear per 8-row group in 1/4096 columns, [5] = extra frame columns of the sheared
  * u16 frame, [6] = first row / [7] = rows the rectify LUT can reach, [8] = owner cells outside their tile's band ("extras":
- * one slot each, flushed one by one), [9] = the most extras of one tile; [10], [11] = 0. */
+ * one slot each, flushed one by one), [9] = the most extras of one tile -- all of the plan frames take by default (ownership per
+ * 8-row group on wide tiles where the rig allows it); [10], [11] = tile width and halo of the second plan (ownership per row, for
+ * frames too dense for the first plan's tiles), 0 = none. */
 int xm_cols_info(xm_handle* h, int32_t info[12]);
 /* The owner-tile analysis of xm_create on its own (host code, no device needed): would this rig's tables qualify?  info as
  * xm_cols_info (info[0] = 2 or 0), plus [10] = the largest distance of a time column from its cell's first column, [11] = LDS
