@@ -32,6 +32,10 @@
 #pragma once
 #include "xmaps_k1cols.hpp"
 
+#ifndef XM_OWN_WAVES
+#define XM_OWN_WAVES 1  /* waves per SIMD the 8-events-per-thread kernels are compiled for (experiments: 5, 6) */
+#endif
+
 namespace xm {
 
 constexpr int OWN_BW = 4;         // tile widths are multiples of it (K0b finds two boundaries per tile: its first column and the end of its halo)
@@ -449,7 +453,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
 }
 
 template <bool AOS, bool VEC, int EPT = COLS_EPT>
-__global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : 1) void k_scatter_own(
+__global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : XM_OWN_WAVES) void k_scatter_own(
     const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts, const uint4* __restrict__ aos,
     u32 n, DevTables tb, SlotState* st, uint16_t* __restrict__ frame16, int W, int halo, int flags) {
   {  // every kernel argument in one scalar round trip (see k_scatter_tiled); never true
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : 1) void k_scatter_
 }
 
 template <bool AOS, bool VEC, int EPT = COLS_EPT>
-__global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : 1) void k_scatter_own_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W,
+__global__ __launch_bounds__(COLS_MAX_THREADS, EPT == 4 ? 8 : XM_OWN_WAVES) void k_scatter_own_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W,
                                                                         int halo, int flags) {
   const FrameDesc d = descs[blockIdx.y];
   if (!d.valid || d.n == 0) return;
