@@ -237,6 +237,15 @@ def test_esl_like_rig_real_calibration_geometry():
             r = _ref(tb, frames[f])
             assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]), f
         assert eng.path_counts()["cols"] == 6 and eng.sorted_fallbacks() == 0
+        # a frame too dense for the wide tiles' one event pass (every fourth camera row instead of every thirteenth: ~500 k
+        # events) takes the second plan's 8-column tiles, then a sparse one the first plan's again -- on the slots used above
+        dense = rig.render_events(cp, tb, row_stride=4, seed=5, t0_us=9_000_000)[0]
+        assert len(dense) > 350_000
+        for f, evs in enumerate((dense, frames[2], dense)):
+            d, b, st = eng.process_events(evs)
+            r = _ref(tb, evs)
+            assert np.array_equal(d, r["depth"]) and np.array_equal(b, r["bgr"]) and st.n_inliers == int(r["mask"].sum()), f
+        assert eng.path_counts()["cols"] == 9 and eng.sorted_fallbacks() == 0
 
 
 def _random_shared_rig(seed):
