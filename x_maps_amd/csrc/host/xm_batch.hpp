@@ -20,7 +20,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
   if constexpr (std::is_same<T, long long>::value && !HAS_P) {
     if (cols_w) {  // column tiles: K1 grid = (tiles, frames), K2 on the plain u16 frames
       int rc;
-      if (h->own_mode) {  // owner tiles (the rig's X-map is not injective): two boundaries per tile (its first column, the end of its halo), tiles of own_w + halo
+      if (h->own_mode) {  // owner tiles (the rig's X-map is not injective): two boundaries per tile (its first column, the end of its halo), tiles of the frame's plan (own_set): cols_w + halo columns
         const int ept = own_ept(h, n_mean, cols_w, !AOS && vec16);
         auto kern = ept == 4 ? k_scatter_own_batch<AOS, false, 4> : k_scatter_own_batch<AOS, false>;
         if constexpr (!AOS) {

@@ -199,7 +199,7 @@ struct xm_handle {
   int cols_xr_min = 0, cols_w_max = 0, cols_target = 3700;
   int cols_flags = 0;  // COLS_F_ALL_IN_FRAME when no live (row, column) pair of the rig maps outside the frame
   // owner tiles (xmaps_k1own.hpp): the rig's (row, column) -> cell map is not injective (the reference's own calibration), but
-  // every cell's columns lie within own_halo columns of its first one: cols_ok with own_mode set; fixed tile width own_w
+  // every cell's columns lie within a few (<= 7) columns of its first one: cols_ok with own_mode set; tile widths and halos per plan
   bool own_mode = false;
   // up to two plans (own_setup): [0] ownership per 8-row group, wide tiles -- frames whose tiles fit one event pass of a block;
   // [1] ownership per row, tiles of 8 columns -- denser frames, and rigs whose slant rules [0] out (then it is [0]).  Both write
