@@ -488,8 +488,11 @@ int xm_cols_info(xm_handle* h, int32_t info[12]) {
     info[7] = os.hr;
     info[8] = os.extras;
     info[9] = os.extra_max;
-    info[10] = h->own[1].ok ? h->own[1].w : 0;
-    info[11] = h->own[1].ok ? h->own[1].halo : 0;
+    for (int i = 1; i < xm_handle::OWN_PLANS; ++i)  // (the narrowest plan: the one the densest frames take)
+      if (h->own[i].ok) {
+        info[10] = h->own[i].w;
+        info[11] = h->own[i].halo;
+      }
   }
   return XM_OK;
 }
@@ -504,7 +507,7 @@ int xm_own_plan_info(const xm_config* cfg, int32_t info[12]) {
   const int xmap_h = cfg->xmap_height > 0 ? cfg->xmap_height : cfg->rect_height;
   int xr_min = 32767;
   for (size_t i = 0; i < (size_t)cfg->cam_width * cfg->cam_height; ++i) xr_min = std::min<int>(xr_min, cfg->cam_mapx_i16[i]);
-  OwnPlan pls[2];
+  OwnPlan pls[OWN_PLANS];
   own_plans(cfg, xmap_h, xr_min, pls);
   const OwnPlan& pl = pls[0];  // (the plan frames take by default)
   if (!pl.ok) return XM_OK;

@@ -9,10 +9,12 @@ int cols_width(const xm_handle* h, u64 n) {
   if (h->cols_ok && h->own_mode) {  // owner tiles: the widths the ownership tables are built for; not for nearly empty frames
     // the default plan (wide tiles) while a tile's own + halo columns fit ONE event pass of a block (8 events x 512 threads: past
     // that a tile looks its events up again for every row pass); denser frames take the second plan's narrow tiles
-    const xm_handle::OwnSet& a = h->own[0];
-    const xm_handle::OwnSet& b = h->own[1];
     const double per_col = (double)n / (double)h->tb.xmap_w;
-    const xm_handle::OwnSet& os = b.ok && per_col * (a.w + a.halo) > (double)(COLS_EPT * COLS_MAX_THREADS) ? b : a;  // (the mean tile: measured on the ESL-like frames at 94 % of a block's events, the fuller tiles' second pass included)
+    int pick = 0;  // (the mean tile: measured on the ESL-like frames at 94 % of a block's events, the fuller tiles' second pass included)
+    while (pick + 1 < xm_handle::OWN_PLANS && h->own[pick + 1].ok &&
+           per_col * (h->own[pick].w + h->own[pick].halo) > (double)(COLS_EPT * COLS_MAX_THREADS))
+      pick += 1;
+    const xm_handle::OwnSet& os = h->own[pick];
     const u64 tiles = grid_for(h->tb.xmap_w, os.w);
     return n >= tiles * 128 && n < (1ull << 28) ? os.w : 0;
   }
@@ -27,7 +29,11 @@ int cols_width(const xm_handle* h, u64 n) {
 // owner tiles: events per thread -- eight; four (twice the waves at half the registers for the same tile: xmaps_k1own.hpp) measured
 // the same within the noise (profiles/r05_own_tiles.md) and is kept as an experiment switch ("XM_OWN_EPT" = 4; not for 16-byte SoA loads)
 // the plan whose tiles are W columns wide (cols_width picked it)
-const xm_handle::OwnSet& own_set(const xm_handle* h, int W) { return h->own[1].ok && h->own[1].w == W ? h->own[1] : h->own[0]; }
+const xm_handle::OwnSet& own_set(const xm_handle* h, int W) {
+  for (int i = 1; i < xm_handle::OWN_PLANS; ++i)
+    if (h->own[i].ok && h->own[i].w == W) return h->own[i];
+  return h->own[0];
+}
 
 int own_ept(const xm_handle* h, u64 n, int W, bool vec16) {
   if (vec16 || h->own_ept_forced != 4) return 8;

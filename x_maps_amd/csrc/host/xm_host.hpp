@@ -201,9 +201,11 @@ struct xm_handle {
   // owner tiles (xmaps_k1own.hpp): the rig's (row, column) -> cell map is not injective (the reference's own calibration), but
   // every cell's columns lie within a few (<= 7) columns of its first one: cols_ok with own_mode set; tile widths and halos per plan
   bool own_mode = false;
-  // up to two plans (own_setup): [0] ownership per 8-row group, wide tiles -- frames whose tiles fit one event pass of a block;
-  // [1] ownership per row, tiles of 8 columns -- denser frames, and rigs whose slant rules [0] out (then it is [0]).  Both write
-  // the same frame (every cell a pair maps to, every frame), so consecutive frames of a slot may take different plans.
+  // up to three plans (own_setup), by falling tile width: ownership per 8-row group on tiles of 20 and of 16 columns -- frames
+  // whose tiles fit one event pass of a block --, then ownership per row on tiles of 8 -- denser frames, and rigs whose slant
+  // rules the first two out.  All write the same frame (every cell a pair maps to, every frame), so consecutive frames of a slot
+  // may take different plans.
+  static constexpr int OWN_PLANS = 3;
   struct OwnSet {
     bool ok = false, all_in = false;
     int w = 0, halo = 0, extras = 0;
@@ -213,7 +215,7 @@ struct xm_handle {
     int4* d_tiles = nullptr;
     u32* d_bm = nullptr;
     u32* d_extra_cells = nullptr;
-  } own[2];
+  } own[OWN_PLANS];
   int own_ept_forced = 0;  // "XM_OWN_EPT" (experiments): 4 = four events per thread where a tile then fits one pass
   // XM_FLAG_ADAPTIVE_BATCH: asynchronous device-pointer frames are submitted as GROUPS (multi-frame launches) whenever the GPU
   // is still busy with earlier ones: a frame is launched at once when no group is in flight (an idle GPU -- the 60 Hz live

@@ -237,13 +237,13 @@ void own_plan_as(const xm_config* cfg, int xmap_h, int xr_min, bool grouped, int
   pl.ok = true;
 }
 
-// The rig's plans: out[0] = the one frames take by default, out[1] = the one for frames too dense for out[0]'s tiles (or !ok).
-// Default: [0] ownership per 8-row group at the widest tiles that fit (20, 16, 12, 8 columns: the halo of 4-7 columns costs
-// 1.35 x event reads at 20 against 1.9 x at 8), [1] ownership per row at 8 columns.  "XM_OWN_W" / "XM_OWN_GROUPED=0"
-// (experiments / tests): one plan, that width / per row only.
-void own_plans(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan (&out)[2]) {
-  out[0] = OwnPlan{};
-  out[1] = OwnPlan{};
+// The rig's plans by falling tile width (a frame takes the first whose mean tile fits one event pass of a block: cols_width);
+// !ok entries behind the last one.  Default: ownership per 8-row group at 20 and at 16 columns (the halo of 4-7 columns costs
+// 1.35 x / 1.44 x event reads, against 1.9 x at 8) where the rig allows it, then ownership per row at 8 columns.  "XM_OWN_W" /
+// "XM_OWN_GROUPED=0" (experiments / tests): one plan, that width / per row only.
+constexpr int OWN_PLANS = xm_handle::OWN_PLANS;
+void own_plans(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan (&out)[OWN_PLANS]) {
+  for (OwnPlan& p : out) p = OwnPlan{};
   const char* eg = dbg_opt("XM_OWN_GROUPED");
   const char* ew = dbg_opt("XM_OWN_W");
   const bool try_grouped = !(eg && eg[0] == '0');
@@ -252,13 +252,16 @@ void own_plans(const xm_config* cfg, int xmap_h, int xr_min, OwnPlan (&out)[2]) 
     if (!out[0].ok) own_plan_as(cfg, xmap_h, xr_min, false, atoi(ew), out[0]);
     return;
   }
+  int n = 0;
   if (try_grouped)
-    for (int W : {20, 16, 12, 8}) {
-      own_plan_as(cfg, xmap_h, xr_min, true, W, out[0]);
-      if (out[0].ok) break;
+    for (int W : {20, 16, 12}) {
+      if (n >= OWN_PLANS - 1 || (n == 1 && W < 16)) break;  // (12 columns: only as the widest that fits; 1.58 x event reads lose to per row)
+      own_plan_as(cfg, xmap_h, xr_min, true, W, out[n]);
+      if (out[n].ok) n += 1;
     }
-  own_plan_as(cfg, xmap_h, xr_min, false, 8, out[out[0].ok ? 1 : 0]);
-  if (out[1].ok && out[1].W >= out[0].W) out[1] = OwnPlan{};  // (the second plan is for denser frames: narrower tiles)
+  own_plan_as(cfg, xmap_h, xr_min, false, 8, out[n]);
+  if (out[n].ok) n += 1;
+  else if (n == 0 && try_grouped) own_plan_as(cfg, xmap_h, xr_min, true, 8, out[0]);  // (no per-row plan: the narrow grouped one, if any)
 }
 
 // a plan's device tables and geometry into the kernel argument
@@ -279,7 +282,7 @@ void own_apply(const xm_handle::OwnSet& os, DevTables& tb) {
 
 // Returns XM_OK whether or not the rig qualifies (h->own_mode says); an error only for HIP failures.
 int own_setup(xm_handle* h, const xm_config* cfg, int xr_min) {
-  OwnPlan pls[2];
+  OwnPlan pls[OWN_PLANS];
   own_plans(cfg, h->tb.xmap_h, xr_min, pls);
   if (!pls[0].ok) return XM_OK;
   const auto up = [](auto** dst, const auto& v) -> hipError_t {
@@ -287,7 +290,7 @@ int own_setup(xm_handle* h, const xm_config* cfg, int xr_min) {
     hipError_t e = hipMalloc((void**)dst, v.size() * sizeof(E) + 64);
     return e != hipSuccess ? e : hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice);
   };
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < OWN_PLANS; ++i) {
     const OwnPlan& pl = pls[i];
     if (!pl.ok) continue;
     xm_handle::OwnSet& os = h->own[i];
