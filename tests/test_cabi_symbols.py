@@ -64,3 +64,12 @@ def test_header_is_plain_c_and_layouts_agree(tmp_path):
                                      N.xm_config.cam_mapx_i16.offset, N.XM_ERR_UNSORTED, N.XM_MEM_HOST_PINNED,
                                      ctypes.sizeof(N.xm_ingest_config), ctypes.sizeof(N.xm_ingest_frame),
                                      N.xm_ingest_config.capacity_events.offset, N.xm_ingest_frame.depth.offset]
+
+
+def test_graft_entry_build_checks_the_same_api_version():
+    """__graft_entry__.build() asserts the library's API version: it must be the header's (the driver's build check runs it)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = int(re.search(r"#define\s+XM_API_VERSION\s+(\d+)", open(os.path.join(root, "include", "xmaps.h")).read()).group(1))
+    src = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert int(re.search(r"xm_api_version\(\)\s*==\s*(\d+)", src).group(1)) == hdr
