@@ -35,5 +35,20 @@ print("groups %d  span %.1f us per group  busy %.1f  idle %.1f (%d gaps, mean %.
     groups, (t1 - t0) / 1e3 / groups, busy / 1e3 / groups, sum(gaps) / 1e3 / groups, len(gaps), (sum(gaps) / max(len(gaps), 1)) / 1e3, overlap / 1e3 / groups))
 for k, v in kinds.items():
     print("  %s mean %.2f us (n %d)" % (k, sum(v) / len(v) / 1e3, len(v)))
+# what runs when: time per group by the set of kernel kinds in flight
+ev = []
+for n, s, e in rows:
+    k = "K0b" if "bounds" in n else "K1" if "scatter" in n else "K2"
+    ev.append((s, 1, k)); ev.append((e, -1, k))
+ev.sort()
+cnt = {"K0b": 0, "K1": 0, "K2": 0}
+acc, last = {}, ev[0][0]
+for t, d, k in ev:
+    key = "+".join("%s x%d" % (q, cnt[q]) for q in ("K0b", "K1", "K2") if cnt[q]) or "idle"
+    acc[key] = acc.get(key, 0) + (t - last)
+    last = t
+    cnt[k] += d
+for key, v in sorted(acc.items(), key=lambda kv: -kv[1])[:12]:
+    print("  %-28s %7.2f us per group" % (key, v / 1e3 / groups))
 PY
 rm -rf $OUT
