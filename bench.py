@@ -87,9 +87,10 @@ def parse_args():
                     help="frames per step: a step = ONE group of B C-1M frames through xm_process_batch (one set of multi-frame "
                          "launches, grid = frames x tiles); 0 = a step is one frame through one asynchronous call (round 2's "
                          "headline mode, reported under other_modes by default)")
-    ap.add_argument("--groups-in-flight", type=int, default=4,
-                    help="with --batch: slots = groups x B (default 4 = one group per stream / hardware queue of the handle: 149-151 -> "
-                         "162-166 Gev/s against 3 in alternating runs, 5 / 6 / 8 no different)")
+    ap.add_argument("--groups-in-flight", type=int, default=None,
+                    help="with --batch: slots = groups x B.  Default 4 (one group per stream / hardware queue of the handle: 149-151 -> "
+                         "162-166 Gev/s against 3 in alternating runs, 5 / 6 / 8 no different); --esl: 2 (the ESL-like step is two "
+                         "thirds K2, which is bound by what it writes: 0.256-0.259 ms per step against 0.275 with 4 in the same run)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host->host figures")
@@ -110,7 +111,10 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc, ~30 s); the committed "
                          "profiles/pmc_traffic.json is quoted instead, with its age")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.groups_in_flight is None:
+        args.groups_in_flight = 2 if args.esl else 4
+    return args
 
 
 def spawn_ranks(args):

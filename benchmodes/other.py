@@ -76,6 +76,8 @@ def other_config_legs(args, torch, dist, dev, local_rank):
             a.no_cpu_baseline, a.cpu_seconds = False, min(args.cpu_seconds, 4.0)
         for k, v in over.items():
             setattr(a, k, v)
+        if name == "esl":
+            a.groups_in_flight = 2  # (as `bench.py --esl`: bench.py's --groups-in-flight)
         t0 = time.perf_counter()
         try:
             d = dist
