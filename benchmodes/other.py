@@ -58,12 +58,14 @@ def other_config_legs(args, torch, dist, dev, local_rank):
                     leg[k] = {a: sl[k][a] for a in ing_keys if a in sl[k]}
             if isinstance(sl.get("paced"), dict):
                 leg["paced"] = sl["paced"]
-            for k in ("full_replay_through_processor_host_trigger_finder", "full_replay_through_processor_device_ingest"):
+            for k in ("full_replay_through_processor_default_params", "full_replay_through_processor_host_trigger_finder",
+                      "full_replay_through_processor_device_ingest", "ingest_path_fresh_arrays"):
                 if isinstance(sl.get(k), dict):
                     leg[k] = {a: b for a, b in sl[k].items() if a != "note"}
             ch = sl.get("in_a_process_without_torch")
             if isinstance(ch, dict):  # (the ingest leg and the processor's device-ingest leg: the two the reference's application runs)
-                leg["in_a_process_without_torch"] = {k: ch[k] for k in ("ingest_path", "full_replay_through_processor_device_ingest", "error") if k in ch}
+                leg["in_a_process_without_torch"] = {k: ch[k] for k in ("ingest_path", "ingest_path_fresh_arrays", "full_replay_through_processor_default_params",
+                                                                          "full_replay_through_processor_device_ingest", "error") if k in ch}
         return leg
 
     plan = (("esl", bench_esl, dict(steps=10, esl=True, no_host_path=False)),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XM_API_VERSION 3
+#define XM_API_VERSION 4
 
 /* error codes */
 #define XM_OK 0
@@ -531,7 +531,7 @@ typedef struct xm_ingest_frame {
   uint64_t push_seq;               /* number (from 1) of the xm_ingest_push* call whose packet cut the frame (API version 3) */
   float push_to_publish_us;        /* live latency measured by the library: that push call entered -> the frame's sequence number
                                       published (0 when the frame left in order on the frame stream: EVT chunks, no out thread) */
-  uint32_t reserved;
+  uint32_t owned;                  /* xm_ingest_poll_owned: != 0 = depth / bgr belong to the caller now (API version 4) */
 } xm_ingest_frame;
 int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out);
 void xm_ingest_destroy(xm_ingest* g);
@@ -542,6 +542,24 @@ int xm_ingest_push(xm_ingest* g, const void* eventcd16, size_t n);
 int xm_ingest_push_pinned(xm_ingest* g, const void* eventcd16_pinned, size_t n);
 /* next finished frame, if any: returns 1 and fills *out, 0 if none is ready (never blocks), < 0 on error */
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out);
+/* The same, but the frame's buffers LEAVE the ring with it (out->owned = 1): they are the caller's -- no lifetime rule -- until
+ * each has been given back with xm_frame_pool_release(*pool, buffer, kind) (kind 0: depth, 1: bgr), from any thread, also after
+ * xm_ingest_destroy.  This is the reference's contract for frame_callback -- a fresh array per frame, which the window's thread
+ * keeps as long as it likes (depth_reprojection_pipe.py:164-167, depth_reprojection_processor.py:62-64) -- without copying the
+ * frame a second time on the host: the pinned buffer the DMA filled is handed out and the ring slot gets a spare one (released
+ * buffers are reused; a pool of pinned buffers grows to what the consumer holds at once, at most 1024, "XM_INGEST_POOL_CAP").
+ * out->owned = 0 (no spare buffer could be had): the frame is a view into the ring exactly as xm_ingest_poll returns it. */
+typedef struct xm_frame_pool xm_frame_pool;
+int xm_ingest_poll_owned(xm_ingest* g, xm_ingest_frame* out, xm_frame_pool** pool);
+void xm_frame_pool_release(xm_frame_pool* pool, void* buffer, int kind);
+/* buffers the pool has made so far / in consumers' hands / spare (only while a consumer still holds one of them, or the ingest
+ * is alive: the pool goes with the later of the two).  Any pointer may be NULL. */
+int xm_frame_pool_stats(xm_frame_pool* pool, uint64_t* allocated, uint64_t* outstanding, uint64_t* spare);
+/* Upper bound of the frames the host has not polled yet: frames whose kernels have been issued and not been handed out by
+ * xm_ingest_poll* + packets pushed whose verdict (did it cut a frame?) is still out.  While it stays below result_ring - 1 no
+ * frame can be lost to the ring being lapped.  wait_below > 0: first wait -- for verdicts only, nothing is synchronised -- until
+ * the bound is below that number or no packet is in flight any more (then the caller has frames to poll). */
+int xm_ingest_backlog(xm_ingest* g, int wait_below, uint64_t* backlog);
 /* 1 if the result ring still holds frame `seq` (xm_ingest_frame.seq) intact, 0 if a later frame has been or is being written
  * over it: a caller that copies a frame out of the ring asks this AFTER the copy (the ring is lapped only when the host falls
  * result_ring - 1 frames behind; never in a pipe that polls after every push with result_ring >= 3) */

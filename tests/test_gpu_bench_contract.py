@@ -153,6 +153,8 @@ def test_the_default_line_carries_the_other_baseline_configs():
     assert ip["same_frames_as_host_trigger_finder"] and ip["first_frame_equals_oracle"] and ip["Mevents_per_s_end_to_end"] > 200
     assert ip["host_us_per_push"] < 20
     assert oc["esl"]["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
+    dp = oc["esl"]["full_replay_through_processor_default_params"]  # (the reference's call pattern, this build's default RuntimeParams)
+    assert dp["same_frames_as_host_path"] and dp["every_pass_the_same_frames"] and dp["Mevents_per_s_end_to_end"] > 200, dp
     assert oc["esl"]["in_a_process_without_torch"]["ingest_path"]["same_frames_as_host_trigger_finder"]
     assert oc["graph60"]["latency_us"]["batch_of_60_frames"]["p50"] > 0 and oc["sharded_c10m"]["collective_ms"]["key_frame_merge"] > 0
 
@@ -166,6 +168,7 @@ def test_esl_line_carries_the_stream_legs():
         assert sl[k]["same_frames_as_host_trigger_finder"] and sl[k]["first_frame_equals_oracle"], k
     assert sl["full_replay_through_processor_host_trigger_finder"]["frames_shown"] == ip["frames_cut"]
     assert sl["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
+    assert sl["full_replay_through_processor_default_params"]["same_frames_as_host_path"]
     assert sl["from_evt3_words_period_chunks"]["overflow"] == 0 and sl["from_evt3_words_period_chunks"]["frames_cut"] > 20
     # the same legs in a child process that never imports torch (the reference's situation): same frames, checked the same way
     ch = sl["in_a_process_without_torch"]

@@ -179,6 +179,153 @@ def test_pipe_with_device_ingest_calls_back_with_the_same_frames():
         assert np.array_equal(x, y)
 
 
+def _processor_params(tb, cfg=S.C_TINY, **kw):
+    from x_maps_amd.depth_reprojection_processor import RuntimeParams
+    return RuntimeParams(camera_width=cfg.cam_w, camera_height=cfg.cam_h, projector_width=cfg.proj_w, projector_height=cfg.proj_h,
+                         projector_fps=60, z_near=0.1, z_far=1.2, calib=None, projector_time_map=None, no_frame_dropping=True,
+                         camera_perspective=False, tables=tb, **kw)
+
+
+def test_default_params_take_the_device_ingest_and_hand_out_frames_of_the_consumers_own():
+    """The reference's call pattern -- `with DepthReprojectionProcessor(params)` + process_events(packet),
+    depth_reprojection_processor.py:66-69,107-111 -- with DEFAULT RuntimeParams: the packets go to the device ingest; the window
+    gets the same frames as from the host chain (polarity mask, activity filter, NumPy trigger finder, one fused call per
+    frame), and every frame stays intact however long the window keeps it (a result ring of 4 is lapped several times here):
+    the reference's fresh-array contract, SURVEY 8(b) "Ownership"."""
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(14, seed=4)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+
+    def run(**kw):
+        shown = []
+
+        class Window:
+            def should_close(self):
+                return False
+
+            def show_async(self, img):
+                shown.append(img)  # (kept: never copied)
+
+        with DepthReprojectionProcessor(_processor_params(tb, **kw), window=Window()) as proc:
+            assert (proc._pipe.ingest is not None) == kw.get("device_ingest", True)
+            for p in pk:
+                proc.process_events(p)
+            proc.flush()
+        return shown
+
+    want = run(device_ingest=False)
+    got = run(ingest_result_ring=4)  # defaults otherwise
+    assert len(got) == len(want) >= 10
+    for x, y in zip(got, want):
+        assert x.flags.writeable and np.array_equal(x, y)  # (read after the processor, its ingest and its engine are gone)
+    snap = [g.copy() for g in got]
+    del want
+    for g, c in zip(got, snap):
+        assert np.array_equal(g, c)
+
+
+def test_owned_result_buffers_return_to_the_pool_and_are_reused():
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(12, seed=8)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    tf = IO.TriggerFinderOracle(60)
+    for p in pk:
+        tf.process_events(IO.polarity_filter(p))
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 11, result_ring=4, lossless=True) as ing:
+        held = []
+        for p in pk:
+            ing.push(p)
+            held += ing.poll()  # copy=True: every frame's buffers are the caller's
+        ing.flush()
+        held += ing.poll()
+        _check_frames(tb, held, tf.frames)  # all of them intact although the ring of 4 went round three times
+        st = ing.pool_stats()
+        assert st["outstanding"] == 2 * len(held) == st["allocated"], st  # (depth + BGR per frame)
+        base = held[0].bgr.base
+        view = held[0].bgr[::2, ::2]  # a view keeps the buffer alive ...
+        del held, base
+        import gc
+        gc.collect()
+        st2 = ing.pool_stats()
+        assert st2["outstanding"] == 1 and st2["spare"] == st["outstanding"] - 1, st2
+        del view
+        gc.collect()
+        assert ing.pool_stats()["outstanding"] == 0
+        # ... and a second pass over the stream makes no new buffer: the pool's spare ones go round
+        ing.reset()
+        n_alloc = ing.pool_stats()["allocated"]
+        again = []
+        for p in pk:
+            ing.push(p)
+            again += ing.poll()
+        ing.flush()
+        again += ing.poll()
+        _check_frames(tb, again, tf.frames)
+        assert ing.pool_stats()["allocated"] == n_alloc
+        keep = again[3].bgr  # outlives the ingest: released into a closed pool, freed there
+        want = keep.copy()
+    assert np.array_equal(keep, want)
+    del keep, again
+
+
+def test_an_exhausted_pool_falls_back_to_copies():
+    xm_option("XM_INGEST_POOL_CAP", "3")
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(8, seed=9)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    tf = IO.TriggerFinderOracle(60)
+    for p in pk:
+        tf.process_events(IO.polarity_filter(p))
+    with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, capacity_events=1 << 13, max_packet_events=1 << 11, result_ring=16) as ing:
+        for p in pk:
+            ing.push(p)
+        ing.flush()
+        got = ing.poll()
+        assert ing.pool_stats()["allocated"] <= 3
+        _check_frames(tb, got, tf.frames)
+        assert got[0].bgr.base is not None and got[2].bgr.base is None and got[2].bgr.flags.owndata  # (the pool's buffer / a plain copy)
+
+
+def test_a_frame_event_filter_moves_the_stream_to_the_host_chain_and_back():
+    """Key E (select_next_frame_event_filter, pipe:169): the frame event filters work on the cut frame's events on the host
+    (pipe:131-139), so while one is selected the packets take the host chain; back on NoFilter they take the ingest again."""
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor
+    from x_maps_amd.frame_event_filter import NoFilter
+    tb = S.make_tables(S.C_TINY)
+    stream = _tiny_stream(18, seed=6)
+    pk = _packets(stream, int(1e6 / 60 / 4))
+    third = len(pk) // 3
+    shown = []
+
+    class Window:
+        def should_close(self):
+            return False
+
+        def show_async(self, img):
+            shown.append(img)
+
+    with DepthReprojectionProcessor(_processor_params(tb), window=Window()) as proc:
+        pipe = proc._pipe
+        for p in pk[:third]:
+            proc.process_events(p)
+        proc.flush()
+        n0 = len(shown)
+        assert n0 >= 3 and not pipe._host_chain_active
+        proc.keyboard_cb("e", None, "release")
+        assert not isinstance(pipe.ev_filter_proc.selected_filter(), NoFilter)
+        for p in pk[third:2 * third]:
+            proc.process_events(p)
+        n1 = len(shown)
+        assert n1 > n0 and pipe._host_chain_active and pipe.stats_printer.metrics["frame evs filtered out [%]"].max > 0.0
+        while not isinstance(pipe.ev_filter_proc.selected_filter(), NoFilter):
+            proc.keyboard_cb("e", None, "release")
+        for p in pk[2 * third:]:
+            proc.process_events(p)
+        proc.flush()
+        assert len(shown) > n1 and not pipe._host_chain_active
+
+
 def test_the_slot_is_cleared_before_its_frame_tag_can_wrap(monkeypatch):
     """The ingest slot's tag advances on the device (one per cut frame) and is 19 bits wide in the packed keys: the host clears
     the slot every KEY_MAX_TAG - 16 pushes at the latest.  XM_INGEST_CLEAR_EVERY=3 makes that happen every third push here: the

@@ -57,3 +57,66 @@ def test_synthetic_rig_is_deterministic_and_shaped_like_the_configs():
     assert tb["disp_proj_mapxy_i16"].shape == (480, 640, 2) and (tb["proj_x_map"][:, 0] == 0).all()
     tb10 = S.make_tables(S.C_10M)
     assert (tb10["rect_w"], tb10["rect_h"]) == (3520, 1980) and tb10["proj_x_map"].shape == (1980, 1280)
+
+
+def test_keyboard_cb_honours_metavisions_key_release_contract():
+    """processor.py:96-105: the window calls keyboard_cb(key, scancode, action, mods) on press, repeat AND release; the reference
+    acts on UIAction.RELEASE only and compares UIKeyEvent members.  Enum members (any object with a .name), GLFW integers and
+    plain strings are understood; Metavision itself is not importable here."""
+    import enum
+
+    from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor, FakeWindow
+
+    class UIAction(enum.Enum):  # (the SDK's enums, reduced to what the callback looks at)
+        RELEASE = 0
+        PRESS = 1
+        REPEAT = 2
+
+    class UIKeyEvent(enum.Enum):
+        KEY_ESCAPE = 256
+        KEY_Q = 81
+        KEY_E = 69
+        KEY_S = 83
+        KEY_A = 65
+
+    class Pipe:
+        filters = 0
+
+        def select_next_frame_event_filter(self):
+            self.filters += 1
+
+    proc = DepthReprojectionProcessor(params=None)
+    proc._pipe, proc._window = Pipe(), FakeWindow()
+    for action in (UIAction.PRESS, UIAction.REPEAT):
+        for key in UIKeyEvent:
+            proc.keyboard_cb(key, 0, action, 0)
+    assert proc._pipe.filters == 0 and not proc._window.should_close() and not proc.stats_printer.silent
+    proc.keyboard_cb(UIKeyEvent.KEY_A, 0, UIAction.RELEASE, 0)
+    assert proc._pipe.filters == 0 and not proc._window.should_close()
+    proc.keyboard_cb(UIKeyEvent.KEY_E, 0, UIAction.RELEASE, 0)  # one press-release cycle = one step
+    assert proc._pipe.filters == 1
+    proc.keyboard_cb(UIKeyEvent.KEY_S, 0, UIAction.RELEASE, 0)
+    assert proc.stats_printer.silent
+    proc.keyboard_cb(69, 0, 0, 0)  # GLFW: key 'E', action GLFW_RELEASE
+    proc.keyboard_cb(69, 0, 1, 0)  # ... GLFW_PRESS
+    proc.keyboard_cb("e")          # a headless driver
+    assert proc._pipe.filters == 3
+    proc.keyboard_cb(UIKeyEvent.KEY_Q, 0, UIAction.RELEASE, 0)
+    assert proc._window.should_close()
+    proc._window = FakeWindow()
+    proc.keyboard_cb(UIKeyEvent.KEY_ESCAPE, 0, UIAction.RELEASE, 0)
+    assert proc._window.should_close()
+
+
+def test_stats_are_bounded():
+    """a 60 Hz live loop adds values per frame for as long as it runs: count / mean / extrema stay exact, memory does not grow"""
+    from x_maps_amd import stats
+    sp = stats.StatsPrinter()
+    for i in range(10 * stats.WINDOW):
+        sp.add_metric("m", float(i))
+        with sp.measure_time("t"):
+            pass
+        sp.log(f"line {i}")
+    m = sp.metrics["m"]
+    assert m.count == 10 * stats.WINDOW and m.min == 0.0 and m.max == 10 * stats.WINDOW - 1 and abs(m.mean() - (10 * stats.WINDOW - 1) / 2) < 1e-9
+    assert len(m.recent) == stats.WINDOW == len(sp.timers["t"].recent) == len(sp.logs) and m[-1] == m.max

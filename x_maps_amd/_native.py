@@ -115,7 +115,7 @@ class xm_ingest_frame(C.Structure):
         ("seq", C.c_uint64), ("n_events", C.c_uint64), ("t_first", C.c_int64), ("t_last", C.c_int64),
         ("n_inliers", C.c_uint64), ("n_index_errors", C.c_uint64), ("live_after", C.c_uint64),
         ("overflow", C.c_uint32), ("lost", C.c_uint32), ("depth", C.c_void_p), ("bgr", C.c_void_p), ("push_seq", C.c_uint64),
-        ("push_to_publish_us", C.c_float), ("reserved", C.c_uint32),
+        ("push_to_publish_us", C.c_float), ("owned", C.c_uint32),
     ]
 
 
@@ -178,6 +178,10 @@ SYMBOLS = {
     "xm_ingest_push": (C.c_int, [_P, _P, C.c_size_t]),
     "xm_ingest_push_pinned": (C.c_int, [_P, _P, C.c_size_t]),
     "xm_ingest_poll": (C.c_int, [_P, C.POINTER(xm_ingest_frame)]),
+    "xm_ingest_poll_owned": (C.c_int, [_P, C.POINTER(xm_ingest_frame), C.POINTER(_P)]),
+    "xm_frame_pool_release": (None, [_P, _P, C.c_int]),
+    "xm_frame_pool_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "xm_ingest_backlog": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
     "xm_ingest_flush": (C.c_int, [_P]),
     "xm_ingest_frame_valid": (C.c_int, [_P, C.c_uint64]),
     "xm_ingest_reset": (C.c_int, [_P]),

@@ -18,6 +18,21 @@
 // the ingest stream waits (on the device) for K1 of a frame before anything issued after it appends.  XM_INGEST_NO_LAUNCH_THREAD:
 // the caller does the launch thread's work inside xm_ingest_push* (and waits for each packet's verdict).
 
+// Result buffers that LEAVE the ingest with a frame (xm_ingest_poll_owned) and come back when the consumer lets go of them
+// (xm_frame_pool_release): the reference hands frame_callback a fresh array per frame (depth_reprojection_pipe.py:164-167,
+// SURVEY 8(b) "Ownership"); copying a 6.2 MB frame out of the result ring for that costs more host time than the GPU needs for
+// the frame, so the pinned buffer the DMA filled IS the fresh array and the ring slot gets another one.  The pool outlives its
+// ingest while buffers are out (the last release deletes it).
+struct xm_frame_pool {
+  std::mutex mu;
+  int device = 0;
+  size_t bytes[2] = {0, 0};            // [0] depth (f32), [1] BGR
+  std::vector<void*> free_bufs[2];
+  size_t outstanding = 0;              // buffers in consumers' hands
+  size_t allocated = 0, cap = 0;       // buffers made so far / at most (then the caller copies, as before)
+  bool closed = false;                 // the ingest is gone: a released buffer is freed
+};
+
 struct xm_ingest {
   xm_handle* h = nullptr;
   xm_ingest_config cfg{};
@@ -102,6 +117,13 @@ struct xm_ingest {
   std::vector<float*> h_depth;
   std::vector<uint8_t*> h_bgr;
   uint64_t next_seq = 0;               // frames delivered through xm_ingest_poll so far
+  // owned result buffers (xm_ingest_poll_owned): which buffer a ring slot holds changes under res_mu -- the out side takes the
+  // slot's pointers for frame f and notes f there in one step, the poller swaps a slot's buffers only while the slot still says
+  // "frame next_seq" (so a slot the ring has lapped is never handed out while a DMA writes it)
+  std::mutex res_mu;
+  std::vector<uint64_t> slot_frame;    // frame number + 1 whose copies were enqueued into the slot's buffers last (0: none)
+  xm_frame_pool* pool = nullptr;       // made by the first xm_ingest_poll_owned
+  std::atomic<uint64_t> frames_issued_pub{0};  // = frames_issued, readable by the caller (xm_ingest_backlog)
   // launch side (the launch thread, or the caller without one)
   uint64_t issued = 0;                 // packets whose ingest kernels have been launched
   uint64_t next_verdict = 1;           // the first packet whose verdict has not been handled
@@ -240,8 +262,15 @@ int ingest_out_frame(xm_ingest* g, const xm_ingest::OutJob& j) {
     return XM_OK;
   };
   int rc;
-  if (g->h_bgr[j.slot] && (rc = copy_out(g->h_bgr[j.slot], g->d_out_bgr[j.o], px * 3))) return rc;
-  if (g->h_depth[j.slot] && (rc = copy_out(g->h_depth[j.slot], g->d_out_depth[j.o], px * 4))) return rc;
+  void *dst_bgr, *dst_depth;
+  {
+    std::lock_guard<std::mutex> lk(g->res_mu);
+    dst_bgr = g->h_bgr[j.slot];
+    dst_depth = g->h_depth[j.slot];
+    g->slot_frame[j.slot] = j.frame_no + 1;
+  }
+  if (dst_bgr && (rc = copy_out(dst_bgr, g->d_out_bgr[j.o], px * 3))) return rc;
+  if (dst_depth && (rc = copy_out(dst_depth, g->d_out_depth[j.o], px * 4))) return rc;
   if (!host_seq) {
     hipLaunchKernelGGL(k_ing_publish_seq, dim3(1), dim3(64), 0, os, g->dev.st, j.desc, g->h_status + j.slot, (u64)j.frame_no);
     HIP_TRY(hipGetLastError());
@@ -426,6 +455,7 @@ int ingest_issue_frame(xm_ingest* g, uint64_t push_no, u64 n) {
   }
   g->entry_frame[vi] = f + 1;
   g->frames_issued += 1;
+  g->frames_issued_pub.store(g->frames_issued, std::memory_order_release);
   return XM_OK;
 }
 
@@ -473,9 +503,9 @@ void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
   hipLaunchKernelGGL(k_ing_segment, dim3(1), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
 }
 
-// everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation.  hp = the packet in host memory (the
-// activity filter splits it into sub-packets by time stamps there); NULL for a packet decoded on the device, whose event count
-// then lives at n_dev (device memory) and n is the room of its slot
+// everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation.  hp = the packet in host memory (unused: the
+// activity filter is evaluated on the device for every kind of packet); NULL for a packet decoded on the device, whose event
+// count then lives at n_dev (device memory) and n is the room of its slot
 int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr) {
   xm_handle* h = g->h;
   hipStream_t s = g->stream;
@@ -821,8 +851,8 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, g->frame_stream, d.slot, d.key_frame, (u64)h->key_cells, (unsigned char*)nullptr);
   ING_TRY(hipGetLastError());
   for (int i = 0; i < xm_ingest::STAGE; ++i) {
-    // (the pinned twin h_pkt[i] is allocated by the first PAGEABLE push that lands on the entry: callers that push pinned
-    //  packets or RAW words never pay for 16 x max_packet x 16 bytes of page-locked memory)
+    // (the pinned twins h_pkt[] are allocated by the first PAGEABLE push: callers that push pinned packets or RAW words never
+    //  pay for 16 x max_packet x 16 bytes of page-locked memory)
     ING_TRY(hipMalloc((void**)&g->d_pkt[i], g->max_packet * 16));
     if (!g->d_pkt_n) ING_TRY(hipMalloc((void**)&g->d_pkt_n, xm_ingest::STAGE * sizeof(u32)));
   }
@@ -830,6 +860,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   memset(g->h_status, 0, sizeof(IngestStatus) * g->ring);
   g->h_depth.assign(g->ring, nullptr);
   g->h_bgr.assign(g->ring, nullptr);
+  g->slot_frame.assign(g->ring, 0);
   for (int i = 0; i < g->ring; ++i) {
     if (cfg->want_depth) ING_TRY(hipHostMalloc((void**)&g->h_depth[i], px * 4, hipHostMallocDefault));
     if (cfg->want_bgr) ING_TRY(hipHostMalloc((void**)&g->h_bgr[i], px * 3, hipHostMallocDefault));
@@ -930,6 +961,20 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (g->h_status) (void)hipHostFree(g->h_status);
   for (auto p : g->h_depth) if (p) (void)hipHostFree(p);
   for (auto p : g->h_bgr) if (p) (void)hipHostFree(p);
+  if (xm_frame_pool* pl = g->pool) {  // spare buffers go now, buffers in consumers' hands when they come back (the last one takes the pool along)
+    bool last;
+    {
+      std::lock_guard<std::mutex> lk(pl->mu);
+      pl->closed = true;
+      for (auto& v : pl->free_bufs) {
+        for (void* p : v) (void)hipHostFree(p);
+        v.clear();
+      }
+      last = pl->outstanding == 0;
+    }
+    if (last) delete pl;
+    g->pool = nullptr;
+  }
 
   for (auto& e : g->copied_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : g->k1_ev) if (e) (void)hipEventDestroy(e);
@@ -954,7 +999,13 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   if (!g->threaded) HIP_TRY(hipSetDevice(h->cfg.device));
   const int k = g->pkt_next;
   g->pkt_next = (k + 1) % xm_ingest::STAGE;
-  if (!pinned && n && !g->h_pkt[k] && hipSetDevice(h->cfg.device) == hipSuccess) HIP_TRY(hipHostMalloc((void**)&g->h_pkt[k], g->max_packet * 16, hipHostMallocDefault));
+  if (!pinned && n && !g->h_pkt[k]) {
+    // the pinned twins of the staging entries, ALL of them at the first pageable push (one page-locking pause of the stream's
+    // first packet instead of one on each of its first 16 packets); callers that push pinned packets or RAW words never pay
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (int i = 0; i < xm_ingest::STAGE; ++i)
+      if (!g->h_pkt[i]) HIP_TRY(hipHostMalloc((void**)&g->h_pkt[i], g->max_packet * 16, hipHostMallocDefault));
+  }
   const uint4* hp = pinned ? (const uint4*)eventcd16 : g->h_pkt[k];
   if ((rc = ingest_wait_entry(g, k))) return rc;
   if (n && !pinned) memcpy(g->h_pkt[k], eventcd16, n * 16);  // pageable memory: through the pinned staging ring
@@ -969,7 +1020,7 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   return rc;
 }
 
-int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
+static int ingest_poll(xm_ingest* g, xm_ingest_frame* out, bool owned) {
   if (!g || !out) return fail(XM_ERR_INVALID, "NULL argument");
   if (!g->threaded && g->next_verdict <= g->issued) {  // (no launch thread: a frame whose verdict has arrived meanwhile goes out now)
     int rc = ingest_handle_verdicts(g, 0);
@@ -984,17 +1035,82 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   memcpy(&v, st, sizeof v);
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   const uint64_t seq2 = __atomic_load_n(&st->seq, __ATOMIC_ACQUIRE);  // did the producer rewrite the entry while it was read?
-  const bool lapped = seq > want || seq2 != seq;  // the ring holds a later frame here (or is being rewritten): this one is lost
+  bool lapped = seq > want || seq2 != seq;  // the ring holds a later frame here (or is being rewritten): this one is lost
+  uint64_t newest_slot = 0;
   memset(out, 0, sizeof *out);
   out->seq = g->next_seq;
+  if (!lapped) {
+    out->depth = g->h_depth[slot];
+    out->bgr = g->h_bgr[slot];
+  }
+  if (!lapped && owned && (out->depth || out->bgr)) {
+    // The slot's buffers leave with the frame and the slot gets spare ones -- in one step with the out side's "these are the
+    // buffers of frame f" (res_mu): a slot that says another frame by now has been lapped, its buffers are a DMA's target.
+    if (!g->pool) {
+      xm_frame_pool* pl = new (std::nothrow) xm_frame_pool();
+      if (pl) {
+        pl->device = g->h->cfg.device;
+        const size_t px = (size_t)g->h->out_w * g->h->out_h;
+        pl->bytes[0] = px * 4;
+        pl->bytes[1] = px * 3;
+        pl->cap = 1024;
+        if (const char* e = dbg_opt("XM_INGEST_POOL_CAP")) pl->cap = (size_t)std::max(0, atoi(e));
+        g->pool = pl;
+      }
+    }
+    void* spare[2] = {nullptr, nullptr};
+    bool have = g->pool != nullptr;
+    if (have) {
+      xm_frame_pool* pl = g->pool;
+      std::lock_guard<std::mutex> lk(pl->mu);
+      for (int kind = 0; kind < 2 && have; ++kind) {
+        if (!(kind == 0 ? out->depth != nullptr : out->bgr != nullptr)) continue;
+        if (!pl->free_bufs[kind].empty()) {
+          spare[kind] = pl->free_bufs[kind].back();
+          pl->free_bufs[kind].pop_back();
+        } else if (pl->allocated < pl->cap && hipSetDevice(pl->device) == hipSuccess &&
+                   hipHostMalloc(&spare[kind], pl->bytes[kind], hipHostMallocDefault) == hipSuccess) {
+          pl->allocated += 1;
+        } else {
+          (void)hipGetLastError();
+          spare[kind] = nullptr;
+          have = false;
+        }
+      }
+      if (!have)  // (not both: what was taken goes back; the caller copies this frame out of the ring as xm_ingest_poll's callers do)
+        for (int kind = 0; kind < 2; ++kind)
+          if (spare[kind]) pl->free_bufs[kind].push_back(spare[kind]);
+    }
+    if (have) {
+      std::lock_guard<std::mutex> lk(g->res_mu);
+      newest_slot = g->slot_frame[slot];
+      if (newest_slot == want) {
+        if (out->depth) g->h_depth[slot] = (float*)spare[0];
+        if (out->bgr) g->h_bgr[slot] = (uint8_t*)spare[1];
+        out->owned = 1;
+      } else {
+        lapped = true;
+      }
+    }
+    if (have && out->owned) {
+      std::lock_guard<std::mutex> lk(g->pool->mu);
+      g->pool->outstanding += (out->depth ? 1 : 0) + (out->bgr ? 1 : 0);
+    } else if (have) {
+      std::lock_guard<std::mutex> lk(g->pool->mu);
+      for (int kind = 0; kind < 2; ++kind)
+        if (spare[kind]) g->pool->free_bufs[kind].push_back(spare[kind]);
+    }
+  }
   out->lost = lapped ? 1 : 0;
   if (lapped) {
+    out->depth = nullptr;
+    out->bgr = nullptr;
     if (g->opt_trace) fprintf(stderr, "[ingest] lapped: slot %d want %llu seq %llu seq2 %llu (frames issued %llu, pushes issued %llu)\n", slot,
                                             (unsigned long long)want, (unsigned long long)seq, (unsigned long long)seq2,
                                             (unsigned long long)g->frames_issued, (unsigned long long)g->issued);
     // Nothing of the entry can be trusted for frame next_seq (no statistics, no images: depth / bgr stay NULL).
     // Resume with the oldest frame the ring may still hold intact.
-    const uint64_t newest = std::max(seq, seq2);  // >= want + ring - 1
+    const uint64_t newest = std::max(std::max(seq, seq2), newest_slot);  // >= want + ring - 1
     g->next_seq = std::max<uint64_t>(g->next_seq + 1, newest >= (uint64_t)g->ring ? newest - (uint64_t)g->ring : 0);
     return 1;
   }
@@ -1005,12 +1121,83 @@ int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) {
   out->n_index_errors = v.n_index_errors;
   out->live_after = v.live_after;
   out->overflow = v.overflow;
-  out->depth = g->h_depth[slot];
-  out->bgr = g->h_bgr[slot];
   out->push_seq = v.push_seq;
   out->push_to_publish_us = v.latency_us;
   g->next_seq += 1;
   return 1;
+}
+
+int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) { return ingest_poll(g, out, false); }
+
+int xm_ingest_poll_owned(xm_ingest* g, xm_ingest_frame* out, xm_frame_pool** pool) {
+  if (pool) *pool = nullptr;
+  const int rc = ingest_poll(g, out, true);
+  if (rc == 1 && pool && out->owned) *pool = g->pool;
+  return rc;
+}
+
+void xm_frame_pool_release(xm_frame_pool* pl, void* buffer, int kind) {
+  if (!pl || !buffer || kind < 0 || kind > 1) return;
+  bool last = false, free_it = false;
+  {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    if (pl->outstanding) pl->outstanding -= 1;
+    if (pl->closed) {
+      free_it = true;
+      last = pl->outstanding == 0;
+    } else {
+      pl->free_bufs[kind].push_back(buffer);
+    }
+  }
+  if (free_it) (void)hipHostFree(buffer);
+  if (last) delete pl;
+}
+
+int xm_frame_pool_stats(xm_frame_pool* pl, uint64_t* allocated, uint64_t* outstanding, uint64_t* spare) {
+  if (!pl) return fail(XM_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> lk(pl->mu);
+  if (allocated) *allocated = pl->allocated;
+  if (outstanding) *outstanding = pl->outstanding;
+  if (spare) *spare = pl->free_bufs[0].size() + pl->free_bufs[1].size();
+  return XM_OK;
+}
+
+int xm_ingest_backlog(xm_ingest* g, int wait_below, uint64_t* backlog) {
+  if (!g) return fail(XM_ERR_INVALID, "NULL argument");
+  const auto now = [&]() -> uint64_t {
+    // (handled first: a frame is counted in frames_issued_pub before its packet is in handled)
+    const uint64_t hd = g->threaded ? g->handled.load(std::memory_order_acquire) : g->next_verdict - 1;
+    const uint64_t fi = g->threaded ? g->frames_issued_pub.load(std::memory_order_acquire) : g->frames_issued;
+    const uint64_t posted = g->threaded ? g->posted : g->issued;
+    return (fi - std::min(fi, g->next_seq)) + (posted - std::min(posted, hd));
+  };
+  uint64_t b = now();
+  if (wait_below > 0) {
+    const double c0 = ingest_now();
+    bool waited = false;
+    for (;;) {
+      const uint64_t posted = g->threaded ? g->posted : g->issued;
+      const uint64_t hd = g->threaded ? g->handled.load(std::memory_order_acquire) : g->next_verdict - 1;
+      if (b < (uint64_t)wait_below || hd >= posted) break;  // room, or nothing left in flight that waiting could settle
+      if (!g->threaded) {
+        int rc = ingest_handle_verdicts(g, g->next_verdict);
+        if (rc) return rc;
+      } else {
+        if (g->q_error.load(std::memory_order_relaxed)) return ingest_take_error(g);
+        for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
+      }
+      waited = true;
+      b = now();
+    }
+    if (waited) {  // (counted like a push that waited for a staging entry: the caller's time, spent waiting for the GPU)
+      const double dt = ingest_now() - c0;
+      g->stage_waits += 1;
+      g->push_wait_s += dt;
+      g->push_host_s += dt;
+    }
+  }
+  if (backlog) *backlog = b;
+  return XM_OK;
 }
 
 int xm_ingest_frame_valid(xm_ingest* g, uint64_t seq) {

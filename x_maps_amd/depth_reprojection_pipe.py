@@ -8,9 +8,10 @@ hot path on the GPU.
 `process_ev_frame` is the function the trigger finder calls (trigger_finder.py:172).  In the reference it
 runs six NumPy/Numba/OpenCV stages; here it is one C-ABI call (xm_process_frame_aos) = three HIP kernels,
 and the frame handed to `frame_callback` is a fresh (H, W, 3) uint8 BGR array exactly as before.
-The packet side mirrors pipe:110-119: polarity filter -> activity-noise filter -> trigger finder.  The activity filter runs
-on every packet like the reference's (RuntimeParams.activity_filter, default True) -- as kernels of the device ingest, or, with
-the trigger finder on the host, as x_maps_amd.activity_filter.ActivityNoiseFilterAlgorithm (the same kernels behind one call);
+The packet side mirrors pipe:110-119: polarity filter -> activity-noise filter -> trigger finder -- by default (round 6) as
+kernels of the device ingest (RuntimeParams.device_ingest: process_events(packet) stages the packet and returns; the frames
+arrive through frame_callback as the consumer's own arrays), or on the host (the opt-out, and whenever a frame event filter or a
+caller-supplied activity filter is selected) with x_maps_amd.activity_filter.ActivityNoiseFilterAlgorithm (the same kernels behind one call);
 Metavision's own filter is a binary of the SDK, so the rule is this build's definition (oracle/ingest_oracle.py).
 Out of scope in this build: the timing watchdog.
 """
@@ -85,17 +86,45 @@ class DepthReprojectionPipe:
         # them without the event stream (or any index into it) coming back to the host
         self.ingest = None
         self._raw_dev, self._raw_host = {}, {}  # EVT 3.0 / 2.0 decoders (process_evt3_words / process_evt2_words), created on first use
-        if getattr(p, "device_ingest", False):
+        self._own_act_filter = None
+        self._host_chain_active = False
+        # a caller-supplied activity filter (Metavision's own, where the SDK is installed) runs on the host: so does the chain
+        if getattr(p, "device_ingest", True) and self.activity_filter is None:
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
                                        activity_filter=bool(getattr(p, "activity_filter", True)), want_depth=False,
-                                       result_ring=int(getattr(p, "ingest_result_ring", 8)),
+                                       result_ring=int(getattr(p, "ingest_result_ring", 16)),
                                        lossless=not p.should_drop_frames)  # no_frame_dropping (the default): never lap the ring
             self._ingest_views = bool(getattr(p, "ingest_frame_views", False))
-        elif self.activity_filter is None and getattr(p, "activity_filter", True):
+        else:
+            self._ensure_host_chain()
+
+    def _ensure_host_chain(self):
+        """the host chain's activity filter (pipe:65-67), made when the chain is first needed"""
+        p = self.params
+        if self.activity_filter is None and getattr(p, "activity_filter", True):
             from .activity_filter import ActivityNoiseFilterAlgorithm
             self._own_act_filter = ActivityNoiseFilterAlgorithm(self.calib_maps.engine, int(1e6 / p.projector_fps))  # pipe:65-67
             self.activity_filter = self._own_act_filter
+
+    def _use_ingest(self) -> bool:
+        """Packets go to the device ingest unless a frame event filter is selected (pipe:131-139: those filters re-order the cut
+        frame's events on the host, between the trigger finder and the hot path) -- then the host chain takes the stream, from a
+        clean start on either side (a switch is a user pressing E: the frames around it are not comparable anyway)."""
+        if self.ingest is None:
+            return False
+        want_host = not isinstance(self.ev_filter_proc.selected_filter(), NoFilter)
+        if want_host != self._host_chain_active:
+            self._host_chain_active = want_host
+            if want_host:
+                self.ingest.flush()
+                self._deliver_ingest_frames()
+                self.ingest.reset()
+                self._ensure_host_chain()
+                if self._own_act_filter is not None:
+                    self._own_act_filter.reset()
+            self.trigger_finder.reset()
+        return not want_host
 
     # ---- packets -> frames (host side, in front of the hot path) ---------------------------------------
     def _deliver_ingest_frames(self):
@@ -128,7 +157,7 @@ class DepthReprojectionPipe:
     def _process_raw_words(self, words, fmt):
         from . import evt2, evt3
         mod, dt = (evt2, "<u4") if fmt == 2 else (evt3, "<u2")
-        if self.ingest is not None:
+        if self._use_ingest():
             dev = self._raw_dev.get(fmt)
             if dev is None:
                 cls = evt2.DeviceEvt2Decoder if fmt == 2 else evt3.DeviceEvt3Decoder
@@ -148,7 +177,7 @@ class DepthReprojectionPipe:
             self.process_events(evs)
 
     def process_events(self, evs):
-        if self.ingest is not None:
+        if self._use_ingest():
             self.ingest.push(evs)
             self._deliver_ingest_frames()
             return
@@ -228,7 +257,7 @@ class DepthReprojectionPipe:
         self.trigger_finder.reset()
         if self.ingest is not None:
             self.ingest.reset()  # (buffered events and the activity filter's history: the stream starts over)
-        if getattr(self, "_own_act_filter", None) is not None:
+        if self._own_act_filter is not None:
             self._own_act_filter.reset()
 
     replay_group = 16  # frames per group of process_ev_frames
@@ -242,7 +271,7 @@ class DepthReprojectionPipe:
         self._raw_dev = {}
         if self.ingest is not None:
             self.ingest.close()
-        if getattr(self, "_own_act_filter", None) is not None:
+        if self._own_act_filter is not None:
             self._own_act_filter.close()
             self._own_act_filter = None
         self.calib_maps.engine.close()

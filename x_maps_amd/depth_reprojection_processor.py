@@ -42,19 +42,22 @@ class RuntimeParams:
     # additions of this build (defaults keep the reference's positional signature valid)
     tables: Optional[dict] = None  # pre-built tables instead of `calib`
     device: int = 0
-    device_ingest: bool = False  # polarity / activity filter + frame segmentation on the GPU (x_maps_amd/ingest.py)
+    # polarity / activity filter + buffering + frame segmentation on the GPU (x_maps_amd/ingest.py): process_events(packet) stages
+    # the packet and returns, the frames are cut and processed on the device and handed to frame_callback as the consumer's own
+    # arrays (the pinned buffers their DMA filled).  THE DEFAULT since round 6 -- the same frames as the host chain, which stays
+    # as the opt-out (False: NumPy polarity mask + one GPU call per packet for the activity filter + the NumPy trigger finder,
+    # 20 x slower) and takes over by itself while a frame event filter (key E) or a caller-supplied activity filter is selected.
+    device_ingest: bool = True
     # The activity-noise filter behind the polarity filter, on every packet, as the reference runs it unconditionally
     # (depth_reprojection_pipe.py:65-67,116-117): kernels of the device ingest, or one GPU call per packet in front of the host's
     # trigger finder.  The rule is this build's own definition (Metavision's is a binary: oracle/ingest_oracle.py); False
     # switches the stage off (round 4's default).
     activity_filter: bool = True
     # device ingest only: hand frame_callback / window.show_async a VIEW into the ingest's ring of pinned result buffers instead of
-    # a fresh array (the reference hands out fresh arrays; for its 1080 x 1920 projector that copy is 6.2 MB = ~0.5 ms of host
-    # time per frame).  LIFETIME of such a frame: until `ingest_result_ring` - 1 further frames have been produced -- a window or
-    # encoder that consumes the frame inside the callback, or within the next few frames, never notices; a consumer that keeps
-    # frames longer copies them itself.
+    # an array of the consumer's own.  LIFETIME of such a view: until `ingest_result_ring` - 1 further frames have been produced.
+    # (Since round 6 the default frames cost no host copy either -- xm_ingest_poll_owned --, so views only save the pool.)
     ingest_frame_views: bool = False
-    ingest_result_ring: int = 8
+    ingest_result_ring: int = 16
     # process_evt3_words / process_evt2_words: events in front of a recording's first EVT_TIME_HIGH word are dropped (a reader that
     # waits for the first time base) instead of emitted at time base 0.  Which of the two Metavision's reader does is unpinned
     # (tools/pin_thirdparty.py decides); it matters for the first few words of a file only.
@@ -63,6 +66,14 @@ class RuntimeParams:
     @property
     def should_drop_frames(self):
         return not self.no_frame_dropping
+
+
+def _enum_name(v) -> str:
+    """'KEY_E' for UIKeyEvent.KEY_E, 'RELEASE' for UIAction.RELEASE, 'E' for "e", '69' for 69"""
+    name = getattr(v, "name", None)
+    if isinstance(name, str):
+        return name.upper()
+    return str(v).rsplit(".", 1)[-1].upper()
 
 
 class FakeWindow:
@@ -117,11 +128,18 @@ class DepthReprojectionProcessor:
         return False
 
     def keyboard_cb(self, key, scancode=None, action=None, mods=None):
-        if key in ("q", "Q", "esc"):
+        """Window key callback with Metavision's signature (key, scancode, action, mods), processor.py:96-105: acts on key
+        RELEASE only; Q / Escape close, E selects the next frame event filter, S silences the statistics.  `key` / `action` may be
+        metavision_sdk_ui's UIKeyEvent / UIAction enum members (compared by name, so the SDK need not be importable here), GLFW
+        integers, or plain strings; a caller that passes no action (tests, a headless driver) means "released"."""
+        if action is not None and _enum_name(action) not in ("RELEASE", "0"):  # (GLFW_RELEASE == 0)
+            return
+        k = _enum_name(key)
+        if k in ("KEY_ESCAPE", "ESCAPE", "ESC", "256", "KEY_Q", "Q", "81"):
             self._window.set_close_flag()
-        elif key in ("e", "E"):
+        elif k in ("KEY_E", "E", "69"):
             self._pipe.select_next_frame_event_filter()
-        elif key in ("s", "S"):
+        elif k in ("KEY_S", "S", "83"):
             self.stats_printer.toggle_silence()
 
     def process_events(self, evs):

@@ -39,6 +39,22 @@ class IngestFrame:
     push_to_publish_us: float = 0.0  # the library's own clock: that push call entered -> the frame's sequence number published
 
 
+class _OwnedBuffer:
+    """One result buffer that left the ingest with its frame (xm_ingest_poll_owned): the base object of the NumPy array handed
+    to the consumer; when the last array / view over it is gone the buffer goes back to the library's pool of pinned buffers."""
+    __slots__ = ("_release", "_pool", "_ptr", "_kind", "__array_interface__")
+
+    def __init__(self, release, pool, ptr, kind, shape, typestr):
+        self._release, self._pool, self._ptr, self._kind = release, pool, ptr, kind
+        self.__array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": typestr, "version": 3}
+
+    def __del__(self):
+        try:
+            self._release(self._pool, self._ptr, self._kind)
+        except Exception:  # (interpreter shutdown)
+            pass
+
+
 class DeviceIngest:
     def __init__(self, engine, projector_fps: int, use_polarity: bool = True, activity_filter: bool = False,
                  activity_thresh_us: int = 0, capacity_events: int = 0, max_packet_events: int = 0, result_ring: int = 8,
@@ -71,9 +87,11 @@ class DeviceIngest:
         # behaviour under load -- frames the host did not fetch in time are dropped and reported (`lost`).
         self._lossless = bool(lossless)
         self._ring = int(result_ring) if int(result_ring) > 0 else 8
-        self._pushes_unsynced = 0
         self._fr = N.xm_ingest_frame()
         self._fr_ref = C.byref(self._fr)
+        self._backlog = C.c_uint64(0)
+        self._pool = C.c_void_p(None)
+        self._pool_ref = C.byref(self._pool)
 
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:
@@ -116,11 +134,12 @@ class DeviceIngest:
             N.check(self._lib.xm_ingest_push_pinned(self._g, C.c_void_p(part.ctypes.data), len(part)))
 
     def _backpressure(self, n_pushes):
+        """lossless: frames not polled yet + packets whose verdict is still out (each may cut one) stay below the result ring's
+        size.  Waits for verdicts only (xm_ingest_backlog) -- nothing is synchronised, the GPU's pipeline stays full.  What
+        waiting cannot settle are frames the caller has not polled: the contract is a caller that polls after every push."""
         if not self._lossless:
             return
-        if self._pushes_unsynced + n_pushes > self._ring - 1:
-            self.flush()
-        self._pushes_unsynced += n_pushes
+        N.check(self._lib.xm_ingest_backlog(self._g, max(1, self._ring - n_pushes), C.byref(self._backlog)))
 
     def _view(self, ptr, shape, ctype):
         """NumPy view of one buffer of the pinned result ring (built once per buffer, from the address: np.ctypeslib.as_array on
@@ -133,47 +152,63 @@ class DeviceIngest:
         return v
 
     def poll(self, copy: bool = True) -> list[IngestFrame]:
-        """Frames finished since the last call.  copy=True (default): depth / bgr are fresh NumPy arrays, as the reference's
-        frame_callback gets them (for a 1080 x 1920 projector that copy -- 14.5 MB per frame -- is 1.2 ms of host time);
-        copy=False: views into the pinned result ring, valid until `result_ring` - 1 further frames have been cut (the
-        lifetime xm_ingest_frame documents) -- what a display or an encoder that consumes the frame at once wants."""
+        """Frames finished since the last call.  copy=True (default): depth / bgr are the consumer's own arrays, as the reference's
+        frame_callback gets them -- no lifetime rule; they are the pinned buffers the frame's DMA filled, taken out of the result
+        ring (xm_ingest_poll_owned: nothing is copied on the host; a buffer returns to the library's pool when the last array
+        over it is dropped; only when the pool is exhausted is the frame copied out of the ring instead).  copy=False: views into
+        the pinned result ring, valid until `result_ring` - 1 further frames have been cut (the lifetime xm_ingest_frame
+        documents)."""
         out = []
         fr = self._fr
         h, w = self.shape
-        poll = self._lib.xm_ingest_poll
+        lib = self._lib
         while True:
-            rc = poll(self._g, self._fr_ref)
+            rc = lib.xm_ingest_poll_owned(self._g, self._fr_ref, self._pool_ref) if copy else lib.xm_ingest_poll(self._g, self._fr_ref)
             if rc < 0:
                 N.check(rc)
             if rc == 0:
                 break
             depth = bgr = None
-            if fr.depth:
-                depth = self._view(fr.depth, (h, w), C.c_float)
-                depth = depth.copy() if copy else depth
-            if fr.bgr:
-                bgr = self._view(fr.bgr, (h, w, 3), C.c_uint8)
-                bgr = bgr.copy() if copy else bgr
             lost = bool(fr.lost)
-            if copy and not lost and (depth is not None or bgr is not None) and not self._lib.xm_ingest_frame_valid(self._g, fr.seq):
-                lost, depth, bgr = True, None, None  # the ring was lapped while the frame was being copied out: a torn copy is no frame
+            if copy and fr.owned:
+                pool, rel = self._pool.value, lib.xm_frame_pool_release
+                if fr.depth:
+                    depth = np.asarray(_OwnedBuffer(rel, pool, fr.depth, 0, (h, w), "<f4"))
+                if fr.bgr:
+                    bgr = np.asarray(_OwnedBuffer(rel, pool, fr.bgr, 1, (h, w, 3), "|u1"))
+            else:
+                if fr.depth:
+                    depth = self._view(fr.depth, (h, w), C.c_float)
+                    depth = depth.copy() if copy else depth
+                if fr.bgr:
+                    bgr = self._view(fr.bgr, (h, w, 3), C.c_uint8)
+                    bgr = bgr.copy() if copy else bgr
+                if copy and not lost and (depth is not None or bgr is not None) and not lib.xm_ingest_frame_valid(self._g, fr.seq):
+                    lost, depth, bgr = True, None, None  # the ring was lapped while the frame was being copied out: a torn copy is no frame
             out.append(IngestFrame(int(fr.seq), int(fr.n_events), int(fr.t_first), int(fr.t_last), int(fr.n_inliers),
                                    int(fr.n_index_errors), int(fr.live_after), int(fr.overflow), lost, depth, bgr, int(fr.push_seq), float(fr.push_to_publish_us)))
         return out
+
+    def pool_stats(self) -> dict:
+        """The pool of pinned result buffers behind poll(copy=True): buffers made so far (beyond the result ring's own), in
+        consumers' hands, spare."""
+        if not self._pool.value:
+            return {"allocated": 0, "outstanding": 0, "spare": 0}
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        N.check(self._lib.xm_frame_pool_stats(self._pool, C.byref(a), C.byref(b), C.byref(c)))
+        return {"allocated": int(a.value), "outstanding": int(b.value), "spare": int(c.value)}
 
     def device_stats(self) -> dict:
         """The device's counters once everything pushed so far has run (synchronises): frames cut, events appended behind the
         filters, events dropped because the ring had no room, events still buffered."""
         a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         N.check(self._lib.xm_ingest_device_stats(self._g, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        self._pushes_unsynced = 0
         return {"frames_cut": int(a.value), "events_appended": int(b.value), "events_dropped": int(c.value), "events_live": int(d.value)}
 
     def activity_sequential_packets(self) -> int:
         """activity filter: packets so far that the device judged sequentially (synchronises)"""
         n = C.c_uint64(0)
         N.check(self._lib.xm_ingest_activity_stats(self._g, C.byref(n)))
-        self._pushes_unsynced = 0
         return int(n.value)
 
     def host_stats(self) -> dict:
@@ -188,7 +223,6 @@ class DeviceIngest:
 
     def flush(self):
         N.check(self._lib.xm_ingest_flush(self._g))
-        self._pushes_unsynced = 0
 
     def reset(self):
         N.check(self._lib.xm_ingest_reset(self._g))
