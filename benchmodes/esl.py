@@ -313,6 +313,18 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
             for pk in packets:
                 ing.push_pinned(pk)
             ing.flush(), ing.reset(), ing.poll(copy=False)
+            if not views:
+                # frames as arrays of the caller's own: the pool of pinned buffers behind them grows to what the consumer holds at
+                # once (a live pipe: a handful, made in its first frames; here every pass keeps all its frames until the next pass
+                # has been polled -- two passes' worth, 0.6 ms of page-locking per 6.2 MB buffer): made before the timed passes
+                hold = []
+                for _ in range(2):
+                    for pk in packets:
+                        ing.push_pinned(pk)
+                    ing.flush()
+                    hold.append(ing.poll(copy=True))
+                    ing.reset()
+                del hold
             # three timed passes over the stream, the median one reported (under the HIP runtime PyTorch bundles a fresh ingest's
             # first passes run at anything between 0.45 and 1.0 of its settled rate; in a process without torch they do not)
             passes = []
@@ -351,6 +363,8 @@ def esl_stream_legs(eng, cp, tables, n_mean, O, camera, device, n_frames=48):
                           "passes_ms": all_dt,
                           "outputs": ("BGR u8" + (" + depth f32" if want_depth else "")) + (", views into the pinned result ring" if views else ", arrays of the caller's own (the frames' pinned buffers leave the ring: xm_ingest_poll_owned)"),
                           "pcie_GBps_out": round(len(got) * eng.out_h * eng.out_w * (3 + (4 if want_depth else 0)) / dt / 1e9, 2)}
+            if not views:
+                out[label]["result_buffer_pool"] = ing.pool_stats()
     run(False, True, "ingest_path")                      # what frame_callback gets in the reference: the BGR frame
     run(False, True, "ingest_path_filter_off", act_on=False)
     run(True, True, "ingest_path_depth_and_bgr")

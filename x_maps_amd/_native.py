@@ -41,6 +41,11 @@ class XMapsNativeError(RuntimeError):
     pass
 
 
+class XMapsTooMany(ValueError):
+    """XM_ERR_TOO_MANY: more events / words than the buffer the call was given can hold (nothing has advanced: hand the input
+    over again in smaller pieces)"""
+
+
 def _hipcc() -> str | None:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -276,7 +281,9 @@ def check(rc: int, *, index_error_ok: bool = False) -> int:
         if index_error_ok:
             return rc
         raise IndexError(msg)  # NumPy fancy indexing out of range
-    if rc == XM_ERR_INVALID or rc == XM_ERR_TOO_MANY or rc == XM_ERR_UNSORTED:
+    if rc == XM_ERR_TOO_MANY:
+        raise XMapsTooMany(msg)
+    if rc == XM_ERR_INVALID or rc == XM_ERR_UNSORTED:
         raise ValueError(msg)
     if rc == XM_ERR_NOMEM:
         raise MemoryError(msg)

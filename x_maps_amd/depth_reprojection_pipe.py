@@ -163,10 +163,21 @@ class DepthReprojectionPipe:
                 cls = evt2.DeviceEvt2Decoder if fmt == 2 else evt3.DeviceEvt3Decoder
                 dev = self._raw_dev[fmt] = cls(self.calib_maps.engine, max_words=1 << 20,
                                                wait_for_time_base=bool(getattr(self.params, "raw_wait_for_time_base", False)))
+            from ._native import XMapsTooMany
             w = np.ascontiguousarray(words, dtype=dt)
-            for a in range(0, len(w), dev.max_words):
-                dev.push(self.ingest, w[a:a + dev.max_words])
+
+            def push(piece):
+                try:
+                    dev.push(self.ingest, piece)
+                except XMapsTooMany:  # (vector words: up to 12 events each -- more than a packet slot holds; nothing has advanced)
+                    if len(piece) < 2:
+                        raise
+                    push(piece[:len(piece) // 2])
+                    push(piece[len(piece) // 2:])
+                    return
                 self._deliver_ingest_frames()
+            for a in range(0, len(w), dev.max_words):
+                push(w[a:a + dev.max_words])
             return
         host = self._raw_host.get(fmt)
         if host is None:
