@@ -135,6 +135,24 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
     pipeline_fractions(roofline, alg, pt, wl, value, world, s_frame, fps, helper_runs=paths["cols"] > 0 or paths["general"] > 0)
     # ---- other ways in (never `value`) -------------------------------------------------------------------------------
     other = {}
+    if B and bgr_out is not None:
+        # what the reference's frame_callback actually receives: the BGR frame alone (depth_reprojection_pipe.py:164-167) -- the
+        # same groups with no depth frame asked for (K2 then skips its 8.3 MB f32 store per 1080 x 1920 frame)
+        def step_group_bgr(i):
+            aos, offs, _ = groups[i % G]
+            o = (i % (slots // B)) * B
+            eng.process_events_batch_device(aos.data_ptr(), offs, None, bgr_out[o].data_ptr())
+        tmb = Timer(torch, None, dev, eng.sync)
+        eb = tmb.prewarm(step_group_bgr, 0.1)
+        elb, _ = tmb.blocks(lambda: [step_group_bgr(i) for i in range(steps)], int(min(200, max(3, round(0.2 / max(steps * eb, 1e-6))))))
+        dtb = float(np.median(elb))
+        ok_b = None
+        if O is not None:
+            eng.sync()
+            ok_b = bool(np.array_equal(bgr_out[((steps - 1) % (slots // B)) * B].cpu().numpy(), ref_of(host[((steps - 1) % G) * B])["bgr"]))
+        other["groups_bgr_only"] = {"value": round(ev_per_step * steps / dtb / 1e6, 2), "unit": "Mevents/s", "ms_per_step": round(dtb / steps * 1e3, 5),
+                                    "us_per_frame": round(dtb / (steps * fps) * 1e6, 3), "first_frame_of_the_last_group_bgr_equal": ok_b,
+                                    "note": "the step above with the BGR frame as the only output -- what frame_callback gets in the reference"}
     if B and not args.no_other_modes:
         tm1 = Timer(torch, None, dev, eng.sync)
         e1 = tm1.prewarm(step_single, PREWARM_S)

@@ -41,6 +41,9 @@ def other_config_legs(args, torch, dist, dev, local_rank):
                       "Mevents_per_s_one_frame_at_a_time"):
                 if k in out["config"]:
                     leg[k] = out["config"][k]
+        om = out.get("other_modes") or {}
+        if isinstance(om.get("groups_bgr_only"), dict):  # (configs 0 / 2: the output the reference's frame_callback gets)
+            leg["groups_bgr_only"] = {k: v for k, v in om["groups_bgr_only"].items() if k != "note"}
         ip = out.get("ingest_path")
         ing_keys = ("Mevents_per_s_end_to_end", "frames_per_s", "ms_per_cut_frame", "frames_cut", "activity_filter",
                     "same_frames_as_host_trigger_finder", "first_frame_equals_oracle", "host_us_per_push", "outputs",

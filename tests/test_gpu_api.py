@@ -64,7 +64,8 @@ def test_stage_classes_have_reference_signatures_and_results():
 @pytest.mark.parametrize("activity", [True, False])
 def test_processor_context_manager_end_to_end_stream(activity):
     """Packets -> polarity filter -> activity filter (the default, as in the reference; one GPU call per packet on this path)
-    -> trigger finder -> hot path -> window.show_async, like the reference's loop (pipe:110-119)."""
+    -> trigger finder -> hot path -> window.show_async, like the reference's loop (pipe:110-119) -- the HOST chain
+    (RuntimeParams(device_ingest=False), the opt-out since round 6: the default path is tests/test_gpu_ingest.py's)."""
     import ingest_oracle as IO
     cfg = S.C_TINY
     tb = S.make_tables(cfg)
@@ -84,10 +85,11 @@ def test_processor_context_manager_end_to_end_stream(activity):
     frames_seen = []
 
     params = _params(cfg, tb)
+    params.device_ingest = False
     if not activity:
         params.activity_filter = False
     with DepthReprojectionProcessor(params) as proc:
-        assert (proc._pipe.activity_filter is not None) == activity
+        assert (proc._pipe.activity_filter is not None) == activity and proc._pipe.ingest is None
         orig = proc._pipe.process_ev_frame
 
         def spy(evs):

@@ -482,7 +482,7 @@ def test_config3_esl_like_replay_through_the_processor():
     assert (np.diff(stream["t"]) >= 0).all() and 100_000 < np.mean([len(f) for f in rendered]) < 200_000
     params = RuntimeParams(camera_width=640, camera_height=480, projector_width=1080, projector_height=1920, projector_fps=60,
                            z_near=0.1, z_far=1.2, calib=None, projector_time_map=None, no_frame_dropping=True,
-                           camera_perspective=False, tables=tb)
+                           camera_perspective=False, tables=tb, device_ingest=False)  # (the host chain: the test spies on its trigger finder)
     cut, shown = [], []
 
     class Window:

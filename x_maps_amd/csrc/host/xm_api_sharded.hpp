@@ -110,6 +110,7 @@ struct xm_sharded {
   std::condition_variable bcv;
   int b_arrived = 0, b_rc = 0, b_rc_out = 0;
   unsigned long long b_gen = 0;
+  int b_poison = 0;                // != 0: a device thread has LEFT the frame with this error outside an agreement point -- nobody waits for it any more
   // the frame in flight (set by xm_sharded_process_frame, read by the device threads)
   const uint16_t *x = nullptr, *y = nullptr;
   const void* t = nullptr;
@@ -136,14 +137,20 @@ struct xm_sharded {
 namespace {
 
 // fault injection for the tests: xm_debug_option("XM_SHARD_FAIL_AT", "<device index>:<point>") makes that device thread fail in
-// front of collective <point> (1: the first of the frame, 2: the second) -- read when the handle is created
+// front of collective <point> (1: the first of the frame, 2: the second; 3: BEHIND the first agreement, i.e. outside any agreement
+// point -- its peers are then on their way into the collective and must be woken by the poisoned barrier) -- read when the handle is created
 bool dbg_fail_at(const xm_sharded* s, int g, int point) { return s->fail_dev == g && s->fail_point == point; }
 
 // Host barrier among the device threads; returns the first non-zero rc any of them brought (0: everybody is fine).
+// A thread that leaves the frame with an error anywhere else -- hipSetDevice at the top, a collective that returned an error
+// right behind an agreement, the copy at the end of a virtual all-reduce -- will never arrive at the next agreement: it POISONS
+// the barrier on its way out (sharded_leave), which wakes everybody waiting here and makes every later arrival of the frame
+// return at once with that error.  xm_sharded_process_frame clears the barrier before it starts the next frame.
 int sharded_agree(xm_sharded* s, int rc) {
   const int W = (int)s->devs.size();
   if (W == 1) return rc;
   std::unique_lock<std::mutex> lk(s->bmu);
+  if (s->b_poison) return rc ? rc : s->b_poison;
   if (rc && !s->b_rc) s->b_rc = rc;
   const unsigned long long gen = s->b_gen;
   if (++s->b_arrived == W) {
@@ -153,9 +160,19 @@ int sharded_agree(xm_sharded* s, int rc) {
     s->b_gen += 1;
     s->bcv.notify_all();
   } else {
-    s->bcv.wait(lk, [&] { return s->b_gen != gen; });
+    s->bcv.wait(lk, [&] { return s->b_gen != gen || s->b_poison != 0; });
+    if (s->b_gen == gen) return rc ? rc : s->b_poison;  // (poisoned while waiting: the round never completes)
   }
   return s->b_rc_out;
+}
+// a device thread leaves the frame with rc (called once per thread and frame, wherever it returned from)
+void sharded_leave(xm_sharded* s, int rc) {
+  if (!rc || s->devs.size() == 1) return;
+  {
+    std::lock_guard<std::mutex> lk(s->bmu);
+    if (!s->b_poison) s->b_poison = rc;
+  }
+  s->bcv.notify_all();
 }
 // (a peer failed: this thread has nothing to report itself -- xm_sharded_process_frame reports the peer's error, not this one)
 int sharded_peer_failed(xm_sharded::Dev& d, int rc_agreed, int rc_own) {
@@ -172,12 +189,13 @@ int fake_all_gather(xm_sharded* s, int g, const void* send, void* recv, size_t b
   const int W = (int)s->devs.size();
   d.fake_cur = send;
   int rc = hipStreamSynchronize(st) == hipSuccess ? XM_OK : fail(XM_ERR_HIP, "hipStreamSynchronize failed");
-  if ((rc = sharded_agree(s, rc))) return rc;
+  if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
   for (int r = 0; r < W && !rc; ++r)
     if (hipMemcpyAsync((char*)recv + (size_t)r * bytes, s->devs[r]->fake_cur, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
       rc = fail(XM_ERR_HIP, "hipMemcpyAsync (virtual all-gather) failed");
   if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(XM_ERR_HIP, "hipStreamSynchronize failed");
-  return sharded_agree(s, rc);
+  if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
+  return XM_OK;
 }
 
 template <typename T, int OP>
@@ -187,7 +205,7 @@ int fake_all_reduce(xm_sharded* s, int g, T* buf, size_t count, hipStream_t st) 
   d.fake_cur = buf;
   int rc = d.fake_tmp.reserve(count * sizeof(T));
   if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(XM_ERR_HIP, "hipStreamSynchronize failed");
-  if ((rc = sharded_agree(s, rc))) return rc;
+  if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
   std::vector<const void*> ptrs(W);
   for (int r = 0; r < W; ++r) ptrs[r] = s->devs[r]->fake_cur;
   if (hipMemcpyAsync(d.fake_ptrs, ptrs.data(), sizeof(void*) * W, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(XM_ERR_HIP, "hipMemcpyAsync failed");
@@ -196,7 +214,7 @@ int fake_all_reduce(xm_sharded* s, int g, T* buf, size_t count, hipStream_t st) 
     hipLaunchKernelGGL((k_fake_reduce<T, OP>), dim3(gx ? gx : 1), dim3(256), 0, st, (const T* const*)d.fake_ptrs, W, count, (T*)d.fake_tmp.p);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(XM_ERR_HIP, "virtual all-reduce kernel failed");
   }
-  if ((rc = sharded_agree(s, rc))) return rc;  // (everybody has read everybody's buffer)
+  if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);  // (everybody has read everybody's buffer)
   if (hipMemcpyAsync(buf, d.fake_tmp.p, count * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(XM_ERR_HIP, "hipMemcpyAsync failed");
   return XM_OK;
 }
@@ -243,6 +261,7 @@ void sharded_frame_on(xm_sharded* s, int g) {
       };
       rc = before_gather();
       if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
+      if (dbg_fail_at(s, g, 3)) return fail(XM_ERR_HIP, "injected failure (XM_SHARD_FAIL_AT) on device index %d BEHIND the agreement, outside any agreement point", g);
       const void* gathered = d.send.p;  // (one device without RCCL: its own send buffer is the gathered buffer)
       if (s->fake) {
         if ((rc = fake_all_gather(s, g, d.send.p, d.gathered.p, s->cols_send_bytes, st))) return rc;
@@ -315,6 +334,7 @@ void sharded_frame_on(xm_sharded* s, int g) {
     };
     rc = before_min();
     if (const int agreed = sharded_agree(s, rc)) return sharded_peer_failed(d, agreed, rc);
+    if (dbg_fail_at(s, g, 3)) return fail(XM_ERR_HIP, "injected failure (XM_SHARD_FAIL_AT) on device index %d BEHIND the agreement, outside any agreement point", g);
     if (s->fake) {
       rc = s->t_dtype == XM_T_INT64 ? fake_all_reduce<long long, 2>(s, g, (long long*)d.mm, 2, st) : fake_all_reduce<double, 2>(s, g, (double*)d.mm, 2, st);
       if (rc) return rc;
@@ -369,6 +389,7 @@ void sharded_frame_on(xm_sharded* s, int g) {
   };
   d.rc = run();
   if (d.rc) d.err = g_err;
+  sharded_leave(s, d.rc);  // (an error return outside an agreement point must not leave the peers waiting at the next one)
 }
 
 void sharded_thread_main(xm_sharded* s, int g) {
@@ -494,6 +515,12 @@ int xm_sharded_process_frame(xm_sharded* s, const uint16_t* x, const uint16_t* y
   s->bgr_out = bgr_out;
   s->tag = s->tag >= 1000 ? 1 : s->tag + 1;  // (the key frames are cleared every frame: any tag in [1, 2^19) would do)
   const auto run_frame = [&]() -> int {
+    {  // (the device threads are idle: the barrier starts the frame clean, whatever the last frame left in it)
+      std::lock_guard<std::mutex> lk(s->bmu);
+      s->b_arrived = 0;
+      s->b_rc = 0;
+      s->b_poison = 0;
+    }
     {
       std::lock_guard<std::mutex> lk(s->mu);
       s->done = 0;

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       const XM_K2P_GLOBAL uint16_t* src = (const XM_K2P_GLOBAL uint16_t*)k2_pix16 + (__umul24((u32)v, (u32)pix_stride) + (u32)u0);
       if constexpr (PPT == 4) {
         uint2 w = make_uint2(~0u, ~0u);
-        if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint2*>(src);
+        if (XM_CABL(12)) w = make_uint2(0x00210001u + (u32)tx * 4u, 0x00610041u + (u32)tx * 4u);  // (experiments: no offset-table load)
+        else if (in_tab) w = *reinterpret_cast<const XM_K2P_GLOBAL uint2*>(src);
         poff[0] = w.x;
         poff[1] = w.y;
       } else {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       const int gx = bx + c, gy = by + 8 * ro;
       const bool has = sj < nslot && (u32)gx < (u32)a.rect_w && (u32)gy < (u32)a.rect_h;  // (rect_h % 8 == 0)
       K[j] = make_uint4(0, 0, 0, 0);
-      if (has)
+      if (has && !XM_CABL(13))  // (experiments, bit 13: no patch loads)
         K[j] = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(d16 + __umul24((u32)(gx + a.shear_bias + (((g0 + ro) * a.shear_m) >> 12)), (u32)a.rect_h) + (u32)gy);
     }
   };

@@ -90,8 +90,9 @@ class DeviceIngest:
         self._fr = N.xm_ingest_frame()
         self._fr_ref = C.byref(self._fr)
         self._backlog = C.c_uint64(0)
-        self._pool = C.c_void_p(None)
+        self._pool = C.c_void_p(None)   # the pool of the frame polled last (NULL unless its buffers left the ring with it)
         self._pool_ref = C.byref(self._pool)
+        self._pool_seen = None          # ... of this ingest, once a frame has left with its buffers
 
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:
@@ -172,6 +173,7 @@ class DeviceIngest:
             lost = bool(fr.lost)
             if copy and fr.owned:
                 pool, rel = self._pool.value, lib.xm_frame_pool_release
+                self._pool_seen = pool
                 if fr.depth:
                     depth = np.asarray(_OwnedBuffer(rel, pool, fr.depth, 0, (h, w), "<f4"))
                 if fr.bgr:
@@ -192,10 +194,10 @@ class DeviceIngest:
     def pool_stats(self) -> dict:
         """The pool of pinned result buffers behind poll(copy=True): buffers made so far (beyond the result ring's own), in
         consumers' hands, spare."""
-        if not self._pool.value:
+        if not self._pool_seen or not self._g.value:  # (the pool lives as long as the ingest, or a consumer's buffer: ask while the ingest is open)
             return {"allocated": 0, "outstanding": 0, "spare": 0}
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        N.check(self._lib.xm_frame_pool_stats(self._pool, C.byref(a), C.byref(b), C.byref(c)))
+        N.check(self._lib.xm_frame_pool_stats(C.c_void_p(self._pool_seen), C.byref(a), C.byref(b), C.byref(c)))
         return {"allocated": int(a.value), "outstanding": int(b.value), "spare": int(c.value)}
 
     def device_stats(self) -> dict:
