@@ -21,6 +21,84 @@ constexpr int THREADS = 512, EPT = 8, TILES = 320, FRAMES = 32, ROWS = 1320, W =
 constexpr int N = 1000000;  // events per frame
 constexpr int GROUPS = 4;   // distinct groups of 32 frames (1.5 GB of events)
 
+// K1's bands on top of the pattern: per tile 30.7 KB of rectify LUT (16 camera columns around the tile's scan position) and 5.3 KB
+// of X-map (its two time columns) from tables that live in L2, straight into LDS (global_load_lds_dwordx4), the LUT band behind
+// the event loads as in K1; one s_waitcnt vmcnt(0) + barrier before the stores
+constexpr int CAM_H = 480, CAM_W = 640, WX = 16;
+template <bool BANDS>
+__global__ __launch_bounds__(THREADS) void k_tile_bands(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts,
+                                                        const unsigned* __restrict__ lut, const uint16_t* __restrict__ xmap, uint16_t* __restrict__ frame16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tile = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, q0w = tid & ~63;
+  const size_t fo = (size_t)f * N;
+  const int lb_s = (int)((long long)tile * N / TILES), lb_e = (int)((long long)(tile + 1) * N / TILES);
+  uint4* l_xm = reinterpret_cast<uint4*>(smem);                      // 5.3 KB (+ slack)
+  uint4* l_lut = reinterpret_cast<uint4*>(smem + 8 * 1024);          // 30.7 KB
+  const int nq_xm = W * ROWS * 2 / 16, nq_lut = WX * CAM_H * 4 / 16;
+  if (BANDS) {
+    const uint4* g_xm = reinterpret_cast<const uint4*>(xmap + (size_t)tile * W * ROWS);
+    for (int q0 = q0w; q0 < nq_xm; q0 += THREADS)
+      __builtin_amdgcn_global_load_lds((glb_void*)(g_xm + min(q0 + lane, nq_xm - 1)), (lds_void*)(l_xm + q0), 16, 0, 0);
+  }
+  const int a0 = lb_s & ~(EPT - 1);
+  const int base = min(a0 + tid * EPT, (N - 1) & ~(EPT - 1));
+  uint4 xv = make_uint4(0, 0, 0, 0), yv = xv;
+  longlong2 tv[4] = {};
+  if (a0 + tid * EPT < lb_e) {
+    xv = *(const uint4*)(xs + fo + base);
+    yv = *(const uint4*)(ys + fo + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tv[q] = *(const longlong2*)(ts + fo + base + 2 * q);
+    asm volatile("" : "+v"(xv.x), "+v"(xv.y), "+v"(xv.z), "+v"(xv.w), "+v"(yv.x), "+v"(yv.y), "+v"(yv.z), "+v"(yv.w));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(tv[q].x), "+v"(tv[q].y));
+  }
+  if (BANDS) {
+    const int x_lo = min(max(tile * W - WX / 2, 0), CAM_W - WX);
+    const uint4* g_lut = reinterpret_cast<const uint4*>(lut + (size_t)x_lo * CAM_H);
+    for (int q0 = q0w; q0 < nq_lut; q0 += THREADS)
+      __builtin_amdgcn_global_load_lds((glb_void*)(g_lut + min(q0 + lane, nq_lut - 1)), (lds_void*)(l_lut + q0), 16, 0, 0);
+  }
+  unsigned acc = xv.x ^ xv.y ^ xv.z ^ xv.w ^ yv.x ^ yv.y ^ yv.z ^ yv.w;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc ^= (unsigned)tv[q].x ^ (unsigned)tv[q].y;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (BANDS) acc ^= reinterpret_cast<const unsigned*>(smem)[(tid * 37) & 8191];
+  uint16_t* col = frame16 + ((size_t)f * TILES * W + (size_t)tile * W) * ROWS;
+  for (int i = tid; i < W * ROWS; i += THREADS) col[i] = (uint16_t)(acc + i);
+}
+
+template <bool BANDS>
+int run_bands(const char* name, const uint16_t* xs, const uint16_t* ys, const long long* ts, const unsigned* lut, const uint16_t* xmap, uint16_t* frame16) {
+  auto kern = k_tile_bands<BANDS>;
+  const size_t lds = 49 * 1024;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  float sum = 0, best = 1e9f;
+  const int reps = 12;
+  for (int rep = 0; rep < reps + 2; ++rep) {
+    const size_t g = (size_t)(rep % GROUPS) * N * FRAMES;
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(kern, dim3(TILES, FRAMES), dim3(THREADS), lds, 0, xs + g, ys + g, ts + g, lut, xmap, frame16);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep >= 2) {
+      sum += ms;
+      best = ms < best ? ms : best;
+    }
+  }
+  printf("%-34s lds %5zu B  avg %7.1f us  min %7.1f us   (K1's skeleton of memory operations: events + stores%s, one wait + one barrier)\n", name, lds, sum / reps * 1e3,
+         best * 1e3, BANDS ? " + 36 KB of bands per tile out of L2 into LDS" : "");
+  return 0;
+}
+
 template <bool BND, bool LOADS, bool STORES, bool SPEC>
 __global__ __launch_bounds__(THREADS) void k_tile(const uint16_t* __restrict__ xs, const uint16_t* __restrict__ ys, const long long* __restrict__ ts,
                                                   const int4* __restrict__ bounds, uint16_t* __restrict__ frame16, unsigned* sink) {
@@ -117,6 +195,17 @@ int main(int argc, char** argv) {
     if (run<false, true, true, false>("loads + stores", lds, xs, ys, ts, bounds, frame16, sink)) return 1;
     if (run<true, true, true, false>("boundary record -> loads + stores", lds, xs, ys, ts, bounds, frame16, sink)) return 1;
     if (run<true, true, true, true>("speculative loads | boundary record", lds, xs, ys, ts, bounds, frame16, sink)) return 1;
+  }
+  {
+    unsigned* lut;
+    uint16_t* xmap;
+    CK(hipMalloc(&lut, (size_t)CAM_W * CAM_H * 4));
+    CK(hipMalloc(&xmap, (size_t)TILES * W * ROWS * 2 + 4096));
+    CK(hipMemset(lut, 5, (size_t)CAM_W * CAM_H * 4));
+    CK(hipMemset(xmap, 6, (size_t)TILES * W * ROWS * 2 + 4096));
+    CK(hipDeviceSynchronize());
+    if (run_bands<false>("events + stores, wait + barrier", xs, ys, ts, lut, xmap, frame16)) return 1;
+    if (run_bands<true>("... + LUT / X-map bands (LDS-direct)", xs, ys, ts, lut, xmap, frame16)) return 1;
   }
   if (run<false, true, false, false>("loads only", 49 * 1024, xs, ys, ts, bounds, frame16, sink)) return 1;
   if (run<false, false, true, false>("stores only", 49 * 1024, xs, ys, ts, bounds, frame16, sink)) return 1;

@@ -40,6 +40,10 @@ struct K2PipeArgs {  // (only what the loop needs: the whole DevTables would sit
   int proj_w, proj_h, rect_w, rect_h, shear_m, shear_bias;
 };
 
+#ifndef XM_K2P_STAGED
+#define XM_K2P_STAGED 0  /* experiments: 1 = the BGR rows of four-pixel threads through the LDS staging rows, as until round 5 */
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define XM_K2P_GLOBAL __attribute__((address_space(1)))
 #else
@@ -275,7 +279,22 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
               if (u0 + q < a.proj_w) dp[q] = __uint_as_float(e[q].x);
           }
         }
-        if (bgr) {
+        if (bgr && PPT == 4 && (a.proj_w & 3) == 0 && ((u32)(size_t)bgr & 3u) == 0 && !XM_K2P_STAGED) {
+          // Four consecutive pixels = 12 bytes = three dwords per thread, a row's threads back to back: ONE global_store_dwordx3
+          // per thread (4-byte aligned: u0 and the frame's row length are multiples of four pixels), the wave's lanes = runs of
+          // K2_TX * 12 contiguous bytes.  No staging through LDS, no barrier for it (round 6: the staged rows cost three LDS
+          // writes, a barrier and the row copy per item -- on the 1080 x 1920 projector the BGR frame is 6.2 of the 14.5 MB a
+          // frame writes and was a third of K2's time).
+          if (u0 < a.proj_w && v < a.proj_h) {
+            typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+            typedef u32x3 __attribute__((aligned(4))) u32x3_a4;
+            u32x3 w;
+            w.x = (e[0].y & 0xffffffu) | (e[1].y << 24);
+            w.y = ((e[1].y >> 8) & 0xffffu) | (e[2].y << 16);
+            w.z = ((e[2].y >> 16) & 0xffu) | (e[3].y << 8);
+            *reinterpret_cast<XM_K2P_GLOBAL u32x3_a4*>(bgr + (size_t)(__umul24((u32)v, (u32)a.proj_w) + (u32)u0) * 3u) = w;
+          }
+        } else if (bgr) {
           // the row's bytes of this tile: valid_b of them inside the image.  Vector stores of VB bytes when the frame's rows, the
           // tile's first byte and the valid run are all multiples of VB (VB = 16, 8 or 4)
           const int px_in = min((int)K2_TW, a.proj_w - (int)(tile_x * K2_TW));
