@@ -16,7 +16,23 @@ class xmo_tables(C.Structure):
                 ("turbo_bgr", C.c_void_p)]
 
 
+def physical_cores() -> int:
+    """cores, not SMT threads (Linux topology files; falls back to half of os.cpu_count())"""
+    seen = set()
+    try:
+        for d in os.listdir("/sys/devices/system/cpu"):
+            if d.startswith("cpu") and d[3:].isdigit():
+                with open(f"/sys/devices/system/cpu/{d}/topology/thread_siblings_list") as f:
+                    seen.add(f.read().strip())
+    except OSError:
+        seen = set()
+    return len(seen) or max(1, (os.cpu_count() or 2) // 2)
+
+
 def load(omp=False):
+    if omp:  # (read by libgomp when it is loaded: threads stay on their cores, one per core)
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
     name = "libxmaps_oracle_omp.so" if omp else "libxmaps_oracle.so"
     path = os.path.join(HERE, name)
     src = os.path.join(HERE, "xmaps_oracle.c")
@@ -25,13 +41,20 @@ def load(omp=False):
     lib = C.CDLL(path)
     lib.xmo_process_frame.restype = C.c_int
     lib.xmo_num_threads.restype = C.c_int
+    lib.xmo_set_num_threads.argtypes = [C.c_int]
+    lib.xmo_set_num_threads.restype = None
     return lib
 
 
 class COracle:
-    def __init__(self, tables, camera_perspective=False, omp=False):
+    def __init__(self, tables, camera_perspective=False, omp=False, threads=0, reuse_outputs=False):
+        """threads (omp only): 0 = one per physical core; reuse_outputs: process_ev_frame hands out the SAME output arrays every
+        call (the timed baseline: no 20 MB of fresh pages per frame)"""
         from xmaps_oracle import _turbo_bgr
         self.lib = load(omp)
+        if omp:
+            self.lib.xmo_set_num_threads(int(threads) if threads else physical_cores())
+        self._reuse = {} if reuse_outputs else None
         self.keep = [np.ascontiguousarray(tables[k], dtype=np.int16) for k in
                      ("cam_mapx_i16", "cam_mapy_i16", "proj_x_map", "disp_proj_mapxy_i16")]
         self.turbo = np.ascontiguousarray(_turbo_bgr())
@@ -57,8 +80,13 @@ class COracle:
         y = np.ascontiguousarray(y, np.uint16)
         t = np.ascontiguousarray(t, np.int64)
         n = len(t)
-        out = {"disp_map": np.empty(self.fshape, np.float32), "depth": np.empty(self.oshape, np.float32),
-               "bgr": np.empty(self.oshape + (3,), np.uint8)}
+        if self._reuse is not None and self._reuse:
+            out = dict(self._reuse)
+        else:
+            out = {"disp_map": np.empty(self.fshape, np.float32), "depth": np.empty(self.oshape, np.float32),
+                   "bgr": np.empty(self.oshape + (3,), np.uint8)}
+            if self._reuse is not None:
+                self._reuse = dict(out)
         mask = np.empty(n, np.uint8) if want_events else None
         dev = np.empty(n, np.int16) if want_events else None
         ninl = C.c_int64(0)

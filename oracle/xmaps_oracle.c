@@ -37,6 +37,29 @@ int xmo_num_threads(void) {
 #endif
 }
 
+/* bench.py's all-core leg: one thread per PHYSICAL core (256 SMT threads spinning between six short parallel regions per frame
+ * ran anywhere between 11 and 108 Mev/s on the same box).  No-op without OpenMP. */
+void xmo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+/* scratch of the frame stages, kept between calls (a fresh 9-28 MB malloc per frame is a page fault per 4 KB inside the parallel
+ * regions); the checker has one caller at a time */
+static float* g_scratch[2] = {NULL, NULL};
+static int64_t g_scratch_cells[2] = {0, 0};
+static float* scratch(int which, int64_t cells) {
+  if (g_scratch_cells[which] < cells) {
+    free(g_scratch[which]);
+    g_scratch[which] = (float*)malloc(sizeof(float) * (size_t)cells);
+    g_scratch_cells[which] = g_scratch[which] ? cells : 0;
+  }
+  return g_scratch[which];
+}
+
 /* returns 0, or -1 if an index fell outside a table/frame (NumPy would raise IndexError).
  * Outputs (any may be NULL): key_frame u64 [H][W] scratch supplied by the caller (zeroed here),
  * disp_map f32 [H][W] (rect frame or camera frame), depth f32 / bgr u8 of the OUTPUT frame,
@@ -90,13 +113,13 @@ int xmo_process_frame(const xmo_tables* tb, const uint16_t* x, const uint16_t* y
   if (n_inliers) *n_inliers = inl;
 
   const int ow = tb->camera_view ? tb->cam_w : tb->proj_w, oh = tb->camera_view ? tb->cam_h : tb->proj_h;
-  float* frame = disp_map ? disp_map : (float*)malloc(sizeof(float) * cells);
+  float* frame = disp_map ? disp_map : scratch(0, cells);
 #pragma omp parallel for schedule(static)
   for (int64_t c = 0; c < cells; ++c) frame[c] = key_frame[c] ? (float)(key_frame[c] & 0xffff) : 0.0f;
 
   float* rowmax = NULL;
   if (!tb->camera_view) { /* separable 7x7 max, then nearest gather */
-    rowmax = (float*)malloc(sizeof(float) * cells);
+    rowmax = scratch(1, cells);
 #pragma omp parallel for schedule(static)
     for (int r = 0; r < fh; ++r)
       for (int c = 0; c < fw; ++c) {
@@ -142,8 +165,6 @@ int xmo_process_frame(const xmo_tables* tb, const uint16_t* x, const uint16_t* y
         }
       }
     }
-  if (rowmax) free(rowmax);
-  if (!disp_map) free(frame);
   return err ? -1 : 0;
 }
 

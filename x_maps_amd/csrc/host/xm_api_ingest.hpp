@@ -47,6 +47,12 @@ struct xm_ingest {
   int ahead = 0;                       // packets the ingest stream may run ahead of the handled verdicts
   // device
   IngestDev dev{};                     // what every ingest kernel gets by value (ring, pause ring, state, result ring, ...)
+  // Activity filter: TWO sets of per-(bucket, pixel) cells + control words, taken in turn by the packets (set = staging entry & 1):
+  // the first pass of packet p (k_act_first: fills the packet's cells) then depends on nothing of packet p - 1 and is issued by the
+  // COPY side, behind the packet's H2D copy on that stream -- one launch less on the launch thread, whose runtime calls per packet
+  // are what bounds the stream with the filter on (profiles/r05_ingest.md).  A set is free again once packet p - 2 has cleared it
+  // (k_ing_append) and reset its flags (k_ing_segment): when that packet's verdict has been handled.
+  ActDev act_base{};                   // set 0 (dev.act is pointed at the packet's set before its kernels are launched)
   static constexpr int VRING = 64;     // per-packet rings: frame descriptor, frame info (device), verdict (pinned host)
   FrameDesc* d_descs = nullptr;
   IngFrameInfo* d_infos = nullptr;
@@ -95,6 +101,7 @@ struct xm_ingest {
   bool opt_out_no_query = false;       // "XM_INGEST_OUT_NO_QUERY"
   bool opt_evt3_out_stream = false;    // "XM_INGEST_EVT3_OUT_STREAM"
   bool opt_trace = false;              // "XM_INGEST_TRACE"
+  bool opt_act_on_launch_side = false; // "XM_INGEST_ACT_ON_LAUNCH_SIDE": k_act_first issued by the launch thread on the ingest stream, as in round 5 (A/B)
   double t_out_wait_s = 0.0;           // XM_INGEST_TRACE: launch side waiting for the out side to have enqueued frame f - NOUT
   double t_out_s = 0.0;                // XM_INGEST_TRACE: host seconds the out side spent enqueuing
   float* d_out_depth[NOUT] = {};
@@ -144,6 +151,8 @@ struct xm_ingest {
     xm_evt3* dec = nullptr;
     bool pinned = true;
     bool arrived = false;              // the copy side has issued the packet's H2D copy / the chunk's decoding and recorded copied_ev[k]
+    bool act_done = false;             // ... and the activity filter's first pass (k_act_first) behind it, on the same stream
+    uint64_t push_no = 0;              // number of the push (from 1; the caller's count = the launch side's `issued` + 1 when its turn comes)
   };
   static constexpr unsigned QCAP = 64;
   Job queue[QCAP];
@@ -493,6 +502,30 @@ int ingest_handle_verdicts(xm_ingest* g, uint64_t block_upto) {
   return XM_OK;
 }
 
+// the activity filter's state as packet `k` (staging entry) sees it: its set of cells and control words
+ActDev ingest_act_set(const xm_ingest* g, int k) {
+  ActDev a = g->act_base;
+  if (a.last_ts && (k & 1)) {
+    a.cells += (size_t)a.cam_w * (size_t)a.cam_h * ACT_NB;
+    a.ctl += 4;
+  }
+  return a;
+}
+
+// The copy side's share of the activity filter (only with a copy thread: it must not be the thread that handles the verdicts it
+// waits for): k_act_first of packet push_no on `stream`, behind what brought the packet to d_pkt[k].  Returns true when launched.
+bool ingest_act_first_on_copy_side(xm_ingest* g, int k, size_t n, const u32* n_dev, uint64_t push_no, hipStream_t stream) {
+  if (!g->copy_threaded || !g->act_base.last_ts || !n || !push_no || g->opt_act_on_launch_side) return false;
+  // the set's previous packet (push_no - 2) must have emptied the cells and reset the flags: its verdict has been handled
+  while (g->handled.load(std::memory_order_acquire) + 2 < push_no) {
+    if (g->q_error.load(std::memory_order_relaxed)) return false;
+    __builtin_ia32_pause();
+  }
+  hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_THREADS - 1) / ING_THREADS)), dim3(ING_THREADS), 0, stream, ingest_act_set(g, k),
+                     (const uint4*)g->d_pkt[k], n_dev, (u32)n, g->cfg.use_polarity ? 1 : 0);
+  return hipGetLastError() == hipSuccess;
+}
+
 // the three ingest launches of one (sub-)packet
 void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
   const unsigned nb = (bound + ING_EPB - 1) / ING_EPB;
@@ -506,7 +539,7 @@ void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
 // everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation.  hp = the packet in host memory (unused: the
 // activity filter is evaluated on the device for every kind of packet); NULL for a packet decoded on the device, whose event
 // count then lives at n_dev (device memory) and n is the room of its slot
-int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr) {
+int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr, bool act_done = false) {
   xm_handle* h = g->h;
   hipStream_t s = g->stream;
   // the ingest stream stays at most `ahead` packets in front of the verdicts handled here
@@ -545,7 +578,8 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
   // like records.
   // (On the ingest stream like the rest: a stream of its own -- a fifth one beside the handle's four hardware queues -- measured
   //  61 us per packet against 47; on the stream the packet arrives on, beside the previous packet's kernels, no different.)
-  if (g->dev.act.last_ts && n)
+  g->dev.act = ingest_act_set(g, k);  // (the packet's set of cells: k_ing_count reads them, k_ing_append empties them, k_ing_segment resets its flags)
+  if (g->dev.act.last_ts && n && !act_done)
     hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_THREADS - 1) / ING_THREADS)), dim3(ING_THREADS), 0, s, g->dev.act,
                        (const uint4*)g->d_pkt[k], n_dev, (u32)n, g->cfg.use_polarity ? 1 : 0);
   ingest_launch3(g, p, (u32)n);
@@ -556,25 +590,27 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
 }
 
 // one packet of records, the copy side: H2D on the copy stream (beside the previous packets' kernels) + the event behind it
-int ingest_copy_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
+int ingest_copy_records(xm_ingest* g, int k, size_t n, const uint4* hp, uint64_t push_no = 0, bool* act_done = nullptr) {
   if (n) {
     HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
+    const bool done = ingest_act_first_on_copy_side(g, k, n, nullptr, push_no, g->copy_stream);
+    if (act_done) *act_done = done;
     HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
   }
   return XM_OK;
 }
 
 // ... the launch side: everything else (arrived: the copy side has done its part already)
-int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp, bool arrived) {
+int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp, bool arrived, bool act_done = false) {
   g->out_serial_now = false;
   int rc = arrived ? XM_OK : ingest_copy_records(g, k, n, hp);
   if (rc) return rc;
   if (n) HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
-  return ingest_process(g, k, n, hp);
+  return ingest_process(g, k, n, hp, nullptr, arrived && act_done);
 }
 
-int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned);                 // (xm_api_evt3.hpp)
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived);  // (xm_api_evt3.hpp)
+int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, uint64_t push_no = 0, bool* act_done = nullptr);  // (xm_api_evt3.hpp)
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived, bool act_done = false);          // (xm_api_evt3.hpp)
 
 // every verdict in, every frame's kernels launched and run
 int ingest_finish(xm_ingest* g) {
@@ -590,8 +626,8 @@ int ingest_finish(xm_ingest* g) {
 
 int ingest_run_job(xm_ingest* g, const xm_ingest::Job& j) {
   switch (j.kind) {
-    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host, j.arrived);
-    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.arrived);
+    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host, j.arrived, j.act_done);
+    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.arrived, j.act_done);
     case 3: return ingest_process(g, j.k, j.n, nullptr);
     case 4: return ingest_finish(g);
     default: return XM_OK;
@@ -694,7 +730,10 @@ void ingest_copy_thread_main(xm_ingest* g) {
     xm_ingest::Job j = g->cqueue[t % xm_ingest::QCAP];
     g->c_tail.store(t + 1, std::memory_order_release);
     if ((j.kind == 0 || j.kind == 1) && !g->q_error.load(std::memory_order_relaxed)) {
-      const int rc = j.kind == 0 ? ingest_copy_records(g, j.k, j.n, (const uint4*)j.host) : ingest_copy_evt3(g, j.dec, j.k, j.host, j.n, j.pinned);
+      bool act_done = false;
+      const int rc = j.kind == 0 ? ingest_copy_records(g, j.k, j.n, (const uint4*)j.host, j.push_no, &act_done)
+                                 : ingest_copy_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.push_no, &act_done);
+      j.act_done = act_done;
       if (rc != XM_OK) {
         if (g->q_error.load(std::memory_order_relaxed) == 0) {
           g->q_error_text = g_err;  // thread-local text of this thread
@@ -812,6 +851,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   if (const char* e = dbg_opt("XM_INGEST_HOST_SEQ")) g->host_seq = e[0] != '0';
   g->opt_evt3_out_stream = dbg_opt("XM_INGEST_EVT3_OUT_STREAM") != nullptr;
   g->opt_trace = dbg_opt("XM_INGEST_TRACE") != nullptr;
+  g->opt_act_on_launch_side = dbg_opt("XM_INGEST_ACT_ON_LAUNCH_SIDE") != nullptr;
   IngestDev& d = g->dev;
   d.cap = g->capacity;
   d.room = g->max_packet * (u64)(1 + g->ahead);
@@ -821,7 +861,8 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipMalloc((void**)&d.pring, d.pcap * 8));
   ING_TRY(hipMalloc((void**)&d.blk, sizeof(IngBlk) * ING_MAX_BLOCKS));
   if (cfg->activity_filter) {
-    int rc_ = act_alloc(&d.act, h->tb.cam_w, h->tb.cam_h, g->act_thresh, (size_t)g->max_packet);
+    int rc_ = act_alloc(&d.act, h->tb.cam_w, h->tb.cam_h, g->act_thresh, (size_t)g->max_packet, 2);
+    g->act_base = d.act;
     if (rc_) {
       xm_ingest_destroy(g);
       return rc_;
@@ -940,7 +981,8 @@ void xm_ingest_destroy(xm_ingest* g) {
   if (d.buf) (void)hipFree(d.buf);
   if (d.pring) (void)hipFree(d.pring);
   if (d.blk) (void)hipFree(d.blk);
-  act_free(&d.act);
+  act_free(&g->act_base);
+  d.act = ActDev{};
   if (d.st) (void)hipFree(d.st);
   if (d.key_frame) (void)hipFree(d.key_frame);
   if (d.slot) (void)hipFree(d.slot);
@@ -1013,7 +1055,7 @@ static int ingest_push(xm_ingest* g, const void* eventcd16, size_t n, bool pinne
   g->pkt_push[k] = g->posted;
   g->push_t[g->posted % xm_ingest::VRING] = c0;
   xm_ingest::Job j;
-  j.kind = 0; j.k = k; j.n = n; j.host = hp;
+  j.kind = 0; j.k = k; j.n = n; j.host = hp; j.push_no = g->posted;
   rc = ingest_submit(g, j, false);
   g->push_host_s += ingest_now() - c0;
   g->push_calls += 1;
@@ -1231,9 +1273,9 @@ int xm_ingest_reset(xm_ingest* g) {
   // depth_reprojection.py:76) and its stamps then start below everything the history holds -- against the old history every
   // event with a neighbour that ever fired would pass.  (Metavision's filter object keeps its state there; the frames behind
   // the first period of a loop are what differs.)
-  if (g->dev.act.last_ts) {
-    std::vector<long long> init((size_t)g->dev.act.cam_w * g->dev.act.cam_h, ING_NO_TS);
-    HIP_TRY(hipMemcpy(g->dev.act.last_ts, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+  if (g->act_base.last_ts) {
+    std::vector<long long> init((size_t)g->act_base.cam_w * g->act_base.cam_h, ING_NO_TS);
+    HIP_TRY(hipMemcpy(g->act_base.last_ts, init.data(), init.size() * 8, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipDeviceSynchronize());  // (default-stream work: the ingest's non-blocking streams do not wait for it)
   return XM_OK;
@@ -1350,12 +1392,12 @@ int xm_activity_stats(xm_activity* f, uint64_t* sequential_packets) {
 int xm_ingest_activity_stats(xm_ingest* g, uint64_t* sequential_packets) {
   if (!g) return fail(XM_ERR_INVALID, "NULL argument");
   if (sequential_packets) *sequential_packets = 0;
-  if (!g->dev.act.last_ts) return XM_OK;
+  if (!g->act_base.last_ts) return XM_OK;
   int rc = xm_ingest_flush(g);
   if (rc) return rc;
-  u32 c[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpy(c, g->dev.act.ctl, sizeof c, hipMemcpyDeviceToHost));
-  if (sequential_packets) *sequential_packets = c[2];
+  u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (both sets' control words)
+  HIP_TRY(hipMemcpy(c, g->act_base.ctl, sizeof c, hipMemcpyDeviceToHost));
+  if (sequential_packets) *sequential_packets = (uint64_t)c[2] + c[6];
   return XM_OK;
 }
 

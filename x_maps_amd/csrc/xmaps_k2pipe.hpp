@@ -36,6 +36,17 @@ __host__ __device__ inline bool k2_pipe_tile_ok(const int4& rec) {
 // This one waits for the wave's LDS operations and joins the barrier; the prefetched registers are waited for where they are used.
 __device__ __forceinline__ void k2p_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// the output frames are written once and not read again by any kernel: XM_K2P_NT = 1 marks their stores non-temporal (experiment)
+#ifndef XM_K2P_NT
+#define XM_K2P_NT 0
+#endif
+typedef u32 k2p_u32x4 __attribute__((ext_vector_type(4)));
+#if XM_K2P_NT
+#define k2p_store(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define k2p_store(ptr, val) (*(ptr) = (val))  /* (a macro: a template parameter would drop the pointee's 4-byte alignment) */
+#endif
+
 struct K2PipeArgs {  // (only what the loop needs: the whole DevTables would sit in scalar registers across it)
   int proj_w, proj_h, rect_w, rect_h, shear_m, shear_bias;
 };
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
               if constexpr (PPT >= 4) {
 #pragma unroll
                 for (int q = 0; q < PPT; q += 4)
-                  reinterpret_cast<XM_K2P_GLOBAL uint4*>(dp)[q >> 2] = make_uint4(e[q].x, e[q + 1].x, e[q + 2].x, e[q + 3].x);
+                  k2p_store(reinterpret_cast<XM_K2P_GLOBAL k2p_u32x4*>(dp) + (q >> 2), (k2p_u32x4{e[q].x, e[q + 1].x, e[q + 2].x, e[q + 3].x}));
               } else {
                 *reinterpret_cast<XM_K2P_GLOBAL uint2*>(dp) = make_uint2(e[0].x, e[1].x);
               }
@@ -279,7 +290,10 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
               if (u0 + q < a.proj_w) dp[q] = __uint_as_float(e[q].x);
           }
         }
-        if (bgr && PPT == 4 && (a.proj_w & 3) == 0 && ((u32)(size_t)bgr & 3u) == 0 && !XM_K2P_STAGED) {
+        bool bgr_direct = false;
+        if constexpr (PPT == 4 && !XM_K2P_STAGED) bgr_direct = bgr && (a.proj_w & 3) == 0 && ((u32)(size_t)bgr & 3u) == 0;
+        if (bgr_direct) {
+         if constexpr (PPT == 4) {
           // Four consecutive pixels = 12 bytes = three dwords per thread, a row's threads back to back: ONE global_store_dwordx3
           // per thread (4-byte aligned: u0 and the frame's row length are multiples of four pixels), the wave's lanes = runs of
           // K2_TX * 12 contiguous bytes.  No staging through LDS, no barrier for it (round 6: the staged rows cost three LDS
@@ -288,12 +302,13 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
           if (u0 < a.proj_w && v < a.proj_h) {
             typedef u32 u32x3 __attribute__((ext_vector_type(3)));
             typedef u32x3 __attribute__((aligned(4))) u32x3_a4;
-            u32x3 w;
+            u32x3_a4 w;
             w.x = (e[0].y & 0xffffffu) | (e[1].y << 24);
             w.y = ((e[1].y >> 8) & 0xffffu) | (e[2].y << 16);
             w.z = ((e[2].y >> 16) & 0xffu) | (e[3].y << 8);
-            *reinterpret_cast<XM_K2P_GLOBAL u32x3_a4*>(bgr + (size_t)(__umul24((u32)v, (u32)a.proj_w) + (u32)u0) * 3u) = w;
+            k2p_store(reinterpret_cast<XM_K2P_GLOBAL u32x3_a4*>(bgr + (size_t)(__umul24((u32)v, (u32)a.proj_w) + (u32)u0) * 3u), w);
           }
+         }
         } else if (bgr) {
           // the row's bytes of this tile: valid_b of them inside the image.  Vector stores of VB bytes when the frame's rows, the
           // tile's first byte and the valid run are all multiples of VB (VB = 16, 8 or 4)
