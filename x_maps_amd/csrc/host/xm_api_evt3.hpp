@@ -73,15 +73,12 @@ int evt3_run(xm_evt3* d, const void* words_host, size_t n_words, bool pinned, ui
 }
 
 // one chunk of words, the copy side: H2D + the three decode launches on the decoder's stream + the event behind them
-int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, uint64_t push_no, bool* act_done) {
+int ingest_words_to_events(const xm_evt3* d) { return d && d->format == 2 ? 1 : 12; }
+
+int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned) {
   if (n_words) {
     int rc = evt3_enqueue(d, words, n_words, pinned, g->d_pkt[k], (size_t)g->max_packet, d->stream, g->d_pkt_n + k);
     if (rc) return rc;
-    {  // (the activity filter's first pass behind the decoding, on the decoder's stream: see ingest_act_first_on_copy_side)
-      const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * (d->format == 2 ? 1 : 12));
-      const bool done = ingest_act_first_on_copy_side(g, k, bound, g->d_pkt_n + k, push_no, d->stream);
-      if (act_done) *act_done = done;
-    }
     HIP_TRY(hipEventRecord(g->copied_ev[k], d->stream));
     d->cur ^= 1;
   }
@@ -89,14 +86,14 @@ int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t 
 }
 
 // ... the launch side: everything behind it, nothing waited for: the ingest's kernels read the chunk's event count on the device
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived, bool act_done) {
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived) {
   g->out_serial_now = !g->opt_evt3_out_stream;  // (see xm_ingest::out_serial_now)
   int rc0 = arrived ? XM_OK : ingest_copy_evt3(g, d, k, words, n_words, pinned);
   if (rc0) return rc0;
   if (n_words) HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
   // (upper bound of the chunk's events for the host's bookkeeping: an EVT 3.0 vector word yields up to 12, everything else at most one)
   const size_t bound = std::min<size_t>((size_t)g->max_packet, n_words * (d->format == 2 ? 1 : 12));
-  return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? g->d_pkt_n + k : nullptr, arrived && act_done);
+  return ingest_process(g, k, n_words ? bound : 0, nullptr, n_words ? g->d_pkt_n + k : nullptr);
 }
 
 }  // namespace

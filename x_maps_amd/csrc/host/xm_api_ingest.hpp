@@ -48,10 +48,13 @@ struct xm_ingest {
   // device
   IngestDev dev{};                     // what every ingest kernel gets by value (ring, pause ring, state, result ring, ...)
   // Activity filter: TWO sets of per-(bucket, pixel) cells + control words, taken in turn by the packets (set = staging entry & 1):
-  // the first pass of packet p (k_act_first: fills the packet's cells) then depends on nothing of packet p - 1 and is issued by the
-  // COPY side, behind the packet's H2D copy on that stream -- one launch less on the launch thread, whose runtime calls per packet
-  // are what bounds the stream with the filter on (profiles/r05_ingest.md).  A set is free again once packet p - 2 has cleared it
-  // (k_ing_append) and reset its flags (k_ing_segment): when that packet's verdict has been handled.
+  // the first pass of packet p (k_act_first: fills the packet's cells) then depends on nothing of packet p - 1 -- only on packet
+  // p - 2 having emptied the set (k_ing_append) and reset its flags (k_ing_segment).  When packet p is already on its way to the
+  // device while packet p - 1 is being launched (a replay, a camera ahead of the GPU), its first pass goes out INSIDE packet p - 1's
+  // k_ing_count launch (k_ing_count_act, ingest_launch3): the stream's chain per packet is count -> append -> segment with the filter
+  // on as with it off (round 6: 930-990 -> 1070-1095 Mev/s on the ESL-like stream; the first pass on the copy stream, behind the
+  // packet's DMA, held up the next packet's copy and ran 705-1000, on the frame stream 600: profiles/r06_ingest.md).  A packet
+  // that arrives alone (a live camera) gets its first pass as a launch of its own in front of its k_ing_count, as in round 5.
   ActDev act_base{};                   // set 0 (dev.act is pointed at the packet's set before its kernels are launched)
   static constexpr int VRING = 64;     // per-packet rings: frame descriptor, frame info (device), verdict (pinned host)
   FrameDesc* d_descs = nullptr;
@@ -101,7 +104,10 @@ struct xm_ingest {
   bool opt_out_no_query = false;       // "XM_INGEST_OUT_NO_QUERY"
   bool opt_evt3_out_stream = false;    // "XM_INGEST_EVT3_OUT_STREAM"
   bool opt_trace = false;              // "XM_INGEST_TRACE"
-  bool opt_act_on_launch_side = false; // "XM_INGEST_ACT_ON_LAUNCH_SIDE": k_act_first issued by the launch thread on the ingest stream, as in round 5 (A/B)
+  bool opt_act_fuse = true;            // "XM_INGEST_ACT_FUSE" = 0: never ride k_act_first of the NEXT packet on this packet's k_ing_count launch (A/B)
+  uint64_t act_fused_push = 0;         // launch side: the packet whose k_act_first went out with its predecessor's k_ing_count (k_ing_count_act)
+  uint64_t act_fused_count = 0;        // ... how many did (statistics)
+  const void* next_job = nullptr;      // launch side: the job queued behind the one being run, if it is a packet that has arrived (else NULL)
   double t_out_wait_s = 0.0;           // XM_INGEST_TRACE: launch side waiting for the out side to have enqueued frame f - NOUT
   double t_out_s = 0.0;                // XM_INGEST_TRACE: host seconds the out side spent enqueuing
   float* d_out_depth[NOUT] = {};
@@ -151,7 +157,6 @@ struct xm_ingest {
     xm_evt3* dec = nullptr;
     bool pinned = true;
     bool arrived = false;              // the copy side has issued the packet's H2D copy / the chunk's decoding and recorded copied_ev[k]
-    bool act_done = false;             // ... and the activity filter's first pass (k_act_first) behind it, on the same stream
     uint64_t push_no = 0;              // number of the push (from 1; the caller's count = the launch side's `issued` + 1 when its turn comes)
   };
   static constexpr unsigned QCAP = 64;
@@ -502,6 +507,8 @@ int ingest_handle_verdicts(xm_ingest* g, uint64_t block_upto) {
   return XM_OK;
 }
 
+int ingest_words_to_events(const xm_evt3* d);  // (xm_api_evt3.hpp) upper bound of the events one word of the decoder's format yields
+
 // the activity filter's state as packet `k` (staging entry) sees it: its set of cells and control words
 ActDev ingest_act_set(const xm_ingest* g, int k) {
   ActDev a = g->act_base;
@@ -512,25 +519,28 @@ ActDev ingest_act_set(const xm_ingest* g, int k) {
   return a;
 }
 
-// The copy side's share of the activity filter (only with a copy thread: it must not be the thread that handles the verdicts it
-// waits for): k_act_first of packet push_no on `stream`, behind what brought the packet to d_pkt[k].  Returns true when launched.
-bool ingest_act_first_on_copy_side(xm_ingest* g, int k, size_t n, const u32* n_dev, uint64_t push_no, hipStream_t stream) {
-  if (!g->copy_threaded || !g->act_base.last_ts || !n || !push_no || g->opt_act_on_launch_side) return false;
-  // the set's previous packet (push_no - 2) must have emptied the cells and reset the flags: its verdict has been handled
-  while (g->handled.load(std::memory_order_acquire) + 2 < push_no) {
-    if (g->q_error.load(std::memory_order_relaxed)) return false;
-    __builtin_ia32_pause();
-  }
-  hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_THREADS - 1) / ING_THREADS)), dim3(ING_THREADS), 0, stream, ingest_act_set(g, k),
-                     (const uint4*)g->d_pkt[k], n_dev, (u32)n, g->cfg.use_polarity ? 1 : 0);
-  return hipGetLastError() == hipSuccess;
-}
-
-// the three ingest launches of one (sub-)packet
+// the three ingest launches of one (sub-)packet.  With the activity filter on and the NEXT packet already on its way to the device
+// (g->next_job: a replay, or a camera that is ahead of the GPU), that packet's first pass (k_act_first) rides on this packet's
+// k_ing_count launch (k_ing_count_act: the other set of cells) instead of being a link of its own in the chain of the stream.
 void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
   const unsigned nb = (bound + ING_EPB - 1) / ING_EPB;
   if (nb) {
-    hipLaunchKernelGGL(k_ing_count, dim3(nb), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
+    const xm_ingest::Job* nx = (const xm_ingest::Job*)g->next_job;
+    bool fused = false;
+    if (nx && g->dev.act.last_ts && g->opt_act_fuse) {
+      const bool words = nx->kind == 1;
+      const size_t n2 = words ? std::min<size_t>((size_t)g->max_packet, nx->n * (size_t)ingest_words_to_events(nx->dec)) : nx->n;
+      const unsigned nb2 = (unsigned)((n2 + ING_THREADS - 1) / ING_THREADS);
+      if (n2 && hipStreamWaitEvent(g->stream, g->copied_ev[nx->k], 0) == hipSuccess) {
+        hipLaunchKernelGGL(k_ing_count_act, dim3(nb + nb2), dim3(ING_THREADS), 0, g->stream, g->dev, pp, (u32)nb, ingest_act_set(g, nx->k),
+                           (const uint4*)g->d_pkt[nx->k], words ? (const u32*)(g->d_pkt_n + nx->k) : (const u32*)nullptr, (u32)n2,
+                           g->cfg.use_polarity ? 1 : 0);
+        g->act_fused_push = pp.push_no + 1;
+        g->act_fused_count += 1;
+        fused = true;
+      }
+    }
+    if (!fused) hipLaunchKernelGGL(k_ing_count, dim3(nb), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
     hipLaunchKernelGGL(k_ing_append, dim3(nb), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
   }
   hipLaunchKernelGGL(k_ing_segment, dim3(1), dim3(ING_THREADS), 0, g->stream, g->dev, pp);
@@ -539,7 +549,7 @@ void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
 // everything behind the packet's arrival in d_pkt[k]: filters, append, segmentation.  hp = the packet in host memory (unused: the
 // activity filter is evaluated on the device for every kind of packet); NULL for a packet decoded on the device, whose event
 // count then lives at n_dev (device memory) and n is the room of its slot
-int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr, bool act_done = false) {
+int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_dev = nullptr) {
   xm_handle* h = g->h;
   hipStream_t s = g->stream;
   // the ingest stream stays at most `ahead` packets in front of the verdicts handled here
@@ -573,13 +583,11 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
   p.src = g->d_pkt[k];
   p.n = (u32)n;
   p.n_dev = n_dev;
-  // activity filter: one more launch (the per-(bucket, pixel) cells of the packet, one event per thread; xmaps_ingest.hpp) -- the
-  // flags themselves are computed by k_ing_count as it counts.  Nothing is decided here: a chunk decoded on the device is treated
-  // like records.
-  // (On the ingest stream like the rest: a stream of its own -- a fifth one beside the handle's four hardware queues -- measured
-  //  61 us per packet against 47; on the stream the packet arrives on, beside the previous packet's kernels, no different.)
+  // activity filter: the packet's first pass (the per-(bucket, pixel) cells, one event per thread; xmaps_ingest.hpp) -- unless it
+  // went out with the packet before (ingest_launch3) -- then the flags themselves are computed by k_ing_count as it counts.
+  // Nothing is decided here: a chunk decoded on the device is treated like records.
   g->dev.act = ingest_act_set(g, k);  // (the packet's set of cells: k_ing_count reads them, k_ing_append empties them, k_ing_segment resets its flags)
-  if (g->dev.act.last_ts && n && !act_done)
+  if (g->dev.act.last_ts && n && g->act_fused_push != push_no)  // (fused: it went out with the packet before, ingest_launch3)
     hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_THREADS - 1) / ING_THREADS)), dim3(ING_THREADS), 0, s, g->dev.act,
                        (const uint4*)g->d_pkt[k], n_dev, (u32)n, g->cfg.use_polarity ? 1 : 0);
   ingest_launch3(g, p, (u32)n);
@@ -590,27 +598,25 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
 }
 
 // one packet of records, the copy side: H2D on the copy stream (beside the previous packets' kernels) + the event behind it
-int ingest_copy_records(xm_ingest* g, int k, size_t n, const uint4* hp, uint64_t push_no = 0, bool* act_done = nullptr) {
+int ingest_copy_records(xm_ingest* g, int k, size_t n, const uint4* hp) {
   if (n) {
     HIP_TRY(hipMemcpyAsync(g->d_pkt[k], hp, n * 16, hipMemcpyHostToDevice, g->copy_stream));
-    const bool done = ingest_act_first_on_copy_side(g, k, n, nullptr, push_no, g->copy_stream);
-    if (act_done) *act_done = done;
     HIP_TRY(hipEventRecord(g->copied_ev[k], g->copy_stream));
   }
   return XM_OK;
 }
 
 // ... the launch side: everything else (arrived: the copy side has done its part already)
-int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp, bool arrived, bool act_done = false) {
+int ingest_issue_records(xm_ingest* g, int k, size_t n, const uint4* hp, bool arrived) {
   g->out_serial_now = false;
   int rc = arrived ? XM_OK : ingest_copy_records(g, k, n, hp);
   if (rc) return rc;
   if (n) HIP_TRY(hipStreamWaitEvent(g->stream, g->copied_ev[k], 0));
-  return ingest_process(g, k, n, hp, nullptr, arrived && act_done);
+  return ingest_process(g, k, n, hp, nullptr);
 }
 
-int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, uint64_t push_no = 0, bool* act_done = nullptr);  // (xm_api_evt3.hpp)
-int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived, bool act_done = false);          // (xm_api_evt3.hpp)
+int ingest_copy_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned);  // (xm_api_evt3.hpp)
+int ingest_issue_evt3(xm_ingest* g, xm_evt3* d, int k, const void* words, size_t n_words, bool pinned, bool arrived);          // (xm_api_evt3.hpp)
 
 // every verdict in, every frame's kernels launched and run
 int ingest_finish(xm_ingest* g) {
@@ -626,8 +632,8 @@ int ingest_finish(xm_ingest* g) {
 
 int ingest_run_job(xm_ingest* g, const xm_ingest::Job& j) {
   switch (j.kind) {
-    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host, j.arrived, j.act_done);
-    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.arrived, j.act_done);
+    case 0: return ingest_issue_records(g, j.k, j.n, (const uint4*)j.host, j.arrived);
+    case 1: return ingest_issue_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.arrived);
     case 3: return ingest_process(g, j.k, j.n, nullptr);
     case 4: return ingest_finish(g);
     default: return XM_OK;
@@ -672,7 +678,15 @@ void ingest_thread_main(xm_ingest* g) {
     g->q_tail.store(t + 1, std::memory_order_release);
     if (j.kind != 2) {
       const double cj = ingest_now();
+      // the job queued behind this one, if it is a packet whose copy / decoding the copy side has issued already (its slot of the
+      // queue is not reused before q_tail passes it)
+      g->next_job = nullptr;
+      if ((j.kind == 0 || j.kind == 1 || j.kind == 3) && g->q_head.load(std::memory_order_acquire) > t + 1) {
+        const xm_ingest::Job& c = g->queue[(t + 1) % xm_ingest::QCAP];
+        if ((c.kind == 0 || c.kind == 1) && c.arrived && c.n) g->next_job = &c;
+      }
       note(ingest_run_job(g, j));
+      g->next_job = nullptr;
       g->t_jobs_s += ingest_now() - cj;
     }
     g->q_done.store(t + 1, std::memory_order_release);
@@ -730,10 +744,7 @@ void ingest_copy_thread_main(xm_ingest* g) {
     xm_ingest::Job j = g->cqueue[t % xm_ingest::QCAP];
     g->c_tail.store(t + 1, std::memory_order_release);
     if ((j.kind == 0 || j.kind == 1) && !g->q_error.load(std::memory_order_relaxed)) {
-      bool act_done = false;
-      const int rc = j.kind == 0 ? ingest_copy_records(g, j.k, j.n, (const uint4*)j.host, j.push_no, &act_done)
-                                 : ingest_copy_evt3(g, j.dec, j.k, j.host, j.n, j.pinned, j.push_no, &act_done);
-      j.act_done = act_done;
+      const int rc = j.kind == 0 ? ingest_copy_records(g, j.k, j.n, (const uint4*)j.host) : ingest_copy_evt3(g, j.dec, j.k, j.host, j.n, j.pinned);
       if (rc != XM_OK) {
         if (g->q_error.load(std::memory_order_relaxed) == 0) {
           g->q_error_text = g_err;  // thread-local text of this thread
@@ -851,7 +862,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   if (const char* e = dbg_opt("XM_INGEST_HOST_SEQ")) g->host_seq = e[0] != '0';
   g->opt_evt3_out_stream = dbg_opt("XM_INGEST_EVT3_OUT_STREAM") != nullptr;
   g->opt_trace = dbg_opt("XM_INGEST_TRACE") != nullptr;
-  g->opt_act_on_launch_side = dbg_opt("XM_INGEST_ACT_ON_LAUNCH_SIDE") != nullptr;
+  if (const char* e = dbg_opt("XM_INGEST_ACT_FUSE")) g->opt_act_fuse = e[0] != '0';
   IngestDev& d = g->dev;
   d.cap = g->capacity;
   d.room = g->max_packet * (u64)(1 + g->ahead);

@@ -242,17 +242,18 @@ __device__ inline void act_sequential(const ActDev& a, const uint4* __restrict__
   }
 }
 
-// Pass 1 of a packet: the (bucket, pixel) cells and the check that the buckets run forwards.  One event per thread: a quarter-period packet of the reference's rig
+// Pass 1 of a packet: the (bucket, pixel) cells and the check that the buckets run forwards.  (A launch of its own, k_act_first, or --
+// the ingest, when the packet is on the device early enough -- the tail blocks of the packet before's k_ing_count launch: k_ing_count_act.)  One event per thread: a quarter-period packet of the reference's rig
 // (~42 k events) is 165 blocks -- the work is a divergent atomic or two per event, which wants the whole chip.
-__global__ __launch_bounds__(ING_THREADS) void k_act_first(ActDev a, const uint4* __restrict__ src, const u32* __restrict__ n_dev, u32 n_room,
-                                                           int use_pol) {
+__device__ __forceinline__ void act_first_body(const ActDev& a, const uint4* __restrict__ src, const u32* __restrict__ n_dev, u32 n_room, int use_pol,
+                                               const u32 blk) {
   u32 n = n_room;
   if (n_dev) {
     const u32 m = *n_dev;
     n = m < n_room ? m : n_room;
   }
   const u32 tid = threadIdx.x;
-  const u32 i = blockIdx.x * ING_THREADS + tid;
+  const u32 i = blk * ING_THREADS + tid;
   bool bad = false;
   if (i < n) {
     const long long t0 = rec_t(src[0]), W = a.thresh + 1;
@@ -278,6 +279,11 @@ __global__ __launch_bounds__(ING_THREADS) void k_act_first(ActDev a, const uint4
   //  measured as 20 us for this kernel with a "last block finishes the job" pattern against 5 without; the kernel boundary in
   //  front of k_act_mark publishes the cells and the flag for free)
   if (bad) __hip_atomic_store(&a.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(ING_THREADS) void k_act_first(ActDev a, const uint4* __restrict__ src, const u32* __restrict__ n_dev, u32 n_room,
+                                                           int use_pol) {
+  act_first_body(a, src, n_dev, n_room, use_pol, blockIdx.x);
 }
 
 // Pass 2, per event (parallel path): is event i of the packet kept?  (cells complete: k_act_first has run)
@@ -455,13 +461,13 @@ __device__ inline void ing_block_local(const IngestPush& p, const ActDev& act, u
   L.n_pauses = s.cnt[0][0] + s.cnt[0][1] + s.cnt[0][2] + s.cnt[0][3];
 }
 
-__global__ __launch_bounds__(ING_THREADS) void k_ing_count(IngestDev d, IngestPush p) {
+__device__ __forceinline__ void ing_count_body(const IngestDev& d, const IngestPush& p, const u32 blk) {
   __shared__ IngShared s;
   const u32 n = ing_packet_n(p);
   const u32 nb = (n + ING_EPB - 1) / ING_EPB;
-  if (blockIdx.x >= nb) return;
+  if (blk >= nb) return;
   IngLocal L;
-  ing_block_local<true>(p, d.act, n, blockIdx.x, d.pause_thresh, s, L);
+  ing_block_local<true>(p, d.act, n, blk, d.pause_thresh, s, L);
   if (threadIdx.x == 0) {
     IngBlk o;
     o.kept = L.n_kept;
@@ -469,8 +475,20 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_count(IngestDev d, IngestPu
     o.first_t = L.n_kept ? s.t[0] : 0;
     o.last_t = L.n_kept ? s.t[L.n_kept - 1] : 0;
     o.pad = 0;
-    d.blk[blockIdx.x] = o;
+    d.blk[blk] = o;
   }
+}
+
+__global__ __launch_bounds__(ING_THREADS) void k_ing_count(IngestDev d, IngestPush p) { ing_count_body(d, p, blockIdx.x); }
+
+// k_ing_count of packet k and, in the same launch, the activity filter's first pass of packet k + 1 (already on the device: a
+// replay, or a camera that is ahead of the GPU): blocks [0, nb_count) count, the blocks behind them fill packet k + 1's cells --
+// the OTHER set of cells (xm_ingest: two sets, taken in turns), emptied by k_ing_append of packet k - 1, which ran in front of
+// this launch.  The two halves touch nothing in common; the first pass then costs no link in the stream's chain of launches.
+__global__ __launch_bounds__(ING_THREADS) void k_ing_count_act(IngestDev d, IngestPush p, u32 nb_count, ActDev a2, const uint4* __restrict__ src2,
+                                                               const u32* __restrict__ n_dev2, u32 n_room2, int use_pol2) {
+  if (blockIdx.x < nb_count) ing_count_body(d, p, blockIdx.x);
+  else act_first_body(a2, src2, n_dev2, n_room2, use_pol2, blockIdx.x - nb_count);
 }
 
 // The packet's block records -> what lies in front of block `b` (kept events, pauses) and the packet's totals.  A pause in

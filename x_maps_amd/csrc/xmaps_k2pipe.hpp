@@ -213,6 +213,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
     for (int q = 0; q < PPT; ++q) e[q] = make_uint2(0u, 0u);
     if (m0.run) {
       const int cols = m0.rec.z, rows_p = m0.rec.w;
+      if (!XM_CABL(19))  // (experiments, bit 19: no row-maxima pass)
       {  // 7-tap max along the rows of every patch column, in place (see frame_proj_tiled_body)
         const int nseg = rows_p >> 3, tasks = cols * nseg;
         constexpr int CH = 4;
@@ -239,8 +240,12 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
         const u32 off_q = CONSEC ? (p0[q >> 1] >> ((q & 1) * 16)) & 0xffffu : p0[q];
         if (off_q != (CONSEC ? 0xffffu : ~0u)) {
           const uint16_t* p = tile + off_q;
+          if (XM_CABL(20)) {  // (experiments, bit 20: one tap instead of seven)
+            best = (u32)p[3 * rows_p];
+          } else {
 #pragma unroll
-          for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
+            for (int j = 0; j < 7; ++j) best = max(best, (u32)p[j * rows_p]);
+          }
         }
         if (best < (u32)n_lds) e[q] = s_dlut[best];
         else e[q] = ((const XM_K2P_GLOBAL uint2*)dlut)[min(best, 65535u)];  // (a disparity beyond the LDS copy: x noise far off the scan; the wait drains the prefetch, rarely)
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
               if constexpr (PPT >= 4) {
 #pragma unroll
                 for (int q = 0; q < PPT; q += 4)
+                  if (!XM_CABL(18) || e[q].x == 0x12345678u)  // (experiments, bit 18: no output stores)
                   k2p_store(reinterpret_cast<XM_K2P_GLOBAL k2p_u32x4*>(dp) + (q >> 2), (k2p_u32x4{e[q].x, e[q + 1].x, e[q + 2].x, e[q + 3].x}));
               } else {
                 *reinterpret_cast<XM_K2P_GLOBAL uint2*>(dp) = make_uint2(e[0].x, e[1].x);
@@ -306,6 +312,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
             w.x = (e[0].y & 0xffffffu) | (e[1].y << 24);
             w.y = ((e[1].y >> 8) & 0xffffu) | (e[2].y << 16);
             w.z = ((e[2].y >> 16) & 0xffu) | (e[3].y << 8);
+            if (!XM_CABL(18) || w.x == 0x12345678u)
             k2p_store(reinterpret_cast<XM_K2P_GLOBAL u32x3_a4*>(bgr + (size_t)(__umul24((u32)v, (u32)a.proj_w) + (u32)u0) * 3u), w);
           }
          }
