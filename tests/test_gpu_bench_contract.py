@@ -13,7 +13,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_LINES = {}
+
+
 def _run(*flags, **extra_env):
+    """bench.py with these flags -> its JSON line (an identical invocation is run once per session: several tests read one line)"""
+    key = (flags, tuple(sorted(extra_env.items())))
+    if key not in _LINES:
+        _LINES[key] = _run_bench(*flags, **extra_env)
+    return _LINES[key]
+
+
+def _default_line():
+    # the line as the driver takes it, with everything in it (other engine settings, the other BASELINE configs, a short CPU leg)
+    return _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1")
+
+
+def _run_bench(*flags, **extra_env):
     env = dict(os.environ, XM_BENCH_PREWARM_S="0.05", **extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600, env=env,
                        cwd=ROOT)
@@ -23,7 +39,7 @@ def _run(*flags, **extra_env):
 
 
 def test_default_line_as_the_driver_calls_it():
-    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1", "--no-other-modes")
+    d = _default_line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -50,7 +66,7 @@ def test_default_line_as_the_driver_calls_it():
 
 
 def test_the_default_line_carries_the_other_engine_settings():
-    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path", "--no-other-configs")
+    d = _default_line()
     om = d["other_modes"]
     for k in ("eventcd_records", "one_frame_per_call", "one_frame_per_call_eager", "forced_general", "camera_view"):
         assert om[k]["value"] > 1000 and om[k]["unit"] == "Mevents/s", k
@@ -117,9 +133,9 @@ def _check_roofline(r):
 
 
 def test_default_and_single_frame_lines_carry_the_three_fractions():
-    for flags in (("--steps", "20", "--warmup", "5"), ("--batch", "0", "--no-adaptive", "--steps", "40", "--warmup", "5")):
-        d = _run(*flags, "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
-        _check_roofline(d["roofline"])
+    _check_roofline(_default_line()["roofline"])
+    d = _run("--batch", "0", "--no-adaptive", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-modes", "--no-host-path")
+    _check_roofline(d["roofline"])
 
 
 
@@ -141,7 +157,7 @@ def test_the_default_line_carries_the_other_baseline_configs():
     """the one line the driver records proves every BASELINE config: compact legs for the ESL-like stand-in (configs 0 / 2, with the
     camera-like stream through the device ingest and through the processor), the 60-frame graph (config 4) and the sharded C-10M
     frame (config 3), each with value, ms_per_step, roofline fractions and parity"""
-    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    d = _default_line()
     assert d["n_gpus"] == 1 and d["rccl_ranks_seen"] is None
     oc = d["other_configs"]
     for name in ("esl", "graph60", "sharded_c10m"):

@@ -37,10 +37,3 @@ for i, nm in enumerate(names):
     prev = m
 import subprocess
 print("kernel duration by events:", eng.profile_frame_device(X.data_ptr(), Y.data_ptr(), T.data_ptr(), None, len(t), depth.data_ptr(), None).gpu_ms)
-
-if os.environ.get("XM_STAMP_WAVES"):
-    print("per-wave stamps of block 0 (ticks since the wave-0 start), phases 1 2 3 4 5 6 7 8 9:")
-    raw = np.mean([b for b in acc_raw], axis=0)
-    t0 = raw[0, 0]
-    for w in range(16):
-        print(f"  wave {w:2d} start {raw[w,0]-t0:7.0f} | " + " ".join(f"{raw[w,i]-t0:7.0f}" for i in (1, 2, 3, 4, 5, 6, 7, 8, 9)))

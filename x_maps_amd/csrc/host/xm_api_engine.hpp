@@ -346,13 +346,6 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     }
     hipLaunchKernelGGL(k_reset_slot, dim3(1024), dim3(BLOCK), 0, s.stream, s.st, s.key_frame, (u64)h->key_cells, s.dirty);
     XM_TRY_CREATE(hipGetLastError());
-#ifdef XM_BLOG
-    {
-      const u32 id = (u32)i;  // experiments only: the block log is indexed by slot
-      XM_TRY_CREATE(hipMemcpyAsync(&s.st->pad[0], &id, sizeof id, hipMemcpyHostToDevice, s.stream));
-      XM_TRY_CREATE(hipStreamSynchronize(s.stream));
-    }
-#endif
   }
   hipLaunchKernelGGL(k_reset_slot, dim3(1), dim3(BLOCK), 0, h->slots[0].stream, h->aux_st, (u64*)nullptr, (u64)0,
                      (unsigned char*)nullptr);
@@ -584,19 +577,6 @@ int xm_sync(xm_handle* h) {
   return XM_OK;
 }
 
-#ifdef XM_BLOG
-// experiments only: copy out (and clear) the per-block log of the hot kernels
-int xm_debug_blog(unsigned long long* out /*[BLOG_FRAMES * BLOG_SLOTS * BLOG_PER][4]*/, unsigned int cap, unsigned int* n_out) {
-  HIP_TRY(hipDeviceSynchronize());
-  const unsigned int n = xm::BLOG_FRAMES * xm::BLOG_SLOTS * xm::BLOG_PER;
-  if (out && cap >= n) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(xm::g_blog), sizeof(unsigned long long) * 4 * n));
-  void* p = nullptr;
-  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(xm::g_blog)));
-  HIP_TRY(hipMemset(p, 0, sizeof(unsigned long long) * 4 * n));
-  if (n_out) *n_out = n;
-  return XM_OK;
-}
-#endif
 #ifdef XM_ABLATE
 // experiments only: copy out the s_memtime timeline written by k_scatter_tiled
 int xm_debug_timeline(unsigned long long* out /*[64][16]*/) {

@@ -110,7 +110,8 @@ struct ActDev {
                           // (stamp - bucket start) + 1; 0 = no event.  All zero between packets (k_ing_append / k_act_update clear)
   unsigned char* keep;    // [max_packet] the packet's keep flags
   u32* ctl;               // [0] != 0: the packet failed k_act_first's check (judged sequentially: by block 0 of k_act_mark, or block
-                          // after block inside k_ing_count); [2]: packets judged sequentially so far (statistics); [3]: k_ing_count's
+                          // after block inside k_ing_count); [1]: tickets taken by k_ing_count's blocks of a sequential packet (their
+                          // place in the chain); [2]: packets judged sequentially so far (statistics); [3]: k_ing_count's
                           // blocks that have done their part of a sequential packet
   long long thresh;       // T
   int cam_w, cam_h;
@@ -375,7 +376,7 @@ struct IngShared {
 
 // MARK (k_ing_count with the activity filter on): the flags are computed here and left in act.keep, where k_ing_append
 // (MARK = false) reads them.  A packet that failed k_act_first's check is judged in stream order: block b waits for block b - 1
-// (blocks are dispatched in order, so the one waited for is always resident), then takes its 512 events through act_sequential
+// (`block` is a ticket taken when the block started -- ing_count_body --, so the one waited for is always running), then takes its 512 events through act_sequential
 // -- a chain over the blocks, slow and exact, fences only on this path.
 template <bool MARK>
 __device__ inline void ing_block_local(const IngestPush& p, const ActDev& act, u32 n, u32 block, long long thresh, IngShared& s, IngLocal& L) {
@@ -461,11 +462,19 @@ __device__ inline void ing_block_local(const IngestPush& p, const ActDev& act, u
   L.n_pauses = s.cnt[0][0] + s.cnt[0][1] + s.cnt[0][2] + s.cnt[0][3];
 }
 
-__device__ __forceinline__ void ing_count_body(const IngestDev& d, const IngestPush& p, const u32 blk) {
+__device__ __forceinline__ void ing_count_body(const IngestDev& d, const IngestPush& p, u32 blk) {
   __shared__ IngShared s;
   const u32 n = ing_packet_n(p);
   const u32 nb = (n + ING_EPB - 1) / ING_EPB;
   if (blk >= nb) return;
+  if (d.act.last_ts && d.act.ctl[0]) {
+    // a packet that is judged sequentially (ing_block_local): the blocks take their place in the chain by TICKET, in the order
+    // in which they start -- whatever order the hardware dispatches them in, the block a block waits for is already running
+    __shared__ u32 s_ticket;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&d.act.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    blk = s_ticket;  // (nb blocks get here: the tickets are a permutation of 0 .. nb - 1)
+  }
   IngLocal L;
   ing_block_local<true>(p, d.act, n, blk, d.pause_thresh, s, L);
   if (threadIdx.x == 0) {
@@ -750,6 +759,7 @@ __global__ __launch_bounds__(ING_THREADS) void k_ing_segment(IngestDev d, Ingest
       }
       if (d.act.last_ts) {  // (the packet's flags have been consumed: the next packet on this set of cells decides afresh)
         d.act.ctl[0] = 0u;
+        d.act.ctl[1] = 0u;
         d.act.ctl[3] = 0u;
       }
       s_first = ~0ull;

@@ -242,6 +242,22 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     }
     col_lin = !__any(!ok);
   }
+  // The per-event section below keeps ~110 block-uniform values alive at once -- the scalar file holds 102, and what does not fit
+  // is parked in lanes of spill VGPRs (v_writelane / v_readlane: 500 of the section's 2 200 instructions, a VALU slot each, in a
+  // kernel bound by its instruction issue).  The values that are only ever OPERANDS of per-lane arithmetic are moved to vector
+  // registers of their own here (the block has room: 102 of the 128 its occupancy allows) -- XM_OWN_VPIN = 0 keeps them scalar (A/B)
+#ifndef XM_OWN_VPIN
+#define XM_OWN_VPIN 1
+#endif
+  u32 v_cam_w = (u32)tb.cam_w, v_cam_h = (u32)tb.cam_h, v_xmap_h = (u32)tb.xmap_h, v_own_hr = (u32)tb.own_hr, v_rp_inv = rp_inv, v_A_lo = A_lo;
+  int v_x_offset = tb.x_offset, v_r_lo = r_lo, v_RP = RP, v_Wc = Wc, v_W = W, v_nxs = nxs;
+  u32 v_A_span = A_span, v_used_n = (u32)(lb_e - lb_s);
+  float v_col_inv = col_inv;
+#if XM_OWN_VPIN
+  asm volatile("" : "+v"(v_cam_w), "+v"(v_cam_h), "+v"(v_xmap_h), "+v"(v_own_hr), "+v"(v_rp_inv), "+v"(v_A_lo));
+  asm volatile("" : "+v"(v_x_offset), "+v"(v_r_lo), "+v"(v_RP), "+v"(v_Wc), "+v"(v_W), "+v"(v_nxs), "+v"(v_A_span), "+v"(v_used_n), "+v"(v_col_inv));
+#endif
+  const auto col_est_v = [&](const u32 rel) { return __float2uint_rz(fmaxf((float)rel * v_col_inv - 0.5f, 0.0f)); };
   for (int rp = 0; rp < n_rp; ++rp) {
   for (int pass = 0; pass < n_pass; ++pass) {
     const bool on = wave_on(pass);
@@ -251,7 +267,7 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     int e0;
     if constexpr (VEC) e0 = pass * cap + tid * EPT;
     else e0 = pass * cap + tid;
-    const u32 used_n = (u32)(lb_e - lb_s);
+    const u32 used_n = v_used_n;
     const int u0 = VEC ? a0 + e0 - lb_s : e0;
     int tl[EPT];
     u32 rel[EPT];
@@ -259,9 +275,9 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u64 a64 = (u64)(tt[k] - t_first);
-      const u32 r = (u32)a64 - A_lo;
+      const u32 r = (u32)a64 - v_A_lo;
       const bool used = (u32)(u0 + (VEC ? k : k * nthreads)) < used_n;
-      const bool in_tile = (u32)(a64 >> 32) == 0u && r < A_span;
+      const bool in_tile = (u32)(a64 >> 32) == 0u && r < v_A_span;
       bad = bad || (used && !in_tile);
       live[k] = used && in_tile;
       rel[k] = live[k] ? r : 0u;
@@ -269,8 +285,8 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
     if (col_lin) {
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
-        const u32 e = col_est(rel[k]);
-        tl[k] = (int)e + (rel[k] + A_lo >= s_thr[3 + 1 + e] ? 1 : 0);
+        const u32 e = col_est_v(rel[k]);
+        tl[k] = (int)e + (rel[k] + v_A_lo >= s_thr[3 + 1 + e] ? 1 : 0);
       }
     } else {
 #pragma unroll
@@ -292,10 +308,10 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u32 xk = xy[k] & 0xffffu, yk = xy[k] >> 16;
-      const bool inside = xk < (u32)tb.cam_w && yk < (u32)tb.cam_h;
-      oob_here += (u32)__popcll(__ballot(live[k] && !inside && tl[k] < Wc));
+      const bool inside = xk < v_cam_w && yk < v_cam_h;
+      oob_here += (u32)__popcll(__ballot(live[k] && !inside && tl[k] < v_Wc));
       live[k] = live[k] && inside;
-      l[k] = XM_CABL(5) ? ((yk * 2u + 100u) << 16) | (xk + 50u) : lut[live[k] ? __umul24(xk, (u32)tb.cam_h) + yk : 0u];
+      l[k] = XM_CABL(5) ? ((yk * 2u + 100u) << 16) | (xk + 50u) : lut[live[k] ? __umul24(xk, v_cam_h) + yk : 0u];
     }
     if (rp == 0 && pass == 0) XM_CSTAMP(4);  // LUT gathers issued
     // A2: the packed X-map (xp | delta << 13) from L2
@@ -304,9 +320,9 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int yr = (int)l[k] >> 16;
-      rr[k] = yr - r_lo;
-      live[k] = live[k] && (u32)rr[k] < (u32)tb.own_hr;  // 0 <= yr < H - 1 (xmd:23): own_hr rows from r_lo on, all of them valid
-      xm[k] = XM_CABL(5) ? (u32)(tb.x_offset + 300 + ((c0 + tl[k]) * 3 >> 2) + (yr >> 2)) : xmo_tile[live[k] ? __umul24((u32)tl[k], (u32)tb.xmap_h) + (u32)yr : 0u];
+      rr[k] = yr - v_r_lo;
+      live[k] = live[k] && (u32)rr[k] < v_own_hr;  // 0 <= yr < H - 1 (xmd:23): own_hr rows from r_lo on, all of them valid
+      xm[k] = XM_CABL(5) ? (u32)(tb.x_offset + 300 + ((c0 + tl[k]) * 3 >> 2) + (yr >> 2)) : xmo_tile[live[k] ? __umul24((u32)tl[k], v_xmap_h) + (u32)yr : 0u];
     }
     const u32 val_base = (u32)(e0 + 1) << 16;
     // (two copies of the loop, one per kind of rig, instead of a branch per event: the kernel is bound by its own instruction issue)
@@ -315,28 +331,28 @@ __device__ __forceinline__ void scatter_own_body(gp_u16 xs, gp_u16 ys, gp_i64 ts
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
         const int xr = (int)(short)(l[k] & 0xffff);
-        const int delta = (int)(xm[k] >> OWN_XP_BITS), fu = (int)(xm[k] & ((1u << OWN_XP_BITS) - 1u)) - tb.x_offset;
+        const int delta = (int)(xm[k] >> OWN_XP_BITS), fu = (int)(xm[k] & ((1u << OWN_XP_BITS) - 1u)) - v_x_offset;
         const int disp = fu - xr;          // (xm_create has checked the range: xmd:27's wrap never triggers)
         bool write = live[k] && disp >= 0;  // xmd:29; an undefined X-map cell is packed as 0: fu = -x_offset < xr_min <= xr
         int fc = fu;
         if constexpr (!ALL_IN) {
           if (fc < 0) fc += tb.rect_w;  // NumPy's negative wrap
           const bool in_frame = (u32)fc < (u32)tb.rect_w && rr[k] + r_lo < tb.rect_h;
-          oob_here += (u32)__popcll(__ballot(write && !in_frame && tl[k] < Wc));
+          oob_here += (u32)__popcll(__ballot(write && !in_frame && tl[k] < v_Wc));
           write = write && in_frame;
         }
-        in_here += (u32)__popcll(__ballot(write && tl[k] < Wc));  // counted by the tile whose own columns hold the event
-        const int jo = tl[k] - delta;                             // the cell's owner column, relative to c0
-        write = write && (u32)jo < (u32)W;
+        in_here += (u32)__popcll(__ballot(write && tl[k] < v_Wc));  // counted by the tile whose own columns hold the event
+        const int jo = tl[k] - delta;                               // the cell's owner column, relative to c0
+        write = write && (u32)jo < (u32)v_W;
         // the cell's column inside its row's band: its frame column - the band's origin (both before the frame's shear: the
         // table holds the origin, the flush adds the row's shear)
         const int row = write ? rr[k] : 0;
         const int sx = fc - (int)(short)(s_tab[row >> ent_sh] & 0xffffu);
-        const u32 rpo = __umul24((u32)row, rp_inv) >> 20;  // the row's pass
-        const int idx = (int)((rpo << 24) | (u32)(__mul24(sx, RP) + row - (int)__umul24(rpo, (u32)RP)));
+        const u32 rpo = __umul24((u32)row, v_rp_inv) >> 20;  // the row's pass
+        const int idx = (int)((rpo << 24) | (u32)(__mul24(sx, v_RP) + row - (int)__umul24(rpo, (u32)v_RP)));
         // a cell outside the band (an "extra"): marked with its pair, looked up below in the tiles that have any
         const int extra = (int)(0x80000000u | ((u32)tl[k] << 16) | (u32)row);
-        code[k] = write ? ((u32)sx < (u32)nxs ? idx : extra) : -1;
+        code[k] = write ? ((u32)sx < (u32)v_nxs ? idx : extra) : -1;
         val[k] = (val_base + ((u32)(VEC ? k : k * nthreads) << 16)) | (u32)disp;
       }
     };

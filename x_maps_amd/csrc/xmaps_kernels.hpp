@@ -295,30 +295,6 @@ __device__ inline u32 xcd_contiguous_in_frame(u32 b, u32 nb, u32 frame) {
   return start + (bv - first) / N_XCD;
 }
 
-// experiments only (-DXM_ABLATE): every block of the three hot kernels logs {kind, slot state, tag, start, end} in the
-// 100 MHz real-time counter -> a block-level timeline of the pipelined run (tools/block_timeline.py)
-#ifdef XM_BLOG
-// [tag & 7][slot][block within the frame: K0 at 0, K1 at 1024, K2 at 2048][kind|tag, start, end, -]: no atomics, one store
-constexpr u32 BLOG_FRAMES = 8, BLOG_SLOTS = 16, BLOG_PER = 4096;
-__device__ unsigned long long g_blog[BLOG_FRAMES * BLOG_SLOTS * BLOG_PER][4];
-#define XM_BLOG_BEGIN() const unsigned long long blog_t0 = __builtin_amdgcn_s_memrealtime()
-#define XM_BLOG_END(kind, stp, tagv)                                                                     \
-  do {                                                                                                   \
-    if (threadIdx.x == 0) { /* thread 0 only, no barrier: its end stands for the block's */              \
-      const unsigned long long blog_t1 = __builtin_amdgcn_s_memrealtime();                               \
-      const u32 lb = blockIdx.y * gridDim.x + blockIdx.x;                                                \
-      const u32 sl = (stp)->pad[0] % BLOG_SLOTS;                                                         \
-      const u32 bi = (((tagv) & (BLOG_FRAMES - 1)) * BLOG_SLOTS + sl) * BLOG_PER + (kind) * 1024u + ((kind) == 2 ? lb % 2048u : lb % 1024u); \
-      g_blog[bi][0] = (unsigned long long)(kind) | ((unsigned long long)(tagv) << 8) | ((unsigned long long)sl << 40) | (1ull << 63); \
-      g_blog[bi][1] = blog_t0;                                                                           \
-      g_blog[bi][2] = blog_t1;                                                                           \
-    }                                                                                                    \
-  } while (0)
-#else
-#define XM_BLOG_BEGIN() do { } while (0)
-#define XM_BLOG_END(kind, stp, tagv) do { } while (0)
-#endif
-
 // ---- wave helpers (wave = 64 lanes) ------------------------------------------------------------------
 __device__ inline u64 wave_min_u64(u64 v) {
 #pragma unroll
@@ -374,7 +350,6 @@ template <typename T, bool AOS, bool HAS_P, int VEC>
 __device__ __forceinline__ void minmax_body(const T* __restrict__ t, const int16_t* __restrict__ p,
                                             const uint4* __restrict__ aos, u64 n, SlotState* st, u32 tag_override,
                                             const u32 blk, const u32 nblk) {
-  XM_BLOG_BEGIN();
   // the frame tag is only needed for the final atomics: its load (kernarg -> st -> tag_b, a dependent scalar chain) must
   // not sit in front of the event loads
   u64 lo = MM_INIT_MIN, hi = MM_INIT_MAX;
@@ -489,7 +464,6 @@ __device__ __forceinline__ void minmax_body(const T* __restrict__ t, const int16
                              __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  XM_BLOG_END(0, st, tag);
 }
 
 template <typename T, bool AOS, bool HAS_P, int VEC>
@@ -811,11 +785,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_direct_batch(const FrameDesc*
 __device__ int g_ablate = 0;  // bit0: no flush atomics, bit1: no LDS slot atomics, bit2: no band loads, bit3: no time divide
 #define XM_ABL(bit) (g_ablate & (1 << (bit)))  // bit 2 (band loads) no longer wired
 __device__ unsigned long long g_timeline[64][16];  // [block][phase] s_memtime stamps of thread 0 (experiments only)
-#ifdef XM_STAMP_WAVES  // rows = the 16 waves of blocks 0..3 instead of thread 0 of blocks 0..63
-#define XM_STAMP(ph) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4) g_timeline[blockIdx.x * 16 + (threadIdx.x >> 6)][ph] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define XM_STAMP(ph) do { if ((threadIdx.x == 0) && blockIdx.x < 64) g_timeline[blockIdx.x][ph] = __builtin_amdgcn_s_memtime(); } while (0)
-#endif
 #else
 #define XM_ABL(bit) 0
 #define XM_STAMP(ph) do { } while (0)
@@ -852,7 +822,6 @@ __device__ __forceinline__ void scatter_tiled_body(
   static_assert(!(AOS && VEC), "AoS records are loaded one per lane");
   constexpr bool PROJ32 = KEY32 && VIEW == 0, CAM32 = KEY32 && VIEW == 1;  // (see KEY32_DISP_BITS)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XM_BLOG_BEGIN();
   // LDS carve-up (16-byte aligned pieces; the two bands keep 16 B of slack for their alignment shift).  The LUT band and
   // the winner slots SHARE one region: the band is only read by the first gather of the fast path, the slots only written
   // after it -- two extra barriers buy 26 KB per block, i.e. a third resident block per CU (block residency is what bounds
@@ -1404,7 +1373,6 @@ __device__ __forceinline__ void scatter_tiled_body(
     if (s_oob) __hip_atomic_fetch_add(&c[CNT_OOB], s_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   XM_STAMP(10);
-  XM_BLOG_END(1, st, tag);
 }
 
 template <typename T, bool AOS, bool HAS_P, int VIEW, bool VEC, bool KEY32 = false>
@@ -1751,7 +1719,6 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
   constexpr int FLAG_LINES = 8, FLAG_COLS = 128;  // patch columns x 128-byte lines per column (rows_p <= 96 -> <= 7 lines)
   __shared__ unsigned char s_live[FLAG_COLS * FLAG_LINES];
   const int tid = threadIdx.x, tx = tid & (K2_TX - 1), ty = tid / K2_TX;
-  XM_BLOG_BEGIN();
   XM_K2STAMP(0);
   // XCD-aware tile order (see xcd_contiguous): each XCD takes a contiguous run of the tile raster, so the halos that
   // neighbouring tiles share (3 of 22 patch columns each side, boundary cache lines above/below) hit in its own L2.
@@ -2155,7 +2122,6 @@ __device__ __forceinline__ void frame_proj_tiled_body(const u64* __restrict__ ke
     }
   }
   XM_K2STAMP(6);
-  XM_BLOG_END(2, st, tag);
 }
 
 template <int FMT = 0, int PPT = 2>

@@ -30,6 +30,28 @@ from .trigger_finder import RobustTriggerFinder
 from .x_maps_disparity import XMapsDisparity
 
 
+_ACT_WARNED = False
+
+
+def _warn_activity_rule_unpinned() -> None:
+    """Once per process: this build's activity-noise rule (an earlier event at one of the 8 neighbours within T, inclusive; the own
+    pixel does not count; per-pixel maximum stamp) is its own definition -- Metavision's ActivityNoiseFilterAlgorithm
+    (depth_reprojection_pipe.py:65-67 of the reference) ships as a binary and no fixture of it exists yet
+    (tests/golden/g10_metavision.npz, written by tools/pin_thirdparty.py on a reference installation).  Frames may differ from the
+    reference's by the events the two rules judge differently; pass `activity_filter=` (Metavision's own) for the reference's rule."""
+    global _ACT_WARNED
+    if _ACT_WARNED:
+        return
+    _ACT_WARNED = True
+    import os
+    import warnings
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g10_metavision.npz")):
+        warnings.warn("x_maps_amd: the activity-noise filter runs this build's own rule, unpinned against Metavision's "
+                      "ActivityNoiseFilterAlgorithm (no g10_metavision.npz fixture yet: tools/pin_thirdparty.py); pass the SDK's "
+                      "filter as DepthReprojectionPipe(activity_filter=...) or RuntimeParams(activity_filter=False) to leave it out",
+                      RuntimeWarning, stacklevel=3)
+
+
 @dataclass
 class DepthReprojectionPipe:
     params: "RuntimeParams"
@@ -88,6 +110,8 @@ class DepthReprojectionPipe:
         self._raw_dev, self._raw_host = {}, {}  # EVT 3.0 / 2.0 decoders (process_evt3_words / process_evt2_words), created on first use
         self._own_act_filter = None
         self._host_chain_active = False
+        if self.activity_filter is None and getattr(p, "activity_filter", True):
+            _warn_activity_rule_unpinned()
         # a caller-supplied activity filter (Metavision's own, where the SDK is installed) runs on the host: so does the chain
         if getattr(p, "device_ingest", True) and self.activity_filter is None:
             from .ingest import DeviceIngest
