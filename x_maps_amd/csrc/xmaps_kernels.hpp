@@ -2326,16 +2326,6 @@ __global__ __launch_bounds__(BLOCK) void k_frame_direct_u16(const uint16_t* __re
   if (bgr) store_bgr_block(bgr, (u64)blockIdx.x * BLOCK, n_pixels, e.y);
 }
 
-// packed-key frame -> f32 disparity frame (stage A3 / A3' output)
-__global__ __launch_bounds__(BLOCK) void k_decode_keys(const u64* __restrict__ f, u64 n_cells, u32 tag,
-                                                       float* __restrict__ out) {
-  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n_cells) {
-    const u64 k = f[i];
-    out[i] = (u32)(k >> KEY_TAG_SHIFT) == tag ? (float)(u32)(k & 0xffff) : 0.0f;
-  }
-}
-
 // =====================================================================================================
 // stage / debug kernels (reference stage signatures; not on the fused path)
 // =====================================================================================================
