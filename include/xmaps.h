@@ -518,6 +518,10 @@ typedef struct xm_ingest_config {
 #define XM_INGEST_NO_LAUNCH_THREAD 1u /* By default xm_ingest_push* only stages the packet and posts it to a launch thread owned
                                        * by the ingest, which issues the copy and the ~10 launches (the caller pays ~2 us per pinned
                                        * packet instead of ~35).  With this flag the calling thread issues them itself. */
+#define XM_INGEST_ACT_SELF 2u          /* activity filter: an earlier event at the event's OWN pixel qualifies too (a 3 x 3 window that
+                                       * includes its centre).  The rule is this build's own definition (Metavision's filter is a
+                                       * binary); the variants it may turn out to need are configuration: this flag, and a strict
+                                       * comparison (t - t' < T) = activity_thresh_us - 1 on integer stamps. */
 typedef struct xm_ingest_frame {
   uint64_t seq;                    /* frame number, from 0 */
   uint64_t n_events;               /* events of the cut frame */
@@ -589,6 +593,7 @@ int xm_activity_create(xm_handle* h, int64_t thresh_us, size_t max_packet_events
 void xm_activity_destroy(xm_activity* f);
 int xm_activity_process(xm_activity* f, const void* eventcd16, size_t n, uint8_t* keep_out, size_t* n_kept /* nullable */);
 int xm_activity_reset(xm_activity* f); /* forget the history */
+int xm_activity_set_rule(xm_activity* f, int self_counts); /* != 0: as XM_INGEST_ACT_SELF, from the next packet on */
 /* packets (pieces) so far whose stamps ran backwards or spanned more than 8 thresholds: judged sequentially on the device */
 int xm_activity_stats(xm_activity* f, uint64_t* sequential_packets);
 int xm_ingest_activity_stats(xm_ingest* g, uint64_t* sequential_packets); /* the same for an ingest's filter (synchronises) */

@@ -15,7 +15,8 @@
                            (2) history: this rule keeps the pixel's MAXIMUM stamp, OpenEB overwrites with the LATEST event's
                                -- identical on a time-ordered stream, which a camera's is;
                            (3) the event's own pixel: excluded here (an isolated hot pixel firing repeatedly is noise); if
-                               OpenEB's window includes the centre, events repeating at one pixel within T are kept there;
+                               OpenEB's window includes the centre, events repeating at one pixel within T are kept there
+                               (include_self=True here, XM_INGEST_ACT_SELF / RuntimeParams.activity_include_self there);
                            (4) borders: the neighbourhood is clipped to the sensor here; coordinates outside the sensor are
                                dropped (NumPy would raise), OpenEB's behaviour there is not known.
   TriggerFinderOracle    find_trigger / process_events of python/trigger_finder.py:128-189 written out over plain arrays
@@ -34,8 +35,8 @@ def polarity_filter(evs):
 
 
 class ActivityFilterOracle:
-    def __init__(self, width, height, thresh_us):
-        self.w, self.h, self.thresh = int(width), int(height), int(thresh_us)
+    def __init__(self, width, height, thresh_us, include_self=False):
+        self.w, self.h, self.thresh, self.include_self = int(width), int(height), int(thresh_us), bool(include_self)
         self.last = np.full((self.h, self.w), np.iinfo(np.int64).min, np.int64)
         self.has = np.zeros((self.h, self.w), bool)
 
@@ -43,14 +44,14 @@ class ActivityFilterOracle:
         """evs: positive events in stream order -> the kept ones."""
         keep = np.zeros(len(evs), bool)
         xs, ys, ts = evs["x"].astype(np.int64), evs["y"].astype(np.int64), evs["t"].astype(np.int64)
-        last, has, w, h, T = self.last, self.has, self.w, self.h, self.thresh
+        last, has, w, h, T, own = self.last, self.has, self.w, self.h, self.thresh, self.include_self
         for i in range(len(evs)):
             x, y, t = xs[i], ys[i], ts[i]
             y0, y1, x0, x1 = max(y - 1, 0), min(y + 1, h - 1), max(x - 1, 0), min(x + 1, w - 1)
             k = False
             for yy in range(y0, y1 + 1):
                 for xx in range(x0, x1 + 1):
-                    if (yy != y or xx != x) and has[yy, xx] and t - last[yy, xx] <= T:
+                    if (own or yy != y or xx != x) and has[yy, xx] and t - last[yy, xx] <= T:  # (own: variant (3) above)
                         k = True
             keep[i] = k
             if not has[y, x] or t > last[y, x]:
@@ -59,7 +60,7 @@ class ActivityFilterOracle:
         return evs[keep]
 
 
-def activity_filter_c(lib, evs, state, thresh_us):
+def activity_filter_c(lib, evs, state, thresh_us, include_self=False):
     """The same rule through oracle/xmaps_oracle.c:xmo_activity_filter (fast; pinned to ActivityFilterOracle in
     tests/test_oracle_ingest.py).  state = (last int64[h, w], has uint8[h, w]) carried by the caller."""
     import ctypes as C
@@ -68,23 +69,23 @@ def activity_filter_c(lib, evs, state, thresh_us):
     for k in ("x", "y", "p", "t"):
         rec[k] = evs[k]
     keep = np.zeros(len(evs), np.uint8)
-    lib.xmo_activity_filter.restype = C.c_int64
-    lib.xmo_activity_filter(C.c_void_p(rec.ctypes.data), C.c_int64(len(rec)), C.c_int(has.shape[1]), C.c_int(has.shape[0]), C.c_int64(int(thresh_us)),
-                            C.c_void_p(last.ctypes.data), C.c_void_p(has.ctypes.data), C.c_void_p(keep.ctypes.data))
+    lib.xmo_activity_filter2.restype = C.c_int64
+    lib.xmo_activity_filter2(C.c_void_p(rec.ctypes.data), C.c_int64(len(rec)), C.c_int(has.shape[1]), C.c_int(has.shape[0]), C.c_int64(int(thresh_us)),
+                             C.c_void_p(last.ctypes.data), C.c_void_p(has.ctypes.data), C.c_void_p(keep.ctypes.data), C.c_int(1 if include_self else 0))
     return evs[keep.view(bool)]
 
 
 class ActivityFilterC:
     """ActivityFilterOracle's interface over the C form"""
 
-    def __init__(self, width, height, thresh_us):
+    def __init__(self, width, height, thresh_us, include_self=False):
         import c_oracle
         self.lib = c_oracle.load(False)
-        self.thresh = int(thresh_us)
+        self.thresh, self.include_self = int(thresh_us), bool(include_self)
         self.state = (np.zeros((int(height), int(width)), np.int64), np.zeros((int(height), int(width)), np.uint8))
 
     def process(self, evs):
-        return activity_filter_c(self.lib, evs, self.state, self.thresh)
+        return activity_filter_c(self.lib, evs, self.state, self.thresh, self.include_self)
 
 
 class TriggerFinderOracle:

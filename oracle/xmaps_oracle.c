@@ -172,7 +172,7 @@ int xmo_process_frame(const xmo_tables* tb, const uint16_t* x, const uint16_t* y
  * streams of ESL size (and bench.py's cpu legs) can be judged in milliseconds; pinned against the Python form in
  * tests/test_oracle_ingest.py.  rec: 16-byte EventCD records (x:u16@0, y:u16@2, p:i16@4, t:i64@8); every record takes part.
  * last / has: the per-pixel history the caller keeps between packets (int64 / uint8, h x w).  Returns the number kept. */
-int64_t xmo_activity_filter(const void* rec, int64_t n, int w, int h, int64_t thresh, int64_t* last, uint8_t* has, uint8_t* keep) {
+int64_t xmo_activity_filter2(const void* rec, int64_t n, int w, int h, int64_t thresh, int64_t* last, uint8_t* has, uint8_t* keep, int include_self) {
   const uint8_t* r = (const uint8_t*)rec;
   int64_t kept = 0;
   for (int64_t i = 0; i < n; ++i) {
@@ -182,7 +182,7 @@ int64_t xmo_activity_filter(const void* rec, int64_t n, int w, int h, int64_t th
     const int y0 = y > 0 ? y - 1 : 0, y1 = y + 1 < h ? y + 1 : h - 1, x0 = x > 0 ? x - 1 : 0, x1 = x + 1 < w ? x + 1 : w - 1;
     for (int yy = y0; yy <= y1; ++yy)
       for (int xx = x0; xx <= x1; ++xx)
-        if ((yy != y || xx != x) && has[(int64_t)yy * w + xx] && t - last[(int64_t)yy * w + xx] <= thresh) k = 1;
+        if ((include_self || yy != y || xx != x) && has[(int64_t)yy * w + xx] && t - last[(int64_t)yy * w + xx] <= thresh) k = 1;
     keep[i] = k;
     kept += k;
     const int64_t c = (int64_t)y * w + x;
@@ -190,4 +190,7 @@ int64_t xmo_activity_filter(const void* rec, int64_t n, int w, int h, int64_t th
     has[c] = 1;
   }
   return kept;
+}
+int64_t xmo_activity_filter(const void* rec, int64_t n, int w, int h, int64_t thresh, int64_t* last, uint8_t* has, uint8_t* keep) {
+  return xmo_activity_filter2(rec, n, w, h, thresh, last, has, keep, 0);  /* (the rule as defined: the own pixel does not count) */
 }

@@ -37,9 +37,9 @@ def _stream(n, seed, span_us, cluster=0.6, start=1_000_000, sort=True):
     return ev
 
 
-def _check(eng, packets, thresh, want_sequential=None, max_packet=0):
-    ora = IO.ActivityFilterOracle(CFG.cam_w, CFG.cam_h, thresh)
-    with ActivityNoiseFilterAlgorithm(eng, thresh, max_packet_events=max_packet) as act:
+def _check(eng, packets, thresh, want_sequential=None, max_packet=0, include_self=False):
+    ora = IO.ActivityFilterOracle(CFG.cam_w, CFG.cam_h, thresh, include_self=include_self)
+    with ActivityNoiseFilterAlgorithm(eng, thresh, max_packet_events=max_packet, include_self=include_self) as act:
         for k, p in enumerate(packets):
             want = ora.process(p)
             got = act.process_events(p)
@@ -60,6 +60,26 @@ def test_single_bucket_packets(eng):
     ev = _stream(6000, 1, 40_000)
     pk = TI._packets(ev, 4_000)
     _check(eng, pk, 16_666, want_sequential=False)
+
+
+@pytest.mark.parametrize("shape", ["one bucket", "several buckets", "stamps running backwards"])
+def test_the_variant_whose_window_includes_the_own_pixel(eng, shape):
+    """XM_INGEST_ACT_SELF / xm_activity_set_rule: an earlier event at the event's OWN pixel qualifies too (one of the ways Metavision's
+    filter may differ from this build's definition: oracle/ingest_oracle.py) -- parallel and sequential paths == the oracle's variant,
+    and the variant does keep events the default rule drops (a pixel firing repeatedly)"""
+    if shape == "one bucket":
+        ev, span, T, seq = _stream(6000, 11, 40_000, cluster=0.3), 4_000, 16_666, False
+    elif shape == "several buckets":
+        ev, span, T, seq = _stream(9000, 12, 60_000, cluster=0.3), 9_000, 2_000, False
+    else:
+        ev, span, T, seq = _stream(5000, 13, 40_000, cluster=0.3, sort=False), 10 ** 9, 3_000, True
+    rng = np.random.default_rng(14)
+    hot = rng.random(len(ev)) < 0.2  # a fifth of the events at three hot pixels far from everything else's neighbourhood
+    ev["x"][hot], ev["y"][hot] = rng.integers(0, 3, int(hot.sum())) * 7 + 2, 1
+    pk = TI._packets(ev, span) if span < 10 ** 9 else [ev[i:i + 1200] for i in range(0, len(ev), 1200)]
+    _check(eng, pk, T, want_sequential=seq, include_self=True)
+    a, b = IO.ActivityFilterC(CFG.cam_w, CFG.cam_h, T), IO.ActivityFilterC(CFG.cam_w, CFG.cam_h, T, include_self=True)
+    assert sum(len(b.process(p)) for p in pk) > sum(len(a.process(p)) for p in pk)
 
 
 def test_packets_spanning_several_thresholds_stay_parallel(eng):
@@ -137,9 +157,9 @@ def test_mask_form_and_empty_packet(eng):
 
 
 # ---- through the ingest: every kind of packet, flags consumed on the device -----------------------------------------------------
-def _frames_cpu(pk, thresh=int(1e6 / 60)):
+def _frames_cpu(pk, thresh=int(1e6 / 60), include_self=False):
     tf = IO.TriggerFinderOracle(60)
-    act = IO.ActivityFilterOracle(CFG.cam_w, CFG.cam_h, thresh)
+    act = IO.ActivityFilterOracle(CFG.cam_w, CFG.cam_h, thresh, include_self=include_self)
     for p in pk:
         tf.process_events(act.process(IO.polarity_filter(p)))
     return tf.frames
@@ -167,6 +187,26 @@ def test_ingest_filter_on_chunks_decoded_on_the_device(fmt, count):
         assert ing.activity_sequential_packets() == 0
         dec.close()
     TI._check_frames(tb, got, want)
+
+
+def test_ingest_with_the_rule_variants_as_configuration():
+    """the strict comparison (threshold - 1) and the own-pixel variant through the ingest's kernels (the fused first pass included:
+    the packets are pushed back to back) == the CPU chain with the oracle's variants"""
+    tb = S.make_tables(CFG)
+    stream = TI._tiny_stream(10, seed=47)
+    pk = TI._packets(stream, int(1e6 / 60 / 4))
+    T = int(1e6 / 60)
+    for own, thr in ((True, T), (False, T - 1), (True, 900)):
+        want = _frames_cpu(pk, thr, include_self=own)
+        assert len(want) >= 2
+        with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, activity_filter=True, activity_thresh_us=thr, activity_include_self=own,
+                                                  capacity_events=1 << 15, max_packet_events=1 << 13, result_ring=64) as ing:
+            got = []
+            for p in pk:
+                ing.push(p)
+            ing.flush()
+            got += ing.poll()
+        TI._check_frames(tb, got, want)
 
 
 def test_ingest_filter_with_period_chunks_and_a_short_threshold():

@@ -89,8 +89,14 @@ def test_activity_rule_c_form_equals_the_python_form():
         t = rng.integers(0, 30_000, n)
         ev["t"] = 10_000 + (np.sort(t) if sort else t)
         ev["x"], ev["y"], ev["p"] = rng.integers(0, 40, n), rng.integers(0, 30, n), 1
-        a, b = IO.ActivityFilterOracle(40, 30, 900), IO.ActivityFilterC(40, 30, 900)
-        for k in range(0, n, 700):
-            want, got = a.process(ev[k:k + 700]), b.process(ev[k:k + 700])
-            assert np.array_equal(want, got)
-        assert 0 < len(want) < 700
+        for own in (False, True):  # (own: the variant whose 3 x 3 window includes the event's own pixel)
+            a, b = IO.ActivityFilterOracle(40, 30, 900, include_self=own), IO.ActivityFilterC(40, 30, 900, include_self=own)
+            kept = 0
+            for k in range(0, n, 700):
+                want, got = a.process(ev[k:k + 700]), b.process(ev[k:k + 700])
+                assert np.array_equal(want, got)
+                kept += len(want)
+            assert 0 < len(want) < 700
+            if own:
+                assert kept > kept_default  # (events repeating at one pixel within T are kept by the variant only)
+            kept_default = kept

@@ -107,11 +107,17 @@ ACT_THRESHOLDS = (int(1e6 / 60), 2_000, 200)
 def check_metavision_activity_cpu(d):
     """this build's OWN activity rule (oracle/ingest_oracle.py) == ActivityNoiseFilterAlgorithm; a failure here names which of the
     documented differences (1)-(4) is real"""
+    verdicts = {}
     for thr in ACT_THRESHOLDS:
         ev, want, cuts = _events(d, f"act{thr}_in"), _events(d, f"act{thr}_kept"), d[f"act{thr}_packet_cuts"]
-        f = IO.ActivityFilterC(64, 48, thr)
-        got = np.concatenate([f.process(ev[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
-        assert _same_events(got, want), (thr, len(got), len(want))
+        # the rule as defined, and the variants that are configuration (RuntimeParams.activity_strict / activity_include_self,
+        # XM_INGEST_ACT_SELF, activity_thresh_us - 1): a failure names the one that matches, if any
+        for name, t, own in (("as defined", thr, False), ("strict", thr - 1, False), ("own pixel", thr, True), ("strict + own pixel", thr - 1, True)):
+            f = IO.ActivityFilterC(64, 48, t, include_self=own)
+            got = np.concatenate([f.process(ev[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+            verdicts[(thr, name)] = _same_events(got, want)
+    matching = [n for n in ("as defined", "strict", "own pixel", "strict + own pixel") if all(verdicts[(thr, n)] for thr in ACT_THRESHOLDS)]
+    assert "as defined" in matching, ("the fixture matches these variants of the rule instead (make them the defaults): %s" % matching, verdicts)
 
 
 # ---- the real fixtures (skip while absent) -----------------------------------------------------------------------------------------

@@ -103,6 +103,7 @@ class xm_frame_stats(C.Structure):
 
 
 XM_INGEST_NO_LAUNCH_THREAD = 1
+XM_INGEST_ACT_SELF = 2
 
 
 class xm_ingest_config(C.Structure):
@@ -213,6 +214,7 @@ SYMBOLS = {
     "xm_activity_destroy": (None, [_P]),
     "xm_activity_process": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t)]),
     "xm_activity_reset": (C.c_int, [_P]),
+    "xm_activity_set_rule": (C.c_int, [_P, C.c_int]),
     "xm_activity_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_ingest_activity_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_evt3_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),

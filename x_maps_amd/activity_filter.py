@@ -21,11 +21,13 @@ from .synthetic import EVENT_CD_DTYPE
 
 
 class ActivityNoiseFilterAlgorithm:
-    def __init__(self, engine, threshold_us: int, max_packet_events: int = 0):
+    def __init__(self, engine, threshold_us: int, max_packet_events: int = 0, include_self: bool = False):
         self._lib = engine._lib
         self._f = C.c_void_p(None)
         self.threshold_us = int(threshold_us)
         N.check(self._lib.xm_activity_create(engine._h, self.threshold_us, int(max_packet_events), C.byref(self._f)))
+        if include_self:  # (a variant of the rule: the event's own pixel counts; the strict comparison is threshold_us - 1)
+            N.check(self._lib.xm_activity_set_rule(self._f, 1))
 
     def process_events(self, evs: np.ndarray, return_mask: bool = False):
         """evs: EventCD records (every one of them takes part: hand in the polarity filter's output) -> the kept records."""

@@ -873,6 +873,7 @@ int xm_ingest_create(xm_handle* h, const xm_ingest_config* cfg, xm_ingest** out)
   ING_TRY(hipMalloc((void**)&d.blk, sizeof(IngBlk) * ING_MAX_BLOCKS));
   if (cfg->activity_filter) {
     int rc_ = act_alloc(&d.act, h->tb.cam_w, h->tb.cam_h, g->act_thresh, (size_t)g->max_packet, 2);
+    d.act.self_counts = (cfg->flags & XM_INGEST_ACT_SELF) ? 1 : 0;
     g->act_base = d.act;
     if (rc_) {
       xm_ingest_destroy(g);
@@ -1352,6 +1353,12 @@ int xm_activity_create(xm_handle* h, int64_t thresh_us, size_t max_packet_events
     return rc;
   }
   *out = f;
+  return XM_OK;
+}
+
+int xm_activity_set_rule(xm_activity* f, int self_counts) {
+  if (!f) return fail(XM_ERR_INVALID, "NULL argument");
+  f->act.self_counts = self_counts ? 1 : 0;  // (by value in every launch: takes effect with the next packet)
   return XM_OK;
 }
 

@@ -115,6 +115,8 @@ struct ActDev {
                           // blocks that have done their part of a sequential packet
   long long thresh;       // T
   int cam_w, cam_h;
+  int self_counts;        // != 0: an earlier event at the event's OWN pixel qualifies too (a 3 x 3 window that includes its centre: one of
+                          // the ways Metavision's filter may differ -- oracle/ingest_oracle.py lists them; XM_INGEST_ACT_SELF)
 };
 
 struct IngestDev {        // by value to every ingest kernel
@@ -201,7 +203,7 @@ __device__ inline bool act_seen_recently(const ActDev& a, const ActEv& e) {
   for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
-      if (dx == 0 && dy == 0) continue;
+      if (dx == 0 && dy == 0 && !a.self_counts) continue;
       const int xx = e.x + dx, yy = e.y + dy;
       if (xx < 0 || xx >= a.cam_w || yy < 0 || yy >= a.cam_h) continue;
       const long long lt = __hip_atomic_load(&a.last_ts[(u32)yy * (u32)a.cam_w + (u32)xx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -232,7 +234,7 @@ __device__ inline void act_sequential(const ActDev& a, const uint4* __restrict__
       act = act_seen_recently(a, e);
       for (u32 j = 0; j < tid && !act; ++j) {
         const int dx = s_x[j] - e.x, dy = s_y[j] - e.y;
-        act = s_part[j] && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && (dx | dy) != 0 && e.t - s_t[j] <= a.thresh;
+        act = s_part[j] && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && ((dx | dy) != 0 || a.self_counts) && e.t - s_t[j] <= a.thresh;
       }
     }
     if (valid) a.keep[i] = (e.part && act) ? 1 : 0;
@@ -300,7 +302,7 @@ __device__ inline bool act_keep(const ActDev& a, const ActEv& e, u32 i, long lon
   for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
-      if (dx == 0 && dy == 0) continue;
+      if (dx == 0 && dy == 0 && !a.self_counts) continue;
       const int xx = e.x + dx, yy = e.y + dy;
       if (xx < 0 || xx >= a.cam_w || yy < 0 || yy >= a.cam_h) continue;
       const u32 q = (u32)yy * (u32)a.cam_w + (u32)xx;

@@ -117,18 +117,25 @@ class DepthReprojectionPipe:
             from .ingest import DeviceIngest
             self.ingest = DeviceIngest(self.calib_maps.engine, p.projector_fps, use_polarity=True,
                                        activity_filter=bool(getattr(p, "activity_filter", True)), want_depth=False,
+                                       activity_thresh_us=self._activity_thresh_us(), activity_include_self=bool(getattr(p, "activity_include_self", False)),
                                        result_ring=int(getattr(p, "ingest_result_ring", 16)),
                                        lossless=not p.should_drop_frames)  # no_frame_dropping (the default): never lap the ring
             self._ingest_views = bool(getattr(p, "ingest_frame_views", False))
         else:
             self._ensure_host_chain()
 
+    def _activity_thresh_us(self) -> int:
+        """int(1e6 / fps) as the reference passes it (pipe:65-68); one less for the strict comparison (integer stamps)"""
+        p = self.params
+        return int(1e6 / p.projector_fps) - (1 if getattr(p, "activity_strict", False) else 0)
+
     def _ensure_host_chain(self):
         """the host chain's activity filter (pipe:65-67), made when the chain is first needed"""
         p = self.params
         if self.activity_filter is None and getattr(p, "activity_filter", True):
             from .activity_filter import ActivityNoiseFilterAlgorithm
-            self._own_act_filter = ActivityNoiseFilterAlgorithm(self.calib_maps.engine, int(1e6 / p.projector_fps))  # pipe:65-67
+            self._own_act_filter = ActivityNoiseFilterAlgorithm(self.calib_maps.engine, self._activity_thresh_us(),  # pipe:65-67
+                                                                include_self=bool(getattr(p, "activity_include_self", False)))
             self.activity_filter = self._own_act_filter
 
     def _use_ingest(self) -> bool:

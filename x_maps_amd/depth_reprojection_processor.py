@@ -53,6 +53,10 @@ class RuntimeParams:
     # trigger finder.  The rule is this build's own definition (Metavision's is a binary: oracle/ingest_oracle.py); False
     # switches the stage off (round 4's default).
     activity_filter: bool = True
+    # the two variants of that rule a fixture of Metavision's filter (tools/pin_thirdparty.py) may call for, as configuration:
+    # a strict comparison t - t' < T (= threshold T - 1 on integer stamps) and a 3 x 3 window that includes the event's own pixel
+    activity_strict: bool = False
+    activity_include_self: bool = False
     # device ingest only: hand frame_callback / window.show_async a VIEW into the ingest's ring of pinned result buffers instead of
     # an array of the consumer's own.  LIFETIME of such a view: until `ingest_result_ring` - 1 further frames have been produced.
     # (Since round 6 the default frames cost no host copy either -- xm_ingest_poll_owned --, so views only save the pool.)

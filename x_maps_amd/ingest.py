@@ -59,7 +59,7 @@ class DeviceIngest:
     def __init__(self, engine, projector_fps: int, use_polarity: bool = True, activity_filter: bool = False,
                  activity_thresh_us: int = 0, capacity_events: int = 0, max_packet_events: int = 0, result_ring: int = 8,
                  expected_events_per_frame: int = 0, want_depth: bool = True, want_bgr: bool = True, min_events_per_frame: int = 0,
-                 launch_thread: bool = True, lossless: bool = False):
+                 launch_thread: bool = True, lossless: bool = False, activity_include_self: bool = False):
         self._e = engine
         self._lib = engine._lib
         cfg = N.xm_ingest_config()
@@ -76,6 +76,8 @@ class DeviceIngest:
         cfg.expected_events_per_frame = int(expected_events_per_frame)
         cfg.want_depth, cfg.want_bgr = int(want_depth), int(want_bgr)
         cfg.flags = 0 if launch_thread else N.XM_INGEST_NO_LAUNCH_THREAD  # (default: push() posts to the ingest's launch thread)
+        if activity_include_self:  # (a variant of this build's activity rule: an earlier event at the event's own pixel qualifies too)
+            cfg.flags |= N.XM_INGEST_ACT_SELF
         self._g = C.c_void_p(None)
         N.check(self._lib.xm_ingest_create(engine._h, C.byref(cfg), C.byref(self._g)))
         self.max_packet = int(max_packet_events) or (1 << 19)
