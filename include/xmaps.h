@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XM_API_VERSION 4
+#define XM_API_VERSION 5  /* 5: xm_activity_set_rule, XM_INGEST_ACT_SELF (round 6) */
 
 /* error codes */
 #define XM_OK 0

@@ -21,7 +21,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in xmaps.h but not exported by libxmaps_hip.so"
     assert set(names) == set(N.SYMBOLS), set(names) ^ set(N.SYMBOLS)
-    assert lib.xm_api_version() == 4
+    assert lib.xm_api_version() == 5
 
 
 def test_struct_layouts_match_the_header():
