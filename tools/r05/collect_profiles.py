@@ -11,6 +11,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "5"  # (tools/r06/make_profiles.sh passes 6)
 src = os.path.join(ROOT, "gpurun_out", tag)
 out = os.path.join(ROOT, "gpurun_out", tag + "_profiles")
 os.makedirs(out, exist_ok=True)
@@ -65,7 +66,7 @@ SETS = (("groups", "C-1M (BASELINE configs[1]), projector view, groups of 32 fra
 Q = "--no-cpu-baseline --no-other-modes --no-host-path --no-pmc"
 avg_us = {}
 with open(os.path.join(out, f"{tag}_kernel_trace.md"), "w") as f:
-    f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of bench.py (MI355X, ROCm 7.2), round 5\n\n"
+    f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of bench.py (MI355X, ROCm 7.2), round {rnd}\n\n"
             "Group modes: a bench step = one group of 32 frames through one xm_process_batch call = ONE launch each of the boundary pass\n"
             "(k_cols_bounds_batch), K1 (k_scatter_cols_batch: column tiles; k_scatter_own_batch: owner tiles) and K2 (k_frame_proj_pipe:\n"
             "persistent, software-pipelined blocks).  Per-frame cost = avg us / 32.\n\n")
@@ -121,7 +122,7 @@ with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
 base = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 old = json.load(open(base)) if os.path.exists(base) else {}
 old.update({k: v for k, v in traffic.items() if v})
-old["_note_r05"] = ("projector_groups / camera_groups / projector_groups_esl / projector_sharded (merge = columns) / projector_sharded_keys / projector: round 5 (tools/r05/make_profiles.sh, tag %s), "
-                    "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 calibration; summary profiles/%s_pmc.md" % (tag, tag))
+old["_note_r0" + rnd] = ("projector_groups / camera_groups / projector_groups_esl / projector_sharded (merge = columns) / projector_sharded_keys / projector: round %s (tools/r0%s/make_profiles.sh, tag %s), "
+                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2*FETCH_SIZE + WRITE_SIZE per the gfx950 calibration; summary profiles/%s_pmc.md" % (rnd, rnd, tag, tag))
 json.dump(old, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(out)), {k: list(v) for k, v in traffic.items()})

@@ -46,6 +46,6 @@ timeout 200 python bench.py --sharded --lanes 4 --no-cpu-baseline > $OUT/bench_s
 timeout 300 python bench.py --esl > $OUT/bench_esl.json 2> $OUT/bench_esl.err
 timeout 200 python bench.py --batch 0 --no-cpu-baseline --no-host-path --no-other-modes --no-pmc > $OUT/bench_one_frame_per_call.json 2> $OUT/bench_one.err
 timeout 200 python bench.py --camera-perspective --no-cpu-baseline --no-other-modes --no-host-path --no-pmc > $OUT/bench_camera.json 2> $OUT/bench_camera.err
-python tools/r06/collect_profiles.py $TAG > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
+python tools/r05/collect_profiles.py $TAG 6 > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
 python3 -c "import glob, os, sys; [os.remove(f) for p in ('*.db', '*.csv') for f in glob.glob(os.path.join(sys.argv[1], p))]" "$OUT"
 ls $OUT | wc -l; du -sh $OUT gpurun_out/${TAG}_profiles
