@@ -597,6 +597,9 @@ int xm_activity_set_rule(xm_activity* f, int self_counts); /* != 0: as XM_INGEST
 /* packets (pieces) so far whose stamps ran backwards or spanned more than 8 thresholds: judged sequentially on the device */
 int xm_activity_stats(xm_activity* f, uint64_t* sequential_packets);
 int xm_ingest_activity_stats(xm_ingest* g, uint64_t* sequential_packets); /* the same for an ingest's filter (synchronises) */
+/* packets so far whose first pass of the activity filter went out inside the packet before's counting launch (they were queued
+ * when that one was launched: a replay, a camera ahead of the GPU) instead of as a launch of their own (synchronises) */
+int xm_ingest_fused_first_passes(xm_ingest* g, uint64_t* n);
 
 /* ---- EVT 3.0 words -> EventCD records on the device --------------------------------------------------------------
  * The reader in front of the ingest for recordings (Prophesee RAW files, EVT 3.0: a public format; the reference reads them

@@ -189,6 +189,34 @@ def test_ingest_filter_on_chunks_decoded_on_the_device(fmt, count):
     TI._check_frames(tb, got, want)
 
 
+def test_first_pass_rides_on_the_packet_before_when_packets_queue_up_and_not_for_a_packet_alone():
+    """round 6: pushed back to back (a replay) the packets' first passes go out inside their predecessors' k_ing_count launch
+    (k_ing_count_act); a packet that arrives alone (flush after every push: a live camera's situation) gets a launch of its own.
+    Both == the CPU chain, frame by frame; so does a caller that issues the launches itself (no threads: never fused)."""
+    tb = S.make_tables(CFG)
+    stream = TI._tiny_stream(10, seed=53)
+    pk = TI._packets(stream, int(1e6 / 60 / 4))
+    want = _frames_cpu(pk)
+    assert len(want) >= 2
+    for mode in ("queued", "alone", "no threads"):
+        with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, activity_filter=True, capacity_events=1 << 15, max_packet_events=1 << 13,
+                                                  result_ring=64, launch_thread=mode != "no threads") as ing:
+            got = []
+            for p in pk:
+                ing.push(p)
+                if mode == "alone":
+                    ing.flush()
+                    got += ing.poll()
+            ing.flush()
+            got += ing.poll()
+            fused = ing.activity_fused_first_passes()
+        TI._check_frames(tb, got, want)
+        if mode == "queued":
+            assert fused > 0, (fused, len(pk))  # (how many depends on how far the pushes run ahead of the launch thread)
+        else:
+            assert fused == 0, (mode, fused)
+
+
 def test_ingest_with_the_rule_variants_as_configuration():
     """the strict comparison (threshold - 1) and the own-pixel variant through the ingest's kernels (the fused first pass included:
     the packets are pushed back to back) == the CPU chain with the oracle's variants"""

@@ -217,6 +217,7 @@ SYMBOLS = {
     "xm_activity_set_rule": (C.c_int, [_P, C.c_int]),
     "xm_activity_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_ingest_activity_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "xm_ingest_fused_first_passes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "xm_evt3_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xm_evt3_wait_for_time_base": (C.c_int, [_P, C.c_int]),
     "xm_evt3_destroy": (None, [_P]),

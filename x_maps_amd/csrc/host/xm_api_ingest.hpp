@@ -1419,6 +1419,14 @@ int xm_ingest_activity_stats(xm_ingest* g, uint64_t* sequential_packets) {
   return XM_OK;
 }
 
+int xm_ingest_fused_first_passes(xm_ingest* g, uint64_t* n) {
+  if (!g || !n) return fail(XM_ERR_INVALID, "NULL argument");
+  int rc = xm_ingest_flush(g);  // (the launch thread's count: read when it is idle)
+  if (rc) return rc;
+  *n = g->act_fused_count;
+  return XM_OK;
+}
+
 int xm_activity_reset(xm_activity* f) {
   if (!f) return fail(XM_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(f->device));

@@ -215,6 +215,12 @@ class DeviceIngest:
         N.check(self._lib.xm_ingest_activity_stats(self._g, C.byref(n)))
         return int(n.value)
 
+    def activity_fused_first_passes(self) -> int:
+        """activity filter: packets so far whose first pass rode on the packet before's counting launch (synchronises)"""
+        n = C.c_uint64(0)
+        N.check(self._lib.xm_ingest_fused_first_passes(self._g, C.byref(n)))
+        return int(n.value)
+
     def host_stats(self) -> dict:
         """What the calling thread has paid inside push() so far (xm_ingest_host_stats)."""
         n, sec, waits, wsec = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0), C.c_double(0.0)
