@@ -154,7 +154,7 @@ class DepthReprojectionProcessor:
 
     def process_evt3_words(self, words):
         """A chunk of a recording's EVT 3.0 words (x_maps_amd.evt3.read_raw_words) instead of an EventCD packet; with
-        RuntimeParams(device_ingest=True) the words are decoded on the device in front of the ingest."""
+        the device ingest (RuntimeParams.device_ingest, the default) the words are decoded on the device in front of it."""
         self.stats_printer.print_stats_if_needed()
         self._pipe.process_evt3_words(words)
         self.stats_printer.print_stats_if_needed()
