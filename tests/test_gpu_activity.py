@@ -217,6 +217,29 @@ def test_first_pass_rides_on_the_packet_before_when_packets_queue_up_and_not_for
             assert fused == 0, (mode, fused)
 
 
+def test_empty_packets_between_the_packets_do_not_upset_the_turns_of_the_two_sets_of_cells():
+    """the packets take the filter's two sets of cells in turns, and the next packet's first pass runs beside this packet's counting
+    launch: an empty push in between (a camera's iterator may deliver one) must not make two packets share a set"""
+    tb = S.make_tables(CFG)
+    stream = TI._tiny_stream(10, seed=59)
+    pk = TI._packets(stream, int(1e6 / 60 / 4))
+    for every in (1, 2, 3):
+        seq = []
+        for i, p in enumerate(pk):
+            seq.append(p)
+            if i % every == 0:
+                seq.append(p[:0])
+        want = _frames_cpu(seq)  # (the trigger finder decides once per packet: the CPU chain sees the empty ones too)
+        assert len(want) >= 2
+        with XMapsEngine(tb) as eng, DeviceIngest(eng, 60, activity_filter=True, capacity_events=1 << 15, max_packet_events=1 << 13,
+                                                  result_ring=64) as ing:
+            for p in seq:
+                ing.push(p)
+            ing.flush()
+            got = ing.poll()
+        TI._check_frames(tb, got, want)
+
+
 def test_ingest_with_the_rule_variants_as_configuration():
     """the strict comparison (threshold - 1) and the own-pixel variant through the ingest's kernels (the fused first pass included:
     the packets are pushed back to back) == the CPU chain with the oracle's variants"""

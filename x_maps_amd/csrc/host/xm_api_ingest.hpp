@@ -105,6 +105,7 @@ struct xm_ingest {
   bool opt_evt3_out_stream = false;    // "XM_INGEST_EVT3_OUT_STREAM"
   bool opt_trace = false;              // "XM_INGEST_TRACE"
   bool opt_act_fuse = true;            // "XM_INGEST_ACT_FUSE" = 0: never ride k_act_first of the NEXT packet on this packet's k_ing_count launch (A/B)
+  int act_toggle = 0;                  // launch side: the set of cells the next non-empty packet takes (ingest_act_set)
   uint64_t act_fused_push = 0;         // launch side: the packet whose k_act_first went out with its predecessor's k_ing_count (k_ing_count_act)
   uint64_t act_fused_count = 0;        // ... how many did (statistics)
   const void* next_job = nullptr;      // launch side: the job queued behind the one being run, if it is a packet that has arrived (else NULL)
@@ -509,10 +510,12 @@ int ingest_handle_verdicts(xm_ingest* g, uint64_t block_upto) {
 
 int ingest_words_to_events(const xm_evt3* d);  // (xm_api_evt3.hpp) upper bound of the events one word of the decoder's format yields
 
-// the activity filter's state as packet `k` (staging entry) sees it: its set of cells and control words
-ActDev ingest_act_set(const xm_ingest* g, int k) {
+// the activity filter's state as a packet sees it: its set of cells and control words.  The packets that take part -- the
+// non-empty ones -- take the two sets strictly in turns (xm_ingest::act_toggle, advanced by ingest_process; an empty push between
+// two packets must not make them share a set: the second one's first pass runs beside the first one's counting launch)
+ActDev ingest_act_set(const xm_ingest* g, int set) {
   ActDev a = g->act_base;
-  if (a.last_ts && (k & 1)) {
+  if (a.last_ts && (set & 1)) {
     a.cells += (size_t)a.cam_w * (size_t)a.cam_h * ACT_NB;
     a.ctl += 4;
   }
@@ -532,7 +535,7 @@ void ingest_launch3(xm_ingest* g, const IngestPush& pp, u32 bound) {
       const size_t n2 = words ? std::min<size_t>((size_t)g->max_packet, nx->n * (size_t)ingest_words_to_events(nx->dec)) : nx->n;
       const unsigned nb2 = (unsigned)((n2 + ING_THREADS - 1) / ING_THREADS);
       if (n2 && hipStreamWaitEvent(g->stream, g->copied_ev[nx->k], 0) == hipSuccess) {
-        hipLaunchKernelGGL(k_ing_count_act, dim3(nb + nb2), dim3(ING_THREADS), 0, g->stream, g->dev, pp, (u32)nb, ingest_act_set(g, nx->k),
+        hipLaunchKernelGGL(k_ing_count_act, dim3(nb + nb2), dim3(ING_THREADS), 0, g->stream, g->dev, pp, (u32)nb, ingest_act_set(g, g->act_toggle /* the set the next packet will take: ingest_process has advanced it for this one */),
                            (const uint4*)g->d_pkt[nx->k], words ? (const u32*)(g->d_pkt_n + nx->k) : (const u32*)nullptr, (u32)n2,
                            g->cfg.use_polarity ? 1 : 0);
         g->act_fused_push = pp.push_no + 1;
@@ -586,7 +589,9 @@ int ingest_process(xm_ingest* g, int k, size_t n, const uint4* hp, const u32* n_
   // activity filter: the packet's first pass (the per-(bucket, pixel) cells, one event per thread; xmaps_ingest.hpp) -- unless it
   // went out with the packet before (ingest_launch3) -- then the flags themselves are computed by k_ing_count as it counts.
   // Nothing is decided here: a chunk decoded on the device is treated like records.
-  g->dev.act = ingest_act_set(g, k);  // (the packet's set of cells: k_ing_count reads them, k_ing_append empties them, k_ing_segment resets its flags)
+  const int act_set = g->act_toggle;  // (the packet's set of cells: k_ing_count reads them, k_ing_append empties them, k_ing_segment resets its flags)
+  if (n) g->act_toggle ^= 1;          // (an empty packet launches k_ing_segment only: it takes no turn)
+  g->dev.act = ingest_act_set(g, act_set);
   if (g->dev.act.last_ts && n && g->act_fused_push != push_no)  // (fused: it went out with the packet before, ingest_launch3)
     hipLaunchKernelGGL(k_act_first, dim3((unsigned)((n + ING_THREADS - 1) / ING_THREADS)), dim3(ING_THREADS), 0, s, g->dev.act,
                        (const uint4*)g->d_pkt[k], n_dev, (u32)n, g->cfg.use_polarity ? 1 : 0);
