@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: the ingest with the next packet's k_act_first riding on k_ing_count (tests, soak, A/B); K2 on the ESL-like rig with parts switched off
+# (the K2 ablation legs need variants/libxmaps_abl.so: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DXM_ABLATE x_maps_amd/csrc/xmaps_hip.hip -o variants/libxmaps_abl.so)
 cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r06
 timeout 900 python -m pytest tests/test_gpu_activity.py tests/test_gpu_ingest.py tests/test_gpu_evt2.py tests/test_gpu_evt3.py tests/test_gpu_on_arrival.py tests/test_gpu_configs.py -q -m gpu -x > gpurun_out/r06/t10.log 2>&1
 echo "pytest rc $?" >> gpurun_out/r06/t10.log; tail -6 gpurun_out/r06/t10.log

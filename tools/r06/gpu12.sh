@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: owner-tile K1 with its block-uniform operands pinned in vector registers (fewer SGPR spills: v_readlane / v_writelane) -- tests, A/B
+# (variants/libxmaps_novpin.so: the same hipcc line as x_maps_amd/_native.py's with -DXM_OWN_VPIN=0 -o variants/libxmaps_novpin.so)
 cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r06
 timeout 900 python -m pytest tests/test_gpu_own.py tests/test_gpu_configs.py -q -m gpu -x > gpurun_out/r06/t12.log 2>&1
 echo "pytest rc $?" >> gpurun_out/r06/t12.log; tail -4 gpurun_out/r06/t12.log
