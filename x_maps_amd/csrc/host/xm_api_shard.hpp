@@ -196,8 +196,12 @@ int xm_shard_cols_scatter(xm_handle* h, uint16_t* x, uint16_t* y, int64_t* t, si
   hipLaunchKernelGGL(k_shard_cols_prepare, dim3(1), dim3(256), 0, s, x, y, (long long*)t, (u64)n, (const unsigned char*)gathered_dev,
                      (u64)send_bytes, rank, world, h->tb, (u64)cap_events, mm, frame16, h->aux_st, desc);
   const int flags = h->cols_flags | COLS_F_EXT_EXTREMA;
-  hipLaunchKernelGGL(k_cols_bounds_batch<false>, dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, COLS_BOUNDS_PER_BLOCK), 1), dim3(256), 0, s,
-                     (const FrameDesc*)desc, h->tb, W, flags, 0);
+  if (W <= 16)  // (16 lanes per boundary: cols_bounds_per_block)
+    hipLaunchKernelGGL((k_cols_bounds_batch<false, 16>), dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, cols_bounds_per_block(16)), 1), dim3(256), 0, s,
+                       (const FrameDesc*)desc, h->tb, W, flags, 0);
+  else
+    hipLaunchKernelGGL(k_cols_bounds_batch<false>, dim3(grid_for(grid_for(h->tb.xmap_w, W) + 1, cols_bounds_per_block(32)), 1), dim3(256), 0, s,
+                       (const FrameDesc*)desc, h->tb, W, flags, 0);
   auto kern = k_scatter_cols_batch<false, true>;  // (the piece starts 8-aligned: 16-byte event loads)
   const size_t lds = cols_lds_bytes(h, W);
   int rc;

@@ -33,7 +33,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
         rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc) return rc;
         prof_slot(0);
-        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(2 * grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
+        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(2 * grid_for(h->tb.xmap_w, cols_w) + 1, cols_bounds_per_block(32)), n_frames),
                   dim3(256), 0, stream, d_descs, tbo, cols_w, 0, os.halo);
         prof_slot(1);
         XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w, ept)), lds, stream, d_descs, tbo,
@@ -47,8 +47,12 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
       if (rc) return rc;
       prof_slot(0);
-      XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, COLS_BOUNDS_PER_BLOCK), n_frames),
-                dim3(256), 0, stream, d_descs, h->tb, cols_w, 0, 0);
+      if (cols_w <= 16)  // (16 lanes per boundary: see cols_bounds_per_block)
+        XM_LAUNCH((k_cols_bounds_batch<AOS, 16>), dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, cols_bounds_per_block(16)), n_frames),
+                  dim3(256), 0, stream, d_descs, h->tb, cols_w, 0, 0);
+      else
+        XM_LAUNCH(k_cols_bounds_batch<AOS>, dim3(grid_for(grid_for(h->tb.xmap_w, cols_w) + 1, cols_bounds_per_block(32)), n_frames),
+                  dim3(256), 0, stream, d_descs, h->tb, cols_w, 0, 0);
       prof_slot(1);
       XM_LAUNCH(kern, dim3(grid_for(h->tb.xmap_w, cols_w), n_frames), dim3(cols_threads(h, n_mean, cols_w)), lds, stream, d_descs, h->tb,
                 cols_w, h->w_x, h->cols_xr_min, h->cols_flags | (d_descs_redo ? COLS_F_DEVICE_REDO : 0));

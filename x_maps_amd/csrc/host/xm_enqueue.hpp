@@ -61,12 +61,16 @@ unsigned cols_threads(const xm_handle* h, u64 n, int W, int ept = COLS_EPT) {
 void launch_cols_bounds(xm_handle* h, const EventsView& ev, uint16_t* frame16, int W, hipStream_t stream) {
   const int split = h->own_mode ? own_set(h, W).halo : 0;  // owner tiles: two boundaries per tile (tile = W columns + a halo behind them)
   const unsigned nb = (split ? 2u : 1u) * grid_for(h->tb.xmap_w, W);
-  if (ev.aos)
-    XM_LAUNCH(k_cols_bounds<true>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
-              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
+  const bool g16 = !split && W <= 16;  // (16 lanes per boundary on the column tiles: cols_bounds_per_block)
+  const unsigned gx = grid_for(nb + 1, cols_bounds_per_block(g16 ? 16 : 32));
+  if (ev.aos && g16)
+    XM_LAUNCH((k_cols_bounds<true, 16>), dim3(gx), dim3(256), 0, stream, ev.x, (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
+  else if (ev.aos)
+    XM_LAUNCH(k_cols_bounds<true>, dim3(gx), dim3(256), 0, stream, ev.x, (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
+  else if (g16)
+    XM_LAUNCH((k_cols_bounds<false, 16>), dim3(gx), dim3(256), 0, stream, ev.x, (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
   else
-    XM_LAUNCH(k_cols_bounds<false>, dim3(grid_for(nb + 1, COLS_BOUNDS_PER_BLOCK)), dim3(256), 0, stream, ev.x,
-              (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
+    XM_LAUNCH(k_cols_bounds<false>, dim3(gx), dim3(256), 0, stream, ev.x, (const long long*)ev.t, (const uint4*)ev.aos, (u32)ev.n, h->tb, W, frame16, split);
 }
 
 int launch_scatter_cols(xm_handle* h, const EventsView& ev, SlotState* st, uint16_t* frame16, int W, hipStream_t stream) {

@@ -155,7 +155,7 @@ __device__ __forceinline__ int cols_x_at(gp_u16 xs, gp_u4 aos, int i) {
   else return (int)xs[i];
 }
 
-// ---- K0b's search: COLS_BOUNDS_LANES lanes per boundary ------------------------------------------------------------------------
+// ---- K0b's search: G lanes per boundary ------------------------------------------------------------------------
 // lb = first event with (u64)(t - tmin) >= A.  State per boundary: event lo is below (or lo == -1), event hi is at or past it (or
 // hi == n); the answer is hi once hi - lo == 1.  Round 1: G probes, G * FIN events apart, centred on where an evenly filled scan
 // has the boundary (known before anything is loaded).  Last round (<= G * FIN unknown positions): every lane takes FIN consecutive
@@ -163,14 +163,19 @@ __device__ __forceinline__ int cols_x_at(gp_u16 xs, gp_u4 aos, int i) {
 // In between (a guess that missed by more than G * FIN * G / 2 events: bursts, unsorted streams): even splits into G probes.
 // For a stream that is not sorted the result is still a deterministic function of (stream, A): neighbouring tiles read the same
 // boundary, and the per-event verification of K1 catches the rest.
-constexpr int COLS_BOUNDS_LANES = 32, COLS_BOUNDS_FIN = 4;
-constexpr int COLS_BOUNDS_PER_BLOCK = 256 / COLS_BOUNDS_LANES;
+// G = 32 lanes per boundary, or 16 (round 6) where a tile is at most 16 columns wide and has no halo boundary (the column tiles:
+// lane l of a group computes the threshold of column j W + l): half the waves and half the probe lines per boundary -- the
+// pipelined step is bound by the HBM bytes of its three kernels, K0b's scattered 8-byte probes pull a line each (56 MB per group
+// of 32 C-1M frames), and 16 lanes move the step from 0.1964 to 0.1937 ms (profiles/r06_k1_chain.md section 3).
+constexpr int COLS_BOUNDS_FIN = 4;
+constexpr int cols_bounds_per_block(int G) { return 256 / G; }
 
 // probes of one round, FIN per lane in probing order (lane-major), act[k] / pr[k] = probed / at or past the boundary, q[k] their
 // positions (non-decreasing in probing order): narrow (lo, hi).  Executed by the whole wave; gl = the group's first lane.
+template <int G>
 __device__ __forceinline__ void cols_narrow(const int (&q)[COLS_BOUNDS_FIN], const bool (&act)[COLS_BOUNDS_FIN],
                                             const bool (&pr)[COLS_BOUNDS_FIN], const int gl, int& lo, int& hi) {
-  constexpr int G = COLS_BOUNDS_LANES, FIN = COLS_BOUNDS_FIN;
+  constexpr int FIN = COLS_BOUNDS_FIN;
   int kk = FIN, last_q = -1;  // the lane's first probe at or past the boundary; its last probe
   bool any_act = false;
 #pragma unroll
@@ -216,7 +221,7 @@ __host__ __device__ inline size_t cols_frame_bytes(size_t key_cells, int xmap_w)
   return cols_thr_offset(key_cells, xmap_w) + sizeof(u32) * ((size_t)xmap_w + 2) + 64;
 }
 
-template <bool AOS>
+template <bool AOS, int G>
 __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos, const int n, const DevTables& tb, const int W,
                                                  XM_GLOBAL unsigned char* frame_base, const u32 blk, gp_i64 ext_mm = nullptr,
                                                  const int first = 0,  // first: events [0, first) are filler (shards: alignment)
@@ -226,10 +231,10 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   const size_t key_cells = frame16_cells(tb);
   XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
   XM_GLOBAL u32* thr = (XM_GLOBAL u32*)(frame_base + cols_thr_offset(key_cells, tb.xmap_w));
-  constexpr int G = COLS_BOUNDS_LANES, FIN = COLS_BOUNDS_FIN;
+  constexpr int FIN = COLS_BOUNDS_FIN;
   const int lane = threadIdx.x & 63, sl = lane & (G - 1), gl = lane & ~(G - 1);
   const int nb = split ? 2 * ((tb.xmap_w + W - 1) / W) : (tb.xmap_w + W - 1) / W;
-  const int j_raw = (int)blk * COLS_BOUNDS_PER_BLOCK + (int)threadIdx.x / G;
+  const int j_raw = (int)blk * cols_bounds_per_block(G) + (int)threadIdx.x / G;
   const bool live = j_raw <= nb;  // (a group past the last boundary runs along with its wave and stores nothing)
   if (!__any(live)) return;       // wave-uniform
   const int j = min(j_raw, nb);
@@ -288,7 +293,7 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
     act[0] = true;
     pr[0] = (u64)(tv[0] - t_first) >= (u64)A;
   }
-  cols_narrow(q, act, pr, gl, lo, hi);
+  cols_narrow<G>(q, act, pr, gl, lo, hi);
   int x_base = -1, x_cnt = 0;
   u64 x4 = 0;  // the lane's FIN x values of the last round, 16 bits each
   while (__any(hi - lo > 1)) {
@@ -319,7 +324,7 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
 #pragma unroll
       for (int k = 0; k < FIN; ++k) x4 |= (u64)xk[k] << (16 * k);
     }
-    cols_narrow(q, act, pr, gl, lo, hi);
+    cols_narrow<G>(q, act, pr, gl, lo, hi);
   }
   const int lb = max(hi, first);
   // median x of the three events at / behind the boundary and of the three in front of it: from the last round's probes where
@@ -336,22 +341,22 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
     bounds[j] = make_int4(lb, max(min(a0, a1), min(max(a0, a1), a2)), max(min(e0, e1), min(max(e0, e1), e2)), 0);
 }
 
-template <bool AOS>
+template <bool AOS, int G = 32>
 __global__ __launch_bounds__(256) void k_cols_bounds(const uint16_t* __restrict__ xs, const long long* __restrict__ ts,
                                                                         const uint4* __restrict__ aos, u32 n, DevTables tb, int W,
                                                                         uint16_t* __restrict__ frame16, int split = 0) {
-  cols_bounds_body<AOS>((gp_u16)xs, (gp_i64)ts, (gp_u4)aos, (int)n, tb, W, (XM_GLOBAL unsigned char*)frame16, blockIdx.x, nullptr, 0,
-                        split);
+  cols_bounds_body<AOS, G>((gp_u16)xs, (gp_i64)ts, (gp_u4)aos, (int)n, tb, W, (XM_GLOBAL unsigned char*)frame16, blockIdx.x, nullptr, 0,
+                           split);
 }
 
-template <bool AOS>
+template <bool AOS, int G = 32>
 __global__ __launch_bounds__(256) void k_cols_bounds_batch(const FrameDesc* __restrict__ descs, DevTables tb, int W, int flags = 0,
                                                            int split = 0) {
   const FrameDesc d = descs[blockIdx.y];
   const bool ext = flags & COLS_F_EXT_EXTREMA;
   if (!d.valid || (d.n == 0 && !ext)) return;
-  cols_bounds_body<AOS>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x,
-                        ext ? (gp_i64)d.p : nullptr, ext ? (int)d.pad : 0, split);
+  cols_bounds_body<AOS, G>((gp_u16)d.x, (gp_i64)d.t, (gp_u4)d.aos, (int)d.n, tb, W, (XM_GLOBAL unsigned char*)d.key_frame, blockIdx.x,
+                           ext ? (gp_i64)d.p : nullptr, ext ? (int)d.pad : 0, split);
 }
 
 // ---- the kernel body ---------------------------------------------------------------------------------------------------------
