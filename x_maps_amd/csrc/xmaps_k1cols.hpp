@@ -16,7 +16,7 @@
 //     0 from xm_create.  A slot whose pair can never hold a winner (xp - x_offset < the smallest rectified x of the LUT:
 //     the X-map's undefined cells) is "dead" and is skipped by the check and by the flush alike.
 //   * the tile's events are the index range [lb(c0), lb(c0 + W)) of the time-sorted stream, lb(c) = first event whose time
-//     column is >= c, found by a small kernel of its own (k_cols_bounds: half a wave per boundary, 32 probes around the
+//     column is >= c, found by a small kernel of its own (k_cols_bounds: 16 or 32 lanes per boundary, that many probes around the
 //     interpolated position, then 4 consecutive events per lane = two dependent round trips for an evenly filled scan).  lb() is a deterministic function
 //     of (stream, c), so neighbouring tiles share their boundary whatever the stream looks like; a non-monotone pair marks
 //     the frame as failed.
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(BLOCK) void k_cols_check(DevTables tb, int xr_min, 
   if (outside) atomicAdd(n_dup + 1, outside);
 }
 
-// ---- the event-range search (half a wave per boundary) -----------------------------------------------------------
+// ---- the event-range search (G = 16 or 32 lanes per boundary) -----------------------------------------------------------
 template <bool AOS>
 __device__ __forceinline__ long long cols_t_at(gp_i64 ts, gp_u4 aos, int i) {
   if constexpr (AOS) {
@@ -205,7 +205,7 @@ __device__ __forceinline__ void cols_narrow(const int (&q)[COLS_BOUNDS_FIN], con
   }
 }
 
-// ---- K0b: the tile boundaries of one frame, half a wave per boundary ----------------------------------------------------------------
+// ---- K0b: the tile boundaries of one frame, G lanes per boundary ----------------------------------------------------------------
 // bounds[j] = {lb(j * W), median x of the three events at / behind it, median x of the three events in front of it, 0} for
 // j = 0 .. nb (nb = ceil(xmap_w / W) tiles; bounds[nb].x = n), thr[c] for c = 0 .. xmap_w (see cols_threshold).  Tile j of K1
 // owns events [bounds[j].x, bounds[j+1].x) and centres its camera-column window between bounds[j].y and bounds[j+1].z.
