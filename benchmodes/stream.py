@@ -182,7 +182,8 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     # ---- the same frames with other engine settings (extra information, never the headline `value`) -----------------------
     eng.close()  # one engine at a time: two engines would share the high-priority hardware queues
     other_modes = None
-    if world == 1 and not args.no_other_modes:
+    # (XM_BENCH_FORCE_SHARDED_LEG: the tests' stand-in of an N > 1 run on a one-GPU box -- as there, no extra single-GPU loops)
+    if world == 1 and not args.no_other_modes and os.environ.get("XM_BENCH_FORCE_SHARDED_LEG") != "1":
         other_modes = {}
         modes = []  # (name, engine flags, camera view, frames per call, launch workers)
         if B:

@@ -85,8 +85,8 @@ def test_one_frame_per_call_mode_still_prints_the_line():
     assert d["parity"]["depth_bit_exact"] and d["config"]["k1_paths_frames"]["cols"] > 0
 
 
-@pytest.mark.parametrize("flags,workload", [(("--graph", "--steps", "60"), "C-60x1M"), (("--sharded", "--steps", "10"), "C-10M"),
-                                            (("--esl", "--steps", "50", "--no-host-path"), "C-ESL")])
+@pytest.mark.parametrize("flags,workload", [(("--graph", "--steps", "60"), "C-60x1M"), (("--sharded", "--steps", "5"), "C-10M"),
+                                            (("--esl", "--steps", "20"), "C-ESL")])
 def test_other_configurations_print_one_json_line(flags, workload):
     d = _run(*flags, "--no-cpu-baseline")
     assert workload in d["config"]["workload"] and d["value"] > 100 and d["ms_per_step"] > 0
@@ -176,7 +176,7 @@ def test_the_default_line_carries_the_other_baseline_configs():
 
 
 def test_esl_line_carries_the_stream_legs():
-    d = _run("--esl", "--steps", "20", "--no-cpu-baseline", "--no-other-modes")
+    d = _run("--esl", "--steps", "20", "--no-cpu-baseline")  # (the invocation of the C-ESL case above: run once)
     ip = d["ingest_path"]
     assert ip["same_frames_as_host_trigger_finder"] and ip["first_frame_equals_oracle"] and ip["frames_cut"] > 20
     sl = d["stream_legs"]

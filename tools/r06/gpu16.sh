@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the whole GPU suite, smoke(), the driver's line and the ESL-like line on the round's final build
 cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r06
-( time timeout 1500 python -m pytest tests -q -m gpu -x --durations=12 ) > gpurun_out/r06/t16.log 2>&1
+( time timeout 1500 python -m pytest tests -q -m gpu -x --durations=40 ) > gpurun_out/r06/t16.log 2>&1
 echo "pytest rc $?" >> gpurun_out/r06/t16.log; tail -24 gpurun_out/r06/t16.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06/smoke16.log 2>&1; echo "smoke rc $?"; tail -4 gpurun_out/r06/smoke16.log
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r06/bench16.json 2> gpurun_out/r06/bench16.err; echo "bench rc $?"

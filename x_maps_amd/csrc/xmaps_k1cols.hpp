@@ -166,7 +166,11 @@ __device__ __forceinline__ int cols_x_at(gp_u16 xs, gp_u4 aos, int i) {
 // G = 32 lanes per boundary, or 16 (round 6) where a tile is at most 16 columns wide and has no halo boundary (the column tiles:
 // lane l of a group computes the threshold of column j W + l): half the waves and half the probe lines per boundary -- the
 // pipelined step is bound by the HBM bytes of its three kernels, K0b's scattered 8-byte probes pull a line each (56 MB per group
-// of 32 C-1M frames), and 16 lanes move the step from 0.1964 to 0.1937 ms (profiles/r06_k1_chain.md section 3).
+// of 32 C-1M frames), and 16 lanes move the step from 0.1964 to 0.1937 ms (profiles/r06_k1_chain.md section 3).  The 16-lane form
+// also probes less: round 1 is FOUR probes 1 024 events apart, and the 1 024-event window they leave is entered by interpolation
+// (the stamps at its two ends say where in it the threshold falls: G * FIN consecutive events around that place; an evenly filled
+// scan misses such a window by ~16 events rms) -- ten lines per boundary instead of twenty-two, K0b 16.9 -> 13.0 us, the step
+// 0.1930 -> 0.1908 ms.  At most three interpolated windows, then the even splits: what is read decides, the stamps only guess.
 constexpr int COLS_BOUNDS_FIN = 4;
 constexpr int cols_bounds_per_block(int G) { return 256 / G; }
 
@@ -232,6 +236,7 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   XM_GLOBAL int4* bounds = (XM_GLOBAL int4*)(frame_base + cols_bounds_offset(key_cells));
   XM_GLOBAL u32* thr = (XM_GLOBAL u32*)(frame_base + cols_thr_offset(key_cells, tb.xmap_w));
   constexpr int FIN = COLS_BOUNDS_FIN;
+  constexpr bool INTERP = G == 16;
   const int lane = threadIdx.x & 63, sl = lane & (G - 1), gl = lane & ~(G - 1);
   const int nb = split ? 2 * ((tb.xmap_w + W - 1) / W) : (tb.xmap_w + W - 1) / W;
   const int j_raw = (int)blk * cols_bounds_per_block(G) + (int)threadIdx.x / G;
@@ -268,8 +273,11 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   }
   if (search) {
     const double g = ((double)c - 0.5) / (double)max(tb.t_px_scale, 1) * (double)n;
-    q[0] = min(max((int)fmin(fmax(g, 0.0), (double)(n - 1)) + (sl - G / 2) * (G * FIN), 0), n - 1);
-    tv[0] = cols_t_at<AOS>(ts, aos, q[0]);
+    // G = 32: 32 probes G * FIN events apart.  G = 16 (INTERP): FOUR probes 1024 events apart (+-2048 events around the estimate,
+    // four lines instead of sixteen); the window they leave is entered by interpolating between its ends' stamps (below)
+    const int step1 = INTERP ? (sl < 4 ? (2 * sl - 3) * 512 : 0) : (sl - G / 2) * (G * FIN);
+    q[0] = min(max((int)fmin(fmax(g, 0.0), (double)(n - 1)) + step1, 0), n - 1);
+    if (!INTERP || sl < 4) tv[0] = cols_t_at<AOS>(ts, aos, q[0]);
   }
   if (t_last < t_first) t_last = t_first;  // not sorted at all: keep the arithmetic defined; K1's verification flags the frame
   const u64 span64 = (u64)(t_last - t_first);
@@ -290,22 +298,47 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
   if (c <= 0 || !live || n == 0) hi = 0;
   else if (c >= tb.xmap_w) lo = n - 1;
   if (hi - lo > 1) {  // == search
-    act[0] = true;
-    pr[0] = (u64)(tv[0] - t_first) >= (u64)A;
+    act[0] = !INTERP || sl < 4;
+    pr[0] = act[0] && (u64)(tv[0] - t_first) >= (u64)A;
   }
   cols_narrow<G>(q, act, pr, gl, lo, hi);
-  int x_base = -1, x_cnt = 0;
+  // INTERP: a = t - tmin at the two ends of (lo, hi), for the interpolation (index -1 <-> 0, index n <-> span + 1; an end that is
+  // one of this round's probes: its lane's stamp).  Only ever a GUESS of where to read: what is read decides.
+  u32 a_lo = 0, a_hi = span == 0xffffffffu ? span : span + 1u;
+  const auto ends_from = [&](const bool on, const int start, const int count) {  // the probes were `count` consecutive events from `start`
+    const u64 af = (u64)(__shfl(tv[0], gl, 64) - t_first), al = (u64)(__shfl(tv[FIN - 1], gl + G - 1, 64) - t_first);
+    if (on && hi == start) a_hi = (u32)min(af, (u64)0xffffffffu);
+    if (on && lo == start + count - 1) a_lo = (u32)min(al, (u64)0xffffffffu);
+  };
+  if constexpr (INTERP) {
+    const u32 a0 = (u32)min((u64)(tv[0] - t_first), (u64)0xffffffffu);
+    const u64 gm = (1ull << G) - 1ull;
+    const u64 m_lo = (__ballot(act[0] && q[0] == lo) >> gl) & gm, m_hi = (__ballot(act[0] && q[0] == hi) >> gl) & gm;
+    const u32 v_lo = __shfl(a0, gl + (m_lo ? __builtin_ctzll(m_lo) : 0), 64), v_hi = __shfl(a0, gl + (m_hi ? __builtin_ctzll(m_hi) : 0), 64);
+    if (m_lo) a_lo = v_lo;
+    if (m_hi) a_hi = v_hi;
+  }
+  int x_base = -1, x_cnt = 0, rounds = 0;
   u64 x4 = 0;  // the lane's FIN x values of the last round, 16 bits each
   while (__any(hi - lo > 1)) {
     const bool need = hi - lo > 1;
     const int unknown = hi - lo - 1;          // positions lo + 1 .. hi - 1
     const bool fin = unknown <= G * FIN;      // consecutive events: this round settles the boundary
     const int stride = (unknown + G - 1) / G;
+    // INTERP, at most three times (then the even splits: adversarial stamps must not make this a walk): G * FIN consecutive events
+    // around where the boundary would lie if the stamps between the window's ends were evenly spread
+    const bool dense = fin || (INTERP && rounds < 3);
+    int start = lo + 1;
+    if (!fin && dense) {
+      const double fr = a_hi > a_lo ? fmin(fmax(((double)A - (double)a_lo) / ((double)a_hi - (double)a_lo), 0.0), 1.0) : 0.5;
+      start = min(max(lo + 1 + (int)(fr * (double)unknown) - G * FIN / 2, lo + 1), hi - G * FIN);
+    }
+    rounds += 1;
     u32 xk[FIN];
 #pragma unroll
     for (int k = 0; k < FIN; ++k) {
-      q[k] = fin ? lo + 1 + FIN * sl + k : lo + (sl + 1) * stride;
-      act[k] = need && q[k] < hi && (fin || k == 0);
+      q[k] = dense ? start + FIN * sl + k : lo + (sl + 1) * stride;
+      act[k] = need && q[k] < hi && (dense || k == 0);
       xk[k] = 0;
       if constexpr (AOS) {
         const uint4 r = aos[act[k] ? q[k] : 0];
@@ -313,18 +346,19 @@ __device__ __forceinline__ void cols_bounds_body(gp_u16 xs, gp_i64 ts, gp_u4 aos
         xk[k] = r.x & 0xffffu;
       } else {
         tv[k] = ts[act[k] ? q[k] : 0];
-        if (fin) xk[k] = xs[act[k] ? q[k] : 0];
+        if (dense) xk[k] = xs[act[k] ? q[k] : 0];
       }
       pr[k] = act[k] && (u64)(tv[k] - t_first) >= (u64)A;
     }
     if (need) {
-      x_base = fin ? lo + 1 : -1;
-      x_cnt = unknown;
+      x_base = dense ? start : -1;
+      x_cnt = dense ? min(G * FIN, hi - start) : 0;
       x4 = 0;
 #pragma unroll
       for (int k = 0; k < FIN; ++k) x4 |= (u64)xk[k] << (16 * k);
     }
     cols_narrow<G>(q, act, pr, gl, lo, hi);
+    if constexpr (INTERP) ends_from(dense && !fin && need, start, G * FIN);
   }
   const int lb = max(hi, first);
   // median x of the three events at / behind the boundary and of the three in front of it: from the last round's probes where
