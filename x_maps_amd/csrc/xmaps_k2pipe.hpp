@@ -51,6 +51,9 @@ struct K2PipeArgs {  // (only what the loop needs: the whole DevTables would sit
   int proj_w, proj_h, rect_w, rect_h, shear_m, shear_bias;
 };
 
+#ifndef XM_K2P_EMU_COMPACT
+#define XM_K2P_EMU_COMPACT 0
+#endif
 #ifndef XM_K2P_STAGED
 #define XM_K2P_STAGED 0  /* experiments: 1 = the BGR rows of four-pixel threads through the LDS staging rows, as until round 5 */
 #endif
@@ -174,6 +177,10 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
       const int gx = bx + c, gy = by + 8 * ro;
       const bool has = sj < nslot && (u32)gx < (u32)a.rect_w && (u32)gy < (u32)a.rect_h;  // (rect_h % 8 == 0)
       K[j] = make_uint4(0, 0, 0, 0);
+      if (XM_K2P_EMU_COMPACT || XM_CABL(21)) {  // (experiments, bit 21 / -DXM_K2P_EMU_COMPACT=1: the traffic of a COMPACT frame -- 41 % of the quads, contiguous per tile, 1.35 x overlap)
+        const int live = (nslot * 105) >> 8, per_tile = (live * 190) >> 8;
+        if (sj < live) K[j] = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(d16 + (size_t)m.lin * (size_t)per_tile * 8u + (size_t)sj * 8u);
+      } else
       if (has && !XM_CABL(13))  // (experiments, bit 13: no patch loads)
         K[j] = *reinterpret_cast<const XM_K2P_GLOBAL uint4*>(d16 + __umul24((u32)(gx + a.shear_bias + (((g0 + ro) * a.shear_m) >> 12)), (u32)a.rect_h) + (u32)gy);
     }
