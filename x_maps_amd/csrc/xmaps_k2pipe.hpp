@@ -47,6 +47,12 @@ typedef u32 k2p_u32x4 __attribute__((ext_vector_type(4)));
 #define k2p_store(ptr, val) (*(ptr) = (val))  /* (a macro: a template parameter would drop the pointee's 4-byte alignment) */
 #endif
 
+#ifdef XM_ABLATE  // experiments (tools/k2p_phases.py): per block, the cycles (s_memtime) between the loop's phase marks, summed over its items
+#define XM_K2P_MARK(ph) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_sum[ph] += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define XM_K2P_MARK(ph) do { } while (0)
+#endif
+
 struct K2PipeArgs {  // (only what the loop needs: the whole DevTables would sit in scalar registers across it)
   int proj_w, proj_h, rect_w, rect_h, shear_m, shear_bias;
 };
@@ -214,7 +220,13 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
   m1 = meta_at(f, b);
   if (m1.run) issue(m1, p1);
   k2p_lds_barrier();
+#ifdef XM_ABLATE
+  unsigned long long ph_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime(), ph_items = 0;
+#endif
   for (;;) {
+#ifdef XM_ABLATE
+    ph_items += 1;
+#endif
     uint2 e[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) e[q] = make_uint2(0u, 0u);
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
         }
       }
       k2p_lds_barrier();
+      XM_K2P_MARK(0);  // the row maxima pass (its barriers included)
 #pragma unroll
       for (int q = 0; q < PPT; ++q) {
         u32 best = 0;
@@ -258,13 +271,16 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
         else e[q] = ((const XM_K2P_GLOBAL uint2*)dlut)[min(best, 65535u)];  // (a disparity beyond the LDS copy: x noise far off the scan; the wait drains the prefetch, rarely)
       }
     }
+    XM_K2P_MARK(1);     // taps + table look-ups (s_memtime waits for the LDS counter: the values are there)
     k2p_lds_barrier();  // every pixel has sampled the patch: the next one may take its place
+    XM_K2P_MARK(2);     // the barrier behind the sampling
 #pragma unroll
     for (int q = 0; q < NP; ++q) {  // (pinned HERE: sunk behind the stores below, the copy would wait for them -- the counter is in order)
       p0[q] = p1[q];
       asm volatile("" : "+v"(p0[q]));
     }
     if (m1.run) to_lds(m1);
+    XM_K2P_MARK(3);  // the wait for the next item's patch (vmcnt) + its LDS writes
     if (m0.run) {  // item 0's outputs
       const FrameDesc& d = descs[m0.f];
       XM_K2P_GLOBAL float* depth = (XM_K2P_GLOBAL float*)d.depth;
@@ -424,13 +440,24 @@ __global__ __launch_bounds__(K2_TX* K2_TY) void k_frame_proj_pipe(const FrameDes
         }
       }
     }
+    XM_K2P_MARK(4);  // the output stores (issued)
     if (m1.f >= n_frames) break;  // (items are visited in order: nothing behind an item past the end)
     m0 = m1;
     advance(f, b);
     m1 = meta_at(f, b);
+    XM_K2P_MARK(5);             // the next item's tile record + frame descriptor (scalar loads)
     if (m1.run) issue(m1, p1);  // in flight during the next item's reduce + sample phase
+    XM_K2P_MARK(6);             // its loads issued
     k2p_lds_barrier();          // the next patch is in LDS, the staging rows are free again
+    XM_K2P_MARK(7);
   }
+#ifdef XM_ABLATE
+  if (tid == 0 && blockIdx.x < 64) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g_timeline[blockIdx.x][k] = ph_sum[k];
+    g_timeline[blockIdx.x][8] = ph_items;
+  }
+#endif
 }
 
 }  // namespace xm
