@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6: the pipelined K2 without per-lane regions (variants/libxmaps_k2bf.so) against the round's K2 (variants/libxmaps_base.so): tests, timing, counters
+# (the variant libraries are builds of tools/r06/patches/k2_branch_free.patch applied to xmaps_k2pipe.hpp: its first half = libxmaps_k2m.so, all of it = libxmaps_k2bf.so;
+#  variants/libxmaps_base.so = a build of the commit itself: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared x_maps_amd/csrc/xmaps_hip.hip -o <lib>)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r06
 V=${1:-variants/libxmaps_k2bf.so}
