@@ -164,8 +164,8 @@ __device__ __forceinline__ int cols_x_at(gp_u16 xs, gp_u4 aos, int i) {
 // For a stream that is not sorted the result is still a deterministic function of (stream, A): neighbouring tiles read the same
 // boundary, and the per-event verification of K1 catches the rest.
 // G = 32 lanes per boundary, or 16 (round 6) where a tile is at most 16 columns wide and has no halo boundary (the column tiles:
-// lane l of a group computes the threshold of column j W + l): half the waves and half the probe lines per boundary -- the
-// pipelined step is bound by the HBM bytes of its three kernels, K0b's scattered 8-byte probes pull a line each (56 MB per group
+// lane l of a group computes the threshold of column j W + l): half the waves and half the probe lines per boundary -- in the
+// pipelined step a kernel costs about what it costs alone, K0b's scattered 8-byte probes pull a line each (56 MB per group
 // of 32 C-1M frames), and 16 lanes move the step from 0.1964 to 0.1937 ms (profiles/r06_k1_chain.md section 3).  The 16-lane form
 // also probes less: round 1 is FOUR probes 1 024 events apart, and the 1 024-event window they leave is entered by interpolation
 // (the stamps at its two ends say where in it the threshold falls: G * FIN consecutive events around that place; an evenly filled
