@@ -188,6 +188,7 @@ int xm_create(const xm_config* cfg, xm_handle** out) {
     if (const char* e = dbg_opt("XM_K2_PER_CU")) {
       h->k2_per_cu_max = std::max(1, atoi(e));
     }
+    if (const char* e = dbg_opt("XM_COLS_LDS_PAD")) h->cols_lds_pad = std::max(0, std::min(64 * 1024, atoi(e)));
     if (const char* e = dbg_opt("XM_K2_CONSEC")) h->k2_consec = e[0] != '0' ? 1 : 0;  // experiments / tests: the strided pixel assignment
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;

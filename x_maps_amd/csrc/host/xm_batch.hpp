@@ -43,7 +43,7 @@ int launch_batch_t(xm_handle* h, const FrameDesc* d_descs, int n_frames, u64 n_m
       if constexpr (!AOS) {
         if (vec16) kern = k_scatter_cols_batch<false, true>;
       }
-      const size_t lds = cols_lds_bytes(h, cols_w);
+      const size_t lds = cols_lds_bytes(h, cols_w) + (size_t)h->cols_lds_pad;  // (pad: experiments -- fewer K1 blocks per CU, room for another kernel's)
       rc = h->ensure_lds(reinterpret_cast<const void*>(kern), lds);
       if (rc) return rc;
       prof_slot(0);

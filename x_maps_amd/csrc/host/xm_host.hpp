@@ -197,6 +197,7 @@ struct xm_handle {
   bool cols_single = false;  // XM_COLS=2: also for single-frame calls (default: groups of frames only -- a single frame's third
                              // launch, the boundary pass, costs the pipelined one-frame-per-call path more than the tiles save)
   int cols_xr_min = 0, cols_w_max = 0, cols_target = 3700;
+  int cols_lds_pad = 0;  // XM_COLS_LDS_PAD (experiments): bytes of dynamic LDS a column-tile block asks for beyond its carve-up
   int cols_flags = 0;  // COLS_F_ALL_IN_FRAME when no live (row, column) pair of the rig maps outside the frame
   // owner tiles (xmaps_k1own.hpp): the rig's (row, column) -> cell map is not injective (the reference's own calibration), but
   // every cell's columns lie within a few (<= 7) columns of its first one: cols_ok with own_mode set; tile widths and halos per plan
