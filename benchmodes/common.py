@@ -322,3 +322,18 @@ def parity_ok(p):
                 ok = ok and (r is not False)
         return ok
     return None
+
+
+_LEG_T0 = [None]
+
+
+def leg_clock(name):
+    """XM_BENCH_LEG_TIMES=1: wall time since the previous mark, to stderr (where a bench.py run spends its minutes)"""
+    import os, sys, time
+    if os.environ.get("XM_BENCH_LEG_TIMES") != "1":
+        return
+    now = time.perf_counter()
+    if _LEG_T0[0] is not None:
+        sys.stderr.write("[bench legs] %-44s %7.2f s\n" % (name, now - _LEG_T0[0]))
+        sys.stderr.flush()
+    _LEG_T0[0] = now

@@ -9,6 +9,7 @@ import time
 
 import numpy as np
 
+from .common import leg_clock
 from .common import (BENCH_PY, HBM_PEAK_GBS, PREWARM_S, ROOT, TARGET_TIMED_S, Timer, apply_measured_traffic, cpu_baseline_leg, depth_parity,
                      n_blocks_for, parity_ok, pipeline_fractions, roofline_dict, roofline_of, traffic_file_age)
 
@@ -23,12 +24,15 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
     from x_maps_amd.ingest import DeviceIngest
 
     camera = args.camera_perspective
+    leg_clock("esl: start")
     cp, tables, _, _ = rig.make_esl_like(row_stride=13, device=local_rank)
+    leg_clock("esl: rig (calibration tables, X-map)")
     B = args.batch  # frames per call (0: one frame per call, what DepthReprojectionPipe.process_ev_frame supplies)
     G = args.groups_in_flight if B else 1
     nf = max(8, B * G)
     host = [rig.render_events(cp, tables, row_stride=13, seed=rank * nf + f)[0] for f in range(nf)]
     lens = [len(e) for e in host]
+    leg_clock("esl: frames rendered")
     n_mean = float(np.mean(lens))
     slots = args.slots or (max(4, B * G) if B else 4)
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=slots)
@@ -183,6 +187,7 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
                                        "last_frame_depth_bit_exact": ok_a,
                                        "note": "xm_process_frame_aos per frame on a handle with XM_FLAG_ADAPTIVE_BATCH (asynchronous, "
                                                "device-resident records)"}
+    leg_clock("esl: parity + timed blocks + other modes")
     # what the pipe does per projector frame: one synchronous host call, EventCD records in, BGR frame out
     for i in range(20):
         eng.process_events(host[i % nf], want_depth=False, want_bgr=True)
@@ -194,11 +199,13 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
     lat = np.array(lat) * 1e3
     # a camera-like stream through the device-side ingest and through the processor, end to end
     ingest = None
+    leg_clock("esl: per-frame host calls")
     if not args.no_host_path and world == 1:
         try:
             ingest = esl_stream_legs(eng, cp, tables, int(n_mean), O, camera, local_rank)
         except Exception as e:  # never lose the line to the extra legs
             ingest = {"error": repr(e)[:300]}
+        leg_clock("esl: stream legs")
         # ... and once more in a process that never imports torch -- the reference's own situation (Metavision + NumPy + OpenCV):
         # there the library runs on ROCm's HIP runtime instead of the older copy PyTorch ships and loads first in this process
         if "error" not in ingest and not getattr(args, "no_stream_child", False):
@@ -210,6 +217,7 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
             except Exception as e:
                 ch = {"error": repr(e)[:300]}
             ingest["in_a_process_without_torch"] = ch
+    leg_clock("esl: stream legs in a child process")
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         e0 = host[0]
@@ -218,6 +226,7 @@ def bench_esl(args, torch, dist, dev, rank, local_rank, world):
         cpu["ms_per_frame"] = round(len(e0) / cpu["value"] / 1e3, 3)
         cpu["reference_published_ms_per_frame"] = ("2.67 +- 0.31 (Numba on a Threadripper PRO 5955WX, real ESL frames: BASELINE.md section 1; other "
                                                    "hardware -- the port above is 3-17x slower than that and flatters any GPU / CPU ratio)")
+    leg_clock("esl: cpu baseline")
     out = {
         "metric": "Mevents/s to depth frame, ESL-like frames (640x480 camera, 1080x1920 projector, ~150k ev/frame)",
         "value": round(value, 2), "unit": "Mevents/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,

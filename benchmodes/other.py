@@ -62,7 +62,7 @@ def other_config_legs(args, torch, dist, dev, local_rank):
             if isinstance(sl.get("paced"), dict):
                 leg["paced"] = sl["paced"]
             for k in ("full_replay_through_processor_default_params", "full_replay_through_processor_host_trigger_finder",
-                      "full_replay_through_processor_device_ingest", "ingest_path_fresh_arrays"):
+                      "full_replay_through_processor_device_ingest", "ingest_path_fresh_arrays", "ingest_path_depth_and_bgr"):
                 if isinstance(sl.get(k), dict):
                     leg[k] = {a: b for a, b in sl[k].items() if a != "note"}
             ch = sl.get("in_a_process_without_torch")

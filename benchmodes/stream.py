@@ -9,6 +9,7 @@ import time
 import numpy as np
 
 from .other import other_config_legs
+from .common import leg_clock
 from .common import (BENCH_PY, HBM_PEAK_GBS, PREWARM_S, ROOT, TARGET_TIMED_S, Timer, apply_measured_traffic, cpu_baseline_leg, depth_parity,
                      n_blocks_for, parity_ok, pipeline_fractions, roofline_dict, roofline_of, traffic_file_age)
 
@@ -34,6 +35,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     H, W = eng.out_h, eng.out_w
     n_ev = cfg.n_events
 
+    leg_clock('start')
     # ---- synthetic frames -> HBM (SoA columns, the layout K1 reads), laid out back to back ------------------------
     nf = args.frames or (args.groups_in_flight * B if B else 32)
     if B and (nf % B or slots % B):
@@ -96,6 +98,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
 
     step = make_step(eng, depth_out, bgr_out, n_out, B)
 
+    leg_clock('frames rendered + uploaded')
     # ---- parity gate before any timing: first (and last) frame of step 0 against the CPU oracle (rank 0) ----------------
     parity = None
     O = None
@@ -122,6 +125,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
             sys.exit(1)
 
     tm = Timer(torch, dist, dev, eng.sync)
+    leg_clock('parity gate')
     # ---- W warm-up steps, fixed pre-warm, per-kernel profile pass, short re-warm, R timed blocks of exactly K steps ----
     run_steps(step, args.warmup)
     est = tm.prewarm(step, PREWARM_S)
@@ -174,11 +178,13 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
         roofline["traffic_measured_in_run"] = False
         roofline["traffic_source"] += "; " + traffic_file_age()
 
+    leg_clock('timed blocks + profile pass')
     # ---- CPU baseline (rank 0 at N = 1 only) ---------------------------------------------------------------------------
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline_leg(args, O, tables, host_frames[0], n_ev, camera, bgr_out is not None)
 
+    leg_clock('cpu baseline')
     # ---- the same frames with other engine settings (extra information, never the headline `value`) -----------------------
     eng.close()  # one engine at a time: two engines would share the high-priority hardware queues
     other_modes = None
@@ -280,6 +286,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     eng = XMapsEngine(tables, camera_perspective=camera, device=local_rank, n_slots=4, **mode_kw) \
         if (not args.no_host_path and world == 1) else None
     hf4 = [host_frames[f] for f in range(4)]
+    leg_clock('other engine settings')
     # ---- PCIe-inclusive figures: events start in host memory, depth + BGR end in host memory (never `value`) ------
     host_path = None
     if not args.no_host_path and world == 1:
@@ -319,6 +326,7 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
                           "note": "end to end: events start in (pinned) host memory, depth+BGR end in host memory, copies of "
                                   "one frame overlap the kernels of another; PCIe-bound; never the headline value"})
 
+    leg_clock('host path')
     # ---- end to end with the device-side ingest: RAW camera packets (all polarities) in host memory -> frames in host memory ----
     ingest_path = None
     if not args.no_host_path and world == 1:
@@ -364,7 +372,9 @@ def bench_stream(args, torch, dist, dev, rank, local_rank, world):
     if ingest_path:
         out["ingest_path"] = ingest_path
     if world == 1 and not args.no_other_modes and not args.no_other_configs and B and not camera:
+        leg_clock("ingest path")
         out["other_configs"] = other_config_legs(args, torch, dist, dev, local_rank)
+        leg_clock("other configs")
     return out
 
 

@@ -86,7 +86,7 @@ def test_one_frame_per_call_mode_still_prints_the_line():
 
 
 @pytest.mark.parametrize("flags,workload", [(("--graph", "--steps", "60"), "C-60x1M"), (("--sharded", "--steps", "5"), "C-10M"),
-                                            (("--esl", "--steps", "20"), "C-ESL")])
+                                            (("--esl", "--steps", "20", "--no-host-path"), "C-ESL")])
 def test_other_configurations_print_one_json_line(flags, workload):
     d = _run(*flags, "--no-cpu-baseline")
     assert workload in d["config"]["workload"] and d["value"] > 100 and d["ms_per_step"] > 0
@@ -143,7 +143,7 @@ def test_multi_gpu_line_carries_the_sharded_frame_beside_the_replicas():
     """With N > 1 ranks the default line reports frame-level replicas (no collective) and, beside it, one C-10M frame sharded by
     event index over the same ranks with the collective time listed separately.  One GPU here: the leg is forced through a
     one-rank process group (RCCL kernels run, nothing crosses xGMI)."""
-    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path", "--no-other-configs",
+    d = _run("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host-path", "--no-other-configs", "--no-pmc",
              XM_BENCH_FORCE_DIST="1", XM_BENCH_FORCE_SHARDED_LEG="1")
     sh = d["other_modes"]["one_frame_sharded_over_the_ranks"]
     assert sh["scaling"] == "strong" and sh["value"] > 1000 and sh["parity"]["depth_bit_exact"]
@@ -175,19 +175,21 @@ def test_the_default_line_carries_the_other_baseline_configs():
     assert oc["graph60"]["latency_us"]["batch_of_60_frames"]["p50"] > 0 and oc["sharded_c10m"]["collective_ms"]["key_frame_merge"] > 0
 
 
-def test_esl_line_carries_the_stream_legs():
-    d = _run("--esl", "--steps", "20", "--no-cpu-baseline")  # (the invocation of the C-ESL case above: run once)
-    ip = d["ingest_path"]
+def test_esl_leg_of_the_default_line_carries_the_stream_legs():
+    """the camera-like stream through the ingest, through the processor and as EVT 3.0 words, in bench.py's process and in a child
+    that never imports torch -- read off the ESL-like leg of the line the driver records (`bench.py --esl` prints the same legs in
+    full: `stream_legs`)"""
+    e = _default_line()["other_configs"]["esl"]
+    ip = e["ingest_path"]
     assert ip["same_frames_as_host_trigger_finder"] and ip["first_frame_equals_oracle"] and ip["frames_cut"] > 20
-    sl = d["stream_legs"]
     for k in ("ingest_path_depth_and_bgr", "ingest_path_fresh_arrays"):
-        assert sl[k]["same_frames_as_host_trigger_finder"] and sl[k]["first_frame_equals_oracle"], k
-    assert sl["full_replay_through_processor_host_trigger_finder"]["frames_shown"] == ip["frames_cut"]
-    assert sl["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
-    assert sl["full_replay_through_processor_default_params"]["same_frames_as_host_path"]
-    assert sl["from_evt3_words_period_chunks"]["overflow"] == 0 and sl["from_evt3_words_period_chunks"]["frames_cut"] > 20
+        assert e[k]["same_frames_as_host_trigger_finder"] and e[k]["first_frame_equals_oracle"], k
+    assert e["full_replay_through_processor_host_trigger_finder"]["frames_shown"] == ip["frames_cut"]
+    assert e["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
+    assert e["full_replay_through_processor_default_params"]["same_frames_as_host_path"]
+    assert e["from_evt3_words_period_chunks"]["overflow"] == 0 and e["from_evt3_words_period_chunks"]["frames_cut"] > 20
     # the same legs in a child process that never imports torch (the reference's situation): same frames, checked the same way
-    ch = sl["in_a_process_without_torch"]
+    ch = e["in_a_process_without_torch"]
     assert "error" not in ch, ch
     assert ch["ingest_path"]["same_frames_as_host_trigger_finder"] and ch["ingest_path"]["first_frame_equals_oracle"]
     assert ch["ingest_path"]["frames_cut"] == ip["frames_cut"] and ch["full_replay_through_processor_device_ingest"]["same_frames_as_host_path"]
